@@ -1,0 +1,316 @@
+"""Shared test utilities: ctypes bindings of the ORACLE libraries (test infrastructure only),
+a minimal extended-XYZ reader, and synthetic-crystal builders.
+
+Nothing here is imported by the product package ``gpumd_amd``.
+"""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int)
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t) if a is not None else None
+
+
+# --------------------------------------------------------------------------------------------
+# extended XYZ (the subset of read_xyz.cu:141-400 the fixtures use)
+# --------------------------------------------------------------------------------------------
+def read_xyz_frames(path):
+    frames = []
+    with open(path) as f:
+        lines = f.read().split("\n")
+    i = 0
+    while i < len(lines) and lines[i].strip():
+        n = int(lines[i].split()[0])
+        comment = lines[i + 1]
+        kv = {}
+        for m in re.finditer(r'(\w+)=("([^"]*)"|(\S+))', comment):
+            kv[m.group(1).lower()] = m.group(3) if m.group(3) is not None else m.group(4)
+        lat = np.array([float(x) for x in kv["lattice"].split()]).reshape(3, 3)  # rows a,b,c
+        props = kv["properties"].split(":")
+        cols = []
+        off = 0
+        for k in range(0, len(props), 3):
+            name, typ, cnt = props[k].lower(), props[k + 1], int(props[k + 2])
+            cols.append((name, typ, cnt, off))
+            off += cnt
+        body = [lines[i + 2 + a].split() for a in range(n)]
+        fr = {"n": n, "lattice": lat, "comment": kv}
+        # GPUMD stores h = [a b c] as columns: h[0]=ax h[1]=bx h[2]=cx h[3]=ay ... (read_xyz.cu:208-216)
+        fr["h"] = np.ascontiguousarray(lat.T.reshape(9))
+        pbc = kv.get("pbc", "T T T").split()
+        fr["pbc"] = np.array([1 if p.upper().startswith("T") else 0 for p in pbc], dtype=np.int32)
+        for name, typ, cnt, o in cols:
+            if typ == "S":
+                fr[name] = [b[o] for b in body]
+            else:
+                fr[name] = np.array([[float(x) for x in b[o:o + cnt]] for b in body])
+        for key in ("energy",):
+            if key in kv:
+                fr[key] = float(kv[key])
+        if "virial" in kv:
+            fr["virial"] = np.array([float(x) for x in kv["virial"].split()])
+        frames.append(fr)
+        i += 2 + n
+    return frames
+
+
+def types_from_species(species, symbols):
+    idx = {s: k for k, s in enumerate(symbols)}
+    return np.array([idx[s] for s in species], dtype=np.int32)
+
+
+def soa(pos_nx3):
+    """(N,3) -> GPUMD SoA [x..|y..|z..]"""
+    return np.ascontiguousarray(np.asarray(pos_nx3, dtype=np.float64).T.reshape(-1))
+
+
+def replicate(h, species_or_type, pos_nx3, reps):
+    """Supercell with GPUMD's atom order (replicate.cu:50-71): i, j, k outer loops, basis inner."""
+    H = np.asarray(h, dtype=np.float64).reshape(3, 3)  # columns a,b,c
+    a, b, c = H[:, 0], H[:, 1], H[:, 2]
+    pos = np.asarray(pos_nx3, dtype=np.float64)
+    out = []
+    typ = []
+    for i in range(reps[0]):
+        for j in range(reps[1]):
+            for k in range(reps[2]):
+                out.append(pos + i * a + j * b + k * c)
+                typ.append(np.asarray(species_or_type))
+    Hn = H * np.array(reps, dtype=np.float64)[None, :]
+    return np.ascontiguousarray(Hn.reshape(9)), np.concatenate(typ), np.concatenate(out)
+
+
+# --------------------------------------------------------------------------------------------
+# oracle: our plain-C restatement
+# --------------------------------------------------------------------------------------------
+class NepoInfo(C.Structure):
+    _fields_ = [
+        ("version", C.c_int), ("num_types", C.c_int), ("zbl_enabled", C.c_int),
+        ("zbl_flexible", C.c_int), ("rc_radial_max", C.c_double), ("rc_angular_max", C.c_double),
+        ("n_max_radial", C.c_int), ("n_max_angular", C.c_int), ("basis_size_radial", C.c_int),
+        ("basis_size_angular", C.c_int), ("L_max", C.c_int), ("has_222", C.c_int),
+        ("has_1111", C.c_int), ("num_L", C.c_int), ("dim", C.c_int), ("num_neurons", C.c_int),
+        ("MN_radial", C.c_int), ("MN_angular", C.c_int), ("num_para", C.c_int)]
+
+
+def build_oracle(ref=False):
+    subprocess.run(["make", "-s", "-C", ORACLE_DIR], check=True)
+    if ref and os.path.isdir("/root/reference"):
+        subprocess.run(["make", "-s", "-C", ORACLE_DIR, "_ref"], check=True)
+
+
+_oracle_lib = None
+
+
+def oracle_lib():
+    global _oracle_lib
+    if _oracle_lib is None:
+        path = os.path.join(ORACLE_DIR, "libnep_oracle.so")
+        if not os.path.exists(path):
+            build_oracle()
+        L = C.CDLL(path)
+        L.nepo_model_load.restype = C.c_void_p
+        L.nepo_model_load.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
+        L.nepo_model_free.argtypes = [C.c_void_p]
+        L.nepo_model_info.argtypes = [C.c_void_p, C.POINTER(NepoInfo)]
+        L.nepo_model_symbol.restype = C.c_char_p
+        L.nepo_model_symbol.argtypes = [C.c_void_p, C.c_int]
+        L.nepo_model_param.restype = C.c_double
+        L.nepo_model_param.argtypes = [C.c_void_p, C.c_int]
+        L.nepo_lists_build.restype = C.c_void_p
+        L.nepo_lists_build.argtypes = [C.c_void_p, C.c_int, _ip, _dp, _ip, _dp, C.c_int]
+        L.nepo_lists_path.argtypes = [C.c_void_p]
+        L.nepo_lists_get.argtypes = [C.c_void_p, C.c_int, _ip, _ip, C.c_int]
+        L.nepo_lists_free.argtypes = [C.c_void_p]
+        L.nepo_compute.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, _ip, _dp, _ip, _dp,
+                                   _dp, _dp, _dp, _dp, _dp]
+        L.nepo_apply_pbc.argtypes = [C.c_int, _dp, _ip, _dp]
+        L.nepo_velocity_verlet.argtypes = [C.c_int, C.c_int, C.c_double, _dp, _dp, _dp, _dp]
+        L.nepo_thermo.argtypes = [C.c_int, C.c_double, _dp, _dp, _dp, _dp, _dp]
+        L.nepo_run_nve.argtypes = [C.c_void_p, C.c_int, C.c_int, _ip, _dp, _ip, _dp, C.c_double,
+                                   C.c_int, _dp, _dp, _dp, _dp, _dp, _dp]
+        _oracle_lib = L
+    return _oracle_lib
+
+
+class Oracle:
+    """Our CPU restatement of the reference NEP path (oracle/nep_oracle.c)."""
+
+    def __init__(self, nep_txt):
+        L = oracle_lib()
+        err = C.create_string_buffer(512)
+        self.h = L.nepo_model_load(nep_txt.encode(), err, 512)
+        if not self.h:
+            raise RuntimeError("oracle: " + err.value.decode())
+        self.info = NepoInfo()
+        L.nepo_model_info(self.h, C.byref(self.info))
+        self.symbols = [L.nepo_model_symbol(self.h, t).decode() for t in range(self.info.num_types)]
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            oracle_lib().nepo_model_free(self.h)
+            self.h = None
+
+    def compute(self, typ, h, pos_soa, pbc=(1, 1, 1), precision=32, path=-1, stages=False):
+        L = oracle_lib()
+        n = len(typ)
+        typ = np.ascontiguousarray(typ, dtype=np.int32)
+        h = np.ascontiguousarray(h, dtype=np.float64)
+        pbc = np.ascontiguousarray(pbc, dtype=np.int32)
+        pos = np.ascontiguousarray(pos_soa, dtype=np.float64)
+        pe = np.zeros(n)
+        f = np.zeros(3 * n)
+        v = np.zeros(9 * n)
+        q = np.zeros(self.info.dim * n) if stages else None
+        fp = np.zeros(self.info.dim * n) if stages else None
+        st = L.nepo_compute(self.h, precision, path, n, _p(typ, _ip), _p(h, _dp), _p(pbc, _ip),
+                            _p(pos, _dp), _p(pe, _dp), _p(f, _dp), _p(v, _dp), _p(q, _dp), _p(fp, _dp))
+        if st != 0:
+            raise RuntimeError("oracle compute failed: %d" % st)
+        if stages:
+            return pe, f, v, q.reshape(self.info.dim, n), fp.reshape(self.info.dim, n)
+        return pe, f, v
+
+    def lists(self, typ, h, pos_soa, pbc=(1, 1, 1), path=-1):
+        """-> dict which -> (nn[N], nl[ld,N]) ; which in skin/radial/angular"""
+        L = oracle_lib()
+        n = len(typ)
+        typ = np.ascontiguousarray(typ, dtype=np.int32)
+        h = np.ascontiguousarray(h, dtype=np.float64)
+        pbc = np.ascontiguousarray(pbc, dtype=np.int32)
+        pos = np.ascontiguousarray(pos_soa, dtype=np.float64)
+        hl = L.nepo_lists_build(self.h, n, _p(typ, _ip), _p(h, _dp), _p(pbc, _ip), _p(pos, _dp), path)
+        if not hl:
+            raise RuntimeError("oracle list build failed")
+        out = {"path": L.nepo_lists_path(hl)}
+        for which, name in ((0, "skin"), (1, "radial"), (2, "angular")):
+            nn = np.zeros(n, dtype=np.int32)
+            mx = L.nepo_lists_get(hl, which, _p(nn, _ip), None, 0)
+            if mx < 0:
+                continue
+            nl = np.full((max(mx, 1), n), -1, dtype=np.int32)
+            L.nepo_lists_get(hl, which, _p(nn, _ip), _p(nl, _ip), max(mx, 1))
+            out[name] = (nn, nl)
+        L.nepo_lists_free(hl)
+        return out
+
+    def run_nve(self, typ, h, pos_soa, vel_soa, mass, dt, nsteps, pbc=(1, 1, 1), precision=32):
+        L = oracle_lib()
+        n = len(typ)
+        typ = np.ascontiguousarray(typ, dtype=np.int32)
+        h = np.ascontiguousarray(h, dtype=np.float64)
+        pbc = np.ascontiguousarray(pbc, dtype=np.int32)
+        pos = np.array(pos_soa, dtype=np.float64)
+        vel = np.array(vel_soa, dtype=np.float64)
+        mass = np.ascontiguousarray(mass, dtype=np.float64)
+        pe = np.zeros(n)
+        f = np.zeros(3 * n)
+        v = np.zeros(9 * n)
+        th = np.zeros(8 * nsteps)
+        rb = L.nepo_run_nve(self.h, precision, n, _p(typ, _ip), _p(h, _dp), _p(pbc, _ip), _p(mass, _dp),
+                            dt, nsteps, _p(pos, _dp), _p(vel, _dp), _p(pe, _dp), _p(f, _dp), _p(v, _dp),
+                            _p(th, _dp))
+        if rb < 0:
+            raise RuntimeError("oracle run failed: %d" % rb)
+        return dict(pos=pos, vel=vel, pe=pe, force=f, virial=v, thermo=th.reshape(nsteps, 8), rebuilds=rb)
+
+
+def oracle_apply_pbc(h, pos_soa, pbc=(1, 1, 1)):
+    L = oracle_lib()
+    pos = np.array(pos_soa, dtype=np.float64)
+    n = pos.size // 3
+    h = np.ascontiguousarray(h, dtype=np.float64)
+    pbc = np.ascontiguousarray(pbc, dtype=np.int32)
+    L.nepo_apply_pbc(n, _p(h, _dp), _p(pbc, _ip), _p(pos, _dp))
+    return pos
+
+
+def oracle_thermo(volume, mass, pe, vel, virial):
+    L = oracle_lib()
+    n = len(mass)
+    th = np.zeros(8)
+    a = [np.ascontiguousarray(x, dtype=np.float64) for x in (mass, pe, vel, virial)]
+    L.nepo_thermo(n, volume, _p(a[0], _dp), _p(a[1], _dp), _p(a[2], _dp), _p(a[3], _dp), _p(th, _dp))
+    return th
+
+
+# --------------------------------------------------------------------------------------------
+# oracle/_ref: the reference's own NEP_CPU compiled in place
+# --------------------------------------------------------------------------------------------
+_ref_lib = None
+
+
+def ref_available():
+    return os.path.exists(os.path.join(ORACLE_DIR, "_ref", "libnepcpu_ref.so"))
+
+
+def ref_lib():
+    global _ref_lib
+    if _ref_lib is None:
+        L = C.CDLL(os.path.join(ORACLE_DIR, "_ref", "libnepcpu_ref.so"))
+        L.nepref_create.restype = C.c_void_p
+        L.nepref_create.argtypes = [C.c_char_p]
+        L.nepref_destroy.argtypes = [C.c_void_p]
+        L.nepref_compute.argtypes = [C.c_void_p, C.c_int, _ip, _dp, _dp, _dp, _dp, _dp]
+        L.nepref_descriptor.argtypes = [C.c_void_p, C.c_int, _ip, _dp, _dp, _dp]
+        L.nepref_neighbors.argtypes = [C.c_void_p, C.c_int, C.c_int, _ip, _ip, C.c_int]
+        L.nepref_info.argtypes = [C.c_void_p, _dp, _dp, _ip, _ip]
+        _ref_lib = L
+    return _ref_lib
+
+
+class RefNepCpu:
+    def __init__(self, nep_txt):
+        self.L = ref_lib()
+        self.h = self.L.nepref_create(nep_txt.encode())
+        rr, ra = C.c_double(), C.c_double()
+        dim, nt = C.c_int(), C.c_int()
+        self.L.nepref_info(self.h, C.byref(rr), C.byref(ra), C.byref(dim), C.byref(nt))
+        self.dim = dim.value
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.nepref_destroy(self.h)
+            self.h = None
+
+    def compute(self, typ, h, pos_soa):
+        n = len(typ)
+        typ = np.ascontiguousarray(typ, dtype=np.int32)
+        h = np.ascontiguousarray(h, dtype=np.float64)
+        pos = np.ascontiguousarray(pos_soa, dtype=np.float64)
+        pe = np.zeros(n)
+        f = np.zeros(3 * n)
+        v = np.zeros(9 * n)
+        self.L.nepref_compute(self.h, n, _p(typ, _ip), _p(h, _dp), _p(pos, _dp), _p(pe, _dp), _p(f, _dp), _p(v, _dp))
+        return pe, f, v
+
+    def descriptor(self, typ, h, pos_soa):
+        n = len(typ)
+        typ = np.ascontiguousarray(typ, dtype=np.int32)
+        h = np.ascontiguousarray(h, dtype=np.float64)
+        pos = np.ascontiguousarray(pos_soa, dtype=np.float64)
+        d = np.zeros(self.dim * n)
+        self.L.nepref_descriptor(self.h, n, _p(typ, _ip), _p(h, _dp), _p(pos, _dp), _p(d, _dp))
+        return d.reshape(self.dim, n)
+
+    def neighbors(self, n, which, ld=512):
+        nn = np.zeros(n, dtype=np.int32)
+        nl = np.full((ld, n), -1, dtype=np.int32)
+        self.L.nepref_neighbors(self.h, which, n, _p(nn, _ip), _p(nl, _ip), ld)
+        return nn, nl
+
+
+def neighbor_sets(nn, nl):
+    """per-atom sorted tuple of neighbour indices (multiset, since small boxes repeat images)"""
+    return [tuple(sorted(nl[:nn[i], i].tolist())) for i in range(len(nn))]
