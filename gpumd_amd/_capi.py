@@ -1,0 +1,78 @@
+"""ctypes declarations of the C ABI in include/nepmi.h (one place, so signatures cannot drift).
+
+`bind(cdll)` only attaches argtypes/restype; it does not decide which library is loaded.  The
+product loads gpumd_amd/lib/libnepmi.so (gfx950 code objects) through `gpumd_amd.load_library()`.
+"""
+import ctypes as C
+
+c_i64 = C.c_int64
+c_dp = C.POINTER(C.c_double)
+c_ip = C.POINTER(C.c_int)
+VP = C.c_void_p  # device pointers travel as integers
+
+
+class NepmiInfo(C.Structure):
+    _fields_ = [
+        ("version", C.c_int), ("num_types", C.c_int), ("zbl_enabled", C.c_int), ("zbl_flexible", C.c_int),
+        ("zbl_rc_inner", C.c_double), ("zbl_rc_outer", C.c_double),
+        ("rc_radial", C.c_double), ("rc_angular", C.c_double),
+        ("MN_radial", C.c_int), ("MN_angular", C.c_int),
+        ("n_max_radial", C.c_int), ("n_max_angular", C.c_int),
+        ("basis_size_radial", C.c_int), ("basis_size_angular", C.c_int),
+        ("L_max", C.c_int), ("has_q_222", C.c_int), ("has_q_1111", C.c_int), ("num_L", C.c_int),
+        ("dim", C.c_int), ("num_neurons", C.c_int), ("num_para", C.c_int)]
+
+
+class NepmiStats(C.Structure):
+    _fields_ = [
+        ("num_compute", c_i64), ("num_rebuild", c_i64),
+        ("max_nn_skin", C.c_int), ("max_nn_radial", C.c_int), ("max_nn_angular", C.c_int),
+        ("mean_nn_radial", C.c_double), ("mean_nn_angular", C.c_double),
+        ("ms_force_last", C.c_double), ("ms_kernel", C.c_double * 8)]
+
+
+# every symbol include/nepmi.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "nepmi_last_error": (C.c_char_p, []),
+    "nepmi_version": (C.c_int, []),
+    "nepmi_model_load": (VP, [C.c_char_p]),
+    "nepmi_model_free": (None, [VP]),
+    "nepmi_model_info": (C.c_int, [VP, C.POINTER(NepmiInfo)]),
+    "nepmi_model_symbol": (C.c_char_p, [VP, C.c_int]),
+    "nepmi_engine_create": (VP, [VP, c_i64, VP]),
+    "nepmi_engine_destroy": (None, [VP]),
+    "nepmi_force_compute": (C.c_int, [VP, c_dp, c_ip, c_i64, VP, VP, VP, VP, VP]),
+    "nepmi_potential_compute": (C.c_int, [VP, c_dp, c_ip, c_i64, VP, VP, VP, VP, VP]),
+    "nepmi_apply_pbc": (C.c_int, [VP, c_dp, c_ip, c_i64, VP]),
+    "nepmi_zero_properties": (C.c_int, [VP, c_i64, VP, VP, VP]),
+    "nepmi_vv_step1": (C.c_int, [VP, c_i64, C.c_double, VP, VP, VP, VP]),
+    "nepmi_vv_step2": (C.c_int, [VP, c_i64, C.c_double, VP, VP, VP]),
+    "nepmi_find_thermo": (C.c_int, [VP, c_i64, C.c_double, VP, VP, VP, VP, VP]),
+    "nepmi_run_nve": (C.c_int, [VP, c_dp, c_ip, c_i64, VP, VP, C.c_double, c_i64, VP, VP, VP, VP, VP,
+                                c_i64, c_dp]),
+    "nepmi_neighbors_export": (C.c_int, [VP, C.c_int, VP, VP, c_i64]),
+    "nepmi_descriptors_export": (C.c_int, [VP, VP, VP]),
+    "nepmi_engine_stats": (C.c_int, [VP, C.c_int, C.POINTER(NepmiStats)]),
+    "nepmi_engine_set_timing": (C.c_int, [VP, C.c_int]),
+    "nepmi_engine_set_generic": (C.c_int, [VP, C.c_int]),
+}
+
+
+def bind(lib):
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export it
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+class NepmiError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("nepmi error %d: %s" % (code, msg))
+        self.code = code
+
+
+def check(lib, status):
+    if status < 0:
+        raise NepmiError(status, lib.nepmi_last_error().decode())
+    return status

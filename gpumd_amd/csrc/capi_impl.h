@@ -1,0 +1,264 @@
+// C ABI (include/nepmi.h) on top of EngineT<NEPMI_BACKEND>.  Included exactly once by
+// engine.hip (NEPMI_BACKEND = HipBackend, the product) and by tests/emu/emu.cpp (host loops, test
+// infrastructure only).  The including file defines:
+//   using NepmiBackend = ...;   NepmiBackend nepmi_make_backend(void* stream);
+#pragma once
+#include "../../include/nepmi.h"
+#include "engine_impl.h"
+
+#include <exception>
+#include <string>
+
+struct nepmi_model {
+  nepmi::NepModel m;
+};
+
+struct nepmi_engine {
+  nepmi::EngineT<NepmiBackend>* e;
+};
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const std::string& msg)
+{
+  g_last_error = msg;
+  return code;
+}
+
+template <class F>
+int guarded(F&& f)
+{
+  try {
+    f();
+    return NEPMI_OK;
+  } catch (const nepmi::EngineError& e) {
+    return fail(e.code, e.msg);
+  } catch (const std::exception& e) {
+    return fail(NEPMI_ERR_HIP, e.what());
+  }
+}
+
+} // namespace
+
+extern "C" {
+
+const char* nepmi_last_error(void) { return g_last_error.c_str(); }
+int nepmi_version(void) { return NEPMI_VERSION; }
+
+nepmi_model* nepmi_model_load(const char* path)
+{
+  if (!path) {
+    fail(NEPMI_ERR_ARG, "null path");
+    return nullptr;
+  }
+  nepmi_model* m = new nepmi_model();
+  bool unsupported = false;
+  const std::string err = nepmi::load_nep_model(path, m->m, &unsupported);
+  if (!err.empty()) {
+    g_last_error = err;
+    delete m;
+    return nullptr;
+  }
+  return m;
+}
+
+void nepmi_model_free(nepmi_model* m) { delete m; }
+
+int nepmi_model_info(const nepmi_model* mm, nepmi_info* o)
+{
+  if (!mm || !o)
+    return fail(NEPMI_ERR_ARG, "null argument");
+  const nepmi::NepModel& m = mm->m;
+  o->version = m.version;
+  o->num_types = m.num_types;
+  o->zbl_enabled = m.zbl_enabled;
+  o->zbl_flexible = m.zbl_flexible;
+  o->zbl_rc_inner = m.zbl_rc_inner;
+  o->zbl_rc_outer = m.zbl_rc_outer;
+  o->rc_radial = m.rc_radial_max;
+  o->rc_angular = m.rc_angular_max;
+  o->MN_radial = m.MN_radial;
+  o->MN_angular = m.MN_angular;
+  o->n_max_radial = m.n_max_radial;
+  o->n_max_angular = m.n_max_angular;
+  o->basis_size_radial = m.basis_size_radial;
+  o->basis_size_angular = m.basis_size_angular;
+  o->L_max = m.L_max;
+  o->has_q_222 = m.has_q_222;
+  o->has_q_1111 = m.has_q_1111;
+  o->num_L = m.num_L;
+  o->dim = m.dim;
+  o->num_neurons = m.num_neurons;
+  o->num_para = m.num_para;
+  return NEPMI_OK;
+}
+
+const char* nepmi_model_symbol(const nepmi_model* m, int type)
+{
+  if (!m || type < 0 || type >= m->m.num_types)
+    return "";
+  return m->m.symbols[type].c_str();
+}
+
+nepmi_engine* nepmi_engine_create(const nepmi_model* m, int64_t n_atoms, void* stream)
+{
+  if (!m) {
+    fail(NEPMI_ERR_ARG, "null model");
+    return nullptr;
+  }
+  nepmi_engine* e = new nepmi_engine();
+  e->e = nullptr;
+  const int st = guarded([&] { e->e = new nepmi::EngineT<NepmiBackend>(m->m, n_atoms, nepmi_make_backend(stream)); });
+  if (st != NEPMI_OK) {
+    delete e;
+    return nullptr;
+  }
+  return e;
+}
+
+void nepmi_engine_destroy(nepmi_engine* e)
+{
+  if (e) {
+    delete e->e;
+    delete e;
+  }
+}
+
+int nepmi_force_compute(
+  nepmi_engine* e, const double h[9], const int pbc[3], int64_t n, const int* type, double* pos, double* pe,
+  double* force, double* virial)
+{
+  if (!e)
+    return fail(NEPMI_ERR_ARG, "null engine");
+  return guarded([&] {
+    e->e->apply_pbc(h, pbc, n, pos);
+    e->e->zero_properties(n, pe, force, virial);
+    e->e->potential_compute(h, pbc, n, type, pos, pe, force, virial);
+  });
+}
+
+int nepmi_potential_compute(
+  nepmi_engine* e, const double h[9], const int pbc[3], int64_t n, const int* type, const double* pos,
+  double* pe, double* force, double* virial)
+{
+  if (!e)
+    return fail(NEPMI_ERR_ARG, "null engine");
+  return guarded([&] { e->e->potential_compute(h, pbc, n, type, pos, pe, force, virial); });
+}
+
+int nepmi_apply_pbc(nepmi_engine* e, const double h[9], const int pbc[3], int64_t n, double* pos)
+{
+  if (!e)
+    return fail(NEPMI_ERR_ARG, "null engine");
+  return guarded([&] { e->e->apply_pbc(h, pbc, n, pos); });
+}
+
+int nepmi_zero_properties(nepmi_engine* e, int64_t n, double* pe, double* force, double* virial)
+{
+  if (!e)
+    return fail(NEPMI_ERR_ARG, "null engine");
+  return guarded([&] { e->e->zero_properties(n, pe, force, virial); });
+}
+
+int nepmi_vv_step1(
+  nepmi_engine* e, int64_t n, double dt, const double* mass, const double* force, double* pos, double* vel)
+{
+  if (!e)
+    return fail(NEPMI_ERR_ARG, "null engine");
+  return guarded([&] { e->e->velocity_verlet(true, n, dt, mass, force, pos, vel, nullptr); });
+}
+
+int nepmi_vv_step2(nepmi_engine* e, int64_t n, double dt, const double* mass, const double* force, double* vel)
+{
+  if (!e)
+    return fail(NEPMI_ERR_ARG, "null engine");
+  return guarded([&] { e->e->velocity_verlet(false, n, dt, mass, force, nullptr, vel, nullptr); });
+}
+
+int nepmi_find_thermo(
+  nepmi_engine* e, int64_t n, double volume, const double* mass, const double* pe, const double* vel,
+  const double* virial, double* thermo8)
+{
+  if (!e)
+    return fail(NEPMI_ERR_ARG, "null engine");
+  return guarded([&] { e->e->find_thermo(n, volume, mass, pe, vel, virial, thermo8); });
+}
+
+int nepmi_run_nve(
+  nepmi_engine* e, const double h[9], const int pbc[3], int64_t n, const int* type, const double* mass,
+  double dt, int64_t nsteps, double* pos, double* vel, double* pe, double* force, double* virial,
+  int64_t thermo_every, double* thermo_host)
+{
+  if (!e)
+    return fail(NEPMI_ERR_ARG, "null engine");
+  return guarded([&] {
+    e->e->run_nve(h, pbc, n, type, mass, dt, nsteps, pos, vel, pe, force, virial, thermo_every, thermo_host);
+  });
+}
+
+int nepmi_neighbors_export(nepmi_engine* e, int which, int* nn, int* nl, int64_t ld)
+{
+  if (!e || which < 0 || which > 2 || !nn || !nl)
+    return fail(NEPMI_ERR_ARG, "bad argument");
+  int mx = -1;
+  const int st = guarded([&] { e->e->export_lists(which, nn, nl, ld, &mx); });
+  if (st != NEPMI_OK)
+    return st;
+  int ms, mr, ma;
+  double ar, aa;
+  const int st2 = guarded([&] { e->e->list_stats(ms, mr, ma, ar, aa); });
+  if (st2 != NEPMI_OK)
+    return st2;
+  return which == 0 ? mr : which == 1 ? ma : ms;
+}
+
+int nepmi_descriptors_export(nepmi_engine* e, float* q, float* fp)
+{
+  if (!e)
+    return fail(NEPMI_ERR_ARG, "null engine");
+  return guarded([&] { e->e->export_descriptors(q, fp); });
+}
+
+int nepmi_engine_stats(nepmi_engine* e, int with_lists, nepmi_stats* out)
+{
+  if (!e || !out)
+    return fail(NEPMI_ERR_ARG, "null argument");
+  return guarded([&] {
+    auto& eng = *e->e;
+    eng.backend().sync();
+    std::memset(out, 0, sizeof(*out));
+    out->num_compute = eng.num_compute;
+    out->num_rebuild = eng.num_rebuild;
+    if (with_lists && eng.num_compute > 0)
+      eng.list_stats(out->max_nn_skin, out->max_nn_radial, out->max_nn_angular, out->mean_nn_radial, out->mean_nn_angular);
+    out->ms_force_last = eng.backend().region_ms(nepmi::kRegionForce);
+    out->ms_kernel[0] = eng.backend().slot_ms(nepmi::kSlotGather);
+    out->ms_kernel[1] = eng.backend().slot_ms(nepmi::kSlotRadial);
+    out->ms_kernel[2] = eng.backend().slot_ms(nepmi::kSlotAngular);
+    out->ms_kernel[3] = eng.backend().slot_ms(nepmi::kSlotAnn);
+    out->ms_kernel[4] = eng.backend().slot_ms(nepmi::kSlotAngForce);
+    out->ms_kernel[5] = eng.backend().slot_ms(nepmi::kSlotForce);
+    out->ms_kernel[6] = eng.backend().slot_ms(nepmi::kSlotVV);
+    out->ms_kernel[7] = eng.backend().region_ms(nepmi::kRegionRebuild);
+  });
+}
+
+int nepmi_engine_set_timing(nepmi_engine* e, int on)
+{
+  if (!e)
+    return fail(NEPMI_ERR_ARG, "null engine");
+  e->e->backend().set_timing(on != 0);
+  return NEPMI_OK;
+}
+
+int nepmi_engine_set_generic(nepmi_engine* e, int on)
+{
+  if (!e)
+    return fail(NEPMI_ERR_ARG, "null engine");
+  e->e->set_force_generic(on != 0);
+  return NEPMI_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,492 @@
+// Engine: owns the device state of one NEP potential instance and sequences the kernels.
+// Host logic only; templated on the backend so that tests/emu can drive the same sequencing
+// with the host-loop backend.  The product (engine.hip) instantiates it with HipBackend only.
+//
+// Replaces (reference, src/force): NEP::NEP allocation half (nep.cu:379-391), Neighbor
+// (neighbor.cu:741-833), NEP::compute_large_box (nep.cu:996-1137).
+#pragma once
+#include "nep_bodies.h"
+#include "nep_model.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace nepmi {
+
+enum KernelSlot {
+  kSlotGather = 0,
+  kSlotRadial = 1,
+  kSlotAngular = 2, // angular descriptor
+  kSlotAnn = 3,
+  kSlotAngForce = 4,
+  kSlotForce = 5,
+  kSlotVV = 6,
+  kSlotThermo = 7,
+  kSlotRebuild = 8,
+  kSlotMisc = 9,
+  kNumSlots = 10
+};
+enum RegionSlot { kRegionRebuild = 0, kRegionForce = 1, kNumRegions = 2 };
+
+struct EngineError {
+  int code;
+  std::string msg;
+};
+
+inline void box_from_h9(const double h9[9], const int pbc[3], BoxD& box)
+{
+  // Box::get_inverse / get_volume / get_area / set_is_orthogonal, src/model/box.cu:23-117
+  double* h = box.h;
+  for (int k = 0; k < 9; ++k)
+    h[k] = h9[k];
+  h[9] = h[4] * h[8] - h[5] * h[7];
+  h[10] = h[2] * h[7] - h[1] * h[8];
+  h[11] = h[1] * h[5] - h[2] * h[4];
+  h[12] = h[5] * h[6] - h[3] * h[8];
+  h[13] = h[0] * h[8] - h[2] * h[6];
+  h[14] = h[2] * h[3] - h[0] * h[5];
+  h[15] = h[3] * h[7] - h[4] * h[6];
+  h[16] = h[1] * h[6] - h[0] * h[7];
+  h[17] = h[0] * h[4] - h[1] * h[3];
+  const double det = h[0] * (h[4] * h[8] - h[5] * h[7]) + h[1] * (h[5] * h[6] - h[3] * h[8]) +
+                     h[2] * (h[3] * h[7] - h[4] * h[6]);
+  for (int k = 9; k < 18; ++k)
+    h[k] /= det;
+  for (int k = 0; k < 18; ++k)
+    box.hf[k] = (float)h[k];
+  for (int d = 0; d < 3; ++d)
+    box.pbc[d] = pbc[d] ? 1 : 0;
+  box.ortho = h[1] == 0 && h[2] == 0 && h[3] == 0 && h[5] == 0 && h[6] == 0 && h[7] == 0;
+  box.volume = std::fabs(det);
+  auto cross_norm = [](const double* a, const double* b) {
+    const double s1 = a[1] * b[2] - a[2] * b[1];
+    const double s2 = a[2] * b[0] - a[0] * b[2];
+    const double s3 = a[0] * b[1] - a[1] * b[0];
+    return std::sqrt(s1 * s1 + s2 * s2 + s3 * s3);
+  };
+  const double a[3] = {h[0], h[3], h[6]}, bb[3] = {h[1], h[4], h[7]}, c[3] = {h[2], h[5], h[8]};
+  box.thickness[0] = box.volume / cross_norm(bb, c);
+  box.thickness[1] = box.volume / cross_norm(c, a);
+  box.thickness[2] = box.volume / cross_norm(a, bb);
+}
+
+template <class B>
+class EngineT
+{
+public:
+  static constexpr double kSkin = 1.0; // neighbor.cuh:212
+
+  EngineT(const NepModel& model, int64_t n_atoms, B backend) : model_(model), be_(backend), N_(n_atoms)
+  {
+    std::memset(&b_, 0, sizeof(b_));
+    std::memset(&md_, 0, sizeof(md_));
+    std::memset(&box_, 0, sizeof(box_));
+    upload_model();
+    allocate();
+  }
+
+  ~EngineT()
+  {
+    for (void* p : allocs_)
+      be_.free(p);
+  }
+
+  B& backend() { return be_; }
+  const NepModel& model() const { return model_; }
+  const Bufs& bufs() const { return b_; }
+  int64_t num_atoms() const { return N_; }
+  int64_t num_compute = 0, num_rebuild = 0;
+
+  // Potential::compute (adds to pe/force/virial; positions already wrapped)
+  void potential_compute(
+    const double h9[9], const int pbc[3], int64_t n, const int* type, const double* pos, double* pe,
+    double* force, double* virial)
+  {
+    if (n != N_)
+      throw EngineError{-4, "number of atoms differs from the engine's capacity"};
+    BoxD box;
+    box_from_h9(h9, pbc, box);
+    bool need_rebuild = !have_list_;
+    if (have_list_) {
+      for (int k = 0; k < 9; ++k)
+        if (box.h[k] != box_.h[k])
+          need_rebuild = true;
+      for (int d = 0; d < 3; ++d)
+        if (box.pbc[d] != box_.pbc[d])
+          need_rebuild = true;
+    }
+    box_ = box;
+    if (!need_rebuild) {
+      be_.memset(b_.flags + kFlagMoved, 0, sizeof(int));
+      CheckGatherBody cg{box_, b_, pos};
+      be_.template launch<128>(kSlotGather, N_, cg);
+      int flags[kNumFlags];
+      be_.d2h(flags, b_.flags, sizeof(flags));
+      check_overflow(flags);
+      if (flags[kFlagMoved])
+        need_rebuild = true;
+    }
+    if (need_rebuild)
+      rebuild(type, pos);
+    force_kernels(pe, force, virial);
+    ++num_compute;
+  }
+
+  void apply_pbc(const double h9[9], const int pbc[3], int64_t n, double* pos)
+  {
+    BoxD box;
+    box_from_h9(h9, pbc, box);
+    ApplyPbcBody body{box, n, pos};
+    be_.template launch<256>(kSlotMisc, n, body);
+  }
+
+  void zero_properties(int64_t n, double* pe, double* force, double* virial)
+  {
+    ZeroPropsBody body{n, pe, force, virial};
+    be_.template launch<256>(kSlotMisc, n, body);
+  }
+
+  void velocity_verlet(
+    bool step1, int64_t n, double dt, const double* mass, const double* force, double* pos, double* vel,
+    const BoxD* wrap_box)
+  {
+    VelocityVerletBody body;
+    std::memset(&body, 0, sizeof(body));
+    body.N = n;
+    body.dt = dt;
+    body.is_step1 = step1 ? 1 : 0;
+    body.fuse_wrap = wrap_box ? 1 : 0;
+    if (wrap_box)
+      body.box = *wrap_box;
+    body.mass = mass;
+    body.force = force;
+    body.pos = pos;
+    body.vel = vel;
+    be_.template launch<256>(kSlotVV, n, body);
+  }
+
+  void find_thermo(
+    int64_t n, double volume, const double* mass, const double* pe, const double* vel,
+    const double* virial, double* thermo8)
+  {
+    be_.thermo(kSlotThermo, n, volume, mass, pe, vel, virial, thermo8, thermo_scratch_);
+  }
+
+  // Run::perform_a_run for `ensemble nve` (run.cu:250-318)
+  void run_nve(
+    const double h9[9], const int pbc[3], int64_t n, const int* type, const double* mass, double dt,
+    int64_t nsteps, double* pos, double* vel, double* pe, double* force, double* virial,
+    int64_t thermo_every, double* thermo_host)
+  {
+    BoxD box;
+    box_from_h9(h9, pbc, box);
+    int64_t rec = 0;
+    for (int64_t step = 0; step < nsteps; ++step) {
+      velocity_verlet(true, n, dt, mass, force, pos, vel, &box); // vv1 + gpu_apply_pbc
+      zero_properties(n, pe, force, virial);
+      potential_compute(h9, pbc, n, type, pos, pe, force, virial);
+      velocity_verlet(false, n, dt, mass, force, pos, vel, nullptr);
+      if (thermo_every > 0 && (step + 1) % thermo_every == 0) {
+        find_thermo(n, box.volume, mass, pe, vel, virial, thermo_dev_);
+        be_.d2h(thermo_host + 8 * rec, thermo_dev_, 8 * sizeof(double));
+        ++rec;
+      }
+    }
+    be_.sync();
+    int flags[kNumFlags];
+    be_.d2h(flags, b_.flags, sizeof(flags));
+    check_overflow(flags);
+  }
+
+  void export_lists(int which, int* nn, int* nl, int64_t ld, int* max_out)
+  {
+    if (!have_list_)
+      throw EngineError{-4, "no force evaluation has been performed yet"};
+    ExportListsBody body{b_, which, nn, nl, ld};
+    be_.template launch<64>(kSlotMisc, N_, body);
+    int flags[kNumFlags];
+    be_.d2h(flags, b_.flags, sizeof(flags));
+    check_overflow(flags);
+    // the caller computes maxima from nn; engine-side maxima of the Verlet lists:
+    *max_out = which == 2 ? flags[kFlagMaxSkin] : -1;
+  }
+
+  void export_descriptors(float* q, float* fp)
+  {
+    if (!have_list_)
+      throw EngineError{-4, "no force evaluation has been performed yet"};
+    ExportDescBody body{b_, model_.dim, q, fp};
+    be_.template launch<64>(kSlotMisc, N_, body);
+  }
+
+  // per-step list statistics of the last compute (host reduction over nn arrays)
+  void list_stats(int& max_skin, int& max_rad, int& max_ang, double& mean_rad, double& mean_ang)
+  {
+    std::vector<int> nr(N_), na(N_);
+    be_.d2h(nr.data(), b_.nn_rad, sizeof(int) * N_);
+    be_.d2h(na.data(), b_.nn_angstep, sizeof(int) * N_);
+    int flags[kNumFlags];
+    be_.d2h(flags, b_.flags, sizeof(flags));
+    max_skin = flags[kFlagMaxSkin];
+    max_rad = max_ang = 0;
+    double sr = 0, sa = 0;
+    for (int64_t i = 0; i < N_; ++i) {
+      if (nr[i] > max_rad) max_rad = nr[i];
+      if (na[i] > max_ang) max_ang = na[i];
+      sr += nr[i];
+      sa += na[i];
+    }
+    mean_rad = sr / (double)N_;
+    mean_ang = sa / (double)N_;
+  }
+
+private:
+  template <class T>
+  T* dalloc(size_t count)
+  {
+    void* p = be_.alloc(sizeof(T) * (count ? count : 1));
+    allocs_.push_back(p);
+    return (T*)p;
+  }
+
+  template <class T>
+  const T* upload(const std::vector<T>& v)
+  {
+    T* p = dalloc<T>(v.size());
+    if (!v.empty())
+      be_.h2d(p, v.data(), sizeof(T) * v.size());
+    return p;
+  }
+
+  void upload_model()
+  {
+    const NepModel& m = model_;
+    md_.T = m.num_types;
+    md_.NR = m.n_max_radial;
+    md_.KR = m.basis_size_radial;
+    md_.NA = m.n_max_angular;
+    md_.KA = m.basis_size_angular;
+    md_.has222 = m.has_q_222;
+    md_.has1111 = m.has_q_1111;
+    md_.numL = m.num_L;
+    md_.dim = m.dim;
+    md_.nneu = m.num_neurons;
+    md_.version = m.version;
+    md_.zbl_enabled = m.zbl_enabled;
+    md_.zbl_flexible = m.zbl_flexible;
+    md_.zbl_rc_inner = (float)m.zbl_rc_inner;
+    md_.zbl_rc_outer = (float)m.zbl_rc_outer;
+    md_.b1 = m.b1;
+    md_.rc_r_max = (float)m.rc_radial_max;
+    md_.rc_a_max = (float)m.rc_angular_max;
+    md_.c_rad = upload(m.c_rad);
+    md_.c_ang = upload(m.c_ang);
+    md_.w0 = upload(m.w0);
+    md_.b0 = upload(m.b0);
+    md_.w1 = upload(m.w1);
+    md_.b1t = upload(m.b1t);
+    md_.qscale = upload(m.q_scaler);
+    md_.rc_r = upload(m.rc_radial_f);
+    md_.rc_a = upload(m.rc_angular_f);
+    md_.zbl_para = upload(m.zbl_para_f);
+    md_.atomic_number = upload(m.atomic_numbers);
+  }
+
+  void allocate()
+  {
+    const NepModel& m = model_;
+    const int64_t N = N_;
+    if (N < 1 || N > kMaxAtomsPerEngine)
+      throw EngineError{-4, "number of atoms per engine must be in [1, 2^25]"};
+    if (m.num_types > 127)
+      throw EngineError{-3, "more than 127 types"};
+    b_.N = N;
+    // Neighbor::initialize, neighbor.cu:824-833
+    const double rcs = m.rc_radial_max + kSkin;
+    b_.MN_rad = m.MN_radial;
+    b_.MN_skin = (int)(m.MN_radial * rcs * rcs * rcs / (m.rc_radial_max * m.rc_radial_max * m.rc_radial_max));
+    const double ras = m.rc_angular_max + kSkin;
+    b_.MN_ang = (int)(m.MN_angular * ras * ras * ras / (m.rc_angular_max * m.rc_angular_max * m.rc_angular_max)) + 1;
+    if (b_.MN_ang > 65000)
+      throw EngineError{-3, "angular Verlet list capacity above 65000 slots is not supported"};
+    b_.rc_skin_sq = (float)(rcs * rcs);
+    b_.rc_askin_sq = (float)(ras * ras);
+    b_.cid = dalloc<int>(N);
+    b_.perm = dalloc<int>(N);
+    b_.posq = dalloc<PosQ>(N);
+    b_.x0s = dalloc<double>(3 * N);
+    b_.nn_skin = dalloc<int>(N);
+    b_.nl_skin = dalloc<int>((size_t)b_.MN_skin * N);
+    b_.nn_ang = dalloc<int>(N);
+    b_.nl_ang = dalloc<int>((size_t)b_.MN_ang * N);
+    b_.rev_ang = dalloc<unsigned short>((size_t)b_.MN_ang * N);
+    b_.nn_rad = dalloc<int>(N);
+    b_.rstash = dalloc<F4>((size_t)b_.MN_rad * N);
+    b_.nn_angstep = dalloc<int>(N);
+    b_.astash = dalloc<F4>((size_t)b_.MN_ang * N);
+    b_.f12 = dalloc<F4>((size_t)b_.MN_ang * N);
+    b_.q = dalloc<float>((size_t)m.dim * N);
+    b_.fp = dalloc<float>((size_t)m.dim * N);
+    b_.sbuf = dalloc<float>((size_t)(m.n_max_angular + 1) * kNumHarm * N);
+    b_.KRP = ((m.basis_size_radial + 1) + 3) / 4 * 4;
+    b_.atab = dalloc<float>((size_t)N * m.num_types * b_.KRP);
+    b_.pe_i = dalloc<float>(N);
+    b_.zbl = dalloc<float>(m.zbl_enabled ? (size_t)10 * N : 1);
+    b_.flags = dalloc<int>(kNumFlags);
+    be_.memset(b_.flags, 0, sizeof(int) * kNumFlags);
+    thermo_scratch_ = dalloc<double>(8 * 1024);
+    thermo_dev_ = dalloc<double>(8);
+    select_shape();
+  }
+
+  void check_overflow(const int* flags)
+  {
+    if (flags[kFlagOverflow]) {
+      char msg[256];
+      std::snprintf(
+        msg, sizeof msg,
+        "neighbour list capacity exceeded (flags=%d; Verlet max %d of %d, angular Verlet max %d of %d, "
+        "radial capacity %d): increase MN in the cutoff line of nep.txt",
+        flags[kFlagOverflow], flags[kFlagMaxSkin], b_.MN_skin, flags[kFlagMaxAng], b_.MN_ang, b_.MN_rad);
+      throw EngineError{-6, msg};
+    }
+  }
+
+  // Neighbor::find_neighbor (neighbor.cu:303-365) + find_cell_list (:164-215)
+  void rebuild(const int* type, const double* pos)
+  {
+    const NepModel& m = model_;
+    const double rc_list = m.rc_radial_max + kSkin;
+    const double rc_cell = 0.5 * rc_list;
+    int nb[3];
+    for (int d = 0; d < 3; ++d) {
+      if (box_.pbc[d]) {
+        if (box_.thickness[d] <= 2.5 * rc_list) { // NEP::compute -> small box (nep.cu:1305-1314)
+          char msg[200];
+          std::snprintf(
+            msg, sizeof msg,
+            "box thickness %.3f A in periodic direction %d is <= 2.5*(rc+skin) = %.3f A: small-box path "
+            "is not implemented on the device",
+            box_.thickness[d], d, 2.5 * rc_list);
+          throw EngineError{-7, msg};
+        }
+        nb[d] = (int)std::floor(box_.thickness[d] / rc_cell);
+      } else {
+        nb[d] = 1;
+      }
+    }
+    const int64_t ncell = (int64_t)nb[0] * nb[1] * nb[2];
+    if (ncell > ((int64_t)1 << 30))
+      throw EngineError{-3, "too many cells"};
+    if (ncell > ncell_cap_) {
+      // grow-only (cell arrays are small next to the lists)
+      b_.cell_count = dalloc<int>(ncell + 1);
+      b_.cell_fill = dalloc<int>(ncell);
+      scan_scratch_ = dalloc<int>(ncell / 1024 + 1024);
+      ncell_cap_ = ncell;
+    }
+    b_.nbx = nb[0];
+    b_.nby = nb[1];
+    b_.nbz = nb[2];
+    b_.rc_inv_cell = 2.0 / rc_list;
+    be_.memset(b_.cell_count, 0, sizeof(int) * (ncell + 1));
+    be_.memset(b_.cell_fill, 0, sizeof(int) * ncell);
+    be_.memset(b_.flags + kFlagMaxSkin, 0, 2 * sizeof(int));
+    be_.begin_region(kRegionRebuild);
+    be_.template launch<256>(kSlotMisc, N_, BinAtomsBody{box_, b_, pos});
+    be_.exclusive_scan(b_.cell_count, ncell + 1, scan_scratch_);
+    be_.template launch<256>(kSlotMisc, N_, FillCellsBody{b_});
+    be_.template launch<256>(kSlotMisc, ncell, SortCellsBody{b_});
+    be_.template launch<256>(kSlotMisc, N_, GatherSortedBody{b_, pos, type});
+    be_.template launch<128>(kSlotMisc, N_, BuildListsBody{box_, b_});
+    be_.template launch<128>(kSlotMisc, N_, ReverseSlotsBody{b_});
+    be_.end_region(kRegionRebuild);
+    int flags[kNumFlags];
+    be_.d2h(flags, b_.flags, sizeof(flags));
+    check_overflow(flags);
+    have_list_ = true;
+    ++num_rebuild;
+  }
+
+  // ---- shape dispatch ----
+  using S_PbTeA = Shape<6, 6, 6, 6, 5, 2>;   // examples/nep_train/nep.txt
+  using S_PbTeB = Shape<4, 8, 4, 8, 5, 2>;   // tests/gpumd/dump_observer/PbTe_species/PbTe.txt
+  using S_C2022 = Shape<10, 10, 8, 8, 6, 1>; // potentials/nep/C_2022_NEP4.txt
+  using S_UNEP = Shape<4, 8, 4, 8, 6, 0>;    // potentials/nep/Song-2024-UNEP-v1-...txt (16 types)
+  using S_BZO = Shape<8, 8, 6, 8, 5, 0>;     // tests_pytest/fixtures/models/nep_BaZrO3.txt (3 types)
+
+  template <class S>
+  bool shape_matches() const
+  {
+    const NepModel& m = model_;
+    if (!S::fixed)
+      return true;
+    return S::NR == m.n_max_radial && S::KR == m.basis_size_radial && S::NA == m.n_max_angular &&
+           S::KA == m.basis_size_angular && S::NL == m.num_L && (S::TS == 0 || S::TS == m.num_types);
+  }
+
+  void select_shape()
+  {
+    if (shape_matches<S_PbTeA>()) shape_ = 1;
+    else if (shape_matches<S_PbTeB>()) shape_ = 2;
+    else if (shape_matches<S_C2022>()) shape_ = 3;
+    else if (shape_matches<S_UNEP>()) shape_ = 4;
+    else if (shape_matches<S_BZO>()) shape_ = 5;
+    else shape_ = 0;
+    if (force_generic_)
+      shape_ = 0;
+  }
+
+public:
+  void set_force_generic(bool on)
+  {
+    force_generic_ = on;
+    select_shape();
+  }
+  int shape_id() const { return shape_; }
+
+private:
+  template <class S>
+  void force_kernels_shape(double* pe, double* force, double* virial)
+  {
+    be_.begin_region(kRegionForce);
+    be_.template launch<64>(kSlotRadial, N_, RadialDescBody<S>{box_, md_, b_});
+    be_.template launch<64>(kSlotAngular, N_, AngularDescBody<S>{box_, md_, b_});
+    be_.template launch<64>(kSlotAnn, N_, AnnBody<S>{md_, b_});
+    be_.template launch<64>(kSlotAngForce, N_, AngularForceBody<S>{md_, b_});
+    be_.template launch<64>(kSlotForce, N_, ForceAssembleBody<S>{md_, b_, pe, force, virial});
+    be_.end_region(kRegionForce);
+  }
+
+  void force_kernels(double* pe, double* force, double* virial)
+  {
+    switch (shape_) {
+      case 1: force_kernels_shape<S_PbTeA>(pe, force, virial); break;
+      case 2: force_kernels_shape<S_PbTeB>(pe, force, virial); break;
+      case 3: force_kernels_shape<S_C2022>(pe, force, virial); break;
+      case 4: force_kernels_shape<S_UNEP>(pe, force, virial); break;
+      case 5: force_kernels_shape<S_BZO>(pe, force, virial); break;
+      default: force_kernels_shape<ShapeGeneric>(pe, force, virial); break;
+    }
+  }
+
+  NepModel model_;
+  B be_;
+  int64_t N_;
+  ModelD md_;
+  Bufs b_;
+  BoxD box_;
+  bool have_list_ = false;
+  bool force_generic_ = false;
+  int shape_ = 0;
+  int64_t ncell_cap_ = 0;
+  int* scan_scratch_ = nullptr;
+  double* thermo_scratch_ = nullptr;
+  double* thermo_dev_ = nullptr;
+  std::vector<void*> allocs_;
+};
+
+} // namespace nepmi

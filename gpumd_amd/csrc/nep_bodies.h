@@ -1,0 +1,967 @@
+// Per-atom kernel bodies of the NEP force path (one work-item = one atom unless stated).
+//
+// Each body is a small functor: the HIP backend launches it as a gfx950 kernel
+// (backend_hip.h: nepmi_kernel<BLOCK, Body>), the test-only emulator (tests/emu) runs the same
+// functor in a host loop.  Bodies only see raw device pointers held in `Bufs`.
+//
+// Data-flow per force evaluation (internal, cell-sorted atom order):
+//   CheckGather   caller x,y,z  -> posq (FP64 pos + type, 32 B/atom), skin-violation flag
+//   RadialDesc    skin list + posq -> per-step radial pair stash (r12 + packed j/t2, 16 B/pair),
+//                 radial descriptor components q[0..NR]
+//   AngularDesc   angular skin list + posq -> angular pair stash, s_{n,lm} sums, q[NR+1..dim)
+//   Ann           q -> U_i, Fp = dU/dq, and the per-atom radial force table A_i[t2][k]
+//   AngularForce  s, Fp -> adjoint G; partial forces f12 = dU_i/dr_ij per angular pair (+ ZBL)
+//   ForceAssemble radial pair forces from A_i/A_j, angular f12 - f21 via reverse slots,
+//                 per-atom virial; scatter-adds into the caller's FP64 arrays.
+// Reference kernels replaced: find_neighbor_list_large_box, find_descriptor, find_force_radial,
+// find_partial_force_angular, gpu_find_force_many_body, find_force_ZBL (src/force/nep.cu:436-975,
+// src/force/potential.cu:170-297).
+#pragma once
+#include "nep_dev.h"
+
+namespace nepmi {
+
+struct alignas(16) F4 {
+  float x, y, z;
+  int w; // packed integer payload (never interpreted as a float)
+};
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define NEPMI_ATOMIC_ADD(ptr, v) atomicAdd((ptr), (v))
+#define NEPMI_ATOMIC_OR(ptr, v) atomicOr((ptr), (v))
+#define NEPMI_ATOMIC_MAX(ptr, v) atomicMax((ptr), (v))
+#else
+NEPMI_HD int host_fetch_add(int* p, int v) { int o = *p; *p = o + v; return o; }
+#define NEPMI_ATOMIC_ADD(ptr, v) host_fetch_add((ptr), (v))
+#define NEPMI_ATOMIC_OR(ptr, v) (*(ptr) |= (v))
+#define NEPMI_ATOMIC_MAX(ptr, v) (*(ptr) = (*(ptr) > (v) ? *(ptr) : (v)))
+#endif
+
+// compile-time model shape; -1 = take the value from ModelD at run time (generic fallback).
+// TS > 0: number of atom types handled with register-resident per-type accumulators.
+template <int NR_, int KR_, int NA_, int KA_, int NL_, int TS_>
+struct Shape {
+  static constexpr int NR = NR_, KR = KR_, NA = NA_, KA = KA_, NL = NL_, TS = TS_;
+  static constexpr bool fixed = NR_ >= 0;
+  static constexpr int NRM = NR_ >= 0 ? NR_ : 19;
+  static constexpr int KRM = KR_ >= 0 ? KR_ : 19;
+  static constexpr int NAM = NA_ >= 0 ? NA_ : 19;
+  static constexpr int KAM = KA_ >= 0 ? KA_ : 19;
+  static constexpr int NLM = NL_ >= 0 ? NL_ : 6;
+  static constexpr int DIMM = (NRM + 1) + (NAM + 1) * NLM;
+};
+using ShapeGeneric = Shape<-1, -1, -1, -1, -1, 0>;
+
+enum FlagSlot { kFlagMoved = 0, kFlagOverflow = 1, kFlagMaxSkin = 2, kFlagMaxAng = 3, kNumFlags = 8 };
+
+struct Bufs {
+  int64_t N;
+  // cell list
+  int nbx, nby, nbz;
+  double rc_inv_cell;
+  float rc_skin_sq;     // float(double (rc_r_max+skin)^2), neighbor.cu:363
+  float rc_askin_sq;    // (rc_a_max+skin)^2
+  int* cell_count;      // [ncell+1] -> exclusive scan in place = cell_start
+  int* cell_fill;       // [ncell]
+  int* cid;             // [N] caller order
+  int* perm;            // [N] internal k -> caller index
+  PosQ* posq;           // [N]
+  double* x0s;          // [3][N] internal order, positions at the last rebuild
+  int MN_skin, MN_ang, MN_rad;
+  int* nn_skin;  int* nl_skin;               // [MN_skin][N]
+  int* nn_ang;   int* nl_ang;  unsigned short* rev_ang; // [MN_ang][N]
+  int* nn_rad;   F4* rstash;                 // per step: [MN_rad][N]
+  int* nn_angstep; F4* astash;               // per step: [MN_ang][N]
+  F4* f12;                                   // [MN_ang][N]
+  float* q;    // [dim][N]
+  float* fp;   // [dim][N]
+  float* sbuf; // [(NA+1)*24][N]
+  float* atab; // [N][T*KRP]
+  int KRP;
+  float* pe_i; // [N]
+  float* zbl;  // [10][N] (fx fy fz, vxx vyy vzz vxy vxz vyz, pe) when zbl enabled
+  int* flags;  // [kNumFlags]
+};
+
+// ------------------------------------------------------------------------------------------------
+// streaming bodies on the caller's arrays
+// ------------------------------------------------------------------------------------------------
+
+// gpu_apply_pbc, force.cu:424-459
+struct ApplyPbcBody {
+  BoxD box;
+  int64_t N;
+  double* pos;
+  NEPMI_HD void operator()(int64_t i) const
+  {
+    double x = pos[i], y = pos[N + i], z = pos[2 * N + i];
+    wrap_position(box, x, y, z);
+    pos[i] = x;
+    pos[N + i] = y;
+    pos[2 * N + i] = z;
+  }
+};
+
+// initialize_properties, force.cu:314-333
+struct ZeroPropsBody {
+  int64_t N;
+  double *pe, *force, *virial;
+  NEPMI_HD void operator()(int64_t i) const
+  {
+    pe[i] = 0.0;
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+      force[d * N + i] = 0.0;
+#pragma unroll
+    for (int d = 0; d < 9; ++d)
+      virial[d * N + i] = 0.0;
+  }
+};
+
+// gpu_velocity_verlet, ensemble.cu:176-214 (+ optional fused wrap for step 1 of the fused loop)
+struct VelocityVerletBody {
+  int64_t N;
+  double dt;
+  int is_step1;
+  int fuse_wrap;
+  BoxD box;
+  const double* mass;
+  const double* force;
+  double* pos;
+  double* vel;
+  NEPMI_HD void operator()(int64_t i) const
+  {
+    const double half = dt * 0.5;
+    const double minv = 1.0 / mass[i];
+    double v[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const double a = force[d * N + i] * minv;
+#if defined(__HIP_DEVICE_COMPILE__)
+      v[d] = __dadd_rn(vel[d * N + i], __dmul_rn(a, half));
+#else
+      v[d] = vel[d * N + i] + a * half;
+#endif
+      vel[d * N + i] = v[d];
+    }
+    if (is_step1) {
+      double r[3];
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        r[d] = __dadd_rn(pos[d * N + i], __dmul_rn(v[d], dt));
+#else
+        r[d] = pos[d * N + i] + v[d] * dt;
+#endif
+      }
+      if (fuse_wrap)
+        wrap_position(box, r[0], r[1], r[2]);
+#pragma unroll
+      for (int d = 0; d < 3; ++d)
+        pos[d * N + i] = r[d];
+    }
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// neighbour rebuild (find_cell_list + gpu_find_neighbor_ON1, neighbor.cu:42-215)
+// ------------------------------------------------------------------------------------------------
+
+struct BinAtomsBody {
+  BoxD box;
+  Bufs b;
+  const double* pos; // caller order
+  NEPMI_HD void operator()(int64_t i) const
+  {
+    int cx, cy, cz;
+    cell_of(box, pos[i], pos[b.N + i], pos[2 * b.N + i], b.rc_inv_cell, b.nbx, b.nby, b.nbz, cx, cy, cz);
+    const int c = cx + b.nbx * (cy + b.nby * cz);
+    b.cid[i] = c;
+    NEPMI_ATOMIC_ADD(&b.cell_count[c], 1);
+  }
+};
+
+struct FillCellsBody {
+  Bufs b; // cell_count already scanned (cell_start)
+  NEPMI_HD void operator()(int64_t i) const
+  {
+    const int c = b.cid[i];
+    const int slot = NEPMI_ATOMIC_ADD(&b.cell_fill[c], 1);
+    b.perm[b.cell_count[c] + slot] = (int)i;
+  }
+};
+
+// one work-item per cell: ascending caller index inside a cell => deterministic internal order
+struct SortCellsBody {
+  Bufs b;
+  NEPMI_HD void operator()(int64_t c) const
+  {
+    const int lo = b.cell_count[c], hi = b.cell_count[c + 1];
+    for (int a = lo + 1; a < hi; ++a) {
+      const int v = b.perm[a];
+      int p = a - 1;
+      while (p >= lo && b.perm[p] > v) {
+        b.perm[p + 1] = b.perm[p];
+        --p;
+      }
+      b.perm[p + 1] = v;
+    }
+  }
+};
+
+// internal k <- caller perm[k]: packed position/type and the rebuild snapshot x0
+struct GatherSortedBody {
+  Bufs b;
+  const double* pos;
+  const int* type;
+  NEPMI_HD void operator()(int64_t k) const
+  {
+    const int64_t i = b.perm[k];
+    PosQ p;
+    p.x = pos[i];
+    p.y = pos[b.N + i];
+    p.z = pos[2 * b.N + i];
+    p.type = type[i];
+    p.pad = 0;
+    b.posq[k] = p;
+    b.x0s[k] = p.x;
+    b.x0s[b.N + k] = p.y;
+    b.x0s[2 * b.N + k] = p.z;
+  }
+};
+
+// gpu_find_neighbor_ON1 (neighbor.cu:85-162) in internal indices: because atoms are stored in
+// cell order, the members of cell c are simply the index range [cell_start[c], cell_start[c+1]).
+// Writes the radial Verlet list (d < rc_r + skin) and the angular Verlet list (d < rc_a + skin).
+struct BuildListsBody {
+  BoxD box;
+  Bufs b;
+  NEPMI_HD void operator()(int64_t k) const
+  {
+    const int64_t N = b.N;
+    const PosQ p1 = b.posq[k];
+    const int c = b.cid[b.perm[k]];
+    const int cx = c % b.nbx, cy = (c / b.nbx) % b.nby, cz = c / (b.nbx * b.nby);
+    const int lx = box.pbc[0] ? 2 : 0, ly = box.pbc[1] ? 2 : 0, lz = box.pbc[2] ? 2 : 0;
+    int cnt = 0, cnta = 0;
+    for (int kz = -lz; kz <= lz; ++kz) {
+      int z2 = cz + kz;
+      if (z2 < 0) z2 += b.nbz; else if (z2 >= b.nbz) z2 -= b.nbz;
+      for (int ky = -ly; ky <= ly; ++ky) {
+        int y2 = cy + ky;
+        if (y2 < 0) y2 += b.nby; else if (y2 >= b.nby) y2 -= b.nby;
+        for (int kx = -lx; kx <= lx; ++kx) {
+          int x2 = cx + kx;
+          if (x2 < 0) x2 += b.nbx; else if (x2 >= b.nbx) x2 -= b.nbx;
+          const int c2 = x2 + b.nbx * (y2 + b.nby * z2);
+          const int lo = b.cell_count[c2], hi = b.cell_count[c2 + 1];
+          for (int j = lo; j < hi; ++j) {
+            if (j == k)
+              continue;
+            const PosQ p2 = b.posq[j];
+            float x, y, z;
+            const float d2 = pair_geometry(box, p1, p2, x, y, z);
+            if (d2 < b.rc_skin_sq) {
+              if (cnt < b.MN_skin)
+                b.nl_skin[(int64_t)cnt * N + k] = j;
+              ++cnt;
+              if (d2 < b.rc_askin_sq) {
+                if (cnta < b.MN_ang)
+                  b.nl_ang[(int64_t)cnta * N + k] = j;
+                ++cnta;
+              }
+            }
+          }
+        }
+      }
+    }
+    if (cnt > b.MN_skin || cnta > b.MN_ang) {
+      NEPMI_ATOMIC_OR(&b.flags[kFlagOverflow], 1);
+      cnt = cnt > b.MN_skin ? b.MN_skin : cnt;
+      cnta = cnta > b.MN_ang ? b.MN_ang : cnta;
+    }
+    b.nn_skin[k] = cnt;
+    b.nn_ang[k] = cnta;
+    NEPMI_ATOMIC_MAX(&b.flags[kFlagMaxSkin], cnt);
+    NEPMI_ATOMIC_MAX(&b.flags[kFlagMaxAng], cnta);
+  }
+};
+
+// rev_ang[s][k] = slot of k in j's angular Verlet list (the pair test is exactly symmetric).
+struct ReverseSlotsBody {
+  Bufs b;
+  NEPMI_HD void operator()(int64_t k) const
+  {
+    const int64_t N = b.N;
+    const int nn = b.nn_ang[k];
+    for (int s = 0; s < nn; ++s) {
+      const int j = b.nl_ang[(int64_t)s * N + k];
+      const int nj = b.nn_ang[j];
+      int r = 65535;
+      for (int s2 = 0; s2 < nj; ++s2)
+        if (b.nl_ang[(int64_t)s2 * N + j] == (int)k) {
+          r = s2;
+          break;
+        }
+      if (r == 65535)
+        NEPMI_ATOMIC_OR(&b.flags[kFlagOverflow], 2);
+      b.rev_ang[(int64_t)s * N + k] = (unsigned short)r;
+    }
+  }
+};
+
+// gpu_check_atom_distance (neighbor.cu:646-684) fused with the per-step gather of the caller's
+// positions into internal order.
+struct CheckGatherBody {
+  BoxD box;
+  Bufs b;
+  const double* pos;
+  NEPMI_HD void operator()(int64_t k) const
+  {
+    const int64_t N = b.N;
+    const int64_t i = b.perm[k];
+    const double x = pos[i], y = pos[N + i], z = pos[2 * N + i];
+    float dx = (float)(x - b.x0s[k]);
+    float dy = (float)(y - b.x0s[N + k]);
+    float dz = (float)(z - b.x0s[2 * N + k]);
+    mic_f(box, dx, dy, dz);
+    if ((double)(dx * dx + dy * dy + dz * dz) > 0.25) // skin^2/4, skin = 1 A (neighbor.cuh:212)
+      NEPMI_ATOMIC_OR(&b.flags[kFlagMoved], 1);
+    b.posq[k].x = x;
+    b.posq[k].y = y;
+    b.posq[k].z = z;
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// force path
+// ------------------------------------------------------------------------------------------------
+
+NEPMI_HD float pair_rc(const float* rc, int t1, int t2) { return (rc[t1] + rc[t2]) * 0.5f; }
+
+// find_neighbor_list_large_box (radial half, nep.cu:436-486) + radial part of find_descriptor
+// (nep.cu:488-547).
+template <class S>
+struct RadialDescBody {
+  BoxD box;
+  ModelD m;
+  Bufs b;
+  NEPMI_HD void operator()(int64_t k) const
+  {
+    const int64_t N = b.N;
+    const int NR = S::fixed ? S::NR : m.NR;
+    const int KR = S::fixed ? S::KR : m.KR;
+    const PosQ p1 = b.posq[k];
+    const int t1 = p1.type;
+    const float rc1 = m.rc_r[t1];
+    constexpr int TSM = S::TS > 0 ? S::TS : 1;
+    float Ssum[TSM][S::KRM + 1];
+    float q[S::NRM + 1];
+#pragma unroll
+    for (int t = 0; t < TSM; ++t)
+#pragma unroll
+      for (int kk = 0; kk <= S::KRM; ++kk)
+        Ssum[t][kk] = 0.0f;
+#pragma unroll
+    for (int n = 0; n <= S::NRM; ++n)
+      q[n] = 0.0f;
+
+    const int nn = b.nn_skin[k];
+    int cnt = 0;
+    for (int s = 0; s < nn; ++s) {
+      const int j = b.nl_skin[(int64_t)s * N + k];
+      const PosQ p2 = b.posq[j];
+      float x, y, z;
+      const float d2 = pair_geometry(box, p1, p2, x, y, z);
+      const int t2 = p2.type;
+      const float rc = (rc1 + m.rc_r[t2]) * 0.5f;
+      if (d2 >= rc * rc)
+        continue;
+      F4 e;
+      e.x = x;
+      e.y = y;
+      e.z = z;
+      e.w = (int)((unsigned)j | ((unsigned)t2 << kIdxBits));
+      if (cnt < b.MN_rad)
+        b.rstash[(int64_t)cnt * N + k] = e;
+      ++cnt;
+      const float d = sqrtf(d2);
+      const float rcinv = 1.0f / rc;
+      float fc;
+      cutoff_fc(rcinv, d, fc);
+      float fn[S::KRM + 1];
+      if (S::fixed)
+        basis_fn<S::KRM>(rcinv, d, fc, fn);
+      else
+        basis_fn_rt(KR, rcinv, d, fc, fn);
+      if (S::TS > 0) {
+#pragma unroll
+        for (int t = 0; t < TSM; ++t) {
+          const float w = (TSM == 1 || t2 == t) ? 1.0f : 0.0f;
+#pragma unroll
+          for (int kk = 0; kk <= S::KRM; ++kk)
+            Ssum[t][kk] = fmaf(w, fn[kk], Ssum[t][kk]);
+        }
+      } else {
+        const float* c = m.c_rad + (size_t)(t1 * m.T + t2) * (NR + 1) * (KR + 1);
+        for (int n = 0; n <= NR; ++n) {
+          float g = 0.0f;
+          for (int kk = 0; kk <= KR; ++kk)
+            g += fn[kk] * c[n * (KR + 1) + kk];
+          q[n] += g;
+        }
+      }
+    }
+    if (cnt > b.MN_rad) {
+      NEPMI_ATOMIC_OR(&b.flags[kFlagOverflow], 4);
+      cnt = b.MN_rad;
+    }
+    b.nn_rad[k] = cnt;
+
+    if (S::TS > 0) {
+      // q[n] = sum_t2 sum_k c[t1][t2][n][k] S[t2][k]; type loop is wave-uniform => scalar loads
+      for (int tu = 0; tu < m.T; ++tu) {
+        if (!NEPMI_WAVE_ANY(t1 == tu))
+          continue;
+        float qq[S::NRM + 1];
+#pragma unroll
+        for (int n = 0; n <= S::NRM; ++n)
+          qq[n] = 0.0f;
+#pragma unroll
+        for (int t2 = 0; t2 < TSM; ++t2) {
+          const float* c = m.c_rad + (size_t)(tu * m.T + t2) * (S::NRM + 1) * (S::KRM + 1);
+#pragma unroll
+          for (int n = 0; n <= S::NRM; ++n)
+#pragma unroll
+            for (int kk = 0; kk <= S::KRM; ++kk)
+              qq[n] = fmaf(c[n * (S::KRM + 1) + kk], Ssum[t2][kk], qq[n]);
+        }
+        if (t1 == tu) {
+#pragma unroll
+          for (int n = 0; n <= S::NRM; ++n)
+            q[n] = qq[n];
+        }
+      }
+    }
+    for (int n = 0; n <= NR; ++n)
+      b.q[(int64_t)n * N + k] = q[n] * m.qscale[n];
+  }
+};
+
+// find_neighbor_list_large_box (angular half) + angular part of find_descriptor (nep.cu:549-640)
+template <class S>
+struct AngularDescBody {
+  BoxD box;
+  ModelD m;
+  Bufs b;
+  NEPMI_HD void operator()(int64_t k) const
+  {
+    const int64_t N = b.N;
+    const int NR = S::fixed ? S::NR : m.NR;
+    const int NA = S::fixed ? S::NA : m.NA;
+    const int KA = S::fixed ? S::KA : m.KA;
+    const PosQ p1 = b.posq[k];
+    const int t1 = p1.type;
+    const float rc1 = m.rc_a[t1];
+    float s[(S::NAM + 1) * kNumHarm];
+#pragma unroll
+    for (int a = 0; a < (S::NAM + 1) * kNumHarm; ++a)
+      s[a] = 0.0f;
+
+    const int nn = b.nn_ang[k];
+    int cnt = 0;
+    for (int sl = 0; sl < nn; ++sl) {
+      const int j = b.nl_ang[(int64_t)sl * N + k];
+      const PosQ p2 = b.posq[j];
+      float x, y, z;
+      const float d2 = pair_geometry(box, p1, p2, x, y, z);
+      const int t2 = p2.type;
+      const float rc = (rc1 + m.rc_a[t2]) * 0.5f;
+      const bool inside = d2 < rc * rc;
+      F4 e;
+      e.x = x;
+      e.y = y;
+      e.z = z;
+      e.w = inside ? (1 | (t2 << 8)) : 0;
+      b.astash[(int64_t)sl * N + k] = e;
+      if (!inside)
+        continue;
+      ++cnt;
+      const float d = sqrtf(d2);
+      const float dinv = 1.0f / d;
+      const float rcinv = 1.0f / rc;
+      float fc;
+      cutoff_fc(rcinv, d, fc);
+      float fn[S::KAM + 1];
+      if (S::fixed)
+        basis_fn<S::KAM>(rcinv, d, fc, fn);
+      else
+        basis_fn_rt(KA, rcinv, d, fc, fn);
+      float bh[kNumHarm];
+      harmonics(x * dinv, y * dinv, z * dinv, bh);
+      const float* c = m.c_ang + (size_t)(t1 * m.T + t2) * (NA + 1) * (KA + 1);
+#pragma unroll
+      for (int n = 0; n <= S::NAM; ++n) {
+        if (!S::fixed && n > NA)
+          break;
+        float g = 0.0f;
+#pragma unroll
+        for (int kk = 0; kk <= S::KAM; ++kk) {
+          if (!S::fixed && kk > KA)
+            break;
+          g += fn[kk] * c[n * (KA + 1) + kk];
+        }
+#pragma unroll
+        for (int a = 0; a < kNumHarm; ++a)
+          s[n * kNumHarm + a] = fmaf(g, bh[a], s[n * kNumHarm + a]);
+      }
+    }
+    b.nn_angstep[k] = cnt;
+
+#pragma unroll
+    for (int n = 0; n <= S::NAM; ++n) {
+      if (!S::fixed && n > NA)
+        break;
+#pragma unroll
+      for (int a = 0; a < kNumHarm; ++a)
+        b.sbuf[(int64_t)(n * kNumHarm + a) * N + k] = s[n * kNumHarm + a];
+      float qn[6];
+      invariants(m, &s[n * kNumHarm], qn, 1);
+      for (int L = 0; L < m.numL; ++L) {
+        const int d = (NR + 1) + L * (NA + 1) + n;
+        b.q[(int64_t)d * N + k] = qn[L] * m.qscale[d];
+      }
+    }
+  }
+};
+
+// apply_ann_one_layer (nep_utilities.cuh:169-194, NEP5 :285-310) + the per-atom radial force
+// table  A_i[t2][k] = sum_n Fp_i[n] c[t1][t2][n][k]  (the n-contraction of find_force_radial,
+// nep.cu:699-754, done once per atom instead of once per pair).
+template <class S>
+struct AnnBody {
+  ModelD m;
+  Bufs b;
+  NEPMI_HD void operator()(int64_t k) const
+  {
+    const int64_t N = b.N;
+    const int NR = S::fixed ? S::NR : m.NR;
+    const int KR = S::fixed ? S::KR : m.KR;
+    const int dim = S::fixed ? S::DIMM : m.dim;
+    const int nneu = m.nneu;
+    const int t1 = b.posq[k].type;
+    float q[S::DIMM], Fp[S::DIMM];
+#pragma unroll
+    for (int d = 0; d < S::DIMM; ++d) {
+      if (!S::fixed && d >= dim)
+        break;
+      q[d] = b.q[(int64_t)d * N + k];
+      Fp[d] = 0.0f;
+    }
+    float E = 0.0f;
+    for (int tu = 0; tu < m.T; ++tu) {
+      if (!NEPMI_WAVE_ANY(t1 == tu))
+        continue;
+      const float* w0 = m.w0 + (size_t)tu * nneu * dim;
+      const float* b0 = m.b0 + (size_t)tu * nneu;
+      const float* w1 = m.w1 + (size_t)tu * nneu;
+      float g[S::DIMM];
+#pragma unroll
+      for (int d = 0; d < S::DIMM; ++d)
+        g[d] = 0.0f;
+      float e = 0.0f;
+      for (int j = 0; j < nneu; ++j) {
+        const float* w = w0 + (size_t)j * dim;
+        float a = 0.0f;
+#pragma unroll
+        for (int d = 0; d < S::DIMM; ++d) {
+          if (!S::fixed && d >= dim)
+            break;
+          a = fmaf(w[d], q[d], a);
+        }
+        const float h = tanhf(a - b0[j]);
+        const float wj = w1[j];
+        e = fmaf(wj, h, e);
+        const float coef = wj * (1.0f - h * h);
+#pragma unroll
+        for (int d = 0; d < S::DIMM; ++d) {
+          if (!S::fixed && d >= dim)
+            break;
+          g[d] = fmaf(coef, w[d], g[d]);
+        }
+      }
+      e -= m.b1 + m.b1t[tu];
+      if (t1 == tu) {
+        E = e;
+#pragma unroll
+        for (int d = 0; d < S::DIMM; ++d) {
+          if (!S::fixed && d >= dim)
+            break;
+          Fp[d] = g[d] * m.qscale[d];
+        }
+      }
+      // radial force table for atoms of this type
+      const int KRP = b.KRP;
+      for (int t2 = 0; t2 < m.T; ++t2) {
+        const float* c = m.c_rad + (size_t)(tu * m.T + t2) * (NR + 1) * (KR + 1);
+#pragma unroll
+        for (int kk = 0; kk <= S::KRM; ++kk) {
+          if (!S::fixed && kk > KR)
+            break;
+          float a = 0.0f;
+#pragma unroll
+          for (int n = 0; n <= S::NRM; ++n) {
+            if (!S::fixed && n > NR)
+              break;
+            a = fmaf(g[n] * m.qscale[n], c[n * (KR + 1) + kk], a);
+          }
+          if (t1 == tu)
+            b.atab[(size_t)k * (m.T * KRP) + t2 * KRP + kk] = a;
+        }
+      }
+    }
+    b.pe_i[k] = E;
+#pragma unroll
+    for (int d = 0; d < S::DIMM; ++d) {
+      if (!S::fixed && d >= dim)
+        break;
+      b.fp[(int64_t)d * N + k] = Fp[d];
+    }
+  }
+};
+
+// find_partial_force_angular (nep.cu:774-861) in adjoint form + find_force_ZBL (nep.cu:863-975).
+//   f12 = dU_i/dr_ij = rhat * sum_abc Q_abc b_abc + (1/d)(I - rhat rhat^T) sum_abc P_abc grad b_abc,
+//   P_abc = sum_n G[n][abc] g_n(d),  Q_abc = sum_n G[n][abc] g_n'(d),  G = dU_i/ds (invariants_adjoint)
+template <class S>
+struct AngularForceBody {
+  ModelD m;
+  Bufs b;
+  NEPMI_HD void operator()(int64_t k) const
+  {
+    const int64_t N = b.N;
+    const int NR = S::fixed ? S::NR : m.NR;
+    const int NA = S::fixed ? S::NA : m.NA;
+    const int KA = S::fixed ? S::KA : m.KA;
+    const int t1 = b.posq[k].type;
+    const float rc1 = m.rc_a[t1];
+
+    float G[(S::NAM + 1) * kNumHarm];
+#pragma unroll
+    for (int n = 0; n <= S::NAM; ++n) {
+      if (!S::fixed && n > NA)
+        break;
+      float fpn[6];
+      for (int L = 0; L < m.numL; ++L)
+        fpn[L] = b.fp[(int64_t)((NR + 1) + L * (NA + 1) + n) * N + k];
+#pragma unroll
+      for (int a = 0; a < kNumHarm; ++a)
+        G[n * kNumHarm + a] = b.sbuf[(int64_t)(n * kNumHarm + a) * N + k];
+      invariants_adjoint(m, fpn, 1, &G[n * kNumHarm]);
+    }
+
+    float zf[3] = {0, 0, 0}, zv[6] = {0, 0, 0, 0, 0, 0}, zpe = 0.0f;
+    float pzi = 0.0f;
+    int zi = 0;
+    if (m.zbl_enabled) {
+      zi = m.atomic_number[t1];
+      pzi = powf((float)zi, 0.23f);
+    }
+
+    const int nn = b.nn_ang[k];
+    for (int sl = 0; sl < nn; ++sl) {
+      const F4 e = b.astash[(int64_t)sl * N + k];
+      const int flag = e.w;
+      F4 out;
+      out.x = out.y = out.z = 0.0f;
+      out.w = 0;
+      if (flag & 1) {
+        const int t2 = flag >> 8;
+        const float x = e.x, y = e.y, z = e.z;
+        const float d = sqrtf(dot3f(x, x, y, y, z, z));
+        const float dinv = 1.0f / d;
+        const float rc = (rc1 + m.rc_a[t2]) * 0.5f;
+        const float rcinv = 1.0f / rc;
+        float fc, fcp;
+        cutoff_fc_fcp(rcinv, d, fc, fcp);
+        float fn[S::KAM + 1], fnp[S::KAM + 1];
+        if (S::fixed)
+          basis_fn_fnp<S::KAM>(rcinv, d, fc, fcp, fn, fnp);
+        else
+          basis_fn_fnp_rt(KA, rcinv, d, fc, fcp, fn, fnp);
+        float P[kNumHarm], Q[kNumHarm];
+#pragma unroll
+        for (int a = 0; a < kNumHarm; ++a)
+          P[a] = Q[a] = 0.0f;
+        const float* c = m.c_ang + (size_t)(t1 * m.T + t2) * (NA + 1) * (KA + 1);
+#pragma unroll
+        for (int n = 0; n <= S::NAM; ++n) {
+          if (!S::fixed && n > NA)
+            break;
+          float g = 0.0f, gp = 0.0f;
+#pragma unroll
+          for (int kk = 0; kk <= S::KAM; ++kk) {
+            if (!S::fixed && kk > KA)
+              break;
+            const float cc = c[n * (KA + 1) + kk];
+            g = fmaf(fn[kk], cc, g);
+            gp = fmaf(fnp[kk], cc, gp);
+          }
+#pragma unroll
+          for (int a = 0; a < kNumHarm; ++a) {
+            P[a] = fmaf(G[n * kNumHarm + a], g, P[a]);
+            Q[a] = fmaf(G[n * kNumHarm + a], gp, Q[a]);
+          }
+        }
+        const float ux = x * dinv, uy = y * dinv, uz = z * dinv;
+        float w, vx, vy, vz;
+        harmonics_contract(ux, uy, uz, P, Q, w, vx, vy, vz);
+        const float udv = ux * vx + uy * vy + uz * vz;
+        out.x = ux * w + (vx - ux * udv) * dinv;
+        out.y = uy * w + (vy - uy * udv) * dinv;
+        out.z = uz * w + (vz - uz * udv) * dinv;
+
+        if (m.zbl_enabled) {
+          const int zj = m.atomic_number[t2];
+          const float a_inv = (pzi + powf((float)zj, 0.23f)) * 2.134563f;
+          const float zizj = 14.399645f * (float)zi * (float)zj;
+          float f, fp;
+          if (m.zbl_flexible) {
+            const int ta = t1 < t2 ? t1 : t2, tb = t1 < t2 ? t2 : t1;
+            const int zidx = ta * m.T - (ta * (ta - 1)) / 2 + (tb - ta);
+            zbl_pair(m.zbl_para + 10 * zidx, zizj, a_inv, 0.0f, 0.0f, d, dinv, f, fp);
+          } else {
+            zbl_pair(nullptr, zizj, a_inv, m.zbl_rc_inner, m.zbl_rc_outer, d, dinv, f, fp);
+          }
+          const float f2 = fp * dinv * 0.5f;
+          const float fx = x * f2, fy = y * f2, fz = z * f2; // f12; f21 = -f12
+          zf[0] += fx + fx;
+          zf[1] += fy + fy;
+          zf[2] += fz + fz;
+          zv[0] -= x * fx;
+          zv[1] -= y * fy;
+          zv[2] -= z * fz;
+          zv[3] -= x * fy;
+          zv[4] -= x * fz;
+          zv[5] -= y * fz;
+          zpe += f * 0.5f;
+        }
+      }
+      b.f12[(int64_t)sl * N + k] = out;
+    }
+    if (m.zbl_enabled) {
+#pragma unroll
+      for (int d = 0; d < 3; ++d)
+        b.zbl[(int64_t)d * N + k] = zf[d];
+#pragma unroll
+      for (int d = 0; d < 6; ++d)
+        b.zbl[(int64_t)(3 + d) * N + k] = zv[d];
+      b.zbl[(int64_t)9 * N + k] = zpe;
+    }
+  }
+};
+
+// find_force_radial (nep.cu:661-772) + gpu_find_force_many_body (potential.cu:170-297) + the
+// accumulation into the caller's FP64 per-atom arrays (potential += , force +=, virial +=).
+template <class S>
+struct ForceAssembleBody {
+  ModelD m;
+  Bufs b;
+  double* pe;     // caller order
+  double* force;  // [3][N]
+  double* virial; // [9][N]
+  NEPMI_HD void operator()(int64_t k) const
+  {
+    const int64_t N = b.N;
+    const int KR = S::fixed ? S::KR : m.KR;
+    const int t1 = b.posq[k].type;
+    const float rc1 = m.rc_r[t1];
+    const int KRP = b.KRP;
+    const int arow = m.T * KRP;
+    constexpr int TSM = S::TS > 0 ? S::TS : 1;
+    float Aown[TSM][S::KRM + 1];
+    if (S::TS > 0) {
+#pragma unroll
+      for (int t = 0; t < TSM; ++t)
+#pragma unroll
+        for (int kk = 0; kk <= S::KRM; ++kk)
+          Aown[t][kk] = b.atab[(size_t)k * arow + t * KRP + kk];
+    }
+    float F[3] = {0, 0, 0};
+    float W[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+    // ---- radial pairs ----
+    const int nr = b.nn_rad[k];
+    for (int sl = 0; sl < nr; ++sl) {
+      const F4 e = b.rstash[(int64_t)sl * N + k];
+      const unsigned wbits = (unsigned)e.w;
+      const int j = (int)(wbits & (unsigned)kIdxMask);
+      const int t2 = (int)(wbits >> kIdxBits);
+      const float x = e.x, y = e.y, z = e.z;
+      const float d = sqrtf(dot3f(x, x, y, y, z, z));
+      const float dinv = 1.0f / d;
+      const float rc = (rc1 + m.rc_r[t2]) * 0.5f;
+      const float rcinv = 1.0f / rc;
+      float fc, fcp;
+      cutoff_fc_fcp(rcinv, d, fc, fcp);
+      float fn[S::KRM + 1], fnp[S::KRM + 1];
+      if (S::fixed)
+        basis_fn_fnp<S::KRM>(rcinv, d, fc, fcp, fn, fnp);
+      else
+        basis_fn_fnp_rt(KR, rcinv, d, fc, fcp, fn, fnp);
+      const float* Aj = b.atab + (size_t)j * arow + t1 * KRP;
+      float s12 = 0.0f, s21 = 0.0f;
+      if (S::TS > 0) {
+#pragma unroll
+        for (int t = 0; t < TSM; ++t) {
+          float a = 0.0f;
+#pragma unroll
+          for (int kk = 0; kk <= S::KRM; ++kk)
+            a = fmaf(fnp[kk], Aown[t][kk], a);
+          if (TSM == 1 || t2 == t)
+            s12 = a;
+        }
+#pragma unroll
+        for (int kk = 0; kk <= S::KRM; ++kk)
+          s21 = fmaf(fnp[kk], Aj[kk], s21);
+      } else {
+        const float* Ai = b.atab + (size_t)k * arow + t2 * KRP;
+        for (int kk = 0; kk <= KR; ++kk) {
+          s12 = fmaf(fnp[kk], Ai[kk], s12);
+          s21 = fmaf(fnp[kk], Aj[kk], s21);
+        }
+      }
+      const float fs = (s12 + s21) * dinv; // f12 - f21 = fs * r12
+      const float bb = s21 * dinv;         // f21 = -bb * r12
+      F[0] = fmaf(fs, x, F[0]);
+      F[1] = fmaf(fs, y, F[1]);
+      F[2] = fmaf(fs, z, F[2]);
+      const float bx = bb * x, by = bb * y, bz = bb * z;
+      W[0] -= x * bx;
+      W[1] -= y * by;
+      W[2] -= z * bz;
+      W[3] -= x * by;
+      W[4] -= x * bz;
+      W[5] -= y * bz;
+    }
+    W[6] = W[3];
+    W[7] = W[4];
+    W[8] = W[5];
+
+    // ---- angular pairs: f12 - f21 through the reverse slot ----
+    const int na = b.nn_ang[k];
+    for (int sl = 0; sl < na; ++sl) {
+      const F4 e = b.astash[(int64_t)sl * N + k];
+      if (!(e.w & 1))
+        continue;
+      const int j = b.nl_ang[(int64_t)sl * N + k];
+      const int rs = b.rev_ang[(int64_t)sl * N + k];
+      const F4 f12 = b.f12[(int64_t)sl * N + k];
+      const F4 f21 = b.f12[(int64_t)rs * N + j];
+      F[0] += f12.x - f21.x;
+      F[1] += f12.y - f21.y;
+      F[2] += f12.z - f21.z;
+      W[0] += e.x * f21.x;
+      W[1] += e.y * f21.y;
+      W[2] += e.z * f21.z;
+      W[3] += e.x * f21.y;
+      W[4] += e.x * f21.z;
+      W[5] += e.y * f21.z;
+      W[6] += e.y * f21.x;
+      W[7] += e.z * f21.x;
+      W[8] += e.z * f21.y;
+    }
+
+    double E = (double)b.pe_i[k];
+    double Fd[3] = {(double)F[0], (double)F[1], (double)F[2]};
+    double Wd[9];
+#pragma unroll
+    for (int d = 0; d < 9; ++d)
+      Wd[d] = (double)W[d];
+    if (m.zbl_enabled) {
+#pragma unroll
+      for (int d = 0; d < 3; ++d)
+        Fd[d] += (double)b.zbl[(int64_t)d * N + k];
+#pragma unroll
+      for (int d = 0; d < 6; ++d)
+        Wd[d] += (double)b.zbl[(int64_t)(3 + d) * N + k];
+      Wd[6] += (double)b.zbl[(int64_t)(3 + 3) * N + k];
+      Wd[7] += (double)b.zbl[(int64_t)(3 + 4) * N + k];
+      Wd[8] += (double)b.zbl[(int64_t)(3 + 5) * N + k];
+      E += (double)b.zbl[(int64_t)9 * N + k];
+    }
+    const int64_t i = b.perm[k];
+    pe[i] += E;
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+      force[d * N + i] += Fd[d];
+#pragma unroll
+    for (int d = 0; d < 9; ++d)
+      virial[d * N + i] += Wd[d];
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// diagnostics
+// ------------------------------------------------------------------------------------------------
+
+// which: 0 radial (per step), 1 angular (per step), 2 Verlet skin list.  Caller indices, ascending.
+struct ExportListsBody {
+  Bufs b;
+  int which;
+  int* nn_out;
+  int* nl_out;
+  int64_t ld;
+  NEPMI_HD void operator()(int64_t k) const
+  {
+    const int64_t N = b.N;
+    const int64_t i = b.perm[k];
+    int cnt = 0;
+    const int total = which == 0 ? b.nn_rad[k] : which == 1 ? b.nn_ang[k] : b.nn_skin[k];
+    for (int s = 0; s < total; ++s) {
+      int j;
+      if (which == 0) {
+        j = (int)((unsigned)b.rstash[(int64_t)s * N + k].w & (unsigned)kIdxMask);
+      } else if (which == 1) {
+        if (!(b.astash[(int64_t)s * N + k].w & 1))
+          continue;
+        j = b.nl_ang[(int64_t)s * N + k];
+      } else {
+        j = b.nl_skin[(int64_t)s * N + k];
+      }
+      const int jc = b.perm[j];
+      if (cnt < ld) {
+        // insertion into the ascending column
+        int p = cnt - 1;
+        while (p >= 0 && nl_out[(int64_t)p * N + i] > jc) {
+          nl_out[(int64_t)(p + 1) * N + i] = nl_out[(int64_t)p * N + i];
+          --p;
+        }
+        nl_out[(int64_t)(p + 1) * N + i] = jc;
+      }
+      ++cnt;
+    }
+    nn_out[i] = cnt;
+  }
+};
+
+// q / Fp planes to caller order
+struct ExportDescBody {
+  Bufs b;
+  int dim;
+  float* q_out;
+  float* fp_out;
+  NEPMI_HD void operator()(int64_t k) const
+  {
+    const int64_t N = b.N;
+    const int64_t i = b.perm[k];
+    for (int d = 0; d < dim; ++d) {
+      if (q_out)
+        q_out[(int64_t)d * N + i] = b.q[(int64_t)d * N + k];
+      if (fp_out)
+        fp_out[(int64_t)d * N + i] = b.fp[(int64_t)d * N + k];
+    }
+  }
+};
+
+} // namespace nepmi

@@ -1,0 +1,479 @@
+// Device-side data structures and NEP math (inline, single precision unless noted).
+//
+// Everything here is `NEPMI_HD` so that the per-atom kernel bodies (nep_bodies.h) can also be
+// compiled by g++ into the test-only logic emulator under tests/emu (this container has no GPU).
+// The product library libnepmi.so contains only the gfx950 device code paths.
+//
+// Arithmetic that decides neighbour membership (r12, MIC, d^2 < rc^2) is written as explicit fma
+// chains in a fixed order, the same chains the oracle documents (oracle/nep_oracle_core.inc:21-27),
+// so that neighbour indices are bit-exact; everything else is free to be contracted.
+#pragma once
+#include <cmath>
+#include <cstdint>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define NEPMI_HD __host__ __device__ __forceinline__
+#else
+#define NEPMI_HD inline
+#endif
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define NEPMI_WAVE_ANY(pred) (__any((int)(pred)))
+#else
+#define NEPMI_WAVE_ANY(pred) (pred)
+#endif
+
+namespace nepmi {
+
+constexpr int kNumHarm = 24;       // (L_max+1)^2 - 1 for L_max = 4
+constexpr int kIdxBits = 25;       // neighbour index bits in a packed pair word
+constexpr int kIdxMask = (1 << kIdxBits) - 1;
+constexpr int64_t kMaxAtomsPerEngine = (int64_t)1 << kIdxBits;
+
+// numerical constants of the NEP descriptor definition (nep_utilities.cuh:18-46): squared
+// normalisation of the real spherical harmonics and the 4-/5-body coupling constants.
+#define NEPMI_C3B_INIT                                                                              \
+  {0.238732414637843f, 0.119366207318922f, 0.119366207318922f, 0.099471839432435f,                 \
+   0.596831036594608f, 0.596831036594608f, 0.149207759148652f, 0.149207759148652f,                 \
+   0.139260575205408f, 0.104445431404056f, 0.104445431404056f, 1.044454314040563f,                 \
+   1.044454314040563f, 0.174075719006761f, 0.174075719006761f, 0.011190581936149f,                 \
+   0.223811638722978f, 0.223811638722978f, 0.111905819361489f, 0.111905819361489f,                 \
+   1.566681471060845f, 1.566681471060845f, 0.195835183882606f, 0.195835183882606f}
+#define NEPMI_C4B_0 (-0.007499480826664f)
+#define NEPMI_C4B_1 (-0.134990654879954f)
+#define NEPMI_C4B_2 (0.067495327439977f)
+#define NEPMI_C4B_3 (0.404971964639861f)
+#define NEPMI_C4B_4 (-0.809943929279723f)
+#define NEPMI_C5B_0 (0.026596810706114f)
+#define NEPMI_C5B_1 (0.053193621412227f)
+#define NEPMI_C5B_2 (0.026596810706114f)
+
+#define NEPMI_PI 3.1415927f
+#define NEPMI_HALF_PI 1.5707963f
+
+// One atom in the engine's internal (cell-sorted) order: FP64 position + type, 32 B.
+struct alignas(16) PosQ {
+  double x, y, z;
+  int type;
+  int pad;
+};
+
+// Box, the subset of src/model/box.cuh the path needs: h[0..8] cell (columns a,b,c), h[9..17]
+// inverse; float copy for the FP32 kernels (Box::float_h... refreshed by set_is_orthogonal,
+// box.cu:111-117).
+struct BoxD {
+  double h[18];
+  float hf[18];
+  double thickness[3];
+  double volume;
+  int pbc[3];
+  int ortho;
+};
+
+struct ModelD {
+  int T, NR, KR, NA, KA;
+  int has222, has1111, numL, dim, nneu, version;
+  int zbl_enabled, zbl_flexible;
+  float zbl_rc_inner, zbl_rc_outer;
+  float b1;
+  float rc_r_max, rc_a_max;
+  const float* c_rad;  // [T*T][NR+1][KR+1]
+  const float* c_ang;  // [T*T][NA+1][KA+1]
+  const float* w0;     // [T][nneu][dim]
+  const float* b0;     // [T][nneu]
+  const float* w1;     // [T][nneu]
+  const float* b1t;    // [T]
+  const float* qscale; // [dim]
+  const float* rc_r;   // [T]
+  const float* rc_a;   // [T]
+  const float* zbl_para;   // [T(T+1)/2][10]
+  const int* atomic_number; // [T]
+};
+
+// ---- geometry -------------------------------------------------------------------------------
+
+// a*b + c*d + e*f as fma(e,f, fma(c,d, a*b))
+NEPMI_HD float dot3f(float a, float b, float c, float d, float e, float f)
+{
+  return fmaf(e, f, fmaf(c, d, a * b));
+}
+
+// apply_mic (float), src/model/box.cuh:84-129
+NEPMI_HD void mic_f(const BoxD& box, float& x, float& y, float& z)
+{
+  const float* H = box.hf;
+  if (box.ortho) {
+    if (box.pbc[0]) {
+      const float L = H[0], hl = L * 0.5f;
+      if (x < -hl) x += L; else if (x > hl) x -= L;
+    }
+    if (box.pbc[1]) {
+      const float L = H[4], hl = L * 0.5f;
+      if (y < -hl) y += L; else if (y > hl) y -= L;
+    }
+    if (box.pbc[2]) {
+      const float L = H[8], hl = L * 0.5f;
+      if (z < -hl) z += L; else if (z > hl) z -= L;
+    }
+  } else {
+    float sx = dot3f(H[9], x, H[10], y, H[11], z);
+    float sy = dot3f(H[12], x, H[13], y, H[14], z);
+    float sz = dot3f(H[15], x, H[16], y, H[17], z);
+    if (box.pbc[0]) sx -= nearbyintf(sx);
+    if (box.pbc[1]) sy -= nearbyintf(sy);
+    if (box.pbc[2]) sz -= nearbyintf(sz);
+    x = dot3f(H[0], sx, H[1], sy, H[2], sz);
+    y = dot3f(H[3], sx, H[4], sy, H[5], sz);
+    z = dot3f(H[6], sx, H[7], sy, H[8], sz);
+  }
+}
+
+// r12 exactly as the reference kernels form it: double subtraction, round to float, float MIC
+// (nep.cu:467-472); returns d^2 as the fixed fma chain.
+NEPMI_HD float pair_geometry(const BoxD& box, const PosQ& a, const PosQ& b, float& x, float& y, float& z)
+{
+  x = (float)(b.x - a.x);
+  y = (float)(b.y - a.y);
+  z = (float)(b.z - a.z);
+  mic_f(box, x, y, z);
+  return dot3f(x, x, y, y, z, z);
+}
+
+// gpu_apply_pbc, force.cu:424-459 (double; explicit non-fused ops so the CPU oracle, the device
+// and the emulator give identical bits).
+NEPMI_HD void wrap_position(const BoxD& box, double& x, double& y, double& z)
+{
+  const double* h = box.h;
+#if defined(__HIP_DEVICE_COMPILE__)
+#define NEPMI_DM(a, b) __dmul_rn(a, b)
+#define NEPMI_DA(a, b) __dadd_rn(a, b)
+#else
+#define NEPMI_DM(a, b) ((a) * (b))
+#define NEPMI_DA(a, b) ((a) + (b))
+#endif
+  double sx = NEPMI_DA(NEPMI_DA(NEPMI_DM(h[9], x), NEPMI_DM(h[10], y)), NEPMI_DM(h[11], z));
+  double sy = NEPMI_DA(NEPMI_DA(NEPMI_DM(h[12], x), NEPMI_DM(h[13], y)), NEPMI_DM(h[14], z));
+  double sz = NEPMI_DA(NEPMI_DA(NEPMI_DM(h[15], x), NEPMI_DM(h[16], y)), NEPMI_DM(h[17], z));
+  if (box.pbc[0]) { if (sx < 0.0) sx += 1.0; else if (sx > 1.0) sx -= 1.0; }
+  if (box.pbc[1]) { if (sy < 0.0) sy += 1.0; else if (sy > 1.0) sy -= 1.0; }
+  if (box.pbc[2]) { if (sz < 0.0) sz += 1.0; else if (sz > 1.0) sz -= 1.0; }
+  x = NEPMI_DA(NEPMI_DA(NEPMI_DM(h[0], sx), NEPMI_DM(h[1], sy)), NEPMI_DM(h[2], sz));
+  y = NEPMI_DA(NEPMI_DA(NEPMI_DM(h[3], sx), NEPMI_DM(h[4], sy)), NEPMI_DM(h[5], sz));
+  z = NEPMI_DA(NEPMI_DA(NEPMI_DM(h[6], sx), NEPMI_DM(h[7], sy)), NEPMI_DM(h[8], sz));
+#undef NEPMI_DM
+#undef NEPMI_DA
+}
+
+// find_cell_id, neighbor.cuh:76-110
+NEPMI_HD void cell_of(
+  const BoxD& box, double x, double y, double z, double rc_inv, int nbx, int nby, int nbz,
+  int& cx, int& cy, int& cz)
+{
+  const double* h = box.h;
+  const double sx = h[9] * x + h[10] * y + h[11] * z;
+  const double sy = h[12] * x + h[13] * y + h[14] * z;
+  const double sz = h[15] * x + h[16] * y + h[17] * z;
+  cx = (int)floor(sx * box.thickness[0] * rc_inv);
+  cy = (int)floor(sy * box.thickness[1] * rc_inv);
+  cz = (int)floor(sz * box.thickness[2] * rc_inv);
+  while (cx < 0) cx += nbx;
+  while (cx >= nbx) cx -= nbx;
+  while (cy < 0) cy += nby;
+  while (cy >= nby) cy -= nby;
+  while (cz < 0) cz += nbz;
+  while (cz >= nbz) cz -= nbz;
+}
+
+// ---- radial functions -----------------------------------------------------------------------
+
+// find_fc / find_fc_and_fcp, nep_utilities.cuh:409-431 (caller guarantees d < rc)
+NEPMI_HD void cutoff_fc(float rcinv, float d, float& fc)
+{
+  fc = 0.5f * cosf(NEPMI_PI * d * rcinv) + 0.5f;
+}
+NEPMI_HD void cutoff_fc_fcp(float rcinv, float d, float& fc, float& fcp)
+{
+  float s, c;
+#if defined(__HIP_DEVICE_COMPILE__)
+  sincosf(NEPMI_PI * d * rcinv, &s, &c);
+#else
+  s = sinf(NEPMI_PI * d * rcinv);
+  c = cosf(NEPMI_PI * d * rcinv);
+#endif
+  fc = 0.5f * c + 0.5f;
+  fcp = -NEPMI_HALF_PI * s * rcinv;
+}
+
+// find_fn, nep_utilities.cuh:572-588: f_k = (T_k(x)+1)/2 * fc, x = 2 (d/rc - 1)^2 - 1
+template <int K>
+NEPMI_HD void basis_fn(float rcinv, float d, float fc, float* fn)
+{
+  const float dr = d * rcinv - 1.0f;
+  const float x = 2.0f * dr * dr - 1.0f;
+  const float hfc = 0.5f * fc;
+  fn[0] = fc;
+  if (K >= 1)
+    fn[1] = (x + 1.0f) * hfc;
+  float tm2 = 1.0f, tm1 = x;
+#pragma unroll
+  for (int k = 2; k <= K; ++k) {
+    const float t = 2.0f * x * tm1 - tm2;
+    tm2 = tm1;
+    tm1 = t;
+    fn[k] = (t + 1.0f) * hfc;
+  }
+}
+
+// find_fn_and_fnp, nep_utilities.cuh:590-623: values and d/dr via U_{k-1}
+template <int K>
+NEPMI_HD void basis_fn_fnp(float rcinv, float d, float fc, float fcp, float* fn, float* fnp)
+{
+  const float dr = d * rcinv - 1.0f;
+  const float x = 2.0f * dr * dr - 1.0f;
+  const float dxdr = 4.0f * dr * rcinv; // dx/dr
+  const float hfc = 0.5f * fc, hfcp = 0.5f * fcp;
+  fn[0] = fc;
+  fnp[0] = fcp;
+  if (K >= 1) {
+    fn[1] = (x + 1.0f) * hfc;
+    fnp[1] = dxdr * hfc + (x + 1.0f) * hfcp;
+  }
+  float tm2 = 1.0f, tm1 = x;
+  float u0 = 1.0f, u1 = 2.0f * x; // U_0, U_1
+#pragma unroll
+  for (int k = 2; k <= K; ++k) {
+    const float t = 2.0f * x * tm1 - tm2;
+    tm2 = tm1;
+    tm1 = t;
+    // dT_k/dx = k U_{k-1}
+    fnp[k] = ((float)k * u1) * dxdr * hfc + (t + 1.0f) * hfcp;
+    fn[k] = (t + 1.0f) * hfc;
+    const float u2 = 2.0f * x * u1 - u0;
+    u0 = u1;
+    u1 = u2;
+  }
+}
+
+// Runtime-K variants (generic fallback path).
+NEPMI_HD void basis_fn_rt(int K, float rcinv, float d, float fc, float* fn)
+{
+  const float dr = d * rcinv - 1.0f;
+  const float x = 2.0f * dr * dr - 1.0f;
+  const float hfc = 0.5f * fc;
+  fn[0] = fc;
+  if (K >= 1)
+    fn[1] = (x + 1.0f) * hfc;
+  float tm2 = 1.0f, tm1 = x;
+  for (int k = 2; k <= K; ++k) {
+    const float t = 2.0f * x * tm1 - tm2;
+    tm2 = tm1;
+    tm1 = t;
+    fn[k] = (t + 1.0f) * hfc;
+  }
+}
+NEPMI_HD void basis_fn_fnp_rt(int K, float rcinv, float d, float fc, float fcp, float* fn, float* fnp)
+{
+  const float dr = d * rcinv - 1.0f;
+  const float x = 2.0f * dr * dr - 1.0f;
+  const float dxdr = 4.0f * dr * rcinv;
+  const float hfc = 0.5f * fc, hfcp = 0.5f * fcp;
+  fn[0] = fc;
+  fnp[0] = fcp;
+  if (K >= 1) {
+    fn[1] = (x + 1.0f) * hfc;
+    fnp[1] = dxdr * hfc + (x + 1.0f) * hfcp;
+  }
+  float tm2 = 1.0f, tm1 = x;
+  float u0 = 1.0f, u1 = 2.0f * x;
+  for (int k = 2; k <= K; ++k) {
+    const float t = 2.0f * x * tm1 - tm2;
+    tm2 = tm1;
+    tm1 = t;
+    fnp[k] = ((float)k * u1) * dxdr * hfc + (t + 1.0f) * hfcp;
+    fn[k] = (t + 1.0f) * hfc;
+    const float u2 = 2.0f * x * u1 - u0;
+    u0 = u1;
+    u1 = u2;
+  }
+}
+
+// ---- angular basis ----------------------------------------------------------------------------
+//
+// b_abc(x,y,z) for a unit vector: the 24 unnormalised real harmonics of L = 1..4 in the order of
+// accumulate_s (nep_utilities.cuh:1674-1756): block L starts at L^2-1; entry 0 is the m = 0
+// polynomial in z, then (Re, Im) pairs of z-polynomial * (x+iy)^m for m = 1..L.
+NEPMI_HD void harmonics(float x, float y, float z, float* b)
+{
+  const float z2 = z * z;
+  const float x2y2 = x * x - y * y, xy2 = 2.0f * x * y;          // (x+iy)^2
+  const float x3 = x * x2y2 - y * xy2, y3 = x * xy2 + y * x2y2;  // (x+iy)^3
+  const float x4 = x * x3 - y * y3, y4 = x * y3 + y * x3;        // (x+iy)^4
+  b[0] = z;
+  b[1] = x;
+  b[2] = y;
+  b[3] = 3.0f * z2 - 1.0f;
+  b[4] = z * x;
+  b[5] = z * y;
+  b[6] = x2y2;
+  b[7] = xy2;
+  const float p31 = 5.0f * z2 - 1.0f;
+  b[8] = (5.0f * z2 - 3.0f) * z;
+  b[9] = p31 * x;
+  b[10] = p31 * y;
+  b[11] = z * x2y2;
+  b[12] = z * xy2;
+  b[13] = x3;
+  b[14] = y3;
+  const float p41 = (7.0f * z2 - 3.0f) * z, p42 = 7.0f * z2 - 1.0f;
+  b[15] = (35.0f * z2 - 30.0f) * z2 + 3.0f;
+  b[16] = p41 * x;
+  b[17] = p41 * y;
+  b[18] = p42 * x2y2;
+  b[19] = p42 * xy2;
+  b[20] = z * x3;
+  b[21] = z * y3;
+  b[22] = x4;
+  b[23] = y4;
+}
+
+// w = sum_abc Q[abc] b_abc ,  v = sum_abc P[abc] grad_u b_abc   (grad over unconstrained x,y,z)
+NEPMI_HD void harmonics_contract(
+  float x, float y, float z, const float* P, const float* Q, float& w, float& vx, float& vy, float& vz)
+{
+  const float z2 = z * z;
+  const float x2y2 = x * x - y * y, xy2 = 2.0f * x * y;
+  const float x3 = x * x2y2 - y * xy2, y3 = x * xy2 + y * x2y2;
+  const float x4 = x * x3 - y * y3, y4 = x * y3 + y * x3;
+  const float p31 = 5.0f * z2 - 1.0f;
+  const float p41 = (7.0f * z2 - 3.0f) * z, p42 = 7.0f * z2 - 1.0f;
+  // values
+  w = Q[0] * z + Q[1] * x + Q[2] * y + Q[3] * (3.0f * z2 - 1.0f) + Q[4] * (z * x) + Q[5] * (z * y) +
+      Q[6] * x2y2 + Q[7] * xy2 + Q[8] * ((5.0f * z2 - 3.0f) * z) + Q[9] * (p31 * x) + Q[10] * (p31 * y) +
+      Q[11] * (z * x2y2) + Q[12] * (z * xy2) + Q[13] * x3 + Q[14] * y3 +
+      Q[15] * ((35.0f * z2 - 30.0f) * z2 + 3.0f) + Q[16] * (p41 * x) + Q[17] * (p41 * y) +
+      Q[18] * (p42 * x2y2) + Q[19] * (p42 * xy2) + Q[20] * (z * x3) + Q[21] * (z * y3) + Q[22] * x4 +
+      Q[23] * y4;
+  // d/dx
+  // (x+iy)^m derivative: d/dx (Re,Im)_m = m (Re,Im)_{m-1};  d/dy (Re,Im)_m = m (-Im, Re)_{m-1}
+  vx = P[1] + P[4] * z + P[6] * (2.0f * x) + P[7] * (2.0f * y) + P[9] * p31 + P[11] * (z * 2.0f * x) +
+       P[12] * (z * 2.0f * y) + P[13] * (3.0f * x2y2) + P[14] * (3.0f * xy2) + P[16] * p41 +
+       P[18] * (p42 * 2.0f * x) + P[19] * (p42 * 2.0f * y) + P[20] * (z * 3.0f * x2y2) +
+       P[21] * (z * 3.0f * xy2) + P[22] * (4.0f * x3) + P[23] * (4.0f * y3);
+  vy = P[2] + P[5] * z - P[6] * (2.0f * y) + P[7] * (2.0f * x) + P[10] * p31 - P[11] * (z * 2.0f * y) +
+       P[12] * (z * 2.0f * x) - P[13] * (3.0f * xy2) + P[14] * (3.0f * x2y2) + P[17] * p41 -
+       P[18] * (p42 * 2.0f * y) + P[19] * (p42 * 2.0f * x) - P[20] * (z * 3.0f * xy2) +
+       P[21] * (z * 3.0f * x2y2) - P[22] * (4.0f * y3) + P[23] * (4.0f * x3);
+  vz = P[0] + P[3] * (6.0f * z) + P[4] * x + P[5] * y + P[8] * (15.0f * z2 - 3.0f) +
+       P[9] * (10.0f * z * x) + P[10] * (10.0f * z * y) + P[11] * x2y2 + P[12] * xy2 +
+       P[15] * ((140.0f * z2 - 60.0f) * z) + P[16] * ((21.0f * z2 - 3.0f) * x) +
+       P[17] * ((21.0f * z2 - 3.0f) * y) + P[18] * (14.0f * z * x2y2) + P[19] * (14.0f * z * xy2) +
+       P[20] * x3 + P[21] * y3;
+}
+
+// 3-/4-/5-body invariants of one radial order from its 24 sums (find_q, nep_utilities.cuh:
+// 1758-1770, 1859-1872).  q is strided by `stride` (= n_max_angular + 1).
+NEPMI_HD void invariants(const ModelD& m, const float* s, float* q, int stride)
+{
+  const float C3B[kNumHarm] = NEPMI_C3B_INIT;
+#pragma unroll
+  for (int L = 1; L <= 4; ++L) {
+    const int st = L * L - 1;
+    float acc = 0.0f;
+#pragma unroll
+    for (int k = 1; k < 2 * L + 1; ++k)
+      acc += C3B[st + k] * s[st + k] * s[st + k];
+    q[(L - 1) * stride] = 2.0f * acc + C3B[st] * s[st] * s[st];
+  }
+  int Lidx = 4;
+  if (m.has222) {
+    q[(Lidx++) * stride] = NEPMI_C4B_0 * s[3] * s[3] * s[3] + NEPMI_C4B_1 * s[3] * (s[4] * s[4] + s[5] * s[5]) +
+                           NEPMI_C4B_2 * s[3] * (s[6] * s[6] + s[7] * s[7]) +
+                           NEPMI_C4B_3 * s[6] * (s[5] * s[5] - s[4] * s[4]) + NEPMI_C4B_4 * s[4] * s[5] * s[7];
+  }
+  if (m.has1111) {
+    const float s0 = s[0] * s[0], s12 = s[1] * s[1] + s[2] * s[2];
+    q[(Lidx++) * stride] = NEPMI_C5B_0 * s0 * s0 + NEPMI_C5B_1 * s0 * s12 + NEPMI_C5B_2 * s12 * s12;
+  }
+}
+
+// Adjoint of `invariants`: G[abc] = sum_L Fp_L dq_L/ds_abc (+ 4-/5-body), in place of s.
+// fp is strided like q.
+NEPMI_HD void invariants_adjoint(const ModelD& m, const float* fp, int stride, float* s /* in: s, out: G */)
+{
+  const float C3B[kNumHarm] = NEPMI_C3B_INIT;
+  float g4[5] = {0, 0, 0, 0, 0}, g5[3] = {0, 0, 0};
+  int Lidx = 4;
+  if (m.has222) {
+    const float F = fp[(Lidx++) * stride];
+    const float s0 = s[3], s1 = s[4], s2 = s[5], s3 = s[6], s4 = s[7];
+    g4[0] = F * (3.0f * NEPMI_C4B_0 * s0 * s0 + NEPMI_C4B_1 * (s1 * s1 + s2 * s2) + NEPMI_C4B_2 * (s3 * s3 + s4 * s4));
+    g4[1] = F * (2.0f * NEPMI_C4B_1 * s0 * s1 - 2.0f * NEPMI_C4B_3 * s3 * s1 + NEPMI_C4B_4 * s2 * s4);
+    g4[2] = F * (2.0f * NEPMI_C4B_1 * s0 * s2 + 2.0f * NEPMI_C4B_3 * s3 * s2 + NEPMI_C4B_4 * s1 * s4);
+    g4[3] = F * (2.0f * NEPMI_C4B_2 * s0 * s3 + NEPMI_C4B_3 * (s2 * s2 - s1 * s1));
+    g4[4] = F * (2.0f * NEPMI_C4B_2 * s0 * s4 + NEPMI_C4B_4 * s1 * s2);
+  }
+  if (m.has1111) {
+    const float F = fp[(Lidx++) * stride];
+    const float s0 = s[0], s1 = s[1], s2 = s[2];
+    const float s12 = s1 * s1 + s2 * s2;
+    g5[0] = F * (4.0f * NEPMI_C5B_0 * s0 * s0 * s0 + 2.0f * NEPMI_C5B_1 * s0 * s12);
+    g5[1] = F * (2.0f * NEPMI_C5B_1 * s0 * s0 * s1 + 4.0f * NEPMI_C5B_2 * s12 * s1);
+    g5[2] = F * (2.0f * NEPMI_C5B_1 * s0 * s0 * s2 + 4.0f * NEPMI_C5B_2 * s12 * s2);
+  }
+#pragma unroll
+  for (int L = 1; L <= 4; ++L) {
+    const int st = L * L - 1;
+    const float F = fp[(L - 1) * stride];
+    s[st] = 2.0f * C3B[st] * F * s[st];
+#pragma unroll
+    for (int k = 1; k < 2 * L + 1; ++k)
+      s[st + k] = 4.0f * C3B[st + k] * F * s[st + k];
+  }
+#pragma unroll
+  for (int k = 0; k < 5; ++k)
+    s[3 + k] += g4[k];
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+    s[k] += g5[k];
+}
+
+// find_f_and_fp_zbl, nep_utilities.cuh:433-508.  para10 == nullptr: universal ZBL.
+NEPMI_HD void zbl_pair(
+  const float* para10, float zizj, float a_inv, float rc_in, float rc_out, float d, float dinv, float& f,
+  float& fp)
+{
+  const float U[8] = {0.18175f, 3.1998f, 0.50986f, 0.94229f, 0.28022f, 0.4029f, 0.02817f, 0.20162f};
+  const float x = d * a_inv;
+  float phi = 0.0f, phip = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const float a = para10 ? para10[2 + 2 * k] : U[2 * k];
+    const float b = para10 ? para10[3 + 2 * k] : U[2 * k + 1];
+    const float t = a * expf(-b * x);
+    phi += t;
+    phip -= b * t;
+  }
+  phi *= zizj;
+  phip *= zizj * a_inv;
+  phip = phip * dinv - phi * dinv * dinv;
+  phi *= dinv;
+  const float r1 = para10 ? para10[0] : rc_in;
+  const float r2 = para10 ? para10[1] : rc_out;
+  float fc, fcp;
+  if (d < r1) {
+    fc = 1.0f;
+    fcp = 0.0f;
+  } else if (d < r2) {
+    const float pf = NEPMI_PI / (r2 - r1);
+    fc = cosf(pf * (d - r1)) * 0.5f + 0.5f;
+    fcp = -sinf(pf * (d - r1)) * pf * 0.5f;
+  } else {
+    fc = 0.0f;
+    fcp = 0.0f;
+  }
+  fp = phip * fc + phi * fcp;
+  f = phi * fc;
+}
+
+} // namespace nepmi

@@ -1,0 +1,226 @@
+// nep.txt parser.  Format: src/force/nep.cu:100-377 of the reference; nep3 header and shared ANN
+// block as accepted by its vendored NEP_CPU (nep.cpp:2568-2872).
+#include "nep_model.h"
+
+#include <cmath>
+#include <cstdlib>
+#include <fstream>
+#include <sstream>
+
+namespace nepmi {
+
+namespace {
+
+const char* const kElements[kMaxTypes] = {
+  "H",  "He", "Li", "Be", "B",  "C",  "N",  "O",  "F",  "Ne", "Na", "Mg", "Al", "Si", "P",  "S",
+  "Cl", "Ar", "K",  "Ca", "Sc", "Ti", "V",  "Cr", "Mn", "Fe", "Co", "Ni", "Cu", "Zn", "Ga", "Ge",
+  "As", "Se", "Br", "Kr", "Rb", "Sr", "Y",  "Zr", "Nb", "Mo", "Tc", "Ru", "Rh", "Pd", "Ag", "Cd",
+  "In", "Sn", "Sb", "Te", "I",  "Xe", "Cs", "Ba", "La", "Ce", "Pr", "Nd", "Pm", "Sm", "Eu", "Gd",
+  "Tb", "Dy", "Ho", "Er", "Tm", "Yb", "Lu", "Hf", "Ta", "W",  "Re", "Os", "Ir", "Pt", "Au", "Hg",
+  "Tl", "Pb", "Bi", "Po", "At", "Rn", "Fr", "Ra", "Ac", "Th", "Pa", "U",  "Np", "Pu"};
+
+std::vector<std::string> next_tokens(std::istream& in)
+{
+  std::string line;
+  std::vector<std::string> t;
+  if (!std::getline(in, line))
+    return t;
+  std::istringstream ss(line);
+  std::string w;
+  while (ss >> w)
+    t.push_back(w);
+  return t;
+}
+
+bool starts_with(const std::string& s, const char* p) { return s.rfind(p, 0) == 0; }
+
+} // namespace
+
+std::string load_nep_model(const std::string& path, NepModel& m, bool* unsupported)
+{
+  if (unsupported)
+    *unsupported = false;
+  auto unsup = [&](const std::string& msg) {
+    if (unsupported)
+      *unsupported = true;
+    return msg;
+  };
+  std::ifstream in(path);
+  if (!in)
+    return "Failed to open " + path + ".";
+
+  auto tok = next_tokens(in);
+  if (tok.size() < 3)
+    return "The first line of nep.txt should have at least 3 items.";
+  const std::string& head = tok[0];
+  // header: nep{3,4,5}[_zbl]; every other suffix (charge, dipole, polarizability, temperature)
+  // is a different model_type in the reference (nep.cu:113-143) and outside this engine.
+  if (head == "nep3" || head == "nep3_zbl")
+    m.version = 3;
+  else if (head == "nep4" || head == "nep4_zbl")
+    m.version = 4;
+  else if (head == "nep5" || head == "nep5_zbl")
+    m.version = 5;
+  else if (starts_with(head, "nep"))
+    return unsup(head + " is a NEP variant outside this engine (only potential models nep3/4/5[_zbl]).");
+  else
+    return head + " is an unsupported NEP model.";
+  m.zbl_enabled = head.size() > 4;
+  m.num_types = std::atoi(tok[1].c_str());
+  if (m.num_types < 1 || m.num_types > kMaxTypes || (int)tok.size() != 2 + m.num_types)
+    return "The first line of nep.txt should have " + std::to_string(m.num_types) + " atom symbols.";
+  const int T = m.num_types;
+  m.symbols.assign(tok.begin() + 2, tok.end());
+  m.atomic_numbers.assign(T, 0);
+  for (int t = 0; t < T; ++t)
+    for (int e = 0; e < kMaxTypes; ++e)
+      if (m.symbols[t] == kElements[e])
+        m.atomic_numbers[t] = e + 1;
+
+  if (m.zbl_enabled) {
+    tok = next_tokens(in);
+    if (tok.size() != 3 && tok.size() != 4)
+      return "This line should be zbl rc_inner rc_outer [zbl_factor].";
+    m.zbl_rc_inner = std::atof(tok[1].c_str());
+    m.zbl_rc_outer = std::atof(tok[2].c_str());
+    if (m.zbl_rc_inner == 0 && m.zbl_rc_outer == 0)
+      m.zbl_flexible = true;
+    else if (tok.size() == 4)
+      return unsup("type-wise ZBL cutoff factor is not supported by this engine.");
+  }
+
+  tok = next_tokens(in);
+  if (tok.empty() || tok[0] != "cutoff" || ((int)tok.size() != 5 && (int)tok.size() != 2 * T + 3))
+    return "cutoff should have 4 or num_types * 2 + 2 parameters.";
+  m.rc_radial.assign(T, 0.0);
+  m.rc_angular.assign(T, 0.0);
+  for (int t = 0; t < T; ++t) {
+    const bool per_type = tok.size() != 5;
+    m.rc_radial[t] = std::atof(tok[per_type ? 1 + 2 * t : 1].c_str());
+    m.rc_angular[t] = std::atof(tok[per_type ? 2 + 2 * t : 2].c_str());
+    m.rc_radial_max = std::max(m.rc_radial_max, m.rc_radial[t]);
+    m.rc_angular_max = std::max(m.rc_angular_max, m.rc_angular[t]);
+    if (m.rc_angular[t] > m.rc_radial[t])
+      return "angular cutoff should not be larger than radial cutoff.";
+  }
+  m.MN_radial = (int)std::ceil(std::atoi(tok[tok.size() - 2].c_str()) * 1.25);
+  m.MN_angular = (int)std::ceil(std::atoi(tok[tok.size() - 1].c_str()) * 1.25);
+
+  tok = next_tokens(in);
+  if (tok.size() != 3 || tok[0] != "n_max")
+    return "This line should be n_max n_max_radial n_max_angular.";
+  m.n_max_radial = std::atoi(tok[1].c_str());
+  m.n_max_angular = std::atoi(tok[2].c_str());
+  tok = next_tokens(in);
+  if (tok.size() != 3 || tok[0] != "basis_size")
+    return "This line should be basis_size basis_size_radial basis_size_angular.";
+  m.basis_size_radial = std::atoi(tok[1].c_str());
+  m.basis_size_angular = std::atoi(tok[2].c_str());
+  tok = next_tokens(in);
+  if (tok.size() < 4 || tok[0] != "l_max")
+    return "This line should be l_max l_max_3body has_q_222 has_q_1111 [...].";
+  m.L_max = std::atoi(tok[1].c_str());
+  m.has_q_222 = std::atoi(tok[2].c_str()) != 0;
+  m.has_q_1111 = std::atoi(tok[3].c_str()) != 0;
+  for (size_t k = 4; k < tok.size(); ++k)
+    if (std::atoi(tok[k].c_str()) != 0)
+      return unsup("extra 4-body invariants (112/123/233/134) are not supported by this engine.");
+  if (m.L_max != 4)
+    return unsup("only l_max = 4 models are supported by this engine.");
+  m.num_L = m.L_max + m.has_q_222 + m.has_q_1111;
+  tok = next_tokens(in);
+  if (tok.size() != 3 || tok[0] != "ANN")
+    return "This line should be ANN num_neurons 0.";
+  m.num_neurons = std::atoi(tok[1].c_str());
+  if (m.n_max_radial < 0 || m.n_max_radial > 19 || m.n_max_angular < 0 || m.n_max_angular > 19 ||
+      m.basis_size_radial < 0 || m.basis_size_radial > 19 || m.basis_size_angular < 0 ||
+      m.basis_size_angular > 19 || m.num_neurons < 1 || m.num_neurons > 200)
+    return "n_max / basis_size / num_neurons out of range.";
+  const int nR1 = m.n_max_radial + 1, nA1 = m.n_max_angular + 1;
+  const int kR1 = m.basis_size_radial + 1, kA1 = m.basis_size_angular + 1;
+  m.dim = nR1 + nA1 * m.num_L;
+
+  const int per_type = (m.dim + 2) * m.num_neurons;
+  if (m.version == 3)
+    m.num_para_ann = per_type + 1;
+  else if (m.version == 4)
+    m.num_para_ann = per_type * T + 1;
+  else
+    m.num_para_ann = (per_type + 1) * T + 1;
+  m.num_c_radial = T * T * nR1 * kR1;
+  m.num_para = m.num_para_ann + m.num_c_radial + T * T * nA1 * kA1;
+
+  m.params.resize((size_t)m.num_para + m.dim);
+  for (size_t k = 0; k < m.params.size(); ++k) {
+    tok = next_tokens(in);
+    if (tok.empty())
+      return "nep.txt ends after " + std::to_string(k) + " of " + std::to_string(m.params.size()) + " parameters.";
+    m.params[k] = std::atof(tok[0].c_str());
+  }
+  if (m.zbl_flexible) {
+    m.zbl_para.resize(10 * (size_t)(T * (T + 1) / 2));
+    for (size_t k = 0; k < m.zbl_para.size(); ++k) {
+      tok = next_tokens(in);
+      if (tok.empty())
+        return "missing flexible-ZBL parameters.";
+      m.zbl_para[k] = std::atof(tok[0].c_str());
+    }
+  }
+
+  // ---- single-precision tables.  The reference stores float(parsed value) (nep.cu:353-357). ----
+  const int nn = m.num_neurons, dim = m.dim;
+  m.w0.resize((size_t)T * nn * dim);
+  m.b0.resize((size_t)T * nn);
+  m.w1.resize((size_t)T * nn);
+  m.b1t.assign(T, 0.0f);
+  size_t off = 0;
+  for (int t = 0; t < T; ++t) {
+    if (t > 0 && m.version == 3)
+      off = 0; // one ANN block shared by every type
+    for (int k = 0; k < nn * dim; ++k)
+      m.w0[(size_t)t * nn * dim + k] = (float)m.params[off + k];
+    off += (size_t)nn * dim;
+    for (int k = 0; k < nn; ++k)
+      m.b0[(size_t)t * nn + k] = (float)m.params[off + k];
+    off += nn;
+    for (int k = 0; k < nn; ++k)
+      m.w1[(size_t)t * nn + k] = (float)m.params[off + k];
+    off += nn;
+    if (m.version == 5)
+      m.b1t[t] = (float)m.params[off++];
+  }
+  m.b1 = (float)m.params[off++];
+  if ((int)off != m.num_para_ann)
+    return "internal error: ANN layout mismatch.";
+
+  // descriptor coefficients: file index (n*(K+1)+k)*T*T + t1*T + t2, radial block then angular.
+  m.c_rad.resize((size_t)T * T * nR1 * kR1);
+  m.c_ang.resize((size_t)T * T * nA1 * kA1);
+  const double* c = m.params.data() + m.num_para_ann;
+  for (int t1 = 0; t1 < T; ++t1)
+    for (int t2 = 0; t2 < T; ++t2) {
+      const int pair = t1 * T + t2;
+      for (int n = 0; n < nR1; ++n)
+        for (int k = 0; k < kR1; ++k)
+          m.c_rad[((size_t)pair * nR1 + n) * kR1 + k] = (float)c[(size_t)(n * kR1 + k) * T * T + pair];
+      for (int n = 0; n < nA1; ++n)
+        for (int k = 0; k < kA1; ++k)
+          m.c_ang[((size_t)pair * nA1 + n) * kA1 + k] =
+            (float)c[m.num_c_radial + (size_t)(n * kA1 + k) * T * T + pair];
+    }
+  m.q_scaler.resize(dim);
+  for (int d = 0; d < dim; ++d)
+    m.q_scaler[d] = (float)m.params[(size_t)m.num_para + d];
+  m.rc_radial_f.resize(T);
+  m.rc_angular_f.resize(T);
+  for (int t = 0; t < T; ++t) {
+    m.rc_radial_f[t] = (float)m.rc_radial[t];
+    m.rc_angular_f[t] = (float)m.rc_angular[t];
+  }
+  m.zbl_para_f.resize(m.zbl_para.size());
+  for (size_t k = 0; k < m.zbl_para.size(); ++k)
+    m.zbl_para_f[k] = (float)m.zbl_para[k];
+  return "";
+}
+
+} // namespace nepmi

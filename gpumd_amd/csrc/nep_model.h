@@ -1,0 +1,45 @@
+// nep.txt -> host-side model description.
+// Follows the file format consumed by the reference's NEP::NEP (src/force/nep.cu:100-377) and the
+// nep3 conventions of its vendored NEP_CPU (tools/.../for_perioidc_table/nep.cpp:2568-2872).
+#pragma once
+#include <string>
+#include <vector>
+
+namespace nepmi {
+
+constexpr int kMaxTypes = 94;
+
+struct NepModel {
+  int version = 0; // 3, 4, 5
+  bool zbl_enabled = false, zbl_flexible = false;
+  double zbl_rc_inner = 0, zbl_rc_outer = 0;
+  int num_types = 0;
+  std::vector<std::string> symbols;
+  std::vector<int> atomic_numbers;
+  std::vector<double> rc_radial, rc_angular; // per type
+  double rc_radial_max = 0, rc_angular_max = 0;
+  int MN_radial = 0, MN_angular = 0; // enlarged by 1.25 (nep.cu:234-235)
+  int n_max_radial = 0, n_max_angular = 0, basis_size_radial = 0, basis_size_angular = 0;
+  int L_max = 0, has_q_222 = 0, has_q_1111 = 0, num_L = 0, dim = 0, num_neurons = 0;
+  int num_para_ann = 0, num_para = 0, num_c_radial = 0;
+
+  // raw parameters in file order (ANN, descriptor c, then q_scaler[dim])
+  std::vector<double> params;
+  std::vector<double> zbl_para; // 10 per unordered type pair (flexible ZBL only)
+
+  // --- re-laid-out single-precision tables (what the device consumes) ---
+  // c_rad[(t1*T+t2)][n][k], c_ang likewise  (nep.cu:75-98 re-layout)
+  std::vector<float> c_rad, c_ang;
+  // per type: w0[neuron][dim], b0[neuron], w1[neuron], b1t (nep5 per-type output bias, else 0)
+  std::vector<float> w0, b0, w1, b1t;
+  float b1 = 0.0f;
+  std::vector<float> q_scaler;
+  std::vector<float> rc_radial_f, rc_angular_f;
+  std::vector<float> zbl_para_f;
+};
+
+// returns empty string on success, else the error text; *unsupported is set when the file is a
+// valid NEP model that this engine does not cover (charge/dipole variants, extra invariants...).
+std::string load_nep_model(const std::string& path, NepModel& m, bool* unsupported);
+
+} // namespace nepmi

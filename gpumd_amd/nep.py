@@ -1,0 +1,160 @@
+"""Host-side mirror of the reference's NEP potential object (src/force/nep.cuh `class NEP :
+public Potential`) on top of the C ABI.  Arrays are torch CUDA tensors in GPUMD's SoA layout:
+
+    position/velocity/force : float64 [3*N]  (x.. | y.. | z..)
+    virial                  : float64 [9*N]  planes xx,yy,zz,xy,xz,yz,yx,zx,zy
+    potential               : float64 [N];  type: int32 [N];  mass: float64 [N]
+    box                     : 9 host floats ax,bx,cx,ay,by,cy,az,bz,cz (Box::cpu_h[0..8])
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi
+
+
+def _h9(box):
+    h = np.ascontiguousarray(np.asarray(box, dtype=np.float64).reshape(9))
+    return h, h.ctypes.data_as(_capi.c_dp)
+
+
+def _pbc3(pbc):
+    p = np.ascontiguousarray(np.asarray(pbc, dtype=np.int32).reshape(3))
+    return p, p.ctypes.data_as(_capi.c_ip)
+
+
+class Model:
+    """Parsed nep.txt (host only; mirrors the parsing half of NEP::NEP, nep.cu:100-377)."""
+
+    def __init__(self, path, lib=None):
+        from . import load_library
+        self.lib = lib if lib is not None else load_library()
+        self.path = path
+        self.handle = self.lib.nepmi_model_load(path.encode())
+        if not self.handle:
+            raise _capi.NepmiError(-2, self.lib.nepmi_last_error().decode())
+        self.info = _capi.NepmiInfo()
+        _capi.check(self.lib, self.lib.nepmi_model_info(self.handle, C.byref(self.info)))
+        self.symbols = [self.lib.nepmi_model_symbol(self.handle, t).decode() for t in range(self.info.num_types)]
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.nepmi_model_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        self.close()
+
+
+class NEP:
+    """One NEP potential instance bound to `n_atoms` atoms on the current HIP device.
+
+    `compute(box, type, position, potential, force, virial)` has the argument meaning of
+    Potential::compute (src/force/potential.cuh:37-43): it ADDS to the three output arrays.
+    `force_compute` is Force::compute (force.cu:771-855): wrap, zero, compute.
+    """
+
+    def __init__(self, model, n_atoms, stream=None, pbc=(1, 1, 1), lib=None):
+        import torch
+        if isinstance(model, str):
+            model = Model(model, lib=lib)
+        self.model = model
+        self.lib = model.lib
+        if lib is None:
+            if not torch.cuda.is_available():
+                raise RuntimeError("gpumd_amd.NEP needs an MI355X (gfx950) device; there is no CPU fallback")
+        self.n = int(n_atoms)
+        self.pbc = tuple(int(p) for p in pbc)
+        self._stream = stream
+        sp = None
+        if stream is not None:
+            sp = C.c_void_p(stream.cuda_stream)
+        elif lib is None:
+            sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        self.handle = self.lib.nepmi_engine_create(model.handle, self.n, sp)
+        if not self.handle:
+            raise _capi.NepmiError(-5, self.lib.nepmi_last_error().decode())
+
+    # -- helpers -------------------------------------------------------------------------------
+    @staticmethod
+    def _ptr(t):
+        if t is None:
+            return None
+        if hasattr(t, "data_ptr"):
+            return C.c_void_p(t.data_ptr())
+        return C.c_void_p(t.ctypes.data)  # numpy (emulator tests only)
+
+    def _ck(self, st):
+        return _capi.check(self.lib, st)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.nepmi_engine_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        self.close()
+
+    # -- the plugin surface --------------------------------------------------------------------
+    def compute(self, box, type, position, potential, force, virial):
+        _, hp = _h9(box)
+        _, pp = _pbc3(self.pbc)
+        self._ck(self.lib.nepmi_potential_compute(
+            self.handle, hp, pp, self.n, self._ptr(type), self._ptr(position), self._ptr(potential),
+            self._ptr(force), self._ptr(virial)))
+
+    def force_compute(self, box, type, position, potential, force, virial):
+        _, hp = _h9(box)
+        _, pp = _pbc3(self.pbc)
+        self._ck(self.lib.nepmi_force_compute(
+            self.handle, hp, pp, self.n, self._ptr(type), self._ptr(position), self._ptr(potential),
+            self._ptr(force), self._ptr(virial)))
+
+    def apply_pbc(self, box, position):
+        _, hp = _h9(box)
+        _, pp = _pbc3(self.pbc)
+        self._ck(self.lib.nepmi_apply_pbc(self.handle, hp, pp, self.n, self._ptr(position)))
+
+    def vv_step1(self, dt, mass, force, position, velocity):
+        self._ck(self.lib.nepmi_vv_step1(self.handle, self.n, float(dt), self._ptr(mass), self._ptr(force),
+                                         self._ptr(position), self._ptr(velocity)))
+
+    def vv_step2(self, dt, mass, force, velocity):
+        self._ck(self.lib.nepmi_vv_step2(self.handle, self.n, float(dt), self._ptr(mass), self._ptr(force),
+                                         self._ptr(velocity)))
+
+    def find_thermo(self, volume, mass, potential, velocity, virial, thermo8):
+        self._ck(self.lib.nepmi_find_thermo(self.handle, self.n, float(volume), self._ptr(mass),
+                                            self._ptr(potential), self._ptr(velocity), self._ptr(virial),
+                                            self._ptr(thermo8)))
+
+    def run_nve(self, box, type, mass, dt, nsteps, position, velocity, potential, force, virial,
+                thermo_every=0):
+        """Run::perform_a_run for `ensemble nve` -> thermo array [(nsteps // thermo_every), 8] (host)."""
+        _, hp = _h9(box)
+        _, pp = _pbc3(self.pbc)
+        nrec = (nsteps // thermo_every) if thermo_every > 0 else 0
+        th = np.zeros((max(nrec, 1), 8))
+        self._ck(self.lib.nepmi_run_nve(
+            self.handle, hp, pp, self.n, self._ptr(type), self._ptr(mass), float(dt), int(nsteps),
+            self._ptr(position), self._ptr(velocity), self._ptr(potential), self._ptr(force),
+            self._ptr(virial), int(thermo_every), th.ctypes.data_as(_capi.c_dp)))
+        return th[:nrec]
+
+    # -- diagnostics ---------------------------------------------------------------------------
+    def neighbors(self, which, nn, nl, ld):
+        return self._ck(self.lib.nepmi_neighbors_export(self.handle, int(which), self._ptr(nn), self._ptr(nl), int(ld)))
+
+    def descriptors(self, q, fp):
+        self._ck(self.lib.nepmi_descriptors_export(self.handle, self._ptr(q), self._ptr(fp)))
+
+    def stats(self, with_lists=False):
+        st = _capi.NepmiStats()
+        self._ck(self.lib.nepmi_engine_stats(self.handle, 1 if with_lists else 0, C.byref(st)))
+        return st
+
+    def set_timing(self, on=True):
+        self._ck(self.lib.nepmi_engine_set_timing(self.handle, 1 if on else 0))
+
+    def set_generic(self, on=True):
+        self._ck(self.lib.nepmi_engine_set_generic(self.handle, 1 if on else 0))

@@ -1,0 +1,160 @@
+/* nepmi.h -- C ABI of libnepmi.so, the MI355X (gfx950) NEP force engine + velocity-Verlet path.
+ *
+ * This is the drop-in boundary for GPUMD's per-step force path.  The reference has no FFI: the
+ * boundary there is the C++ virtual interface Potential::compute / Force::compute operating on
+ * device arrays (GPU_Vector<T>::data()).  Each entry point below names the reference interface
+ * it replaces (paths relative to the reference tree, file:line).  INTEGRATION.md shows the
+ * `class NEP_MI : public Potential` adaptor a GPUMD maintainer would add on top of these calls.
+ *
+ * Conventions (identical to the reference's, src/model/atom.cuh:32-42, src/force/force.cu:568-571):
+ *   - every `double*` / `int*` named pos/vel/force/pe/virial/type/mass is a DEVICE pointer on the
+ *     current HIP device, owned by the caller, SoA in the caller's atom order:
+ *       pos/vel/force  [x0..xN-1 | y0..yN-1 | z0..zN-1]          (3N doubles)
+ *       virial         9 planes xx,yy,zz,xy,xz,yz,yx,zx,zy        (9N doubles)
+ *       pe             N doubles;  type N ints;  mass N doubles
+ *   - units eV, Angstrom, amu; time in GPUMD's natural unit (fs / 10.18051).
+ *   - box h[9] is the HOST array Box::cpu_h[0..8] = ax,bx,cx,ay,by,cy,az,bz,cz
+ *     (lattice vectors are the columns; src/model/read_xyz.cu:208-216); pbc[3] host ints.
+ *   - all calls are asynchronous on the engine's stream unless stated; single host thread per
+ *     engine (like the reference), several engines (one per GPU / process) may coexist.
+ *   - return value 0 on success, negative nepmi_status on error; nepmi_last_error() gives the text.
+ *     (The reference exits the process on error, src/utilities/error.cuh:23-63; the adaptor in
+ *     INTEGRATION.md restores that behaviour with one macro.)
+ *   - no torch / STL / HIP types in any signature: plain pointers and sizes only.  The stream is
+ *     passed as void* (a hipStream_t); NULL means the default stream.
+ */
+#ifndef NEPMI_H
+#define NEPMI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NEPMI_VERSION 100
+
+typedef enum {
+  NEPMI_OK = 0,
+  NEPMI_ERR_IO = -1,          /* cannot open / short file */
+  NEPMI_ERR_FORMAT = -2,      /* nep.txt violates the format of src/force/nep.cu:100-377 */
+  NEPMI_ERR_UNSUPPORTED = -3, /* valid model/box outside this engine's envelope */
+  NEPMI_ERR_ARG = -4,
+  NEPMI_ERR_HIP = -5,         /* HIP runtime error or no gfx950 device */
+  NEPMI_ERR_CAPACITY = -6,    /* a neighbour list exceeded its MN capacity (the reference corrupts
+                                 memory silently here, src/force/nep.cu:234-235,1014-1034) */
+  NEPMI_ERR_SMALL_BOX = -7    /* a periodic thickness <= 2.5*(rc+skin): reference takes
+                                 nep_small_box.cuh; not implemented on the device yet */
+} nepmi_status;
+
+typedef struct nepmi_model nepmi_model;   /* parsed nep.txt (host)            */
+typedef struct nepmi_engine nepmi_engine; /* device state of one potential    */
+
+/* Mirrors what NEP::NEP prints / keeps in ParaMB + ANN (src/force/nep.cuh, nep.cu:100-395). */
+typedef struct {
+  int version;     /* 3, 4, 5 */
+  int num_types;
+  int zbl_enabled, zbl_flexible;
+  double zbl_rc_inner, zbl_rc_outer;
+  double rc_radial, rc_angular; /* maxima over types */
+  int MN_radial, MN_angular;    /* already enlarged by 1.25 (nep.cu:234-235) */
+  int n_max_radial, n_max_angular;
+  int basis_size_radial, basis_size_angular;
+  int L_max, has_q_222, has_q_1111, num_L;
+  int dim, num_neurons;
+  int num_para; /* ANN + descriptor parameters, without q_scaler */
+} nepmi_info;
+
+const char* nepmi_last_error(void);
+int nepmi_version(void);
+
+/* ---- model: replaces NEP::NEP(const char* file_potential, int num_atoms) parsing half,
+ *      src/force/nep.cu:100-377 + update_potential :402-434.  Host only, no GPU needed. ---- */
+nepmi_model* nepmi_model_load(const char* nep_txt_path);
+void nepmi_model_free(nepmi_model* m);
+int nepmi_model_info(const nepmi_model* m, nepmi_info* out);
+const char* nepmi_model_symbol(const nepmi_model* m, int type); /* element symbol of a type */
+
+/* ---- engine: replaces the allocation half of NEP::NEP (nep.cu:379-391) + Neighbor
+ *      (src/force/neighbor.cu:802-833).  n_atoms is fixed for the life of the engine. ---- */
+nepmi_engine* nepmi_engine_create(const nepmi_model* m, int64_t n_atoms, void* hip_stream);
+void nepmi_engine_destroy(nepmi_engine* e);
+
+/* ---- Force::compute, src/force/force.cu:771-855 (gpu_apply_pbc :424-459,
+ *      initialize_properties :314-333, then potentials[0]->compute): wraps pos in place, zeroes
+ *      pe/force/virial, adds the NEP contribution. ---- */
+int nepmi_force_compute(
+  nepmi_engine* e, const double h[9], const int pbc[3], int64_t n, const int* type, double* pos,
+  double* pe, double* force, double* virial);
+
+/* ---- Potential::compute == NEP::compute, src/force/nep.cu:1356-1389 (large-box branch
+ *      :996-1137): ADDS to pe/force/virial, expects wrapped positions, applies the Verlet-skin
+ *      policy of Neighbor::find_neighbor_global (neighbor.cu:741-800) internally. ---- */
+int nepmi_potential_compute(
+  nepmi_engine* e, const double h[9], const int pbc[3], int64_t n, const int* type,
+  const double* pos, double* pe, double* force, double* virial);
+
+/* gpu_apply_pbc (force.cu:424-459) and initialize_properties (force.cu:314-333) on their own. */
+int nepmi_apply_pbc(nepmi_engine* e, const double h[9], const int pbc[3], int64_t n, double* pos);
+int nepmi_zero_properties(nepmi_engine* e, int64_t n, double* pe, double* force, double* virial);
+
+/* ---- Ensemble::velocity_verlet, src/integrate/ensemble.cu:176-214,348-397
+ *      (Ensemble_NVE::compute1/compute2, ensemble_nve.cu:31-95).  dt in natural units. ---- */
+int nepmi_vv_step1(
+  nepmi_engine* e, int64_t n, double dt, const double* mass, const double* force, double* pos,
+  double* vel);
+int nepmi_vv_step2(
+  nepmi_engine* e, int64_t n, double dt, const double* mass, const double* force, double* vel);
+
+/* ---- Ensemble::find_thermo, ensemble.cu:434-673: thermo8 (DEVICE, 8 doubles) =
+ *      T, U, sxx, syy, szz, sxy, sxz, syz   (stress = (sum virial + sum m v v) / volume). ---- */
+int nepmi_find_thermo(
+  nepmi_engine* e, int64_t n, double volume, const double* mass, const double* pe,
+  const double* vel, const double* virial, double* thermo8);
+
+/* ---- fused NVE loop == Run::perform_a_run restricted to `ensemble nve`
+ *      (src/main_gpumd/run.cu:250-318): nsteps x { vv1, Force::compute, vv2, find_thermo }.
+ *      thermo_host (HOST, 8 doubles per recorded step) receives find_thermo's output every
+ *      `thermo_every` steps (0 = never); returns after the last step has finished.  The caller's
+ *      device arrays hold the final state in the caller's atom order. ---- */
+int nepmi_run_nve(
+  nepmi_engine* e, const double h[9], const int pbc[3], int64_t n, const int* type,
+  const double* mass, double dt, int64_t nsteps, double* pos, double* vel, double* pe,
+  double* force, double* virial, int64_t thermo_every, double* thermo_host);
+
+/* ---- diagnostics / parity hooks ---- */
+
+/* Per-step radial (which = 0) / angular (which = 1) neighbour lists of the LAST compute, in the
+ * caller's atom indices, ascending, column-major nl[slot*n + atom] with ld slots: the contents
+ * of NEP_Data::NN_radial/NL_radial/NN_angular/NL_angular (nep.cuh) after
+ * find_neighbor_list_large_box (nep.cu:436-486).  which = 2: the Verlet-skin list
+ * (Neighbor::NN/NL, neighbor.cu:85-162).  nn and nl are DEVICE pointers.  Returns the largest
+ * count, or a negative status. */
+int nepmi_neighbors_export(nepmi_engine* e, int which, int* nn, int* nl, int64_t ld);
+
+/* Descriptor q (scaled by q_scaler) and Fp = dU/dq * q_scaler of the last compute; DEVICE float
+ * arrays [dim][n] in caller order (NEP_Data::Fp layout, nep.cu:655-657).  Either may be NULL. */
+int nepmi_descriptors_export(nepmi_engine* e, float* q, float* fp);
+
+typedef struct {
+  int64_t num_compute;   /* calls of potential_compute               */
+  int64_t num_rebuild;   /* Verlet-list rebuilds (neighbor.cu:741-800) */
+  int max_nn_skin, max_nn_radial, max_nn_angular; /* what neighbor.out reports, nep.cu:1014-1034 */
+  double mean_nn_radial, mean_nn_angular;         /* measured means of the last compute */
+  double ms_force_last;  /* HIP-event time of the last force evaluation (all force kernels)   */
+  double ms_kernel[8];   /* last launch of: 0 gather/skin-check, 1 radial descriptor, 2 angular
+                            descriptor, 3 ANN, 4 angular partial force, 5 force assembly,
+                            6 velocity-Verlet, 7 list rebuild (whole) */
+} nepmi_stats;
+/* Synchronises the stream.  with_lists != 0 also recounts the per-step list lengths. */
+int nepmi_engine_stats(nepmi_engine* e, int with_lists, nepmi_stats* out);
+/* Enable per-kernel HIP-event timing (adds event records on the engine's stream). */
+int nepmi_engine_set_timing(nepmi_engine* e, int on);
+/* Force the run-time-shaped (generic) kernel instantiation instead of a model-shape-specialised
+ * one; used by the parity tests to cover both code paths with one model. */
+int nepmi_engine_set_generic(nepmi_engine* e, int on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NEPMI_H */

@@ -1,0 +1,76 @@
+// TEST INFRASTRUCTURE ONLY -- never part of, linked into, or loaded by the product.
+//
+// Kernel-logic emulator: the per-atom kernel bodies of gpumd_amd/csrc/nep_bodies.h and the engine
+// sequencing of engine_impl.h, compiled by g++ and driven by plain host loops, exported through
+// the same C ABI (include/nepmi.h) as tests/emu/libnepmi_emu.so.  Its only purpose is to let the
+// CPU test tier (`pytest -m "not gpu"`, this container has no GPU) check the kernel *logic*
+// against the oracle before the code ever reaches an MI355X.  "Device pointers" are host pointers.
+// The product library (gpumd_amd/lib/libnepmi.so) contains none of this and the gpumd_amd package
+// refuses to run without a gfx950 device.
+#include <cstdlib>
+#include <cstring>
+
+#include "../../gpumd_amd/csrc/nep_bodies.h"
+
+namespace nepmi {
+
+struct HostLoopBackend {
+  void* alloc(size_t bytes) { return std::calloc(1, bytes ? bytes : 1); }
+  void free(void* p) { std::free(p); }
+  void memset(void* p, int v, size_t bytes) { std::memset(p, v, bytes); }
+  void h2d(void* dst, const void* src, size_t bytes) { std::memcpy(dst, src, bytes); }
+  void d2h(void* dst, const void* src, size_t bytes) { std::memcpy(dst, src, bytes); }
+  void sync() {}
+  void begin_region(int) {}
+  void end_region(int) {}
+  double region_ms(int) { return 0.0; }
+  double slot_ms(int) { return 0.0; }
+  void set_timing(bool) {}
+
+  template <int BLOCK, class Body>
+  void launch(int, int64_t n, const Body& body)
+  {
+    for (int64_t i = 0; i < n; ++i)
+      body(i);
+  }
+
+  void exclusive_scan(int* data, int64_t n, int*)
+  {
+    int run = 0;
+    for (int64_t i = 0; i < n; ++i) {
+      const int v = data[i];
+      data[i] = run;
+      run += v;
+    }
+  }
+
+  void thermo(
+    int, int64_t n, double volume, const double* mass, const double* pe, const double* vel,
+    const double* virial, double* th, double*)
+  {
+    double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const double *vx = vel, *vy = vel + n, *vz = vel + 2 * n;
+    for (int64_t i = 0; i < n; ++i) {
+      const double m = mass[i];
+      s[0] += (vx[i] * vx[i] + vy[i] * vy[i] + vz[i] * vz[i]) * m;
+      s[1] += pe[i];
+      s[2] += virial[0 * n + i] + vx[i] * vx[i] * m;
+      s[3] += virial[1 * n + i] + vy[i] * vy[i] * m;
+      s[4] += virial[2 * n + i] + vz[i] * vz[i] * m;
+      s[5] += virial[3 * n + i] + vx[i] * vy[i] * m;
+      s[6] += virial[4 * n + i] + vx[i] * vz[i] * m;
+      s[7] += virial[5 * n + i] + vy[i] * vz[i] * m;
+    }
+    th[0] = s[0] / (3.0 * (double)n * 8.617343e-5);
+    th[1] = s[1];
+    for (int k = 2; k < 8; ++k)
+      th[k] = s[k] / volume;
+  }
+};
+
+} // namespace nepmi
+
+using NepmiBackend = nepmi::HostLoopBackend;
+static NepmiBackend nepmi_make_backend(void*) { return NepmiBackend(); }
+
+#include "../../gpumd_amd/csrc/capi_impl.h"
