@@ -1,0 +1,354 @@
+// libnepmi.so -- gfx950 (MI355X) build of the NEP force engine: HIP backend + C ABI.
+//
+// hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared engine.hip nep_model.cpp -o libnepmi.so
+//
+// All force-path kernels are the per-atom bodies of nep_bodies.h launched through
+// nepmi_kernel<BLOCK, Body>; the block-cooperative kernels (prefix scan of the cell histogram,
+// thermo reduction) live here.  One engine = one HIP stream; no host<->device traffic on the hot
+// path other than the 32-byte flag read-back per force call (the reference's 4-byte skin-check
+// D2H, neighbor.cu:752, extended with overflow flags).
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <stdexcept>
+#include <string>
+
+#include "engine_impl.h"
+
+namespace nepmi {
+
+#define NEPMI_HIP_CHECK(expr)                                                                       \
+  do {                                                                                              \
+    hipError_t err__ = (expr);                                                                      \
+    if (err__ != hipSuccess)                                                                        \
+      throw std::runtime_error(std::string("HIP error: ") + hipGetErrorString(err__) + " at " +     \
+                               __FILE__ + ":" + std::to_string(__LINE__) + " (" #expr ")");         \
+  } while (0)
+
+template <int BLOCK, class Body>
+__global__ void __launch_bounds__(BLOCK) nepmi_kernel(const Body body, const int64_t n)
+{
+  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  if (i < n)
+    body(i);
+}
+
+// ---- exclusive scan of int32, in place: 3 kernels (block scan, scan of block sums, add) ----
+constexpr int kScanBlock = 256;
+constexpr int kScanItems = 8;
+constexpr int kScanTile = kScanBlock * kScanItems;
+
+__device__ __forceinline__ int wave_inclusive_scan(int v, int lane)
+{
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int t = __shfl_up(v, off, 64);
+    if (lane >= off)
+      v += t;
+  }
+  return v;
+}
+
+// block-wide exclusive scan of one value per thread; returns exclusive prefix, *total = block sum
+template <int BLOCK>
+__device__ __forceinline__ int block_exclusive_scan(int v, int* total)
+{
+  __shared__ int wave_sums[BLOCK / 64];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int inc = wave_inclusive_scan(v, lane);
+  if (lane == 63)
+    wave_sums[wid] = inc;
+  __syncthreads();
+  int base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < BLOCK / 64; ++w) {
+    const int s = wave_sums[w];
+    if (w < wid)
+      base += s;
+    tot += s;
+  }
+  __syncthreads();
+  *total = tot;
+  return base + inc - v;
+}
+
+__global__ void __launch_bounds__(kScanBlock) nepmi_scan_tiles(int* data, int64_t n, int* tile_sums)
+{
+  const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+  int v[kScanItems];
+  int sum = 0;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    v[k] = (base + k < n) ? data[base + k] : 0;
+    sum += v[k];
+  }
+  int total;
+  int run = block_exclusive_scan<kScanBlock>(sum, &total);
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k) {
+    if (base + k < n)
+      data[base + k] = run;
+    run += v[k];
+  }
+  if (threadIdx.x == 0)
+    tile_sums[blockIdx.x] = total;
+}
+
+__global__ void __launch_bounds__(1024) nepmi_scan_sums(int* sums, int64_t m)
+{
+  __shared__ int carry;
+  if (threadIdx.x == 0)
+    carry = 0;
+  __syncthreads();
+  for (int64_t start = 0; start < m; start += 1024) {
+    const int64_t i = start + threadIdx.x;
+    const int v = i < m ? sums[i] : 0;
+    int total;
+    const int ex = block_exclusive_scan<1024>(v, &total);
+    const int c = carry;
+    if (i < m)
+      sums[i] = c + ex;
+    __syncthreads();
+    if (threadIdx.x == 0)
+      carry = c + total;
+    __syncthreads();
+  }
+}
+
+__global__ void __launch_bounds__(kScanBlock) nepmi_scan_add(int* data, int64_t n, const int* tile_sums)
+{
+  const int add = tile_sums[blockIdx.x];
+  const int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
+#pragma unroll
+  for (int k = 0; k < kScanItems; ++k)
+    if (base + k < n)
+      data[base + k] += add;
+}
+
+// ---- Ensemble::find_thermo (ensemble.cu:434-673): 8 sums in one pass over the atoms ----
+constexpr int kThermoBlock = 256;
+constexpr int kThermoMaxBlocks = 1024;
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1)
+    v += __shfl_down(v, off, 64);
+  return v;
+}
+
+__global__ void __launch_bounds__(kThermoBlock) nepmi_thermo_partial(
+  int64_t n, const double* __restrict__ mass, const double* __restrict__ pe, const double* __restrict__ vel,
+  const double* __restrict__ virial, double* __restrict__ partial)
+{
+  double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int64_t i = (int64_t)blockIdx.x * kThermoBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThermoBlock) {
+    const double m = mass[i];
+    const double vx = vel[i], vy = vel[n + i], vz = vel[2 * n + i];
+    s[0] += (vx * vx + vy * vy + vz * vz) * m;
+    s[1] += pe[i];
+    s[2] += virial[i] + vx * vx * m;
+    s[3] += virial[n + i] + vy * vy * m;
+    s[4] += virial[2 * n + i] + vz * vz * m;
+    s[5] += virial[3 * n + i] + vx * vy * m;
+    s[6] += virial[4 * n + i] + vx * vz * m;
+    s[7] += virial[5 * n + i] + vy * vz * m;
+  }
+  __shared__ double red[kThermoBlock / 64][8];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const double w = wave_sum(s[q]);
+    if (lane == 0)
+      red[wid][q] = w;
+  }
+  __syncthreads();
+  if (threadIdx.x < 8) {
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < kThermoBlock / 64; ++w)
+      t += red[w][threadIdx.x];
+    partial[(int64_t)blockIdx.x * 8 + threadIdx.x] = t;
+  }
+}
+
+__global__ void __launch_bounds__(64) nepmi_thermo_final(
+  int nblocks, int64_t n, double volume, const double* __restrict__ partial, double* __restrict__ thermo8)
+{
+  // 8 quantities x 8 lanes each; fixed order => deterministic
+  const int q = threadIdx.x >> 3, sub = threadIdx.x & 7;
+  double t = 0.0;
+  for (int b = sub; b < nblocks; b += 8)
+    t += partial[(int64_t)b * 8 + q];
+  t += __shfl_down(t, 4, 8);
+  t += __shfl_down(t, 2, 8);
+  t += __shfl_down(t, 1, 8);
+  if (sub == 0) {
+    if (q == 0)
+      thermo8[0] = t / (3.0 * (double)n * 8.617343e-5); // K_B, src/utilities/common.cuh:22
+    else if (q == 1)
+      thermo8[1] = t;
+    else
+      thermo8[q] = t / volume;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+
+struct HipTiming {
+  hipEvent_t slot_start[16], slot_stop[16];
+  hipEvent_t reg_start[4], reg_stop[4];
+  bool slot_used[16], reg_used[4];
+  bool created = false;
+};
+
+struct HipBackend {
+  hipStream_t stream = nullptr;
+  HipTiming* timing = nullptr; // shared by copies of the backend
+  int* pinned = nullptr;       // 64-byte pinned staging for flag read-back
+  bool timing_on = false;
+
+  void* alloc(size_t bytes)
+  {
+    void* p = nullptr;
+    NEPMI_HIP_CHECK(hipMalloc(&p, bytes ? bytes : 1));
+    return p;
+  }
+  void free(void* p) { (void)hipFree(p); }
+  void memset(void* p, int v, size_t bytes) { NEPMI_HIP_CHECK(hipMemsetAsync(p, v, bytes, stream)); }
+  void h2d(void* dst, const void* src, size_t bytes)
+  {
+    NEPMI_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream));
+    NEPMI_HIP_CHECK(hipStreamSynchronize(stream));
+  }
+  void d2h(void* dst, const void* src, size_t bytes)
+  {
+    if (bytes <= 64 && pinned) {
+      NEPMI_HIP_CHECK(hipMemcpyAsync(pinned, src, bytes, hipMemcpyDeviceToHost, stream));
+      NEPMI_HIP_CHECK(hipStreamSynchronize(stream));
+      std::memcpy(dst, pinned, bytes);
+    } else {
+      NEPMI_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, stream));
+      NEPMI_HIP_CHECK(hipStreamSynchronize(stream));
+    }
+  }
+  void sync() { NEPMI_HIP_CHECK(hipStreamSynchronize(stream)); }
+
+  void set_timing(bool on)
+  {
+    if (on && !timing->created) {
+      for (int k = 0; k < 16; ++k) {
+        NEPMI_HIP_CHECK(hipEventCreate(&timing->slot_start[k]));
+        NEPMI_HIP_CHECK(hipEventCreate(&timing->slot_stop[k]));
+        timing->slot_used[k] = false;
+      }
+      for (int k = 0; k < 4; ++k) {
+        NEPMI_HIP_CHECK(hipEventCreate(&timing->reg_start[k]));
+        NEPMI_HIP_CHECK(hipEventCreate(&timing->reg_stop[k]));
+        timing->reg_used[k] = false;
+      }
+      timing->created = true;
+    }
+    timing_on = on;
+  }
+  void begin_region(int r)
+  {
+    if (timing_on) {
+      NEPMI_HIP_CHECK(hipEventRecord(timing->reg_start[r], stream));
+    }
+  }
+  void end_region(int r)
+  {
+    if (timing_on) {
+      NEPMI_HIP_CHECK(hipEventRecord(timing->reg_stop[r], stream));
+      timing->reg_used[r] = true;
+    }
+  }
+  double region_ms(int r)
+  {
+    if (!timing->created || !timing->reg_used[r])
+      return 0.0;
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, timing->reg_start[r], timing->reg_stop[r]) != hipSuccess)
+      return 0.0;
+    return ms;
+  }
+  double slot_ms(int s)
+  {
+    if (!timing->created || !timing->slot_used[s])
+      return 0.0;
+    float ms = 0.0f;
+    if (hipEventElapsedTime(&ms, timing->slot_start[s], timing->slot_stop[s]) != hipSuccess)
+      return 0.0;
+    return ms;
+  }
+
+  template <int BLOCK, class Body>
+  void launch(int slot, int64_t n, const Body& body)
+  {
+    if (n <= 0)
+      return;
+    const int64_t grid = (n + BLOCK - 1) / BLOCK;
+    const bool t = timing_on && slot != 9; // kSlotMisc is not timed
+    if (t)
+      NEPMI_HIP_CHECK(hipEventRecord(timing->slot_start[slot], stream));
+    hipLaunchKernelGGL((nepmi_kernel<BLOCK, Body>), dim3((unsigned)grid), dim3(BLOCK), 0, stream, body, n);
+    NEPMI_HIP_CHECK(hipGetLastError());
+    if (t) {
+      NEPMI_HIP_CHECK(hipEventRecord(timing->slot_stop[slot], stream));
+      timing->slot_used[slot] = true;
+    }
+  }
+
+  void exclusive_scan(int* data, int64_t n, int* scratch)
+  {
+    const int64_t tiles = (n + kScanTile - 1) / kScanTile;
+    hipLaunchKernelGGL(nepmi_scan_tiles, dim3((unsigned)tiles), dim3(kScanBlock), 0, stream, data, n, scratch);
+    NEPMI_HIP_CHECK(hipGetLastError());
+    if (tiles > 1) {
+      hipLaunchKernelGGL(nepmi_scan_sums, dim3(1), dim3(1024), 0, stream, scratch, tiles);
+      hipLaunchKernelGGL(nepmi_scan_add, dim3((unsigned)tiles), dim3(kScanBlock), 0, stream, data, n, scratch);
+      NEPMI_HIP_CHECK(hipGetLastError());
+    }
+  }
+
+  void thermo(
+    int slot, int64_t n, double volume, const double* mass, const double* pe, const double* vel,
+    const double* virial, double* thermo8, double* scratch)
+  {
+    int64_t nb = (n + kThermoBlock - 1) / kThermoBlock;
+    if (nb > kThermoMaxBlocks)
+      nb = kThermoMaxBlocks;
+    hipLaunchKernelGGL(
+      nepmi_thermo_partial, dim3((unsigned)nb), dim3(kThermoBlock), 0, stream, n, mass, pe, vel, virial, scratch);
+    hipLaunchKernelGGL(nepmi_thermo_final, dim3(1), dim3(64), 0, stream, (int)nb, n, volume, scratch, thermo8);
+    NEPMI_HIP_CHECK(hipGetLastError());
+    (void)slot;
+  }
+};
+
+} // namespace nepmi
+
+using NepmiBackend = nepmi::HipBackend;
+
+static NepmiBackend nepmi_make_backend(void* stream)
+{
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count < 1)
+    throw nepmi::EngineError{-5, "no HIP device visible: libnepmi.so needs an MI355X (gfx950); there is no CPU path"};
+  int dev = 0;
+  NEPMI_HIP_CHECK(hipGetDevice(&dev));
+  hipDeviceProp_t prop;
+  NEPMI_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+  if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+    throw nepmi::EngineError{-5, std::string("device is ") + prop.gcnArchName + ", this library carries gfx950 code only"};
+  NepmiBackend b;
+  b.stream = (hipStream_t)stream;
+  b.timing = new nepmi::HipTiming();
+  void* p = nullptr;
+  NEPMI_HIP_CHECK(hipHostMalloc(&p, 64, hipHostMallocDefault));
+  b.pinned = (int*)p;
+  return b;
+}
+
+#include "capi_impl.h"

@@ -23,6 +23,7 @@ COPIES = {
     # BaZrO3 golden regression of tests_pytest
     "tests_pytest/fixtures/models/nep_BaZrO3.txt": "BaZrO3/nep.txt",
     "tests_pytest/fixtures/golden/bulk_bazro3.npz": "BaZrO3/bulk_bazro3.npz",
+    "tests_pytest/fixtures/structures/BaZrO3-nat40-rattled.xyz": "BaZrO3/BaZrO3-nat40-rattled.xyz",
     # carbon + UNEP (configs 4, 5) and a nep3 model
     "potentials/nep/C_2022_NEP4.txt": "C/nep.txt",
     "tests/gpumd/dump_observer/carbon_observe/C_2022_NEP3.txt": "C/nep3.txt",

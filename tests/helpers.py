@@ -314,3 +314,171 @@ class RefNepCpu:
 def neighbor_sets(nn, nl):
     """per-atom sorted tuple of neighbour indices (multiset, since small boxes repeat images)"""
     return [tuple(sorted(nl[:nn[i], i].tolist())) for i in range(len(nn))]
+
+
+# --------------------------------------------------------------------------------------------
+# synthetic configurations (seeded) used by the emulator and the GPU parity tests alike
+# --------------------------------------------------------------------------------------------
+def golden(*parts):
+    return os.path.join(GOLDEN, *parts)
+
+
+def pbte_supercell(reps, rattle=0.03, seed=1, symbols=("Te", "Pb"), num_types=None):
+    """replicate (replicate.cu:50-71 order) of the 250-atom triclinic PbTe cell + Gaussian rattle.
+    For models with other species the types are assigned round-robin over `num_types`."""
+    fr = read_xyz_frames(golden("PbTe", "model.xyz"))[0]
+    if num_types is None:
+        typ0 = types_from_species(fr["species"], list(symbols))
+    else:
+        typ0 = (np.arange(fr["n"]) * 7 % num_types).astype(np.int32)
+    h, typ, pos = replicate(fr["h"], typ0, fr["pos"], reps)
+    rng = np.random.default_rng(seed)
+    pos = pos + rng.normal(0.0, rattle, pos.shape)
+    x = oracle_apply_pbc(h, soa(pos))
+    return h, typ.astype(np.int32), x
+
+
+def rocksalt_orthogonal(cells, a=6.5704, rattle=0.02, seed=3):
+    """orthogonal rock-salt PbTe (SURVEY 8d.3 variant): 8 atoms per conventional cell."""
+    basis = np.array([[0, 0, 0], [.5, .5, 0], [.5, 0, .5], [0, .5, .5],
+                      [.5, 0, 0], [0, .5, 0], [0, 0, .5], [.5, .5, .5]]) * a
+    typ0 = np.array([1, 1, 1, 1, 0, 0, 0, 0], dtype=np.int32)  # Pb = 1, Te = 0 (nep4 2 Te Pb)
+    h0 = np.diag([a, a, a]).reshape(9)
+    h, typ, pos = replicate(h0, typ0, basis, cells)
+    rng = np.random.default_rng(seed)
+    pos = pos + rng.normal(0.0, rattle, pos.shape)
+    x = oracle_apply_pbc(h, soa(pos))
+    return h, typ.astype(np.int32), x
+
+
+def fcc_alloy(cells, a, num_types, rattle=0.05, seed=5):
+    basis = np.array([[0, 0, 0], [.5, .5, 0], [.5, 0, .5], [0, .5, .5]]) * a
+    h0 = np.diag([a, a, a]).reshape(9)
+    h, _, pos = replicate(h0, np.zeros(4, dtype=np.int32), basis, cells)
+    rng = np.random.default_rng(seed)
+    typ = rng.integers(0, num_types, len(pos)).astype(np.int32)
+    pos = pos + rng.normal(0.0, rattle, pos.shape)
+    x = oracle_apply_pbc(h, soa(pos))
+    return h, typ, x
+
+
+def diamond(cells, a, rattle=0.03, seed=9):
+    fcc = np.array([[0, 0, 0], [.5, .5, 0], [.5, 0, .5], [0, .5, .5]])
+    basis = np.concatenate([fcc, fcc + 0.25]) * a
+    h0 = np.diag([a, a, a]).reshape(9)
+    h, typ, pos = replicate(h0, np.zeros(8, dtype=np.int32), basis, cells)
+    rng = np.random.default_rng(seed)
+    pos = pos + rng.normal(0.0, rattle, pos.shape)
+    x = oracle_apply_pbc(h, soa(pos))
+    return h, typ.astype(np.int32), x
+
+
+MASS = {"Te": 127.6, "Pb": 207.2, "C": 12.011, "Ba": 137.327, "Zr": 91.224, "O": 15.999, "H": 1.008}
+K_B = 8.617343e-5
+TIME_UNIT = 10.18051  # fs per natural time unit (src/utilities/common.cuh:26)
+
+
+def maxwell_velocities(mass, temperature, seed=11):
+    """Gaussian velocities at `temperature`, zero net momentum, SoA [vx|vy|vz] in natural units."""
+    rng = np.random.default_rng(seed)
+    n = len(mass)
+    v = rng.normal(0.0, 1.0, (3, n)) * np.sqrt(K_B * temperature / mass)[None, :]
+    v -= (v * mass[None, :]).sum(axis=1, keepdims=True) / mass.sum()
+    t_now = (mass[None, :] * v * v).sum() / (3.0 * n * K_B)
+    v *= np.sqrt(temperature / t_now)
+    return np.ascontiguousarray(v.reshape(-1))
+
+
+# --------------------------------------------------------------------------------------------
+# drivers for the C ABI: `EmuDriver` = tests/emu host-loop emulator (CPU tier, kernel logic),
+# `GpuDriver` = the product library on cuda:0.  Both go through gpumd_amd.nep.NEP.
+# --------------------------------------------------------------------------------------------
+class EmuDriver:
+    name = "emu"
+
+    def __init__(self):
+        from gpumd_amd import _capi
+        subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "emu")], check=True)
+        self.lib = _capi.bind(C.CDLL(os.path.join(ROOT, "tests", "emu", "libnepmi_emu.so")))
+
+    def model(self, nep_txt):
+        from gpumd_amd.nep import Model
+        return Model(nep_txt, lib=self.lib)
+
+    def engine(self, model, n, pbc=(1, 1, 1)):
+        from gpumd_amd.nep import NEP
+        return NEP(model, n, pbc=pbc, lib=self.lib)
+
+    def dev(self, a):
+        return np.array(a, copy=True)
+
+    def zeros(self, n, dtype=np.float64):
+        return np.zeros(n, dtype=dtype)
+
+    def host(self, a):
+        return np.array(a, copy=True)
+
+    def sync(self):
+        pass
+
+
+class GpuDriver:
+    name = "gpu"
+
+    def __init__(self):
+        import torch
+        import gpumd_amd
+        assert torch.cuda.is_available()
+        self.torch = torch
+        self.devi = torch.device("cuda:0")
+        self.lib = gpumd_amd.load_library()
+
+    def model(self, nep_txt):
+        import gpumd_amd
+        return gpumd_amd.Model(nep_txt)
+
+    def engine(self, model, n, pbc=(1, 1, 1)):
+        import gpumd_amd
+        return gpumd_amd.NEP(model, n, pbc=pbc)
+
+    def dev(self, a):
+        return self.torch.from_numpy(np.ascontiguousarray(a)).to(self.devi)
+
+    def zeros(self, n, dtype=np.float64):
+        tdt = {np.float64: self.torch.float64, np.float32: self.torch.float32, np.int32: self.torch.int32}[dtype]
+        return self.torch.zeros(n, dtype=tdt, device=self.devi)
+
+    def host(self, a):
+        self.torch.cuda.synchronize()
+        return a.cpu().numpy()
+
+    def sync(self):
+        self.torch.cuda.synchronize()
+
+
+def engine_force(drv, eng, h, typ, x):
+    """Force::compute through the C ABI -> (wrapped pos, pe, f, v) as numpy."""
+    n = len(typ)
+    d_t, d_x = drv.dev(typ), drv.dev(x)
+    d_pe, d_f, d_v = drv.zeros(n), drv.zeros(3 * n), drv.zeros(9 * n)
+    eng.force_compute(h, d_t, d_x, d_pe, d_f, d_v)
+    return drv.host(d_x), drv.host(d_pe), drv.host(d_f), drv.host(d_v)
+
+
+def engine_lists(drv, eng, n, which, ld=512):
+    nn = drv.zeros(n, dtype=np.int32)
+    nl = drv.zeros(ld * n, dtype=np.int32)
+    mx = eng.neighbors(which, nn, nl, ld)
+    return mx, drv.host(nn), drv.host(nl).reshape(ld, n)
+
+
+def assert_lists_equal(nn, nl, onn, onl):
+    assert np.array_equal(nn, onn)
+    ld = min(nl.shape[0], onl.shape[0])
+    assert onn.max() <= ld
+    mask = np.arange(ld)[:, None] < nn[None, :]
+    assert np.array_equal(np.where(mask, nl[:ld], -1), np.where(mask, onl[:ld], -1))
+
+
+# the reference's own regression tolerances, tests_pytest/conftest.py:51-60
+TOL = dict(energy_rtol=1e-5, energy_atol=1e-8, force_rtol=1e-4, force_atol=1e-6, virial_rtol=1e-4, virial_atol=1e-6)

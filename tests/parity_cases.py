@@ -1,0 +1,204 @@
+"""Parity cases shared by the CPU tier (tests/emu host-loop emulator: kernel LOGIC) and the GPU
+tier (the product library on an MI355X).  Every case drives the C ABI of include/nepmi.h and
+checks against the oracle on the same seeded input.
+
+Stated tolerances (FP32 kernels, FP64 accumulation into the caller's arrays):
+  neighbour lists (Verlet, radial, angular)  : bit-exact index sets, ascending order
+  wrapped positions                          : bit-exact
+  total energy                               : rtol 1e-5              (reference TOLERANCES)
+  forces vs FP64 oracle                      : |d| <= 1e-4 |f| + 3e-5 eV/A   (reference
+                                               transform-invariance atol, conftest.py:81-82)
+  forces vs FP32 oracle                      : |d| <= 1e-4 |f| + 1e-5 eV/A
+  per-atom virial vs FP64 oracle             : |d| <= 1e-4 |w| + 1e-4 eV
+"""
+import numpy as np
+
+import helpers as H
+
+MODELS = {
+    # name: (nep.txt, structure builder, num_types or None)
+    "PbTe-A": ("PbTe/nep.txt", lambda: H.pbte_supercell((2, 2, 2)), None),
+    "PbTe-B": ("PbTe/nep_B.txt", lambda: H.pbte_supercell((2, 2, 2), seed=2), None),
+    "PbTe-ortho": ("PbTe/nep.txt", lambda: H.rocksalt_orthogonal((4, 4, 5)), None),
+    "C-2022": ("C/nep.txt", lambda: H.diamond((6, 6, 7), 3.57), 1),
+    "C-nep3": ("C/nep3.txt", lambda: H.diamond((6, 7, 6), 3.57, seed=10), 1),
+    "UNEP-v1": ("UNEP/nep.txt", lambda: H.fcc_alloy((5, 5, 6), 3.9, 16), 16),
+    "BaZrO3": ("BaZrO3/nep.txt", lambda: H.pbte_supercell((2, 2, 2), num_types=3, seed=4), 3),
+    "water-model": ("water/nep.txt", lambda: H.pbte_supercell((2, 2, 2), num_types=2, seed=5), 2),
+}
+
+
+def check_force_parity(drv, name, generic=False, check_lists=True):
+    nep_rel, build, _ = MODELS[name]
+    nep = H.golden(*nep_rel.split("/"))
+    h, typ, x = build()
+    n = len(typ)
+    orc = H.Oracle(nep)
+    pe32, f32, v32, q32, fp32 = orc.compute(typ, h, x, precision=32, path=0, stages=True)
+    pe64, f64, v64 = orc.compute(typ, h, x, precision=64, path=0)
+
+    model = drv.model(nep)
+    assert model.info.dim == orc.info.dim and model.info.num_types == orc.info.num_types
+    eng = drv.engine(model, n)
+    if generic:
+        eng.set_generic(True)
+    xw, pe, f, v = H.engine_force(drv, eng, h, typ, x)
+
+    assert np.array_equal(xw, H.oracle_apply_pbc(h, x)), "wrapped positions must be bit-exact"
+    np.testing.assert_allclose(pe.sum(), pe64.sum(), rtol=1e-5, atol=1e-8)
+    np.testing.assert_allclose(pe, pe64, rtol=1e-5, atol=2e-5)
+    assert np.all(np.abs(f - f64) <= 1e-4 * np.abs(f64) + 3e-5), np.abs(f - f64).max()
+    assert np.all(np.abs(f - f32) <= 1e-4 * np.abs(f32) + 1e-5), np.abs(f - f32).max()
+    assert np.all(np.abs(v - v64) <= 1e-4 * np.abs(v64) + 1e-4), np.abs(v - v64).max()
+    # total virial (what thermo/stress uses)
+    vt, vt64 = v.reshape(9, n).sum(axis=1), v64.reshape(9, n).sum(axis=1)
+    np.testing.assert_allclose(vt, vt64, rtol=1e-4, atol=1e-3 * np.sqrt(n) * 1e-2)
+    # Newton's third law: the forces of a periodic system sum to zero (to FP32 accumulation noise)
+    assert np.abs(f.reshape(3, n).sum(axis=1)).max() < 1e-4 * np.sqrt(n)
+
+    # stage-wise: descriptors and dU/dq
+    q = drv.zeros(orc.info.dim * n, dtype=np.float32)
+    fp = drv.zeros(orc.info.dim * n, dtype=np.float32)
+    eng.descriptors(q, fp)
+    q, fp = drv.host(q).reshape(-1, n), drv.host(fp).reshape(-1, n)
+    np.testing.assert_allclose(q, q32, rtol=2e-5, atol=2e-5 * np.abs(q32).max())
+    np.testing.assert_allclose(fp, fp32, rtol=2e-4, atol=2e-4 * np.abs(fp32).max())
+
+    if check_lists:
+        L = orc.lists(typ, h, x, path=0)
+        for which, key in ((2, "skin"), (0, "radial"), (1, "angular")):
+            onn, onl = L[key]
+            mx, nn, nl = H.engine_lists(drv, eng, n, which, ld=int(onn.max()) + 2)
+            assert mx == onn.max()
+            H.assert_lists_equal(nn, nl, onn, onl)
+        st = eng.stats(True)
+        assert st.max_nn_radial == L["radial"][0].max() and st.max_nn_angular == L["angular"][0].max()
+        assert abs(st.mean_nn_radial - L["radial"][0].mean()) < 1e-9
+    return eng
+
+
+def check_translation_and_wrap(drv):
+    """Lattice-vector shifts and a rigid translation change nothing but FP32 rounding
+    (tests_pytest/test_invariances.py)."""
+    nep = H.golden("PbTe", "nep.txt")
+    h, typ, x = H.pbte_supercell((2, 2, 2), seed=21)
+    n = len(typ)
+    model = drv.model(nep)
+    eng = drv.engine(model, n)
+    _, pe0, f0, v0 = H.engine_force(drv, eng, h, typ, x)
+    H3 = np.asarray(h).reshape(3, 3)
+    shift = np.zeros(3 * n)
+    rng = np.random.default_rng(3)
+    k = rng.integers(-1, 2, (n, 3))  # move every atom by its own lattice vector combination
+    d = k @ H3.T
+    x2 = x + d.T.reshape(-1)
+    eng2 = drv.engine(model, n)
+    xw, pe1, f1, v1 = H.engine_force(drv, eng2, h, typ, x2)
+    np.testing.assert_allclose(pe1.sum(), pe0.sum(), rtol=1e-6)
+    assert np.abs(f1 - f0).max() < 3e-5
+    # rigid translation
+    t = np.array([0.37, -1.91, 2.5])
+    x3 = x + np.repeat(t, n)
+    eng3 = drv.engine(model, n)
+    _, pe2, f2, _ = H.engine_force(drv, eng3, h, typ, x3)
+    np.testing.assert_allclose(pe2.sum(), pe0.sum(), rtol=1e-6)
+    assert np.abs(f2 - f0).max() < 3e-5
+
+
+def check_nve_against_oracle(drv, nsteps=20, reps=(2, 2, 2)):
+    """Run::perform_a_run (nve): trajectory, thermo and rebuild policy vs the oracle's loop."""
+    nep = H.golden("PbTe", "nep.txt")
+    h, typ, x = H.pbte_supercell(reps, rattle=0.02, seed=31)
+    n = len(typ)
+    orc = H.Oracle(nep)
+    mass = np.array([H.MASS[orc.symbols[t]] for t in typ])
+    vel = H.maxwell_velocities(mass, 6000.0, seed=5)  # hot: forces a list rebuild within the run
+    dt = 2.0 / H.TIME_UNIT
+    # initial forces
+    pe0, f0, v0 = orc.compute(typ, h, x, precision=32, path=0)
+    ref = orc.run_nve(typ, h, x, vel, mass, dt, nsteps, precision=32)
+
+    model = drv.model(nep)
+    eng = drv.engine(model, n)
+    d_t, d_m = drv.dev(typ), drv.dev(mass)
+    d_x, d_v = drv.dev(x), drv.dev(vel)
+    d_pe, d_f, d_w = drv.zeros(n), drv.zeros(3 * n), drv.zeros(9 * n)
+    eng.force_compute(h, d_t, d_x, d_pe, d_f, d_w)  # Run: initial force before the loop
+    th = eng.run_nve(h, d_t, d_m, dt, nsteps, d_x, d_v, d_pe, d_f, d_w, thermo_every=1)
+    xs, vs = drv.host(d_x), drv.host(d_v)
+    assert th.shape == (nsteps, 8)
+    # positions are FP64 state driven by FP32 forces: agreement degrades slowly with steps
+    H3 = np.asarray(h).reshape(3, 3)
+    dx = (xs - ref["pos"]).reshape(3, n)
+    frac = np.linalg.solve(H3, dx)
+    frac -= np.rint(frac)
+    assert np.abs(H3 @ frac).max() < 1e-6
+    assert np.abs(vs - ref["vel"]).max() < 1e-6
+    np.testing.assert_allclose(th[:, 0], ref["thermo"][:, 0], rtol=1e-6)   # temperature
+    np.testing.assert_allclose(th[:, 1], ref["thermo"][:, 1], rtol=1e-6)   # potential energy
+    np.testing.assert_allclose(th[:, 2:], ref["thermo"][:, 2:], rtol=1e-4, atol=1e-6)
+    st = eng.stats()
+    assert st.num_rebuild == ref["rebuilds"], (st.num_rebuild, ref["rebuilds"])
+    assert st.num_rebuild >= 2
+    # energy conservation over the short run (test_md_conservation.py: drift < 2e-3 dt^2 N)
+    ke = 1.5 * n * H.K_B * th[:, 0]
+    etot = ke + th[:, 1]
+    assert np.abs(etot - etot[0]).max() < 2e-3 * (2.0 ** 2) * n
+
+
+def check_streaming_ops(drv):
+    """apply_pbc, velocity-Verlet halves and find_thermo alone, against the oracle (FP64)."""
+    h, typ, x = H.pbte_supercell((2, 2, 2), seed=41)
+    n = len(typ)
+    rng = np.random.default_rng(2)
+    mass = np.where(typ == 0, 127.6, 207.2)
+    vel = rng.normal(0, 0.01, 3 * n)
+    f = rng.normal(0, 1.0, 3 * n)
+    pe = rng.normal(-3, 0.1, n)
+    w = rng.normal(0, 1.0, 9 * n)
+    xs = x + rng.normal(0, 3.0, 3 * n)  # some atoms outside the cell
+    model = drv.model(H.golden("PbTe", "nep.txt"))
+    eng = drv.engine(model, n)
+    d_x = drv.dev(xs)
+    eng.apply_pbc(h, d_x)
+    assert np.array_equal(drv.host(d_x), H.oracle_apply_pbc(h, xs))
+    # vv
+    L = H.oracle_lib()
+    dt = 1.0 / H.TIME_UNIT
+    xo, vo = x.copy(), vel.copy()
+    L.nepo_velocity_verlet(1, n, dt, H._p(mass, H._dp), H._p(f, H._dp), H._p(xo, H._dp), H._p(vo, H._dp))
+    d_x, d_v, d_f, d_m = drv.dev(x), drv.dev(vel), drv.dev(f), drv.dev(mass)
+    eng.vv_step1(dt, d_m, d_f, d_x, d_v)
+    assert np.array_equal(drv.host(d_x), xo) and np.array_equal(drv.host(d_v), vo)
+    L.nepo_velocity_verlet(0, n, dt, H._p(mass, H._dp), H._p(f, H._dp), H._p(xo, H._dp), H._p(vo, H._dp))
+    eng.vv_step2(dt, d_m, d_f, d_v)
+    assert np.array_equal(drv.host(d_v), vo)
+    # thermo
+    vol = abs(np.linalg.det(np.asarray(h).reshape(3, 3)))
+    tho = H.oracle_thermo(vol, mass, pe, vo, w)
+    d_th = drv.zeros(8)
+    eng.find_thermo(vol, d_m, drv.dev(pe), d_v, drv.dev(w), d_th)
+    np.testing.assert_allclose(drv.host(d_th), tho, rtol=1e-12, atol=1e-12)
+
+
+def check_error_paths(drv):
+    import pytest
+    from gpumd_amd import NepmiError
+    model = drv.model(H.golden("PbTe", "nep.txt"))
+    # 250-atom cell: thickness 18.97 A <= 2.5*(8+1): small-box branch is not on the device yet
+    fr = H.read_xyz_frames(H.golden("PbTe", "model.xyz"))[0]
+    typ = H.types_from_species(fr["species"], model.symbols)
+    eng = drv.engine(model, fr["n"])
+    with pytest.raises(NepmiError) as ei:
+        H.engine_force(drv, eng, fr["h"], typ, H.soa(fr["pos"]))
+    assert ei.value.code == -7
+    # wrong atom count
+    h, typ, x = H.pbte_supercell((2, 2, 2))
+    eng = drv.engine(model, len(typ) - 1)
+    with pytest.raises(NepmiError):
+        H.engine_force(drv, eng, h, typ, x)
+    # unsupported / malformed model files
+    with pytest.raises(NepmiError):
+        drv.model(H.golden("PbTe", "model.xyz"))
+    with pytest.raises(NepmiError):
+        drv.model(H.golden("PbTe", "does_not_exist.txt"))

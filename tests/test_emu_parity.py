@@ -1,0 +1,38 @@
+"""CPU tier: the kernel bodies + engine sequencing run by the host-loop emulator (tests/emu, test
+infrastructure) against the oracle.  Validates the kernel LOGIC where no GPU exists; the same
+cases run on the real library under -m gpu (test_gpu_parity.py)."""
+import pytest
+
+import helpers as H
+import parity_cases as P
+
+
+@pytest.fixture(scope="module")
+def drv():
+    return H.EmuDriver()
+
+
+@pytest.mark.parametrize("name", list(P.MODELS))
+def test_force_parity(drv, name):
+    P.check_force_parity(drv, name)
+
+
+@pytest.mark.parametrize("name", ["PbTe-A", "UNEP-v1", "C-2022"])
+def test_force_parity_generic_shape(drv, name):
+    P.check_force_parity(drv, name, generic=True, check_lists=False)
+
+
+def test_invariances(drv):
+    P.check_translation_and_wrap(drv)
+
+
+def test_nve_run(drv):
+    P.check_nve_against_oracle(drv)
+
+
+def test_streaming_ops(drv):
+    P.check_streaming_ops(drv)
+
+
+def test_error_paths(drv):
+    P.check_error_paths(drv)
