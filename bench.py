@@ -1,0 +1,210 @@
+#!/usr/bin/env python
+"""bench.py -- atom-steps/s of the NEP NVE hot path (BASELINE.json's metric) on MI355X.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one MD step of Run::perform_a_run for `ensemble nve` (src/main_gpumd/run.cu:250-318):
+velocity-Verlet half-kick + drift, pbc wrap, zero, NEP force call (skin check, list rebuild when
+needed, descriptor, ANN, forces, virial), second half-kick -- over all atoms, through the C ABI of
+libnepmi.so (nepmi_run_nve).  Workload at N = 1: BASELINE.json configs[2], PbTe 1,024,000 atoms
+(`replicate 16 16 16` of the 250-atom cell of examples/gpumd_static, model examples/nep_train/nep.txt),
+rattled, 300 K Maxwell velocities, dt = 1 fs.  Inputs are resident in HBM before the timed region.
+
+One JSON line is printed by rank 0 (see the contract in the task description); it also carries
+  "roofline":     dominant force kernel vs the HBM roofline, durations from HIP events recorded on
+                  the engine's own stream inside the timed region
+  "cpu_baseline": the reference's own NEP_CPU (oracle/_ref) timed on this box's host cores on a
+                  bounded 16,000-atom sample of the same crystal (rank 0, N = 1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+KERNEL_NAMES = ["gather_skin_check", "radial_descriptor", "angular_descriptor", "ann", "angular_partial_force",
+                "force_assemble", "velocity_verlet", "list_rebuild"]
+
+
+def build_pbte(reps, rattle=0.02, seed=42, temperature=300.0):
+    import helpers as H
+    fr = H.read_xyz_frames(H.golden("PbTe", "model.xyz"))[0]
+    typ0 = H.types_from_species(fr["species"], ["Te", "Pb"])
+    h, typ, pos = H.replicate(fr["h"], typ0, fr["pos"], reps)
+    rng = np.random.default_rng(seed)
+    pos = pos + rng.normal(0.0, rattle, pos.shape)
+    typ = typ.astype(np.int32)
+    mass = np.where(typ == 0, H.MASS["Te"], H.MASS["Pb"]).astype(np.float64)
+    vel = H.maxwell_velocities(mass, temperature, seed=seed + 1)
+    return h, typ, H.soa(pos), mass, vel
+
+
+def algorithmic_bytes(info, nn_r, nn_a):
+    """compulsory HBM bytes per atom-step, split per kernel."""
+    dim, nr1 = info.dim, info.n_max_radial + 1
+    per_kernel = {
+        "velocity_verlet": 128.0 + 80.0,                        # VV1 (m, f, x rw, v rw) + VV2 (m, f, v rw)
+        "gather_skin_check": 24.0,                              # skin check re-reads x
+        "radial_descriptor": 28.0 + 4.0 * nn_r + 4.0 * nr1,      # x+type, radial list, q_radial out
+        "angular_descriptor": 28.0 + 4.0 * nn_a + 4.0 * (dim - nr1),
+        "ann": 4.0 * dim + 4.0 * dim + 8.0,                      # q in, Fp out, pe
+        "angular_partial_force": 4.0 * nn_a + 4.0 * (dim - nr1) + 12.0 * nn_a,   # list, Fp in, f12 out
+        "force_assemble": 28.0 + 4.0 * nn_r + 4.0 * nr1 + 12.0 * nn_a + 24.0 + 72.0,  # x, list, Fp, f12 in; f, virial out
+    }
+    total = 232.0 + 160.0 + 8.0 * (nn_r + nn_a) + 8.0 * dim + 24.0 * nn_a
+    return per_kernel, total
+
+
+def cpu_baseline(seconds=12.0):
+    """NEP_CPU (reference, compiled in place into oracle/_ref) on a 16,000-atom PbTe replica; one
+    iteration = compute() + a host velocity-Verlet update, so that it is an atom-STEP."""
+    import helpers as H
+    nep = H.golden("PbTe", "nep.txt")
+    h, typ, x, mass, vel = build_pbte((4, 4, 4))
+    n = len(typ)
+    if H.ref_available():
+        eng, kind = H.RefNepCpu(nep), "reference"
+        compute = lambda xx: eng.compute(typ, h, xx)
+        cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+    else:
+        eng, kind = H.Oracle(nep), "port"
+        compute = lambda xx: eng.compute(typ, h, xx, precision=64, path=0)
+        cores = 1
+    dt = 1.0 / H.TIME_UNIT
+    x = H.oracle_apply_pbc(h, x)
+    _, f, _ = compute(x)  # warm-up + initial force
+    minv = np.tile(1.0 / mass, 3)
+    calls, t0 = 0, time.perf_counter()
+    while True:
+        vel += 0.5 * dt * f * minv
+        x = H.oracle_apply_pbc(h, x + dt * vel)
+        _, f, _ = compute(x)
+        vel += 0.5 * dt * f * minv
+        calls += 1
+        el = time.perf_counter() - t0
+        if el > seconds or calls >= 50:
+            break
+    return {"value": n * calls / el, "unit": "atom-steps/s", "cores": cores, "kind": kind,
+            "sample": "PbTe %d atoms (replicate 4 4 4), %d NVE steps, %.1f s; NEP_CPU is serial outside its descriptor loop"
+                      % (n, calls, el)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--reps", type=int, nargs=3, default=[16, 16, 16], help="replicate na nb nc of the 250-atom cell")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import gpumd_amd
+    import helpers as H
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; there is no CPU path for the product")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    # ---- workload (per rank; see DESIGN.md section 7 for the N > 1 decomposition) ----
+    reps = tuple(args.reps)
+    h, typ, x, mass, vel = build_pbte(reps, seed=42 + rank)
+    n = len(typ)
+    nep_txt = H.golden("PbTe", "nep.txt")
+    model = gpumd_amd.Model(nep_txt)
+    eng = gpumd_amd.NEP(model, n)
+    dt = 1.0 / H.TIME_UNIT
+    t_type = torch.from_numpy(typ).to(dev)
+    t_mass = torch.from_numpy(mass).to(dev)
+    t_x = torch.from_numpy(x).to(dev)
+    t_v = torch.from_numpy(vel).to(dev)
+    t_pe = torch.zeros(n, dtype=torch.float64, device=dev)
+    t_f = torch.zeros(3 * n, dtype=torch.float64, device=dev)
+    t_w = torch.zeros(9 * n, dtype=torch.float64, device=dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # initial force (Run::perform_a_run computes it before the loop), then warm-up steps
+    eng.force_compute(h, t_type, t_x, t_pe, t_f, t_w)
+    if args.warmup > 0:
+        eng.run_nve(h, t_type, t_mass, dt, args.warmup, t_x, t_v, t_pe, t_f, t_w)
+    eng.set_timing(True)
+    reb0 = eng.stats().num_rebuild
+    barrier()
+    t0 = time.perf_counter()
+    th = eng.run_nve(h, t_type, t_mass, dt, args.steps, t_x, t_v, t_pe, t_f, t_w, thermo_every=args.steps)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    st = eng.stats(with_lists=True)
+    eng.set_timing(False)
+
+    t_el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
+    elapsed = float(t_el.item())
+    total_atoms = n * world
+    value = total_atoms * args.steps / elapsed
+
+    if rank == 0:
+        per_kernel, b_step = algorithmic_bytes(model.info, st.mean_nn_radial, st.mean_nn_angular)
+        kern = {}
+        for k, name in enumerate(KERNEL_NAMES):
+            if st.launches[k] > 0:
+                kern[name] = {"launches": int(st.launches[k]), "avg_ms": st.ms_kernel_sum[k] / st.launches[k]}
+        force_kernels = [k for k in kern if k in per_kernel and k not in ("velocity_verlet", "gather_skin_check")]
+        dom = max(force_kernels, key=lambda k: kern[k]["avg_ms"] * kern[k]["launches"]) if force_kernels else None
+        roofline = None
+        if dom:
+            achieved = per_kernel[dom] * n / (kern[dom]["avg_ms"] * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                        "algorithmic_bytes_per_atom": per_kernel[dom], "avg_launch_ms": kern[dom]["avg_ms"],
+                        "note": "FP32-VALU/gather bound stage (SURVEY.md 8d); see step_hbm_frac for the whole step"}
+        out = {
+            "metric": "atom-steps/sec, NEP PbTe NVE (nep4 2 Te Pb, examples/nep_train/nep.txt)",
+            "value": value, "unit": "atom-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32 kernels, f64 state/accumulation", "data": "synthetic",
+            "config": {"workload": "PbTe %d atoms/GPU (replicate %d %d %d of the 250-atom cell), NEP NVE, dt 1 fs, 300 K"
+                                   % ((n,) + reps),
+                       "atoms_total": total_atoms, "rebuilds_in_timed_region": int(st.num_rebuild - reb0),
+                       "mean_nn_radial": st.mean_nn_radial, "mean_nn_angular": st.mean_nn_angular,
+                       "parallelism": "1 GPU" if world == 1 else "%d independent periodic replicas (no halo yet)" % world},
+            "roofline": roofline,
+            "step_algorithmic_bytes_per_atom": b_step,
+            "step_hbm_frac": b_step * (n * args.steps / elapsed) / (HBM_PEAK_GBS * 1e9),
+            "kernels": kern,
+            "thermo_last": [float(v) for v in th[-1]] if len(th) else None,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

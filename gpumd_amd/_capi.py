@@ -28,7 +28,8 @@ class NepmiStats(C.Structure):
         ("num_compute", c_i64), ("num_rebuild", c_i64),
         ("max_nn_skin", C.c_int), ("max_nn_radial", C.c_int), ("max_nn_angular", C.c_int),
         ("mean_nn_radial", C.c_double), ("mean_nn_angular", C.c_double),
-        ("ms_force_last", C.c_double), ("ms_kernel", C.c_double * 8)]
+        ("ms_force_last", C.c_double), ("ms_kernel", C.c_double * 8),
+        ("ms_kernel_sum", C.c_double * 8), ("launches", c_i64 * 8)]
 
 
 # every symbol include/nepmi.h declares: name -> (restype, argtypes)

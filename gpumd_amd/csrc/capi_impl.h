@@ -234,13 +234,15 @@ int nepmi_engine_stats(nepmi_engine* e, int with_lists, nepmi_stats* out)
     if (with_lists && eng.num_compute > 0)
       eng.list_stats(out->max_nn_skin, out->max_nn_radial, out->max_nn_angular, out->mean_nn_radial, out->mean_nn_angular);
     out->ms_force_last = eng.backend().region_ms(nepmi::kRegionForce);
-    out->ms_kernel[0] = eng.backend().slot_ms(nepmi::kSlotGather);
-    out->ms_kernel[1] = eng.backend().slot_ms(nepmi::kSlotRadial);
-    out->ms_kernel[2] = eng.backend().slot_ms(nepmi::kSlotAngular);
-    out->ms_kernel[3] = eng.backend().slot_ms(nepmi::kSlotAnn);
-    out->ms_kernel[4] = eng.backend().slot_ms(nepmi::kSlotAngForce);
-    out->ms_kernel[5] = eng.backend().slot_ms(nepmi::kSlotForce);
-    out->ms_kernel[6] = eng.backend().slot_ms(nepmi::kSlotVV);
+    const int slots[7] = {nepmi::kSlotGather, nepmi::kSlotRadial, nepmi::kSlotAngular, nepmi::kSlotAnn,
+                          nepmi::kSlotAngForce, nepmi::kSlotForce, nepmi::kSlotVV};
+    for (int k = 0; k < 7; ++k) {
+      out->ms_kernel[k] = eng.backend().slot_ms(slots[k]);
+      out->ms_kernel_sum[k] = eng.backend().slot_sum(slots[k]);
+      out->launches[k] = eng.backend().slot_count(slots[k]);
+    }
+    out->ms_kernel_sum[7] = eng.backend().region_sum(nepmi::kRegionRebuild);
+    out->launches[7] = eng.backend().region_count(nepmi::kRegionRebuild);
     out->ms_kernel[7] = eng.backend().region_ms(nepmi::kRegionRebuild);
   });
 }

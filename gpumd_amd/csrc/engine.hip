@@ -195,11 +195,18 @@ __global__ void __launch_bounds__(64) nepmi_thermo_final(
 
 // ------------------------------------------------------------------------------------------------
 
-struct HipTiming {
-  hipEvent_t slot_start[16], slot_stop[16];
-  hipEvent_t reg_start[4], reg_stop[4];
-  bool slot_used[16], reg_used[4];
+struct EventTimer {
+  static constexpr int kPool = 128;
+  hipEvent_t start[kPool], stop[kPool];
+  int used = 0;
   bool created = false;
+  double sum_ms = 0.0, last_ms = 0.0;
+  int64_t count = 0;
+};
+
+struct HipTiming {
+  EventTimer slot[16];
+  EventTimer reg[4];
 };
 
 struct HipBackend {
@@ -234,54 +241,69 @@ struct HipBackend {
   }
   void sync() { NEPMI_HIP_CHECK(hipStreamSynchronize(stream)); }
 
+  // ---- HIP-event timing on the engine's own stream (bench.py's roofline leg) ----
+  void timer_drain(EventTimer& t)
+  {
+    if (t.used == 0)
+      return;
+    NEPMI_HIP_CHECK(hipEventSynchronize(t.stop[t.used - 1]));
+    for (int k = 0; k < t.used; ++k) {
+      float ms = 0.0f;
+      NEPMI_HIP_CHECK(hipEventElapsedTime(&ms, t.start[k], t.stop[k]));
+      t.sum_ms += ms;
+      t.last_ms = ms;
+      ++t.count;
+    }
+    t.used = 0;
+  }
+  void timer_start(EventTimer& t)
+  {
+    if (!t.created) {
+      for (int k = 0; k < EventTimer::kPool; ++k) {
+        NEPMI_HIP_CHECK(hipEventCreate(&t.start[k]));
+        NEPMI_HIP_CHECK(hipEventCreate(&t.stop[k]));
+      }
+      t.created = true;
+    }
+    if (t.used == EventTimer::kPool)
+      timer_drain(t);
+    NEPMI_HIP_CHECK(hipEventRecord(t.start[t.used], stream));
+  }
+  void timer_stop(EventTimer& t)
+  {
+    NEPMI_HIP_CHECK(hipEventRecord(t.stop[t.used], stream));
+    ++t.used;
+  }
   void set_timing(bool on)
   {
-    if (on && !timing->created) {
-      for (int k = 0; k < 16; ++k) {
-        NEPMI_HIP_CHECK(hipEventCreate(&timing->slot_start[k]));
-        NEPMI_HIP_CHECK(hipEventCreate(&timing->slot_stop[k]));
-        timing->slot_used[k] = false;
-      }
-      for (int k = 0; k < 4; ++k) {
-        NEPMI_HIP_CHECK(hipEventCreate(&timing->reg_start[k]));
-        NEPMI_HIP_CHECK(hipEventCreate(&timing->reg_stop[k]));
-        timing->reg_used[k] = false;
-      }
-      timing->created = true;
+    for (int k = 0; k < 16; ++k) {
+      timer_drain(timing->slot[k]);
+      timing->slot[k].sum_ms = 0.0;
+      timing->slot[k].count = 0;
+    }
+    for (int k = 0; k < 4; ++k) {
+      timer_drain(timing->reg[k]);
+      timing->reg[k].sum_ms = 0.0;
+      timing->reg[k].count = 0;
     }
     timing_on = on;
   }
   void begin_region(int r)
   {
-    if (timing_on) {
-      NEPMI_HIP_CHECK(hipEventRecord(timing->reg_start[r], stream));
-    }
+    if (timing_on)
+      timer_start(timing->reg[r]);
   }
   void end_region(int r)
   {
-    if (timing_on) {
-      NEPMI_HIP_CHECK(hipEventRecord(timing->reg_stop[r], stream));
-      timing->reg_used[r] = true;
-    }
+    if (timing_on)
+      timer_stop(timing->reg[r]);
   }
-  double region_ms(int r)
-  {
-    if (!timing->created || !timing->reg_used[r])
-      return 0.0;
-    float ms = 0.0f;
-    if (hipEventElapsedTime(&ms, timing->reg_start[r], timing->reg_stop[r]) != hipSuccess)
-      return 0.0;
-    return ms;
-  }
-  double slot_ms(int s)
-  {
-    if (!timing->created || !timing->slot_used[s])
-      return 0.0;
-    float ms = 0.0f;
-    if (hipEventElapsedTime(&ms, timing->slot_start[s], timing->slot_stop[s]) != hipSuccess)
-      return 0.0;
-    return ms;
-  }
+  double region_ms(int r) { timer_drain(timing->reg[r]); return timing->reg[r].last_ms; }
+  double region_sum(int r) { timer_drain(timing->reg[r]); return timing->reg[r].sum_ms; }
+  int64_t region_count(int r) { timer_drain(timing->reg[r]); return timing->reg[r].count; }
+  double slot_ms(int s) { timer_drain(timing->slot[s]); return timing->slot[s].last_ms; }
+  double slot_sum(int s) { timer_drain(timing->slot[s]); return timing->slot[s].sum_ms; }
+  int64_t slot_count(int s) { timer_drain(timing->slot[s]); return timing->slot[s].count; }
 
   template <int BLOCK, class Body>
   void launch(int slot, int64_t n, const Body& body)
@@ -289,15 +311,13 @@ struct HipBackend {
     if (n <= 0)
       return;
     const int64_t grid = (n + BLOCK - 1) / BLOCK;
-    const bool t = timing_on && slot != 9; // kSlotMisc is not timed
+    const bool t = timing_on && slot != kSlotMisc;
     if (t)
-      NEPMI_HIP_CHECK(hipEventRecord(timing->slot_start[slot], stream));
+      timer_start(timing->slot[slot]);
     hipLaunchKernelGGL((nepmi_kernel<BLOCK, Body>), dim3((unsigned)grid), dim3(BLOCK), 0, stream, body, n);
     NEPMI_HIP_CHECK(hipGetLastError());
-    if (t) {
-      NEPMI_HIP_CHECK(hipEventRecord(timing->slot_stop[slot], stream));
-      timing->slot_used[slot] = true;
-    }
+    if (t)
+      timer_stop(timing->slot[slot]);
   }
 
   void exclusive_scan(int* data, int64_t n, int* scratch)

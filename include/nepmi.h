@@ -145,6 +145,8 @@ typedef struct {
   double ms_kernel[8];   /* last launch of: 0 gather/skin-check, 1 radial descriptor, 2 angular
                             descriptor, 3 ANN, 4 angular partial force, 5 force assembly,
                             6 velocity-Verlet, 7 list rebuild (whole) */
+  double ms_kernel_sum[8]; /* same slots: sum over all launches since timing was (re)enabled */
+  int64_t launches[8];     /* ... and their number (slot 7: rebuilds)                       */
 } nepmi_stats;
 /* Synchronises the stream.  with_lists != 0 also recounts the per-step list lengths. */
 int nepmi_engine_stats(nepmi_engine* e, int with_lists, nepmi_stats* out);

@@ -25,6 +25,10 @@ struct HostLoopBackend {
   void end_region(int) {}
   double region_ms(int) { return 0.0; }
   double slot_ms(int) { return 0.0; }
+  double slot_sum(int) { return 0.0; }
+  int64_t slot_count(int) { return 0; }
+  double region_sum(int) { return 0.0; }
+  int64_t region_count(int) { return 0; }
   void set_timing(bool) {}
 
   template <int BLOCK, class Body>
