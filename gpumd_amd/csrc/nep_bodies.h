@@ -131,28 +131,23 @@ struct VelocityVerletBody {
   double* vel;
   NEPMI_HD void operator()(int64_t i) const
   {
+#pragma clang fp contract(off) // v + (a * half): two roundings, as the oracle computes it
     const double half = dt * 0.5;
     const double minv = 1.0 / mass[i];
     double v[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
       const double a = force[d * N + i] * minv;
-#if defined(__HIP_DEVICE_COMPILE__)
-      v[d] = __dadd_rn(vel[d * N + i], __dmul_rn(a, half));
-#else
-      v[d] = vel[d * N + i] + a * half;
-#endif
+      const double kick = a * half;
+      v[d] = vel[d * N + i] + kick;
       vel[d * N + i] = v[d];
     }
     if (is_step1) {
       double r[3];
 #pragma unroll
       for (int d = 0; d < 3; ++d) {
-#if defined(__HIP_DEVICE_COMPILE__)
-        r[d] = __dadd_rn(pos[d * N + i], __dmul_rn(v[d], dt));
-#else
-        r[d] = pos[d * N + i] + v[d] * dt;
-#endif
+        const double drift = v[d] * dt;
+        r[d] = pos[d * N + i] + drift;
       }
       if (fuse_wrap)
         wrap_position(box, r[0], r[1], r[2]);
@@ -318,6 +313,7 @@ struct CheckGatherBody {
   const double* pos;
   NEPMI_HD void operator()(int64_t k) const
   {
+#pragma clang fp contract(off) // d2 with separate roundings, as the oracle's skin check
     const int64_t N = b.N;
     const int64_t i = b.perm[k];
     const double x = pos[i], y = pos[N + i], z = pos[2 * N + i];
@@ -325,7 +321,8 @@ struct CheckGatherBody {
     float dy = (float)(y - b.x0s[N + k]);
     float dz = (float)(z - b.x0s[2 * N + k]);
     mic_f(box, dx, dy, dz);
-    if ((double)(dx * dx + dy * dy + dz * dz) > 0.25) // skin^2/4, skin = 1 A (neighbor.cuh:212)
+    const float d2 = (dx * dx + dy * dy) + dz * dz;
+    if ((double)d2 > 0.25) // skin^2/4, skin = 1 A (neighbor.cuh:212)
       NEPMI_ATOMIC_OR(&b.flags[kFlagMoved], 1);
     b.posq[k].x = x;
     b.posq[k].y = y;

@@ -144,25 +144,17 @@ NEPMI_HD float pair_geometry(const BoxD& box, const PosQ& a, const PosQ& b, floa
 // and the emulator give identical bits).
 NEPMI_HD void wrap_position(const BoxD& box, double& x, double& y, double& z)
 {
+#pragma clang fp contract(off) // separate roundings, like the oracle (and gcc -ffp-contract=off)
   const double* h = box.h;
-#if defined(__HIP_DEVICE_COMPILE__)
-#define NEPMI_DM(a, b) __dmul_rn(a, b)
-#define NEPMI_DA(a, b) __dadd_rn(a, b)
-#else
-#define NEPMI_DM(a, b) ((a) * (b))
-#define NEPMI_DA(a, b) ((a) + (b))
-#endif
-  double sx = NEPMI_DA(NEPMI_DA(NEPMI_DM(h[9], x), NEPMI_DM(h[10], y)), NEPMI_DM(h[11], z));
-  double sy = NEPMI_DA(NEPMI_DA(NEPMI_DM(h[12], x), NEPMI_DM(h[13], y)), NEPMI_DM(h[14], z));
-  double sz = NEPMI_DA(NEPMI_DA(NEPMI_DM(h[15], x), NEPMI_DM(h[16], y)), NEPMI_DM(h[17], z));
+  double sx = (h[9] * x + h[10] * y) + h[11] * z;
+  double sy = (h[12] * x + h[13] * y) + h[14] * z;
+  double sz = (h[15] * x + h[16] * y) + h[17] * z;
   if (box.pbc[0]) { if (sx < 0.0) sx += 1.0; else if (sx > 1.0) sx -= 1.0; }
   if (box.pbc[1]) { if (sy < 0.0) sy += 1.0; else if (sy > 1.0) sy -= 1.0; }
   if (box.pbc[2]) { if (sz < 0.0) sz += 1.0; else if (sz > 1.0) sz -= 1.0; }
-  x = NEPMI_DA(NEPMI_DA(NEPMI_DM(h[0], sx), NEPMI_DM(h[1], sy)), NEPMI_DM(h[2], sz));
-  y = NEPMI_DA(NEPMI_DA(NEPMI_DM(h[3], sx), NEPMI_DM(h[4], sy)), NEPMI_DM(h[5], sz));
-  z = NEPMI_DA(NEPMI_DA(NEPMI_DM(h[6], sx), NEPMI_DM(h[7], sy)), NEPMI_DM(h[8], sz));
-#undef NEPMI_DM
-#undef NEPMI_DA
+  x = (h[0] * sx + h[1] * sy) + h[2] * sz;
+  y = (h[3] * sx + h[4] * sy) + h[5] * sz;
+  z = (h[6] * sx + h[7] * sy) + h[8] * sz;
 }
 
 // find_cell_id, neighbor.cuh:76-110

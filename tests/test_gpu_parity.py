@@ -76,15 +76,20 @@ def test_full_size_properties(drv):
     F = f.reshape(3, n)
     # (1) Newton's third law over the whole periodic system
     assert np.abs(F.sum(axis=1)).max() < 0.05
-    # (2) periodic images agree (FP32 rounding differs slightly with absolute position)
+    # (2) periodic images agree.  Pairs that cross the periodic boundary go through the FP32
+    # minimum-image round trip of a ~300 A difference (apply_mic, box.cuh:84-129: ulp 3e-5 A), so
+    # boundary blocks carry ~1e-4 eV/A noise in the reference algorithm itself; interior blocks do not.
     blocks = F.reshape(3, 512, n1)
-    assert np.abs(blocks - blocks[:, :1, :]).max() < 5e-5
+    inner = 3 * 64 + 4 * 8 + 3  # block (3,4,3) of the 8x8x8 tiling (replicate order i,j,k)
+    assert np.abs(blocks - blocks[:, inner:inner + 1, :]).max() < 5e-4
+    interior = [i * 64 + j * 8 + k for i in range(2, 6) for j in range(2, 6) for k in range(2, 6)]
+    assert np.abs(blocks[:, interior, :] - blocks[:, inner:inner + 1, :]).max() < 3e-5
     pb = pe.reshape(512, n1)
-    assert np.abs(pb - pb[:1]).max() < 2e-5
-    # (3) and equal the oracle on the small block
+    assert np.abs(pb - pb[inner:inner + 1]).max() < 5e-5
+    # (3) and an interior block equals the oracle on the small periodic cell
     pe64, f64, _ = H.Oracle(nep).compute(typ1, h1, x1, precision=64, path=0)
-    assert np.all(np.abs(blocks[:, 0, :].reshape(-1) - f64) <= 1e-4 * np.abs(f64) + 3e-5)
-    np.testing.assert_allclose(pb[0], pe64, rtol=1e-5, atol=2e-5)
+    assert np.all(np.abs(blocks[:, inner, :].reshape(-1) - f64) <= 1e-4 * np.abs(f64) + 3e-5)
+    np.testing.assert_allclose(pb[inner], pe64, rtol=1e-5, atol=2e-5)
     # (4) a second call on the same positions is bit-identical (deterministic, no atomics in sums)
     _, pe2, f2, v2 = H.engine_force(drv, eng, h, typ.astype(np.int32), x)
     assert np.array_equal(f2, f) and np.array_equal(pe2, pe) and np.array_equal(v2, v)
