@@ -25,10 +25,17 @@ namespace nepmi {
                                __FILE__ + ":" + std::to_string(__LINE__) + " (" #expr ")");         \
   } while (0)
 
+// One work-item per atom.  Workgroup -> tile mapping is XCD-aware: the dispatcher places workgroup
+// b on XCD b % 8 (MI355X_MICROARCH.md, observed, used for speed only), so XCD x is given the
+// contiguous tile range [x * gridDim/8, (x+1) * gridDim/8).  With the brick-major atom order this
+// keeps each XCD's private 4 MiB L2 on one compact slab of the crystal instead of the whole box.
+// gridDim.x is always a multiple of 8 (surplus tiles exit).
 template <int BLOCK, class Body>
 __global__ void __launch_bounds__(BLOCK) nepmi_kernel(const Body body, const int64_t n)
 {
-  const int64_t i = (int64_t)blockIdx.x * BLOCK + threadIdx.x;
+  const unsigned per_xcd = gridDim.x >> 3;
+  const unsigned tile = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+  const int64_t i = (int64_t)tile * BLOCK + threadIdx.x;
   if (i < n)
     body(i);
 }
@@ -310,7 +317,7 @@ struct HipBackend {
   {
     if (n <= 0)
       return;
-    const int64_t grid = (n + BLOCK - 1) / BLOCK;
+    const int64_t grid = ((n + BLOCK - 1) / BLOCK + 7) / 8 * 8;
     const bool t = timing_on && slot != kSlotMisc;
     if (t)
       timer_start(timing->slot[slot]);

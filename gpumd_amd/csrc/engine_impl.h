@@ -282,6 +282,10 @@ private:
     md_.b1 = m.b1;
     md_.rc_r_max = (float)m.rc_radial_max;
     md_.rc_a_max = (float)m.rc_angular_max;
+    md_.uniform_rc = 1;
+    for (int t = 0; t < m.num_types; ++t)
+      if (m.rc_radial_f[t] != m.rc_radial_f[0] || m.rc_angular_f[t] != m.rc_angular_f[0])
+        md_.uniform_rc = 0;
     md_.c_rad = upload(m.c_rad);
     md_.c_ang = upload(m.c_ang);
     md_.w0 = upload(m.w0);
@@ -324,7 +328,7 @@ private:
     b_.nl_ang = dalloc<int>((size_t)b_.MN_ang * N);
     b_.rev_ang = dalloc<unsigned short>((size_t)b_.MN_ang * N);
     b_.nn_rad = dalloc<int>(N);
-    b_.rstash = dalloc<F4>((size_t)b_.MN_rad * N);
+    b_.rstash = dalloc<F4>((size_t)b_.MN_skin * N);
     b_.nn_angstep = dalloc<int>(N);
     b_.astash = dalloc<F4>((size_t)b_.MN_ang * N);
     b_.f12 = dalloc<F4>((size_t)b_.MN_ang * N);
@@ -378,7 +382,8 @@ private:
         nb[d] = 1;
       }
     }
-    const int64_t ncell = (int64_t)nb[0] * nb[1] * nb[2];
+    const int gb[3] = {(nb[0] + kBrick - 1) / kBrick, (nb[1] + kBrick - 1) / kBrick, (nb[2] + kBrick - 1) / kBrick};
+    const int64_t ncell = (int64_t)gb[0] * gb[1] * gb[2] * (kBrick * kBrick * kBrick); // padded to whole bricks
     if (ncell > ((int64_t)1 << 30))
       throw EngineError{-3, "too many cells"};
     if (ncell > ncell_cap_) {
@@ -391,6 +396,9 @@ private:
     b_.nbx = nb[0];
     b_.nby = nb[1];
     b_.nbz = nb[2];
+    b_.gbx = gb[0];
+    b_.gby = gb[1];
+    b_.gbz = gb[2];
     b_.rc_inv_cell = 2.0 / rc_list;
     be_.memset(b_.cell_count, 0, sizeof(int) * (ncell + 1));
     be_.memset(b_.cell_fill, 0, sizeof(int) * ncell);

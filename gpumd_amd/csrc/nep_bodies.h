@@ -57,7 +57,8 @@ enum FlagSlot { kFlagMoved = 0, kFlagOverflow = 1, kFlagMaxSkin = 2, kFlagMaxAng
 struct Bufs {
   int64_t N;
   // cell list
-  int nbx, nby, nbz;
+  int nbx, nby, nbz;    // cells per direction (Box::get_num_bins)
+  int gbx, gby, gbz;    // bricks (4x4x4 cells) per direction = ceil(nb / 4)
   double rc_inv_cell;
   float rc_skin_sq;     // float(double (rc_r_max+skin)^2), neighbor.cu:363
   float rc_askin_sq;    // (rc_a_max+skin)^2
@@ -70,7 +71,7 @@ struct Bufs {
   int MN_skin, MN_ang, MN_rad;
   int* nn_skin;  int* nl_skin;               // [MN_skin][N]
   int* nn_ang;   int* nl_ang;  unsigned short* rev_ang; // [MN_ang][N]
-  int* nn_rad;   F4* rstash;                 // per step: [MN_rad][N]
+  int* nn_rad;   F4* rstash;                 // per step: [MN_skin][N] pair records at their Verlet slots
   int* nn_angstep; F4* astash;               // per step: [MN_ang][N]
   F4* f12;                                   // [MN_ang][N]
   float* q;    // [dim][N]
@@ -162,6 +163,26 @@ struct VelocityVerletBody {
 // neighbour rebuild (find_cell_list + gpu_find_neighbor_ON1, neighbor.cu:42-215)
 // ------------------------------------------------------------------------------------------------
 
+// Cells are numbered brick-major: 4x4x4-cell bricks in x-fastest order, cells z,y,x inside a brick.
+// Atoms are stored in cell order, so 64 consecutive atoms (one wavefront) sit in a compact ~4x4x1
+// cell slab and their 5x5x5-cell neighbourhoods overlap almost completely: neighbour gathers
+// (posq, A-table, f12) of a wavefront hit the same few KB, and a contiguous range of workgroups
+// (what one XCD runs, see backend_hip) stays inside a few-MB working set of its private L2.
+constexpr int kBrick = 4;
+NEPMI_HD int cell_index(const Bufs& b, int cx, int cy, int cz)
+{
+  const int brick = ((cz >> 2) * b.gby + (cy >> 2)) * b.gbx + (cx >> 2);
+  return (brick << 6) | ((cz & 3) << 4) | ((cy & 3) << 2) | (cx & 3);
+}
+NEPMI_HD void cell_coords(const Bufs& b, int c, int& cx, int& cy, int& cz)
+{
+  const int brick = c >> 6, l = c & 63;
+  const int bx = brick % b.gbx, by = (brick / b.gbx) % b.gby, bz = brick / (b.gbx * b.gby);
+  cx = (bx << 2) | (l & 3);
+  cy = (by << 2) | ((l >> 2) & 3);
+  cz = (bz << 2) | (l >> 4);
+}
+
 struct BinAtomsBody {
   BoxD box;
   Bufs b;
@@ -170,7 +191,7 @@ struct BinAtomsBody {
   {
     int cx, cy, cz;
     cell_of(box, pos[i], pos[b.N + i], pos[2 * b.N + i], b.rc_inv_cell, b.nbx, b.nby, b.nbz, cx, cy, cz);
-    const int c = cx + b.nbx * (cy + b.nby * cz);
+    const int c = cell_index(b, cx, cy, cz);
     b.cid[i] = c;
     NEPMI_ATOMIC_ADD(&b.cell_count[c], 1);
   }
@@ -236,7 +257,8 @@ struct BuildListsBody {
     const int64_t N = b.N;
     const PosQ p1 = b.posq[k];
     const int c = b.cid[b.perm[k]];
-    const int cx = c % b.nbx, cy = (c / b.nbx) % b.nby, cz = c / (b.nbx * b.nby);
+    int cx, cy, cz;
+    cell_coords(b, c, cx, cy, cz);
     const int lx = box.pbc[0] ? 2 : 0, ly = box.pbc[1] ? 2 : 0, lz = box.pbc[2] ? 2 : 0;
     int cnt = 0, cnta = 0;
     for (int kz = -lz; kz <= lz; ++kz) {
@@ -248,7 +270,7 @@ struct BuildListsBody {
         for (int kx = -lx; kx <= lx; ++kx) {
           int x2 = cx + kx;
           if (x2 < 0) x2 += b.nbx; else if (x2 >= b.nbx) x2 -= b.nbx;
-          const int c2 = x2 + b.nbx * (y2 + b.nby * z2);
+          const int c2 = cell_index(b, x2, y2, z2);
           const int lo = b.cell_count[c2], hi = b.cell_count[c2 + 1];
           for (int j = lo; j < hi; ++j) {
             if (j == k)
@@ -334,6 +356,8 @@ struct CheckGatherBody {
 // force path
 // ------------------------------------------------------------------------------------------------
 
+constexpr int kGather = 4; // neighbour entries whose gathers are issued together
+
 NEPMI_HD float pair_rc(const float* rc, int t1, int t2) { return (rc[t1] + rc[t2]) * 0.5f; }
 
 // find_neighbor_list_large_box (radial half, nep.cu:436-486) + radial part of find_descriptor
@@ -365,53 +389,71 @@ struct RadialDescBody {
 
     const int nn = b.nn_skin[k];
     int cnt = 0;
-    for (int s = 0; s < nn; ++s) {
-      const int j = b.nl_skin[(int64_t)s * N + k];
-      const PosQ p2 = b.posq[j];
-      float x, y, z;
-      const float d2 = pair_geometry(box, p1, p2, x, y, z);
-      const int t2 = p2.type;
-      const float rc = (rc1 + m.rc_r[t2]) * 0.5f;
-      if (d2 >= rc * rc)
-        continue;
-      F4 e;
-      e.x = x;
-      e.y = y;
-      e.z = z;
-      e.w = (int)((unsigned)j | ((unsigned)t2 << kIdxBits));
-      if (cnt < b.MN_rad)
-        b.rstash[(int64_t)cnt * N + k] = e;
-      ++cnt;
-      const float d = sqrtf(d2);
-      const float rcinv = 1.0f / rc;
-      float fc;
-      cutoff_fc(rcinv, d, fc);
-      float fn[S::KRM + 1];
-      if (S::fixed)
-        basis_fn<S::KRM>(rcinv, d, fc, fn);
-      else
-        basis_fn_rt(KR, rcinv, d, fc, fn);
-      if (S::TS > 0) {
+    // The Verlet list is walked in chunks of kGather entries: all index loads of a chunk, then all
+    // position gathers, then the arithmetic -- kGather independent gathers in flight per lane
+    // instead of one dependent load pair per neighbour.
+    const int* __restrict__ nl = b.nl_skin + k;
+    const PosQ* __restrict__ posq = b.posq;
+    F4* __restrict__ rstash = b.rstash + k;
+    for (int s0 = 0; s0 < nn; s0 += kGather) {
+      int jj[kGather];
+      PosQ pp[kGather];
+      // entries past the end re-read the last valid slot (no branches around the loads)
 #pragma unroll
-        for (int t = 0; t < TSM; ++t) {
-          const float w = (TSM == 1 || t2 == t) ? 1.0f : 0.0f;
+      for (int u = 0; u < kGather; ++u)
+        jj[u] = nl[(int64_t)(s0 + u < nn ? s0 + u : nn - 1) * N];
 #pragma unroll
-          for (int kk = 0; kk <= S::KRM; ++kk)
-            Ssum[t][kk] = fmaf(w, fn[kk], Ssum[t][kk]);
-        }
-      } else {
-        const float* c = m.c_rad + (size_t)(t1 * m.T + t2) * (NR + 1) * (KR + 1);
-        for (int n = 0; n <= NR; ++n) {
-          float g = 0.0f;
-          for (int kk = 0; kk <= KR; ++kk)
-            g += fn[kk] * c[n * (KR + 1) + kk];
-          q[n] += g;
+      for (int u = 0; u < kGather; ++u)
+        pp[u] = posq[jj[u]];
+#pragma unroll
+      for (int u = 0; u < kGather; ++u) {
+        if (s0 + u >= nn)
+          continue;
+        const int j = jj[u];
+        const PosQ p2 = pp[u];
+        float x, y, z;
+        const float d2 = pair_geometry(box, p1, p2, x, y, z);
+        const int t2 = p2.type;
+        const float rc = m.uniform_rc ? m.rc_r_max : (rc1 + m.rc_r[t2]) * 0.5f;
+        const bool inside = d2 < rc * rc;
+        // The pair record goes to the Verlet slot itself (not a compacted slot): every lane of
+        // the wavefront stores to the same row -> one contiguous 1 KiB store per slot.
+        F4 e;
+        e.x = x;
+        e.y = y;
+        e.z = z;
+        e.w = inside ? (int)((unsigned)j | ((unsigned)t2 << kIdxBits)) : -1;
+        rstash[(int64_t)(s0 + u) * N] = e;
+        if (!inside)
+          continue;
+        ++cnt;
+        const float d = sqrtf(d2);
+        const float rcinv = 1.0f / rc;
+        float fc;
+        cutoff_fc(rcinv, d, fc);
+        float fn[S::KRM + 1];
+        if (S::fixed)
+          basis_fn<S::KRM>(rcinv, d, fc, fn);
+        else
+          basis_fn_rt(KR, rcinv, d, fc, fn);
+        if (S::TS > 0) {
+#pragma unroll
+          for (int t = 0; t < TSM; ++t) {
+            const float w = (TSM == 1 || t2 == t) ? 1.0f : 0.0f;
+#pragma unroll
+            for (int kk = 0; kk <= S::KRM; ++kk)
+              Ssum[t][kk] = fmaf(w, fn[kk], Ssum[t][kk]);
+          }
+        } else {
+          const float* c = m.c_rad + (size_t)(t1 * m.T + t2) * (NR + 1) * (KR + 1);
+          for (int n = 0; n <= NR; ++n) {
+            float g = 0.0f;
+            for (int kk = 0; kk <= KR; ++kk)
+              g += fn[kk] * c[n * (KR + 1) + kk];
+            q[n] += g;
+          }
         }
       }
-    }
-    if (cnt > b.MN_rad) {
-      NEPMI_ATOMIC_OR(&b.flags[kFlagOverflow], 4);
-      cnt = b.MN_rad;
     }
     b.nn_rad[k] = cnt;
 
@@ -426,7 +468,7 @@ struct RadialDescBody {
           qq[n] = 0.0f;
 #pragma unroll
         for (int t2 = 0; t2 < TSM; ++t2) {
-          const float* c = m.c_rad + (size_t)(tu * m.T + t2) * (S::NRM + 1) * (S::KRM + 1);
+          cfloat_ptr c = as_const(m.c_rad) + (size_t)(tu * m.T + t2) * (S::NRM + 1) * (S::KRM + 1);
 #pragma unroll
           for (int n = 0; n <= S::NRM; ++n)
 #pragma unroll
@@ -473,7 +515,7 @@ struct AngularDescBody {
       float x, y, z;
       const float d2 = pair_geometry(box, p1, p2, x, y, z);
       const int t2 = p2.type;
-      const float rc = (rc1 + m.rc_a[t2]) * 0.5f;
+      const float rc = m.uniform_rc ? m.rc_a_max : (rc1 + m.rc_a[t2]) * 0.5f;
       const bool inside = d2 < rc * rc;
       F4 e;
       e.x = x;
@@ -559,16 +601,17 @@ struct AnnBody {
     for (int tu = 0; tu < m.T; ++tu) {
       if (!NEPMI_WAVE_ANY(t1 == tu))
         continue;
-      const float* w0 = m.w0 + (size_t)tu * nneu * dim;
-      const float* b0 = m.b0 + (size_t)tu * nneu;
-      const float* w1 = m.w1 + (size_t)tu * nneu;
+      cfloat_ptr w0 = as_const(m.w0) + (size_t)tu * nneu * dim;
+      cfloat_ptr b0 = as_const(m.b0) + (size_t)tu * nneu;
+      cfloat_ptr w1 = as_const(m.w1) + (size_t)tu * nneu;
+      cfloat_ptr qs = as_const(m.qscale);
       float g[S::DIMM];
 #pragma unroll
       for (int d = 0; d < S::DIMM; ++d)
         g[d] = 0.0f;
       float e = 0.0f;
       for (int j = 0; j < nneu; ++j) {
-        const float* w = w0 + (size_t)j * dim;
+        cfloat_ptr w = w0 + (size_t)j * dim;
         float a = 0.0f;
 #pragma unroll
         for (int d = 0; d < S::DIMM; ++d) {
@@ -587,20 +630,20 @@ struct AnnBody {
           g[d] = fmaf(coef, w[d], g[d]);
         }
       }
-      e -= m.b1 + m.b1t[tu];
+      e -= m.b1 + as_const(m.b1t)[tu];
       if (t1 == tu) {
         E = e;
 #pragma unroll
         for (int d = 0; d < S::DIMM; ++d) {
           if (!S::fixed && d >= dim)
             break;
-          Fp[d] = g[d] * m.qscale[d];
+          Fp[d] = g[d] * qs[d];
         }
       }
       // radial force table for atoms of this type
       const int KRP = b.KRP;
       for (int t2 = 0; t2 < m.T; ++t2) {
-        const float* c = m.c_rad + (size_t)(tu * m.T + t2) * (NR + 1) * (KR + 1);
+        cfloat_ptr c = as_const(m.c_rad) + (size_t)(tu * m.T + t2) * (NR + 1) * (KR + 1);
 #pragma unroll
         for (int kk = 0; kk <= S::KRM; ++kk) {
           if (!S::fixed && kk > KR)
@@ -610,7 +653,7 @@ struct AnnBody {
           for (int n = 0; n <= S::NRM; ++n) {
             if (!S::fixed && n > NR)
               break;
-            a = fmaf(g[n] * m.qscale[n], c[n * (KR + 1) + kk], a);
+            a = fmaf(g[n] * qs[n], c[n * (KR + 1) + kk], a);
           }
           if (t1 == tu)
             b.atab[(size_t)k * (m.T * KRP) + t2 * KRP + kk] = a;
@@ -677,7 +720,7 @@ struct AngularForceBody {
         const float x = e.x, y = e.y, z = e.z;
         const float d = sqrtf(dot3f(x, x, y, y, z, z));
         const float dinv = 1.0f / d;
-        const float rc = (rc1 + m.rc_a[t2]) * 0.5f;
+        const float rc = m.uniform_rc ? m.rc_a_max : (rc1 + m.rc_a[t2]) * 0.5f;
         const float rcinv = 1.0f / rc;
         float fc, fcp;
         cutoff_fc_fcp(rcinv, d, fc, fcp);
@@ -788,58 +831,80 @@ struct ForceAssembleBody {
     float W[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 
     // ---- radial pairs ----
-    const int nr = b.nn_rad[k];
-    for (int sl = 0; sl < nr; ++sl) {
-      const F4 e = b.rstash[(int64_t)sl * N + k];
-      const unsigned wbits = (unsigned)e.w;
-      const int j = (int)(wbits & (unsigned)kIdxMask);
-      const int t2 = (int)(wbits >> kIdxBits);
-      const float x = e.x, y = e.y, z = e.z;
-      const float d = sqrtf(dot3f(x, x, y, y, z, z));
-      const float dinv = 1.0f / d;
-      const float rc = (rc1 + m.rc_r[t2]) * 0.5f;
-      const float rcinv = 1.0f / rc;
-      float fc, fcp;
-      cutoff_fc_fcp(rcinv, d, fc, fcp);
-      float fn[S::KRM + 1], fnp[S::KRM + 1];
-      if (S::fixed)
-        basis_fn_fnp<S::KRM>(rcinv, d, fc, fcp, fn, fnp);
-      else
-        basis_fn_fnp_rt(KR, rcinv, d, fc, fcp, fn, fnp);
-      const float* Aj = b.atab + (size_t)j * arow + t1 * KRP;
-      float s12 = 0.0f, s21 = 0.0f;
-      if (S::TS > 0) {
+    const int nr = b.nn_skin[k]; // pair records sit at their Verlet slots; w = -1 marks "outside rc"
+    const F4* __restrict__ rstash = b.rstash + k;
+    const float* __restrict__ atab = b.atab;
+    for (int s0 = 0; s0 < nr; s0 += kGather) {
+      F4 ee[kGather];
+      float Aj[kGather][S::KRM + 1];
 #pragma unroll
-        for (int t = 0; t < TSM; ++t) {
-          float a = 0.0f;
+      for (int u = 0; u < kGather; ++u)
+        ee[u] = rstash[(int64_t)(s0 + u < nr ? s0 + u : nr - 1) * N];
 #pragma unroll
-          for (int kk = 0; kk <= S::KRM; ++kk)
-            a = fmaf(fnp[kk], Aown[t][kk], a);
-          if (TSM == 1 || t2 == t)
-            s12 = a;
-        }
+      for (int u = 0; u < kGather; ++u) {
+        const int j = ee[u].w == -1 ? (int)k : (int)((unsigned)ee[u].w & (unsigned)kIdxMask);
+        const float* row = atab + (size_t)j * arow + t1 * KRP;
 #pragma unroll
-        for (int kk = 0; kk <= S::KRM; ++kk)
-          s21 = fmaf(fnp[kk], Aj[kk], s21);
-      } else {
-        const float* Ai = b.atab + (size_t)k * arow + t2 * KRP;
-        for (int kk = 0; kk <= KR; ++kk) {
-          s12 = fmaf(fnp[kk], Ai[kk], s12);
-          s21 = fmaf(fnp[kk], Aj[kk], s21);
+        for (int kk = 0; kk <= S::KRM; ++kk) {
+          if (!S::fixed && kk > KR)
+            break;
+          Aj[u][kk] = row[kk];
         }
       }
-      const float fs = (s12 + s21) * dinv; // f12 - f21 = fs * r12
-      const float bb = s21 * dinv;         // f21 = -bb * r12
-      F[0] = fmaf(fs, x, F[0]);
-      F[1] = fmaf(fs, y, F[1]);
-      F[2] = fmaf(fs, z, F[2]);
-      const float bx = bb * x, by = bb * y, bz = bb * z;
-      W[0] -= x * bx;
-      W[1] -= y * by;
-      W[2] -= z * bz;
-      W[3] -= x * by;
-      W[4] -= x * bz;
-      W[5] -= y * bz;
+#pragma unroll
+      for (int u = 0; u < kGather; ++u) {
+        if (s0 + u >= nr || ee[u].w == -1)
+          continue;
+        const F4 e = ee[u];
+        const unsigned wbits = (unsigned)e.w;
+        const int t2 = (int)(wbits >> kIdxBits);
+        const float x = e.x, y = e.y, z = e.z;
+        const float d = sqrtf(dot3f(x, x, y, y, z, z));
+        const float dinv = 1.0f / d;
+        const float rc = m.uniform_rc ? m.rc_r_max : (rc1 + m.rc_r[t2]) * 0.5f;
+        const float rcinv = 1.0f / rc;
+        float fc, fcp;
+        cutoff_fc_fcp(rcinv, d, fc, fcp);
+        float fn[S::KRM + 1], fnp[S::KRM + 1];
+        if (S::fixed)
+          basis_fn_fnp<S::KRM>(rcinv, d, fc, fcp, fn, fnp);
+        else
+          basis_fn_fnp_rt(KR, rcinv, d, fc, fcp, fn, fnp);
+        float s12 = 0.0f, s21 = 0.0f;
+        if (S::TS > 0) {
+#pragma unroll
+          for (int t = 0; t < TSM; ++t) {
+            float a = 0.0f;
+#pragma unroll
+            for (int kk = 0; kk <= S::KRM; ++kk)
+              a = fmaf(fnp[kk], Aown[t][kk], a);
+            if (TSM == 1 || t2 == t)
+              s12 = a;
+          }
+        } else {
+          const float* Ai = atab + (size_t)k * arow + t2 * KRP;
+          for (int kk = 0; kk <= KR; ++kk)
+            s12 = fmaf(fnp[kk], Ai[kk], s12);
+        }
+#pragma unroll
+        for (int kk = 0; kk <= S::KRM; ++kk) {
+          if (!S::fixed && kk > KR)
+            break;
+          s21 = fmaf(fnp[kk], Aj[u][kk], s21);
+        }
+        const float fs = (s12 + s21) * dinv; // f12 - f21 = fs * r12
+        const float bb = s21 * dinv;         // f21 = -bb * r12
+        F[0] = fmaf(fs, x, F[0]);
+        F[1] = fmaf(fs, y, F[1]);
+        F[2] = fmaf(fs, z, F[2]);
+        const float bx = bb * x, by = bb * y, bz = bb * z;
+        W[0] -= x * bx;
+        W[1] -= y * by;
+        W[2] -= z * bz;
+        W[3] -= x * by;
+        W[4] -= x * bz;
+        W[5] -= y * bz;
+      }
     }
     W[6] = W[3];
     W[7] = W[4];
@@ -914,11 +979,14 @@ struct ExportListsBody {
     const int64_t N = b.N;
     const int64_t i = b.perm[k];
     int cnt = 0;
-    const int total = which == 0 ? b.nn_rad[k] : which == 1 ? b.nn_ang[k] : b.nn_skin[k];
+    const int total = which == 1 ? b.nn_ang[k] : b.nn_skin[k];
     for (int s = 0; s < total; ++s) {
       int j;
       if (which == 0) {
-        j = (int)((unsigned)b.rstash[(int64_t)s * N + k].w & (unsigned)kIdxMask);
+        const int w = b.rstash[(int64_t)s * N + k].w;
+        if (w == -1)
+          continue;
+        j = (int)((unsigned)w & (unsigned)kIdxMask);
       } else if (which == 1) {
         if (!(b.astash[(int64_t)s * N + k].w & 1))
           continue;

@@ -26,6 +26,17 @@
 
 namespace nepmi {
 
+// Read-only model tables (weights, descriptor coefficients) are read through the CONSTANT address
+// space on the device: loads whose address is wave-uniform then become scalar (s_load) loads
+// feeding SGPR operands instead of 64 identical vector loads.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const __attribute__((address_space(4))) float* cfloat_ptr;
+NEPMI_HD cfloat_ptr as_const(const float* p) { return (cfloat_ptr)p; }
+#else
+typedef const float* cfloat_ptr;
+NEPMI_HD cfloat_ptr as_const(const float* p) { return p; }
+#endif
+
 constexpr int kNumHarm = 24;       // (L_max+1)^2 - 1 for L_max = 4
 constexpr int kIdxBits = 25;       // neighbour index bits in a packed pair word
 constexpr int kIdxMask = (1 << kIdxBits) - 1;
@@ -78,6 +89,7 @@ struct ModelD {
   float zbl_rc_inner, zbl_rc_outer;
   float b1;
   float rc_r_max, rc_a_max;
+  int uniform_rc; // every type has the same (rc_radial, rc_angular): pair cutoffs are constants
   const float* c_rad;  // [T*T][NR+1][KR+1]
   const float* c_ang;  // [T*T][NA+1][KA+1]
   const float* w0;     // [T][nneu][dim]
