@@ -40,6 +40,20 @@ __global__ void __launch_bounds__(BLOCK) nepmi_kernel(const Body body, const int
     body(i);
 }
 
+// Same mapping, for bodies that stage a read-only table (descriptor coefficients) in LDS first.
+template <int BLOCK, class Body>
+__global__ void __launch_bounds__(BLOCK) nepmi_kernel_lds(const Body body, const int64_t n)
+{
+  extern __shared__ __attribute__((aligned(16))) float nepmi_lds[];
+  body.lds_stage(nepmi_lds, (int)threadIdx.x, BLOCK);
+  __syncthreads();
+  const unsigned per_xcd = gridDim.x >> 3;
+  const unsigned tile = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+  const int64_t i = (int64_t)tile * BLOCK + threadIdx.x;
+  if (i < n)
+    body.run(i, (lds_cfloat_ptr)nepmi_lds);
+}
+
 // ---- exclusive scan of int32, in place: 3 kernels (block scan, scan of block sums, add) ----
 constexpr int kScanBlock = 256;
 constexpr int kScanItems = 8;
@@ -322,6 +336,26 @@ struct HipBackend {
     if (t)
       timer_start(timing->slot[slot]);
     hipLaunchKernelGGL((nepmi_kernel<BLOCK, Body>), dim3((unsigned)grid), dim3(BLOCK), 0, stream, body, n);
+    NEPMI_HIP_CHECK(hipGetLastError());
+    if (t)
+      timer_stop(timing->slot[slot]);
+  }
+
+  template <int BLOCK, class Body>
+  void launch_lds(int slot, int64_t n, const Body& body)
+  {
+    if (n <= 0)
+      return;
+    const int64_t grid = ((n + BLOCK - 1) / BLOCK + 7) / 8 * 8;
+    const size_t lds_bytes = ((size_t)body.lds_floats() * sizeof(float) + 15) / 16 * 16;
+    if (lds_bytes > 64 * 1024)
+      NEPMI_HIP_CHECK(hipFuncSetAttribute(
+        reinterpret_cast<const void*>(&nepmi_kernel_lds<BLOCK, Body>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (int)lds_bytes));
+    const bool t = timing_on;
+    if (t)
+      timer_start(timing->slot[slot]);
+    hipLaunchKernelGGL((nepmi_kernel_lds<BLOCK, Body>), dim3((unsigned)grid), dim3(BLOCK), lds_bytes, stream, body, n);
     NEPMI_HIP_CHECK(hipGetLastError());
     if (t)
       timer_stop(timing->slot[slot]);

@@ -310,7 +310,7 @@ private:
     b_.N = N;
     // Neighbor::initialize, neighbor.cu:824-833
     const double rcs = m.rc_radial_max + kSkin;
-    b_.MN_rad = m.MN_radial;
+    b_.MN_acomp = m.MN_angular;
     b_.MN_skin = (int)(m.MN_radial * rcs * rcs * rcs / (m.rc_radial_max * m.rc_radial_max * m.rc_radial_max));
     const double ras = m.rc_angular_max + kSkin;
     b_.MN_ang = (int)(m.MN_angular * ras * ras * ras / (m.rc_angular_max * m.rc_angular_max * m.rc_angular_max)) + 1;
@@ -328,10 +328,11 @@ private:
     b_.nl_ang = dalloc<int>((size_t)b_.MN_ang * N);
     b_.rev_ang = dalloc<unsigned short>((size_t)b_.MN_ang * N);
     b_.nn_rad = dalloc<int>(N);
-    b_.rstash = dalloc<F4>((size_t)b_.MN_skin * N);
+    b_.rstash = dalloc<F4>((size_t)(b_.MN_ang + b_.MN_skin) * N);
     b_.nn_angstep = dalloc<int>(N);
-    b_.astash = dalloc<F4>((size_t)b_.MN_ang * N);
-    b_.f12 = dalloc<F4>((size_t)b_.MN_ang * N);
+    b_.acomp = dalloc<F4>((size_t)b_.MN_acomp * N);
+    b_.amap = dalloc<unsigned short>((size_t)b_.MN_ang * N);
+    b_.f12 = dalloc<F4>((size_t)b_.MN_acomp * N);
     b_.q = dalloc<float>((size_t)m.dim * N);
     b_.fp = dalloc<float>((size_t)m.dim * N);
     b_.sbuf = dalloc<float>((size_t)(m.n_max_angular + 1) * kNumHarm * N);
@@ -353,8 +354,8 @@ private:
       std::snprintf(
         msg, sizeof msg,
         "neighbour list capacity exceeded (flags=%d; Verlet max %d of %d, angular Verlet max %d of %d, "
-        "radial capacity %d): increase MN in the cutoff line of nep.txt",
-        flags[kFlagOverflow], flags[kFlagMaxSkin], b_.MN_skin, flags[kFlagMaxAng], b_.MN_ang, b_.MN_rad);
+        "angular capacity %d): increase MN in the cutoff line of nep.txt",
+        flags[kFlagOverflow], flags[kFlagMaxSkin], b_.MN_skin, flags[kFlagMaxAng], b_.MN_ang, b_.MN_acomp);
       throw EngineError{-6, msg};
     }
   }
@@ -462,9 +463,9 @@ private:
   {
     be_.begin_region(kRegionForce);
     be_.template launch<64>(kSlotRadial, N_, RadialDescBody<S>{box_, md_, b_});
-    be_.template launch<64>(kSlotAngular, N_, AngularDescBody<S>{box_, md_, b_});
+    be_.template launch_lds<64>(kSlotAngular, N_, AngularDescBody<S>{md_, b_});
     be_.template launch<64>(kSlotAnn, N_, AnnBody<S>{md_, b_});
-    be_.template launch<64>(kSlotAngForce, N_, AngularForceBody<S>{md_, b_});
+    be_.template launch_lds<64>(kSlotAngForce, N_, AngularForceBody<S>{md_, b_});
     be_.template launch<64>(kSlotForce, N_, ForceAssembleBody<S>{md_, b_, pe, force, virial});
     be_.end_region(kRegionForce);
   }

@@ -68,12 +68,17 @@ struct Bufs {
   int* perm;            // [N] internal k -> caller index
   PosQ* posq;           // [N]
   double* x0s;          // [3][N] internal order, positions at the last rebuild
-  int MN_skin, MN_ang, MN_rad;
-  int* nn_skin;  int* nl_skin;               // [MN_skin][N]
-  int* nn_ang;   int* nl_ang;  unsigned short* rev_ang; // [MN_ang][N]
-  int* nn_rad;   F4* rstash;                 // per step: [MN_skin][N] pair records at their Verlet slots
-  int* nn_angstep; F4* astash;               // per step: [MN_ang][N]
-  F4* f12;                                   // [MN_ang][N]
+  // Verlet lists (rebuilt when an atom moved > skin/2), internal indices, [slot][atom]:
+  //   list A: candidates with d < rc_a + skin (angular AND radial), with reverse slots
+  //   list B: the remaining radial candidates, rc_a + skin <= d < rc_r + skin
+  int MN_skin, MN_ang, MN_acomp;
+  int* nn_ang;   int* nl_ang;  unsigned short* rev_ang; // A: [MN_ang][N]
+  int* nn_skin;  int* nl_skin;                          // B: [MN_skin][N]
+  // per step
+  int* nn_rad;   F4* rstash;   // pair records (r12, j | t2 << 25 or -1) at rows [A slots | MN_ang + B slots]
+  int* nn_angstep; F4* acomp;  // compacted angular pair records [MN_acomp][N]
+  unsigned short* amap;        // [MN_ang][N]: A slot -> compact angular slot of this step, 0xFFFF = none
+  F4* f12;                     // [MN_acomp][N] partial forces dU_i/dr_ij at compact slots
   float* q;    // [dim][N]
   float* fp;   // [dim][N]
   float* sbuf; // [(NA+1)*24][N]
@@ -83,6 +88,8 @@ struct Bufs {
   float* zbl;  // [10][N] (fx fy fz, vxx vyy vzz vxy vxz vyz, pe) when zbl enabled
   int* flags;  // [kNumFlags]
 };
+
+constexpr unsigned short kNoSlot = 0xFFFF;
 
 // ------------------------------------------------------------------------------------------------
 // streaming bodies on the caller's arrays
@@ -248,7 +255,8 @@ struct GatherSortedBody {
 
 // gpu_find_neighbor_ON1 (neighbor.cu:85-162) in internal indices: because atoms are stored in
 // cell order, the members of cell c are simply the index range [cell_start[c], cell_start[c+1]).
-// Writes the radial Verlet list (d < rc_r + skin) and the angular Verlet list (d < rc_a + skin).
+// The Verlet list (d < rc_r + skin) is written as two lists: A = also within rc_a + skin (the only
+// pairs that can become angular neighbours before the next rebuild), B = the rest.
 struct BuildListsBody {
   BoxD box;
   Bufs b;
@@ -260,7 +268,7 @@ struct BuildListsBody {
     int cx, cy, cz;
     cell_coords(b, c, cx, cy, cz);
     const int lx = box.pbc[0] ? 2 : 0, ly = box.pbc[1] ? 2 : 0, lz = box.pbc[2] ? 2 : 0;
-    int cnt = 0, cnta = 0;
+    int cnta = 0, cntb = 0;
     for (int kz = -lz; kz <= lz; ++kz) {
       int z2 = cz + kz;
       if (z2 < 0) z2 += b.nbz; else if (z2 >= b.nbz) z2 -= b.nbz;
@@ -279,32 +287,33 @@ struct BuildListsBody {
             float x, y, z;
             const float d2 = pair_geometry(box, p1, p2, x, y, z);
             if (d2 < b.rc_skin_sq) {
-              if (cnt < b.MN_skin)
-                b.nl_skin[(int64_t)cnt * N + k] = j;
-              ++cnt;
               if (d2 < b.rc_askin_sq) {
                 if (cnta < b.MN_ang)
                   b.nl_ang[(int64_t)cnta * N + k] = j;
                 ++cnta;
+              } else {
+                if (cntb < b.MN_skin)
+                  b.nl_skin[(int64_t)cntb * N + k] = j;
+                ++cntb;
               }
             }
           }
         }
       }
     }
-    if (cnt > b.MN_skin || cnta > b.MN_ang) {
-      NEPMI_ATOMIC_OR(&b.flags[kFlagOverflow], 1);
-      cnt = cnt > b.MN_skin ? b.MN_skin : cnt;
-      cnta = cnta > b.MN_ang ? b.MN_ang : cnta;
-    }
-    b.nn_skin[k] = cnt;
-    b.nn_ang[k] = cnta;
-    NEPMI_ATOMIC_MAX(&b.flags[kFlagMaxSkin], cnt);
+    NEPMI_ATOMIC_MAX(&b.flags[kFlagMaxSkin], cnta + cntb);
     NEPMI_ATOMIC_MAX(&b.flags[kFlagMaxAng], cnta);
+    if (cnta > b.MN_ang || cnta + cntb > b.MN_skin) {
+      NEPMI_ATOMIC_OR(&b.flags[kFlagOverflow], 1);
+      cnta = cnta > b.MN_ang ? b.MN_ang : cnta;
+      cntb = cntb > b.MN_skin ? b.MN_skin : cntb;
+    }
+    b.nn_ang[k] = cnta;
+    b.nn_skin[k] = cntb;
   }
 };
 
-// rev_ang[s][k] = slot of k in j's angular Verlet list (the pair test is exactly symmetric).
+// rev_ang[s][k] = slot of k in j's list A (the pair test is exactly symmetric).
 struct ReverseSlotsBody {
   Bufs b;
   NEPMI_HD void operator()(int64_t k) const
@@ -314,13 +323,13 @@ struct ReverseSlotsBody {
     for (int s = 0; s < nn; ++s) {
       const int j = b.nl_ang[(int64_t)s * N + k];
       const int nj = b.nn_ang[j];
-      int r = 65535;
+      int r = kNoSlot;
       for (int s2 = 0; s2 < nj; ++s2)
         if (b.nl_ang[(int64_t)s2 * N + j] == (int)k) {
           r = s2;
           break;
         }
-      if (r == 65535)
+      if (r == kNoSlot)
         NEPMI_ATOMIC_OR(&b.flags[kFlagOverflow], 2);
       b.rev_ang[(int64_t)s * N + k] = (unsigned short)r;
     }
@@ -358,10 +367,23 @@ struct CheckGatherBody {
 
 constexpr int kGather = 4; // neighbour entries whose gathers are issued together
 
-NEPMI_HD float pair_rc(const float* rc, int t1, int t2) { return (rc[t1] + rc[t2]) * 0.5f; }
+// c_ang staged in LDS: [T*T pairs][stride] with an odd stride so that lanes of different type
+// pairs land on different banks (lanes of the same pair read one address: broadcast).
+NEPMI_HD int cang_stride(const ModelD& m) { return ((m.NA + 1) * (m.KA + 1)) | 1; }
+NEPMI_HD int cang_floats(const ModelD& m) { return m.T * m.T * cang_stride(m); }
+NEPMI_HD void cang_stage(const ModelD& m, float* dst, int tid, int nth)
+{
+  const int per = (m.NA + 1) * (m.KA + 1), stride = cang_stride(m);
+  for (int idx = tid; idx < m.T * m.T * per; idx += nth) {
+    const int pair = idx / per, r = idx - pair * per;
+    dst[pair * stride + r] = m.c_ang[idx];
+  }
+}
 
-// find_neighbor_list_large_box (radial half, nep.cu:436-486) + radial part of find_descriptor
-// (nep.cu:488-547).
+// find_neighbor_list_large_box (nep.cu:436-486: the per-step radial AND angular membership test) +
+// radial part of find_descriptor (nep.cu:488-547).  Walks list A then list B; every candidate's
+// pair record goes to rstash at its Verlet row (coalesced), angular members are additionally
+// compacted into acomp (what the angular kernels iterate) and registered in amap.
 template <class S>
 struct RadialDescBody {
   BoxD box;
@@ -374,7 +396,7 @@ struct RadialDescBody {
     const int KR = S::fixed ? S::KR : m.KR;
     const PosQ p1 = b.posq[k];
     const int t1 = p1.type;
-    const float rc1 = m.rc_r[t1];
+    const float rc1 = m.rc_r[t1], rca1 = m.rc_a[t1];
     constexpr int TSM = S::TS > 0 ? S::TS : 1;
     float Ssum[TSM][S::KRM + 1];
     float q[S::NRM + 1];
@@ -387,27 +409,33 @@ struct RadialDescBody {
     for (int n = 0; n <= S::NRM; ++n)
       q[n] = 0.0f;
 
-    const int nn = b.nn_skin[k];
-    int cnt = 0;
-    // The Verlet list is walked in chunks of kGather entries: all index loads of a chunk, then all
-    // position gathers, then the arithmetic -- kGather independent gathers in flight per lane
-    // instead of one dependent load pair per neighbour.
-    const int* __restrict__ nl = b.nl_skin + k;
+    const int na = b.nn_ang[k], nb = b.nn_skin[k];
+    const int nn = na + nb;
+    int cnt = 0, ca = 0;
+    // The lists are walked in chunks of kGather entries: all index loads of a chunk, then all
+    // position gathers, then the arithmetic -- kGather independent gathers in flight per lane.
+    const int* __restrict__ nlA = b.nl_ang + k;
+    const int* __restrict__ nlB = b.nl_skin + k;
     const PosQ* __restrict__ posq = b.posq;
     F4* __restrict__ rstash = b.rstash + k;
+    F4* __restrict__ acomp = b.acomp + k;
+    unsigned short* __restrict__ amap = b.amap + k;
     for (int s0 = 0; s0 < nn; s0 += kGather) {
       int jj[kGather];
       PosQ pp[kGather];
       // entries past the end re-read the last valid slot (no branches around the loads)
 #pragma unroll
-      for (int u = 0; u < kGather; ++u)
-        jj[u] = nl[(int64_t)(s0 + u < nn ? s0 + u : nn - 1) * N];
+      for (int u = 0; u < kGather; ++u) {
+        const int idx = s0 + u < nn ? s0 + u : nn - 1;
+        jj[u] = idx < na ? nlA[(int64_t)idx * N] : nlB[(int64_t)(idx - na) * N];
+      }
 #pragma unroll
       for (int u = 0; u < kGather; ++u)
         pp[u] = posq[jj[u]];
 #pragma unroll
       for (int u = 0; u < kGather; ++u) {
-        if (s0 + u >= nn)
+        const int idx = s0 + u;
+        if (idx >= nn)
           continue;
         const int j = jj[u];
         const PosQ p2 = pp[u];
@@ -416,14 +444,27 @@ struct RadialDescBody {
         const int t2 = p2.type;
         const float rc = m.uniform_rc ? m.rc_r_max : (rc1 + m.rc_r[t2]) * 0.5f;
         const bool inside = d2 < rc * rc;
-        // The pair record goes to the Verlet slot itself (not a compacted slot): every lane of
+        // The pair record goes to the Verlet row itself (not a compacted slot): every lane of
         // the wavefront stores to the same row -> one contiguous 1 KiB store per slot.
         F4 e;
         e.x = x;
         e.y = y;
         e.z = z;
         e.w = inside ? (int)((unsigned)j | ((unsigned)t2 << kIdxBits)) : -1;
-        rstash[(int64_t)(s0 + u) * N] = e;
+        const int row = idx < na ? idx : b.MN_ang + (idx - na);
+        rstash[(int64_t)row * N] = e;
+        if (idx < na) {
+          const float rca = m.uniform_rc ? m.rc_a_max : (rca1 + m.rc_a[t2]) * 0.5f;
+          unsigned short slot = kNoSlot;
+          if (d2 < rca * rca) {
+            if (ca < b.MN_acomp) {
+              acomp[(int64_t)ca * N] = e;
+              slot = (unsigned short)ca;
+            }
+            ++ca;
+          }
+          amap[(int64_t)idx * N] = slot;
+        }
         if (!inside)
           continue;
         ++cnt;
@@ -455,7 +496,12 @@ struct RadialDescBody {
         }
       }
     }
+    if (ca > b.MN_acomp) {
+      NEPMI_ATOMIC_OR(&b.flags[kFlagOverflow], 4);
+      ca = b.MN_acomp;
+    }
     b.nn_rad[k] = cnt;
+    b.nn_angstep[k] = ca;
 
     if (S::TS > 0) {
       // q[n] = sum_t2 sum_k c[t1][t2][n][k] S[t2][k]; type loop is wave-uniform => scalar loads
@@ -487,47 +533,45 @@ struct RadialDescBody {
   }
 };
 
-// find_neighbor_list_large_box (angular half) + angular part of find_descriptor (nep.cu:549-640)
+// angular part of find_descriptor (nep.cu:549-640) on the compacted angular pair records:
+// no gathers, no geometry, every lane of the wavefront has real work in every iteration.
 template <class S>
 struct AngularDescBody {
-  BoxD box;
   ModelD m;
   Bufs b;
-  NEPMI_HD void operator()(int64_t k) const
+  static constexpr bool kUsesLds = true;
+  NEPMI_HD int lds_floats() const { return cang_floats(m); }
+  NEPMI_HD void lds_stage(float* dst, int tid, int nth) const { cang_stage(m, dst, tid, nth); }
+
+  template <class LP>
+  NEPMI_HD void run(int64_t k, LP cang) const
   {
     const int64_t N = b.N;
     const int NR = S::fixed ? S::NR : m.NR;
     const int NA = S::fixed ? S::NA : m.NA;
     const int KA = S::fixed ? S::KA : m.KA;
-    const PosQ p1 = b.posq[k];
-    const int t1 = p1.type;
+    const int t1 = b.posq[k].type;
     const float rc1 = m.rc_a[t1];
+    const int cstride = cang_stride(m);
     float s[(S::NAM + 1) * kNumHarm];
 #pragma unroll
     for (int a = 0; a < (S::NAM + 1) * kNumHarm; ++a)
       s[a] = 0.0f;
 
-    const int nn = b.nn_ang[k];
-    int cnt = 0;
-    for (int sl = 0; sl < nn; ++sl) {
-      const int j = b.nl_ang[(int64_t)sl * N + k];
-      const PosQ p2 = b.posq[j];
-      float x, y, z;
-      const float d2 = pair_geometry(box, p1, p2, x, y, z);
-      const int t2 = p2.type;
-      const float rc = m.uniform_rc ? m.rc_a_max : (rc1 + m.rc_a[t2]) * 0.5f;
-      const bool inside = d2 < rc * rc;
-      F4 e;
-      e.x = x;
-      e.y = y;
-      e.z = z;
-      e.w = inside ? (1 | (t2 << 8)) : 0;
-      b.astash[(int64_t)sl * N + k] = e;
-      if (!inside)
-        continue;
-      ++cnt;
-      const float d = sqrtf(d2);
+    const int na = b.nn_angstep[k];
+    const F4* __restrict__ acomp = b.acomp + k;
+    F4 e_next;
+    if (na > 0)
+      e_next = acomp[0];
+    for (int a = 0; a < na; ++a) {
+      const F4 e = e_next;
+      if (a + 1 < na)
+        e_next = acomp[(int64_t)(a + 1) * N]; // in flight while this record is processed
+      const int t2 = (int)((unsigned)e.w >> kIdxBits);
+      const float x = e.x, y = e.y, z = e.z;
+      const float d = sqrtf(dot3f(x, x, y, y, z, z));
       const float dinv = 1.0f / d;
+      const float rc = m.uniform_rc ? m.rc_a_max : (rc1 + m.rc_a[t2]) * 0.5f;
       const float rcinv = 1.0f / rc;
       float fc;
       cutoff_fc(rcinv, d, fc);
@@ -538,7 +582,7 @@ struct AngularDescBody {
         basis_fn_rt(KA, rcinv, d, fc, fn);
       float bh[kNumHarm];
       harmonics(x * dinv, y * dinv, z * dinv, bh);
-      const float* c = m.c_ang + (size_t)(t1 * m.T + t2) * (NA + 1) * (KA + 1);
+      LP c = cang + (t1 * m.T + t2) * cstride;
 #pragma unroll
       for (int n = 0; n <= S::NAM; ++n) {
         if (!S::fixed && n > NA)
@@ -548,22 +592,21 @@ struct AngularDescBody {
         for (int kk = 0; kk <= S::KAM; ++kk) {
           if (!S::fixed && kk > KA)
             break;
-          g += fn[kk] * c[n * (KA + 1) + kk];
+          g = fmaf(fn[kk], c[n * (KA + 1) + kk], g);
         }
 #pragma unroll
-        for (int a = 0; a < kNumHarm; ++a)
-          s[n * kNumHarm + a] = fmaf(g, bh[a], s[n * kNumHarm + a]);
+        for (int h = 0; h < kNumHarm; ++h)
+          s[n * kNumHarm + h] = fmaf(g, bh[h], s[n * kNumHarm + h]);
       }
     }
-    b.nn_angstep[k] = cnt;
 
 #pragma unroll
     for (int n = 0; n <= S::NAM; ++n) {
       if (!S::fixed && n > NA)
         break;
 #pragma unroll
-      for (int a = 0; a < kNumHarm; ++a)
-        b.sbuf[(int64_t)(n * kNumHarm + a) * N + k] = s[n * kNumHarm + a];
+      for (int h = 0; h < kNumHarm; ++h)
+        b.sbuf[(int64_t)(n * kNumHarm + h) * N + k] = s[n * kNumHarm + h];
       float qn[6];
       invariants(m, &s[n * kNumHarm], qn, 1);
       for (int L = 0; L < m.numL; ++L) {
@@ -677,7 +720,12 @@ template <class S>
 struct AngularForceBody {
   ModelD m;
   Bufs b;
-  NEPMI_HD void operator()(int64_t k) const
+  static constexpr bool kUsesLds = true;
+  NEPMI_HD int lds_floats() const { return cang_floats(m); }
+  NEPMI_HD void lds_stage(float* dst, int tid, int nth) const { cang_stage(m, dst, tid, nth); }
+
+  template <class LP>
+  NEPMI_HD void run(int64_t k, LP cang) const
   {
     const int64_t N = b.N;
     const int NR = S::fixed ? S::NR : m.NR;
@@ -685,6 +733,7 @@ struct AngularForceBody {
     const int KA = S::fixed ? S::KA : m.KA;
     const int t1 = b.posq[k].type;
     const float rc1 = m.rc_a[t1];
+    const int cstride = cang_stride(m);
 
     float G[(S::NAM + 1) * kNumHarm];
 #pragma unroll
@@ -692,11 +741,12 @@ struct AngularForceBody {
       if (!S::fixed && n > NA)
         break;
       float fpn[6];
-      for (int L = 0; L < m.numL; ++L)
-        fpn[L] = b.fp[(int64_t)((NR + 1) + L * (NA + 1) + n) * N + k];
 #pragma unroll
-      for (int a = 0; a < kNumHarm; ++a)
-        G[n * kNumHarm + a] = b.sbuf[(int64_t)(n * kNumHarm + a) * N + k];
+      for (int L = 0; L < 6; ++L)
+        fpn[L] = L < m.numL ? b.fp[(int64_t)((NR + 1) + L * (NA + 1) + n) * N + k] : 0.0f;
+#pragma unroll
+      for (int h = 0; h < kNumHarm; ++h)
+        G[n * kNumHarm + h] = b.sbuf[(int64_t)(n * kNumHarm + h) * N + k];
       invariants_adjoint(m, fpn, 1, &G[n * kNumHarm]);
     }
 
@@ -708,86 +758,89 @@ struct AngularForceBody {
       pzi = powf((float)zi, 0.23f);
     }
 
-    const int nn = b.nn_ang[k];
-    for (int sl = 0; sl < nn; ++sl) {
-      const F4 e = b.astash[(int64_t)sl * N + k];
-      const int flag = e.w;
-      F4 out;
-      out.x = out.y = out.z = 0.0f;
-      out.w = 0;
-      if (flag & 1) {
-        const int t2 = flag >> 8;
-        const float x = e.x, y = e.y, z = e.z;
-        const float d = sqrtf(dot3f(x, x, y, y, z, z));
-        const float dinv = 1.0f / d;
-        const float rc = m.uniform_rc ? m.rc_a_max : (rc1 + m.rc_a[t2]) * 0.5f;
-        const float rcinv = 1.0f / rc;
-        float fc, fcp;
-        cutoff_fc_fcp(rcinv, d, fc, fcp);
-        float fn[S::KAM + 1], fnp[S::KAM + 1];
-        if (S::fixed)
-          basis_fn_fnp<S::KAM>(rcinv, d, fc, fcp, fn, fnp);
-        else
-          basis_fn_fnp_rt(KA, rcinv, d, fc, fcp, fn, fnp);
-        float P[kNumHarm], Q[kNumHarm];
+    const int na = b.nn_angstep[k];
+    const F4* __restrict__ acomp = b.acomp + k;
+    F4* __restrict__ f12 = b.f12 + k;
+    F4 e_next;
+    if (na > 0)
+      e_next = acomp[0];
+    for (int a = 0; a < na; ++a) {
+      const F4 e = e_next;
+      if (a + 1 < na)
+        e_next = acomp[(int64_t)(a + 1) * N];
+      const int t2 = (int)((unsigned)e.w >> kIdxBits);
+      const float x = e.x, y = e.y, z = e.z;
+      const float d = sqrtf(dot3f(x, x, y, y, z, z));
+      const float dinv = 1.0f / d;
+      const float rc = m.uniform_rc ? m.rc_a_max : (rc1 + m.rc_a[t2]) * 0.5f;
+      const float rcinv = 1.0f / rc;
+      float fc, fcp;
+      cutoff_fc_fcp(rcinv, d, fc, fcp);
+      float fn[S::KAM + 1], fnp[S::KAM + 1];
+      if (S::fixed)
+        basis_fn_fnp<S::KAM>(rcinv, d, fc, fcp, fn, fnp);
+      else
+        basis_fn_fnp_rt(KA, rcinv, d, fc, fcp, fn, fnp);
+      float P[kNumHarm], Q[kNumHarm];
 #pragma unroll
-        for (int a = 0; a < kNumHarm; ++a)
-          P[a] = Q[a] = 0.0f;
-        const float* c = m.c_ang + (size_t)(t1 * m.T + t2) * (NA + 1) * (KA + 1);
+      for (int h = 0; h < kNumHarm; ++h)
+        P[h] = Q[h] = 0.0f;
+      LP c = cang + (t1 * m.T + t2) * cstride;
 #pragma unroll
-        for (int n = 0; n <= S::NAM; ++n) {
-          if (!S::fixed && n > NA)
+      for (int n = 0; n <= S::NAM; ++n) {
+        if (!S::fixed && n > NA)
+          break;
+        float g = 0.0f, gp = 0.0f;
+#pragma unroll
+        for (int kk = 0; kk <= S::KAM; ++kk) {
+          if (!S::fixed && kk > KA)
             break;
-          float g = 0.0f, gp = 0.0f;
-#pragma unroll
-          for (int kk = 0; kk <= S::KAM; ++kk) {
-            if (!S::fixed && kk > KA)
-              break;
-            const float cc = c[n * (KA + 1) + kk];
-            g = fmaf(fn[kk], cc, g);
-            gp = fmaf(fnp[kk], cc, gp);
-          }
-#pragma unroll
-          for (int a = 0; a < kNumHarm; ++a) {
-            P[a] = fmaf(G[n * kNumHarm + a], g, P[a]);
-            Q[a] = fmaf(G[n * kNumHarm + a], gp, Q[a]);
-          }
+          const float cc = c[n * (KA + 1) + kk];
+          g = fmaf(fn[kk], cc, g);
+          gp = fmaf(fnp[kk], cc, gp);
         }
-        const float ux = x * dinv, uy = y * dinv, uz = z * dinv;
-        float w, vx, vy, vz;
-        harmonics_contract(ux, uy, uz, P, Q, w, vx, vy, vz);
-        const float udv = ux * vx + uy * vy + uz * vz;
-        out.x = ux * w + (vx - ux * udv) * dinv;
-        out.y = uy * w + (vy - uy * udv) * dinv;
-        out.z = uz * w + (vz - uz * udv) * dinv;
-
-        if (m.zbl_enabled) {
-          const int zj = m.atomic_number[t2];
-          const float a_inv = (pzi + powf((float)zj, 0.23f)) * 2.134563f;
-          const float zizj = 14.399645f * (float)zi * (float)zj;
-          float f, fp;
-          if (m.zbl_flexible) {
-            const int ta = t1 < t2 ? t1 : t2, tb = t1 < t2 ? t2 : t1;
-            const int zidx = ta * m.T - (ta * (ta - 1)) / 2 + (tb - ta);
-            zbl_pair(m.zbl_para + 10 * zidx, zizj, a_inv, 0.0f, 0.0f, d, dinv, f, fp);
-          } else {
-            zbl_pair(nullptr, zizj, a_inv, m.zbl_rc_inner, m.zbl_rc_outer, d, dinv, f, fp);
-          }
-          const float f2 = fp * dinv * 0.5f;
-          const float fx = x * f2, fy = y * f2, fz = z * f2; // f12; f21 = -f12
-          zf[0] += fx + fx;
-          zf[1] += fy + fy;
-          zf[2] += fz + fz;
-          zv[0] -= x * fx;
-          zv[1] -= y * fy;
-          zv[2] -= z * fz;
-          zv[3] -= x * fy;
-          zv[4] -= x * fz;
-          zv[5] -= y * fz;
-          zpe += f * 0.5f;
+#pragma unroll
+        for (int h = 0; h < kNumHarm; ++h) {
+          P[h] = fmaf(G[n * kNumHarm + h], g, P[h]);
+          Q[h] = fmaf(G[n * kNumHarm + h], gp, Q[h]);
         }
       }
-      b.f12[(int64_t)sl * N + k] = out;
+      const float ux = x * dinv, uy = y * dinv, uz = z * dinv;
+      float w, vx, vy, vz;
+      harmonics_contract(ux, uy, uz, P, Q, w, vx, vy, vz);
+      const float udv = ux * vx + uy * vy + uz * vz;
+      F4 out;
+      out.x = ux * w + (vx - ux * udv) * dinv;
+      out.y = uy * w + (vy - uy * udv) * dinv;
+      out.z = uz * w + (vz - uz * udv) * dinv;
+      out.w = 0;
+      f12[(int64_t)a * N] = out;
+
+      if (m.zbl_enabled) {
+        const int zj = m.atomic_number[t2];
+        const float a_inv = (pzi + powf((float)zj, 0.23f)) * 2.134563f;
+        const float zizj = 14.399645f * (float)zi * (float)zj;
+        float f, fp;
+        if (m.zbl_flexible) {
+          const int ta = t1 < t2 ? t1 : t2, tb = t1 < t2 ? t2 : t1;
+          const int zidx = ta * m.T - (ta * (ta - 1)) / 2 + (tb - ta);
+          zbl_pair(m.zbl_para + 10 * zidx, zizj, a_inv, 0.0f, 0.0f, d, dinv, f, fp);
+        } else {
+          zbl_pair(nullptr, zizj, a_inv, m.zbl_rc_inner, m.zbl_rc_outer, d, dinv, f, fp);
+        }
+        const float f2 = fp * dinv * 0.5f;
+        const float fx = x * f2, fy = y * f2, fz = z * f2; // f12; f21 = -f12
+        zf[0] += fx + fx;
+        zf[1] += fy + fy;
+        zf[2] += fz + fz;
+        zv[0] -= x * fx;
+        zv[1] -= y * fy;
+        zv[2] -= z * fz;
+        zv[3] -= x * fy;
+        zv[4] -= x * fz;
+        zv[5] -= y * fz;
+        zpe += f * 0.5f;
+      }
     }
     if (m.zbl_enabled) {
 #pragma unroll
@@ -803,6 +856,9 @@ struct AngularForceBody {
 
 // find_force_radial (nep.cu:661-772) + gpu_find_force_many_body (potential.cu:170-297) + the
 // accumulation into the caller's FP64 per-atom arrays (potential += , force +=, virial +=).
+// One walk over the pair records (list A rows, then list B rows): every record inside rc_r gives
+// the radial pair force from the two per-atom tables A_i, A_j; records of list A that are angular
+// members this step (amap) add f12 - f21, with f21 found through the static reverse slot.
 template <class S>
 struct ForceAssembleBody {
   ModelD m;
@@ -828,18 +884,25 @@ struct ForceAssembleBody {
           Aown[t][kk] = b.atab[(size_t)k * arow + t * KRP + kk];
     }
     float F[3] = {0, 0, 0};
-    float W[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    float W[6] = {0, 0, 0, 0, 0, 0};  // radial part: symmetric (xx yy zz xy xz yz)
+    float Wa[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}; // angular part: xx yy zz xy xz yz yx zx zy
 
-    // ---- radial pairs ----
-    const int nr = b.nn_skin[k]; // pair records sit at their Verlet slots; w = -1 marks "outside rc"
+    const int na = b.nn_ang[k], nbn = b.nn_skin[k];
+    const int nn = na + nbn;
     const F4* __restrict__ rstash = b.rstash + k;
     const float* __restrict__ atab = b.atab;
-    for (int s0 = 0; s0 < nr; s0 += kGather) {
+    const unsigned short* __restrict__ amap = b.amap;
+    const unsigned short* __restrict__ rev = b.rev_ang + k;
+    const F4* __restrict__ f12 = b.f12;
+    for (int s0 = 0; s0 < nn; s0 += kGather) {
       F4 ee[kGather];
       float Aj[kGather][S::KRM + 1];
 #pragma unroll
-      for (int u = 0; u < kGather; ++u)
-        ee[u] = rstash[(int64_t)(s0 + u < nr ? s0 + u : nr - 1) * N];
+      for (int u = 0; u < kGather; ++u) {
+        const int idx = s0 + u < nn ? s0 + u : nn - 1;
+        const int row = idx < na ? idx : b.MN_ang + (idx - na);
+        ee[u] = rstash[(int64_t)row * N];
+      }
 #pragma unroll
       for (int u = 0; u < kGather; ++u) {
         const int j = ee[u].w == -1 ? (int)k : (int)((unsigned)ee[u].w & (unsigned)kIdxMask);
@@ -853,10 +916,12 @@ struct ForceAssembleBody {
       }
 #pragma unroll
       for (int u = 0; u < kGather; ++u) {
-        if (s0 + u >= nr || ee[u].w == -1)
+        const int idx = s0 + u;
+        if (idx >= nn || ee[u].w == -1)
           continue;
         const F4 e = ee[u];
         const unsigned wbits = (unsigned)e.w;
+        const int j = (int)(wbits & (unsigned)kIdxMask);
         const int t2 = (int)(wbits >> kIdxBits);
         const float x = e.x, y = e.y, z = e.z;
         const float d = sqrtf(dot3f(x, x, y, y, z, z));
@@ -904,42 +969,43 @@ struct ForceAssembleBody {
         W[3] -= x * by;
         W[4] -= x * bz;
         W[5] -= y * bz;
-      }
-    }
-    W[6] = W[3];
-    W[7] = W[4];
-    W[8] = W[5];
 
-    // ---- angular pairs: f12 - f21 through the reverse slot ----
-    const int na = b.nn_ang[k];
-    for (int sl = 0; sl < na; ++sl) {
-      const F4 e = b.astash[(int64_t)sl * N + k];
-      if (!(e.w & 1))
-        continue;
-      const int j = b.nl_ang[(int64_t)sl * N + k];
-      const int rs = b.rev_ang[(int64_t)sl * N + k];
-      const F4 f12 = b.f12[(int64_t)sl * N + k];
-      const F4 f21 = b.f12[(int64_t)rs * N + j];
-      F[0] += f12.x - f21.x;
-      F[1] += f12.y - f21.y;
-      F[2] += f12.z - f21.z;
-      W[0] += e.x * f21.x;
-      W[1] += e.y * f21.y;
-      W[2] += e.z * f21.z;
-      W[3] += e.x * f21.y;
-      W[4] += e.x * f21.z;
-      W[5] += e.y * f21.z;
-      W[6] += e.y * f21.x;
-      W[7] += e.z * f21.x;
-      W[8] += e.z * f21.y;
+        if (idx < na) {
+          const unsigned short a = amap[(int64_t)idx * N + k];
+          if (a != kNoSlot) {
+            const int rs = rev[(int64_t)idx * N];
+            const unsigned short ap = amap[(int64_t)rs * N + j];
+            const F4 fa = f12[(int64_t)a * N + k];
+            const F4 fb = f12[(int64_t)ap * N + j];
+            F[0] += fa.x - fb.x;
+            F[1] += fa.y - fb.y;
+            F[2] += fa.z - fb.z;
+            Wa[0] += x * fb.x;
+            Wa[1] += y * fb.y;
+            Wa[2] += z * fb.z;
+            Wa[3] += x * fb.y;
+            Wa[4] += x * fb.z;
+            Wa[5] += y * fb.z;
+            Wa[6] += y * fb.x;
+            Wa[7] += z * fb.x;
+            Wa[8] += z * fb.y;
+          }
+        }
+      }
     }
 
     double E = (double)b.pe_i[k];
     double Fd[3] = {(double)F[0], (double)F[1], (double)F[2]};
     double Wd[9];
-#pragma unroll
-    for (int d = 0; d < 9; ++d)
-      Wd[d] = (double)W[d];
+    Wd[0] = (double)(W[0] + Wa[0]);
+    Wd[1] = (double)(W[1] + Wa[1]);
+    Wd[2] = (double)(W[2] + Wa[2]);
+    Wd[3] = (double)(W[3] + Wa[3]);
+    Wd[4] = (double)(W[4] + Wa[4]);
+    Wd[5] = (double)(W[5] + Wa[5]);
+    Wd[6] = (double)(W[3] + Wa[6]);
+    Wd[7] = (double)(W[4] + Wa[7]);
+    Wd[8] = (double)(W[5] + Wa[8]);
     if (m.zbl_enabled) {
 #pragma unroll
       for (int d = 0; d < 3; ++d)
@@ -978,21 +1044,23 @@ struct ExportListsBody {
   {
     const int64_t N = b.N;
     const int64_t i = b.perm[k];
+    const int na = b.nn_ang[k], nb = b.nn_skin[k];
     int cnt = 0;
-    const int total = which == 1 ? b.nn_ang[k] : b.nn_skin[k];
+    const int total = which == 1 ? b.nn_angstep[k] : na + nb;
     for (int s = 0; s < total; ++s) {
       int j;
-      if (which == 0) {
-        const int w = b.rstash[(int64_t)s * N + k].w;
-        if (w == -1)
-          continue;
-        j = (int)((unsigned)w & (unsigned)kIdxMask);
-      } else if (which == 1) {
-        if (!(b.astash[(int64_t)s * N + k].w & 1))
-          continue;
-        j = b.nl_ang[(int64_t)s * N + k];
+      if (which == 1) {
+        j = (int)((unsigned)b.acomp[(int64_t)s * N + k].w & (unsigned)kIdxMask);
       } else {
-        j = b.nl_skin[(int64_t)s * N + k];
+        const int row = s < na ? s : b.MN_ang + (s - na);
+        if (which == 0) {
+          const int w = b.rstash[(int64_t)row * N + k].w;
+          if (w == -1)
+            continue;
+          j = (int)((unsigned)w & (unsigned)kIdxMask);
+        } else {
+          j = s < na ? b.nl_ang[(int64_t)s * N + k] : b.nl_skin[(int64_t)(s - na) * N + k];
+        }
       }
       const int jc = b.perm[j];
       if (cnt < ld) {

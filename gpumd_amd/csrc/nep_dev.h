@@ -32,9 +32,12 @@ namespace nepmi {
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef const __attribute__((address_space(4))) float* cfloat_ptr;
 NEPMI_HD cfloat_ptr as_const(const float* p) { return (cfloat_ptr)p; }
+// tables staged in LDS by the workgroup are read through an LDS-typed pointer (ds_read, not flat)
+typedef const __attribute__((address_space(3))) float* lds_cfloat_ptr;
 #else
 typedef const float* cfloat_ptr;
 NEPMI_HD cfloat_ptr as_const(const float* p) { return p; }
+typedef const float* lds_cfloat_ptr;
 #endif
 
 constexpr int kNumHarm = 24;       // (L_max+1)^2 - 1 for L_max = 4

@@ -9,6 +9,7 @@
 // refuses to run without a gfx950 device.
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 #include "../../gpumd_amd/csrc/nep_bodies.h"
 
@@ -36,6 +37,16 @@ struct HostLoopBackend {
   {
     for (int64_t i = 0; i < n; ++i)
       body(i);
+  }
+
+  // bodies with a workgroup-staged table: the "LDS" is an ordinary host buffer here
+  template <int BLOCK, class Body>
+  void launch_lds(int, int64_t n, const Body& body)
+  {
+    std::vector<float> lds((size_t)body.lds_floats() + 1);
+    body.lds_stage(lds.data(), 0, 1);
+    for (int64_t i = 0; i < n; ++i)
+      body.run(i, (const float*)lds.data());
   }
 
   void exclusive_scan(int* data, int64_t n, int*)
