@@ -176,10 +176,19 @@ def main():
         force_kernels = [k for k in kern if k in per_kernel and k not in ("velocity_verlet", "gather_skin_check")]
         dom = max(force_kernels, key=lambda k: kern[k]["avg_ms"] * kern[k]["launches"]) if force_kernels else None
         roofline = None
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if dom and os.path.exists(tfile):
+            # HBM-side bytes per launch from a separate rocprofv3 PMC pass of this same command
+            # (profiles/*_pmc_*.csv); only meaningful for the 1,024,000-atom workload it was taken on
+            tj = json.load(open(tfile))
+            if tj.get("atoms") == n and dom in tj.get("kernels", {}):
+                traffic = tj["kernels"][dom]["hbm_bytes_per_launch"]
         if dom:
             achieved = per_kernel[dom] * n / (kern[dom]["avg_ms"] * 1e-3) / 1e9
             roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                        "algorithmic_bytes_per_launch": per_kernel[dom] * n,
                         "algorithmic_bytes_per_atom": per_kernel[dom], "avg_launch_ms": kern[dom]["avg_ms"],
                         "note": "FP32-VALU/gather bound stage (SURVEY.md 8d); see step_hbm_frac for the whole step"}
         out = {
