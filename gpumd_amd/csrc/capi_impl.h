@@ -148,6 +148,23 @@ int nepmi_potential_compute(
   return guarded([&] { e->e->potential_compute(h, pbc, n, type, pos, pe, force, virial); });
 }
 
+int nepmi_potential_compute_levels(
+  nepmi_engine* e, const double h[9], const int pbc[3], int64_t n, const int* type, const double* pos,
+  const signed char* level, double* pe, double* force, double* virial)
+{
+  if (!e)
+    return fail(NEPMI_ERR_ARG, "null engine");
+  return guarded([&] { e->e->potential_compute_levels(h, pbc, n, type, pos, level, pe, force, virial); });
+}
+
+int nepmi_engine_invalidate(nepmi_engine* e)
+{
+  if (!e)
+    return fail(NEPMI_ERR_ARG, "null engine");
+  e->e->invalidate();
+  return NEPMI_OK;
+}
+
 int nepmi_apply_pbc(nepmi_engine* e, const double h[9], const int pbc[3], int64_t n, double* pos)
 {
   if (!e)

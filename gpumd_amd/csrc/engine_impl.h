@@ -79,7 +79,7 @@ class EngineT
 public:
   static constexpr double kSkin = 1.0; // neighbor.cuh:212
 
-  EngineT(const NepModel& model, int64_t n_atoms, B backend) : model_(model), be_(backend), N_(n_atoms)
+  EngineT(const NepModel& model, int64_t n_atoms, B backend) : model_(model), be_(backend), cap_(n_atoms), N_(n_atoms)
   {
     std::memset(&b_, 0, sizeof(b_));
     std::memset(&md_, 0, sizeof(md_));
@@ -105,11 +105,25 @@ public:
     const double h9[9], const int pbc[3], int64_t n, const int* type, const double* pos, double* pe,
     double* force, double* virial)
   {
-    if (n != N_)
-      throw EngineError{-4, "number of atoms differs from the engine's capacity"};
+    potential_compute_levels(h9, pbc, n, type, pos, nullptr, pe, force, virial);
+  }
+
+  // The same on a LOCAL system of a domain decomposition: n <= capacity atoms, of which only those
+  // with level 2 (owned) receive forces; level 1 (inner ghosts) get descriptors and partial
+  // forces, level 0 (outer ghosts) only lend their positions.  Mirrors the N1..N5 ranges of
+  // NEP_MULTIGPU (src/force/nep_multigpu.cuh:42-50).  level == nullptr: every atom is owned.
+  void potential_compute_levels(
+    const double h9[9], const int pbc[3], int64_t n, const int* type, const double* pos,
+    const signed char* level, double* pe, double* force, double* virial)
+  {
+    if (n < 1 || n > cap_)
+      throw EngineError{-4, "number of atoms exceeds the engine's capacity"};
     BoxD box;
     box_from_h9(h9, pbc, box);
-    bool need_rebuild = !have_list_;
+    bool need_rebuild = !have_list_ || n != N_;
+    N_ = n;
+    b_.N = n;
+    b_.level = level;
     if (have_list_) {
       for (int k = 0; k < 9; ++k)
         if (box.h[k] != box_.h[k])
@@ -302,7 +316,7 @@ private:
   void allocate()
   {
     const NepModel& m = model_;
-    const int64_t N = N_;
+    const int64_t N = cap_;
     if (N < 1 || N > kMaxAtomsPerEngine)
       throw EngineError{-4, "number of atoms per engine must be in [1, 2^25]"};
     if (m.num_types > 127)
@@ -340,6 +354,7 @@ private:
     b_.atab = dalloc<float>((size_t)N * m.num_types * b_.KRP);
     b_.pe_i = dalloc<float>(N);
     b_.zbl = dalloc<float>(m.zbl_enabled ? (size_t)10 * N : 1);
+    b_.lvl = dalloc<signed char>(N);
     b_.flags = dalloc<int>(kNumFlags);
     be_.memset(b_.flags, 0, sizeof(int) * kNumFlags);
     thermo_scratch_ = dalloc<double>(8 * 1024);
@@ -380,7 +395,12 @@ private:
         }
         nb[d] = (int)std::floor(box_.thickness[d] / rc_cell);
       } else {
-        nb[d] = 1;
+        // The reference uses ONE bin in a non-periodic direction (box.cu:80-91), i.e. an O(N^2)
+        // sweep along it; the neighbour SETS do not depend on the binning, so bin it as well
+        // (edge bins absorb atoms outside the box).  Needed for the ghost-padded local boxes.
+        nb[d] = (int)std::floor(box_.thickness[d] / rc_cell);
+        if (nb[d] < 1)
+          nb[d] = 1;
       }
     }
     const int gb[3] = {(nb[0] + kBrick - 1) / kBrick, (nb[1] + kBrick - 1) / kBrick, (nb[2] + kBrick - 1) / kBrick};
@@ -450,6 +470,7 @@ private:
   }
 
 public:
+  void invalidate() { have_list_ = false; }
   void set_force_generic(bool on)
   {
     force_generic_ = on;
@@ -484,7 +505,8 @@ private:
 
   NepModel model_;
   B be_;
-  int64_t N_;
+  int64_t cap_; // allocation size (atoms)
+  int64_t N_;   // atoms of the current (local) system, <= cap_; stride of every [slot][atom] array
   ModelD md_;
   Bufs b_;
   BoxD box_;

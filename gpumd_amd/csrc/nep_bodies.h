@@ -87,6 +87,8 @@ struct Bufs {
   float* pe_i; // [N]
   float* zbl;  // [10][N] (fx fy fz, vxx vyy vzz vxy vxz vyz, pe) when zbl enabled
   int* flags;  // [kNumFlags]
+  const signed char* level; // caller order, or nullptr: 2 owned, 1 inner ghost, 0 outer ghost
+  signed char* lvl;         // [N] the same in internal order (sampled at list rebuild)
 };
 
 constexpr unsigned short kNoSlot = 0xFFFF;
@@ -250,6 +252,7 @@ struct GatherSortedBody {
     b.x0s[k] = p.x;
     b.x0s[b.N + k] = p.y;
     b.x0s[2 * b.N + k] = p.z;
+    b.lvl[k] = b.level ? b.level[i] : (signed char)2;
   }
 };
 
@@ -267,17 +270,21 @@ struct BuildListsBody {
     const int c = b.cid[b.perm[k]];
     int cx, cy, cz;
     cell_coords(b, c, cx, cy, cz);
-    const int lx = box.pbc[0] ? 2 : 0, ly = box.pbc[1] ? 2 : 0, lz = box.pbc[2] ? 2 : 0;
+    // periodic directions wrap (>= 5 bins guaranteed), non-periodic ones stop at the box edge
+    const int lx = b.nbx > 1 ? 2 : 0, ly = b.nby > 1 ? 2 : 0, lz = b.nbz > 1 ? 2 : 0;
     int cnta = 0, cntb = 0;
     for (int kz = -lz; kz <= lz; ++kz) {
       int z2 = cz + kz;
-      if (z2 < 0) z2 += b.nbz; else if (z2 >= b.nbz) z2 -= b.nbz;
+      if (box.pbc[2]) { if (z2 < 0) z2 += b.nbz; else if (z2 >= b.nbz) z2 -= b.nbz; }
+      else if (z2 < 0 || z2 >= b.nbz) continue;
       for (int ky = -ly; ky <= ly; ++ky) {
         int y2 = cy + ky;
-        if (y2 < 0) y2 += b.nby; else if (y2 >= b.nby) y2 -= b.nby;
+        if (box.pbc[1]) { if (y2 < 0) y2 += b.nby; else if (y2 >= b.nby) y2 -= b.nby; }
+        else if (y2 < 0 || y2 >= b.nby) continue;
         for (int kx = -lx; kx <= lx; ++kx) {
           int x2 = cx + kx;
-          if (x2 < 0) x2 += b.nbx; else if (x2 >= b.nbx) x2 -= b.nbx;
+          if (box.pbc[0]) { if (x2 < 0) x2 += b.nbx; else if (x2 >= b.nbx) x2 -= b.nbx; }
+          else if (x2 < 0 || x2 >= b.nbx) continue;
           const int c2 = cell_index(b, x2, y2, z2);
           const int lo = b.cell_count[c2], hi = b.cell_count[c2 + 1];
           for (int j = lo; j < hi; ++j) {
@@ -392,6 +399,11 @@ struct RadialDescBody {
   NEPMI_HD void operator()(int64_t k) const
   {
     const int64_t N = b.N;
+    if (b.lvl[k] < 1) { // outer ghost: lends its position only
+      b.nn_rad[k] = 0;
+      b.nn_angstep[k] = 0;
+      return;
+    }
     const int NR = S::fixed ? S::NR : m.NR;
     const int KR = S::fixed ? S::KR : m.KR;
     const PosQ p1 = b.posq[k];
@@ -547,6 +559,8 @@ struct AngularDescBody {
   NEPMI_HD void run(int64_t k, LP cang) const
   {
     const int64_t N = b.N;
+    if (b.lvl[k] < 1)
+      return;
     const int NR = S::fixed ? S::NR : m.NR;
     const int NA = S::fixed ? S::NA : m.NA;
     const int KA = S::fixed ? S::KA : m.KA;
@@ -627,6 +641,8 @@ struct AnnBody {
   NEPMI_HD void operator()(int64_t k) const
   {
     const int64_t N = b.N;
+    if (b.lvl[k] < 1)
+      return;
     const int NR = S::fixed ? S::NR : m.NR;
     const int KR = S::fixed ? S::KR : m.KR;
     const int dim = S::fixed ? S::DIMM : m.dim;
@@ -728,6 +744,8 @@ struct AngularForceBody {
   NEPMI_HD void run(int64_t k, LP cang) const
   {
     const int64_t N = b.N;
+    if (b.lvl[k] < 1)
+      return;
     const int NR = S::fixed ? S::NR : m.NR;
     const int NA = S::fixed ? S::NA : m.NA;
     const int KA = S::fixed ? S::KA : m.KA;
@@ -869,6 +887,8 @@ struct ForceAssembleBody {
   NEPMI_HD void operator()(int64_t k) const
   {
     const int64_t N = b.N;
+    if (b.lvl[k] < 2) // forces only for owned atoms
+      return;
     const int KR = S::fixed ? S::KR : m.KR;
     const int t1 = b.posq[k].type;
     const float rc1 = m.rc_r[t1];

@@ -184,12 +184,12 @@ NEPMI_HD void cell_of(
   cx = (int)floor(sx * box.thickness[0] * rc_inv);
   cy = (int)floor(sy * box.thickness[1] * rc_inv);
   cz = (int)floor(sz * box.thickness[2] * rc_inv);
-  while (cx < 0) cx += nbx;
-  while (cx >= nbx) cx -= nbx;
-  while (cy < 0) cy += nby;
-  while (cy >= nby) cy -= nby;
-  while (cz < 0) cz += nbz;
-  while (cz >= nbz) cz -= nbz;
+  if (box.pbc[0]) { while (cx < 0) cx += nbx; while (cx >= nbx) cx -= nbx; }
+  else { cx = cx < 0 ? 0 : (cx >= nbx ? nbx - 1 : cx); }
+  if (box.pbc[1]) { while (cy < 0) cy += nby; while (cy >= nby) cy -= nby; }
+  else { cy = cy < 0 ? 0 : (cy >= nby ? nby - 1 : cy); }
+  if (box.pbc[2]) { while (cz < 0) cz += nbz; while (cz >= nbz) cz -= nbz; }
+  else { cz = cz < 0 ? 0 : (cz >= nbz ? nbz - 1 : cz); }
 }
 
 // ---- radial functions -----------------------------------------------------------------------

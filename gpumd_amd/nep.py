@@ -103,6 +103,17 @@ class NEP:
             self.handle, hp, pp, self.n, self._ptr(type), self._ptr(position), self._ptr(potential),
             self._ptr(force), self._ptr(virial)))
 
+    def compute_levels(self, box, pbc, n, type, position, level, potential, force, virial):
+        """Potential::compute on a local (owned + ghost) system; see nepmi_potential_compute_levels."""
+        _, hp = _h9(box)
+        _, pp = _pbc3(pbc)
+        self._ck(self.lib.nepmi_potential_compute_levels(
+            self.handle, hp, pp, int(n), self._ptr(type), self._ptr(position), self._ptr(level),
+            self._ptr(potential), self._ptr(force), self._ptr(virial)))
+
+    def invalidate(self):
+        self._ck(self.lib.nepmi_engine_invalidate(self.handle))
+
     def force_compute(self, box, type, position, potential, force, virial):
         _, hp = _h9(box)
         _, pp = _pbc3(self.pbc)

@@ -94,6 +94,19 @@ int nepmi_potential_compute(
   nepmi_engine* e, const double h[9], const int pbc[3], int64_t n, const int* type,
   const double* pos, double* pe, double* force, double* virial);
 
+/* ---- the same call on the LOCAL system of a spatial domain decomposition (replaces the per-GPU
+ *      ranges N1..N5 of NEP_MULTIGPU::compute, src/force/nep_multigpu.cuh:42-50, :1416-1803):
+ *      n (<= the engine's capacity) owned + ghost atoms; level[i] (DEVICE, n signed chars) = 2 owned
+ *      (forces, virial, energy are produced), 1 inner ghost (descriptors + partial forces are
+ *      recomputed redundantly, like the reference's inner ring), 0 outer ghost (position only).
+ *      level == NULL: all owned.  Directions with pbc = 0 are open: ghosts carry their periodic
+ *      image shift explicitly.  Levels are sampled when the Verlet list is rebuilt; call
+ *      nepmi_engine_invalidate after changing the composition of the local system. ---- */
+int nepmi_potential_compute_levels(
+  nepmi_engine* e, const double h[9], const int pbc[3], int64_t n, const int* type,
+  const double* pos, const signed char* level, double* pe, double* force, double* virial);
+int nepmi_engine_invalidate(nepmi_engine* e);
+
 /* gpu_apply_pbc (force.cu:424-459) and initialize_properties (force.cu:314-333) on their own. */
 int nepmi_apply_pbc(nepmi_engine* e, const double h[9], const int pbc[3], int64_t n, double* pos);
 int nepmi_zero_properties(nepmi_engine* e, int64_t n, double* pe, double* force, double* virial);
