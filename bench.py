@@ -97,6 +97,98 @@ def cpu_baseline(seconds=12.0):
                       % (n, calls, el)}
 
 
+def kernel_report(st, info, n_atoms_per_launch):
+    """per-kernel mean durations (HIP events) + the roofline object of the dominant force kernel"""
+    per_kernel, b_step = algorithmic_bytes(info, st.mean_nn_radial, st.mean_nn_angular)
+    kern = {}
+    for k, name in enumerate(KERNEL_NAMES):
+        if st.launches[k] > 0:
+            kern[name] = {"launches": int(st.launches[k]), "avg_ms": st.ms_kernel_sum[k] / st.launches[k]}
+    force_kernels = [k for k in kern if k in per_kernel and k not in ("velocity_verlet", "gather_skin_check")]
+    dom = max(force_kernels, key=lambda k: kern[k]["avg_ms"] * kern[k]["launches"]) if force_kernels else None
+    roofline = None
+    if dom:
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tfile):
+            # HBM-side bytes per launch from a separate rocprofv3 PMC pass of this same command
+            # (profiles/*_pmc_*.csv); only meaningful for the workload size it was taken on
+            tj = json.load(open(tfile))
+            if tj.get("atoms") == n_atoms_per_launch and dom in tj.get("kernels", {}):
+                traffic = tj["kernels"][dom]["hbm_bytes_per_launch"]
+        achieved = per_kernel[dom] * n_atoms_per_launch / (kern[dom]["avg_ms"] * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                    "algorithmic_bytes_per_launch": per_kernel[dom] * n_atoms_per_launch,
+                    "algorithmic_bytes_per_atom": per_kernel[dom], "avg_launch_ms": kern[dom]["avg_ms"],
+                    "note": "FP32-VALU/gather bound stage (SURVEY.md 8d); see step_hbm_frac for the whole step"}
+    return kern, roofline, b_step
+
+
+def run_decomposed(args, world, rank, dev, model, h_block, typ, x, mass, vel, reps):
+    """N > 1: spatial decomposition (gpumd_amd/domain.py), one rank per GPU, ghost positions over RCCL."""
+    import torch
+    import torch.distributed as dist
+    import gpumd_amd
+    import helpers as H
+    from gpumd_amd.domain import DomainMD, choose_grid
+
+    grid = choose_grid(world)
+    Hb = np.asarray(h_block).reshape(3, 3)
+    Hg = Hb * np.asarray(grid, dtype=np.float64)[None, :]       # global cell = grid x block
+    coords = (rank % grid[0], (rank // grid[0]) % grid[1], rank // (grid[0] * grid[1]))
+    n = len(typ)
+    offset = Hb @ np.asarray(coords, dtype=np.float64)            # this rank's block of the global crystal
+    X = torch.from_numpy(x.reshape(3, n) + offset[:, None]).to(dev)
+    V = torch.from_numpy(vel.reshape(3, n).copy()).to(dev)
+    T = torch.from_numpy(typ).to(dev)
+    M = torch.from_numpy(mass).to(dev)
+    staged = os.environ.get("NEPMI_DIST_BACKEND", "nccl") != "nccl"
+    md = DomainMD(lambda cap: gpumd_amd.NEP(model, cap), model.info.rc_radial, Hg.reshape(9), (1, 1, 1), grid, rank,
+                  world, dev, stage_through_host=staged)
+    md.setup(X, V, T, M)
+    dt = 1.0 / H.TIME_UNIT
+    md.initial_forces()
+    md.run(args.warmup, dt)
+    md.engine.set_timing(True)
+    dec0 = md.num_decompositions
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    md.run(args.steps, dt)
+    dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    st = md.engine.stats(with_lists=True)
+    th = md.thermo()
+    t_el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    md._all_reduce(t_el, dist.ReduceOp.MAX)
+    elapsed = float(t_el.item())
+    n_loc = torch.tensor([md.n_loc], dtype=torch.float64, device=dev)
+    md._all_reduce(n_loc, dist.ReduceOp.MAX)
+    if rank == 0:
+        kern, roofline, b_step = kernel_report(st, model.info, md.n_loc)
+        total = md.n_total
+        out = {
+            "metric": "atom-steps/sec, NEP PbTe NVE (nep4 2 Te Pb, examples/nep_train/nep.txt)",
+            "value": total * args.steps / elapsed, "unit": "atom-steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32 kernels, f64 state/accumulation", "data": "synthetic",
+            "config": {"workload": "PbTe %d atoms/GPU (replicate %d %d %d of the 250-atom cell per GPU), NEP NVE, dt 1 fs, 300 K"
+                                   % ((n,) + reps),
+                       "atoms_total": total, "parallelism": "spatial decomposition %dx%dx%d, ghost shell 2(rc+skin), "
+                       "RCCL send/recv of ghost positions" % grid,
+                       "local_atoms_max": int(n_loc.item()), "decompositions_in_timed_region": md.num_decompositions - dec0,
+                       "mean_nn_radial": st.mean_nn_radial, "mean_nn_angular": st.mean_nn_angular},
+            "roofline": roofline, "step_algorithmic_bytes_per_atom": b_step,
+            "step_hbm_frac": b_step * (total * args.steps / elapsed) / (HBM_PEAK_GBS * 1e9 * world),
+            "kernels": kern, "thermo_last": [float(v) for v in th],
+        }
+        print(json.dumps(out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -119,20 +211,30 @@ def main():
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU path for the product")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # NEPMI_DIST_BACKEND=gloo: functional check of the N > 1 path on a box with fewer GPUs than
+    # ranks (ranks share devices, messages staged through host memory); never a performance run.
+    backend = os.environ.get("NEPMI_DIST_BACKEND", "nccl")
+    local_dev = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
-    # ---- workload (per rank; see DESIGN.md section 7 for the N > 1 decomposition) ----
+    # ---- workload: every rank generates its own block of `reps` cells (weak scaling) ----
     reps = tuple(args.reps)
     h, typ, x, mass, vel = build_pbte(reps, seed=42 + rank)
     n = len(typ)
     nep_txt = H.golden("PbTe", "nep.txt")
     model = gpumd_amd.Model(nep_txt)
-    eng = gpumd_amd.NEP(model, n)
     dt = 1.0 / H.TIME_UNIT
+    if world > 1:
+        run_decomposed(args, world, rank, dev, model, h, typ, x, mass, vel, reps)
+        return
+    eng = gpumd_amd.NEP(model, n)
     t_type = torch.from_numpy(typ).to(dev)
     t_mass = torch.from_numpy(mass).to(dev)
     t_x = torch.from_numpy(x).to(dev)
@@ -168,29 +270,7 @@ def main():
     value = total_atoms * args.steps / elapsed
 
     if rank == 0:
-        per_kernel, b_step = algorithmic_bytes(model.info, st.mean_nn_radial, st.mean_nn_angular)
-        kern = {}
-        for k, name in enumerate(KERNEL_NAMES):
-            if st.launches[k] > 0:
-                kern[name] = {"launches": int(st.launches[k]), "avg_ms": st.ms_kernel_sum[k] / st.launches[k]}
-        force_kernels = [k for k in kern if k in per_kernel and k not in ("velocity_verlet", "gather_skin_check")]
-        dom = max(force_kernels, key=lambda k: kern[k]["avg_ms"] * kern[k]["launches"]) if force_kernels else None
-        roofline = None
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if dom and os.path.exists(tfile):
-            # HBM-side bytes per launch from a separate rocprofv3 PMC pass of this same command
-            # (profiles/*_pmc_*.csv); only meaningful for the 1,024,000-atom workload it was taken on
-            tj = json.load(open(tfile))
-            if tj.get("atoms") == n and dom in tj.get("kernels", {}):
-                traffic = tj["kernels"][dom]["hbm_bytes_per_launch"]
-        if dom:
-            achieved = per_kernel[dom] * n / (kern[dom]["avg_ms"] * 1e-3) / 1e9
-            roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                        "algorithmic_bytes_per_launch": per_kernel[dom] * n,
-                        "algorithmic_bytes_per_atom": per_kernel[dom], "avg_launch_ms": kern[dom]["avg_ms"],
-                        "note": "FP32-VALU/gather bound stage (SURVEY.md 8d); see step_hbm_frac for the whole step"}
+        kern, roofline, b_step = kernel_report(st, model.info, n)
         out = {
             "metric": "atom-steps/sec, NEP PbTe NVE (nep4 2 Te Pb, examples/nep_train/nep.txt)",
             "value": value, "unit": "atom-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -200,7 +280,7 @@ def main():
                                    % ((n,) + reps),
                        "atoms_total": total_atoms, "rebuilds_in_timed_region": int(st.num_rebuild - reb0),
                        "mean_nn_radial": st.mean_nn_radial, "mean_nn_angular": st.mean_nn_angular,
-                       "parallelism": "1 GPU" if world == 1 else "%d independent periodic replicas (no halo yet)" % world},
+                       "parallelism": "1 GPU"},
             "roofline": roofline,
             "step_algorithmic_bytes_per_atom": b_step,
             "step_hbm_frac": b_step * (n * args.steps / elapsed) / (HBM_PEAK_GBS * 1e9),
