@@ -1,0 +1,60 @@
+// Force / Potential: the plugin surface of src/force/{force,potential}.cuh kept as is; the NEP
+// implementation behind it is libnepmi.so through its C ABI (include/nepmi.h).
+#pragma once
+#include "model.h"
+
+#include <memory>
+
+extern "C" {
+#include "../../include/nepmi.h"
+}
+
+namespace gmi {
+
+// src/force/potential.cuh:21-43
+class Potential
+{
+public:
+  int N1 = 0, N2 = 0;
+  double rc = 0.0;
+  virtual ~Potential() = default;
+  virtual void compute(
+    Box& box, const GPU_Vector<int>& type, const GPU_Vector<double>& position,
+    GPU_Vector<double>& potential, GPU_Vector<double>& force, GPU_Vector<double>& virial) = 0;
+};
+
+// class NEP : public Potential (src/force/nep.cuh) on top of the C ABI
+class NEP_MI : public Potential
+{
+public:
+  NEP_MI(const char* file_potential, int num_atoms);
+  ~NEP_MI() override;
+  void compute(
+    Box& box, const GPU_Vector<int>& type, const GPU_Vector<double>& position,
+    GPU_Vector<double>& potential, GPU_Vector<double>& force, GPU_Vector<double>& virial) override;
+  nepmi_engine* engine() { return engine_; }
+  void write_neighbor_out() const; // neighbor.out, nep.cu:1014-1034
+
+private:
+  nepmi_model* model_ = nullptr;
+  nepmi_engine* engine_ = nullptr;
+};
+
+// src/force/force.cuh:25-52
+class Force
+{
+public:
+  // `potential <file>`: factory keyed on the first token of the file (force.cu:75-218)
+  void parse_potential(const std::vector<std::string>& param, const Box& box, int number_of_atoms);
+  // wrap, zero, dispatch (force.cu:771-855)
+  void compute(
+    Box& box, GPU_Vector<double>& position, GPU_Vector<int>& type, GPU_Vector<double>& potential,
+    GPU_Vector<double>& force, GPU_Vector<double>& virial);
+  std::vector<std::unique_ptr<Potential>> potentials;
+  nepmi_engine* engine() const;
+};
+
+// element list of a potential file (read_xyz.cu:427-480 reads it before model.xyz)
+std::vector<std::string> potential_elements(const std::string& file_potential);
+
+} // namespace gmi

@@ -1,0 +1,330 @@
+#include "run.h"
+
+#include <chrono>
+#include <cstring>
+#include <fstream>
+
+namespace gmi {
+
+static std::vector<std::string> strip(const std::string& line)
+{
+  // tokens up to a '#' comment (run.cu:188-200)
+  std::vector<std::string> t = get_tokens(line), out;
+  for (auto& w : t) {
+    if (!w.empty() && w[0] == '#')
+      break;
+    out.push_back(w);
+  }
+  return out;
+}
+
+Run::Run(bool check_only) : check_only_(check_only)
+{
+  // initialize_position (src/model/read_xyz.cu:427-530): run.in is scanned first for the
+  // potential file (its element list fixes the type indices), then model.xyz is read.
+  std::ifstream in("run.in");
+  if (!in)
+    input_error("Cannot open run.in.");
+  std::string line;
+  while (std::getline(in, line)) {
+    auto t = strip(line);
+    if (!t.empty() && t[0] == "potential") {
+      if (t.size() < 2)
+        input_error("potential should have 1 or 2 parameters.");
+      potential_file = t[1];
+      break;
+    }
+  }
+  if (potential_file.empty())
+    input_error("There is no 'potential' keyword before run.");
+  elements = potential_elements(potential_file);
+  has_velocity_in_xyz = read_xyz("model.xyz", elements, box, atom);
+  if (!has_velocity_in_xyz)
+    initialize_velocity(initial_temperature, false, 0, atom); // default 300 K (run.cu:155-160)
+  thermo.resize(check_only_ ? 0 : 12);
+}
+
+void Run::execute_run_in()
+{
+  std::ifstream in("run.in");
+  std::string line;
+  while (std::getline(in, line)) {
+    auto t = strip(line);
+    if (!t.empty())
+      parse_one_keyword(t);
+  }
+}
+
+void Run::parse_one_keyword(const std::vector<std::string>& p)
+{
+  const std::string& k = p[0];
+  if (k == "replicate") {
+    if (p.size() != 4)
+      input_error("replicate should have 3 parameters.");
+    if (gpu_allocated)
+      input_error("replicate should be put before potential.");
+    const int n[3] = {std::atoi(p[1].c_str()), std::atoi(p[2].c_str()), std::atoi(p[3].c_str())};
+    if (n[0] < 1 || n[1] < 1 || n[2] < 1)
+      input_error("replicate numbers should be >= 1.");
+    replicate(n, box, atom);
+    if (!has_velocity_in_xyz)
+      initialize_velocity(initial_temperature, false, 0, atom);
+  } else if (k == "potential") {
+    if (check_only_) {
+      std::printf("potential %s (elements:", p[1].c_str());
+      for (auto& e : elements)
+        std::printf(" %s", e.c_str());
+      std::printf(")\n");
+      return;
+    }
+    if (!gpu_allocated) {
+      atom.allocate_gpu();
+      gpu_allocated = true;
+    }
+    force.parse_potential(p, box, atom.number_of_atoms);
+  } else if (k == "velocity") {
+    if (p.size() != 2 && p.size() != 4)
+      input_error("velocity should have 1 or 2 parameters.");
+    initial_temperature = std::atof(p[1].c_str());
+    if (initial_temperature <= 0.0)
+      input_error("initial temperature should be a positive number.");
+    const bool use_seed = p.size() == 4;
+    const int seed = use_seed ? std::atoi(p[3].c_str()) : 0;
+    if (!has_velocity_in_xyz) {
+      initialize_velocity(initial_temperature, use_seed, seed, atom);
+      std::printf("Initialized velocities with input T = %g K.\n", initial_temperature);
+    }
+    if (gpu_allocated)
+      atom.velocity_per_atom.copy_from_host(atom.cpu_velocity_per_atom.data());
+  } else if (k == "ensemble") {
+    if (p.size() < 2)
+      input_error("ensemble should have at least 1 parameter.");
+    if (p[1] != "nve")
+      input_error("ensemble " + p[1] + " is not available in gpumd-mi yet (nve only; DESIGN.md section 8).");
+    ensemble = p[1];
+    std::printf("Use NVE ensemble for this run.\n");
+  } else if (k == "time_step") {
+    if (p.size() != 2)
+      input_error("time_step should have 1 parameter.");
+    time_step = std::atof(p[1].c_str());
+    std::printf("Time step for this run is %g fs.\n", time_step);
+    time_step /= TIME_UNIT_CONVERSION;
+  } else if (k == "dump_thermo") {
+    if (p.size() != 2)
+      input_error("dump_thermo should have 1 parameter.");
+    dump_thermo_interval = std::atoi(p[1].c_str());
+    if (dump_thermo_interval <= 0)
+      input_error("thermo dump interval should > 0.");
+    std::printf("Dump thermo every %d steps.\n", dump_thermo_interval);
+  } else if (k == "dump_restart") {
+    if (p.size() != 2)
+      input_error("dump_restart should have 1 parameter.");
+    dump_restart_interval = std::atoi(p[1].c_str());
+  } else if (k == "dump_xyz") {
+    if (p.size() < 3)
+      input_error("dump_xyz should have at least 2 parameters.");
+    DumpXyz d;
+    d.interval = std::atoi(p[1].c_str());
+    if (d.interval <= 0)
+      input_error("dump interval should > 0.");
+    d.filename = p[2];
+    for (size_t m = 3; m < p.size(); ++m) {
+      if (p[m] == "precision") {
+        if (m + 1 >= p.size())
+          input_error("precision should be followed by single or double.");
+        d.precision = p[m + 1] == "single" ? 1 : 2;
+        ++m;
+      } else if (p[m] == "mass") d.has_mass = true;
+      else if (p[m] == "velocity") d.has_velocity = true;
+      else if (p[m] == "force") d.has_force = true;
+      else if (p[m] == "potential") d.has_potential = true;
+      else if (p[m] == "virial") d.has_virial = true;
+      else input_error("Unrecognized argument in dump_xyz.");
+    }
+    dump_xyzs.push_back(d);
+    std::printf("Dump extended XYZ every %d steps into file %s.\n", d.interval, d.filename.c_str());
+  } else if (k == "run") {
+    if (p.size() != 2)
+      input_error("run should have 1 parameter.");
+    number_of_steps = std::atoi(p[1].c_str());
+    std::printf("Run %d steps.\n", number_of_steps);
+    if (check_only_) {
+      std::printf("(--check-input: %d atoms, dt = %g fs, no GPU work)\n", atom.number_of_atoms, time_step * TIME_UNIT_CONVERSION);
+    } else {
+      perform_a_run();
+    }
+    // properties do not propagate to the next run (measure.cu:88)
+    dump_thermo_interval = 0;
+    dump_restart_interval = 0;
+    dump_xyzs.clear();
+  } else {
+    input_error("'" + k + "' is invalid keyword (or outside the path gpumd-mi covers).");
+  }
+}
+
+void Run::find_thermo()
+{
+  nepmi_find_thermo(
+    force.engine(), atom.number_of_atoms, box.get_volume(), atom.mass.data(), atom.potential_per_atom.data(),
+    atom.velocity_per_atom.data(), atom.virial_per_atom.data(), thermo.data());
+}
+
+// Dump_Thermo (src/measure/dump_thermo.cu:56-132)
+void Run::dump_thermo(int step)
+{
+  if (dump_thermo_interval <= 0 || (step + 1) % dump_thermo_interval != 0)
+    return;
+  static FILE* fid = nullptr;
+  static int header_for = -1;
+  if (!fid)
+    fid = std::fopen("thermo.out", "a");
+  if (header_for != number_of_steps + dump_thermo_interval * 1000003) {
+    header_for = number_of_steps + dump_thermo_interval * 1000003;
+  }
+  double t[8];
+  thermo.copy_to_host(t, 8);
+  const double ke = 1.5 * atom.number_of_atoms * K_B * t[0];
+  std::fprintf(fid, "%20.10e%20.10e%20.10e%20.10e%20.10e%20.10e%20.10e%20.10e%20.10e", t[0], ke, t[1],
+               t[2] * PRESSURE_UNIT_CONVERSION, t[3] * PRESSURE_UNIT_CONVERSION, t[4] * PRESSURE_UNIT_CONVERSION,
+               t[7] * PRESSURE_UNIT_CONVERSION, t[6] * PRESSURE_UNIT_CONVERSION, t[5] * PRESSURE_UNIT_CONVERSION);
+  const double* h = box.cpu_h;
+  std::fprintf(fid, "%20.10e%20.10e%20.10e%20.10e%20.10e%20.10e%20.10e%20.10e%20.10e\n", h[0], h[3], h[6], h[1], h[4],
+               h[7], h[2], h[5], h[8]);
+  std::fflush(fid);
+}
+
+// Dump_XYZ (src/measure/dump_xyz.cu:196-420)
+void Run::dump_xyz(DumpXyz& d, int step)
+{
+  if ((step + 1) % d.interval != 0)
+    return;
+  if (!d.fid)
+    d.fid = std::fopen(d.filename.c_str(), "a");
+  const int N = atom.number_of_atoms;
+  const char* fmt = d.precision == 1 ? " %.9g" : " %.17g";
+  std::vector<double> pos(3 * (size_t)N), vel, frc, pe, vir(9 * (size_t)N);
+  atom.position_per_atom.copy_to_host(pos.data());
+  atom.virial_per_atom.copy_to_host(vir.data());
+  if (d.has_velocity) { vel.resize(3 * (size_t)N); atom.velocity_per_atom.copy_to_host(vel.data()); }
+  if (d.has_force) { frc.resize(3 * (size_t)N); atom.force_per_atom.copy_to_host(frc.data()); }
+  if (d.has_potential) { pe.resize(N); atom.potential_per_atom.copy_to_host(pe.data()); }
+  double t[8];
+  thermo.copy_to_host(t, 8);
+  double tv[6] = {0, 0, 0, 0, 0, 0};
+  for (int c = 0; c < 6; ++c)
+    for (int n = 0; n < N; ++n)
+      tv[c] += vir[(size_t)c * N + n];
+  auto tensor = [&](const char* name, const double* v) {
+    std::fprintf(d.fid, " %s=\"", name);
+    for (int k = 0; k < 9; ++k)
+      std::fprintf(d.fid, k == 0 ? fmt + 1 : fmt, v[k]);
+    std::fprintf(d.fid, "\"");
+  };
+  std::fprintf(d.fid, "%d\n", N);
+  std::fprintf(d.fid, "Time=%.8f", global_time * TIME_UNIT_CONVERSION);
+  std::fprintf(d.fid, " pbc=\"%c %c %c\"", box.pbc_x ? 'T' : 'F', box.pbc_y ? 'T' : 'F', box.pbc_z ? 'T' : 'F');
+  const double* h = box.cpu_h;
+  const double lattice[9] = {h[0], h[3], h[6], h[1], h[4], h[7], h[2], h[5], h[8]};
+  tensor("Lattice", lattice);
+  std::fprintf(d.fid, " energy=");
+  std::fprintf(d.fid, fmt + 1, t[1]);
+  const double virial[9] = {tv[0], tv[3], tv[4], tv[3], tv[1], tv[5], tv[4], tv[5], tv[2]};
+  tensor("virial", virial);
+  const double stress[9] = {t[2], t[5], t[6], t[5], t[3], t[7], t[6], t[7], t[4]};
+  tensor("stress", stress);
+  std::fprintf(d.fid, " Properties=species:S:1:pos:R:3");
+  if (d.has_mass) std::fprintf(d.fid, ":mass:R:1");
+  if (d.has_velocity) std::fprintf(d.fid, ":vel:R:3");
+  if (d.has_force) std::fprintf(d.fid, ":forces:R:3");
+  if (d.has_potential) std::fprintf(d.fid, ":energy_atom:R:1");
+  if (d.has_virial) std::fprintf(d.fid, ":virial:R:9");
+  std::fprintf(d.fid, "\n");
+  const int vidx[9] = {0, 3, 4, 6, 1, 5, 7, 8, 2}; // dump_xyz.cu: xx xy xz yx yy yz zx zy zz
+  for (int n = 0; n < N; ++n) {
+    std::fprintf(d.fid, "%s", atom.cpu_atom_symbol[n].c_str());
+    for (int c = 0; c < 3; ++c) std::fprintf(d.fid, fmt, pos[n + (size_t)N * c]);
+    if (d.has_mass) std::fprintf(d.fid, fmt, atom.cpu_mass[n]);
+    if (d.has_velocity)
+      for (int c = 0; c < 3; ++c) std::fprintf(d.fid, fmt, vel[n + (size_t)N * c] / TIME_UNIT_CONVERSION);
+    if (d.has_force)
+      for (int c = 0; c < 3; ++c) std::fprintf(d.fid, fmt, frc[n + (size_t)N * c]);
+    if (d.has_potential) std::fprintf(d.fid, fmt, pe[n]);
+    if (d.has_virial)
+      for (int c = 0; c < 9; ++c) std::fprintf(d.fid, fmt, vir[n + (size_t)N * vidx[c]]);
+    std::fprintf(d.fid, "\n");
+  }
+  std::fflush(d.fid);
+}
+
+// Dump_Restart (src/measure/dump_restart.cu:66-136), full precision instead of %g
+void Run::dump_restart(int step)
+{
+  if (dump_restart_interval <= 0 || (step + 1) % dump_restart_interval != 0)
+    return;
+  const int N = atom.number_of_atoms;
+  std::vector<double> pos(3 * (size_t)N), vel(3 * (size_t)N);
+  atom.position_per_atom.copy_to_host(pos.data());
+  atom.velocity_per_atom.copy_to_host(vel.data());
+  FILE* fid = std::fopen("restart.xyz", "w");
+  const double* h = box.cpu_h;
+  std::fprintf(fid, "%d\n", N);
+  std::fprintf(fid, "pbc=\"%c %c %c\" Lattice=\"%.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g\" "
+                    "Properties=species:S:1:pos:R:3:mass:R:1:vel:R:3\n",
+               box.pbc_x ? 'T' : 'F', box.pbc_y ? 'T' : 'F', box.pbc_z ? 'T' : 'F', h[0], h[3], h[6], h[1], h[4], h[7], h[2],
+               h[5], h[8]);
+  for (int n = 0; n < N; ++n)
+    std::fprintf(fid, "%s %.17g %.17g %.17g %.17g %.17g %.17g %.17g\n", atom.cpu_atom_symbol[n].c_str(), pos[n],
+                 pos[n + (size_t)N], pos[n + 2 * (size_t)N], atom.cpu_mass[n], vel[n] / TIME_UNIT_CONVERSION,
+                 vel[n + (size_t)N] / TIME_UNIT_CONVERSION, vel[n + 2 * (size_t)N] / TIME_UNIT_CONVERSION);
+  std::fclose(fid);
+}
+
+// Run::perform_a_run (run.cu:211-341) for ensemble nve
+void Run::perform_a_run()
+{
+  if (!gpu_allocated || force.potentials.empty())
+    input_error("No potential is defined before run.");
+  const int N = atom.number_of_atoms;
+  nepmi_engine* e = force.engine();
+  if (dump_thermo_interval > 0) {
+    FILE* fid = std::fopen("thermo.out", "a");
+    std::fprintf(fid, "# dump_thermo %d\n# format_version 1\n# num_atoms %d\n# dt_output %.10e fs\n", dump_thermo_interval, N,
+                 time_step * dump_thermo_interval * TIME_UNIT_CONVERSION);
+    std::fprintf(fid, "# columns T KE PE sxx syy szz syz sxz sxy ax ay az bx by bz cx cy cz\n");
+    std::fclose(fid);
+  }
+  // initial force (run.cu:220-232)
+  force.compute(box, atom.position_per_atom, atom.type, atom.potential_per_atom, atom.force_per_atom, atom.virial_per_atom);
+  hip_check(hipDeviceSynchronize(), "sync");
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int step = 0; step < number_of_steps; ++step) {
+    global_time += time_step;
+    // integrate.compute1: Ensemble_NVE::compute1 (ensemble_nve.cu:31-57)
+    nepmi_vv_step1(e, N, time_step, atom.mass.data(), atom.force_per_atom.data(), atom.position_per_atom.data(),
+                   atom.velocity_per_atom.data());
+    force.compute(box, atom.position_per_atom, atom.type, atom.potential_per_atom, atom.force_per_atom, atom.virial_per_atom);
+    // integrate.compute2 (ensemble_nve.cu:59-95)
+    nepmi_vv_step2(e, N, time_step, atom.mass.data(), atom.force_per_atom.data(), atom.velocity_per_atom.data());
+    find_thermo();
+    // measure.process
+    dump_thermo(step);
+    for (auto& d : dump_xyzs)
+      dump_xyz(d, step);
+    dump_restart(step);
+    if (number_of_steps >= 10 && (step + 1) % (number_of_steps / 10) == 0)
+      std::printf("    %d steps completed.\n", step + 1);
+  }
+  hip_check(hipDeviceSynchronize(), "sync");
+  const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  std::printf("Time used for this run = %g second.\n", sec);
+  std::printf("Speed of this run = %g atom*step/second.\n", (double)N * number_of_steps / sec); // run.cu:325-326
+  if (auto* p = dynamic_cast<NEP_MI*>(force.potentials[0].get()))
+    p->write_neighbor_out();
+  for (auto& d : dump_xyzs)
+    if (d.fid) {
+      std::fclose(d.fid);
+      d.fid = nullptr;
+    }
+}
+
+} // namespace gmi

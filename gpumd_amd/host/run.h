@@ -1,0 +1,50 @@
+// Run: the run.in interpreter and the MD loop (src/main_gpumd/run.{cu,cuh}), restricted to the
+// keywords of the hot path: potential, replicate, velocity, ensemble nve, time_step, dump_thermo,
+// dump_xyz, dump_restart, run.
+#pragma once
+#include "force.h"
+
+namespace gmi {
+
+struct DumpXyz {
+  int interval = 0;
+  std::string filename;
+  int precision = 2; // 1 single (%.9g), 2 double (%.17g)   -- dump_xyz.cu:163-165
+  bool has_mass = false, has_velocity = false, has_force = false, has_potential = false, has_virial = false;
+  FILE* fid = nullptr;
+};
+
+class Run
+{
+public:
+  explicit Run(bool check_only);
+  void execute_run_in();
+
+private:
+  void parse_one_keyword(const std::vector<std::string>& tokens);
+  void perform_a_run();
+  void find_thermo();
+  void dump_thermo(int step);
+  void dump_xyz(DumpXyz& d, int step);
+  void dump_restart(int step);
+
+  bool check_only_;
+  Box box;
+  Atom atom;
+  Force force;
+  bool has_velocity_in_xyz = false;
+  bool gpu_allocated = false;
+  std::string ensemble = "nve";
+  double time_step = 1.0 / TIME_UNIT_CONVERSION;
+  double global_time = 0.0;
+  int number_of_steps = 0;
+  double initial_temperature = 300.0;
+  int dump_thermo_interval = 0;
+  int dump_restart_interval = 0;
+  std::vector<DumpXyz> dump_xyzs;
+  GPU_Vector<double> thermo; // 8 doubles
+  std::vector<std::string> elements;
+  std::string potential_file;
+};
+
+} // namespace gmi

@@ -1,0 +1,85 @@
+"""gpumd-mi, the C++ host (gpumd_amd/host): run.in / model.xyz parsing on the CPU tier, a full
+single-point + NVE run through the Force::compute surface on the GPU tier."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import helpers as H
+
+EXE = os.path.join(H.ROOT, "gpumd_amd", "bin", "gpumd-mi")
+
+
+def _workdir(tmp_path, run_in):
+    import shutil
+    shutil.copy(H.golden("PbTe", "model.xyz"), tmp_path / "model.xyz")
+    (tmp_path / "run.in").write_text(run_in.replace("NEP", H.golden("PbTe", "nep.txt")))
+    return str(tmp_path)
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _build():
+    if not os.path.exists(EXE):
+        import __graft_entry__ as g
+        g.build()
+
+
+def test_check_input_parses_run_in_and_model(tmp_path):
+    wd = _workdir(tmp_path, "replicate 2 3 1   # comment\npotential NEP\nvelocity 300 seed 42\nensemble nve\n"
+                            "time_step 2\ndump_thermo 5\ndump_xyz 10 d.xyz force velocity precision single\nrun 10\n")
+    out = subprocess.run([EXE, "--check-input"], cwd=wd, capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "Number of atoms is 250." in out.stdout
+    assert "Replicated the box: 2 x 3 x 1, 1500 atoms." in out.stdout
+    assert "elements: Te Pb" in out.stdout
+    assert "Time step for this run is 2 fs." in out.stdout
+    assert "Run 10 steps." in out.stdout
+
+
+@pytest.mark.parametrize("bad,msg", [("potential NEP\nfoo 1\nrun 1\n", "invalid keyword"),
+                                     ("potential NEP\nensemble nvt_ber 300 300 100\nrun 1\n", "not available"),
+                                     ("velocity 300\nrun 1\n", "no 'potential'")])
+def test_input_errors_exit_like_the_reference(tmp_path, bad, msg):
+    wd = _workdir(tmp_path, bad)
+    out = subprocess.run([EXE, "--check-input"], cwd=wd, capture_output=True, text=True)
+    assert out.returncode == 1
+    assert "Input Error" in out.stdout and msg in out.stdout
+
+
+@pytest.mark.gpu
+def test_single_point_matches_oracle(tmp_path):
+    """examples/gpumd_static/run.in (time_step 0, dump force) on a 2x2x2 supercell."""
+    wd = _workdir(tmp_path, "replicate 2 2 2\npotential NEP\nvelocity 1\nensemble nve\ntime_step 0\n"
+                            "dump_xyz 1 dump.xyz force potential precision double\nrun 1\n")
+    out = subprocess.run([EXE], cwd=wd, capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "atom*step/second" in out.stdout
+    fr = H.read_xyz_frames(os.path.join(wd, "dump.xyz"))[0]
+    src = H.read_xyz_frames(H.golden("PbTe", "model.xyz"))[0]
+    orc = H.Oracle(H.golden("PbTe", "nep.txt"))
+    typ0 = H.types_from_species(src["species"], orc.symbols)
+    h, typ, pos = H.replicate(src["h"], typ0, src["pos"], (2, 2, 2))
+    x = H.oracle_apply_pbc(h, H.soa(pos))
+    pe, f, v = orc.compute(typ.astype(np.int32), h, x, precision=64, path=0)
+    assert fr["n"] == 2000
+    np.testing.assert_allclose(fr["energy"], pe.sum(), rtol=1e-5)
+    np.testing.assert_allclose(fr["forces"], f.reshape(3, -1).T, rtol=1e-4, atol=3e-5)
+    np.testing.assert_allclose(fr["energy_atom"][:, 0], pe, rtol=1e-5, atol=2e-5)
+    vt = v.reshape(9, -1).sum(axis=1)
+    np.testing.assert_allclose(fr["virial"], [vt[0], vt[3], vt[4], vt[3], vt[1], vt[5], vt[4], vt[5], vt[2]],
+                               rtol=1e-4, atol=5e-2)
+
+
+@pytest.mark.gpu
+def test_nve_run_writes_thermo(tmp_path):
+    wd = _workdir(tmp_path, "replicate 2 2 2\npotential NEP\nvelocity 300 seed 42\nensemble nve\ntime_step 1\n"
+                            "dump_thermo 10\ndump_restart 40\nrun 40\n")
+    out = subprocess.run([EXE], cwd=wd, capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    th = np.loadtxt(os.path.join(wd, "thermo.out"))
+    assert th.shape == (4, 18)
+    etot = th[:, 1] + th[:, 2]
+    assert np.abs(etot - etot[0]).max() < 2e-3 * 2000  # test_md_conservation.py bound
+    assert 100.0 < th[-1, 0] < 320.0  # equipartition from 300 K on a perfect lattice
+    assert os.path.exists(os.path.join(wd, "restart.xyz")) and os.path.exists(os.path.join(wd, "neighbor.out"))
