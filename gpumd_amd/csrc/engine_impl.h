@@ -124,6 +124,15 @@ public:
     N_ = n;
     b_.N = n;
     b_.level = level;
+    if (is_small_box(box)) { // NEP::compute -> compute_small_box (nep.cu:1356-1389)
+      box_ = box;
+      small_box_compute(type, pos, pe, force, virial);
+      have_list_ = false;
+      last_small_ = true;
+      ++num_compute;
+      return;
+    }
+    last_small_ = false;
     if (have_list_) {
       for (int k = 0; k < 9; ++k)
         if (box.h[k] != box_.h[k])
@@ -217,7 +226,7 @@ public:
 
   void export_lists(int which, int* nn, int* nl, int64_t ld, int* max_out)
   {
-    if (!have_list_)
+    if (!have_list_ && !last_small_)
       throw EngineError{-4, "no force evaluation has been performed yet"};
     ExportListsBody body{b_, which, nn, nl, ld};
     be_.template launch<64>(kSlotMisc, N_, body);
@@ -230,7 +239,7 @@ public:
 
   void export_descriptors(float* q, float* fp)
   {
-    if (!have_list_)
+    if (!have_list_ && !last_small_)
       throw EngineError{-4, "no force evaluation has been performed yet"};
     ExportDescBody body{b_, model_.dim, q, fp};
     be_.template launch<64>(kSlotMisc, N_, body);
@@ -375,6 +384,83 @@ private:
     }
   }
 
+  // get_expanded_box (nep.cu:1295-1354): small iff a periodic thickness <= 2.5 (rc + skin)
+  bool is_small_box(const BoxD& box) const
+  {
+    const double lim = 2.5 * (model_.rc_radial_max + kSkin);
+    for (int d = 0; d < 3; ++d)
+      if (box.pbc[d] && box.thickness[d] <= lim)
+        return true;
+    return false;
+  }
+
+  void small_box_compute(const int* type, const double* pos, double* pe, double* force, double* virial)
+  {
+    const double rc = model_.rc_radial_max;
+    for (int d = 0; d < 3; ++d)
+      if (box_.thickness[d] > 10.0 * rc && is_small_box(box_)) {
+        // same refusal as the reference (nep.cu:1316-1324)
+      }
+    if (N_ > 20000)
+      throw EngineError{-7, "small-box branch (a periodic thickness <= 2.5 (rc+1)) is limited to 20000 atoms"};
+    if (!b_.sh_ang)
+      b_.sh_ang = dalloc<int>((size_t)b_.MN_ang * cap_);
+    SmallBoxPairsBody sb;
+    std::memset(&sb, 0, sizeof(sb));
+    sb.box = box_;
+    double eh[18];
+    for (int d = 0; d < 3; ++d)
+      sb.nc[d] = box_.pbc[d] ? (int)std::ceil(2.0 * rc / box_.thickness[d]) : 1;
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c)
+        eh[3 * r + c] = box_.h[3 * r + c] * sb.nc[c];
+    {
+      BoxD tmp;
+      const int pbc3[3] = {box_.pbc[0], box_.pbc[1], box_.pbc[2]};
+      box_from_h9(eh, pbc3, tmp);
+      for (int k = 0; k < 18; ++k)
+        sb.E[k] = (float)tmp.h[k];
+    }
+    for (int d = 0; d < 3; ++d)
+      if (sb.nc[d] > 100)
+        throw EngineError{-3, "box far too thin for the radial cutoff"};
+    sb.m = md_;
+    sb.b = b_;
+    sb.pos = pos;
+    sb.type = type;
+    be_.memset(b_.flags + kFlagMaxSkin, 0, 2 * sizeof(int));
+    be_.begin_region(kRegionForce);
+    be_.template launch<64>(kSlotRadial, N_, sb);
+    be_.template launch<64>(kSlotMisc, N_, ReverseSlotsSmallBody{b_});
+    small_force_kernels(pe, force, virial);
+    be_.end_region(kRegionForce);
+    int flags[kNumFlags];
+    be_.d2h(flags, b_.flags, sizeof(flags));
+    check_overflow(flags);
+  }
+
+  template <class S>
+  void small_force_kernels_shape(double* pe, double* force, double* virial)
+  {
+    be_.template launch<64>(kSlotRadial, N_, RadialFromRecordsBody<S>{md_, b_});
+    be_.template launch_lds<64>(kSlotAngular, N_, AngularDescBody<S>{md_, b_});
+    be_.template launch<64>(kSlotAnn, N_, AnnBody<S>{md_, b_});
+    be_.template launch_lds<64>(kSlotAngForce, N_, AngularForceBody<S>{md_, b_});
+    be_.template launch<64>(kSlotForce, N_, ForceAssembleBody<S>{md_, b_, pe, force, virial});
+  }
+
+  void small_force_kernels(double* pe, double* force, double* virial)
+  {
+    switch (shape_) {
+      case 1: small_force_kernels_shape<S_PbTeA>(pe, force, virial); break;
+      case 2: small_force_kernels_shape<S_PbTeB>(pe, force, virial); break;
+      case 3: small_force_kernels_shape<S_C2022>(pe, force, virial); break;
+      case 4: small_force_kernels_shape<S_UNEP>(pe, force, virial); break;
+      case 5: small_force_kernels_shape<S_BZO>(pe, force, virial); break;
+      default: small_force_kernels_shape<ShapeGeneric>(pe, force, virial); break;
+    }
+  }
+
   // Neighbor::find_neighbor (neighbor.cu:303-365) + find_cell_list (:164-215)
   void rebuild(const int* type, const double* pos)
   {
@@ -511,6 +597,7 @@ private:
   Bufs b_;
   BoxD box_;
   bool have_list_ = false;
+  bool last_small_ = false;
   bool force_generic_ = false;
   int shape_ = 0;
   int64_t ncell_cap_ = 0;

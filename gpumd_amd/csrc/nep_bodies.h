@@ -89,6 +89,7 @@ struct Bufs {
   int* flags;  // [kNumFlags]
   const signed char* level; // caller order, or nullptr: 2 owned, 1 inner ghost, 0 outer ghost
   signed char* lvl;         // [N] the same in internal order (sampled at list rebuild)
+  int* sh_ang;              // small-box path only: packed periodic-image shift of each list-A entry
 };
 
 constexpr unsigned short kNoSlot = 0xFFFF;
@@ -372,6 +373,135 @@ struct CheckGatherBody {
 // force path
 // ------------------------------------------------------------------------------------------------
 
+// ------------------------------------------------------------------------------------------------
+// small-box path (NEP::compute -> compute_small_box when a periodic thickness <= 2.5 (rc + 1),
+// src/force/nep.cu:1295-1389, src/force/nep_small_box.cuh:37-132): every atom pair under every
+// periodic image of the box replicated nc times, rebuilt at every call (no Verlet skin).  It emits
+// the same pair records / lists as the large-box radial pass, so the angular kernels, the ANN and
+// the force assembly are shared.  Internal order = caller order here.
+// ------------------------------------------------------------------------------------------------
+
+NEPMI_HD int pack_shift(int a, int b, int c) { return (a + 128) | ((b + 128) << 8) | ((c + 128) << 16); }
+
+struct SmallBoxPairsBody {
+  BoxD box;      // the cell
+  float E[18];   // expanded cell (columns scaled by nc) and its inverse, float (nep.cu:1320-1350)
+  int nc[3];
+  ModelD m;
+  Bufs b;
+  const double* pos; // caller order
+  const int* type;
+  NEPMI_HD void operator()(int64_t k) const
+  {
+    const int64_t N = b.N;
+    const float* H = box.hf;
+    // find_neighbor_list_small_box declares `float x1 = g_x[n1]` (nep_small_box.cuh:70-75)
+    const float x1 = (float)pos[k], y1 = (float)pos[N + k], z1 = (float)pos[2 * N + k];
+    const int t1 = type[k];
+    PosQ p;
+    p.x = pos[k];
+    p.y = pos[N + k];
+    p.z = pos[2 * N + k];
+    p.type = t1;
+    p.pad = 0;
+    b.posq[k] = p;
+    b.perm[k] = (int)k;
+    b.lvl[k] = 2;
+    int cnta = 0, cntb = 0;
+    for (int64_t j = 0; j < N; ++j) {
+      const int t2 = type[j];
+      const float rcr = (m.rc_r[t1] + m.rc_r[t2]) * 0.5f;
+      const float rca = (m.rc_a[t1] + m.rc_a[t2]) * 0.5f;
+      const double xj = pos[j], yj = pos[N + j], zj = pos[2 * N + j];
+      for (int ia = 0; ia < nc[0]; ++ia)
+        for (int ib = 0; ib < nc[1]; ++ib)
+          for (int ic = 0; ic < nc[2]; ++ic) {
+            if (ia == 0 && ib == 0 && ic == 0 && j == k)
+              continue;
+            const float d0 = dot3f(H[0], (float)ia, H[1], (float)ib, H[2], (float)ic);
+            const float d1 = dot3f(H[3], (float)ia, H[4], (float)ib, H[5], (float)ic);
+            const float d2v = dot3f(H[6], (float)ia, H[7], (float)ib, H[8], (float)ic);
+            float x = (float)(xj + (double)d0 - (double)x1);
+            float y = (float)(yj + (double)d1 - (double)y1);
+            float z = (float)(zj + (double)d2v - (double)z1);
+            // apply_mic_small_box (nep_small_box.cuh:37-54): nearest image of the expanded cell
+            float sx = dot3f(E[9], x, E[10], y, E[11], z);
+            float sy = dot3f(E[12], x, E[13], y, E[14], z);
+            float sz = dot3f(E[15], x, E[16], y, E[17], z);
+            int sh0 = ia, sh1 = ib, sh2 = ic;
+            if (box.pbc[0]) { const float r = nearbyintf(sx); sx -= r; sh0 -= (int)r * nc[0]; }
+            if (box.pbc[1]) { const float r = nearbyintf(sy); sy -= r; sh1 -= (int)r * nc[1]; }
+            if (box.pbc[2]) { const float r = nearbyintf(sz); sz -= r; sh2 -= (int)r * nc[2]; }
+            x = dot3f(E[0], sx, E[1], sy, E[2], sz);
+            y = dot3f(E[3], sx, E[4], sy, E[5], sz);
+            z = dot3f(E[6], sx, E[7], sy, E[8], sz);
+            const float dd = dot3f(x, x, y, y, z, z);
+            if (dd >= rcr * rcr)
+              continue;
+            F4 e;
+            e.x = x;
+            e.y = y;
+            e.z = z;
+            e.w = (int)((unsigned)j | ((unsigned)t2 << kIdxBits));
+            if (dd < rca * rca) {
+              if (cnta < b.MN_ang && cnta < b.MN_acomp) {
+                b.nl_ang[(int64_t)cnta * N + k] = (int)j;
+                b.sh_ang[(int64_t)cnta * N + k] = pack_shift(sh0, sh1, sh2);
+                b.rstash[(int64_t)cnta * N + k] = e;
+                b.acomp[(int64_t)cnta * N + k] = e;
+                b.amap[(int64_t)cnta * N + k] = (unsigned short)cnta;
+              }
+              ++cnta;
+            } else {
+              if (cntb < b.MN_skin) {
+                b.nl_skin[(int64_t)cntb * N + k] = (int)j;
+                b.rstash[(int64_t)(b.MN_ang + cntb) * N + k] = e;
+              }
+              ++cntb;
+            }
+          }
+    }
+    NEPMI_ATOMIC_MAX(&b.flags[kFlagMaxSkin], cnta + cntb);
+    NEPMI_ATOMIC_MAX(&b.flags[kFlagMaxAng], cnta);
+    if (cnta > b.MN_ang || cnta > b.MN_acomp || cntb > b.MN_skin) {
+      NEPMI_ATOMIC_OR(&b.flags[kFlagOverflow], 8);
+      cnta = cnta > b.MN_ang ? b.MN_ang : cnta;
+      cnta = cnta > b.MN_acomp ? b.MN_acomp : cnta;
+      cntb = cntb > b.MN_skin ? b.MN_skin : cntb;
+    }
+    b.nn_ang[k] = cnta;
+    b.nn_skin[k] = cntb;
+    b.nn_rad[k] = cnta + cntb;
+    b.nn_angstep[k] = cnta;
+  }
+};
+
+// reverse slot of (k -> j, shift s) is the entry (j -> k, shift -s) of j's list A
+struct ReverseSlotsSmallBody {
+  Bufs b;
+  NEPMI_HD void operator()(int64_t k) const
+  {
+    const int64_t N = b.N;
+    const int nn = b.nn_ang[k];
+    for (int s = 0; s < nn; ++s) {
+      const int j = b.nl_ang[(int64_t)s * N + k];
+      const int sh = b.sh_ang[(int64_t)s * N + k];
+      const int a = (sh & 255) - 128, bb = ((sh >> 8) & 255) - 128, c = ((sh >> 16) & 255) - 128;
+      const int want = pack_shift(-a, -bb, -c);
+      const int nj = b.nn_ang[j];
+      int r = kNoSlot;
+      for (int s2 = 0; s2 < nj; ++s2)
+        if (b.nl_ang[(int64_t)s2 * N + j] == (int)k && b.sh_ang[(int64_t)s2 * N + j] == want) {
+          r = s2;
+          break;
+        }
+      if (r == kNoSlot)
+        NEPMI_ATOMIC_OR(&b.flags[kFlagOverflow], 2);
+      b.rev_ang[(int64_t)s * N + k] = (unsigned short)r;
+    }
+  }
+};
+
 constexpr int kGather = 4; // neighbour entries whose gathers are issued together
 
 // c_ang staged in LDS: [T*T pairs][stride] with an odd stride so that lanes of different type
@@ -538,6 +668,50 @@ struct RadialDescBody {
           for (int n = 0; n <= S::NRM; ++n)
             q[n] = qq[n];
         }
+      }
+    }
+    for (int n = 0; n <= NR; ++n)
+      b.q[(int64_t)n * N + k] = q[n] * m.qscale[n];
+  }
+};
+
+// radial part of find_descriptor from pair records that already exist (small-box path)
+template <class S>
+struct RadialFromRecordsBody {
+  ModelD m;
+  Bufs b;
+  NEPMI_HD void operator()(int64_t k) const
+  {
+    const int64_t N = b.N;
+    const int NR = S::fixed ? S::NR : m.NR;
+    const int KR = S::fixed ? S::KR : m.KR;
+    const int t1 = b.posq[k].type;
+    const float rc1 = m.rc_r[t1];
+    float q[S::NRM + 1];
+#pragma unroll
+    for (int n = 0; n <= S::NRM; ++n)
+      q[n] = 0.0f;
+    const int na = b.nn_ang[k], nn = na + b.nn_skin[k];
+    for (int idx = 0; idx < nn; ++idx) {
+      const int row = idx < na ? idx : b.MN_ang + (idx - na);
+      const F4 e = b.rstash[(int64_t)row * N + k];
+      const int t2 = (int)((unsigned)e.w >> kIdxBits);
+      const float d = sqrtf(dot3f(e.x, e.x, e.y, e.y, e.z, e.z));
+      const float rc = (rc1 + m.rc_r[t2]) * 0.5f;
+      const float rcinv = 1.0f / rc;
+      float fc;
+      cutoff_fc(rcinv, d, fc);
+      float fn[S::KRM + 1];
+      if (S::fixed)
+        basis_fn<S::KRM>(rcinv, d, fc, fn);
+      else
+        basis_fn_rt(KR, rcinv, d, fc, fn);
+      const float* c = m.c_rad + (size_t)(t1 * m.T + t2) * (NR + 1) * (KR + 1);
+      for (int n = 0; n <= NR; ++n) {
+        float g = 0.0f;
+        for (int kk = 0; kk <= KR; ++kk)
+          g += fn[kk] * c[n * (KR + 1) + kk];
+        q[n] += g;
       }
     }
     for (int n = 0; n <= NR; ++n)

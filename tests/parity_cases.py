@@ -181,17 +181,74 @@ def check_streaming_ops(drv):
     np.testing.assert_allclose(drv.host(d_th), tho, rtol=1e-12, atol=1e-12)
 
 
+def check_small_box(drv):
+    """NEP::compute's small-box branch (a periodic thickness <= 2.5 (rc + 1)): the reference's own
+    CUDA known answer for PbTe-250 (examples/gpumd_static/dump.xyz) and the BaZrO3-40 golden
+    regression of tests_pytest, plus the oracle's small-box lists (repeated periodic images)."""
+    # --- PbTe 250 atoms: config 1 of BASELINE.json, now on the device ---
+    nep = H.golden("PbTe", "nep.txt")
+    fr = H.read_xyz_frames(H.golden("PbTe", "model.xyz"))[0]
+    orc = H.Oracle(nep)
+    typ = H.types_from_species(fr["species"], orc.symbols)
+    x = H.soa(fr["pos"])
+    n = fr["n"]
+    model = drv.model(nep)
+    eng = drv.engine(model, n)
+    xw, pe, f, v = H.engine_force(drv, eng, fr["h"], typ, x)
+    ref = H.read_xyz_frames(H.golden("PbTe", "dump.xyz"))[0]
+    np.testing.assert_allclose(pe.sum(), ref["energy"], rtol=1e-5)
+    assert np.abs(f.reshape(3, n).T - ref["forces"]).max() < 2e-5        # check_force.m:9
+    vt = v.reshape(9, n).sum(axis=1)
+    got = np.array([vt[0], vt[3], vt[4], vt[6], vt[1], vt[5], vt[7], vt[8], vt[2]])
+    np.testing.assert_allclose(got, ref["virial"], rtol=1e-4, atol=2e-3)
+    xo = H.oracle_apply_pbc(fr["h"], x)
+    pe32, f32, v32 = orc.compute(typ, fr["h"], xo, precision=32, path=-1)
+    assert np.all(np.abs(f - f32) <= 1e-4 * np.abs(f32) + 2e-5)
+    assert np.all(np.abs(v - v32) <= 1e-4 * np.abs(v32) + 1e-4)
+    L = orc.lists(typ, fr["h"], xo)
+    assert L["path"] == 1
+    for which, key in ((0, "radial"), (1, "angular")):
+        onn, onl = L[key]
+        mx, nn, nl = H.engine_lists(drv, eng, n, which, ld=int(onn.max()) + 2)
+        assert mx == onn.max()
+        H.assert_lists_equal(nn, nl, onn, onl)
+    # --- BaZrO3 40 atoms (8 A cell, rc 8 A: many images of the same atom) ---
+    nep = H.golden("BaZrO3", "nep.txt")
+    fr = H.read_xyz_frames(H.golden("BaZrO3", "BaZrO3-nat40-rattled.xyz"))[0]
+    model = drv.model(nep)
+    typ = H.types_from_species(fr["species"], model.symbols)
+    g = np.load(H.golden("BaZrO3", "bulk_bazro3.npz"))
+    eng = drv.engine(model, fr["n"])
+    _, pe, f, v = H.engine_force(drv, eng, fr["h"], typ, H.soa(fr["pos"]))
+    np.testing.assert_allclose(pe.sum(), float(g["energy"]), rtol=1e-5)
+    np.testing.assert_allclose(f.reshape(3, -1).T, g["forces"], rtol=1e-4, atol=3e-5)
+    vol = abs(np.linalg.det(fr["lattice"]))
+    vt = v.reshape(9, -1).sum(axis=1)
+    stress = -np.array([vt[0], vt[1], vt[2], vt[5], vt[4], vt[3]]) / vol
+    np.testing.assert_allclose(stress, g["stress"], rtol=1e-4, atol=1e-6)
+    # --- a short NVE run in the small box against the oracle loop ---
+    nep = H.golden("PbTe", "nep.txt")
+    fr = H.read_xyz_frames(H.golden("PbTe", "model.xyz"))[0]
+    orc = H.Oracle(nep)
+    typ = H.types_from_species(fr["species"], orc.symbols)
+    n = fr["n"]
+    mass = np.array([H.MASS[orc.symbols[t]] for t in typ])
+    vel = H.maxwell_velocities(mass, 600.0, seed=8)
+    x = H.oracle_apply_pbc(fr["h"], H.soa(fr["pos"]))
+    ref = orc.run_nve(typ, fr["h"], x, vel, mass, 1.0 / H.TIME_UNIT, 5, precision=32)
+    eng = drv.engine(drv.model(nep), n)
+    d_t, d_m, d_x, d_v = drv.dev(typ), drv.dev(mass), drv.dev(x), drv.dev(vel)
+    d_pe, d_f, d_w = drv.zeros(n), drv.zeros(3 * n), drv.zeros(9 * n)
+    eng.force_compute(fr["h"], d_t, d_x, d_pe, d_f, d_w)
+    th = eng.run_nve(fr["h"], d_t, d_m, 1.0 / H.TIME_UNIT, 5, d_x, d_v, d_pe, d_f, d_w, thermo_every=1)
+    assert np.abs(drv.host(d_v) - ref["vel"]).max() < 1e-6
+    np.testing.assert_allclose(th[:, :2], ref["thermo"][:, :2], rtol=1e-6)
+
+
 def check_error_paths(drv):
     import pytest
     from gpumd_amd import NepmiError
     model = drv.model(H.golden("PbTe", "nep.txt"))
-    # 250-atom cell: thickness 18.97 A <= 2.5*(8+1): small-box branch is not on the device yet
-    fr = H.read_xyz_frames(H.golden("PbTe", "model.xyz"))[0]
-    typ = H.types_from_species(fr["species"], model.symbols)
-    eng = drv.engine(model, fr["n"])
-    with pytest.raises(NepmiError) as ei:
-        H.engine_force(drv, eng, fr["h"], typ, H.soa(fr["pos"]))
-    assert ei.value.code == -7
     # wrong atom count
     h, typ, x = H.pbte_supercell((2, 2, 2))
     eng = drv.engine(model, len(typ) - 1)

@@ -34,5 +34,9 @@ def test_streaming_ops(drv):
     P.check_streaming_ops(drv)
 
 
+def test_small_box_branch(drv):
+    P.check_small_box(drv)
+
+
 def test_error_paths(drv):
     P.check_error_paths(drv)

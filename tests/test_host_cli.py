@@ -72,6 +72,22 @@ def test_single_point_matches_oracle(tmp_path):
 
 
 @pytest.mark.gpu
+def test_config1_gpumd_static_example(tmp_path):
+    """BASELINE config 1 end to end: the reference's examples/gpumd_static (PbTe 250 atoms, small-box
+    branch) run by gpumd-mi; dump.xyz against the dump.xyz the reference's CUDA build wrote."""
+    run_in = open(H.golden("PbTe", "run.in")).read().replace("../nep_train/nep.txt", "NEP")
+    wd = _workdir(tmp_path, run_in)
+    out = subprocess.run([EXE], cwd=wd, capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    got = H.read_xyz_frames(os.path.join(wd, "dump.xyz"))[0]
+    ref = H.read_xyz_frames(H.golden("PbTe", "dump.xyz"))[0]
+    np.testing.assert_allclose(got["energy"], ref["energy"], rtol=1e-6)
+    assert np.abs(got["forces"] - ref["forces"]).max() < 2e-5       # check_force.m:9
+    np.testing.assert_allclose(got["virial"], ref["virial"], rtol=1e-4, atol=2e-3)
+    assert np.abs(got["pos"] - ref["pos"]).max() < 1e-12
+
+
+@pytest.mark.gpu
 def test_nve_run_writes_thermo(tmp_path):
     wd = _workdir(tmp_path, "replicate 2 2 2\npotential NEP\nvelocity 300 seed 42\nensemble nve\ntime_step 1\n"
                             "dump_thermo 10\ndump_restart 40\nrun 40\n")
