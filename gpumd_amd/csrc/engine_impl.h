@@ -198,6 +198,43 @@ public:
     be_.thermo(kSlotThermo, n, volume, mass, pe, vel, virial, thermo8, thermo_scratch_);
   }
 
+  void berendsen(int64_t n, double temperature, double coupling, const double* thermo8, double* vel)
+  {
+    if (coupling > 1.0e-5) { // ensemble_ber.cu:223
+      BerendsenBody body{n, temperature, coupling, thermo8, vel};
+      be_.template launch<256>(kSlotMisc, n, body);
+    }
+  }
+
+  // Run::perform_a_run for `ensemble nvt_ber T1 T2 Tcoup` (Ensemble_BER, ensemble_ber.cu:195-235;
+  // target temperature ramp of Integrate::compute2, integrate.cu:341-344)
+  void run_nvt_ber(
+    const double h9[9], const int pbc[3], int64_t n, const int* type, const double* mass, double dt,
+    int64_t nsteps, double t1, double t2, double tcoup, double* pos, double* vel, double* pe, double* force,
+    double* virial, int64_t thermo_every, double* thermo_host)
+  {
+    BoxD box;
+    box_from_h9(h9, pbc, box);
+    int64_t rec = 0;
+    for (int64_t step = 0; step < nsteps; ++step) {
+      const double target = t1 + (t2 - t1) * ((double)step / (double)nsteps);
+      velocity_verlet(true, n, dt, mass, force, pos, vel, &box);
+      zero_properties(n, pe, force, virial);
+      potential_compute(h9, pbc, n, type, pos, pe, force, virial);
+      velocity_verlet(false, n, dt, mass, force, pos, vel, nullptr);
+      find_thermo(n, box.volume, mass, pe, vel, virial, thermo_dev_);
+      berendsen(n, target, 1.0 / tcoup, thermo_dev_, vel);
+      if (thermo_every > 0 && (step + 1) % thermo_every == 0) {
+        be_.d2h(thermo_host + 8 * rec, thermo_dev_, 8 * sizeof(double));
+        ++rec;
+      }
+    }
+    be_.sync();
+    int flags[kNumFlags];
+    be_.d2h(flags, b_.flags, sizeof(flags));
+    check_overflow(flags);
+  }
+
   // Run::perform_a_run for `ensemble nve` (run.cu:250-318)
   void run_nve(
     const double h9[9], const int pbc[3], int64_t n, const int* type, const double* mass, double dt,

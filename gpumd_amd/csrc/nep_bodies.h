@@ -169,6 +169,21 @@ struct VelocityVerletBody {
   }
 };
 
+// gpu_berendsen_temperature, src/integrate/ensemble_ber.cu:70-86
+struct BerendsenBody {
+  int64_t N;
+  double temperature, coupling; // target T, 1 / T_coup
+  const double* thermo;         // thermo[0] = instantaneous T (find_thermo)
+  double* vel;
+  NEPMI_HD void operator()(int64_t i) const
+  {
+    const double factor = sqrt(1.0 + coupling * (temperature / thermo[0] - 1.0));
+    vel[i] *= factor;
+    vel[N + i] *= factor;
+    vel[2 * N + i] *= factor;
+  }
+};
+
 // ------------------------------------------------------------------------------------------------
 // neighbour rebuild (find_cell_list + gpu_find_neighbor_ON1, neighbor.cu:42-215)
 // ------------------------------------------------------------------------------------------------

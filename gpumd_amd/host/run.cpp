@@ -99,10 +99,24 @@ void Run::parse_one_keyword(const std::vector<std::string>& p)
   } else if (k == "ensemble") {
     if (p.size() < 2)
       input_error("ensemble should have at least 1 parameter.");
-    if (p[1] != "nve")
-      input_error("ensemble " + p[1] + " is not available in gpumd-mi yet (nve only; DESIGN.md section 8).");
+    if (p[1] == "nve") {
+      std::printf("Use NVE ensemble for this run.\n");
+    } else if (p[1] == "nvt_ber") { // Integrate::parse_ensemble, integrate.cu:424-428, 569-600
+      if (p.size() != 5)
+        input_error("ensemble nvt_ber should have 3 parameters.");
+      temperature1 = std::atof(p[2].c_str());
+      temperature2 = std::atof(p[3].c_str());
+      temperature_coupling = std::atof(p[4].c_str());
+      if (temperature1 <= 0.0 || temperature2 <= 0.0)
+        input_error("Temperature should > 0.");
+      if (temperature_coupling < 1.0)
+        input_error("Temperature coupling should >= 1.");
+      std::printf("Use NVT ensemble for this run.\n    choose the Berendsen method.\n    initial temperature is %g K.\n"
+                  "    final temperature is %g K.\n    tau_T is %g time_step.\n", temperature1, temperature2, temperature_coupling);
+    } else {
+      input_error("ensemble " + p[1] + " is not available in gpumd-mi yet (nve, nvt_ber; DESIGN.md section 8).");
+    }
     ensemble = p[1];
-    std::printf("Use NVE ensemble for this run.\n");
   } else if (k == "time_step") {
     if (p.size() != 2)
       input_error("time_step should have 1 parameter.");
@@ -306,6 +320,10 @@ void Run::perform_a_run()
     // integrate.compute2 (ensemble_nve.cu:59-95)
     nepmi_vv_step2(e, N, time_step, atom.mass.data(), atom.force_per_atom.data(), atom.velocity_per_atom.data());
     find_thermo();
+    if (ensemble == "nvt_ber") { // Ensemble_BER::compute2, ensemble_ber.cu:195-235
+      const double target = temperature1 + (temperature2 - temperature1) * (double(step) / number_of_steps);
+      nepmi_berendsen_scale(e, N, target, 1.0 / temperature_coupling, thermo.data(), atom.velocity_per_atom.data());
+    }
     // measure.process
     dump_thermo(step);
     for (auto& d : dump_xyzs)

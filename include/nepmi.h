@@ -135,6 +135,18 @@ int nepmi_run_nve(
   const double* mass, double dt, int64_t nsteps, double* pos, double* vel, double* pe,
   double* force, double* virial, int64_t thermo_every, double* thermo_host);
 
+/* ---- Berendsen thermostat: gpu_berendsen_temperature (src/integrate/ensemble_ber.cu:70-86),
+ *      v *= sqrt(1 + coupling (T_target / T - 1)) with T = thermo8[0] (DEVICE, from find_thermo) and
+ *      coupling = 1 / T_coup; and the whole `ensemble nvt_ber T1 T2 T_coup` loop
+ *      (Ensemble_BER::compute1/compute2, ensemble_ber.cu:180-235; linear target ramp T1 -> T2,
+ *      integrate.cu:341-344).  thermo_host records find_thermo's output (before the rescale). ---- */
+int nepmi_berendsen_scale(
+  nepmi_engine* e, int64_t n, double temperature, double coupling, const double* thermo8, double* vel);
+int nepmi_run_nvt_ber(
+  nepmi_engine* e, const double h[9], const int pbc[3], int64_t n, const int* type,
+  const double* mass, double dt, int64_t nsteps, double t1, double t2, double t_coup, double* pos,
+  double* vel, double* pe, double* force, double* virial, int64_t thermo_every, double* thermo_host);
+
 /* ---- diagnostics / parity hooks ---- */
 
 /* Per-step radial (which = 0) / angular (which = 1) neighbour lists of the LAST compute, in the

@@ -245,6 +245,43 @@ def check_small_box(drv):
     np.testing.assert_allclose(th[:, :2], ref["thermo"][:, :2], rtol=1e-6)
 
 
+def check_nvt_berendsen(drv, nsteps=30):
+    """`ensemble nvt_ber 300 600 20`: VV + find_thermo + gpu_berendsen_temperature
+    (ensemble_ber.cu:70-86, 195-235) against the same loop built from oracle pieces."""
+    nep = H.golden("PbTe", "nep.txt")
+    h, typ, x = H.pbte_supercell((2, 2, 2), rattle=0.01, seed=51)
+    n = len(typ)
+    orc = H.Oracle(nep)
+    mass = np.array([H.MASS[orc.symbols[t]] for t in typ])
+    vel = H.maxwell_velocities(mass, 300.0, seed=6)
+    dt = 1.0 / H.TIME_UNIT
+    t1, t2, tc = 300.0, 600.0, 20.0
+    vol = abs(np.linalg.det(np.asarray(h).reshape(3, 3)))
+    L = H.oracle_lib()
+    xo, vo = x.copy(), vel.copy()
+    pe, f, w = orc.compute(typ, h, xo, precision=32, path=0)
+    th_ref = []
+    for step in range(nsteps):
+        L.nepo_velocity_verlet(1, n, dt, H._p(mass, H._dp), H._p(f, H._dp), H._p(xo, H._dp), H._p(vo, H._dp))
+        xo = H.oracle_apply_pbc(h, xo)
+        pe, f, w = orc.compute(typ, h, xo, precision=32, path=0)
+        L.nepo_velocity_verlet(0, n, dt, H._p(mass, H._dp), H._p(f, H._dp), H._p(xo, H._dp), H._p(vo, H._dp))
+        th = H.oracle_thermo(vol, mass, pe, vo, w)
+        th_ref.append(th)
+        target = t1 + (t2 - t1) * (step / nsteps)
+        vo *= np.sqrt(1.0 + (1.0 / tc) * (target / th[0] - 1.0))
+    th_ref = np.array(th_ref)
+    eng = drv.engine(drv.model(nep), n)
+    d_t, d_m, d_x, d_v = drv.dev(typ), drv.dev(mass), drv.dev(x), drv.dev(vel)
+    d_pe, d_f, d_w = drv.zeros(n), drv.zeros(3 * n), drv.zeros(9 * n)
+    eng.force_compute(h, d_t, d_x, d_pe, d_f, d_w)
+    th = eng.run_nvt_ber(h, d_t, d_m, dt, nsteps, t1, t2, tc, d_x, d_v, d_pe, d_f, d_w, thermo_every=1)
+    np.testing.assert_allclose(th[:, 0], th_ref[:, 0], rtol=1e-6)
+    np.testing.assert_allclose(th[:, 1], th_ref[:, 1], rtol=1e-6)
+    assert np.abs(drv.host(d_v) - vo).max() < 1e-6
+    assert th[-1, 0] > th[0, 0]  # the thermostat heats the crystal towards the 600 K target
+
+
 def check_error_paths(drv):
     import pytest
     from gpumd_amd import NepmiError

@@ -36,6 +36,10 @@ def test_streaming_ops(drv):
     P.check_streaming_ops(drv)
 
 
+def test_nvt_berendsen(drv):
+    P.check_nvt_berendsen(drv)
+
+
 def test_small_box_branch(drv):
     P.check_small_box(drv)
 

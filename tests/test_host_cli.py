@@ -38,7 +38,7 @@ def test_check_input_parses_run_in_and_model(tmp_path):
 
 
 @pytest.mark.parametrize("bad,msg", [("potential NEP\nfoo 1\nrun 1\n", "invalid keyword"),
-                                     ("potential NEP\nensemble nvt_ber 300 300 100\nrun 1\n", "not available"),
+                                     ("potential NEP\nensemble nvt_nhc 300 300 100\nrun 1\n", "not available"),
                                      ("velocity 300\nrun 1\n", "no 'potential'")])
 def test_input_errors_exit_like_the_reference(tmp_path, bad, msg):
     wd = _workdir(tmp_path, bad)
