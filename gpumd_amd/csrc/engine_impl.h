@@ -7,6 +7,7 @@
 #pragma once
 #include "nep_bodies.h"
 #include "nep_model.h"
+#include "tersoff_bodies.h"
 
 #include <cmath>
 #include <cstdio>
@@ -124,6 +125,8 @@ public:
     N_ = n;
     b_.N = n;
     b_.level = level;
+    if (model_.kind == 1 && is_small_box(box))
+      throw EngineError{-7, "Tersoff-1989: box thickness <= 2.5 (rc + skin) in a periodic direction is not supported"};
     if (is_small_box(box)) { // NEP::compute -> compute_small_box (nep.cu:1356-1389)
       box_ = box;
       small_box_compute(type, pos, pe, force, virial);
@@ -265,8 +268,12 @@ public:
   {
     if (!have_list_ && !last_small_)
       throw EngineError{-4, "no force evaluation has been performed yet"};
-    ExportListsBody body{b_, which, nn, nl, ld};
-    be_.template launch<64>(kSlotMisc, N_, body);
+    if (model_.kind == 1 && which != 2) {
+      be_.template launch<64>(kSlotMisc, N_, TersoffExportBody{b_, tb_, nn, nl, ld});
+    } else {
+      ExportListsBody body{b_, which, nn, nl, ld};
+      be_.template launch<64>(kSlotMisc, N_, body);
+    }
     int flags[kNumFlags];
     be_.d2h(flags, b_.flags, sizeof(flags));
     check_overflow(flags);
@@ -278,6 +285,8 @@ public:
   {
     if (!have_list_ && !last_small_)
       throw EngineError{-4, "no force evaluation has been performed yet"};
+    if (model_.kind != 0)
+      throw EngineError{-4, "descriptors exist for NEP models only"};
     ExportDescBody body{b_, model_.dim, q, fp};
     be_.template launch<64>(kSlotMisc, N_, body);
   }
@@ -388,17 +397,31 @@ private:
     b_.nl_ang = dalloc<int>((size_t)b_.MN_ang * N);
     b_.rev_ang = dalloc<unsigned short>((size_t)b_.MN_ang * N);
     b_.nn_rad = dalloc<int>(N);
-    b_.rstash = dalloc<F4>((size_t)(b_.MN_ang + b_.MN_skin) * N);
     b_.nn_angstep = dalloc<int>(N);
-    b_.acomp = dalloc<F4>((size_t)b_.MN_acomp * N);
-    b_.amap = dalloc<unsigned short>((size_t)b_.MN_ang * N);
-    b_.f12 = dalloc<F4>((size_t)b_.MN_acomp * N);
-    b_.q = dalloc<float>((size_t)m.dim * N);
-    b_.fp = dalloc<float>((size_t)m.dim * N);
-    b_.sbuf = dalloc<float>((size_t)(m.n_max_angular + 1) * kNumHarm * N);
-    b_.KRP = ((m.basis_size_radial + 1) + 3) / 4 * 4;
-    b_.atab = dalloc<float>((size_t)N * m.num_types * b_.KRP);
-    b_.pe_i = dalloc<float>(N);
+    if (m.kind == 0) {
+      b_.rstash = dalloc<F4>((size_t)(b_.MN_ang + b_.MN_skin) * N);
+      b_.acomp = dalloc<F4>((size_t)b_.MN_acomp * N);
+      b_.amap = dalloc<unsigned short>((size_t)b_.MN_ang * N);
+      b_.f12 = dalloc<F4>((size_t)b_.MN_acomp * N);
+      b_.q = dalloc<float>((size_t)m.dim * N);
+      b_.fp = dalloc<float>((size_t)m.dim * N);
+      b_.sbuf = dalloc<float>((size_t)(m.n_max_angular + 1) * kNumHarm * N);
+      b_.KRP = ((m.basis_size_radial + 1) + 3) / 4 * 4;
+      b_.atab = dalloc<float>((size_t)N * m.num_types * b_.KRP);
+      b_.pe_i = dalloc<float>(N);
+    } else { // Tersoff-1989: Tersoff1989::Tersoff1989 allocations (tersoff1989.cu:141-149)
+      tb_.rec = dalloc<D4>((size_t)b_.MN_ang * N);
+      tb_.bb = dalloc<double>((size_t)b_.MN_ang * N);
+      tb_.bp = dalloc<double>((size_t)b_.MN_ang * N);
+      tb_.f12 = dalloc<D4>((size_t)b_.MN_ang * N);
+      tb_.pe_d = dalloc<double>(N);
+      for (int k = 0; k < 3; ++k) {
+        const TersoffSet& s = m.ters[k];
+        tp_.p[k] = TersoffSetD{s.a, s.b, s.lambda, s.mu, s.beta, s.n, s.c, s.d, s.h, s.r1, s.r2, s.c2, s.d2,
+                               s.one_plus_c2overd2, s.pi_factor, s.minus_half_over_n};
+      }
+      tp_.rc_sq = (float)(m.rc_radial_max * m.rc_radial_max);
+    }
     b_.zbl = dalloc<float>(m.zbl_enabled ? (size_t)10 * N : 1);
     b_.lvl = dalloc<signed char>(N);
     b_.flags = dalloc<int>(kNumFlags);
@@ -616,6 +639,13 @@ private:
 
   void force_kernels(double* pe, double* force, double* virial)
   {
+    if (model_.kind == 1) { // Tersoff1989::compute, tersoff1989.cu:508-586
+      be_.begin_region(kRegionForce);
+      be_.template launch<64>(kSlotRadial, N_, TersoffPartialBody{box_, tp_, b_, tb_});
+      be_.template launch<64>(kSlotForce, N_, TersoffAssembleBody{b_, tb_, pe, force, virial});
+      be_.end_region(kRegionForce);
+      return;
+    }
     switch (shape_) {
       case 1: force_kernels_shape<S_PbTeA>(pe, force, virial); break;
       case 2: force_kernels_shape<S_PbTeB>(pe, force, virial); break;
@@ -633,6 +663,8 @@ private:
   ModelD md_;
   Bufs b_;
   BoxD box_;
+  TersoffBufs tb_{};
+  TersoffParamsD tp_{};
   bool have_list_ = false;
   bool last_small_ = false;
   bool force_generic_ = false;

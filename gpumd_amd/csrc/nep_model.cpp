@@ -2,6 +2,7 @@
 // block as accepted by its vendored NEP_CPU (nep.cpp:2568-2872).
 #include "nep_model.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <fstream>
@@ -36,6 +37,59 @@ bool starts_with(const std::string& s, const char* p) { return s.rfind(p, 0) == 
 
 } // namespace
 
+// Tersoff1989::Tersoff1989, src/force/tersoff1989.cu:30-149
+static std::string load_tersoff(std::istream& in, const std::vector<std::string>& head, NepModel& m)
+{
+  m.kind = 1;
+  m.num_types = std::atoi(head[1].c_str());
+  if (m.num_types < 1 || m.num_types > 2 || (int)head.size() != 2 + m.num_types)
+    return "tersoff_1989 supports 1 or 2 element(s), listed on the first line.";
+  m.symbols.assign(head.begin() + 2, head.end());
+  auto finish = [](TersoffSet& t) {
+    t.c2 = t.c * t.c;
+    t.d2 = t.d * t.d;
+    t.one_plus_c2overd2 = 1.0 + t.c2 / t.d2;
+    t.pi_factor = 3.14159265358979323846 / (t.r2 - t.r1); // PI, src/utilities/common.cuh
+    t.minus_half_over_n = -0.5 / t.n;
+  };
+  for (int t = 0; t < m.num_types; ++t) {
+    auto tok = next_tokens(in);
+    if (tok.size() != 11)
+      return "Reading error for Tersoff-1989 potential.";
+    TersoffSet& s = m.ters[t];
+    double* f[11] = {&s.a, &s.b, &s.lambda, &s.mu, &s.beta, &s.n, &s.c, &s.d, &s.h, &s.r1, &s.r2};
+    for (int k = 0; k < 11; ++k)
+      *f[k] = std::atof(tok[k].c_str());
+    finish(s);
+  }
+  double rc = m.ters[0].r2;
+  if (m.num_types == 2) {
+    auto tok = next_tokens(in);
+    if (tok.size() != 1)
+      return "Reading error for Tersoff-1989 potential.";
+    const double chi = std::atof(tok[0].c_str());
+    TersoffSet& q = m.ters[2];
+    q.a = std::sqrt(m.ters[0].a * m.ters[1].a);
+    q.b = std::sqrt(m.ters[0].b * m.ters[1].b) * chi;
+    q.lambda = 0.5 * (m.ters[0].lambda + m.ters[1].lambda);
+    q.mu = 0.5 * (m.ters[0].mu + m.ters[1].mu);
+    q.r1 = std::sqrt(m.ters[0].r1 * m.ters[1].r1);
+    q.r2 = std::sqrt(m.ters[0].r2 * m.ters[1].r2);
+    q.pi_factor = 3.14159265358979323846 / (q.r2 - q.r1);
+    rc = std::max(m.ters[0].r2, m.ters[1].r2);
+  }
+  // the shared Verlet-list machinery sees one cutoff; 50 neighbours like the reference (:141-149)
+  m.rc_radial_max = m.rc_angular_max = rc;
+  m.rc_radial.assign(m.num_types, rc);
+  m.rc_angular.assign(m.num_types, rc);
+  m.rc_radial_f.assign(m.num_types, (float)rc);
+  m.rc_angular_f.assign(m.num_types, (float)rc);
+  m.MN_radial = m.MN_angular = 50;
+  m.atomic_numbers.assign(m.num_types, 0);
+  m.b1t.assign(m.num_types, 0.0f);
+  return "";
+}
+
 std::string load_nep_model(const std::string& path, NepModel& m, bool* unsupported)
 {
   if (unsupported)
@@ -52,6 +106,8 @@ std::string load_nep_model(const std::string& path, NepModel& m, bool* unsupport
   auto tok = next_tokens(in);
   if (tok.size() < 3)
     return "The first line of nep.txt should have at least 3 items.";
+  if (tok[0] == "tersoff_1989")
+    return load_tersoff(in, tok, m);
   const std::string& head = tok[0];
   // header: nep{3,4,5}[_zbl]; every other suffix (charge, dipole, polarizability, temperature)
   // is a different model_type in the reference (nep.cu:113-143) and outside this engine.

@@ -9,7 +9,15 @@ namespace nepmi {
 
 constexpr int kMaxTypes = 94;
 
+// one Tersoff-1989 parameter set + the derived constants of src/force/tersoff1989.cu:66-72
+struct TersoffSet {
+  double a = 0, b = 0, lambda = 0, mu = 0, beta = 0, n = 0, c = 0, d = 0, h = 0, r1 = 0, r2 = 0;
+  double c2 = 0, d2 = 0, one_plus_c2overd2 = 0, pi_factor = 0, minus_half_over_n = 0;
+};
+
 struct NepModel {
+  int kind = 0;    // 0: NEP, 1: Tersoff-1989 (BASELINE config 2)
+  TersoffSet ters[3]; // type 0-0, type 1-1, mixed (tersoff1989.cu:115-140)
   int version = 0; // 3, 4, 5
   bool zbl_enabled = false, zbl_flexible = false;
   double zbl_rc_inner = 0, zbl_rc_outer = 0;

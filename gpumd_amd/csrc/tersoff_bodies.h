@@ -1,0 +1,273 @@
+// Tersoff-1989 (BASELINE config 2) on the shared Verlet-list machinery, FP64 like the reference
+// (src/force/tersoff1989.cu:157-586, src/force/potential.cu:35-134).
+//
+// The engine's list A (rc + skin, static reverse slots) is the Verlet list.  Two kernels per call:
+//   TersoffPartialBody   per atom: local-list membership (FLOAT geometry, as
+//                        gpu_find_local_neighbor_from_global, neighbor.cu:699-737), bond order b and
+//                        b' (step 1, tersoff1989.cu:337-405), partial forces dU_i/dr_ij and U_i
+//                        (step 2, :408-505); pair geometry (double + double MIC) is computed once
+//                        and kept in a per-slot record.
+//   TersoffAssembleBody  F_i = sum_j f12 - f21, virial, through the reverse slot (the reference
+//                        searches j's list linearly, potential.cu:86-92); scatter-add to the caller.
+#pragma once
+#include "nep_bodies.h"
+
+namespace nepmi {
+
+struct TersoffSetD {
+  double a, b, lambda, mu, beta, n, c, d, h, r1, r2;
+  double c2, d2, one_plus_c2overd2, pi_factor, minus_half_over_n;
+};
+
+struct TersoffParamsD {
+  TersoffSetD p[3]; // type 0-0, type 1-1, mixed
+  float rc_sq;      // float(rc * rc), the local-list test
+};
+
+struct alignas(16) D4 {
+  double x, y, z;
+  long long w; // 1 = member of the local list this step
+};
+
+// apply_mic (double), src/model/box.cuh:39-82
+NEPMI_HD void mic_d(const BoxD& box, double& x, double& y, double& z)
+{
+  const double* h = box.h;
+  if (box.ortho) {
+    if (box.pbc[0]) { if (x < -h[0] * 0.5) x += h[0]; else if (x > h[0] * 0.5) x -= h[0]; }
+    if (box.pbc[1]) { if (y < -h[4] * 0.5) y += h[4]; else if (y > h[4] * 0.5) y -= h[4]; }
+    if (box.pbc[2]) { if (z < -h[8] * 0.5) z += h[8]; else if (z > h[8] * 0.5) z -= h[8]; }
+  } else {
+    double sx = h[9] * x + h[10] * y + h[11] * z;
+    double sy = h[12] * x + h[13] * y + h[14] * z;
+    double sz = h[15] * x + h[16] * y + h[17] * z;
+    if (box.pbc[0]) sx -= nearbyint(sx);
+    if (box.pbc[1]) sy -= nearbyint(sy);
+    if (box.pbc[2]) sz -= nearbyint(sz);
+    x = h[0] * sx + h[1] * sy + h[2] * sz;
+    y = h[3] * sx + h[4] * sy + h[5] * sz;
+    z = h[6] * sx + h[7] * sy + h[8] * sz;
+  }
+}
+
+NEPMI_HD const TersoffSetD& ters_pair(const TersoffParamsD& t, int t1, int t2)
+{
+  return (t1 == 0 && t2 == 0) ? t.p[0] : ((t1 == 1 && t2 == 1) ? t.p[1] : t.p[2]);
+}
+
+NEPMI_HD void ters_fc(const TersoffSetD& p, double d, double& fc, double& fcp)
+{
+  if (d < p.r1) {
+    fc = 1.0;
+    fcp = 0.0;
+  } else if (d < p.r2) {
+    fc = cos(p.pi_factor * (d - p.r1)) * 0.5 + 0.5;
+    fcp = -sin(p.pi_factor * (d - p.r1)) * p.pi_factor * 0.5;
+  } else {
+    fc = 0.0;
+    fcp = 0.0;
+  }
+}
+
+struct TersoffBufs {
+  D4* rec;      // [MN_ang][N] pair geometry + membership
+  double* bb;   // [MN_ang][N] bond order
+  double* bp;   // [MN_ang][N] its derivative
+  D4* f12;      // [MN_ang][N] partial forces
+  double* pe_d; // [N]
+};
+
+struct TersoffPartialBody {
+  BoxD box;
+  TersoffParamsD tp;
+  Bufs b;
+  TersoffBufs tb;
+  NEPMI_HD void operator()(int64_t k) const
+  {
+    const int64_t N = b.N;
+    if (b.lvl[k] < 1)
+      return;
+    const PosQ p1 = b.posq[k];
+    const int t1 = p1.type;
+    const TersoffSetD& s1 = tp.p[t1];
+    const int nn = b.nn_ang[k];
+    int cnt = 0;
+    // geometry + membership of every Verlet entry
+    for (int s = 0; s < nn; ++s) {
+      const int j = b.nl_ang[(int64_t)s * N + k];
+      const PosQ p2 = b.posq[j];
+      float xf, yf, zf;
+      const float d2f = pair_geometry(box, p1, p2, xf, yf, zf); // float test of the local list
+      D4 r;
+      r.x = p2.x - p1.x;
+      r.y = p2.y - p1.y;
+      r.z = p2.z - p1.z;
+      mic_d(box, r.x, r.y, r.z);
+      r.w = d2f < tp.rc_sq ? (1 | ((long long)p2.type << 8)) : 0;
+      cnt += (int)(r.w & 1);
+      tb.rec[(int64_t)s * N + k] = r;
+    }
+    b.nn_rad[k] = cnt;
+    b.nn_angstep[k] = cnt;
+    // step 1: bond order
+    for (int i1 = 0; i1 < nn; ++i1) {
+      const D4 r12 = tb.rec[(int64_t)i1 * N + k];
+      if (!(r12.w & 1))
+        continue;
+      const double d12 = sqrt(r12.x * r12.x + r12.y * r12.y + r12.z * r12.z);
+      double zeta = 0.0;
+      for (int i2 = 0; i2 < nn; ++i2) {
+        if (i2 == i1)
+          continue;
+        const D4 r13 = tb.rec[(int64_t)i2 * N + k];
+        if (!(r13.w & 1))
+          continue;
+        const int t3 = (int)(r13.w >> 8);
+        const double d13 = sqrt(r13.x * r13.x + r13.y * r13.y + r13.z * r13.z);
+        const double c123 = (r12.x * r13.x + r12.y * r13.y + r12.z * r13.z) / (d12 * d13);
+        double fc13, fcp13;
+        ters_fc(ters_pair(tp, t1, t3), d13, fc13, fcp13);
+        const double tmp = s1.d2 + (c123 - s1.h) * (c123 - s1.h);
+        zeta += fc13 * (s1.one_plus_c2overd2 - s1.c2 / tmp);
+      }
+      const double bzn = pow(s1.beta * zeta, s1.n);
+      const double b12 = pow(1.0 + bzn, s1.minus_half_over_n);
+      if (zeta < 1.0e-16) { // avoid division by 0
+        tb.bb[(int64_t)i1 * N + k] = 1.0;
+        tb.bp[(int64_t)i1 * N + k] = 0.0;
+      } else {
+        tb.bb[(int64_t)i1 * N + k] = b12;
+        tb.bp[(int64_t)i1 * N + k] = -b12 * bzn * 0.5 / ((1.0 + bzn) * zeta);
+      }
+    }
+    // step 2: partial forces and energy
+    double u = 0.0;
+    for (int i1 = 0; i1 < nn; ++i1) {
+      const D4 r12 = tb.rec[(int64_t)i1 * N + k];
+      D4 out;
+      out.x = out.y = out.z = 0.0;
+      out.w = 0;
+      if (r12.w & 1) {
+        const int t2 = (int)(r12.w >> 8);
+        const TersoffSetD& p12 = ters_pair(tp, t1, t2);
+        const double d12 = sqrt(r12.x * r12.x + r12.y * r12.y + r12.z * r12.z);
+        const double d12inv = 1.0 / d12;
+        double fc12, fcp12;
+        ters_fc(p12, d12, fc12, fcp12);
+        const double fa12 = p12.b * exp(-p12.mu * d12), fap12 = -p12.mu * fa12;
+        const double fr12 = p12.a * exp(-p12.lambda * d12), frp12 = -p12.lambda * fr12;
+        const double b12 = tb.bb[(int64_t)i1 * N + k], bp12 = tb.bp[(int64_t)i1 * N + k];
+        const double factor3 = (fcp12 * (fr12 - b12 * fa12) + fc12 * (frp12 - b12 * fap12)) * d12inv;
+        double fx = r12.x * factor3 * 0.5, fy = r12.y * factor3 * 0.5, fz = r12.z * factor3 * 0.5;
+        u += fc12 * (fr12 - b12 * fa12) * 0.5;
+        for (int i2 = 0; i2 < nn; ++i2) {
+          if (i2 == i1)
+            continue;
+          const D4 r13 = tb.rec[(int64_t)i2 * N + k];
+          if (!(r13.w & 1))
+            continue;
+          const int t3 = (int)(r13.w >> 8);
+          const TersoffSetD& p13 = ters_pair(tp, t1, t3);
+          const double d13 = sqrt(r13.x * r13.x + r13.y * r13.y + r13.z * r13.z);
+          double fc13, fcp13;
+          ters_fc(p13, d13, fc13, fcp13);
+          const double fa13 = p13.b * exp(-p13.mu * d13);
+          const double bp13 = tb.bp[(int64_t)i2 * N + k];
+          const double od = 1.0 / (d12 * d13);
+          const double c123 = (r12.x * r13.x + r12.y * r13.y + r12.z * r13.z) * od;
+          const double c_over = c123 * d12inv * d12inv;
+          const double tmp = s1.d2 + (c123 - s1.h) * (c123 - s1.h);
+          const double g123 = s1.one_plus_c2overd2 - s1.c2 / tmp;
+          const double gp123 = 2.0 * s1.c2 * (c123 - s1.h) / (tmp * tmp);
+          const double ta = (-bp12 * fc12 * fa12 * fc13 - bp13 * fc13 * fa13 * fc12) * gp123;
+          const double tbb = -bp13 * fc13 * fa13 * fcp12 * g123 * d12inv;
+          fx += (r12.x * tbb + ta * (r13.x * od - r12.x * c_over)) * 0.5;
+          fy += (r12.y * tbb + ta * (r13.y * od - r12.y * c_over)) * 0.5;
+          fz += (r12.z * tbb + ta * (r13.z * od - r12.z * c_over)) * 0.5;
+        }
+        out.x = fx;
+        out.y = fy;
+        out.z = fz;
+      }
+      tb.f12[(int64_t)i1 * N + k] = out;
+    }
+    tb.pe_d[k] = u;
+  }
+};
+
+struct TersoffAssembleBody {
+  Bufs b;
+  TersoffBufs tb;
+  double* pe;
+  double* force;
+  double* virial;
+  NEPMI_HD void operator()(int64_t k) const
+  {
+    const int64_t N = b.N;
+    if (b.lvl[k] < 2)
+      return;
+    double F[3] = {0, 0, 0}, W[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const int nn = b.nn_ang[k];
+    for (int s = 0; s < nn; ++s) {
+      const D4 r = tb.rec[(int64_t)s * N + k];
+      if (!(r.w & 1))
+        continue;
+      const int j = b.nl_ang[(int64_t)s * N + k];
+      const int rs = b.rev_ang[(int64_t)s * N + k];
+      const D4 f12 = tb.f12[(int64_t)s * N + k];
+      const D4 f21 = tb.f12[(int64_t)rs * N + j];
+      F[0] += f12.x - f21.x;
+      F[1] += f12.y - f21.y;
+      F[2] += f12.z - f21.z;
+      W[0] += r.x * f21.x;
+      W[1] += r.y * f21.y;
+      W[2] += r.z * f21.z;
+      W[3] += r.x * f21.y;
+      W[4] += r.x * f21.z;
+      W[5] += r.y * f21.z;
+      W[6] += r.y * f21.x;
+      W[7] += r.z * f21.x;
+      W[8] += r.z * f21.y;
+    }
+    const int64_t i = b.perm[k];
+    pe[i] += tb.pe_d[k];
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+      force[d * N + i] += F[d];
+#pragma unroll
+    for (int d = 0; d < 9; ++d)
+      virial[d * N + i] += W[d];
+  }
+};
+
+// the local list of the last call, caller indices, ascending (for bit-exact list checks)
+struct TersoffExportBody {
+  Bufs b;
+  TersoffBufs tb;
+  int* nn_out;
+  int* nl_out;
+  int64_t ld;
+  NEPMI_HD void operator()(int64_t k) const
+  {
+    const int64_t N = b.N;
+    const int64_t i = b.perm[k];
+    int cnt = 0;
+    for (int s = 0; s < b.nn_ang[k]; ++s) {
+      if (!(tb.rec[(int64_t)s * N + k].w & 1))
+        continue;
+      const int jc = b.perm[b.nl_ang[(int64_t)s * N + k]];
+      if (cnt < ld) {
+        int p = cnt - 1;
+        while (p >= 0 && nl_out[(int64_t)p * N + i] > jc) {
+          nl_out[(int64_t)(p + 1) * N + i] = nl_out[(int64_t)p * N + i];
+          --p;
+        }
+        nl_out[(int64_t)(p + 1) * N + i] = jc;
+      }
+      ++cnt;
+    }
+    nn_out[i] = cnt;
+  }
+};
+
+} // namespace nepmi

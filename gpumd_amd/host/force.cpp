@@ -25,6 +25,18 @@ NEP_MI::NEP_MI(const char* file_potential, int num_atoms)
   rc = info.rc_radial;
   N1 = 0;
   N2 = num_atoms;
+  if (info.version == 0) { // Tersoff-1989
+    std::printf("Use Tersoff-1989 (%d-element) potential with element(s):", info.num_types);
+    for (int t = 0; t < info.num_types; ++t)
+      std::printf(" %s", nepmi_model_symbol(model_, t));
+    std::printf("\n    cutoff = %g A.\n", info.rc_radial);
+    engine_ = nepmi_engine_create(model_, num_atoms, nullptr);
+    if (!engine_) {
+      std::printf("Tersoff: %s\n", nepmi_last_error());
+      std::exit(1);
+    }
+    return;
+  }
   std::printf("Use the NEP%d potential with %d atom type%s.\n", info.version, info.num_types, info.num_types > 1 ? "s" : "");
   for (int t = 0; t < info.num_types; ++t)
     std::printf("    type %d (%s).\n", t, nepmi_model_symbol(model_, t));
@@ -100,7 +112,7 @@ void Force::parse_potential(const std::vector<std::string>& param, const Box&, i
     input_error("Failed to open " + param[1] + ".");
   std::string name;
   in >> name;
-  if (name.rfind("nep", 0) == 0) {
+  if (name.rfind("nep", 0) == 0 || name == "tersoff_1989") { // both live in libnepmi.so
     potentials.clear();
     potentials.emplace_back(new NEP_MI(param[1].c_str(), number_of_atoms));
   } else {

@@ -482,3 +482,57 @@ def assert_lists_equal(nn, nl, onn, onl):
 
 # the reference's own regression tolerances, tests_pytest/conftest.py:51-60
 TOL = dict(energy_rtol=1e-5, energy_atol=1e-8, force_rtol=1e-4, force_atol=1e-6, virial_rtol=1e-4, virial_atol=1e-6)
+
+
+# --------------------------------------------------------------------------------------------
+# Tersoff-1989 oracle (oracle/tersoff_oracle.c)
+# --------------------------------------------------------------------------------------------
+_terso_lib = None
+
+
+def terso_lib():
+    global _terso_lib
+    if _terso_lib is None:
+        path = os.path.join(ORACLE_DIR, "libtersoff_oracle.so")
+        if not os.path.exists(path):
+            build_oracle()
+        L = C.CDLL(path)
+        L.terso_load.restype = C.c_void_p
+        L.terso_load.argtypes = [C.c_char_p]
+        L.terso_free.argtypes = [C.c_void_p]
+        L.terso_rc.restype = C.c_double
+        L.terso_rc.argtypes = [C.c_void_p]
+        L.terso_compute.argtypes = [C.c_void_p, C.c_int, _ip, _dp, _ip, _dp, _dp, _dp, _dp, _ip, _ip, C.c_int]
+        _terso_lib = L
+    return _terso_lib
+
+
+class TersoffOracle:
+    def __init__(self, path):
+        self.L = terso_lib()
+        self.h = self.L.terso_load(path.encode())
+        if not self.h:
+            raise RuntimeError("tersoff oracle: cannot load " + path)
+        self.rc = self.L.terso_rc(self.h)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.terso_free(self.h)
+            self.h = None
+
+    def compute(self, typ, h, pos_soa, pbc=(1, 1, 1), lists=False):
+        n = len(typ)
+        typ = np.ascontiguousarray(typ, dtype=np.int32)
+        h = np.ascontiguousarray(h, dtype=np.float64)
+        pbc = np.ascontiguousarray(pbc, dtype=np.int32)
+        pos = np.ascontiguousarray(pos_soa, dtype=np.float64)
+        pe, f, v = np.zeros(n), np.zeros(3 * n), np.zeros(9 * n)
+        nn = np.zeros(n, dtype=np.int32)
+        nl = np.full((64, n), -1, dtype=np.int32)
+        mx = self.L.terso_compute(self.h, n, _p(typ, _ip), _p(h, _dp), _p(pbc, _ip), _p(pos, _dp), _p(pe, _dp),
+                                  _p(f, _dp), _p(v, _dp), _p(nn, _ip), _p(nl, _ip), 64)
+        if mx < 0:
+            raise RuntimeError("tersoff oracle failed")
+        if lists:
+            return pe, f, v, nn, nl[:max(mx, 1)]
+        return pe, f, v
