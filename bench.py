@@ -152,20 +152,23 @@ def run_decomposed(args, world, rank, dev, model, h_block, typ, x, mass, vel, re
     md.run(args.warmup, dt)
     md.engine.set_timing(True)
     dec0 = md.num_decompositions
-    dist.barrier()
+    if world > 1:
+        dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     md.run(args.steps, dt)
-    dist.barrier()
+    if world > 1:
+        dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     st = md.engine.stats(with_lists=True)
     th = md.thermo()
     t_el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    md._all_reduce(t_el, dist.ReduceOp.MAX)
-    elapsed = float(t_el.item())
     n_loc = torch.tensor([md.n_loc], dtype=torch.float64, device=dev)
-    md._all_reduce(n_loc, dist.ReduceOp.MAX)
+    if world > 1:
+        md._all_reduce(t_el, dist.ReduceOp.MAX)
+        md._all_reduce(n_loc, dist.ReduceOp.MAX)
+    elapsed = float(t_el.item())
     if rank == 0:
         kern, roofline, b_step = kernel_report(st, model.info, md.n_loc)
         total = md.n_total
@@ -185,8 +188,9 @@ def run_decomposed(args, world, rank, dev, model, h_block, typ, x, mass, vel, re
             "kernels": kern, "thermo_last": [float(v) for v in th],
         }
         print(json.dumps(out))
-    dist.barrier()
-    dist.destroy_process_group()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def main():
@@ -196,6 +200,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--reps", type=int, nargs=3, default=[16, 16, 16], help="replicate na nb nc of the 250-atom cell")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--decomposed", action="store_true",
+                    help="run the N > 1 code path (DomainMD) even on one GPU, to measure its host-side overhead")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -231,7 +237,7 @@ def main():
     nep_txt = H.golden("PbTe", "nep.txt")
     model = gpumd_amd.Model(nep_txt)
     dt = 1.0 / H.TIME_UNIT
-    if world > 1:
+    if world > 1 or args.decomposed:
         run_decomposed(args, world, rank, dev, model, h, typ, x, mass, vel, reps)
         return
     eng = gpumd_amd.NEP(model, n)
