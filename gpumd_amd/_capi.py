@@ -29,7 +29,7 @@ class NepmiStats(C.Structure):
         ("max_nn_skin", C.c_int), ("max_nn_radial", C.c_int), ("max_nn_angular", C.c_int),
         ("mean_nn_radial", C.c_double), ("mean_nn_angular", C.c_double),
         ("ms_force_last", C.c_double), ("ms_kernel", C.c_double * 8),
-        ("ms_kernel_sum", C.c_double * 8), ("launches", c_i64 * 8)]
+        ("ms_kernel_sum", C.c_double * 8), ("launches", c_i64 * 8), ("radial_tiles", C.c_int)]
 
 
 # every symbol include/nepmi.h declares: name -> (restype, argtypes)
@@ -61,6 +61,7 @@ SYMBOLS = {
     "nepmi_engine_stats": (C.c_int, [VP, C.c_int, C.POINTER(NepmiStats)]),
     "nepmi_engine_set_timing": (C.c_int, [VP, C.c_int]),
     "nepmi_engine_set_generic": (C.c_int, [VP, C.c_int]),
+    "nepmi_engine_set_tiles": (C.c_int, [VP, C.c_int]),
 }
 
 

@@ -281,6 +281,7 @@ int nepmi_engine_stats(nepmi_engine* e, int with_lists, nepmi_stats* out)
       out->ms_kernel_sum[k] = eng.backend().slot_sum(slots[k]);
       out->launches[k] = eng.backend().slot_count(slots[k]);
     }
+    out->radial_tiles = eng.tiles_active() ? 1 : 0;
     out->ms_kernel_sum[7] = eng.backend().region_sum(nepmi::kRegionRebuild);
     out->launches[7] = eng.backend().region_count(nepmi::kRegionRebuild);
     out->ms_kernel[7] = eng.backend().region_ms(nepmi::kRegionRebuild);
@@ -292,6 +293,14 @@ int nepmi_engine_set_timing(nepmi_engine* e, int on)
   if (!e)
     return fail(NEPMI_ERR_ARG, "null engine");
   e->e->backend().set_timing(on != 0);
+  return NEPMI_OK;
+}
+
+int nepmi_engine_set_tiles(nepmi_engine* e, int on)
+{
+  if (!e)
+    return fail(NEPMI_ERR_ARG, "null engine");
+  e->e->set_use_tiles(on != 0);
   return NEPMI_OK;
 }
 

@@ -55,6 +55,42 @@ __global__ void __launch_bounds__(BLOCK) nepmi_kernel_lds(const Body body, const
 }
 
 // ---- exclusive scan of int32, in place: 3 kernels (block scan, scan of block sums, add) ----
+template <int BLOCK>
+__device__ __forceinline__ int block_exclusive_scan(int v, int* total);
+
+// One 256-thread workgroup per brick (RadialTileBody): stage the brick's 8x8x8-cell window in LDS,
+// then one work-item per atom of the brick.  XCD-aware brick order as in nepmi_kernel.
+template <class Body>
+__global__ void __launch_bounds__(256) nepmi_tile_kernel(const Body body, const int64_t nbricks)
+{
+  extern __shared__ __attribute__((aligned(16))) char nepmi_tile_lds[];
+  NEPMI_LDS(char)* lds = (NEPMI_LDS(char)*)nepmi_tile_lds;
+  const unsigned per_xcd = gridDim.x >> 3;
+  const int64_t brick = (int64_t)(blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+  if (brick >= nbricks)
+    return; // the whole workgroup leaves before the first barrier
+  const int tid = (int)threadIdx.x;
+  body.stage_cells(brick, lds, tid, 256);
+  __syncthreads();
+  {
+    NEPMI_LDS(int)* woff = (NEPMI_LDS(int)*)lds;
+    const int a = woff[2 * tid], c = woff[2 * tid + 1];
+    int total;
+    const int ex = block_exclusive_scan<256>(a + c, &total);
+    woff[2 * tid] = ex;
+    woff[2 * tid + 1] = ex + a;
+    if (tid == 0)
+      woff[512] = total;
+  }
+  __syncthreads();
+  body.stage_copy(lds, tid, 256);
+  __syncthreads();
+  int64_t a0, a1;
+  body.brick_range(brick, a0, a1);
+  for (int64_t k = a0 + tid; k < a1; k += 256)
+    body.compute(k, lds);
+}
+
 constexpr int kScanBlock = 256;
 constexpr int kScanItems = 8;
 constexpr int kScanTile = kScanBlock * kScanItems;
@@ -336,6 +372,26 @@ struct HipBackend {
     if (t)
       timer_start(timing->slot[slot]);
     hipLaunchKernelGGL((nepmi_kernel<BLOCK, Body>), dim3((unsigned)grid), dim3(BLOCK), 0, stream, body, n);
+    NEPMI_HIP_CHECK(hipGetLastError());
+    if (t)
+      timer_stop(timing->slot[slot]);
+  }
+
+  template <class Body>
+  void launch_tile(int slot, int64_t nbricks, const Body& body)
+  {
+    if (nbricks <= 0)
+      return;
+    const int64_t grid = (nbricks + 7) / 8 * 8;
+    const size_t lds_bytes = ((size_t)body.lds_bytes() + 15) / 16 * 16;
+    if (lds_bytes > 64 * 1024)
+      NEPMI_HIP_CHECK(hipFuncSetAttribute(
+        reinterpret_cast<const void*>(&nepmi_tile_kernel<Body>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (int)lds_bytes));
+    const bool t = timing_on;
+    if (t)
+      timer_start(timing->slot[slot]);
+    hipLaunchKernelGGL((nepmi_tile_kernel<Body>), dim3((unsigned)grid), dim3(256), lds_bytes, stream, body, nbricks);
     NEPMI_HIP_CHECK(hipGetLastError());
     if (t)
       timer_stop(timing->slot[slot]);

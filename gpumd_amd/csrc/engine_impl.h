@@ -351,6 +351,8 @@ private:
     md_.b1 = m.b1;
     md_.rc_r_max = (float)m.rc_radial_max;
     md_.rc_a_max = (float)m.rc_angular_max;
+    md_.rcinv_r = 1.0f / md_.rc_r_max;
+    md_.rcinv_a = 1.0f / md_.rc_a_max;
     md_.uniform_rc = 1;
     for (int t = 0; t < m.num_types; ++t)
       if (m.rc_radial_f[t] != m.rc_radial_f[0] || m.rc_angular_f[t] != m.rc_angular_f[0])
@@ -393,8 +395,10 @@ private:
     b_.x0s = dalloc<double>(3 * N);
     b_.nn_skin = dalloc<int>(N);
     b_.nl_skin = dalloc<int>((size_t)b_.MN_skin * N);
+    b_.code_skin = dalloc<unsigned short>((size_t)b_.MN_skin * N);
     b_.nn_ang = dalloc<int>(N);
     b_.nl_ang = dalloc<int>((size_t)b_.MN_ang * N);
+    b_.code_ang = dalloc<unsigned short>((size_t)b_.MN_ang * N);
     b_.rev_ang = dalloc<unsigned short>((size_t)b_.MN_ang * N);
     b_.nn_rad = dalloc<int>(N);
     b_.nn_angstep = dalloc<int>(N);
@@ -578,10 +582,20 @@ private:
     be_.template launch<256>(kSlotMisc, N_, GatherSortedBody{b_, pos, type});
     be_.template launch<128>(kSlotMisc, N_, BuildListsBody{box_, b_});
     be_.template launch<128>(kSlotMisc, N_, ReverseSlotsBody{b_});
+    be_.memset(b_.flags + kFlagMaxWindow, 0, 3 * sizeof(int));
+    num_bricks_ = (int64_t)gb[0] * gb[1] * gb[2];
+    be_.template launch<64>(kSlotMisc, num_bricks_, TileStatsBody{box_, b_});
     be_.end_region(kRegionRebuild);
     int flags[kNumFlags];
     be_.d2h(flags, b_.flags, sizeof(flags));
     check_overflow(flags);
+    // LDS-window radial pass: unique window cells (>= 8 cells per periodic direction), 7-bit rank
+    // in cell, window fits the LDS budget
+    tile_ok_ = use_tiles_ && model_.kind == 0 && flags[kFlagMaxCell] <= 127 && flags[kFlagMaxWindow] <= 5000;
+    for (int d = 0; d < 3; ++d)
+      if (box_.pbc[d] && nb[d] < 8)
+        tile_ok_ = false;
+    tile_.wmax = (flags[kFlagMaxWindow] + 63) / 64 * 64;
     have_list_ = true;
     ++num_rebuild;
   }
@@ -617,6 +631,12 @@ private:
 
 public:
   void invalidate() { have_list_ = false; }
+  void set_use_tiles(bool on)
+  {
+    use_tiles_ = on;
+    have_list_ = false;
+  }
+  bool tiles_active() const { return tile_ok_; }
   void set_force_generic(bool on)
   {
     force_generic_ = on;
@@ -629,7 +649,10 @@ private:
   void force_kernels_shape(double* pe, double* force, double* virial)
   {
     be_.begin_region(kRegionForce);
-    be_.template launch<64>(kSlotRadial, N_, RadialDescBody<S>{box_, md_, b_});
+    if (tile_ok_)
+      be_.launch_tile(kSlotRadial, num_bricks_, RadialTileBody<S>{box_, md_, b_, tile_});
+    else
+      be_.template launch<64>(kSlotRadial, N_, RadialDescBody<S>{box_, md_, b_});
     be_.template launch_lds<64>(kSlotAngular, N_, AngularDescBody<S>{md_, b_});
     be_.template launch<64>(kSlotAnn, N_, AnnBody<S>{md_, b_});
     be_.template launch_lds<64>(kSlotAngForce, N_, AngularForceBody<S>{md_, b_});
@@ -663,6 +686,9 @@ private:
   ModelD md_;
   Bufs b_;
   BoxD box_;
+  TileLayout tile_{0};
+  bool tile_ok_ = false, use_tiles_ = true;
+  int64_t num_bricks_ = 0;
   TersoffBufs tb_{};
   TersoffParamsD tp_{};
   bool have_list_ = false;

@@ -52,7 +52,10 @@ struct Shape {
 };
 using ShapeGeneric = Shape<-1, -1, -1, -1, -1, 0>;
 
-enum FlagSlot { kFlagMoved = 0, kFlagOverflow = 1, kFlagMaxSkin = 2, kFlagMaxAng = 3, kNumFlags = 8 };
+enum FlagSlot {
+  kFlagMoved = 0, kFlagOverflow = 1, kFlagMaxSkin = 2, kFlagMaxAng = 3,
+  kFlagMaxWindow = 4, kFlagMaxBrick = 5, kFlagMaxCell = 6, kNumFlags = 8
+};
 
 struct Bufs {
   int64_t N;
@@ -74,6 +77,8 @@ struct Bufs {
   int MN_skin, MN_ang, MN_acomp;
   int* nn_ang;   int* nl_ang;  unsigned short* rev_ang; // A: [MN_ang][N]
   int* nn_skin;  int* nl_skin;                          // B: [MN_skin][N]
+  unsigned short* code_ang;  // A: window code (window cell << 7 | rank in cell) of each entry
+  unsigned short* code_skin; // B: the same; used by the LDS-window radial pass
   // per step
   int* nn_rad;   F4* rstash;   // pair records (r12, j | t2 << 25 or -1) at rows [A slots | MN_ang + B slots]
   int* nn_angstep; F4* acomp;  // compacted angular pair records [MN_acomp][N]
@@ -303,6 +308,8 @@ struct BuildListsBody {
           else if (x2 < 0 || x2 >= b.nbx) continue;
           const int c2 = cell_index(b, x2, y2, z2);
           const int lo = b.cell_count[c2], hi = b.cell_count[c2 + 1];
+          // window cell of this neighbour cell, relative to the atom's brick (8x8x8 cells)
+          const int wc = (((cz & 3) + 2 + kz) << 6) | (((cy & 3) + 2 + ky) << 3) | ((cx & 3) + 2 + kx);
           for (int j = lo; j < hi; ++j) {
             if (j == k)
               continue;
@@ -310,13 +317,18 @@ struct BuildListsBody {
             float x, y, z;
             const float d2 = pair_geometry(box, p1, p2, x, y, z);
             if (d2 < b.rc_skin_sq) {
+              const unsigned short code = (unsigned short)((wc << 7) | ((j - lo) & 127));
               if (d2 < b.rc_askin_sq) {
-                if (cnta < b.MN_ang)
+                if (cnta < b.MN_ang) {
                   b.nl_ang[(int64_t)cnta * N + k] = j;
+                  b.code_ang[(int64_t)cnta * N + k] = code;
+                }
                 ++cnta;
               } else {
-                if (cntb < b.MN_skin)
+                if (cntb < b.MN_skin) {
                   b.nl_skin[(int64_t)cntb * N + k] = j;
+                  b.code_skin[(int64_t)cntb * N + k] = code;
+                }
                 ++cntb;
               }
             }
@@ -356,6 +368,37 @@ struct ReverseSlotsBody {
         NEPMI_ATOMIC_OR(&b.flags[kFlagOverflow], 2);
       b.rev_ang[(int64_t)s * N + k] = (unsigned short)r;
     }
+  }
+};
+
+// per brick: atoms in the brick, atoms in its 8x8x8-cell window, largest cell -- decides at rebuild
+// whether the LDS-window radial pass can be used for this list generation
+struct TileStatsBody {
+  BoxD box;
+  Bufs b;
+  NEPMI_HD void operator()(int64_t brick) const
+  {
+    const int bx = (int)(brick % b.gbx), by = (int)((brick / b.gbx) % b.gby), bz = (int)(brick / ((int64_t)b.gbx * b.gby));
+    const int nbr = b.cell_count[brick * 64 + 64] - b.cell_count[brick * 64];
+    int win = 0, mxc = 0;
+    for (int wz = 0; wz < 8; ++wz)
+      for (int wy = 0; wy < 8; ++wy)
+        for (int wx = 0; wx < 8; ++wx) {
+          int cx = 4 * bx - 2 + wx, cy = 4 * by - 2 + wy, cz = 4 * bz - 2 + wz;
+          bool ok = true;
+          if (box.pbc[0]) cx = ((cx % b.nbx) + b.nbx) % b.nbx; else ok = ok && cx >= 0 && cx < b.nbx;
+          if (box.pbc[1]) cy = ((cy % b.nby) + b.nby) % b.nby; else ok = ok && cy >= 0 && cy < b.nby;
+          if (box.pbc[2]) cz = ((cz % b.nbz) + b.nbz) % b.nbz; else ok = ok && cz >= 0 && cz < b.nbz;
+          if (!ok)
+            continue;
+          const int c = cell_index(b, cx, cy, cz);
+          const int cnt = b.cell_count[c + 1] - b.cell_count[c];
+          win += cnt;
+          mxc = cnt > mxc ? cnt : mxc;
+        }
+    NEPMI_ATOMIC_MAX(&b.flags[kFlagMaxWindow], win);
+    NEPMI_ATOMIC_MAX(&b.flags[kFlagMaxBrick], nbr);
+    NEPMI_ATOMIC_MAX(&b.flags[kFlagMaxCell], mxc);
   }
 };
 
@@ -541,7 +584,46 @@ struct RadialDescBody {
   BoxD box;
   ModelD m;
   Bufs b;
+
+  // candidate source of the default path: neighbour indices from the Verlet lists, positions
+  // gathered from global memory (L2)
+  struct GlobalFetch {
+    const int* nlA;
+    const int* nlB;
+    const PosQ* posq;
+    int64_t N;
+    struct Tok {
+      int jj[kGather];
+    };
+    // global loads of a chunk's neighbour indices; issued one chunk ahead, i.e. BEFORE the stores
+    // of the chunk being processed (vmcnt retires in order: a load issued behind stores cannot be
+    // waited for without draining those stores)
+    NEPMI_HD void prefetch(int s0, int nn, int na, Tok& t) const
+    {
+      // entries past the end re-read the last valid slot (no branches around the loads)
+#pragma unroll
+      for (int u = 0; u < kGather; ++u) {
+        const int idx = s0 + u < nn ? s0 + u : nn - 1;
+        t.jj[u] = idx < na ? nlA[(int64_t)idx * N] : nlB[(int64_t)(idx - na) * N];
+      }
+    }
+    NEPMI_HD void resolve(const Tok& t, int* jj, PosQ* pp) const
+    {
+#pragma unroll
+      for (int u = 0; u < kGather; ++u) {
+        jj[u] = t.jj[u];
+        pp[u] = posq[jj[u]];
+      }
+    }
+  };
+
   NEPMI_HD void operator()(int64_t k) const
+  {
+    run_with(k, GlobalFetch{b.nl_ang + k, b.nl_skin + k, b.posq, b.N});
+  }
+
+  template <class Fetch>
+  NEPMI_HD void run_with(int64_t k, const Fetch& fetch) const
   {
     const int64_t N = b.N;
     if (b.lvl[k] < 1) { // outer ghost: lends its position only
@@ -571,24 +653,20 @@ struct RadialDescBody {
     int cnt = 0, ca = 0;
     // The lists are walked in chunks of kGather entries: all index loads of a chunk, then all
     // position gathers, then the arithmetic -- kGather independent gathers in flight per lane.
-    const int* __restrict__ nlA = b.nl_ang + k;
-    const int* __restrict__ nlB = b.nl_skin + k;
-    const PosQ* __restrict__ posq = b.posq;
     F4* __restrict__ rstash = b.rstash + k;
     F4* __restrict__ acomp = b.acomp + k;
     unsigned short* __restrict__ amap = b.amap + k;
+    typename Fetch::Tok cur, nxt;
+    if (nn > 0)
+      fetch.prefetch(0, nn, na, cur);
     for (int s0 = 0; s0 < nn; s0 += kGather) {
       int jj[kGather];
       PosQ pp[kGather];
-      // entries past the end re-read the last valid slot (no branches around the loads)
-#pragma unroll
-      for (int u = 0; u < kGather; ++u) {
-        const int idx = s0 + u < nn ? s0 + u : nn - 1;
-        jj[u] = idx < na ? nlA[(int64_t)idx * N] : nlB[(int64_t)(idx - na) * N];
-      }
-#pragma unroll
-      for (int u = 0; u < kGather; ++u)
-        pp[u] = posq[jj[u]];
+      nxt = cur;
+      if (s0 + kGather < nn)
+        fetch.prefetch(s0 + kGather, nn, na, nxt); // next chunk's loads go out before this chunk's stores
+      fetch.resolve(cur, jj, pp);
+      cur = nxt;
 #pragma unroll
       for (int u = 0; u < kGather; ++u) {
         const int idx = s0 + u;
@@ -622,27 +700,40 @@ struct RadialDescBody {
           }
           amap[(int64_t)idx * N] = slot;
         }
-        if (!inside)
-          continue;
-        ++cnt;
-        const float d = sqrtf(d2);
-        const float rcinv = 1.0f / rc;
-        float fc;
-        cutoff_fc(rcinv, d, fc);
-        float fn[S::KRM + 1];
-        if (S::fixed)
-          basis_fn<S::KRM>(rcinv, d, fc, fn);
-        else
-          basis_fn_rt(KR, rcinv, d, fc, fn);
         if (S::TS > 0) {
+          // branch-free: entries outside the cutoff run the same arithmetic with weight 0, so the
+          // kGather candidates of a chunk are independent instruction streams the scheduler can
+          // interleave (the envelope fc is evaluated at min(d, rc) to stay finite)
+          cnt += inside ? 1 : 0;
+          float d, dinv;
+          dist_and_inv(d2, d, dinv);
+          const float rcinv = m.uniform_rc ? m.rcinv_r : 1.0f / rc;
+          const float dc = inside ? d : rc;
+          float fc;
+          cutoff_fc(rcinv, dc, fc);
+          float fn[S::KRM + 1];
+          basis_fn<S::KRM>(rcinv, dc, fc, fn);
 #pragma unroll
           for (int t = 0; t < TSM; ++t) {
-            const float w = (TSM == 1 || t2 == t) ? 1.0f : 0.0f;
+            const float w = (inside && (TSM == 1 || t2 == t)) ? 1.0f : 0.0f;
 #pragma unroll
             for (int kk = 0; kk <= S::KRM; ++kk)
               Ssum[t][kk] = fmaf(w, fn[kk], Ssum[t][kk]);
           }
         } else {
+          if (!inside)
+            continue;
+          ++cnt;
+          float d, dinv;
+          dist_and_inv(d2, d, dinv);
+          const float rcinv = 1.0f / rc;
+          float fc;
+          cutoff_fc(rcinv, d, fc);
+          float fn[S::KRM + 1];
+          if (S::fixed)
+            basis_fn<S::KRM>(rcinv, d, fc, fn);
+          else
+            basis_fn_rt(KR, rcinv, d, fc, fn);
           const float* c = m.c_rad + (size_t)(t1 * m.T + t2) * (NR + 1) * (KR + 1);
           for (int n = 0; n <= NR; ++n) {
             float g = 0.0f;
@@ -687,6 +778,151 @@ struct RadialDescBody {
     }
     for (int n = 0; n <= NR; ++n)
       b.q[(int64_t)n * N + k] = q[n] * m.qscale[n];
+  }
+};
+
+// The LDS-window variant of the radial pass.  One 256-thread workgroup per brick (4x4x4 cells,
+// ~200 atoms): it stages the positions of every atom of the brick's 8x8x8-cell window (~1,700
+// atoms, FP64 x,y,z + packed index/type = 28 B each) in LDS ONCE, and the Verlet entries, stored as
+// 16-bit window codes (window cell << 7 | rank in cell), are resolved against that copy.  The default
+// path issues one L2 request per (atom, neighbour) -- 86 per atom, ~20x redundant across the lanes
+// of a wavefront, and is L2-request-rate bound; here the window is read from
+// L2 once per workgroup (~8 positions per atom).
+//
+// LDS layout (bytes): [0, 2052) int woff[513] | [2052+, ...) int wstart[512] | double wx[W] wy[W] wz[W]
+// | int wword[W] (global index | type << 25).
+constexpr int kTileThreads = 256;
+constexpr int kWinCells = 512;
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define NEPMI_LDS(T) __attribute__((address_space(3))) T
+#else
+#define NEPMI_LDS(T) T
+#endif
+
+struct TileLayout {
+  int wmax; // capacity of the window arrays (atoms)
+  NEPMI_HD int off_woff() const { return 0; }
+  NEPMI_HD int off_wstart() const { return 2064; } // 513 ints, padded to 16 B
+  NEPMI_HD int off_x() const { return 2064 + 2048; }
+  NEPMI_HD int off_y() const { return off_x() + 8 * wmax; }
+  NEPMI_HD int off_z() const { return off_y() + 8 * wmax; }
+  NEPMI_HD int off_word() const { return off_z() + 8 * wmax; }
+  NEPMI_HD int bytes() const { return off_word() + 4 * wmax; }
+};
+
+template <class S>
+struct RadialTileBody {
+  BoxD box;
+  ModelD m;
+  Bufs b;
+  TileLayout lay;
+
+  NEPMI_HD int lds_bytes() const { return lay.bytes(); }
+
+  // phase 1 (all threads): count and first atom of each of the 512 window cells
+  template <class LC>
+  NEPMI_HD void stage_cells(int64_t brick, LC lds, int tid, int nth) const
+  {
+    NEPMI_LDS(int)* woff = (NEPMI_LDS(int)*)(lds + lay.off_woff());
+    NEPMI_LDS(int)* wstart = (NEPMI_LDS(int)*)(lds + lay.off_wstart());
+    const int bx = (int)(brick % b.gbx), by = (int)((brick / b.gbx) % b.gby), bz = (int)(brick / ((int64_t)b.gbx * b.gby));
+    for (int wc = tid; wc < kWinCells; wc += nth) {
+      int cx = 4 * bx - 2 + (wc & 7), cy = 4 * by - 2 + ((wc >> 3) & 7), cz = 4 * bz - 2 + (wc >> 6);
+      bool ok = true;
+      if (box.pbc[0]) cx = ((cx % b.nbx) + b.nbx) % b.nbx; else ok = ok && cx >= 0 && cx < b.nbx;
+      if (box.pbc[1]) cy = ((cy % b.nby) + b.nby) % b.nby; else ok = ok && cy >= 0 && cy < b.nby;
+      if (box.pbc[2]) cz = ((cz % b.nbz) + b.nbz) % b.nbz; else ok = ok && cz >= 0 && cz < b.nbz;
+      int cnt = 0, st = 0;
+      if (ok) {
+        const int c = cell_index(b, cx, cy, cz);
+        st = b.cell_count[c];
+        cnt = b.cell_count[c + 1] - st;
+      }
+      woff[wc] = cnt; // turned into the exclusive prefix by the backend's scan (woff[512] = total)
+      wstart[wc] = st;
+    }
+    if (tid == 0)
+      woff[kWinCells] = 0;
+  }
+
+  // phase 3 (all threads, after the scan of woff): copy the window atoms
+  template <class LC>
+  NEPMI_HD void stage_copy(LC lds, int tid, int nth) const
+  {
+    NEPMI_LDS(const int)* woff = (NEPMI_LDS(const int)*)(lds + lay.off_woff());
+    NEPMI_LDS(const int)* wstart = (NEPMI_LDS(const int)*)(lds + lay.off_wstart());
+    NEPMI_LDS(double)* wx = (NEPMI_LDS(double)*)(lds + lay.off_x());
+    NEPMI_LDS(double)* wy = (NEPMI_LDS(double)*)(lds + lay.off_y());
+    NEPMI_LDS(double)* wz = (NEPMI_LDS(double)*)(lds + lay.off_z());
+    NEPMI_LDS(int)* wword = (NEPMI_LDS(int)*)(lds + lay.off_word());
+    const int W = woff[kWinCells] < lay.wmax ? woff[kWinCells] : lay.wmax;
+    for (int w = tid; w < W; w += nth) {
+      int lo = 0, hi = kWinCells - 1; // largest wc with woff[wc] <= w
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (woff[mid] <= w) lo = mid; else hi = mid - 1;
+      }
+      const int j = wstart[lo] + (w - woff[lo]);
+      const PosQ p = b.posq[j];
+      wx[w] = p.x;
+      wy[w] = p.y;
+      wz[w] = p.z;
+      wword[w] = (int)((unsigned)j | ((unsigned)p.type << kIdxBits));
+    }
+  }
+
+  template <class LC>
+  struct TileFetch {
+    const unsigned short* cA;
+    const unsigned short* cB;
+    int64_t N;
+    LC lds;
+    TileLayout lay;
+    struct Tok {
+      unsigned code[kGather];
+    };
+    NEPMI_HD void prefetch(int s0, int nn, int na, Tok& t) const
+    {
+#pragma unroll
+      for (int u = 0; u < kGather; ++u) {
+        const int idx = s0 + u < nn ? s0 + u : nn - 1;
+        t.code[u] = idx < na ? cA[(int64_t)idx * N] : cB[(int64_t)(idx - na) * N];
+      }
+    }
+    NEPMI_HD void resolve(const Tok& t, int* jj, PosQ* pp) const
+    {
+      NEPMI_LDS(const int)* woff = (NEPMI_LDS(const int)*)(lds + lay.off_woff());
+      NEPMI_LDS(const double)* wx = (NEPMI_LDS(const double)*)(lds + lay.off_x());
+      NEPMI_LDS(const double)* wy = (NEPMI_LDS(const double)*)(lds + lay.off_y());
+      NEPMI_LDS(const double)* wz = (NEPMI_LDS(const double)*)(lds + lay.off_z());
+      NEPMI_LDS(const int)* wword = (NEPMI_LDS(const int)*)(lds + lay.off_word());
+#pragma unroll
+      for (int u = 0; u < kGather; ++u) {
+        const int w = woff[t.code[u] >> 7] + (int)(t.code[u] & 127u);
+        const unsigned word = (unsigned)wword[w];
+        jj[u] = (int)(word & (unsigned)kIdxMask);
+        pp[u].x = wx[w];
+        pp[u].y = wy[w];
+        pp[u].z = wz[w];
+        pp[u].type = (int)(word >> kIdxBits);
+        pp[u].pad = 0;
+      }
+    }
+  };
+
+  // phase 4: the atoms of the brick
+  NEPMI_HD void brick_range(int64_t brick, int64_t& a0, int64_t& a1) const
+  {
+    a0 = b.cell_count[brick * 64];
+    a1 = b.cell_count[brick * 64 + 64];
+  }
+
+  template <class LC>
+  NEPMI_HD void compute(int64_t k, LC lds) const
+  {
+    const RadialDescBody<S> body{box, m, b};
+    body.run_with(k, TileFetch<LC>{b.code_ang + k, b.code_skin + k, b.N, lds, lay});
   }
 };
 
@@ -772,8 +1008,8 @@ struct AngularDescBody {
         e_next = acomp[(int64_t)(a + 1) * N]; // in flight while this record is processed
       const int t2 = (int)((unsigned)e.w >> kIdxBits);
       const float x = e.x, y = e.y, z = e.z;
-      const float d = sqrtf(dot3f(x, x, y, y, z, z));
-      const float dinv = 1.0f / d;
+      float d, dinv;
+      dist_and_inv(dot3f(x, x, y, y, z, z), d, dinv);
       const float rc = m.uniform_rc ? m.rc_a_max : (rc1 + m.rc_a[t2]) * 0.5f;
       const float rcinv = 1.0f / rc;
       float fc;
@@ -977,8 +1213,8 @@ struct AngularForceBody {
         e_next = acomp[(int64_t)(a + 1) * N];
       const int t2 = (int)((unsigned)e.w >> kIdxBits);
       const float x = e.x, y = e.y, z = e.z;
-      const float d = sqrtf(dot3f(x, x, y, y, z, z));
-      const float dinv = 1.0f / d;
+      float d, dinv;
+      dist_and_inv(dot3f(x, x, y, y, z, z), d, dinv);
       const float rc = m.uniform_rc ? m.rc_a_max : (rc1 + m.rc_a[t2]) * 0.5f;
       const float rcinv = 1.0f / rc;
       float fc, fcp;
@@ -1126,24 +1362,25 @@ struct ForceAssembleBody {
 #pragma unroll
       for (int u = 0; u < kGather; ++u) {
         const int idx = s0 + u;
-        if (idx >= nn || ee[u].w == -1)
-          continue;
+        // branch-free radial part: invalid records (past the end / outside rc) run with weight 0
         const F4 e = ee[u];
+        const bool valid = idx < nn && e.w != -1;
         const unsigned wbits = (unsigned)e.w;
         const int j = (int)(wbits & (unsigned)kIdxMask);
-        const int t2 = (int)(wbits >> kIdxBits);
+        const int t2 = valid ? (int)(wbits >> kIdxBits) : t1;
         const float x = e.x, y = e.y, z = e.z;
-        const float d = sqrtf(dot3f(x, x, y, y, z, z));
-        const float dinv = 1.0f / d;
+        float d, dinv;
+        dist_and_inv(dot3f(x, x, y, y, z, z), d, dinv);
         const float rc = m.uniform_rc ? m.rc_r_max : (rc1 + m.rc_r[t2]) * 0.5f;
-        const float rcinv = 1.0f / rc;
+        const float rcinv = m.uniform_rc ? m.rcinv_r : 1.0f / rc;
+        const float dc = valid ? d : 0.5f * rc;
         float fc, fcp;
-        cutoff_fc_fcp(rcinv, d, fc, fcp);
+        cutoff_fc_fcp(rcinv, dc, fc, fcp);
         float fn[S::KRM + 1], fnp[S::KRM + 1];
         if (S::fixed)
-          basis_fn_fnp<S::KRM>(rcinv, d, fc, fcp, fn, fnp);
+          basis_fn_fnp<S::KRM>(rcinv, dc, fc, fcp, fn, fnp);
         else
-          basis_fn_fnp_rt(KR, rcinv, d, fc, fcp, fn, fnp);
+          basis_fn_fnp_rt(KR, rcinv, dc, fc, fcp, fn, fnp);
         float s12 = 0.0f, s21 = 0.0f;
         if (S::TS > 0) {
 #pragma unroll
@@ -1166,8 +1403,9 @@ struct ForceAssembleBody {
             break;
           s21 = fmaf(fnp[kk], Aj[u][kk], s21);
         }
-        const float fs = (s12 + s21) * dinv; // f12 - f21 = fs * r12
-        const float bb = s21 * dinv;         // f21 = -bb * r12
+        const float wgt = valid ? dinv : 0.0f;
+        const float fs = (s12 + s21) * wgt; // f12 - f21 = fs * r12
+        const float bb = s21 * wgt;         // f21 = -bb * r12
         F[0] = fmaf(fs, x, F[0]);
         F[1] = fmaf(fs, y, F[1]);
         F[2] = fmaf(fs, z, F[2]);
@@ -1179,7 +1417,7 @@ struct ForceAssembleBody {
         W[4] -= x * bz;
         W[5] -= y * bz;
 
-        if (idx < na) {
+        if (valid && idx < na) {
           const unsigned short a = amap[(int64_t)idx * N + k];
           if (a != kNoSlot) {
             const int rs = rev[(int64_t)idx * N];

@@ -92,6 +92,7 @@ struct ModelD {
   float zbl_rc_inner, zbl_rc_outer;
   float b1;
   float rc_r_max, rc_a_max;
+  float rcinv_r, rcinv_a; // 1 / rc_*_max (used when uniform_rc)
   int uniform_rc; // every type has the same (rc_radial, rc_angular): pair cutoffs are constants
   const float* c_rad;  // [T*T][NR+1][KR+1]
   const float* c_ang;  // [T*T][NA+1][KA+1]
@@ -194,21 +195,54 @@ NEPMI_HD void cell_of(
 
 // ---- radial functions -----------------------------------------------------------------------
 
-// find_fc / find_fc_and_fcp, nep_utilities.cuh:409-431 (caller guarantees d < rc)
+// cos(pi t) and sin(pi t) for t in [0, 1]: with y = t - 1/2, cos(pi t) = -sin(pi y) and
+// sin(pi t) = cos(pi y); Taylor polynomials in y (|y| <= 1/2) to y^13 / y^14, max error 2e-7.
+// The cutoff envelope only ever needs this range, so the general-argument cosf/sinf (range
+// reduction, ~40 instructions each) is not needed.
+NEPMI_HD void cospi_sinpi_unit(float t, float& c, float& s)
+{
+  const float y = t - 0.5f, y2 = y * y;
+  float sp = 4.663028058e-04f;
+  sp = fmaf(sp, y2, -7.370430946e-03f);
+  sp = fmaf(sp, y2, 8.214588661e-02f);
+  sp = fmaf(sp, y2, -5.992645293e-01f);
+  sp = fmaf(sp, y2, 2.550164040e+00f);
+  sp = fmaf(sp, y2, -5.167712780e+00f);
+  sp = fmaf(sp, y2, 3.141592654e+00f);
+  float cp = -1.046381049e-04f;
+  cp = fmaf(cp, y2, 1.929574309e-03f);
+  cp = fmaf(cp, y2, -2.580689139e-02f);
+  cp = fmaf(cp, y2, 2.353306304e-01f);
+  cp = fmaf(cp, y2, -1.335262769e+00f);
+  cp = fmaf(cp, y2, 4.058712126e+00f);
+  cp = fmaf(cp, y2, -4.934802201e+00f);
+  c = -(sp * y);
+  s = fmaf(cp, y2, 1.0f);
+}
+
+// d = sqrt(d2) and 1/d from one reciprocal-square-root (v_rsq_f32, 1 ulp)
+NEPMI_HD void dist_and_inv(float d2, float& d, float& dinv)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  dinv = __frsqrt_rn(d2);
+#else
+  dinv = 1.0f / sqrtf(d2);
+#endif
+  d = d2 * dinv;
+}
+
+// find_fc / find_fc_and_fcp, nep_utilities.cuh:409-431: fc = (1 + cos(pi d/rc)) / 2 for d < rc
 NEPMI_HD void cutoff_fc(float rcinv, float d, float& fc)
 {
-  fc = 0.5f * cosf(NEPMI_PI * d * rcinv) + 0.5f;
+  float c, s;
+  cospi_sinpi_unit(d * rcinv, c, s);
+  fc = fmaf(0.5f, c, 0.5f);
 }
 NEPMI_HD void cutoff_fc_fcp(float rcinv, float d, float& fc, float& fcp)
 {
-  float s, c;
-#if defined(__HIP_DEVICE_COMPILE__)
-  sincosf(NEPMI_PI * d * rcinv, &s, &c);
-#else
-  s = sinf(NEPMI_PI * d * rcinv);
-  c = cosf(NEPMI_PI * d * rcinv);
-#endif
-  fc = 0.5f * c + 0.5f;
+  float c, s;
+  cospi_sinpi_unit(d * rcinv, c, s);
+  fc = fmaf(0.5f, c, 0.5f);
   fcp = -NEPMI_HALF_PI * s * rcinv;
 }
 

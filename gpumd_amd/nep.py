@@ -180,5 +180,8 @@ class NEP:
     def set_timing(self, on=True):
         self._ck(self.lib.nepmi_engine_set_timing(self.handle, 1 if on else 0))
 
+    def set_tiles(self, on=True):
+        self._ck(self.lib.nepmi_engine_set_tiles(self.handle, 1 if on else 0))
+
     def set_generic(self, on=True):
         self._ck(self.lib.nepmi_engine_set_generic(self.handle, 1 if on else 0))

@@ -172,6 +172,7 @@ typedef struct {
                             6 velocity-Verlet, 7 list rebuild (whole) */
   double ms_kernel_sum[8]; /* same slots: sum over all launches since timing was (re)enabled */
   int64_t launches[8];     /* ... and their number (slot 7: rebuilds)                       */
+  int radial_tiles;        /* 1 if the last force call used the LDS-window radial pass        */
 } nepmi_stats;
 /* Synchronises the stream.  with_lists != 0 also recounts the per-step list lengths. */
 int nepmi_engine_stats(nepmi_engine* e, int with_lists, nepmi_stats* out);
@@ -180,6 +181,10 @@ int nepmi_engine_set_timing(nepmi_engine* e, int on);
 /* Force the run-time-shaped (generic) kernel instantiation instead of a model-shape-specialised
  * one; used by the parity tests to cover both code paths with one model. */
 int nepmi_engine_set_generic(nepmi_engine* e, int on);
+/* Allow (default) or forbid the LDS-window radial pass; forbidding selects the plain gather kernel
+ * (also taken automatically when a periodic direction has fewer than 8 cells or a brick's window
+ * does not fit LDS).  Both give identical lists and pair records. */
+int nepmi_engine_set_tiles(nepmi_engine* e, int on);
 
 #ifdef __cplusplus
 }

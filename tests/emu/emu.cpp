@@ -39,6 +39,30 @@ struct HostLoopBackend {
       body(i);
   }
 
+  // one "workgroup" per brick, phases run back to back (the LDS-window radial pass)
+  template <class Body>
+  void launch_tile(int, int64_t nbricks, const Body& body)
+  {
+    std::vector<double> raw((size_t)body.lds_bytes() / 8 + 8);
+    char* lds = reinterpret_cast<char*>(raw.data());
+    for (int64_t brick = 0; brick < nbricks; ++brick) {
+      body.stage_cells(brick, lds, 0, 1);
+      int* woff = reinterpret_cast<int*>(lds);
+      int run = 0;
+      for (int c = 0; c < 512; ++c) {
+        const int v = woff[c];
+        woff[c] = run;
+        run += v;
+      }
+      woff[512] = run;
+      body.stage_copy(lds, 0, 1);
+      int64_t a0, a1;
+      body.brick_range(brick, a0, a1);
+      for (int64_t k = a0; k < a1; ++k)
+        body.compute(k, lds);
+    }
+  }
+
   // bodies with a workgroup-staged table: the "LDS" is an ordinary host buffer here
   template <int BLOCK, class Body>
   void launch_lds(int, int64_t n, const Body& body)

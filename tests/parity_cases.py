@@ -28,7 +28,7 @@ MODELS = {
 }
 
 
-def check_force_parity(drv, name, generic=False, check_lists=True):
+def check_force_parity(drv, name, generic=False, check_lists=True, tiles=True):
     nep_rel, build, _ = MODELS[name]
     nep = H.golden(*nep_rel.split("/"))
     h, typ, x = build()
@@ -42,7 +42,10 @@ def check_force_parity(drv, name, generic=False, check_lists=True):
     eng = drv.engine(model, n)
     if generic:
         eng.set_generic(True)
+    eng.set_tiles(tiles)
     xw, pe, f, v = H.engine_force(drv, eng, h, typ, x)
+    if not tiles:
+        assert eng.stats().radial_tiles == 0
 
     assert np.array_equal(xw, H.oracle_apply_pbc(h, x)), "wrapped positions must be bit-exact"
     np.testing.assert_allclose(pe.sum(), pe64.sum(), rtol=1e-5, atol=1e-8)

@@ -24,6 +24,17 @@ def test_force_parity_generic_shape(drv, name):
     P.check_force_parity(drv, name, generic=True, check_lists=False)
 
 
+@pytest.mark.parametrize("name", ["PbTe-A", "PbTe-ortho", "UNEP-v1"])
+def test_force_parity_without_lds_window(drv, name):
+    """the plain gather radial kernel (fallback of the LDS-window pass) gives the same answers"""
+    P.check_force_parity(drv, name, tiles=False)
+
+
+def test_lds_window_pass_is_used(drv):
+    eng = P.check_force_parity(drv, "PbTe-A", check_lists=False)
+    assert eng.stats().radial_tiles == 1
+
+
 def test_invariances(drv):
     P.check_translation_and_wrap(drv)
 
