@@ -47,6 +47,30 @@ def build_pbte(reps, rattle=0.02, seed=42, temperature=300.0):
     return h, typ, H.soa(pos), mass, vel
 
 
+def build_workload(name, reps, seed):
+    """-> (label, nep.txt, h, type, x_soa, mass, vel).  `pbte` is BASELINE config 3 (the bench line);
+    `carbon` (C_2022_NEP4, diamond) and `unep` (UNEP-v1, 16-metal fcc alloy) are the model families of
+    configs 5 and 4, offered for single-GPU kernel measurements."""
+    import helpers as H
+    if name == "pbte":
+        h, typ, x, mass, vel = build_pbte(reps, seed=seed)
+        return ("PbTe %d atoms/GPU (replicate %d %d %d of the 250-atom cell), NEP NVE, dt 1 fs, 300 K"
+                % ((len(typ),) + tuple(reps)), H.golden("PbTe", "nep.txt"), h, typ, x, mass, vel)
+    if name == "carbon":
+        cells = tuple(5 * r for r in reps)  # 16 16 16 -> 80^3 diamond cells = 4,096,000 atoms; use --reps 10 10 10 for 1 M
+        h, typ, x = H.diamond(cells, 3.57, rattle=0.02, seed=seed)
+        mass = np.full(len(typ), H.MASS["C"])
+        return ("diamond C %d atoms/GPU (%dx%dx%d cells), C_2022_NEP4, NVE" % ((len(typ),) + cells),
+                H.golden("C", "nep.txt"), h, typ, x, mass, H.maxwell_velocities(mass, 300.0, seed=seed + 1))
+    if name == "unep":
+        cells = tuple(4 * r for r in reps)
+        h, typ, x = H.fcc_alloy(cells, 3.9, 16, rattle=0.02, seed=seed)
+        mass = np.full(len(typ), 100.0)
+        return ("fcc 16-metal alloy %d atoms/GPU (%dx%dx%d cells), UNEP-v1 + ZBL, NVE" % ((len(typ),) + cells),
+                H.golden("UNEP", "nep.txt"), h, typ, x, mass, H.maxwell_velocities(mass, 300.0, seed=seed + 1))
+    raise SystemExit("unknown workload " + name)
+
+
 def algorithmic_bytes(info, nn_r, nn_a):
     """compulsory HBM bytes per atom-step, split per kernel."""
     dim, nr1 = info.dim, info.n_max_radial + 1
@@ -199,6 +223,8 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--reps", type=int, nargs=3, default=[16, 16, 16], help="replicate na nb nc of the 250-atom cell")
+    ap.add_argument("--workload", default="pbte", choices=["pbte", "carbon", "unep"],
+                    help="pbte = BASELINE config 3 (the bench line); the others are extra single-GPU measurements")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--decomposed", action="store_true",
                     help="run the N > 1 code path (DomainMD) even on one GPU, to measure its host-side overhead")
@@ -232,9 +258,8 @@ def main():
 
     # ---- workload: every rank generates its own block of `reps` cells (weak scaling) ----
     reps = tuple(args.reps)
-    h, typ, x, mass, vel = build_pbte(reps, seed=42 + rank)
+    label, nep_txt, h, typ, x, mass, vel = build_workload(args.workload, reps, 42 + rank)
     n = len(typ)
-    nep_txt = H.golden("PbTe", "nep.txt")
     model = gpumd_amd.Model(nep_txt)
     dt = 1.0 / H.TIME_UNIT
     if world > 1 or args.decomposed:
@@ -282,8 +307,7 @@ def main():
             "value": value, "unit": "atom-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32 kernels, f64 state/accumulation", "data": "synthetic",
-            "config": {"workload": "PbTe %d atoms/GPU (replicate %d %d %d of the 250-atom cell), NEP NVE, dt 1 fs, 300 K"
-                                   % ((n,) + reps),
+            "config": {"workload": label,
                        "atoms_total": total_atoms, "rebuilds_in_timed_region": int(st.num_rebuild - reb0),
                        "mean_nn_radial": st.mean_nn_radial, "mean_nn_angular": st.mean_nn_angular,
                        "parallelism": "1 GPU"},
@@ -293,7 +317,7 @@ def main():
             "kernels": kern,
             "thermo_last": [float(v) for v in th[-1]] if len(th) else None,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == "pbte":
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         print(json.dumps(out))
     if world > 1:

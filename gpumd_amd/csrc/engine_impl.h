@@ -428,6 +428,9 @@ private:
     }
     b_.zbl = dalloc<float>(m.zbl_enabled ? (size_t)10 * N : 1);
     b_.lvl = dalloc<signed char>(N);
+    b_.tperm = dalloc<int>(N);
+    b_.tcount = dalloc<int>(((size_t)(N >> kTypeChunkShift) + 2) * m.num_types + 2);
+    b_.tfill = dalloc<int>(((size_t)(N >> kTypeChunkShift) + 2) * m.num_types + 2);
     b_.flags = dalloc<int>(kNumFlags);
     be_.memset(b_.flags, 0, sizeof(int) * kNumFlags);
     thermo_scratch_ = dalloc<double>(8 * 1024);
@@ -580,6 +583,14 @@ private:
     be_.template launch<256>(kSlotMisc, N_, FillCellsBody{b_});
     be_.template launch<256>(kSlotMisc, ncell, SortCellsBody{b_});
     be_.template launch<256>(kSlotMisc, N_, GatherSortedBody{b_, pos, type});
+    {
+      const int64_t nkeys = ((N_ >> kTypeChunkShift) + 1) * model_.num_types;
+      be_.memset(b_.tcount, 0, sizeof(int) * (nkeys + 1));
+      be_.memset(b_.tfill, 0, sizeof(int) * nkeys);
+      be_.template launch<256>(kSlotMisc, N_, TypeCountBody{b_, model_.num_types});
+      be_.exclusive_scan(b_.tcount, nkeys + 1, scan_scratch_);
+      be_.template launch<256>(kSlotMisc, N_, TypeFillBody{b_, model_.num_types});
+    }
     be_.template launch<128>(kSlotMisc, N_, BuildListsBody{box_, b_});
     be_.template launch<128>(kSlotMisc, N_, ReverseSlotsBody{b_});
     be_.memset(b_.flags + kFlagMaxWindow, 0, 3 * sizeof(int));

@@ -94,6 +94,9 @@ struct Bufs {
   int* flags;  // [kNumFlags]
   const signed char* level; // caller order, or nullptr: 2 owned, 1 inner ghost, 0 outer ghost
   signed char* lvl;         // [N] the same in internal order (sampled at list rebuild)
+  int* tperm;               // [N] atoms ordered by (chunk of 1024, type): the ANN kernel's work order
+  int* tcount;              // [(nchunks * T) + 1] histogram / offsets of that order
+  int* tfill;               // [nchunks * T]
   int* sh_ang;              // small-box path only: packed periodic-image shift of each list-A entry
 };
 
@@ -348,6 +351,29 @@ struct BuildListsBody {
   }
 };
 
+// Work order of the ANN kernel: atoms grouped by type inside chunks of 1024 consecutive atoms, so
+// that a wavefront holds (almost always) one type and runs the network once, with that type's
+// weights as scalar operands -- instead of once per type present (16x for the 16-metal UNEP model).
+constexpr int kTypeChunkShift = 10;
+struct TypeCountBody {
+  Bufs b;
+  int T;
+  NEPMI_HD void operator()(int64_t k) const
+  {
+    NEPMI_ATOMIC_ADD(&b.tcount[(k >> kTypeChunkShift) * T + b.posq[k].type], 1);
+  }
+};
+struct TypeFillBody {
+  Bufs b;
+  int T;
+  NEPMI_HD void operator()(int64_t k) const
+  {
+    const int64_t key = (k >> kTypeChunkShift) * T + b.posq[k].type;
+    const int slot = NEPMI_ATOMIC_ADD(&b.tfill[key], 1);
+    b.tperm[b.tcount[key] + slot] = (int)k;
+  }
+};
+
 // rev_ang[s][k] = slot of k in j's list A (the pair test is exactly symmetric).
 struct ReverseSlotsBody {
   Bufs b;
@@ -464,6 +490,7 @@ struct SmallBoxPairsBody {
     p.pad = 0;
     b.posq[k] = p;
     b.perm[k] = (int)k;
+    b.tperm[k] = (int)k;
     b.lvl[k] = 2;
     int cnta = 0, cntb = 0;
     for (int64_t j = 0; j < N; ++j) {
@@ -1063,9 +1090,10 @@ template <class S>
 struct AnnBody {
   ModelD m;
   Bufs b;
-  NEPMI_HD void operator()(int64_t k) const
+  NEPMI_HD void operator()(int64_t g) const
   {
     const int64_t N = b.N;
+    const int64_t k = b.tperm[g]; // type-grouped work order
     if (b.lvl[k] < 1)
       return;
     const int NR = S::fixed ? S::NR : m.NR;
