@@ -1,0 +1,78 @@
+"""Model-format variants the shipped fixtures do not cover, synthesised from the PbTe nep4 file:
+nep5 (per-type output bias), nep3 with two types (one shared network), per-type cutoffs.  The
+engine (emulator on the CPU tier, library on the GPU tier) against the oracle, and the oracle
+against the reference's NEP_CPU where NEP_CPU supports the variant."""
+import numpy as np
+import pytest
+
+import helpers as H
+
+
+def _pbte_lines():
+    with open(H.golden("PbTe", "nep.txt")) as f:
+        return f.read().split("\n")
+
+
+def _write(tmp_path, name, lines):
+    p = tmp_path / name
+    p.write_text("\n".join(lines))
+    return str(p)
+
+
+def make_nep5(tmp_path):
+    L = _pbte_lines()
+    head, par = L[:6], L[6:]
+    dim, nneu = 42, 30
+    per = (dim + 2) * nneu
+    out = ["nep5 2 Te Pb"] + head[1:]
+    out += par[:per] + ["0.0321"] + par[per:2 * per] + ["-0.0456"] + par[2 * per:]
+    return _write(tmp_path, "nep5.txt", out)
+
+
+def make_nep3(tmp_path):
+    L = _pbte_lines()
+    head, par = L[:6], L[6:]
+    per = (42 + 2) * 30
+    out = ["nep3 2 Te Pb"] + head[1:] + par[:per] + par[2 * per:]   # one ANN block + b1 + c + q_scaler
+    return _write(tmp_path, "nep3.txt", out)
+
+
+def make_per_type_cutoff(tmp_path):
+    L = _pbte_lines()
+    out = [L[0], "cutoff 8 4 7.2 3.6 73 8"] + L[2:]
+    return _write(tmp_path, "pertype.txt", out)
+
+
+def _check(drv, nep, ref_cpu):
+    h, typ, x = H.pbte_supercell((2, 2, 2), seed=17)
+    n = len(typ)
+    orc = H.Oracle(nep)
+    pe64, f64, v64 = orc.compute(typ, h, x, precision=64, path=0)
+    if ref_cpu and H.ref_available():
+        pe_r, f_r, v_r = H.RefNepCpu(nep).compute(typ, h, x)
+        np.testing.assert_allclose(f64, f_r, rtol=1e-9, atol=1e-10)
+        np.testing.assert_allclose(pe64, pe_r, rtol=1e-10, atol=1e-10)
+    eng = drv.engine(drv.model(nep), n)
+    _, pe, f, v = H.engine_force(drv, eng, h, typ, x)
+    np.testing.assert_allclose(pe.sum(), pe64.sum(), rtol=1e-5)
+    assert np.all(np.abs(f - f64) <= 1e-4 * np.abs(f64) + 3e-5)
+    assert np.all(np.abs(v - v64) <= 1e-4 * np.abs(v64) + 1e-4)
+    L = orc.lists(typ, h, x, path=0)
+    for which, key in ((0, "radial"), (1, "angular")):
+        onn, onl = L[key]
+        _, nn, nl = H.engine_lists(drv, eng, n, which, ld=int(onn.max()) + 2)
+        H.assert_lists_equal(nn, nl, onn, onl)
+
+
+VARIANTS = [("nep5", make_nep5, True), ("nep3-2types", make_nep3, True), ("per-type-cutoff", make_per_type_cutoff, False)]
+
+
+@pytest.mark.parametrize("name,maker,ref_cpu", VARIANTS)
+def test_variant_on_emulator(tmp_path, name, maker, ref_cpu):
+    _check(H.EmuDriver(), maker(tmp_path), ref_cpu)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,maker,ref_cpu", VARIANTS)
+def test_variant_on_gpu(tmp_path, name, maker, ref_cpu):
+    _check(H.GpuDriver(), maker(tmp_path), ref_cpu)
