@@ -62,6 +62,7 @@ SYMBOLS = {
     "nepmi_engine_set_timing": (C.c_int, [VP, C.c_int]),
     "nepmi_engine_set_generic": (C.c_int, [VP, C.c_int]),
     "nepmi_engine_set_tiles": (C.c_int, [VP, C.c_int]),
+    "nepmi_engine_set_mfma": (C.c_int, [VP, C.c_int]),
 }
 
 

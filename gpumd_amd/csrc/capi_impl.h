@@ -304,6 +304,14 @@ int nepmi_engine_set_tiles(nepmi_engine* e, int on)
   return NEPMI_OK;
 }
 
+int nepmi_engine_set_mfma(nepmi_engine* e, int on)
+{
+  if (!e)
+    return fail(NEPMI_ERR_ARG, "null engine");
+  e->e->set_use_mfma(on != 0);
+  return NEPMI_OK;
+}
+
 int nepmi_engine_set_generic(nepmi_engine* e, int on)
 {
   if (!e)

@@ -54,6 +54,233 @@ __global__ void __launch_bounds__(BLOCK) nepmi_kernel_lds(const Body body, const
     body.run(i, (lds_cfloat_ptr)nepmi_lds);
 }
 
+// ---- per-atom ANN on the matrix cores ---------------------------------------------------------
+// The ANN of one type is two dense contractions over a batch of atoms (nep.cu:521-577 calls
+// apply_ann_one_layer per atom):  H = W0 Q  (neurons x dim  times  dim x atoms)  and
+// dE/dq = W0^T C  (dim x neurons  times  neurons x atoms,  C = w1 (1 - tanh^2)).
+// Work order: one 256-thread workgroup per 1024-atom chunk; inside a chunk the atoms are grouped by
+// type (tperm/tcount), so every wave tile is type-pure.  Per type the workgroup stages the weights
+// in LDS already in v_mfma_f32_32x32x2_f32 operand order (A: lane l holds A[i = l & 31][k = l >> 5]),
+// then each wave runs 64 atoms as two 32-column tiles:
+//   forward   acc[mt] += A(W0 rows 32mt.., k-pair s) x B(q[2s + (l >> 5)][atom l & 31])
+//   backward  the forward accumulator layout (row = (r & 3) + 8 (r >> 2) + 4 (l >> 5), col = l & 31)
+//             is exactly a B operand for the k-pair (neuron n, n + 4), so C is consumed in place.
+// The backward weight matrix carries extra output rows  sum_n qs[n] c[t1][t2][n][k] W0[neuron][n],
+// which makes the radial force table A_i[t2][k] (see AnnBody) fall out of the same MFMA chain.
+// f32 MFMA is an exact k-ordered fmaf chain, so this differs from AnnBody by summation order only.
+typedef float nepmi_f32x16 __attribute__((ext_vector_type(16)));
+constexpr int kAnnSplit = 2;               // workgroups per 1024-atom chunk
+constexpr int kAnnStride = 4 * kAnnSplit;  // wave tiles per pass over a chunk
+
+// tanh(x) = 1 - 2 / (exp(2x) + 1), branch-free (v_exp_f32 + v_rcp_f32); absolute error ~1e-7, the
+// rounding level of the f32 hidden activations themselves.  Saturates correctly at +-inf.
+__device__ __forceinline__ float tanh_fast(float x)
+{
+  const float e = __expf(2.0f * x);
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+}
+
+// register budget: two accumulator sets (16 MT + 16 DT), the C operand (16 MT, partly dead), the
+// q operand buffer (QB k-pairs) and ~60 working registers
+constexpr int ann_mfma_waves(int MT, int DT, int QB)
+{
+  return 16 * (MT + DT) + 60 + 12 * MT + QB <= 128 ? 4 : 16 * (MT + DT) + 60 + 12 * MT + QB <= 168 ? 3 : 2;
+}
+
+// One-off: write type blockIdx.x's weight image (layout: AnnMfmaShape) in MFMA operand order.
+__global__ void __launch_bounds__(256) nepmi_ann_pack(const ModelD m, const Bufs b, const int MT, const int DT)
+{
+  const int dim = m.dim, nneu = m.nneu, T = m.T, NR = m.NR, KR = m.KR, KRP = b.KRP;
+  const int KS = (dim + 1) >> 1;
+  const int tu = blockIdx.x, tid = threadIdx.x;
+  const size_t img_floats = (size_t)(KS * MT + MT * 16 * DT) * 64 + 2 * MT * 32;
+  float* Wf = b.ann_img + tu * img_floats; // [KS][MT][64]
+  float* Wb = Wf + KS * MT * 64;           // [MT*16][DT][64]
+  float* B0 = Wb + MT * 16 * DT * 64;      // [MT*32]
+  float* W1 = B0 + MT * 32;                // [MT*32]
+  const float* w0 = m.w0 + (size_t)tu * nneu * dim;
+  for (int idx = tid; idx < KS * MT * 64; idx += 256) {
+    const int l = idx & 63, mt = (idx >> 6) % MT, s = (idx >> 6) / MT;
+    const int neuron = mt * 32 + (l & 31), kk = 2 * s + (l >> 5);
+    Wf[idx] = (neuron < nneu && kk < dim) ? w0[neuron * dim + kk] : 0.0f;
+  }
+  for (int idx = tid; idx < MT * 16 * DT * 64; idx += 256) {
+    const int l = idx & 63, dt = (idx >> 6) % DT, step = (idx >> 6) / DT;
+    const int r = step & 15, mt = step >> 4;
+    const int neuron = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+    const int d = dt * 32 + (l & 31);
+    float v = 0.0f;
+    if (neuron < nneu) {
+      if (d < dim) {
+        v = w0[neuron * dim + d] * m.qscale[d];
+      } else {
+        const int xr = d - dim, t2 = xr / KRP, kk = xr - t2 * KRP;
+        if (t2 < T && kk <= KR) {
+          const float* c = m.c_rad + (size_t)(tu * T + t2) * (NR + 1) * (KR + 1);
+          for (int n = 0; n <= NR; ++n)
+            v = fmaf(m.qscale[n] * w0[neuron * dim + n], c[n * (KR + 1) + kk], v);
+        }
+      }
+    }
+    Wb[idx] = v;
+  }
+  for (int idx = tid; idx < MT * 32; idx += 256) {
+    B0[idx] = idx < nneu ? m.b0[(size_t)tu * nneu + idx] : 0.0f;
+    W1[idx] = idx < nneu ? m.w1[(size_t)tu * nneu + idx] : 0.0f;
+  }
+}
+
+template <int MT, int DT, int QB>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ann_mfma_waves(MT, DT, QB))))
+nepmi_ann_mfma(const ModelD m, const Bufs b, const int64_t nchunks)
+{
+  extern __shared__ __attribute__((aligned(16))) float nepmi_ann_lds[];
+  const int dim = m.dim, T = m.T, KRP = b.KRP;
+  const int KS = (dim + 1) >> 1;
+  const int img_floats = (KS * MT + MT * 16 * DT) * 64 + 2 * MT * 32;
+  const float* Wf = nepmi_ann_lds;          // [KS][MT][64]
+  const float* Wb = Wf + KS * MT * 64;      // [MT*16][DT][64]
+  const float* B0 = Wb + MT * 16 * DT * 64; // [MT*32]
+  const float* W1 = B0 + MT * 32;           // [MT*32]
+  // kAnnSplit workgroups share one chunk (more, shorter workgroups: less tail at 3 waves/SIMD)
+  const unsigned per_xcd = gridDim.x >> 3;
+  const int64_t wg = (int64_t)(blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+  const int64_t chunk = wg / kAnnSplit;
+  if (chunk >= nchunks)
+    return;
+  const int64_t N = b.N;
+  const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, col = lane & 31;
+  const int wave = (tid >> 6) + 4 * (int)(wg % kAnnSplit); // tile slot of this wave within the chunk
+  for (int tu = 0; tu < T; ++tu) {
+    const int lo = b.tcount[chunk * T + tu], end = b.tcount[chunk * T + tu + 1];
+    if (lo == end)
+      continue;
+    __syncthreads();
+    {
+      const float4* src = reinterpret_cast<const float4*>(b.ann_img + (size_t)tu * img_floats);
+      float4* dst = reinterpret_cast<float4*>(nepmi_ann_lds);
+      for (int idx = tid; idx < img_floats / 4; idx += 256)
+        dst[idx] = src[idx];
+    }
+    __syncthreads();
+    const float ebias = m.b1 + m.b1t[tu];
+    const nepmi_f32x16 zero16 = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    const int nrows = dim + T * KRP;
+    // This wave's tiles: lo + 64 (wave + 4 i).  The loop runs over units = (tile, 32-column half);
+    // the q rows of unit u+1 are requested right after unit u's forward MFMAs have consumed the
+    // operand registers -- i.e. before unit u's stores, so that (vmcnt being in-order) waiting for
+    // them never waits for a store, and the round trip overlaps the backward MFMAs.
+    const int ntiles = (end - lo + 63) >> 6;
+    if (wave >= ntiles)
+      continue;
+    const int nunits = 2 * ((ntiles - wave + kAnnStride - 1) / kAnnStride);
+    int tile = lo + wave * 64;
+    int k_cur, act_cur, k_nxt = 0, act_nxt = 0;
+    {
+      const int gl = tile + lane;
+      k_cur = b.tperm[gl < end ? gl : lo];
+      act_cur = (gl < end && b.lvl[k_cur] >= 1) ? 1 : 0;
+    }
+    // q and fp are stored in work order: column g of the [dim][N] arrays is work item g
+    int gc = min(tile + col, end - 1);
+    float bq[QB];
+#pragma unroll
+    for (int s = 0; s < QB; ++s)
+      bq[s] = b.q[(int64_t)min(2 * s + hi, dim - 1) * N + gc];
+    float e_own = 0.0f;
+#pragma unroll 1
+    for (int u = 0; u < nunits; ++u) {
+      const int nt = u & 1;
+      // keep the weight reads and the row arithmetic inside the loop (registers, not LICM)
+      int hi_o = hi;
+      asm volatile("" : "+v"(hi_o) : : "memory");
+      if (nt == 0) {
+        const int gl = tile + 64 * kAnnStride + lane;
+        const bool more = tile + 64 * kAnnStride < end;
+        k_nxt = b.tperm[(more && gl < end) ? gl : lo];
+        act_nxt = (more && gl < end && b.lvl[k_nxt] >= 1) ? 1 : 0;
+      }
+      const int actc = __shfl(act_cur, nt * 32 + col);
+      nepmi_f32x16 acc[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+        acc[mt] = zero16;
+#pragma unroll
+      for (int s = 0; s < QB; ++s) {
+        if (s < KS) {
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(Wf[(s * MT + mt) * 64 + lane], bq[s], acc[mt], 0, 0, 0);
+        }
+      }
+      const int kc = __shfl(k_cur, nt * 32 + col);
+      const int gc_n = min(nt == 0 ? tile + 32 + col : tile + 64 * kAnnStride + col, end - 1);
+      if (u + 1 < nunits) {
+#pragma unroll
+        for (int s = 0; s < QB; ++s)
+          bq[s] = b.q[(int64_t)min(2 * s + hi_o, dim - 1) * N + gc_n];
+      }
+      float e_part = 0.0f;
+      float cf[MT][16]; // C = w1 (1 - tanh^2): the backward B operand, same lane layout as acc
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int neuron = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi_o;
+          const float h = tanh_fast(acc[mt][r] - B0[neuron]);
+          const float wj = W1[neuron];
+          e_part = fmaf(wj, h, e_part);
+          cf[mt][r] = wj * (1.0f - h * h);
+        }
+      const float e_tot = e_part + __shfl_xor(e_part, 32);
+      if (hi == nt)
+        e_own = e_tot;
+      nepmi_f32x16 out[DT];
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+        out[dt] = zero16;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float bc = cf[mt][r];
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt)
+            out[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+              Wb[((mt * 16 + r) * DT + dt) * 64 + lane], bc, out[dt], 0, 0, 0);
+        }
+      if (actc) {
+        // rows in register order: d = 32 dt + {0,1,2,3, 8,.., 27} + 4 hi, i.e. steps of +1,+1,+1,+5;
+        // rows [dim, dim + T KRP) are the radial-table rows, laid out exactly like atab's row
+        int d = 4 * hi_o;
+        float* pf = b.fp + gc + (int64_t)d * N;
+        float* pa = b.atab + (size_t)kc * (T * KRP) - dim;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float v = out[dt][r];
+            if (d < dim)
+              *pf = v;
+            else if (d < nrows)
+              pa[d] = v;
+            const int step = (r & 3) == 3 ? 5 : 1;
+            d += step;
+            pf += (int64_t)step * N;
+          }
+      }
+      if (nt == 1) {
+        if (act_cur)
+          b.pe_i[k_cur] = e_own - ebias;
+        k_cur = k_nxt;
+        act_cur = act_nxt;
+        tile += 64 * kAnnStride;
+      }
+      gc = gc_n;
+    }
+  }
+}
+
 // ---- exclusive scan of int32, in place: 3 kernels (block scan, scan of block sums, add) ----
 template <int BLOCK>
 __device__ __forceinline__ int block_exclusive_scan(int v, int* total);
@@ -271,6 +498,7 @@ struct HipBackend {
   HipTiming* timing = nullptr; // shared by copies of the backend
   int* pinned = nullptr;       // 64-byte pinned staging for flag read-back
   bool timing_on = false;
+  bool mfma_on = true; // per-atom ANN on the matrix cores when the model shape allows it
 
   void* alloc(size_t bytes)
   {
@@ -376,6 +604,74 @@ struct HipBackend {
     if (t)
       timer_stop(timing->slot[slot]);
   }
+
+  // ANN launch: the MFMA kernel when the shape fits (few types, <= 128 neurons, <= 128 output rows
+  // incl. the radial-table rows), else the per-atom AnnBody.
+  template <int MT, int QB>
+  void launch_ann_mfma(int DT, size_t lds_bytes, int64_t grid, const ModelD& m, const Bufs& b, int64_t nchunks)
+  {
+#define NEPMI_ANN_CASE(D)                                                                           \
+  case D:                                                                                           \
+    if (lds_bytes > 64 * 1024)                                                                      \
+      NEPMI_HIP_CHECK(hipFuncSetAttribute(                                                          \
+        reinterpret_cast<const void*>(&nepmi_ann_mfma<MT, D, QB>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+        (int)lds_bytes));                                                                           \
+    hipLaunchKernelGGL((nepmi_ann_mfma<MT, D, QB>), dim3((unsigned)grid), dim3(256), lds_bytes, stream, m, b, nchunks); \
+    break;
+    switch (DT) {
+      NEPMI_ANN_CASE(1)
+      NEPMI_ANN_CASE(2)
+      NEPMI_ANN_CASE(3)
+      NEPMI_ANN_CASE(4)
+    }
+#undef NEPMI_ANN_CASE
+  }
+
+  void ann_prepare(const ModelD& m, const Bufs& b)
+  {
+    if (!b.ann_img)
+      return;
+    const AnnMfmaShape a = ann_mfma_shape(m.T, m.dim, m.nneu, b.KRP);
+    hipLaunchKernelGGL(nepmi_ann_pack, dim3((unsigned)m.T), dim3(256), 0, stream, m, b, a.MT, a.DT);
+    NEPMI_HIP_CHECK(hipGetLastError());
+  }
+
+  template <class S>
+  void launch_ann(int slot, int64_t n, const ModelD& m, const Bufs& b, bool grouped)
+  {
+    if (!mfma_on || !b.ann_img || !grouped) {
+      launch<64>(slot, n, AnnBody<S>{m, b});
+      return;
+    }
+    if (n <= 0)
+      return;
+    const AnnMfmaShape a = ann_mfma_shape(m.T, m.dim, m.nneu, b.KRP);
+    const size_t lds_bytes = a.img_floats * sizeof(float);
+    const int64_t nchunks = (n >> kTypeChunkShift) + 1;
+    const int64_t grid = (nchunks * kAnnSplit + 7) / 8 * 8;
+    const bool t = timing_on;
+    if (t)
+      timer_start(timing->slot[slot]);
+    if (a.KS <= 24) {
+      switch (a.MT) {
+        case 1: launch_ann_mfma<1, 24>(a.DT, lds_bytes, grid, m, b, nchunks); break;
+        case 2: launch_ann_mfma<2, 24>(a.DT, lds_bytes, grid, m, b, nchunks); break;
+        case 3: launch_ann_mfma<3, 24>(a.DT, lds_bytes, grid, m, b, nchunks); break;
+        default: launch_ann_mfma<4, 24>(a.DT, lds_bytes, grid, m, b, nchunks); break;
+      }
+    } else {
+      switch (a.MT) {
+        case 1: launch_ann_mfma<1, 40>(a.DT, lds_bytes, grid, m, b, nchunks); break;
+        case 2: launch_ann_mfma<2, 40>(a.DT, lds_bytes, grid, m, b, nchunks); break;
+        case 3: launch_ann_mfma<3, 40>(a.DT, lds_bytes, grid, m, b, nchunks); break;
+        default: launch_ann_mfma<4, 40>(a.DT, lds_bytes, grid, m, b, nchunks); break;
+      }
+    }
+    NEPMI_HIP_CHECK(hipGetLastError());
+    if (t)
+      timer_stop(timing->slot[slot]);
+  }
+  void set_mfma(bool on) { mfma_on = on; }
 
   template <class Body>
   void launch_tile(int slot, int64_t nbricks, const Body& body)

@@ -412,6 +412,9 @@ private:
       b_.sbuf = dalloc<float>((size_t)(m.n_max_angular + 1) * kNumHarm * N);
       b_.KRP = ((m.basis_size_radial + 1) + 3) / 4 * 4;
       b_.atab = dalloc<float>((size_t)N * m.num_types * b_.KRP);
+      const AnnMfmaShape as = ann_mfma_shape(m.num_types, m.dim, m.num_neurons, b_.KRP);
+      b_.ann_img = as.ok ? dalloc<float>(as.img_floats * m.num_types) : nullptr;
+      be_.ann_prepare(md_, b_);
       b_.pe_i = dalloc<float>(N);
     } else { // Tersoff-1989: Tersoff1989::Tersoff1989 allocations (tersoff1989.cu:141-149)
       tb_.rec = dalloc<D4>((size_t)b_.MN_ang * N);
@@ -429,8 +432,8 @@ private:
     b_.zbl = dalloc<float>(m.zbl_enabled ? (size_t)10 * N : 1);
     b_.lvl = dalloc<signed char>(N);
     b_.tperm = dalloc<int>(N);
+    b_.tpos = dalloc<int>(N);
     b_.tcount = dalloc<int>(((size_t)(N >> kTypeChunkShift) + 2) * m.num_types + 2);
-    b_.tfill = dalloc<int>(((size_t)(N >> kTypeChunkShift) + 2) * m.num_types + 2);
     b_.flags = dalloc<int>(kNumFlags);
     be_.memset(b_.flags, 0, sizeof(int) * kNumFlags);
     thermo_scratch_ = dalloc<double>(8 * 1024);
@@ -511,7 +514,7 @@ private:
   {
     be_.template launch<64>(kSlotRadial, N_, RadialFromRecordsBody<S>{md_, b_});
     be_.template launch_lds<64>(kSlotAngular, N_, AngularDescBody<S>{md_, b_});
-    be_.template launch<64>(kSlotAnn, N_, AnnBody<S>{md_, b_});
+    be_.template launch_ann<S>(kSlotAnn, N_, md_, b_, false); // identity work order, no type groups
     be_.template launch_lds<64>(kSlotAngForce, N_, AngularForceBody<S>{md_, b_});
     be_.template launch<64>(kSlotForce, N_, ForceAssembleBody<S>{md_, b_, pe, force, virial});
   }
@@ -586,7 +589,6 @@ private:
     {
       const int64_t nkeys = ((N_ >> kTypeChunkShift) + 1) * model_.num_types;
       be_.memset(b_.tcount, 0, sizeof(int) * (nkeys + 1));
-      be_.memset(b_.tfill, 0, sizeof(int) * nkeys);
       be_.template launch<256>(kSlotMisc, N_, TypeCountBody{b_, model_.num_types});
       be_.exclusive_scan(b_.tcount, nkeys + 1, scan_scratch_);
       be_.template launch<256>(kSlotMisc, N_, TypeFillBody{b_, model_.num_types});
@@ -648,6 +650,7 @@ public:
     have_list_ = false;
   }
   bool tiles_active() const { return tile_ok_; }
+  void set_use_mfma(bool on) { be_.set_mfma(on); }
   void set_force_generic(bool on)
   {
     force_generic_ = on;
@@ -665,7 +668,7 @@ private:
     else
       be_.template launch<64>(kSlotRadial, N_, RadialDescBody<S>{box_, md_, b_});
     be_.template launch_lds<64>(kSlotAngular, N_, AngularDescBody<S>{md_, b_});
-    be_.template launch<64>(kSlotAnn, N_, AnnBody<S>{md_, b_});
+    be_.template launch_ann<S>(kSlotAnn, N_, md_, b_, true);
     be_.template launch_lds<64>(kSlotAngForce, N_, AngularForceBody<S>{md_, b_});
     be_.template launch<64>(kSlotForce, N_, ForceAssembleBody<S>{md_, b_, pe, force, virial});
     be_.end_region(kRegionForce);

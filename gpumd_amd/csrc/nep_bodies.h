@@ -89,14 +89,15 @@ struct Bufs {
   float* sbuf; // [(NA+1)*24][N]
   float* atab; // [N][T*KRP]
   int KRP;
+  float* ann_img; // [T][AnnMfmaShape::img_floats] MFMA-operand-order weight images, or null
   float* pe_i; // [N]
   float* zbl;  // [10][N] (fx fy fz, vxx vyy vzz vxy vxz vyz, pe) when zbl enabled
   int* flags;  // [kNumFlags]
   const signed char* level; // caller order, or nullptr: 2 owned, 1 inner ghost, 0 outer ghost
   signed char* lvl;         // [N] the same in internal order (sampled at list rebuild)
   int* tperm;               // [N] atoms ordered by (chunk of 1024, type): the ANN kernel's work order
+  int* tpos;                // [N] inverse of tperm: q and fp are stored in work order, [dim][tpos]
   int* tcount;              // [(nchunks * T) + 1] histogram / offsets of that order
-  int* tfill;               // [nchunks * T]
   int* sh_ang;              // small-box path only: packed periodic-image shift of each list-A entry
 };
 
@@ -355,6 +356,25 @@ struct BuildListsBody {
 // that a wavefront holds (almost always) one type and runs the network once, with that type's
 // weights as scalar operands -- instead of once per type present (16x for the 16-metal UNEP model).
 constexpr int kTypeChunkShift = 10;
+
+// Shape of the matrix-core ANN kernel (engine.hip: nepmi_ann_mfma) for a model: MT 32-neuron row
+// tiles, DT 32-row output tiles (descriptor rows + T*KRP radial-table rows), KS k-pairs over the
+// descriptor.  img_floats = one type's weight image  [KS][MT][64] | [16 MT][DT][64] | b0[32 MT] | w1[32 MT].
+struct AnnMfmaShape {
+  int MT, DT, KS;
+  size_t img_floats;
+  bool ok;
+};
+inline AnnMfmaShape ann_mfma_shape(int T, int dim, int nneu, int KRP)
+{
+  AnnMfmaShape a;
+  a.MT = (nneu + 31) / 32;
+  a.DT = (dim + T * KRP + 31) / 32;
+  a.KS = (dim + 1) / 2;
+  a.img_floats = (size_t)(a.KS * a.MT + a.MT * 16 * a.DT) * 64 + 2 * a.MT * 32;
+  a.ok = T <= 4 && a.MT <= 4 && a.DT <= 4 && a.KS <= 40 && a.img_floats * sizeof(float) <= 144 * 1024;
+  return a;
+}
 struct TypeCountBody {
   Bufs b;
   int T;
@@ -366,11 +386,19 @@ struct TypeCountBody {
 struct TypeFillBody {
   Bufs b;
   int T;
+  // rank of k among the same-type atoms of its chunk that precede it: the work order inside a type
+  // group is ascending in k (deterministic, and neighbouring lanes touch neighbouring rows of q/Fp).
+  // The scan index is wave-uniform, so the type reads are broadcasts.
   NEPMI_HD void operator()(int64_t k) const
   {
-    const int64_t key = (k >> kTypeChunkShift) * T + b.posq[k].type;
-    const int slot = NEPMI_ATOMIC_ADD(&b.tfill[key], 1);
-    b.tperm[b.tcount[key] + slot] = (int)k;
+    const int t = b.posq[k].type;
+    const int64_t k0 = (k >> kTypeChunkShift) << kTypeChunkShift;
+    int rank = 0;
+    for (int64_t kp = k0; kp < k; ++kp)
+      rank += (b.posq[kp].type == t) ? 1 : 0;
+    const int pos = b.tcount[(k >> kTypeChunkShift) * T + t] + rank;
+    b.tperm[pos] = (int)k;
+    b.tpos[k] = pos;
   }
 };
 
@@ -491,6 +519,7 @@ struct SmallBoxPairsBody {
     b.posq[k] = p;
     b.perm[k] = (int)k;
     b.tperm[k] = (int)k;
+    b.tpos[k] = (int)k;
     b.lvl[k] = 2;
     int cnta = 0, cntb = 0;
     for (int64_t j = 0; j < N; ++j) {
@@ -804,7 +833,7 @@ struct RadialDescBody {
       }
     }
     for (int n = 0; n <= NR; ++n)
-      b.q[(int64_t)n * N + k] = q[n] * m.qscale[n];
+      b.q[(int64_t)n * N + b.tpos[k]] = q[n] * m.qscale[n];
   }
 };
 
@@ -993,7 +1022,7 @@ struct RadialFromRecordsBody {
       }
     }
     for (int n = 0; n <= NR; ++n)
-      b.q[(int64_t)n * N + k] = q[n] * m.qscale[n];
+      b.q[(int64_t)n * N + b.tpos[k]] = q[n] * m.qscale[n];
   }
 };
 
@@ -1013,6 +1042,7 @@ struct AngularDescBody {
     const int64_t N = b.N;
     if (b.lvl[k] < 1)
       return;
+    const int64_t gk = b.tpos[k]; // q / fp column of this atom (work order)
     const int NR = S::fixed ? S::NR : m.NR;
     const int NA = S::fixed ? S::NA : m.NA;
     const int KA = S::fixed ? S::KA : m.KA;
@@ -1077,7 +1107,7 @@ struct AngularDescBody {
       invariants(m, &s[n * kNumHarm], qn, 1);
       for (int L = 0; L < m.numL; ++L) {
         const int d = (NR + 1) + L * (NA + 1) + n;
-        b.q[(int64_t)d * N + k] = qn[L] * m.qscale[d];
+        b.q[(int64_t)d * N + gk] = qn[L] * m.qscale[d];
       }
     }
   }
@@ -1106,7 +1136,7 @@ struct AnnBody {
     for (int d = 0; d < S::DIMM; ++d) {
       if (!S::fixed && d >= dim)
         break;
-      q[d] = b.q[(int64_t)d * N + k];
+      q[d] = b.q[(int64_t)d * N + g];
       Fp[d] = 0.0f;
     }
     float E = 0.0f;
@@ -1177,7 +1207,7 @@ struct AnnBody {
     for (int d = 0; d < S::DIMM; ++d) {
       if (!S::fixed && d >= dim)
         break;
-      b.fp[(int64_t)d * N + k] = Fp[d];
+      b.fp[(int64_t)d * N + g] = Fp[d];
     }
   }
 };
@@ -1199,6 +1229,7 @@ struct AngularForceBody {
     const int64_t N = b.N;
     if (b.lvl[k] < 1)
       return;
+    const int64_t gk = b.tpos[k]; // q / fp column of this atom (work order)
     const int NR = S::fixed ? S::NR : m.NR;
     const int NA = S::fixed ? S::NA : m.NA;
     const int KA = S::fixed ? S::KA : m.KA;
@@ -1214,7 +1245,7 @@ struct AngularForceBody {
       float fpn[6];
 #pragma unroll
       for (int L = 0; L < 6; ++L)
-        fpn[L] = L < m.numL ? b.fp[(int64_t)((NR + 1) + L * (NA + 1) + n) * N + k] : 0.0f;
+        fpn[L] = L < m.numL ? b.fp[(int64_t)((NR + 1) + L * (NA + 1) + n) * N + gk] : 0.0f;
 #pragma unroll
       for (int h = 0; h < kNumHarm; ++h)
         G[n * kNumHarm + h] = b.sbuf[(int64_t)(n * kNumHarm + h) * N + k];
@@ -1565,9 +1596,9 @@ struct ExportDescBody {
     const int64_t i = b.perm[k];
     for (int d = 0; d < dim; ++d) {
       if (q_out)
-        q_out[(int64_t)d * N + i] = b.q[(int64_t)d * N + k];
+        q_out[(int64_t)d * N + i] = b.q[(int64_t)d * N + b.tpos[k]];
       if (fp_out)
-        fp_out[(int64_t)d * N + i] = b.fp[(int64_t)d * N + k];
+        fp_out[(int64_t)d * N + i] = b.fp[(int64_t)d * N + b.tpos[k]];
     }
   }
 };

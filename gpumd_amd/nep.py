@@ -183,5 +183,8 @@ class NEP:
     def set_tiles(self, on=True):
         self._ck(self.lib.nepmi_engine_set_tiles(self.handle, 1 if on else 0))
 
+    def set_mfma(self, on=True):
+        self._ck(self.lib.nepmi_engine_set_mfma(self.handle, 1 if on else 0))
+
     def set_generic(self, on=True):
         self._ck(self.lib.nepmi_engine_set_generic(self.handle, 1 if on else 0))

@@ -185,6 +185,11 @@ int nepmi_engine_set_generic(nepmi_engine* e, int on);
  * (also taken automatically when a periodic direction has fewer than 8 cells or a brick's window
  * does not fit LDS).  Both give identical lists and pair records. */
 int nepmi_engine_set_tiles(nepmi_engine* e, int on);
+/* Allow (default) or forbid the matrix-core (v_mfma_f32_32x32x2_f32) ANN kernel; forbidding selects
+ * the per-atom ANN kernel, which is also taken automatically for models with more than 4 types,
+ * more than 128 neurons or more than 128 descriptor + radial-table rows.  The two differ by f32
+ * summation order only. */
+int nepmi_engine_set_mfma(nepmi_engine* e, int on);
 
 #ifdef __cplusplus
 }

@@ -39,6 +39,15 @@ struct HostLoopBackend {
       body(i);
   }
 
+  // the product's MFMA ANN kernel is device-only; the emulator runs the per-atom body
+  template <class S>
+  void launch_ann(int slot, int64_t n, const ModelD& m, const Bufs& b, bool)
+  {
+    launch<64>(slot, n, AnnBody<S>{m, b});
+  }
+  void set_mfma(bool) {}
+  void ann_prepare(const ModelD&, const Bufs&) {}
+
   // one "workgroup" per brick, phases run back to back (the LDS-window radial pass)
   template <class Body>
   void launch_tile(int, int64_t nbricks, const Body& body)

@@ -28,7 +28,7 @@ MODELS = {
 }
 
 
-def check_force_parity(drv, name, generic=False, check_lists=True, tiles=True):
+def check_force_parity(drv, name, generic=False, check_lists=True, tiles=True, mfma=True):
     nep_rel, build, _ = MODELS[name]
     nep = H.golden(*nep_rel.split("/"))
     h, typ, x = build()
@@ -43,6 +43,8 @@ def check_force_parity(drv, name, generic=False, check_lists=True, tiles=True):
     if generic:
         eng.set_generic(True)
     eng.set_tiles(tiles)
+    if not mfma:
+        eng.set_mfma(False)
     xw, pe, f, v = H.engine_force(drv, eng, h, typ, x)
     if not tiles:
         assert eng.stats().radial_tiles == 0

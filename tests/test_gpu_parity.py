@@ -30,6 +30,36 @@ def test_force_parity_without_lds_window(drv, name):
     P.check_force_parity(drv, name, tiles=False)
 
 
+@pytest.mark.parametrize("name", ["PbTe-A", "C-2022", "BaZrO3"])
+def test_force_parity_without_mfma(drv, name):
+    """The per-atom ANN kernel (taken automatically for many-type models such as UNEP-v1)."""
+    P.check_force_parity(drv, name, check_lists=False, mfma=False)
+
+
+@pytest.mark.parametrize("name", ["PbTe-A", "PbTe-B", "C-2022", "BaZrO3"])
+def test_mfma_ann_matches_per_atom_ann(drv, name):
+    """Matrix-core ANN vs per-atom ANN: same contractions, different f32 summation order."""
+    nep_rel, build, _ = P.MODELS[name]
+    nep = H.golden(*nep_rel.split("/"))
+    h, typ, x = build()
+    n = len(typ)
+    model = drv.model(nep)
+    out = []
+    for on in (True, False):
+        eng = drv.engine(model, n)
+        eng.set_mfma(on)
+        _, pe, f, v = H.engine_force(drv, eng, h, typ, x)
+        q = drv.zeros(model.info.dim * n, dtype=np.float32)
+        fp = drv.zeros(model.info.dim * n, dtype=np.float32)
+        eng.descriptors(q, fp)
+        out.append((pe, f, v, drv.host(fp).reshape(-1, n)))
+    (pe1, f1, v1, fp1), (pe0, f0, v0, fp0) = out
+    np.testing.assert_allclose(fp1, fp0, rtol=1e-4, atol=2e-6 * np.abs(fp0).max())
+    np.testing.assert_allclose(pe1, pe0, rtol=1e-5, atol=5e-6)
+    assert np.abs(f1 - f0).max() <= 1e-5 * max(1.0, np.abs(f0).max())
+    assert np.abs(v1 - v0).max() <= 2e-5 * max(1.0, np.abs(v0).max())
+
+
 def test_lds_window_pass_is_used(drv):
     eng = P.check_force_parity(drv, "PbTe-A", check_lists=False)
     assert eng.stats().radial_tiles == 1
