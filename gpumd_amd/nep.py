@@ -114,11 +114,12 @@ class NEP:
     def invalidate(self):
         self._ck(self.lib.nepmi_engine_invalidate(self.handle))
 
-    def force_compute(self, box, type, position, potential, force, virial):
+    def force_compute(self, box, type, position, potential, force, virial, n=None):
+        """n: number of atoms in the arrays (default: the capacity the engine was created with)."""
         _, hp = _h9(box)
         _, pp = _pbc3(self.pbc)
         self._ck(self.lib.nepmi_force_compute(
-            self.handle, hp, pp, self.n, self._ptr(type), self._ptr(position), self._ptr(potential),
+            self.handle, hp, pp, self.n if n is None else int(n), self._ptr(type), self._ptr(position), self._ptr(potential),
             self._ptr(force), self._ptr(virial)))
 
     def apply_pbc(self, box, position):

@@ -461,7 +461,7 @@ def engine_force(drv, eng, h, typ, x):
     n = len(typ)
     d_t, d_x = drv.dev(typ), drv.dev(x)
     d_pe, d_f, d_v = drv.zeros(n), drv.zeros(3 * n), drv.zeros(9 * n)
-    eng.force_compute(h, d_t, d_x, d_pe, d_f, d_v)
+    eng.force_compute(h, d_t, d_x, d_pe, d_f, d_v, n=n)
     return drv.host(d_x), drv.host(d_pe), drv.host(d_f), drv.host(d_v)
 
 

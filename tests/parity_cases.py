@@ -301,3 +301,60 @@ def check_error_paths(drv):
         drv.model(H.golden("PbTe", "model.xyz"))
     with pytest.raises(NepmiError):
         drv.model(H.golden("PbTe", "does_not_exist.txt"))
+
+
+def check_boundary_conditions(drv):
+    """Free and mixed boundaries (Box::pbc_x/y/z = 0, box.cuh:84-129: no minimum image and no wrap
+    along a free direction; neighbor.cuh:76-110: cell index clamped) and degenerate inputs: an atom
+    with no neighbours at all, and an engine used below its capacity."""
+    nep = H.golden("PbTe", "nep.txt")
+    orc = H.Oracle(nep)
+    model = drv.model(nep)
+    h0, typ, x0 = H.pbte_supercell((2, 2, 2), seed=11)
+    n = len(typ)
+    for pbc in ((0, 0, 0), (1, 1, 0), (0, 1, 1), (1, 0, 0)):
+        # vacuum along the free directions: the cell keeps its shape, atoms sit in the middle
+        h = np.array(h0, dtype=np.float64).reshape(-1)[:9].copy().reshape(3, 3)
+        x = np.array(x0).reshape(3, n).copy()
+        for d in range(3):
+            if not pbc[d]:
+                h[:, d] *= 1.6
+        frac = np.linalg.solve(np.array(h0).reshape(-1)[:9].reshape(3, 3), x)
+        for d in range(3):
+            if not pbc[d]:
+                frac[d] = (frac[d] + 0.3) / 1.6
+        x = (h @ frac).reshape(-1)
+        h9 = h.reshape(-1)
+        pe64, f64, v64 = orc.compute(typ, h9, H.oracle_apply_pbc(h9, x, pbc), pbc=pbc, precision=64, path=0)
+        eng = drv.engine(model, n, pbc=pbc)
+        xw, pe, f, v = H.engine_force(drv, eng, h9, typ, x)
+        assert np.array_equal(xw, H.oracle_apply_pbc(h9, x, pbc)), pbc
+        np.testing.assert_allclose(pe, pe64, rtol=1e-5, atol=2e-5)
+        assert np.all(np.abs(f - f64) <= 1e-4 * np.abs(f64) + 3e-5), (pbc, np.abs(f - f64).max())
+        assert np.all(np.abs(v - v64) <= 1e-4 * np.abs(v64) + 1e-4), pbc
+        L = orc.lists(typ, h9, xw, pbc=pbc, path=0)
+        for which, key in ((0, "radial"), (1, "angular")):
+            onn, onl = L[key]
+            mx, nn, nl = H.engine_lists(drv, eng, n, which, ld=int(onn.max()) + 2)
+            H.assert_lists_equal(nn, nl, onn, onl)
+        # surface atoms really lost neighbours
+        assert L["radial"][0].min() < L["radial"][0].max()
+
+    # isolated atoms: three atoms 40 A apart in a 120 A box -> no neighbours, E_i = ANN(q = 0)
+    h9 = np.diag([120.0, 120.0, 120.0]).reshape(-1)
+    typ3 = np.array([0, 1, 0], dtype=np.int32)
+    x3 = H.soa(np.array([[10.0, 10.0, 10.0], [50.0, 50.0, 50.0], [90.0, 90.0, 90.0]]))
+    pe64, f64, v64 = orc.compute(typ3, h9, x3, precision=64, path=0)
+    eng = drv.engine(model, 3)
+    _, pe, f, v = H.engine_force(drv, eng, h9, typ3, x3)
+    np.testing.assert_allclose(pe, pe64, rtol=1e-5, atol=1e-6)
+    assert np.abs(f).max() == 0.0 and np.abs(v).max() == 0.0 and np.abs(f64).max() == 0.0
+    assert pe[0] == pe[2] and pe[0] != pe[1]
+
+    # capacity > n: one engine serves a smaller system than it was created for
+    eng = drv.engine(model, 2 * n)
+    h9 = np.array(h0, dtype=np.float64).reshape(-1)[:9]
+    pe64, f64, _ = orc.compute(typ, h9, x0, precision=64, path=0)
+    _, pe, f, _ = H.engine_force(drv, eng, h9, typ, np.array(x0))
+    np.testing.assert_allclose(pe, pe64, rtol=1e-5, atol=2e-5)
+    assert np.all(np.abs(f - f64) <= 1e-4 * np.abs(f64) + 3e-5)

@@ -53,5 +53,9 @@ def test_small_box_branch(drv):
     P.check_small_box(drv)
 
 
+def test_boundary_conditions_and_degenerate_inputs(drv):
+    P.check_boundary_conditions(drv)
+
+
 def test_error_paths(drv):
     P.check_error_paths(drv)
