@@ -238,6 +238,51 @@ public:
     check_overflow(flags);
   }
 
+  // Ensemble_NHC (ensemble_nhc.cu): chain state in caller-owned device memory (kNhcStateSize doubles)
+  void nhc_init(int64_t n, double temperature, double t_coup, double dt, double* state)
+  {
+    be_.template launch<64>(kSlotMisc, 1, NhcInitBody{n, temperature, t_coup, dt, state});
+  }
+  // one thermostat half-step: chain update from thermo8[0], then v *= factor (both on the device)
+  void nhc_half_step(int64_t n, double temperature, double dt, const double* thermo8, double* state, double* vel)
+  {
+    be_.template launch<64>(kSlotMisc, 1, NhcChainBody{n, temperature, 0.5 * dt, thermo8, state});
+    be_.template launch<256>(kSlotMisc, n, ScaleVelocityBody{n, state + 3 * kNhcLinks, vel});
+  }
+
+  // Run::perform_a_run for `ensemble nvt_nhc T1 T2 Tcoup` (integrate_nvt_nhc_1/2, ensemble_nhc.cu:166-232)
+  void run_nvt_nhc(
+    const double h9[9], const int pbc[3], int64_t n, const int* type, const double* mass, double dt,
+    int64_t nsteps, double t1, double t2, double tcoup, double* pos, double* vel, double* pe, double* force,
+    double* virial, int64_t thermo_every, double* thermo_host)
+  {
+    BoxD box;
+    box_from_h9(h9, pbc, box);
+    if (!nhc_dev_)
+      nhc_dev_ = dalloc<double>(kNhcStateSize);
+    nhc_init(n, t1, tcoup, dt, nhc_dev_);
+    int64_t rec = 0;
+    for (int64_t step = 0; step < nsteps; ++step) {
+      const double target = t1 + (t2 - t1) * ((double)step / (double)nsteps);
+      find_thermo(n, box.volume, mass, pe, vel, virial, thermo_dev_);
+      nhc_half_step(n, target, dt, thermo_dev_, nhc_dev_, vel);
+      velocity_verlet(true, n, dt, mass, force, pos, vel, &box);
+      zero_properties(n, pe, force, virial);
+      potential_compute(h9, pbc, n, type, pos, pe, force, virial);
+      velocity_verlet(false, n, dt, mass, force, pos, vel, nullptr);
+      find_thermo(n, box.volume, mass, pe, vel, virial, thermo_dev_);
+      nhc_half_step(n, target, dt, thermo_dev_, nhc_dev_, vel);
+      if (thermo_every > 0 && (step + 1) % thermo_every == 0) {
+        be_.d2h(thermo_host + 8 * rec, thermo_dev_, 8 * sizeof(double));
+        ++rec;
+      }
+    }
+    be_.sync();
+    int flags[kNumFlags];
+    be_.d2h(flags, b_.flags, sizeof(flags));
+    check_overflow(flags);
+  }
+
   // Run::perform_a_run for `ensemble nve` (run.cu:250-318)
   void run_nve(
     const double h9[9], const int pbc[3], int64_t n, const int* type, const double* mass, double dt,
@@ -713,6 +758,7 @@ private:
   int* scan_scratch_ = nullptr;
   double* thermo_scratch_ = nullptr;
   double* thermo_dev_ = nullptr;
+  double* nhc_dev_ = nullptr;
   std::vector<void*> allocs_;
 };
 

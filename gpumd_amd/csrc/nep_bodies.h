@@ -193,6 +193,100 @@ struct BerendsenBody {
   }
 };
 
+// Nose-Hoover chain (Ensemble_NHC, src/integrate/ensemble_nhc.cu:102-232): the reference copies the
+// temperature to the host and integrates the 4-link chain there; here the chain lives in device
+// memory (state = pos[4] | vel[4] | mas[4] | factor) and one work-item advances it, so a thermostat
+// half-step is two launches and no host round trip.  Suzuki-Yoshida 7 x 4 (Tuckerman's weights).
+constexpr int kNhcLinks = 4;
+constexpr int kNhcStateSize = 3 * kNhcLinks + 1;
+constexpr double kBoltzmann = 8.617343e-5; // src/utilities/common.cuh:22
+
+struct NhcInitBody { // Ensemble_NHC::Ensemble_NHC, ensemble_nhc.cu:30-49
+  int64_t N;
+  double temperature, t_coup, dt;
+  double* st;
+  NEPMI_HD void operator()(int64_t i) const
+  {
+    if (i != 0)
+      return;
+    const double tau = dt * t_coup, kT = kBoltzmann * temperature;
+    for (int m = 0; m < kNhcLinks; ++m) {
+      st[m] = 0.0;
+      st[kNhcLinks + m] = (m & 1) ? -1.0 : 1.0;
+      st[2 * kNhcLinks + m] = kT * tau * tau;
+    }
+    st[2 * kNhcLinks] *= 3.0 * (double)N;
+    st[3 * kNhcLinks] = 1.0;
+  }
+};
+
+struct NhcChainBody { // nhc(), ensemble_nhc.cu:102-164, with Ek2 = T * 3N * k_B (ensemble_nhc.cu:189-191)
+  int64_t N;
+  double temperature, dt2_particle;
+  const double* thermo; // thermo[0] = instantaneous T (find_thermo)
+  double* st;
+  NEPMI_HD void operator()(int64_t i) const
+  {
+    if (i != 0)
+      return;
+    constexpr int M = kNhcLinks;
+    double pos[M], vel[M], mas[M];
+    for (int m = 0; m < M; ++m) {
+      pos[m] = st[m];
+      vel[m] = st[M + m];
+      mas[m] = st[2 * M + m];
+    }
+    const double kT = kBoltzmann * temperature, dN = 3.0 * (double)N;
+    double Ek2 = thermo[0] * dN * kBoltzmann;
+    const double w[7] = {0.784513610477560, 0.235573213359357, -1.17767998417887, 1.31518632068391,
+                         -1.17767998417887, 0.235573213359357, 0.784513610477560};
+    const int n_respa = 4;
+    double factor = 1.0;
+    for (int n1 = 0; n1 < 7; ++n1) {
+      const double dt2 = dt2_particle * w[n1] / n_respa, dt4 = dt2 * 0.5, dt8 = dt4 * 0.5;
+      for (int n2 = 0; n2 < n_respa; ++n2) {
+        double G = vel[M - 2] * vel[M - 2] / mas[M - 2] - kT;
+        vel[M - 1] += dt4 * G;
+        for (int m = M - 2; m >= 0; --m) {
+          const double tmp = exp(-dt8 * vel[m + 1] / mas[m + 1]);
+          G = m == 0 ? Ek2 - dN * kT : vel[m - 1] * vel[m - 1] / mas[m - 1] - kT;
+          vel[m] = tmp * (tmp * vel[m] + dt4 * G);
+        }
+        for (int m = M - 1; m >= 0; --m)
+          pos[m] += dt2 * vel[m] / mas[m];
+        const double fl = exp(-dt2 * vel[0] / mas[0]);
+        Ek2 *= fl * fl;
+        factor *= fl;
+        for (int m = 0; m < M - 1; ++m) {
+          const double tmp = exp(-dt8 * vel[m + 1] / mas[m + 1]);
+          G = m == 0 ? Ek2 - dN * kT : vel[m - 1] * vel[m - 1] / mas[m - 1] - kT;
+          vel[m] = tmp * (tmp * vel[m] + dt4 * G);
+        }
+        G = vel[M - 2] * vel[M - 2] / mas[M - 2] - kT;
+        vel[M - 1] += dt4 * G;
+      }
+    }
+    for (int m = 0; m < M; ++m) {
+      st[m] = pos[m];
+      st[M + m] = vel[m];
+    }
+    st[3 * M] = factor;
+  }
+};
+
+struct ScaleVelocityBody { // scale_velocity_global, ensemble.cu (gpu_scale_velocity)
+  int64_t N;
+  const double* factor;
+  double* vel;
+  NEPMI_HD void operator()(int64_t i) const
+  {
+    const double f = *factor;
+    vel[i] *= f;
+    vel[N + i] *= f;
+    vel[2 * N + i] *= f;
+  }
+};
+
 // ------------------------------------------------------------------------------------------------
 // neighbour rebuild (find_cell_list + gpu_find_neighbor_ON1, neighbor.cu:42-215)
 // ------------------------------------------------------------------------------------------------

@@ -101,9 +101,9 @@ void Run::parse_one_keyword(const std::vector<std::string>& p)
       input_error("ensemble should have at least 1 parameter.");
     if (p[1] == "nve") {
       std::printf("Use NVE ensemble for this run.\n");
-    } else if (p[1] == "nvt_ber") { // Integrate::parse_ensemble, integrate.cu:424-428, 569-600
+    } else if (p[1] == "nvt_ber" || p[1] == "nvt_nhc") { // Integrate::parse_ensemble, integrate.cu:424-432, 569-600
       if (p.size() != 5)
-        input_error("ensemble nvt_ber should have 3 parameters.");
+        input_error("ensemble " + p[1] + " should have 3 parameters.");
       temperature1 = std::atof(p[2].c_str());
       temperature2 = std::atof(p[3].c_str());
       temperature_coupling = std::atof(p[4].c_str());
@@ -111,10 +111,11 @@ void Run::parse_one_keyword(const std::vector<std::string>& p)
         input_error("Temperature should > 0.");
       if (temperature_coupling < 1.0)
         input_error("Temperature coupling should >= 1.");
-      std::printf("Use NVT ensemble for this run.\n    choose the Berendsen method.\n    initial temperature is %g K.\n"
-                  "    final temperature is %g K.\n    tau_T is %g time_step.\n", temperature1, temperature2, temperature_coupling);
+      std::printf("Use NVT ensemble for this run.\n    choose the %s method.\n    initial temperature is %g K.\n"
+                  "    final temperature is %g K.\n    tau_T is %g time_step.\n",
+                  p[1] == "nvt_ber" ? "Berendsen" : "Nose-Hoover chain", temperature1, temperature2, temperature_coupling);
     } else {
-      input_error("ensemble " + p[1] + " is not available in gpumd-mi yet (nve, nvt_ber; DESIGN.md section 8).");
+      input_error("ensemble " + p[1] + " is not available in gpumd-mi yet (nve, nvt_ber, nvt_nhc; DESIGN.md section 8).");
     }
     ensemble = p[1];
   } else if (k == "time_step") {
@@ -311,8 +312,20 @@ void Run::perform_a_run()
   force.compute(box, atom.position_per_atom, atom.type, atom.potential_per_atom, atom.force_per_atom, atom.virial_per_atom);
   hip_check(hipDeviceSynchronize(), "sync");
   const auto t0 = std::chrono::steady_clock::now();
+  // Ensemble_NHC: a fresh chain per run (integrate.cu:85-92), state in device memory
+  double* nhc_state = nullptr;
+  if (ensemble == "nvt_nhc") {
+    hip_check(hipMalloc((void**)&nhc_state, sizeof(double) * NEPMI_NHC_STATE_SIZE), "hipMalloc");
+    if (nepmi_nhc_init(e, N, temperature1, temperature_coupling, time_step, nhc_state) != NEPMI_OK)
+      input_error(nepmi_last_error());
+  }
   for (int step = 0; step < number_of_steps; ++step) {
     global_time += time_step;
+    const double target = temperature1 + (temperature2 - temperature1) * (double(step) / number_of_steps);
+    if (ensemble == "nvt_nhc") { // integrate_nvt_nhc_1, ensemble_nhc.cu:166-197
+      find_thermo();
+      nepmi_nhc_half_step(e, N, target, time_step, thermo.data(), nhc_state, atom.velocity_per_atom.data());
+    }
     // integrate.compute1: Ensemble_NVE::compute1 (ensemble_nve.cu:31-57)
     nepmi_vv_step1(e, N, time_step, atom.mass.data(), atom.force_per_atom.data(), atom.position_per_atom.data(),
                    atom.velocity_per_atom.data());
@@ -320,10 +333,10 @@ void Run::perform_a_run()
     // integrate.compute2 (ensemble_nve.cu:59-95)
     nepmi_vv_step2(e, N, time_step, atom.mass.data(), atom.force_per_atom.data(), atom.velocity_per_atom.data());
     find_thermo();
-    if (ensemble == "nvt_ber") { // Ensemble_BER::compute2, ensemble_ber.cu:195-235
-      const double target = temperature1 + (temperature2 - temperature1) * (double(step) / number_of_steps);
+    if (ensemble == "nvt_ber") // Ensemble_BER::compute2, ensemble_ber.cu:195-235
       nepmi_berendsen_scale(e, N, target, 1.0 / temperature_coupling, thermo.data(), atom.velocity_per_atom.data());
-    }
+    else if (ensemble == "nvt_nhc") // integrate_nvt_nhc_2, ensemble_nhc.cu:199-232
+      nepmi_nhc_half_step(e, N, target, time_step, thermo.data(), nhc_state, atom.velocity_per_atom.data());
     // measure.process
     dump_thermo(step);
     for (auto& d : dump_xyzs)
@@ -333,6 +346,8 @@ void Run::perform_a_run()
       std::printf("    %d steps completed.\n", step + 1);
   }
   hip_check(hipDeviceSynchronize(), "sync");
+  if (nhc_state)
+    (void)hipFree(nhc_state);
   const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   std::printf("Time used for this run = %g second.\n", sec);
   std::printf("Speed of this run = %g atom*step/second.\n", (double)N * number_of_steps / sec); // run.cu:325-326

@@ -35,7 +35,7 @@ private:
   bool has_velocity_in_xyz = false;
   bool gpu_allocated = false;
   std::string ensemble = "nve";
-  double temperature1 = 300.0, temperature2 = 300.0, temperature_coupling = 100.0; // nvt_ber
+  double temperature1 = 300.0, temperature2 = 300.0, temperature_coupling = 100.0; // nvt_ber, nvt_nhc
   double time_step = 1.0 / TIME_UNIT_CONVERSION;
   double global_time = 0.0;
   int number_of_steps = 0;

@@ -147,6 +147,25 @@ int nepmi_run_nvt_ber(
   const double* mass, double dt, int64_t nsteps, double t1, double t2, double t_coup, double* pos,
   double* vel, double* pe, double* force, double* virial, int64_t thermo_every, double* thermo_host);
 
+/* ---- Nose-Hoover chain thermostat: Ensemble_NHC (src/integrate/ensemble_nhc.cu:30-49 constructor,
+ *      :102-164 nhc(), :166-232 integrate_nvt_nhc_1/2), `ensemble nvt_nhc T1 T2 T_coup`.
+ *      chain_state: NEPMI_NHC_STATE_SIZE doubles of DEVICE memory owned by the caller
+ *      (pos_nhc1[4] | vel_nhc1[4] | mas_nhc1[4] | last scale factor).  The reference integrates the
+ *      chain on the host after copying the temperature back; here nepmi_nhc_half_step advances it on
+ *      the device from thermo8[0] (DEVICE, find_thermo) and rescales the velocities -- no host round
+ *      trip.  A step of the ensemble is: find_thermo, half_step, vv_step1, force, vv_step2,
+ *      find_thermo, half_step.  nepmi_run_nvt_nhc is the whole loop (fresh chain, T ramps T1 -> T2,
+ *      integrate.cu:341-344); thermo_host records the second find_thermo of each recorded step. ---- */
+#define NEPMI_NHC_STATE_SIZE 13
+int nepmi_nhc_init(nepmi_engine* e, int64_t n, double temperature, double t_coup, double dt, double* chain_state);
+int nepmi_nhc_half_step(
+  nepmi_engine* e, int64_t n, double temperature, double dt, const double* thermo8, double* chain_state,
+  double* vel);
+int nepmi_run_nvt_nhc(
+  nepmi_engine* e, const double h[9], const int pbc[3], int64_t n, const int* type,
+  const double* mass, double dt, int64_t nsteps, double t1, double t2, double t_coup, double* pos,
+  double* vel, double* pe, double* force, double* virial, int64_t thermo_every, double* thermo_host);
+
 /* ---- diagnostics / parity hooks ---- */
 
 /* Per-step radial (which = 0) / angular (which = 1) neighbour lists of the LAST compute, in the

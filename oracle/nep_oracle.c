@@ -489,6 +489,56 @@ void nepo_thermo(
   th[7] = nepo_tree_sum(n, virial + 5 * (size_t)n, vy, vz, mass, 2) / volume;
 }
 
+/* Nose-Hoover chain of 4 links: Ensemble_NHC constructor (ensemble_nhc.cu:30-49) and the host-side
+ * chain integrator nhc() (ensemble_nhc.cu:102-164): Suzuki-Yoshida weights (7) x 4 sub-steps.
+ * st = eta[4] | p_eta[4] | Q[4].  Returns the velocity scale factor. */
+void nepo_nhc_init(int n, double temperature, double t_coup, double dt, double* st)
+{
+  const double kB = 8.617343e-5;
+  const double tau = dt * t_coup;
+  for (int m = 0; m < 4; ++m) {
+    st[m] = 0.0;
+    st[4 + m] = (m % 2 == 0) ? 1.0 : -1.0;
+    st[8 + m] = kB * temperature * tau * tau;
+  }
+  st[8] *= 3.0 * n;
+}
+
+static double nhc_drive(const double* p, const double* Q, int m, double ek2, double dN, double kT)
+{
+  /* generalised force on link m: link 0 is driven by the particles' kinetic energy */
+  return m == 0 ? ek2 - dN * kT : p[m - 1] * p[m - 1] / Q[m - 1] - kT;
+}
+
+double nepo_nhc(double* st, double ek2, double kT, double dN, double dt2_particle)
+{
+  static const double w[7] = {0.784513610477560, 0.235573213359357, -1.17767998417887, 1.31518632068391,
+                              -1.17767998417887, 0.235573213359357, 0.784513610477560};
+  double *eta = st, *p = st + 4, *Q = st + 8;
+  double factor = 1.0;
+  for (int iw = 0; iw < 7; ++iw) {
+    const double h2 = dt2_particle * w[iw] / 4.0, h4 = 0.5 * h2, h8 = 0.5 * h4;
+    for (int sub = 0; sub < 4; ++sub) {
+      p[3] += h4 * nhc_drive(p, Q, 3, ek2, dN, kT);
+      for (int m = 2; m >= 0; --m) {
+        const double a = exp(-h8 * p[m + 1] / Q[m + 1]);
+        p[m] = a * (a * p[m] + h4 * nhc_drive(p, Q, m, ek2, dN, kT));
+      }
+      for (int m = 3; m >= 0; --m)
+        eta[m] += h2 * p[m] / Q[m];
+      const double s = exp(-h2 * p[0] / Q[0]);
+      ek2 *= s * s;
+      factor *= s;
+      for (int m = 0; m < 3; ++m) {
+        const double a = exp(-h8 * p[m + 1] / Q[m + 1]);
+        p[m] = a * (a * p[m] + h4 * nhc_drive(p, Q, m, ek2, dN, kT));
+      }
+      p[3] += h4 * nhc_drive(p, Q, 3, ek2, dN, kT);
+    }
+  }
+  return factor;
+}
+
 /* Run::perform_a_run, run.cu:250-318 restricted to ensemble nve (ensemble_nve.cu:31-95). */
 int nepo_run_nve(
   const nepo_model* m, int precision, int n, const int* type, const double h[9],

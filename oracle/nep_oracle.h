@@ -85,6 +85,10 @@ void nepo_velocity_verlet(
 
 /* gpu_find_thermo_instant_temperature (ensemble.cu:434-633): thermo[8] =
  * T, U, sxx, syy, szz, sxy, sxz, syz (stress = (virial + m v v)/V, eV/A^3). */
+/* Ensemble_NHC (ensemble_nhc.cu:30-49, 102-164): st = eta[4] | p_eta[4] | Q[4] */
+void nepo_nhc_init(int n, double temperature, double t_coup, double dt, double* st);
+double nepo_nhc(double* st, double ek2, double kT, double dN, double dt2_particle);
+
 void nepo_thermo(
   int n, double volume, const double* mass, const double* pe, const double* vel,
   const double* virial, double* thermo8);

@@ -138,6 +138,9 @@ def oracle_lib():
         L.nepo_apply_pbc.argtypes = [C.c_int, _dp, _ip, _dp]
         L.nepo_velocity_verlet.argtypes = [C.c_int, C.c_int, C.c_double, _dp, _dp, _dp, _dp]
         L.nepo_thermo.argtypes = [C.c_int, C.c_double, _dp, _dp, _dp, _dp, _dp]
+        L.nepo_nhc_init.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, _dp]
+        L.nepo_nhc.argtypes = [_dp, C.c_double, C.c_double, C.c_double, C.c_double]
+        L.nepo_nhc.restype = C.c_double
         L.nepo_run_nve.argtypes = [C.c_void_p, C.c_int, C.c_int, _ip, _dp, _ip, _dp, C.c_double,
                                    C.c_int, _dp, _dp, _dp, _dp, _dp, _dp]
         _oracle_lib = L

@@ -287,6 +287,75 @@ def check_nvt_berendsen(drv, nsteps=30):
     assert th[-1, 0] > th[0, 0]  # the thermostat heats the crystal towards the 600 K target
 
 
+def check_nvt_nhc(drv, nsteps=30):
+    """`ensemble nvt_nhc 300 500 50`: integrate_nvt_nhc_1/2 (ensemble_nhc.cu:166-232) with the chain
+    advanced on the device, against the same loop built from oracle pieces (host chain, nepo_nhc)."""
+    nep = H.golden("PbTe", "nep.txt")
+    h, typ, x = H.pbte_supercell((2, 2, 2), rattle=0.01, seed=52)
+    n = len(typ)
+    orc = H.Oracle(nep)
+    mass = np.array([H.MASS[orc.symbols[t]] for t in typ])
+    vel = H.maxwell_velocities(mass, 300.0, seed=7)
+    dt = 1.0 / H.TIME_UNIT
+    t1, t2, tc = 300.0, 500.0, 50.0
+    vol = abs(np.linalg.det(np.asarray(h).reshape(3, 3)))
+    L = H.oracle_lib()
+    xo, vo = x.copy(), vel.copy()
+    pe, f, w = orc.compute(typ, h, xo, precision=32, path=0)
+    st = np.zeros(12)
+    L.nepo_nhc_init(n, t1, tc, dt, H._p(st, H._dp))
+    th_ref, fac = [], []
+
+    def half(target):
+        th = H.oracle_thermo(vol, mass, pe, vo, w)
+        s = L.nepo_nhc(H._p(st, H._dp), th[0] * 3 * n * H.K_B, H.K_B * target, 3.0 * n, 0.5 * dt)
+        fac.append(s)
+        return th, s
+
+    for step in range(nsteps):
+        target = t1 + (t2 - t1) * (step / nsteps)
+        _, s = half(target)
+        vo *= s
+        L.nepo_velocity_verlet(1, n, dt, H._p(mass, H._dp), H._p(f, H._dp), H._p(xo, H._dp), H._p(vo, H._dp))
+        xo = H.oracle_apply_pbc(h, xo)
+        pe, f, w = orc.compute(typ, h, xo, precision=32, path=0)
+        L.nepo_velocity_verlet(0, n, dt, H._p(mass, H._dp), H._p(f, H._dp), H._p(xo, H._dp), H._p(vo, H._dp))
+        th, s = half(target)
+        th_ref.append(th)
+        vo *= s
+    th_ref = np.array(th_ref)
+    assert min(fac) < 1.0 < max(fac) or max(abs(np.array(fac) - 1.0)) > 1e-6  # the chain really acts
+
+    eng = drv.engine(drv.model(nep), n)
+    d_t, d_m, d_x, d_v = drv.dev(typ), drv.dev(mass), drv.dev(x), drv.dev(vel)
+    d_pe, d_f, d_w = drv.zeros(n), drv.zeros(3 * n), drv.zeros(9 * n)
+    eng.force_compute(h, d_t, d_x, d_pe, d_f, d_w)
+    th = eng.run_nvt_nhc(h, d_t, d_m, dt, nsteps, t1, t2, tc, d_x, d_v, d_pe, d_f, d_w, thermo_every=1)
+    np.testing.assert_allclose(th[:, 0], th_ref[:, 0], rtol=1e-6)
+    np.testing.assert_allclose(th[:, 1], th_ref[:, 1], rtol=1e-6)
+    assert np.abs(drv.host(d_v) - vo).max() < 1e-6
+
+    # the step-level entries give the same trajectory as the one-call loop
+    d_x, d_v = drv.dev(x), drv.dev(vel)
+    d_pe, d_f, d_w = drv.zeros(n), drv.zeros(3 * n), drv.zeros(9 * n)
+    eng2 = drv.engine(drv.model(nep), n)
+    eng2.force_compute(h, d_t, d_x, d_pe, d_f, d_w)
+    d_st, d_th = drv.zeros(eng2.NHC_STATE_SIZE), drv.zeros(8)
+    eng2.nhc_init(t1, tc, dt, d_st)
+    for step in range(nsteps):
+        target = t1 + (t2 - t1) * (step / nsteps)
+        eng2.find_thermo(vol, d_m, d_pe, d_v, d_w, d_th)
+        eng2.nhc_half_step(target, dt, d_th, d_st, d_v)
+        eng2.vv_step1(dt, d_m, d_f, d_x, d_v)
+        eng2.force_compute(h, d_t, d_x, d_pe, d_f, d_w)
+        eng2.vv_step2(dt, d_m, d_f, d_v)
+        eng2.find_thermo(vol, d_m, d_pe, d_v, d_w, d_th)
+        eng2.nhc_half_step(target, dt, d_th, d_st, d_v)
+    np.testing.assert_allclose(drv.host(d_th)[0], th[-1, 0], rtol=1e-9)
+    chain = drv.host(d_st)
+    np.testing.assert_allclose(chain[:12], st, rtol=5e-5, atol=1e-9)  # f32 force noise feeds the chain
+
+
 def check_error_paths(drv):
     import pytest
     from gpumd_amd import NepmiError

@@ -49,6 +49,10 @@ def test_nvt_berendsen(drv):
     P.check_nvt_berendsen(drv)
 
 
+def test_nvt_nose_hoover_chain(drv):
+    P.check_nvt_nhc(drv)
+
+
 def test_small_box_branch(drv):
     P.check_small_box(drv)
 

@@ -38,7 +38,8 @@ def test_check_input_parses_run_in_and_model(tmp_path):
 
 
 @pytest.mark.parametrize("bad,msg", [("potential NEP\nfoo 1\nrun 1\n", "invalid keyword"),
-                                     ("potential NEP\nensemble nvt_nhc 300 300 100\nrun 1\n", "not available"),
+                                     ("potential NEP\nensemble nvt_bdp 300 300 100\nrun 1\n", "not available"),
+                                     ("potential NEP\nensemble nvt_nhc 300 300 0.5\nrun 1\n", "coupling should >= 1"),
                                      ("velocity 300\nrun 1\n", "no 'potential'")])
 def test_input_errors_exit_like_the_reference(tmp_path, bad, msg):
     wd = _workdir(tmp_path, bad)
@@ -99,3 +100,17 @@ def test_nve_run_writes_thermo(tmp_path):
     assert np.abs(etot - etot[0]).max() < 2e-3 * 2000  # test_md_conservation.py bound
     assert 50.0 < th[-1, 0] < 1000.0  # the 250-atom cell is a thermalised snapshot, not a perfect lattice
     assert os.path.exists(os.path.join(wd, "restart.xyz")) and os.path.exists(os.path.join(wd, "neighbor.out"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ens", ["nvt_ber 300 600 20", "nvt_nhc 300 600 50"])
+def test_nvt_run_heats_towards_the_target(tmp_path, ens):
+    """`ensemble nvt_ber|nvt_nhc T1 T2 Tc` through gpumd-mi: the temperature follows the ramp."""
+    wd = _workdir(tmp_path, "replicate 2 2 2\npotential NEP\nvelocity 300 seed 42\nensemble %s\ntime_step 1\n"
+                            "dump_thermo 50\nrun 1000\n" % ens)
+    out = subprocess.run([EXE], cwd=wd, capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    th = np.loadtxt(os.path.join(wd, "thermo.out"))
+    assert th.shape == (20, 18)
+    assert th[-4:, 0].mean() > th[:4, 0].mean() + 100.0
+    assert 400.0 < th[-4:, 0].mean() < 750.0
