@@ -30,6 +30,12 @@ COPIES = {
     "potentials/nep/Song-2024-UNEP-v1-AgAlAuCrCuMgMoNiPbPdPtTaTiVWZr.txt": "UNEP/nep.txt",
     "tests_pytest/fixtures/models/nep_water.txt": "water/nep.txt",
     "potentials/tersoff/Si_Tersoff_1989.txt": "Si/Si_Tersoff_1989.txt",
+    # the remaining shipped NEP models: silicon with 3-, 4- and 5-body descriptors (l_max 4 0 0 / 4 2 0 /
+    # 4 2 1) and the long-range carbon model (rc 7/4, MN 358/71)
+    "potentials/nep/Si_2022_NEP4_3body.txt": "Si/nep_3body.txt",
+    "potentials/nep/Si_2022_NEP4_4body.txt": "Si/nep_4body.txt",
+    "potentials/nep/Si_2022_NEP4_5body.txt": "Si/nep_5body.txt",
+    "potentials/nep/C_2024_NEP4.txt": "C/nep_2024.txt",
 }
 
 

@@ -25,6 +25,11 @@ MODELS = {
     "UNEP-v1": ("UNEP/nep.txt", lambda: H.fcc_alloy((5, 5, 6), 3.9, 16), 16),
     "BaZrO3": ("BaZrO3/nep.txt", lambda: H.pbte_supercell((2, 2, 2), num_types=3, seed=4), 3),
     "water-model": ("water/nep.txt", lambda: H.pbte_supercell((2, 2, 2), num_types=2, seed=5), 2),
+    # the other shipped potentials/nep models: 3-/4-/5-body silicon, long-range carbon (rc 7/4, 16 radial basis)
+    "Si-3body": ("Si/nep_3body.txt", lambda: H.diamond((4, 4, 4), 5.43, seed=21), 1),
+    "Si-4body": ("Si/nep_4body.txt", lambda: H.diamond((4, 4, 5), 5.43, seed=22), 1),
+    "Si-5body": ("Si/nep_5body.txt", lambda: H.diamond((4, 5, 4), 5.43, seed=23), 1),
+    "C-2024": ("C/nep_2024.txt", lambda: H.diamond((6, 6, 6), 3.57, seed=24), 1),
 }
 
 

