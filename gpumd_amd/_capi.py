@@ -45,6 +45,8 @@ SYMBOLS = {
     "nepmi_force_compute": (C.c_int, [VP, c_dp, c_ip, c_i64, VP, VP, VP, VP, VP]),
     "nepmi_potential_compute": (C.c_int, [VP, c_dp, c_ip, c_i64, VP, VP, VP, VP, VP]),
     "nepmi_potential_compute_levels": (C.c_int, [VP, c_dp, c_ip, c_i64, VP, VP, VP, VP, VP, VP]),
+    "nepmi_potential_compute_levels_begin": (C.c_int, [VP, c_dp, c_ip, c_i64, VP, VP, VP, VP, VP, VP]),
+    "nepmi_potential_compute_levels_end": (C.c_int, [VP, c_dp, c_ip, c_i64, VP, VP, VP, VP, VP, VP]),
     "nepmi_engine_invalidate": (C.c_int, [VP]),
     "nepmi_apply_pbc": (C.c_int, [VP, c_dp, c_ip, c_i64, VP]),
     "nepmi_zero_properties": (C.c_int, [VP, c_i64, VP, VP, VP]),

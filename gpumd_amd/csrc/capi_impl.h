@@ -157,6 +157,26 @@ int nepmi_potential_compute_levels(
   return guarded([&] { e->e->potential_compute_levels(h, pbc, n, type, pos, level, pe, force, virial); });
 }
 
+int nepmi_potential_compute_levels_begin(
+  nepmi_engine* e, const double h[9], const int pbc[3], int64_t n, const int* type, const double* pos,
+  const signed char* level, double* pe, double* force, double* virial)
+{
+  if (!e)
+    return fail(NEPMI_ERR_ARG, "null engine");
+  bool started = false;
+  const int st = guarded([&] { started = e->e->potential_compute_levels_begin(h, pbc, n, type, pos, level, pe, force, virial); });
+  return st != NEPMI_OK ? st : (started ? 1 : 0);
+}
+
+int nepmi_potential_compute_levels_end(
+  nepmi_engine* e, const double h[9], const int pbc[3], int64_t n, const int* type, const double* pos,
+  const signed char* level, double* pe, double* force, double* virial)
+{
+  if (!e)
+    return fail(NEPMI_ERR_ARG, "null engine");
+  return guarded([&] { e->e->potential_compute_levels_end(h, pbc, n, type, pos, level, pe, force, virial); });
+}
+
 int nepmi_engine_invalidate(nepmi_engine* e)
 {
   if (!e)

@@ -293,9 +293,10 @@ __global__ void __launch_bounds__(256) nepmi_tile_kernel(const Body body, const 
   extern __shared__ __attribute__((aligned(16))) char nepmi_tile_lds[];
   NEPMI_LDS(char)* lds = (NEPMI_LDS(char)*)nepmi_tile_lds;
   const unsigned per_xcd = gridDim.x >> 3;
-  const int64_t brick = (int64_t)(blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
-  if (brick >= nbricks)
+  const int64_t wg = (int64_t)(blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+  if (wg >= nbricks)
     return; // the whole workgroup leaves before the first barrier
+  const int64_t brick = body.map_brick(wg);
   const int tid = (int)threadIdx.x;
   body.stage_cells(brick, lds, tid, 256);
   __syncthreads();

@@ -100,6 +100,7 @@ public:
   const Bufs& bufs() const { return b_; }
   int64_t num_atoms() const { return N_; }
   int64_t num_compute = 0, num_rebuild = 0;
+  enum Phase { kPhaseAll = 0, kPhaseInterior = 1, kPhaseBoundary = 2 };
 
   // Potential::compute (adds to pe/force/virial; positions already wrapped)
   void potential_compute(
@@ -117,6 +118,7 @@ public:
     const double h9[9], const int pbc[3], int64_t n, const int* type, const double* pos,
     const signed char* level, double* pe, double* force, double* virial)
   {
+    split_pending_ = false;
     if (n < 1 || n > cap_)
       throw EngineError{-4, "number of atoms exceeds the engine's capacity"};
     BoxD box;
@@ -136,18 +138,12 @@ public:
       return;
     }
     last_small_ = false;
-    if (have_list_) {
-      for (int k = 0; k < 9; ++k)
-        if (box.h[k] != box_.h[k])
-          need_rebuild = true;
-      for (int d = 0; d < 3; ++d)
-        if (box.pbc[d] != box_.pbc[d])
-          need_rebuild = true;
-    }
+    if (have_list_ && !same_box(box))
+      need_rebuild = true;
     box_ = box;
     if (!need_rebuild) {
       be_.memset(b_.flags + kFlagMoved, 0, sizeof(int));
-      CheckGatherBody cg{box_, b_, pos};
+      CheckGatherBody cg{box_, b_, pos, 0};
       be_.template launch<128>(kSlotGather, N_, cg);
       int flags[kNumFlags];
       be_.d2h(flags, b_.flags, sizeof(flags));
@@ -157,8 +153,76 @@ public:
     }
     if (need_rebuild)
       rebuild(type, pos);
-    force_kernels(pe, force, virial);
+    force_kernels(pe, force, virial, kPhaseAll);
     ++num_compute;
+  }
+
+  // Split form for a domain-decomposed host that overlaps its ghost exchange with compute:
+  //   begin: positions of the OWNED atoms are final, ghost entries of `pos` may still be in flight
+  //          (they are not read): skin check + gather of the owned atoms and the radial pass of the
+  //          interior bricks (no ghost in the brick's window) are enqueued.  Returns false when
+  //          nothing could be started (no valid list / geometry changed / no LDS-window pass);
+  //   end:   all of `pos` is final: ghosts are gathered and checked, then the boundary bricks and
+  //          the rest of the force path run.  If the skin check asks for a rebuild the interior
+  //          work is discarded and everything is redone on the new list.
+  bool potential_compute_levels_begin(
+    const double h9[9], const int pbc[3], int64_t n, const int* type, const double* pos,
+    const signed char* level, double* pe, double* force, double* virial)
+  {
+    (void)type;
+    (void)pe;
+    (void)force;
+    (void)virial;
+    split_pending_ = false;
+    if (n < 1 || n > cap_)
+      throw EngineError{-4, "number of atoms exceeds the engine's capacity"};
+    BoxD box;
+    box_from_h9(h9, pbc, box);
+    if (!have_list_ || n != N_ || model_.kind != 0 || !tile_ok_ || is_small_box(box) || !same_box(box) ||
+        level != b_.level)
+      return false;
+    be_.memset(b_.flags + kFlagMoved, 0, sizeof(int));
+    CheckGatherBody cg{box_, b_, pos, 1};
+    be_.template launch<128>(kSlotGather, N_, cg);
+    force_kernels(nullptr, nullptr, nullptr, kPhaseInterior);
+    split_pending_ = true;
+    return true;
+  }
+
+  void potential_compute_levels_end(
+    const double h9[9], const int pbc[3], int64_t n, const int* type, const double* pos,
+    const signed char* level, double* pe, double* force, double* virial)
+  {
+    if (!split_pending_) {
+      potential_compute_levels(h9, pbc, n, type, pos, level, pe, force, virial);
+      return;
+    }
+    split_pending_ = false;
+    if (n != N_)
+      throw EngineError{-4, "compute_levels_end: atom count differs from compute_levels_begin"};
+    CheckGatherBody cg{box_, b_, pos, 2};
+    be_.template launch<128>(kSlotGather, N_, cg);
+    int flags[kNumFlags];
+    be_.d2h(flags, b_.flags, sizeof(flags));
+    check_overflow(flags);
+    if (flags[kFlagMoved]) {
+      rebuild(type, pos);
+      force_kernels(pe, force, virial, kPhaseAll);
+    } else {
+      force_kernels(pe, force, virial, kPhaseBoundary);
+    }
+    ++num_compute;
+  }
+
+  bool same_box(const BoxD& box) const
+  {
+    for (int k = 0; k < 9; ++k)
+      if (box.h[k] != box_.h[k])
+        return false;
+    for (int d = 0; d < 3; ++d)
+      if (box.pbc[d] != box_.pbc[d])
+        return false;
+    return true;
   }
 
   void apply_pbc(const double h9[9], const int pbc[3], int64_t n, double* pos)
@@ -612,6 +676,9 @@ private:
       // grow-only (cell arrays are small next to the lists)
       b_.cell_count = dalloc<int>(ncell + 1);
       b_.cell_fill = dalloc<int>(ncell);
+      b_.cell_ghost = dalloc<int>(ncell);
+      b_.brick_flag = dalloc<int>(ncell / 64 + 2);
+      b_.brick_order = dalloc<int>(ncell / 64 + 1);
       scan_scratch_ = dalloc<int>(ncell / 1024 + 1024);
       ncell_cap_ = ncell;
     }
@@ -624,6 +691,7 @@ private:
     b_.rc_inv_cell = 2.0 / rc_list;
     be_.memset(b_.cell_count, 0, sizeof(int) * (ncell + 1));
     be_.memset(b_.cell_fill, 0, sizeof(int) * ncell);
+    be_.memset(b_.cell_ghost, 0, sizeof(int) * ncell);
     be_.memset(b_.flags + kFlagMaxSkin, 0, 2 * sizeof(int));
     be_.begin_region(kRegionRebuild);
     be_.template launch<256>(kSlotMisc, N_, BinAtomsBody{box_, b_, pos});
@@ -642,11 +710,17 @@ private:
     be_.template launch<128>(kSlotMisc, N_, ReverseSlotsBody{b_});
     be_.memset(b_.flags + kFlagMaxWindow, 0, 3 * sizeof(int));
     num_bricks_ = (int64_t)gb[0] * gb[1] * gb[2];
+    if (b_.level)
+      be_.template launch<256>(kSlotMisc, N_, MarkGhostCellsBody{b_});
     be_.template launch<64>(kSlotMisc, num_bricks_, TileStatsBody{box_, b_});
+    be_.memset(b_.brick_flag + num_bricks_, 0, sizeof(int));
+    be_.exclusive_scan(b_.brick_flag, num_bricks_ + 1, scan_scratch_);
+    be_.template launch<64>(kSlotMisc, num_bricks_, BrickOrderBody{b_, num_bricks_});
     be_.end_region(kRegionRebuild);
     int flags[kNumFlags];
     be_.d2h(flags, b_.flags, sizeof(flags));
     check_overflow(flags);
+    num_boundary_bricks_ = flags[kFlagNumBoundary];
     // LDS-window radial pass: unique window cells (>= 8 cells per periodic direction), 7-bit rank
     // in cell, window fits the LDS budget
     tile_ok_ = use_tiles_ && model_.kind == 0 && flags[kFlagMaxCell] <= 127 && flags[kFlagMaxWindow] <= 5000;
@@ -705,11 +779,18 @@ public:
 
 private:
   template <class S>
-  void force_kernels_shape(double* pe, double* force, double* virial)
+  void force_kernels_shape(double* pe, double* force, double* virial, int phase)
   {
+    if (phase == kPhaseInterior) { // radial pass of the bricks whose window holds no ghost
+      be_.launch_tile(kSlotRadial, num_bricks_ - num_boundary_bricks_, RadialTileBody<S>{box_, md_, b_, tile_, 0});
+      return;
+    }
     be_.begin_region(kRegionForce);
-    if (tile_ok_)
-      be_.launch_tile(kSlotRadial, num_bricks_, RadialTileBody<S>{box_, md_, b_, tile_});
+    if (phase == kPhaseBoundary)
+      be_.launch_tile(kSlotRadial, num_boundary_bricks_,
+                      RadialTileBody<S>{box_, md_, b_, tile_, (int)(num_bricks_ - num_boundary_bricks_)});
+    else if (tile_ok_)
+      be_.launch_tile(kSlotRadial, num_bricks_, RadialTileBody<S>{box_, md_, b_, tile_, -1});
     else
       be_.template launch<64>(kSlotRadial, N_, RadialDescBody<S>{box_, md_, b_});
     be_.template launch_lds<64>(kSlotAngular, N_, AngularDescBody<S>{md_, b_});
@@ -719,7 +800,7 @@ private:
     be_.end_region(kRegionForce);
   }
 
-  void force_kernels(double* pe, double* force, double* virial)
+  void force_kernels(double* pe, double* force, double* virial, int phase)
   {
     if (model_.kind == 1) { // Tersoff1989::compute, tersoff1989.cu:508-586
       be_.begin_region(kRegionForce);
@@ -729,12 +810,12 @@ private:
       return;
     }
     switch (shape_) {
-      case 1: force_kernels_shape<S_PbTeA>(pe, force, virial); break;
-      case 2: force_kernels_shape<S_PbTeB>(pe, force, virial); break;
-      case 3: force_kernels_shape<S_C2022>(pe, force, virial); break;
-      case 4: force_kernels_shape<S_UNEP>(pe, force, virial); break;
-      case 5: force_kernels_shape<S_BZO>(pe, force, virial); break;
-      default: force_kernels_shape<ShapeGeneric>(pe, force, virial); break;
+      case 1: force_kernels_shape<S_PbTeA>(pe, force, virial, phase); break;
+      case 2: force_kernels_shape<S_PbTeB>(pe, force, virial, phase); break;
+      case 3: force_kernels_shape<S_C2022>(pe, force, virial, phase); break;
+      case 4: force_kernels_shape<S_UNEP>(pe, force, virial, phase); break;
+      case 5: force_kernels_shape<S_BZO>(pe, force, virial, phase); break;
+      default: force_kernels_shape<ShapeGeneric>(pe, force, virial, phase); break;
     }
   }
 
@@ -747,6 +828,8 @@ private:
   BoxD box_;
   TileLayout tile_{0};
   bool tile_ok_ = false, use_tiles_ = true;
+  bool split_pending_ = false;   // compute_levels_begin ran, compute_levels_end has not yet
+  int64_t num_boundary_bricks_ = 0;
   int64_t num_bricks_ = 0;
   TersoffBufs tb_{};
   TersoffParamsD tp_{};

@@ -54,7 +54,7 @@ using ShapeGeneric = Shape<-1, -1, -1, -1, -1, 0>;
 
 enum FlagSlot {
   kFlagMoved = 0, kFlagOverflow = 1, kFlagMaxSkin = 2, kFlagMaxAng = 3,
-  kFlagMaxWindow = 4, kFlagMaxBrick = 5, kFlagMaxCell = 6, kNumFlags = 8
+  kFlagMaxWindow = 4, kFlagMaxBrick = 5, kFlagMaxCell = 6, kFlagNumBoundary = 7, kNumFlags = 8
 };
 
 struct Bufs {
@@ -67,6 +67,9 @@ struct Bufs {
   float rc_askin_sq;    // (rc_a_max+skin)^2
   int* cell_count;      // [ncell+1] -> exclusive scan in place = cell_start
   int* cell_fill;       // [ncell]
+  int* cell_ghost;      // [ncell] 1: the cell holds an atom that is not owned (level < 2)
+  int* brick_flag;      // [nbricks+1] 1: a ghost sits in the brick's 8x8x8-cell window; scanned in place
+  int* brick_order;     // [nbricks] interior bricks first (ascending), then boundary bricks
   int* cid;             // [N] caller order
   int* perm;            // [N] internal k -> caller index
   PosQ* posq;           // [N]
@@ -528,7 +531,7 @@ struct TileStatsBody {
   {
     const int bx = (int)(brick % b.gbx), by = (int)((brick / b.gbx) % b.gby), bz = (int)(brick / ((int64_t)b.gbx * b.gby));
     const int nbr = b.cell_count[brick * 64 + 64] - b.cell_count[brick * 64];
-    int win = 0, mxc = 0;
+    int win = 0, mxc = 0, ghost = 0;
     for (int wz = 0; wz < 8; ++wz)
       for (int wy = 0; wy < 8; ++wy)
         for (int wx = 0; wx < 8; ++wx) {
@@ -543,23 +546,56 @@ struct TileStatsBody {
           const int cnt = b.cell_count[c + 1] - b.cell_count[c];
           win += cnt;
           mxc = cnt > mxc ? cnt : mxc;
+          ghost |= b.cell_ghost[c];
         }
+    b.brick_flag[brick] = ghost;
     NEPMI_ATOMIC_MAX(&b.flags[kFlagMaxWindow], win);
     NEPMI_ATOMIC_MAX(&b.flags[kFlagMaxBrick], nbr);
     NEPMI_ATOMIC_MAX(&b.flags[kFlagMaxCell], mxc);
   }
 };
 
+// Domain decomposition: cells that hold ghosts, and (after the in-place scan of brick_flag) the
+// brick order "interior first": a brick is interior when no ghost sits in its window, i.e. its
+// radial pass can run while the ghost positions of this step are still in flight.
+struct MarkGhostCellsBody {
+  Bufs b;
+  NEPMI_HD void operator()(int64_t k) const
+  {
+    if (b.lvl[k] < 2)
+      b.cell_ghost[b.cid[b.perm[k]]] = 1; // benign race: all writers store 1
+  }
+};
+struct BrickOrderBody {
+  Bufs b;
+  int64_t nbricks;
+  NEPMI_HD void operator()(int64_t brick) const
+  {
+    const int before = b.brick_flag[brick]; // boundary bricks with a smaller index
+    const int nbound = b.brick_flag[nbricks];
+    const bool boundary = b.brick_flag[brick + 1] != before;
+    if (boundary)
+      b.brick_order[(nbricks - nbound) + before] = (int)brick;
+    else
+      b.brick_order[brick - before] = (int)brick;
+    if (brick == 0)
+      b.flags[kFlagNumBoundary] = nbound;
+  }
+};
+
 // gpu_check_atom_distance (neighbor.cu:646-684) fused with the per-step gather of the caller's
-// positions into internal order.
+// positions into internal order.  which: 0 all atoms, 1 owned only (level 2), 2 ghosts only.
 struct CheckGatherBody {
   BoxD box;
   Bufs b;
   const double* pos;
+  int which;
   NEPMI_HD void operator()(int64_t k) const
   {
 #pragma clang fp contract(off) // d2 with separate roundings, as the oracle's skin check
     const int64_t N = b.N;
+    if (which != 0 && (b.lvl[k] >= 2) != (which == 1))
+      return;
     const int64_t i = b.perm[k];
     const double x = pos[i], y = pos[N + i], z = pos[2 * N + i];
     float dx = (float)(x - b.x0s[k]);
@@ -967,8 +1003,10 @@ struct RadialTileBody {
   ModelD m;
   Bufs b;
   TileLayout lay;
+  int first; // workgroup w runs brick_order[first + w] (first < 0: brick w)
 
   NEPMI_HD int lds_bytes() const { return lay.bytes(); }
+  NEPMI_HD int64_t map_brick(int64_t w) const { return first < 0 ? w : (int64_t)b.brick_order[first + w]; }
 
   // phase 1 (all threads): count and first atom of each of the 512 window cells
   template <class LC>

@@ -20,6 +20,8 @@ ownership:
 The force call on the local (owned + ghost) system is nepmi_potential_compute_levels of the C ABI.
 Everything here is device-agnostic torch code; the engine is injected.
 """
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -46,13 +48,19 @@ def choose_grid(world):
 
 
 class DomainMD:
-    def __init__(self, make_engine, rc, h9, pbc, grid, rank, world, device, group=None, stage_through_host=False):
+    def __init__(self, make_engine, rc, h9, pbc, grid, rank, world, device, group=None, stage_through_host=False,
+                 overlap=None):
         """make_engine(capacity) -> gpumd_amd.NEP-like object.  h9: global Box::cpu_h[0..8].
         stage_through_host: move message payloads through host memory (only for running several
         ranks over gloo with device-resident state, e.g. two ranks sharing the one GPU of a test
         box); on a real node the payloads stay in HBM and travel over RCCL/xGMI."""
         self.make_engine = make_engine
         self.stage = bool(stage_through_host)
+        # overlap the per-step ghost exchange with the interior radial pass (engine compute_levels_begin/_end);
+        # NEPMI_OVERLAP=0 selects the plain exchange-then-compute order
+        self.overlap = (os.environ.get("NEPMI_OVERLAP", "1") != "0") if overlap is None else bool(overlap)
+        self.side = None
+        self.num_overlapped = 0
         self.rc = float(rc)
         self.dev = device
         self.rank, self.world, self.group = rank, world, group
@@ -257,6 +265,7 @@ class DomainMD:
         self.f_loc = torch.zeros((3, n), dtype=torch.float64, device=self.dev)
         self.w_loc = torch.zeros((9, n), dtype=torch.float64, device=self.dev)
         self.f_own = torch.zeros((3, n_own), dtype=torch.float64, device=self.dev)
+        self.x_eng = torch.zeros((3, n), dtype=torch.float64, device=self.dev)
         self.num_decompositions += 1
 
     # ---------------------------------------------------------------------------------------
@@ -283,6 +292,41 @@ class DomainMD:
                                    self.pe_loc, self.f_loc, self.w_loc)
         self.f_own.copy_(self.f_loc[:, : self.n_own])
 
+    def halo_and_forces_overlapped(self):
+        """halo_update + compute_forces with the exchange hidden behind the interior bricks' radial pass:
+        the exchange runs on a side stream (its RCCL send/recv are ordered against that stream only),
+        the engine's first half on the main stream touches owned atoms only, the second half waits
+        for the exchange.  On the CPU tier there are no streams: the first half simply runs BEFORE the
+        exchange, which proves it does not depend on this step's ghost positions."""
+        n_own, e = self.n_own, self.engine
+        self.x_eng[:, :n_own] = self.x - self.origin[:, None]
+        self.pe_loc.zero_()
+        self.f_loc.zero_()
+        self.w_loc.zero_()
+        args = (self.h_loc, self.pbc_loc, self.n_loc, self.t_loc, self.x_eng, self.level, self.pe_loc, self.f_loc,
+                self.w_loc)
+        if self.dev.type == "cuda":
+            if self.side is None:
+                self.side = torch.cuda.Stream(device=self.dev)
+            main = torch.cuda.current_stream(self.dev)
+            ready = torch.cuda.Event()
+            ready.record(main)                      # owned positions (vv1) are final
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(ready)
+                self.halo_update()
+                self.x_eng[:, n_own:] = self.x_loc[:, n_own:] - self.origin[:, None]
+                done = torch.cuda.Event()
+                done.record(self.side)
+            started = e.compute_levels_begin(*args)
+            main.wait_event(done)
+        else:
+            started = e.compute_levels_begin(*args)
+            self.halo_update()
+            self.x_eng[:, n_own:] = self.x_loc[:, n_own:] - self.origin[:, None]
+        e.compute_levels_end(*args)
+        self.num_overlapped += 1 if started else 0
+        self.f_own.copy_(self.f_loc[:, :n_own])
+
     def needs_decomposition(self):
         d = self.x - self.x_ref
         flag = ((d * d).sum(0).max() > 0.25 * SKIN * SKIN).to(torch.int32).reshape(1)
@@ -301,9 +345,12 @@ class DomainMD:
                              e._ptr(self.x), e._ptr(self.v))
         if self.needs_decomposition():
             self.decompose()
+            self.compute_forces()
+        elif self.overlap:
+            self.halo_and_forces_overlapped()
         else:
             self.halo_update()
-        self.compute_forces()
+            self.compute_forces()
         e = self.engine
         e.lib.nepmi_vv_step2(e.handle, self.n_own, float(dt), e._ptr(self.mass), e._ptr(self.f_own), e._ptr(self.v))
 

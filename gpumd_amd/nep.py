@@ -111,6 +111,21 @@ class NEP:
             self.handle, hp, pp, int(n), self._ptr(type), self._ptr(position), self._ptr(level),
             self._ptr(potential), self._ptr(force), self._ptr(virial)))
 
+    def compute_levels_begin(self, box, pbc, n, type, position, level, potential, force, virial):
+        """First half (owned atoms final, ghosts in flight) -> True if interior work was enqueued."""
+        _, hp = _h9(box)
+        _, pp = _pbc3(pbc)
+        return self._ck(self.lib.nepmi_potential_compute_levels_begin(
+            self.handle, hp, pp, int(n), self._ptr(type), self._ptr(position), self._ptr(level),
+            self._ptr(potential), self._ptr(force), self._ptr(virial))) == 1
+
+    def compute_levels_end(self, box, pbc, n, type, position, level, potential, force, virial):
+        _, hp = _h9(box)
+        _, pp = _pbc3(pbc)
+        self._ck(self.lib.nepmi_potential_compute_levels_end(
+            self.handle, hp, pp, int(n), self._ptr(type), self._ptr(position), self._ptr(level),
+            self._ptr(potential), self._ptr(force), self._ptr(virial)))
+
     def invalidate(self):
         self._ck(self.lib.nepmi_engine_invalidate(self.handle))
 

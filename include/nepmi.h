@@ -106,6 +106,23 @@ int nepmi_potential_compute_levels(
   nepmi_engine* e, const double h[9], const int pbc[3], int64_t n, const int* type,
   const double* pos, const signed char* level, double* pe, double* force, double* virial);
 int nepmi_engine_invalidate(nepmi_engine* e);
+/* The same call in two halves, so that a domain-decomposed host can overlap its ghost-position
+ * exchange (the RCCL send/recv that replaces NEP_MULTIGPU's staged copies) with compute:
+ *   _begin: the OWNED (level 2) entries of pos are final; ghost entries may still be in flight and
+ *           are not read.  Enqueues the skin check + gather of the owned atoms and the radial pass
+ *           of the interior bricks (those whose 8x8x8-cell window holds no ghost).  Returns 1 if
+ *           work was started, 0 if not (no valid list yet, geometry changed, LDS-window pass not
+ *           applicable): _end then does everything.
+ *   _end:   every entry of pos is final (the caller has made the engine's stream wait for its
+ *           exchange).  Ghosts are gathered and checked, then the boundary bricks and the rest of
+ *           the force path run; if the skin check asks for a rebuild the interior work is redone
+ *           on the new list.  Results are identical to nepmi_potential_compute_levels. */
+int nepmi_potential_compute_levels_begin(
+  nepmi_engine* e, const double h[9], const int pbc[3], int64_t n, const int* type,
+  const double* pos, const signed char* level, double* pe, double* force, double* virial);
+int nepmi_potential_compute_levels_end(
+  nepmi_engine* e, const double h[9], const int pbc[3], int64_t n, const int* type,
+  const double* pos, const signed char* level, double* pe, double* force, double* virial);
 
 /* gpu_apply_pbc (force.cu:424-459) and initialize_properties (force.cu:314-333) on their own. */
 int nepmi_apply_pbc(nepmi_engine* e, const double h[9], const int pbc[3], int64_t n, double* pos);

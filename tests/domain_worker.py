@@ -46,7 +46,7 @@ def main():
     i1, x1, v1, f1 = md.gather_owned()
     th1 = md.thermo()
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), i0=i0, f0=f0, th0=th0, i1=i1, x1=x1, v1=v1, f1=f1, th1=th1,
-             n_loc=md.n_loc, n_own=md.n_own, ndec=md.num_decompositions)
+             n_loc=md.n_loc, n_own=md.n_own, ndec=md.num_decompositions, nover=md.num_overlapped)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -54,7 +54,8 @@ struct HostLoopBackend {
   {
     std::vector<double> raw((size_t)body.lds_bytes() / 8 + 8);
     char* lds = reinterpret_cast<char*>(raw.data());
-    for (int64_t brick = 0; brick < nbricks; ++brick) {
+    for (int64_t wg = 0; wg < nbricks; ++wg) {
+      const int64_t brick = body.map_brick(wg);
       body.stage_cells(brick, lds, 0, 1);
       int* woff = reinterpret_cast<int*>(lds);
       int run = 0;

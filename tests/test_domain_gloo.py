@@ -20,13 +20,13 @@ def _free_port():
     return p
 
 
-def _run_ranks(world, reps, grid, nsteps, temp, device="cpu"):
+def _run_ranks(world, reps, grid, nsteps, temp, device="cpu", overlap=True):
     out = tempfile.mkdtemp(prefix="nepmi_dom_")
     port = _free_port()
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   OMP_NUM_THREADS="1")
+                   OMP_NUM_THREADS="1", NEPMI_OVERLAP="1" if overlap else "0")
         procs.append(subprocess.Popen([sys.executable, os.path.join(H.ROOT, "tests", "domain_worker.py"), out,
                                        repr(reps), repr(grid), str(nsteps), str(temp), device], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
@@ -47,6 +47,18 @@ def test_decomposed_run_on_gpu_kernels(world, reps, grid):
     """The same decomposition with the product library: ranks share the box's single GPU, payloads
     staged through the host over gloo (what is NOT covered here is only the RCCL transport)."""
     _check_decomposed(world, reps, grid, "gpu")
+
+
+def test_overlapped_exchange_is_bit_identical_to_the_plain_order():
+    """compute_levels_begin (interior bricks, BEFORE this step's ghosts arrive) + _end == the plain
+    exchange-then-compute order, bit for bit; and the split path is really taken."""
+    a = _run_ranks(2, (8, 2, 2), (2, 1, 1), 12, 3000.0, overlap=True)
+    b = _run_ranks(2, (8, 2, 2), (2, 1, 1), 12, 3000.0, overlap=False)
+    assert all(int(r["nover"]) >= 6 for r in a) and all(int(r["nover"]) == 0 for r in b)
+    for ra, rb in zip(a, b):
+        assert np.array_equal(ra["i1"], rb["i1"])
+        assert np.array_equal(ra["x1"], rb["x1"]) and np.array_equal(ra["v1"], rb["v1"])
+        assert np.array_equal(ra["f1"], rb["f1"]) and np.array_equal(ra["th1"], rb["th1"])
 
 
 def _check_decomposed(world, reps, grid, device):
