@@ -18,6 +18,7 @@ One JSON line is printed by rank 0 (see the contract in the task description); i
                   bounded 16,000-atom sample of the same crystal (rank 0, N = 1 only)
 """
 import argparse
+import datetime
 import json
 import os
 import sys
@@ -252,7 +253,8 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            # a wedged exchange should fail fast (watchdog), not hold the node for the default 10 min
+            dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=300))
         else:
             dist.init_process_group(backend)
 
