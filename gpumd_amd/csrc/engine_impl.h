@@ -356,12 +356,23 @@ public:
     BoxD box;
     box_from_h9(h9, pbc, box);
     int64_t rec = 0;
+    bool seam_done = false; // the previous iteration already did this step's vv1 + wrap + zero
     for (int64_t step = 0; step < nsteps; ++step) {
-      velocity_verlet(true, n, dt, mass, force, pos, vel, &box); // vv1 + gpu_apply_pbc
-      zero_properties(n, pe, force, virial);
+      if (!seam_done) {
+        velocity_verlet(true, n, dt, mass, force, pos, vel, &box); // vv1 + gpu_apply_pbc
+        zero_properties(n, pe, force, virial);
+      }
       potential_compute(h9, pbc, n, type, pos, pe, force, virial);
+      const bool record = thermo_every > 0 && (step + 1) % thermo_every == 0;
+      seam_done = !record && step + 1 < nsteps;
+      if (seam_done) {
+        // vv2 of this step + vv1/wrap/zero of the next in one pass (nothing reads v in between)
+        VerletSeamBody body{n, dt, box, mass, force, pos, vel, pe, virial};
+        be_.template launch<256>(kSlotVV, n, body);
+        continue;
+      }
       velocity_verlet(false, n, dt, mass, force, pos, vel, nullptr);
-      if (thermo_every > 0 && (step + 1) % thermo_every == 0) {
+      if (record) {
         find_thermo(n, box.volume, mass, pe, vel, virial, thermo_dev_);
         be_.d2h(thermo_host + 8 * rec, thermo_dev_, 8 * sizeof(double));
         ++rec;
@@ -702,7 +713,7 @@ private:
     {
       const int64_t nkeys = ((N_ >> kTypeChunkShift) + 1) * model_.num_types;
       be_.memset(b_.tcount, 0, sizeof(int) * (nkeys + 1));
-      be_.template launch<256>(kSlotMisc, N_, TypeCountBody{b_, model_.num_types});
+      be_.template launch<64>(kSlotMisc, nkeys, TypeCountBody{b_, model_.num_types});
       be_.exclusive_scan(b_.tcount, nkeys + 1, scan_scratch_);
       be_.template launch<256>(kSlotMisc, N_, TypeFillBody{b_, model_.num_types});
     }

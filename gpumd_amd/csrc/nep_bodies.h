@@ -181,6 +181,48 @@ struct VelocityVerletBody {
   }
 };
 
+// Step n's second half-kick, step n+1's first half-kick + drift + wrap, and initialize_properties
+// for step n+1 in ONE pass over the atoms (run_nve between thermo records): the three kernels it
+// replaces read the same force and touch the same arrays.  The two half-kicks stay two separate
+// rounded additions, so the trajectory is bit-identical to the unfused sequence.
+struct VerletSeamBody {
+  int64_t N;
+  double dt;
+  BoxD box;
+  const double* mass;
+  double* force;
+  double* pos;
+  double* vel;
+  double* pe;
+  double* virial;
+  NEPMI_HD void operator()(int64_t i) const
+  {
+#pragma clang fp contract(off)
+    const double half = dt * 0.5;
+    const double minv = 1.0 / mass[i];
+    double r[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const double a = force[d * N + i] * minv;
+      const double kick = a * half;
+      const double v2 = vel[d * N + i] + kick; // gpu_velocity_verlet, second call of step n
+      const double v1 = v2 + kick;             // first call of step n + 1 (same force)
+      vel[d * N + i] = v1;
+      const double drift = v1 * dt;
+      r[d] = pos[d * N + i] + drift;
+      force[d * N + i] = 0.0;
+    }
+    wrap_position(box, r[0], r[1], r[2]);
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+      pos[d * N + i] = r[d];
+    pe[i] = 0.0;
+#pragma unroll
+    for (int d = 0; d < 9; ++d)
+      virial[d * N + i] = 0.0;
+  }
+};
+
 // gpu_berendsen_temperature, src/integrate/ensemble_ber.cu:70-86
 struct BerendsenBody {
   int64_t N;
@@ -472,12 +514,19 @@ inline AnnMfmaShape ann_mfma_shape(int T, int dim, int nneu, int KRP)
   a.ok = T <= 4 && a.MT <= 4 && a.DT <= 4 && a.KS <= 40 && a.img_floats * sizeof(float) <= 144 * 1024;
   return a;
 }
-struct TypeCountBody {
+struct TypeCountBody { // one work-item per (chunk, type): no atomics, deterministic
   Bufs b;
   int T;
-  NEPMI_HD void operator()(int64_t k) const
+  NEPMI_HD void operator()(int64_t key) const
   {
-    NEPMI_ATOMIC_ADD(&b.tcount[(k >> kTypeChunkShift) * T + b.posq[k].type], 1);
+    const int64_t chunk = key / T;
+    const int t = (int)(key - chunk * T);
+    const int64_t k0 = chunk << kTypeChunkShift;
+    const int64_t k1 = k0 + ((int64_t)1 << kTypeChunkShift) < b.N ? k0 + ((int64_t)1 << kTypeChunkShift) : b.N;
+    int cnt = 0;
+    for (int64_t k = k0; k < k1; ++k)
+      cnt += (b.posq[k].type == t) ? 1 : 0;
+    b.tcount[key] = cnt;
   }
 };
 struct TypeFillBody {
