@@ -365,6 +365,14 @@ int nepmi_engine_set_mfma(nepmi_engine* e, int on)
   return NEPMI_OK;
 }
 
+int nepmi_engine_set_angular_recompute(nepmi_engine* e, int mode)
+{
+  if (!e)
+    return fail(NEPMI_ERR_ARG, "null engine");
+  e->e->set_angular_recompute(mode);
+  return NEPMI_OK;
+}
+
 int nepmi_engine_set_generic(nepmi_engine* e, int on)
 {
   if (!e)

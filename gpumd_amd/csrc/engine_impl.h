@@ -633,9 +633,9 @@ private:
   void small_force_kernels_shape(double* pe, double* force, double* virial)
   {
     be_.template launch<64>(kSlotRadial, N_, RadialFromRecordsBody<S>{md_, b_});
-    be_.template launch_lds<64>(kSlotAngular, N_, AngularDescBody<S>{md_, b_});
+    be_.template launch_lds<64>(kSlotAngular, N_, AngularDescBody<S>{md_, b_, recompute_s()});
     be_.template launch_ann<S>(kSlotAnn, N_, md_, b_, false); // identity work order, no type groups
-    be_.template launch_lds<64>(kSlotAngForce, N_, AngularForceBody<S>{md_, b_});
+    be_.template launch_lds<64>(kSlotAngForce, N_, AngularForceBody<S>{md_, b_, recompute_s()});
     be_.template launch<64>(kSlotForce, N_, ForceAssembleBody<S>{md_, b_, pe, force, virial});
   }
 
@@ -781,6 +781,13 @@ public:
   }
   bool tiles_active() const { return tile_ok_; }
   void set_use_mfma(bool on) { be_.set_mfma(on); }
+  // angular s sums: -1 auto (recompute in the force kernel when the model has few angular
+  // neighbours, MN_angular <= 16), 0 always through sbuf, 1 always recompute
+  void set_angular_recompute(int mode) { recompute_mode_ = mode; }
+  int recompute_s() const
+  {
+    return recompute_mode_ < 0 ? (model_.MN_angular <= 16 ? 1 : 0) : (recompute_mode_ ? 1 : 0);
+  }
   void set_force_generic(bool on)
   {
     force_generic_ = on;
@@ -804,9 +811,9 @@ private:
       be_.launch_tile(kSlotRadial, num_bricks_, RadialTileBody<S>{box_, md_, b_, tile_, -1});
     else
       be_.template launch<64>(kSlotRadial, N_, RadialDescBody<S>{box_, md_, b_});
-    be_.template launch_lds<64>(kSlotAngular, N_, AngularDescBody<S>{md_, b_});
+    be_.template launch_lds<64>(kSlotAngular, N_, AngularDescBody<S>{md_, b_, recompute_s()});
     be_.template launch_ann<S>(kSlotAnn, N_, md_, b_, true);
-    be_.template launch_lds<64>(kSlotAngForce, N_, AngularForceBody<S>{md_, b_});
+    be_.template launch_lds<64>(kSlotAngForce, N_, AngularForceBody<S>{md_, b_, recompute_s()});
     be_.template launch<64>(kSlotForce, N_, ForceAssembleBody<S>{md_, b_, pe, force, virial});
     be_.end_region(kRegionForce);
   }
@@ -839,6 +846,7 @@ private:
   BoxD box_;
   TileLayout tile_{0};
   bool tile_ok_ = false, use_tiles_ = true;
+  int recompute_mode_ = -1;
   bool split_pending_ = false;   // compute_levels_begin ran, compute_levels_end has not yet
   int64_t num_boundary_bricks_ = 0;
   int64_t num_bricks_ = 0;

@@ -1207,12 +1207,70 @@ struct RadialFromRecordsBody {
   }
 };
 
+// s_{n,lm}(i) = sum_j g_n(r_ij) b_lm(rhat_ij) over the compacted angular pair records of atom k
+// (find_descriptor, nep.cu:588-610 + accumulate_s).  Shared by the angular descriptor kernel and by
+// the angular force kernel's recompute path, so that both see bit-identical sums.
+template <class S, class LP>
+NEPMI_HD void angular_s_sums(const ModelD& m, const Bufs& b, int64_t k, int t1, LP cang, float* s)
+{
+  const int64_t N = b.N;
+  const int NA = S::fixed ? S::NA : m.NA;
+  const int KA = S::fixed ? S::KA : m.KA;
+  const float rc1 = m.rc_a[t1];
+  const int cstride = cang_stride(m);
+#pragma unroll
+  for (int a = 0; a < (S::NAM + 1) * kNumHarm; ++a)
+    s[a] = 0.0f;
+  const int na = b.nn_angstep[k];
+  const F4* __restrict__ acomp = b.acomp + k;
+  F4 e_next;
+  if (na > 0)
+    e_next = acomp[0];
+  for (int a = 0; a < na; ++a) {
+    const F4 e = e_next;
+    if (a + 1 < na)
+      e_next = acomp[(int64_t)(a + 1) * N]; // in flight while this record is processed
+    const int t2 = (int)((unsigned)e.w >> kIdxBits);
+    const float x = e.x, y = e.y, z = e.z;
+    float d, dinv;
+    dist_and_inv(dot3f(x, x, y, y, z, z), d, dinv);
+    const float rc = m.uniform_rc ? m.rc_a_max : (rc1 + m.rc_a[t2]) * 0.5f;
+    const float rcinv = 1.0f / rc;
+    float fc;
+    cutoff_fc(rcinv, d, fc);
+    float fn[S::KAM + 1];
+    if (S::fixed)
+      basis_fn<S::KAM>(rcinv, d, fc, fn);
+    else
+      basis_fn_rt(KA, rcinv, d, fc, fn);
+    float bh[kNumHarm];
+    harmonics(x * dinv, y * dinv, z * dinv, bh);
+    LP c = cang + (t1 * m.T + t2) * cstride;
+#pragma unroll
+    for (int n = 0; n <= S::NAM; ++n) {
+      if (!S::fixed && n > NA)
+        break;
+      float g = 0.0f;
+#pragma unroll
+      for (int kk = 0; kk <= S::KAM; ++kk) {
+        if (!S::fixed && kk > KA)
+          break;
+        g = fmaf(fn[kk], c[n * (KA + 1) + kk], g);
+      }
+#pragma unroll
+      for (int h = 0; h < kNumHarm; ++h)
+        s[n * kNumHarm + h] = fmaf(g, bh[h], s[n * kNumHarm + h]);
+    }
+  }
+}
+
 // angular part of find_descriptor (nep.cu:549-640) on the compacted angular pair records:
 // no gathers, no geometry, every lane of the wavefront has real work in every iteration.
 template <class S>
 struct AngularDescBody {
   ModelD m;
   Bufs b;
+  int recompute_s; // the force kernel rebuilds s from the records: do not write sbuf
   static constexpr bool kUsesLds = true;
   NEPMI_HD int lds_floats() const { return cang_floats(m); }
   NEPMI_HD void lds_stage(float* dst, int tid, int nth) const { cang_stage(m, dst, tid, nth); }
@@ -1231,59 +1289,17 @@ struct AngularDescBody {
     const float rc1 = m.rc_a[t1];
     const int cstride = cang_stride(m);
     float s[(S::NAM + 1) * kNumHarm];
-#pragma unroll
-    for (int a = 0; a < (S::NAM + 1) * kNumHarm; ++a)
-      s[a] = 0.0f;
-
-    const int na = b.nn_angstep[k];
-    const F4* __restrict__ acomp = b.acomp + k;
-    F4 e_next;
-    if (na > 0)
-      e_next = acomp[0];
-    for (int a = 0; a < na; ++a) {
-      const F4 e = e_next;
-      if (a + 1 < na)
-        e_next = acomp[(int64_t)(a + 1) * N]; // in flight while this record is processed
-      const int t2 = (int)((unsigned)e.w >> kIdxBits);
-      const float x = e.x, y = e.y, z = e.z;
-      float d, dinv;
-      dist_and_inv(dot3f(x, x, y, y, z, z), d, dinv);
-      const float rc = m.uniform_rc ? m.rc_a_max : (rc1 + m.rc_a[t2]) * 0.5f;
-      const float rcinv = 1.0f / rc;
-      float fc;
-      cutoff_fc(rcinv, d, fc);
-      float fn[S::KAM + 1];
-      if (S::fixed)
-        basis_fn<S::KAM>(rcinv, d, fc, fn);
-      else
-        basis_fn_rt(KA, rcinv, d, fc, fn);
-      float bh[kNumHarm];
-      harmonics(x * dinv, y * dinv, z * dinv, bh);
-      LP c = cang + (t1 * m.T + t2) * cstride;
-#pragma unroll
-      for (int n = 0; n <= S::NAM; ++n) {
-        if (!S::fixed && n > NA)
-          break;
-        float g = 0.0f;
-#pragma unroll
-        for (int kk = 0; kk <= S::KAM; ++kk) {
-          if (!S::fixed && kk > KA)
-            break;
-          g = fmaf(fn[kk], c[n * (KA + 1) + kk], g);
-        }
-#pragma unroll
-        for (int h = 0; h < kNumHarm; ++h)
-          s[n * kNumHarm + h] = fmaf(g, bh[h], s[n * kNumHarm + h]);
-      }
-    }
+    angular_s_sums<S>(m, b, k, t1, cang, s);
 
 #pragma unroll
     for (int n = 0; n <= S::NAM; ++n) {
       if (!S::fixed && n > NA)
         break;
+      if (!recompute_s) {
 #pragma unroll
-      for (int h = 0; h < kNumHarm; ++h)
-        b.sbuf[(int64_t)(n * kNumHarm + h) * N + k] = s[n * kNumHarm + h];
+        for (int h = 0; h < kNumHarm; ++h)
+          b.sbuf[(int64_t)(n * kNumHarm + h) * N + k] = s[n * kNumHarm + h];
+      }
       float qn[6];
       invariants(m, &s[n * kNumHarm], qn, 1);
       for (int L = 0; L < m.numL; ++L) {
@@ -1400,6 +1416,8 @@ template <class S>
 struct AngularForceBody {
   ModelD m;
   Bufs b;
+  int recompute_s; // few angular neighbours: rebuilding s (a second walk over <= MN_a records) is
+                   // cheaper than the (n_a+1)*24 floats per atom written and read back through HBM
   static constexpr bool kUsesLds = true;
   NEPMI_HD int lds_floats() const { return cang_floats(m); }
   NEPMI_HD void lds_stage(float* dst, int tid, int nth) const { cang_stage(m, dst, tid, nth); }
@@ -1419,6 +1437,8 @@ struct AngularForceBody {
     const int cstride = cang_stride(m);
 
     float G[(S::NAM + 1) * kNumHarm];
+    if (recompute_s)
+      angular_s_sums<S>(m, b, k, t1, cang, G);
 #pragma unroll
     for (int n = 0; n <= S::NAM; ++n) {
       if (!S::fixed && n > NA)
@@ -1427,9 +1447,11 @@ struct AngularForceBody {
 #pragma unroll
       for (int L = 0; L < 6; ++L)
         fpn[L] = L < m.numL ? b.fp[(int64_t)((NR + 1) + L * (NA + 1) + n) * N + gk] : 0.0f;
+      if (!recompute_s) {
 #pragma unroll
-      for (int h = 0; h < kNumHarm; ++h)
-        G[n * kNumHarm + h] = b.sbuf[(int64_t)(n * kNumHarm + h) * N + k];
+        for (int h = 0; h < kNumHarm; ++h)
+          G[n * kNumHarm + h] = b.sbuf[(int64_t)(n * kNumHarm + h) * N + k];
+      }
       invariants_adjoint(m, fpn, 1, &G[n * kNumHarm]);
     }
 

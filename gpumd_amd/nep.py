@@ -226,5 +226,8 @@ class NEP:
     def set_mfma(self, on=True):
         self._ck(self.lib.nepmi_engine_set_mfma(self.handle, 1 if on else 0))
 
+    def set_angular_recompute(self, mode=-1):
+        self._ck(self.lib.nepmi_engine_set_angular_recompute(self.handle, int(mode)))
+
     def set_generic(self, on=True):
         self._ck(self.lib.nepmi_engine_set_generic(self.handle, 1 if on else 0))

@@ -226,6 +226,11 @@ int nepmi_engine_set_tiles(nepmi_engine* e, int on);
  * more than 128 neurons or more than 128 descriptor + radial-table rows.  The two differ by f32
  * summation order only. */
 int nepmi_engine_set_mfma(nepmi_engine* e, int on);
+/* Angular s_{n,lm} sums between the angular descriptor and angular force kernels: mode 0 = stored
+ * ((n_a+1)*24 floats per atom through HBM), 1 = rebuilt in the force kernel from the compact pair
+ * records, -1 (default) = rebuilt when the model has few angular neighbours (MN_angular <= 16).
+ * Both give bit-identical results. */
+int nepmi_engine_set_angular_recompute(nepmi_engine* e, int mode);
 
 #ifdef __cplusplus
 }

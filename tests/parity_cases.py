@@ -361,6 +361,23 @@ def check_nvt_nhc(drv, nsteps=30):
     np.testing.assert_allclose(chain[:12], st, rtol=5e-5, atol=1e-9)  # f32 force noise feeds the chain
 
 
+def check_angular_recompute(drv):
+    """The angular force kernel's two sources of the s sums (stored by the descriptor kernel / rebuilt
+    from the compact records) are the same arithmetic in the same order; on the device the two inlined
+    copies may contract multiply-adds differently, so agreement is to f32 rounding, not bitwise."""
+    for name in ("PbTe-A", "C-2022", "UNEP-v1"):
+        nep_rel, build, _ = MODELS[name]
+        model = drv.model(H.golden(*nep_rel.split("/")))
+        h, typ, x = build()
+        out = []
+        for mode in (0, 1):
+            eng = drv.engine(model, len(typ))
+            eng.set_angular_recompute(mode)
+            out.append(H.engine_force(drv, eng, h, typ, x))
+        for a, b in zip(out[0][1:], out[1][1:]):
+            assert np.abs(a - b).max() <= 2e-6 * max(1.0, np.abs(a).max()), name
+
+
 def check_error_paths(drv):
     import pytest
     from gpumd_amd import NepmiError

@@ -85,6 +85,10 @@ def test_nvt_nose_hoover_chain(drv):
     P.check_nvt_nhc(drv)
 
 
+def test_angular_sums_stored_or_recomputed(drv):
+    P.check_angular_recompute(drv)
+
+
 def test_small_box_branch(drv):
     P.check_small_box(drv)
 
