@@ -88,6 +88,26 @@ def algorithmic_bytes(info, nn_r, nn_a):
     return per_kernel, total
 
 
+class _stdout_to_stderr:
+    """The reference's NEP_CPU prints its model summary with printf; keep this process's stdout for
+    the one JSON line by pointing fd 1 at stderr while the CPU baseline runs."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)  # C stdio buffers of the checker library
+        finally:
+            os.dup2(self.saved, 1)
+            os.close(self.saved)
+        return False
+
+
 def cpu_baseline(seconds=12.0):
     """NEP_CPU (reference, compiled in place into oracle/_ref) on a 16,000-atom PbTe replica; one
     iteration = compute() + a host velocity-Verlet update, so that it is an atom-STEP."""
@@ -320,7 +340,8 @@ def main():
             "thermo_last": [float(v) for v in th[-1]] if len(th) else None,
         }
         if world == 1 and not args.no_cpu_baseline and args.workload == "pbte":
-            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+            with _stdout_to_stderr():
+                out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

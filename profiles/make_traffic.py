@@ -1,0 +1,44 @@
+"""fetch/write PMC summaries (summarize_rocpd.py pmc) -> traffic json read by bench.py.
+
+  python profiles/make_traffic.py profiles/r1e_pmc_fetch.csv profiles/r1e_pmc_write.csv 1024000 profiles/r1e_traffic.json
+
+bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE/WRITE_SIZE are in KiB, and on gfx950
+FETCH_SIZE tallies the 128-byte fabric read requests at 64 bytes (MI355X_MICROARCH.md, HBM section).
+"""
+import csv
+import json
+import sys
+
+NAMES = [("CheckGatherBody", "gather_skin_check"), ("RadialTileBody", "radial_descriptor"),
+         ("RadialDescBody", "radial_descriptor"), ("AngularDescBody", "angular_descriptor"),
+         ("nepmi_ann_mfma", "ann"), ("AnnBody", "ann"), ("AngularForceBody", "angular_partial_force"),
+         ("ForceAssembleBody", "force_assemble"), ("VerletSeamBody", "velocity_verlet"),
+         ("VelocityVerletBody", "velocity_verlet_unfused")]
+
+
+def read(path, counter):
+    out = {}
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            if row["counter"] != counter:
+                continue
+            for key, name in NAMES:
+                if key in row["kernel"] and name not in out:
+                    out[name] = float(row["sum_per_dispatch"])
+    return out
+
+
+def main():
+    fetch, write = read(sys.argv[1], "FETCH_SIZE"), read(sys.argv[2], "WRITE_SIZE")
+    kern = {}
+    for name in fetch:
+        w = write.get(name, 0.0)
+        kern[name] = {"fetch_kb": fetch[name], "write_kb": w, "hbm_bytes_per_launch": (2.0 * fetch[name] + w) * 1024.0}
+    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `bench.py --steps 5 --warmup 2`; "
+                         "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch (gfx950 FETCH_SIZE correction, "
+                         "MI355X_MICROARCH.md)", "atoms": int(sys.argv[3]), "kernels": kern},
+              open(sys.argv[4], "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
