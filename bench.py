@@ -332,7 +332,7 @@ def main():
             "config": {"workload": label,
                        "atoms_total": total_atoms, "rebuilds_in_timed_region": int(st.num_rebuild - reb0),
                        "mean_nn_radial": st.mean_nn_radial, "mean_nn_angular": st.mean_nn_angular,
-                       "parallelism": "1 GPU"},
+                       "lds_window_mode": int(st.radial_tiles), "parallelism": "1 GPU"},
             "roofline": roofline,
             "step_algorithmic_bytes_per_atom": b_step,
             "step_hbm_frac": b_step * (n * args.steps / elapsed) / (HBM_PEAK_GBS * 1e9),

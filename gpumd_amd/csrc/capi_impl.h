@@ -334,7 +334,7 @@ int nepmi_engine_stats(nepmi_engine* e, int with_lists, nepmi_stats* out)
       out->ms_kernel_sum[k] = eng.backend().slot_sum(slots[k]);
       out->launches[k] = eng.backend().slot_count(slots[k]);
     }
-    out->radial_tiles = eng.tiles_active() ? 1 : 0;
+    out->radial_tiles = eng.tile_mode_in_use();
     out->ms_kernel_sum[7] = eng.backend().region_sum(nepmi::kRegionRebuild);
     out->launches[7] = eng.backend().region_count(nepmi::kRegionRebuild);
     out->ms_kernel[7] = eng.backend().region_ms(nepmi::kRegionRebuild);
@@ -353,7 +353,7 @@ int nepmi_engine_set_tiles(nepmi_engine* e, int on)
 {
   if (!e)
     return fail(NEPMI_ERR_ARG, "null engine");
-  e->e->set_use_tiles(on != 0);
+  e->e->set_tile_mode(on < 0 ? -1 : on > 2 ? 2 : on);
   return NEPMI_OK;
 }
 

@@ -499,6 +499,7 @@ struct HipBackend {
   HipTiming* timing = nullptr; // shared by copies of the backend
   int* pinned = nullptr;       // 64-byte pinned staging for flag read-back
   bool timing_on = false;
+  hipEvent_t probe_ev[2] = {nullptr, nullptr};
   bool mfma_on = true; // per-atom ANN on the matrix cores when the model shape allows it
 
   void* alloc(size_t bytes)
@@ -573,6 +574,24 @@ struct HipBackend {
       timing->reg[k].count = 0;
     }
     timing_on = on;
+  }
+  // stand-alone stopwatch on the engine's stream (independent of set_timing): used once per engine
+  // to choose between equivalent kernel variants
+  void probe_start()
+  {
+    if (!probe_ev[0]) {
+      NEPMI_HIP_CHECK(hipEventCreate(&probe_ev[0]));
+      NEPMI_HIP_CHECK(hipEventCreate(&probe_ev[1]));
+    }
+    NEPMI_HIP_CHECK(hipEventRecord(probe_ev[0], stream));
+  }
+  double probe_stop_ms()
+  {
+    NEPMI_HIP_CHECK(hipEventRecord(probe_ev[1], stream));
+    NEPMI_HIP_CHECK(hipEventSynchronize(probe_ev[1]));
+    float ms = 0.0f;
+    NEPMI_HIP_CHECK(hipEventElapsedTime(&ms, probe_ev[0], probe_ev[1]));
+    return (double)ms;
   }
   void begin_region(int r)
   {

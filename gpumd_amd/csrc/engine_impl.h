@@ -100,7 +100,7 @@ public:
   const Bufs& bufs() const { return b_; }
   int64_t num_atoms() const { return N_; }
   int64_t num_compute = 0, num_rebuild = 0;
-  enum Phase { kPhaseAll = 0, kPhaseInterior = 1, kPhaseBoundary = 2 };
+  enum Phase { kPhaseAll = 0, kPhaseInterior = 1, kPhaseBoundary = 2, kPhaseRecords = 3 };
 
   // Potential::compute (adds to pe/force/virial; positions already wrapped)
   void potential_compute(
@@ -391,6 +391,10 @@ public:
     if (model_.kind == 1 && which != 2) {
       be_.template launch<64>(kSlotMisc, N_, TersoffExportBody{b_, tb_, nn, nl, ld});
     } else {
+      // the per-step radial/angular lists are read off the pair records; in tile mode 2 the force
+      // path does not write them, so rerun the (idempotent) radial pass with record writing on
+      if (which != 2 && !records_valid_ && have_list_)
+        force_kernels(nullptr, nullptr, nullptr, kPhaseRecords);
       ExportListsBody body{b_, which, nn, nl, ld};
       be_.template launch<64>(kSlotMisc, N_, body);
     }
@@ -774,11 +778,15 @@ private:
 
 public:
   void invalidate() { have_list_ = false; }
-  void set_use_tiles(bool on)
+  // 0: no LDS-window kernels; 1: radial pass only (pair records written for the force assembly);
+  // 2 (default): radial pass and force assembly both work from an LDS position window
+  void set_tile_mode(int mode)
   {
-    use_tiles_ = on;
+    use_tiles_ = mode != 0;
+    tile_mode_ = mode;
     have_list_ = false;
   }
+  int tile_mode_in_use() const { return tile_ok_ ? effective_tile_mode() : 0; }
   bool tiles_active() const { return tile_ok_; }
   void set_use_mfma(bool on) { be_.set_mfma(on); }
   // angular s sums: -1 auto (recompute in the force kernel when the model has few angular
@@ -799,26 +807,68 @@ private:
   template <class S>
   void force_kernels_shape(double* pe, double* force, double* virial, int phase)
   {
+    // tile mode 2: the force assembly rebuilds the pair geometry from its own LDS window, so the
+    // radial pass writes no pair records (the compact angular records are written in any case)
+    const bool force_tile = tile_ok_ && effective_tile_mode() >= 2;
+    const int records = force_tile ? 0 : 1;
+    if (phase == kPhaseRecords) { // diagnostics: materialise the pair records of the current positions
+      be_.launch_tile(kSlotMisc, num_bricks_, RadialTileBody<S>{box_, md_, b_, tile_, -1, 1});
+      records_valid_ = true;
+      return;
+    }
+    if (phase != kPhaseInterior)
+      records_valid_ = records != 0;
     if (phase == kPhaseInterior) { // radial pass of the bricks whose window holds no ghost
-      be_.launch_tile(kSlotRadial, num_bricks_ - num_boundary_bricks_, RadialTileBody<S>{box_, md_, b_, tile_, 0});
+      be_.launch_tile(kSlotRadial, num_bricks_ - num_boundary_bricks_, RadialTileBody<S>{box_, md_, b_, tile_, 0, records});
       return;
     }
     be_.begin_region(kRegionForce);
     if (phase == kPhaseBoundary)
       be_.launch_tile(kSlotRadial, num_boundary_bricks_,
-                      RadialTileBody<S>{box_, md_, b_, tile_, (int)(num_bricks_ - num_boundary_bricks_)});
+                      RadialTileBody<S>{box_, md_, b_, tile_, (int)(num_bricks_ - num_boundary_bricks_), records});
     else if (tile_ok_)
-      be_.launch_tile(kSlotRadial, num_bricks_, RadialTileBody<S>{box_, md_, b_, tile_, -1});
+      be_.launch_tile(kSlotRadial, num_bricks_, RadialTileBody<S>{box_, md_, b_, tile_, -1, records});
     else
-      be_.template launch<64>(kSlotRadial, N_, RadialDescBody<S>{box_, md_, b_});
+      be_.template launch<64>(kSlotRadial, N_, RadialDescBody<S>{box_, md_, b_, 1});
     be_.template launch_lds<64>(kSlotAngular, N_, AngularDescBody<S>{md_, b_, recompute_s()});
     be_.template launch_ann<S>(kSlotAnn, N_, md_, b_, true);
     be_.template launch_lds<64>(kSlotAngForce, N_, AngularForceBody<S>{md_, b_, recompute_s()});
-    be_.template launch<64>(kSlotForce, N_, ForceAssembleBody<S>{md_, b_, pe, force, virial});
+    if (force_tile)
+      be_.launch_tile(kSlotForce, num_bricks_,
+                      ForceTileBody<S>{RadialTileBody<S>{box_, md_, b_, tile_, -1, 0}, pe, force, virial});
+    else
+      be_.template launch<64>(kSlotForce, N_, ForceAssembleBody<S>{md_, b_, pe, force, virial});
     be_.end_region(kRegionForce);
   }
 
+  // Tile mode -1 (default): the two force-assembly variants (pair records written by the radial pass
+  // vs. geometry rebuilt from a second LDS window) are equivalent; which one is faster depends on the
+  // model (angular work per atom, registers).  The engine times the whole force path of its 2nd call
+  // in mode 2 and of its 4th call in mode 1 and keeps the faster one.
+  int effective_tile_mode() const
+  {
+    if (tile_mode_ >= 0)
+      return tile_mode_;
+    if (auto_choice_ >= 0)
+      return auto_choice_;
+    return auto_calls_ < 2 ? 2 : 1;
+  }
+
   void force_kernels(double* pe, double* force, double* virial, int phase)
+  {
+    const bool probing = phase == kPhaseAll && tile_mode_ < 0 && auto_choice_ < 0 && tile_ok_ && model_.kind == 0;
+    if (probing && (auto_calls_ == 1 || auto_calls_ == 3))
+      be_.probe_start();
+    force_kernels_dispatch(pe, force, virial, phase);
+    if (probing) {
+      if (auto_calls_ == 1 || auto_calls_ == 3)
+        auto_ms_[auto_calls_ == 1 ? 0 : 1] = be_.probe_stop_ms();
+      if (++auto_calls_ == 4)
+        auto_choice_ = auto_ms_[1] < auto_ms_[0] ? 1 : 2;
+    }
+  }
+
+  void force_kernels_dispatch(double* pe, double* force, double* virial, int phase)
   {
     if (model_.kind == 1) { // Tersoff1989::compute, tersoff1989.cu:508-586
       be_.begin_region(kRegionForce);
@@ -846,6 +896,10 @@ private:
   BoxD box_;
   TileLayout tile_{0};
   bool tile_ok_ = false, use_tiles_ = true;
+  int tile_mode_ = -1;           // -1 auto, 0 none, 1 radial window only, 2 radial + force windows
+  int auto_choice_ = -1, auto_calls_ = 0;
+  double auto_ms_[2] = {0.0, 0.0};
+  bool records_valid_ = false; // rstash holds the pair records of the last evaluated positions
   int recompute_mode_ = -1;
   bool split_pending_ = false;   // compute_levels_begin ran, compute_levels_end has not yet
   int64_t num_boundary_bricks_ = 0;

@@ -819,6 +819,7 @@ struct RadialDescBody {
   BoxD box;
   ModelD m;
   Bufs b;
+  int write_records; // 0: the force pass recomputes the pair geometry from its own LDS window
 
   // candidate source of the default path: neighbour indices from the Verlet lists, positions
   // gathered from global memory (L2)
@@ -922,7 +923,8 @@ struct RadialDescBody {
         e.z = z;
         e.w = inside ? (int)((unsigned)j | ((unsigned)t2 << kIdxBits)) : -1;
         const int row = idx < na ? idx : b.MN_ang + (idx - na);
-        rstash[(int64_t)row * N] = e;
+        if (write_records)
+          rstash[(int64_t)row * N] = e;
         if (idx < na) {
           const float rca = m.uniform_rc ? m.rc_a_max : (rca1 + m.rc_a[t2]) * 0.5f;
           unsigned short slot = kNoSlot;
@@ -1053,6 +1055,7 @@ struct RadialTileBody {
   Bufs b;
   TileLayout lay;
   int first; // workgroup w runs brick_order[first + w] (first < 0: brick w)
+  int write_records;
 
   NEPMI_HD int lds_bytes() const { return lay.bytes(); }
   NEPMI_HD int64_t map_brick(int64_t w) const { return first < 0 ? w : (int64_t)b.brick_order[first + w]; }
@@ -1158,7 +1161,7 @@ struct RadialTileBody {
   template <class LC>
   NEPMI_HD void compute(int64_t k, LC lds) const
   {
-    const RadialDescBody<S> body{box, m, b};
+    const RadialDescBody<S> body{box, m, b, write_records};
     body.run_with(k, TileFetch<LC>{b.code_ang + k, b.code_skin + k, b.N, lds, lay});
   }
 };
@@ -1571,7 +1574,34 @@ struct ForceAssembleBody {
   double* pe;     // caller order
   double* force;  // [3][N]
   double* virial; // [9][N]
+  // pair records straight from the radial pass (rows [A slots | MN_ang + B slots] of rstash)
+  struct RecordSource {
+    const F4* rstash; // + k
+    int64_t N;
+    int MN_ang;
+    struct State {
+    };
+    NEPMI_HD void begin(int, int, State&) const {}
+    NEPMI_HD void load(int s0, int nn, int na, State&, F4* ee) const
+    {
+#pragma unroll
+      for (int u = 0; u < kGather; ++u) {
+        const int idx = s0 + u < nn ? s0 + u : nn - 1;
+        const int row = idx < na ? idx : MN_ang + (idx - na);
+        ee[u] = rstash[(int64_t)row * N];
+      }
+    }
+  };
+
   NEPMI_HD void operator()(int64_t k) const
+  {
+    run_with(k, RecordSource{b.rstash + k, b.N, b.MN_ang});
+  }
+
+  // src delivers, kGather at a time, the pair records of atom k in list order (A slots, then B
+  // slots): r12 and (j | t2 << kIdxBits), or -1 when the pair is outside the radial cutoff
+  template <class Src>
+  NEPMI_HD void run_with(int64_t k, const Src& src) const
   {
     const int64_t N = b.N;
     if (b.lvl[k] < 2) // forces only for owned atoms
@@ -1596,20 +1626,17 @@ struct ForceAssembleBody {
 
     const int na = b.nn_ang[k], nbn = b.nn_skin[k];
     const int nn = na + nbn;
-    const F4* __restrict__ rstash = b.rstash + k;
     const float* __restrict__ atab = b.atab;
     const unsigned short* __restrict__ amap = b.amap;
     const unsigned short* __restrict__ rev = b.rev_ang + k;
     const F4* __restrict__ f12 = b.f12;
+    typename Src::State st;
+    if (nn > 0)
+      src.begin(nn, na, st);
     for (int s0 = 0; s0 < nn; s0 += kGather) {
       F4 ee[kGather];
       float Aj[kGather][S::KRM + 1];
-#pragma unroll
-      for (int u = 0; u < kGather; ++u) {
-        const int idx = s0 + u < nn ? s0 + u : nn - 1;
-        const int row = idx < na ? idx : b.MN_ang + (idx - na);
-        ee[u] = rstash[(int64_t)row * N];
-      }
+      src.load(s0, nn, na, st, ee);
 #pragma unroll
       for (int u = 0; u < kGather; ++u) {
         const int j = ee[u].w == -1 ? (int)k : (int)((unsigned)ee[u].w & (unsigned)kIdxMask);
@@ -1735,6 +1762,70 @@ struct ForceAssembleBody {
 #pragma unroll
     for (int d = 0; d < 9; ++d)
       virial[d * N + i] += Wd[d];
+  }
+};
+
+// Force assembly without pair records: one 256-thread workgroup per brick stages the same 8x8x8-cell
+// position window as the radial pass and rebuilds every pair's r12 and cutoff decision from it (the
+// identical exact FP64 -> FP32 minimum-image arithmetic, so both passes agree on every pair), instead
+// of the radial pass writing 16 bytes per Verlet entry and this pass reading them back (2 x 1.4 KB
+// per atom and step for PbTe).  Tables of the neighbours are still gathered from L2 by index.
+template <class S>
+struct ForceTileBody {
+  RadialTileBody<S> rt; // staging (stage_cells / stage_copy / brick_range / map_brick), box, model, buffers
+  double* pe;
+  double* force;
+  double* virial;
+
+  NEPMI_HD int lds_bytes() const { return rt.lds_bytes(); }
+  NEPMI_HD int64_t map_brick(int64_t w) const { return rt.map_brick(w); }
+  template <class LC>
+  NEPMI_HD void stage_cells(int64_t brick, LC lds, int tid, int nth) const { rt.stage_cells(brick, lds, tid, nth); }
+  template <class LC>
+  NEPMI_HD void stage_copy(LC lds, int tid, int nth) const { rt.stage_copy(lds, tid, nth); }
+  NEPMI_HD void brick_range(int64_t brick, int64_t& a0, int64_t& a1) const { rt.brick_range(brick, a0, a1); }
+
+  template <class LC>
+  struct WindowSource {
+    typename RadialTileBody<S>::template TileFetch<LC> fetch;
+    BoxD box;
+    ModelD m;
+    PosQ p1;
+    float rc1;
+    struct State {
+      typename RadialTileBody<S>::template TileFetch<LC>::Tok cur;
+    };
+    NEPMI_HD void begin(int nn, int na, State& st) const { fetch.prefetch(0, nn, na, st.cur); }
+    NEPMI_HD void load(int s0, int nn, int na, State& st, F4* ee) const
+    {
+      int jj[kGather];
+      PosQ pp[kGather];
+      typename RadialTileBody<S>::template TileFetch<LC>::Tok nxt = st.cur;
+      if (s0 + kGather < nn)
+        fetch.prefetch(s0 + kGather, nn, na, nxt);
+      fetch.resolve(st.cur, jj, pp);
+      st.cur = nxt;
+#pragma unroll
+      for (int u = 0; u < kGather; ++u) {
+        float x, y, z;
+        const float d2 = pair_geometry(box, p1, pp[u], x, y, z);
+        const int t2 = pp[u].type;
+        const float rc = m.uniform_rc ? m.rc_r_max : (rc1 + m.rc_r[t2]) * 0.5f;
+        ee[u].x = x;
+        ee[u].y = y;
+        ee[u].z = z;
+        ee[u].w = d2 < rc * rc ? (int)((unsigned)jj[u] | ((unsigned)t2 << kIdxBits)) : -1;
+      }
+    }
+  };
+
+  template <class LC>
+  NEPMI_HD void compute(int64_t k, LC lds) const
+  {
+    const ForceAssembleBody<S> fa{rt.m, rt.b, pe, force, virial};
+    const PosQ p1 = rt.b.posq[k];
+    fa.run_with(k, WindowSource<LC>{{rt.b.code_ang + k, rt.b.code_skin + k, rt.b.N, lds, rt.lay}, rt.box, rt.m, p1,
+                                    rt.m.rc_r[p1.type]});
   }
 };
 

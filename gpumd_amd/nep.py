@@ -220,8 +220,11 @@ class NEP:
     def set_timing(self, on=True):
         self._ck(self.lib.nepmi_engine_set_timing(self.handle, 1 if on else 0))
 
-    def set_tiles(self, on=True):
-        self._ck(self.lib.nepmi_engine_set_tiles(self.handle, 1 if on else 0))
+    def set_tiles(self, mode=-1):
+        """0/False: no LDS-window kernels; 1: radial pass only; 2/True: radial pass + force assembly;
+        -1: chosen by the engine (times modes 2 and 1 once)."""
+        mode = 2 if mode is True else 0 if mode is False else int(mode)
+        self._ck(self.lib.nepmi_engine_set_tiles(self.handle, mode))
 
     def set_mfma(self, on=True):
         self._ck(self.lib.nepmi_engine_set_mfma(self.handle, 1 if on else 0))

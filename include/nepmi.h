@@ -208,7 +208,7 @@ typedef struct {
                             6 velocity-Verlet, 7 list rebuild (whole) */
   double ms_kernel_sum[8]; /* same slots: sum over all launches since timing was (re)enabled */
   int64_t launches[8];     /* ... and their number (slot 7: rebuilds)                       */
-  int radial_tiles;        /* 1 if the last force call used the LDS-window radial pass        */
+  int radial_tiles;        /* LDS-window mode of the last force call: 0 none, 1 radial pass, 2 radial pass + force assembly */
 } nepmi_stats;
 /* Synchronises the stream.  with_lists != 0 also recounts the per-step list lengths. */
 int nepmi_engine_stats(nepmi_engine* e, int with_lists, nepmi_stats* out);
@@ -217,9 +217,11 @@ int nepmi_engine_set_timing(nepmi_engine* e, int on);
 /* Force the run-time-shaped (generic) kernel instantiation instead of a model-shape-specialised
  * one; used by the parity tests to cover both code paths with one model. */
 int nepmi_engine_set_generic(nepmi_engine* e, int on);
-/* Allow (default) or forbid the LDS-window radial pass; forbidding selects the plain gather kernel
- * (also taken automatically when a periodic direction has fewer than 8 cells or a brick's window
- * does not fit LDS).  Both give identical lists and pair records. */
+/* LDS-window kernels: 0 = none (plain gather kernel for the radial pass, pair records for the force
+ * assembly), 1 = radial pass only, 2 = radial pass and force assembly, -1 (default) = the engine times
+ * modes 2 and 1 once on its first four force calls and keeps the faster; the window kernels are
+ * also dropped automatically when a periodic direction has fewer than 8 cells or a brick's window
+ * does not fit LDS.  All give identical lists and forces to f32 rounding. */
 int nepmi_engine_set_tiles(nepmi_engine* e, int on);
 /* Allow (default) or forbid the matrix-core (v_mfma_f32_32x32x2_f32) ANN kernel; forbidding selects
  * the per-atom ANN kernel, which is also taken automatically for models with more than 4 types,

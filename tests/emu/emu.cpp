@@ -46,6 +46,8 @@ struct HostLoopBackend {
     launch<64>(slot, n, AnnBody<S>{m, b});
   }
   void set_mfma(bool) {}
+  void probe_start() {}
+  double probe_stop_ms() { return 0.0; } // no clock on the CPU tier: the engine keeps its default variant
   void ann_prepare(const ModelD&, const Bufs&) {}
 
   // one "workgroup" per brick, phases run back to back (the LDS-window radial pass)
