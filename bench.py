@@ -301,6 +301,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # kernel-variant switches for A/B measurements (defaults = what the engine picks itself)
+    if "NEPMI_BENCH_TILES" in os.environ:
+        eng.set_tiles(int(os.environ["NEPMI_BENCH_TILES"]))
+    if "NEPMI_BENCH_RECOMPUTE" in os.environ:
+        eng.set_angular_recompute(int(os.environ["NEPMI_BENCH_RECOMPUTE"]))
+    if "NEPMI_BENCH_MFMA" in os.environ:
+        eng.set_mfma(os.environ["NEPMI_BENCH_MFMA"] != "0")
     # initial force (Run::perform_a_run computes it before the loop), then warm-up steps
     eng.force_compute(h, t_type, t_x, t_pe, t_f, t_w)
     if args.warmup > 0:

@@ -61,6 +61,7 @@ class DomainMD:
         self.overlap = (os.environ.get("NEPMI_OVERLAP", "1") != "0") if overlap is None else bool(overlap)
         self.side = None
         self.num_overlapped = 0
+        self.plain_calls = 0
         self.rc = float(rc)
         self.dev = device
         self.rank, self.world, self.group = rank, world, group
@@ -259,6 +260,7 @@ class DomainMD:
         if self.engine is None or self.n_loc > self.capacity:
             self.capacity = int(self.n_loc * 1.15) + 1024
             self.engine = self.make_engine(self.capacity)
+            self.plain_calls = 0
         self.engine.invalidate()
         n = self.n_loc
         self.pe_loc = torch.zeros(n, dtype=torch.float64, device=self.dev)
@@ -290,6 +292,7 @@ class DomainMD:
         self.w_loc.zero_()
         self.engine.compute_levels(self.h_loc, self.pbc_loc, self.n_loc, self.t_loc, x_eng, self.level,
                                    self.pe_loc, self.f_loc, self.w_loc)
+        self.plain_calls += 1
         self.f_own.copy_(self.f_loc[:, : self.n_own])
 
     def halo_and_forces_overlapped(self):
@@ -346,9 +349,10 @@ class DomainMD:
         if self.needs_decomposition():
             self.decompose()
             self.compute_forces()
-        elif self.overlap:
+        elif self.overlap and self.plain_calls >= 4:
             self.halo_and_forces_overlapped()
         else:
+            # the engine's first four one-call evaluations also time its kernel variants (tile mode -1)
             self.halo_update()
             self.compute_forces()
         e = self.engine
