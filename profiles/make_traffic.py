@@ -12,7 +12,7 @@ import sys
 NAMES = [("CheckGatherBody", "gather_skin_check"), ("RadialTileBody", "radial_descriptor"),
          ("RadialDescBody", "radial_descriptor"), ("AngularDescBody", "angular_descriptor"),
          ("nepmi_ann_mfma", "ann"), ("AnnBody", "ann"), ("AngularForceBody", "angular_partial_force"),
-         ("ForceAssembleBody", "force_assemble"), ("VerletSeamBody", "velocity_verlet"),
+         ("ForceTileBody", "force_assemble"), ("ForceAssembleBody", "force_assemble"), ("VerletSeamBody", "velocity_verlet"),
          ("VelocityVerletBody", "velocity_verlet_unfused")]
 
 
