@@ -17,14 +17,21 @@ NAMES = [("CheckGatherBody", "gather_skin_check"), ("RadialTileBody", "radial_de
 
 
 def read(path, counter):
-    out = {}
+    """first matching NAMES entry wins per bench name, whatever the row order of the csv (e.g. the
+    window force assembly over the record-reading one, which only runs while the engine picks)"""
+    rows = []
     with open(path) as f:
         for row in csv.DictReader(f):
-            if row["counter"] != counter:
-                continue
-            for key, name in NAMES:
-                if key in row["kernel"] and name not in out:
-                    out[name] = float(row["sum_per_dispatch"])
+            if row["counter"] == counter:
+                rows.append(row)
+    out = {}
+    for key, name in NAMES:
+        if name in out:
+            continue
+        for row in rows:
+            if key in row["kernel"]:
+                out[name] = float(row["sum_per_dispatch"])
+                break
     return out
 
 
