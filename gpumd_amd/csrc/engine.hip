@@ -285,10 +285,15 @@ nepmi_ann_mfma(const ModelD m, const Bufs b, const int64_t nchunks)
 template <int BLOCK>
 __device__ __forceinline__ int block_exclusive_scan(int v, int* total);
 
-// One 256-thread workgroup per brick (RadialTileBody): stage the brick's 8x8x8-cell window in LDS,
-// then one work-item per atom of the brick.  XCD-aware brick order as in nepmi_kernel.
+// One 512-thread workgroup per brick (RadialTileBody, ForceTileBody): stage the brick's 8x8x8-cell
+// window in LDS, then TWO adjacent lanes per atom of the brick (~205 atoms), each walking every other
+// chunk of the atom's pair list (run_parts<2>): the window limits a CU to two workgroups, so the lane
+// pair is what gives it 16 wavefronts to hide the table gathers and LDS look-ups behind.
+// XCD-aware brick order as in nepmi_kernel.
+constexpr int kTileParts = 2;
 template <class Body>
-__global__ void __launch_bounds__(256) nepmi_tile_kernel(const Body body, const int64_t nbricks)
+__global__ void __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(Body::kMinWavesPerEu)))
+nepmi_tile_kernel(const Body body, const int64_t nbricks)
 {
   extern __shared__ __attribute__((aligned(16))) char nepmi_tile_lds[];
   NEPMI_LDS(char)* lds = (NEPMI_LDS(char)*)nepmi_tile_lds;
@@ -298,25 +303,26 @@ __global__ void __launch_bounds__(256) nepmi_tile_kernel(const Body body, const 
     return; // the whole workgroup leaves before the first barrier
   const int64_t brick = body.map_brick(wg);
   const int tid = (int)threadIdx.x;
-  body.stage_cells(brick, lds, tid, 256);
+  body.stage_cells(brick, lds, tid, kTileThreads);
   __syncthreads();
   {
+    static_assert(kTileThreads == 512, "one window cell per thread");
     NEPMI_LDS(int)* woff = (NEPMI_LDS(int)*)lds;
-    const int a = woff[2 * tid], c = woff[2 * tid + 1];
+    const int v = woff[tid];
     int total;
-    const int ex = block_exclusive_scan<256>(a + c, &total);
-    woff[2 * tid] = ex;
-    woff[2 * tid + 1] = ex + a;
+    const int ex = block_exclusive_scan<kTileThreads>(v, &total);
+    woff[tid] = ex;
     if (tid == 0)
       woff[512] = total;
   }
   __syncthreads();
-  body.stage_copy(lds, tid, 256);
+  body.stage_copy(lds, tid, kTileThreads);
   __syncthreads();
   int64_t a0, a1;
   body.brick_range(brick, a0, a1);
-  for (int64_t k = a0 + tid; k < a1; k += 256)
-    body.compute(k, lds);
+  const int part = tid % kTileParts;
+  for (int64_t k = a0 + tid / kTileParts; k < a1; k += kTileThreads / kTileParts)
+    body.template compute<kTileParts>(k, part, lds);
 }
 
 constexpr int kScanBlock = 256;
@@ -707,7 +713,7 @@ struct HipBackend {
     const bool t = timing_on;
     if (t)
       timer_start(timing->slot[slot]);
-    hipLaunchKernelGGL((nepmi_tile_kernel<Body>), dim3((unsigned)grid), dim3(256), lds_bytes, stream, body, nbricks);
+    hipLaunchKernelGGL((nepmi_tile_kernel<Body>), dim3((unsigned)grid), dim3(kTileThreads), lds_bytes, stream, body, nbricks);
     NEPMI_HIP_CHECK(hipGetLastError());
     if (t)
       timer_stop(timing->slot[slot]);

@@ -861,10 +861,22 @@ struct RadialDescBody {
   template <class Fetch>
   NEPMI_HD void run_with(int64_t k, const Fetch& fetch) const
   {
+    run_parts<1>(k, 0, fetch);
+  }
+
+  // PARTS lanes (1, or 2 adjacent lanes of a wavefront) share atom k: lane `part` walks the chunks
+  // part, part + PARTS, ... of the list; the compact angular slots are handed out through a
+  // prefix over the lane pair per chunk round, which keeps the sequential slot order, and the
+  // partial sums are combined at the end (NEPMI_PAIR_XCHG = exchange with the partner lane).
+  template <int PARTS, class Fetch>
+  NEPMI_HD void run_parts(int64_t k, int part, const Fetch& fetch) const
+  {
     const int64_t N = b.N;
     if (b.lvl[k] < 1) { // outer ghost: lends its position only
-      b.nn_rad[k] = 0;
-      b.nn_angstep[k] = 0;
+      if (part == 0) {
+        b.nn_rad[k] = 0;
+        b.nn_angstep[k] = 0;
+      }
       return;
     }
     const int NR = S::fixed ? S::NR : m.NR;
@@ -892,48 +904,71 @@ struct RadialDescBody {
     F4* __restrict__ rstash = b.rstash + k;
     F4* __restrict__ acomp = b.acomp + k;
     unsigned short* __restrict__ amap = b.amap + k;
+    constexpr int kStride = PARTS * kGather;
+    const int nrounds = (nn + kStride - 1) / kStride; // the same for every lane that shares the atom
     typename Fetch::Tok cur, nxt;
     if (nn > 0)
-      fetch.prefetch(0, nn, na, cur);
-    for (int s0 = 0; s0 < nn; s0 += kGather) {
+      fetch.prefetch(part * kGather < nn ? part * kGather : 0, nn, na, cur);
+    for (int r = 0; r < nrounds; ++r) {
+      const int s0 = r * kStride + part * kGather;
       int jj[kGather];
       PosQ pp[kGather];
       nxt = cur;
-      if (s0 + kGather < nn)
-        fetch.prefetch(s0 + kGather, nn, na, nxt); // next chunk's loads go out before this chunk's stores
+      if (s0 + kStride < nn)
+        fetch.prefetch(s0 + kStride, nn, na, nxt); // next chunk's loads go out before this chunk's stores
       fetch.resolve(cur, jj, pp);
       cur = nxt;
+      float xs[kGather], ys[kGather], zs[kGather], d2s[kGather];
+      int t2s[kGather];
+      bool ins[kGather], angs[kGather];
+      int mine = 0; // angular members among this lane's entries of the round
+#pragma unroll
+      for (int u = 0; u < kGather; ++u) {
+        const int idx = s0 + u;
+        const PosQ p2 = pp[u];
+        d2s[u] = pair_geometry(box, p1, p2, xs[u], ys[u], zs[u]);
+        t2s[u] = p2.type;
+        const float rc = m.uniform_rc ? m.rc_r_max : (rc1 + m.rc_r[t2s[u]]) * 0.5f;
+        const float rca = m.uniform_rc ? m.rc_a_max : (rca1 + m.rc_a[t2s[u]]) * 0.5f;
+        ins[u] = idx < nn && d2s[u] < rc * rc;
+        angs[u] = idx < na && d2s[u] < rca * rca;
+        mine += angs[u] ? 1 : 0;
+      }
+      int slot_next = ca;
+      if (PARTS > 1 && r * kStride < na) { // pair-uniform: a chunk of this round touches list A
+        const int other = NEPMI_PAIR_XCHG(mine);
+        slot_next = ca + (part == 0 ? 0 : other);
+        ca += mine + other;
+      } else {
+        ca += mine;
+      }
 #pragma unroll
       for (int u = 0; u < kGather; ++u) {
         const int idx = s0 + u;
         if (idx >= nn)
           continue;
-        const int j = jj[u];
-        const PosQ p2 = pp[u];
-        float x, y, z;
-        const float d2 = pair_geometry(box, p1, p2, x, y, z);
-        const int t2 = p2.type;
+        const int t2 = t2s[u];
+        const float d2 = d2s[u];
+        const bool inside = ins[u];
         const float rc = m.uniform_rc ? m.rc_r_max : (rc1 + m.rc_r[t2]) * 0.5f;
-        const bool inside = d2 < rc * rc;
         // The pair record goes to the Verlet row itself (not a compacted slot): every lane of
         // the wavefront stores to the same row -> one contiguous 1 KiB store per slot.
         F4 e;
-        e.x = x;
-        e.y = y;
-        e.z = z;
-        e.w = inside ? (int)((unsigned)j | ((unsigned)t2 << kIdxBits)) : -1;
+        e.x = xs[u];
+        e.y = ys[u];
+        e.z = zs[u];
+        e.w = inside ? (int)((unsigned)jj[u] | ((unsigned)t2 << kIdxBits)) : -1;
         const int row = idx < na ? idx : b.MN_ang + (idx - na);
         if (write_records)
           rstash[(int64_t)row * N] = e;
         if (idx < na) {
-          const float rca = m.uniform_rc ? m.rc_a_max : (rca1 + m.rc_a[t2]) * 0.5f;
           unsigned short slot = kNoSlot;
-          if (d2 < rca * rca) {
-            if (ca < b.MN_acomp) {
-              acomp[(int64_t)ca * N] = e;
-              slot = (unsigned short)ca;
+          if (angs[u]) {
+            if (slot_next < b.MN_acomp) {
+              acomp[(int64_t)slot_next * N] = e;
+              slot = (unsigned short)slot_next;
             }
-            ++ca;
+            ++slot_next;
           }
           amap[(int64_t)idx * N] = slot;
         }
@@ -981,12 +1016,29 @@ struct RadialDescBody {
         }
       }
     }
+    if (PARTS > 1) { // totals on both lanes of the pair
+      cnt += NEPMI_PAIR_XCHG(cnt);
+      if (S::TS > 0) {
+#pragma unroll
+        for (int t = 0; t < TSM; ++t)
+#pragma unroll
+          for (int kk = 0; kk <= S::KRM; ++kk)
+            Ssum[t][kk] += NEPMI_PAIR_XCHG(Ssum[t][kk]);
+      } else {
+#pragma unroll
+        for (int n = 0; n <= S::NRM; ++n)
+          q[n] += NEPMI_PAIR_XCHG(q[n]);
+      }
+    }
     if (ca > b.MN_acomp) {
-      NEPMI_ATOMIC_OR(&b.flags[kFlagOverflow], 4);
+      if (part == 0)
+        NEPMI_ATOMIC_OR(&b.flags[kFlagOverflow], 4);
       ca = b.MN_acomp;
     }
-    b.nn_rad[k] = cnt;
-    b.nn_angstep[k] = ca;
+    if (part == 0) {
+      b.nn_rad[k] = cnt;
+      b.nn_angstep[k] = ca;
+    }
 
     if (S::TS > 0) {
       // q[n] = sum_t2 sum_k c[t1][t2][n][k] S[t2][k]; type loop is wave-uniform => scalar loads
@@ -1013,10 +1065,12 @@ struct RadialDescBody {
         }
       }
     }
-    for (int n = 0; n <= NR; ++n)
-      b.q[(int64_t)n * N + b.tpos[k]] = q[n] * m.qscale[n];
+    if (part == 0)
+      for (int n = 0; n <= NR; ++n)
+        b.q[(int64_t)n * N + b.tpos[k]] = q[n] * m.qscale[n];
   }
 };
+
 
 // The LDS-window variant of the radial pass.  One 256-thread workgroup per brick (4x4x4 cells,
 // ~200 atoms): it stages the positions of every atom of the brick's 8x8x8-cell window (~1,700
@@ -1028,7 +1082,7 @@ struct RadialDescBody {
 //
 // LDS layout (bytes): [0, 2052) int woff[513] | [2052+, ...) int wstart[512] | double wx[W] wy[W] wz[W]
 // | int wword[W] (global index | type << 25).
-constexpr int kTileThreads = 256;
+constexpr int kTileThreads = 512; // workgroup of the window kernels (engine.hip: nepmi_tile_kernel)
 constexpr int kWinCells = 512;
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1056,6 +1110,7 @@ struct RadialTileBody {
   TileLayout lay;
   int first; // workgroup w runs brick_order[first + w] (first < 0: brick w)
   int write_records;
+  static constexpr int kMinWavesPerEu = 1; // no register cap (it already fits two workgroups per CU)
 
   NEPMI_HD int lds_bytes() const { return lay.bytes(); }
   NEPMI_HD int64_t map_brick(int64_t w) const { return first < 0 ? w : (int64_t)b.brick_order[first + w]; }
@@ -1112,7 +1167,7 @@ struct RadialTileBody {
     }
   }
 
-  template <class LC>
+  template <class LC, int G = kGather>
   struct TileFetch {
     const unsigned short* cA;
     const unsigned short* cB;
@@ -1120,12 +1175,12 @@ struct RadialTileBody {
     LC lds;
     TileLayout lay;
     struct Tok {
-      unsigned code[kGather];
+      unsigned code[G];
     };
     NEPMI_HD void prefetch(int s0, int nn, int na, Tok& t) const
     {
 #pragma unroll
-      for (int u = 0; u < kGather; ++u) {
+      for (int u = 0; u < G; ++u) {
         const int idx = s0 + u < nn ? s0 + u : nn - 1;
         t.code[u] = idx < na ? cA[(int64_t)idx * N] : cB[(int64_t)(idx - na) * N];
       }
@@ -1138,7 +1193,7 @@ struct RadialTileBody {
       NEPMI_LDS(const double)* wz = (NEPMI_LDS(const double)*)(lds + lay.off_z());
       NEPMI_LDS(const int)* wword = (NEPMI_LDS(const int)*)(lds + lay.off_word());
 #pragma unroll
-      for (int u = 0; u < kGather; ++u) {
+      for (int u = 0; u < G; ++u) {
         const int w = woff[t.code[u] >> 7] + (int)(t.code[u] & 127u);
         const unsigned word = (unsigned)wword[w];
         jj[u] = (int)(word & (unsigned)kIdxMask);
@@ -1158,11 +1213,11 @@ struct RadialTileBody {
     a1 = b.cell_count[brick * 64 + 64];
   }
 
-  template <class LC>
-  NEPMI_HD void compute(int64_t k, LC lds) const
+  template <int PARTS, class LC>
+  NEPMI_HD void compute(int64_t k, int part, LC lds) const
   {
     const RadialDescBody<S> body{box, m, b, write_records};
-    body.run_with(k, TileFetch<LC>{b.code_ang + k, b.code_skin + k, b.N, lds, lay});
+    body.template run_parts<PARTS>(k, part, TileFetch<LC>{b.code_ang + k, b.code_skin + k, b.N, lds, lay});
   }
 };
 
@@ -1581,11 +1636,12 @@ struct ForceAssembleBody {
     int MN_ang;
     struct State {
     };
-    NEPMI_HD void begin(int, int, State&) const {}
-    NEPMI_HD void load(int s0, int nn, int na, State&, F4* ee) const
+    NEPMI_HD void begin(int, int, int, int, State&) const {}
+    template <int G>
+    NEPMI_HD void load(int s0, int, int nn, int na, State&, F4* ee) const
     {
 #pragma unroll
-      for (int u = 0; u < kGather; ++u) {
+      for (int u = 0; u < G; ++u) {
         const int idx = s0 + u < nn ? s0 + u : nn - 1;
         const int row = idx < na ? idx : MN_ang + (idx - na);
         ee[u] = rstash[(int64_t)row * N];
@@ -1602,6 +1658,16 @@ struct ForceAssembleBody {
   // slots): r12 and (j | t2 << kIdxBits), or -1 when the pair is outside the radial cutoff
   template <class Src>
   NEPMI_HD void run_with(int64_t k, const Src& src) const
+  {
+    run_parts<1, kGather>(k, 0, src);
+  }
+
+  // PARTS lanes share atom k (see RadialDescBody::run_parts): lane `part` takes every PARTS-th
+  // chunk of the pair list; forces and virials are linear in the pairs, so the partial sums are
+  // simply added across the lane pair at the end.
+  // G = pair entries per lane and chunk (their table gathers are issued together)
+  template <int PARTS, int G, class Src>
+  NEPMI_HD void run_parts(int64_t k, int part, const Src& src) const
   {
     const int64_t N = b.N;
     if (b.lvl[k] < 2) // forces only for owned atoms
@@ -1631,14 +1697,15 @@ struct ForceAssembleBody {
     const unsigned short* __restrict__ rev = b.rev_ang + k;
     const F4* __restrict__ f12 = b.f12;
     typename Src::State st;
+    constexpr int kStride = PARTS * G;
     if (nn > 0)
-      src.begin(nn, na, st);
-    for (int s0 = 0; s0 < nn; s0 += kGather) {
-      F4 ee[kGather];
-      float Aj[kGather][S::KRM + 1];
-      src.load(s0, nn, na, st, ee);
+      src.begin(part * G, kStride, nn, na, st);
+    for (int s0 = part * G; s0 < nn; s0 += kStride) {
+      F4 ee[G];
+      float Aj[G][S::KRM + 1];
+      src.template load<G>(s0, kStride, nn, na, st, ee);
 #pragma unroll
-      for (int u = 0; u < kGather; ++u) {
+      for (int u = 0; u < G; ++u) {
         const int j = ee[u].w == -1 ? (int)k : (int)((unsigned)ee[u].w & (unsigned)kIdxMask);
         const float* row = atab + (size_t)j * arow + t1 * KRP;
 #pragma unroll
@@ -1649,7 +1716,7 @@ struct ForceAssembleBody {
         }
       }
 #pragma unroll
-      for (int u = 0; u < kGather; ++u) {
+      for (int u = 0; u < G; ++u) {
         const int idx = s0 + u;
         // branch-free radial part: invalid records (past the end / outside rc) run with weight 0
         const F4 e = ee[u];
@@ -1730,6 +1797,19 @@ struct ForceAssembleBody {
       }
     }
 
+    if (PARTS > 1) {
+#pragma unroll
+      for (int d = 0; d < 3; ++d)
+        F[d] += NEPMI_PAIR_XCHG(F[d]);
+#pragma unroll
+      for (int d = 0; d < 6; ++d)
+        W[d] += NEPMI_PAIR_XCHG(W[d]);
+#pragma unroll
+      for (int d = 0; d < 9; ++d)
+        Wa[d] += NEPMI_PAIR_XCHG(Wa[d]);
+      if (part != 0)
+        return;
+    }
     double E = (double)b.pe_i[k];
     double Fd[3] = {(double)F[0], (double)F[1], (double)F[2]};
     double Wd[9];
@@ -1772,6 +1852,7 @@ struct ForceAssembleBody {
 // per atom and step for PbTe).  Tables of the neighbours are still gathered from L2 by index.
 template <class S>
 struct ForceTileBody {
+  static constexpr int kMinWavesPerEu = 4; // two 512-thread workgroups per CU: <= 128 VGPRs
   RadialTileBody<S> rt; // staging (stage_cells / stage_copy / brick_range / map_brick), box, model, buffers
   double* pe;
   double* force;
@@ -1785,28 +1866,31 @@ struct ForceTileBody {
   NEPMI_HD void stage_copy(LC lds, int tid, int nth) const { rt.stage_copy(lds, tid, nth); }
   NEPMI_HD void brick_range(int64_t brick, int64_t& a0, int64_t& a1) const { rt.brick_range(brick, a0, a1); }
 
-  template <class LC>
+  template <class LC, int G>
   struct WindowSource {
-    typename RadialTileBody<S>::template TileFetch<LC> fetch;
+    typedef typename RadialTileBody<S>::template TileFetch<LC, G> Fetch;
+    Fetch fetch;
     BoxD box;
     ModelD m;
     PosQ p1;
     float rc1;
     struct State {
-      typename RadialTileBody<S>::template TileFetch<LC>::Tok cur;
+      typename Fetch::Tok cur;
     };
-    NEPMI_HD void begin(int nn, int na, State& st) const { fetch.prefetch(0, nn, na, st.cur); }
-    NEPMI_HD void load(int s0, int nn, int na, State& st, F4* ee) const
+    NEPMI_HD void begin(int s0, int, int nn, int na, State& st) const { fetch.prefetch(s0, nn, na, st.cur); }
+    template <int GG>
+    NEPMI_HD void load(int s0, int stride, int nn, int na, State& st, F4* ee) const
     {
-      int jj[kGather];
-      PosQ pp[kGather];
-      typename RadialTileBody<S>::template TileFetch<LC>::Tok nxt = st.cur;
-      if (s0 + kGather < nn)
-        fetch.prefetch(s0 + kGather, nn, na, nxt);
+      static_assert(GG == G, "chunk size of the source and of the walk differ");
+      int jj[G];
+      PosQ pp[G];
+      typename Fetch::Tok nxt = st.cur;
+      if (s0 + stride < nn)
+        fetch.prefetch(s0 + stride, nn, na, nxt);
       fetch.resolve(st.cur, jj, pp);
       st.cur = nxt;
 #pragma unroll
-      for (int u = 0; u < kGather; ++u) {
+      for (int u = 0; u < G; ++u) {
         float x, y, z;
         const float d2 = pair_geometry(box, p1, pp[u], x, y, z);
         const int t2 = pp[u].type;
@@ -1819,12 +1903,13 @@ struct ForceTileBody {
     }
   };
 
-  template <class LC>
-  NEPMI_HD void compute(int64_t k, LC lds) const
+  template <int PARTS, class LC>
+  NEPMI_HD void compute(int64_t k, int part, LC lds) const
   {
     const ForceAssembleBody<S> fa{rt.m, rt.b, pe, force, virial};
     const PosQ p1 = rt.b.posq[k];
-    fa.run_with(k, WindowSource<LC>{{rt.b.code_ang + k, rt.b.code_skin + k, rt.b.N, lds, rt.lay}, rt.box, rt.m, p1,
+    constexpr int G = kGather / PARTS;
+    fa.template run_parts<PARTS, G>(k, part, WindowSource<LC, G>{{rt.b.code_ang + k, rt.b.code_skin + k, rt.b.N, lds, rt.lay}, rt.box, rt.m, p1,
                                     rt.m.rc_r[p1.type]});
   }
 };

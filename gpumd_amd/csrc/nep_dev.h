@@ -20,8 +20,10 @@
 
 #if defined(__HIP_DEVICE_COMPILE__)
 #define NEPMI_WAVE_ANY(pred) (__any((int)(pred)))
+#define NEPMI_PAIR_XCHG(v) (__shfl_xor((v), 1)) // value held by the partner lane (lanes 2i, 2i+1)
 #else
 #define NEPMI_WAVE_ANY(pred) (pred)
+#define NEPMI_PAIR_XCHG(v) (v) // host loops run one lane per atom: never reached with PARTS > 1
 #endif
 
 namespace nepmi {

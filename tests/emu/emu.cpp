@@ -71,7 +71,7 @@ struct HostLoopBackend {
       int64_t a0, a1;
       body.brick_range(brick, a0, a1);
       for (int64_t k = a0; k < a1; ++k)
-        body.compute(k, lds);
+        body.template compute<1>(k, 0, lds);
     }
   }
 
