@@ -281,6 +281,21 @@ nepmi_ann_mfma(const ModelD m, const Bufs b, const int64_t nchunks)
   }
 }
 
+// Two adjacent lanes per atom (Body::run_parts<2>): for bodies whose per-atom register table is what
+// limits them to one wavefront per SIMD (angular force).
+template <int BLOCK, class Body>
+__global__ void __launch_bounds__(BLOCK) nepmi_kernel_lds_pairs(const Body body, const int64_t n)
+{
+  extern __shared__ __attribute__((aligned(16))) float nepmi_lds_pairs[];
+  body.lds_stage(nepmi_lds_pairs, (int)threadIdx.x, BLOCK);
+  __syncthreads();
+  const unsigned per_xcd = gridDim.x >> 3;
+  const unsigned tile = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+  const int64_t i = ((int64_t)tile * BLOCK + threadIdx.x) >> 1;
+  if (i < n)
+    body.template run_parts<2>(i, (int)(threadIdx.x & 1u), (lds_cfloat_ptr)nepmi_lds_pairs);
+}
+
 // ---- exclusive scan of int32, in place: 3 kernels (block scan, scan of block sums, add) ----
 template <int BLOCK>
 __device__ __forceinline__ int block_exclusive_scan(int v, int* total);
@@ -734,6 +749,27 @@ struct HipBackend {
     if (t)
       timer_start(timing->slot[slot]);
     hipLaunchKernelGGL((nepmi_kernel_lds<BLOCK, Body>), dim3((unsigned)grid), dim3(BLOCK), lds_bytes, stream, body, n);
+    NEPMI_HIP_CHECK(hipGetLastError());
+    if (t)
+      timer_stop(timing->slot[slot]);
+  }
+
+  template <int BLOCK, class Body>
+  void launch_lds_pairs(int slot, int64_t n, const Body& body)
+  {
+    if (n <= 0)
+      return;
+    const int64_t grid = ((2 * n + BLOCK - 1) / BLOCK + 7) / 8 * 8;
+    const size_t lds_bytes = ((size_t)body.lds_floats() * sizeof(float) + 15) / 16 * 16;
+    if (lds_bytes > 64 * 1024)
+      NEPMI_HIP_CHECK(hipFuncSetAttribute(
+        reinterpret_cast<const void*>(&nepmi_kernel_lds_pairs<BLOCK, Body>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    const bool t = timing_on;
+    if (t)
+      timer_start(timing->slot[slot]);
+    hipLaunchKernelGGL((nepmi_kernel_lds_pairs<BLOCK, Body>), dim3((unsigned)grid), dim3(BLOCK), lds_bytes, stream,
+                       body, n);
     NEPMI_HIP_CHECK(hipGetLastError());
     if (t)
       timer_stop(timing->slot[slot]);

@@ -639,7 +639,7 @@ private:
     be_.template launch<64>(kSlotRadial, N_, RadialFromRecordsBody<S>{md_, b_});
     be_.template launch_lds<64>(kSlotAngular, N_, AngularDescBody<S>{md_, b_, recompute_s()});
     be_.template launch_ann<S>(kSlotAnn, N_, md_, b_, false); // identity work order, no type groups
-    be_.template launch_lds<64>(kSlotAngForce, N_, AngularForceBody<S>{md_, b_, recompute_s()});
+    launch_angular_force<S>();
     be_.template launch<64>(kSlotForce, N_, ForceAssembleBody<S>{md_, b_, pe, force, virial});
   }
 
@@ -747,6 +747,18 @@ private:
     ++num_rebuild;
   }
 
+  // Angular force: with >= 7 radial channels the per-atom table G (24 floats per channel) holds the
+  // kernel at one wavefront per SIMD; two lanes per atom (channels split between them) bring it to two.
+  // With fewer channels the one-lane form already runs two wavefronts and the split only adds work.
+  template <class S>
+  void launch_angular_force()
+  {
+    if (S::fixed && S::NA + 1 >= 7)
+      be_.template launch_lds_pairs<64>(kSlotAngForce, N_, AngularForceBody<S>{md_, b_, recompute_s()});
+    else
+      be_.template launch_lds<64>(kSlotAngForce, N_, AngularForceBody<S>{md_, b_, recompute_s()});
+  }
+
   // ---- shape dispatch ----
   using S_PbTeA = Shape<6, 6, 6, 6, 5, 2>;   // examples/nep_train/nep.txt
   using S_PbTeB = Shape<4, 8, 4, 8, 5, 2>;   // tests/gpumd/dump_observer/PbTe_species/PbTe.txt
@@ -832,7 +844,7 @@ private:
       be_.template launch<64>(kSlotRadial, N_, RadialDescBody<S>{box_, md_, b_, 1});
     be_.template launch_lds<64>(kSlotAngular, N_, AngularDescBody<S>{md_, b_, recompute_s()});
     be_.template launch_ann<S>(kSlotAnn, N_, md_, b_, true);
-    be_.template launch_lds<64>(kSlotAngForce, N_, AngularForceBody<S>{md_, b_, recompute_s()});
+    launch_angular_force<S>();
     if (force_tile)
       be_.launch_tile(kSlotForce, num_bricks_,
                       ForceTileBody<S>{RadialTileBody<S>{box_, md_, b_, tile_, -1, 0}, pe, force, virial});

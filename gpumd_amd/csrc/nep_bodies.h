@@ -1268,16 +1268,19 @@ struct RadialFromRecordsBody {
 // s_{n,lm}(i) = sum_j g_n(r_ij) b_lm(rhat_ij) over the compacted angular pair records of atom k
 // (find_descriptor, nep.cu:588-610 + accumulate_s).  Shared by the angular descriptor kernel and by
 // the angular force kernel's recompute path, so that both see bit-identical sums.
-template <class S, class LP>
-NEPMI_HD void angular_s_sums(const ModelD& m, const Bufs& b, int64_t k, int t1, LP cang, float* s)
+template <class S, int PARTS, class LP>
+NEPMI_HD void angular_s_sums(const ModelD& m, const Bufs& b, int64_t k, int t1, LP cang, int part, float* s)
 {
+  // PARTS lanes share the atom: lane `part` owns the radial channels n = part, part + PARTS, ... and
+  // keeps them at local rows i = 0, 1, ... of s (PARTS == 1: all channels, row i = n)
+  constexpr int NLOC = (S::NAM + PARTS) / PARTS;
   const int64_t N = b.N;
   const int NA = S::fixed ? S::NA : m.NA;
   const int KA = S::fixed ? S::KA : m.KA;
   const float rc1 = m.rc_a[t1];
   const int cstride = cang_stride(m);
 #pragma unroll
-  for (int a = 0; a < (S::NAM + 1) * kNumHarm; ++a)
+  for (int a = 0; a < NLOC * kNumHarm; ++a)
     s[a] = 0.0f;
   const int na = b.nn_angstep[k];
   const F4* __restrict__ acomp = b.acomp + k;
@@ -1305,8 +1308,9 @@ NEPMI_HD void angular_s_sums(const ModelD& m, const Bufs& b, int64_t k, int t1, 
     harmonics(x * dinv, y * dinv, z * dinv, bh);
     LP c = cang + (t1 * m.T + t2) * cstride;
 #pragma unroll
-    for (int n = 0; n <= S::NAM; ++n) {
-      if (!S::fixed && n > NA)
+    for (int i = 0; i < NLOC; ++i) {
+      const int n = part + PARTS * i;
+      if (n > NA)
         break;
       float g = 0.0f;
 #pragma unroll
@@ -1317,7 +1321,7 @@ NEPMI_HD void angular_s_sums(const ModelD& m, const Bufs& b, int64_t k, int t1, 
       }
 #pragma unroll
       for (int h = 0; h < kNumHarm; ++h)
-        s[n * kNumHarm + h] = fmaf(g, bh[h], s[n * kNumHarm + h]);
+        s[i * kNumHarm + h] = fmaf(g, bh[h], s[i * kNumHarm + h]);
     }
   }
 }
@@ -1347,7 +1351,7 @@ struct AngularDescBody {
     const float rc1 = m.rc_a[t1];
     const int cstride = cang_stride(m);
     float s[(S::NAM + 1) * kNumHarm];
-    angular_s_sums<S>(m, b, k, t1, cang, s);
+    angular_s_sums<S, 1>(m, b, k, t1, cang, 0, s);
 
 #pragma unroll
     for (int n = 0; n <= S::NAM; ++n) {
@@ -1483,6 +1487,18 @@ struct AngularForceBody {
   template <class LP>
   NEPMI_HD void run(int64_t k, LP cang) const
   {
+    run_parts<1>(k, 0, cang);
+  }
+
+  // PARTS lanes (2 = an adjacent lane pair) share the atom: lane `part` holds the rows of G of the radial
+  // channels n = part, part + PARTS, ... only (half the registers: two wavefronts per SIMD instead of
+  // one), forms its share of P and Q, contracts it with the harmonics -- the contraction is linear, so
+  // the partial (w, v) are simply added across the pair -- and lane 0 writes f12.  Same instruction
+  // stream on both lanes: no divergence.
+  template <int PARTS, class LP>
+  NEPMI_HD void run_parts(int64_t k, int part, LP cang) const
+  {
+    constexpr int NLOC = (S::NAM + PARTS) / PARTS;
     const int64_t N = b.N;
     if (b.lvl[k] < 1)
       return;
@@ -1494,12 +1510,13 @@ struct AngularForceBody {
     const float rc1 = m.rc_a[t1];
     const int cstride = cang_stride(m);
 
-    float G[(S::NAM + 1) * kNumHarm];
+    float G[NLOC * kNumHarm];
     if (recompute_s)
-      angular_s_sums<S>(m, b, k, t1, cang, G);
+      angular_s_sums<S, PARTS>(m, b, k, t1, cang, part, G);
 #pragma unroll
-    for (int n = 0; n <= S::NAM; ++n) {
-      if (!S::fixed && n > NA)
+    for (int i = 0; i < NLOC; ++i) {
+      const int n = part + PARTS * i;
+      if (n > NA)
         break;
       float fpn[6];
 #pragma unroll
@@ -1508,9 +1525,9 @@ struct AngularForceBody {
       if (!recompute_s) {
 #pragma unroll
         for (int h = 0; h < kNumHarm; ++h)
-          G[n * kNumHarm + h] = b.sbuf[(int64_t)(n * kNumHarm + h) * N + k];
+          G[i * kNumHarm + h] = b.sbuf[(int64_t)(n * kNumHarm + h) * N + k];
       }
-      invariants_adjoint(m, fpn, 1, &G[n * kNumHarm]);
+      invariants_adjoint(m, fpn, 1, &G[i * kNumHarm]);
     }
 
     float zf[3] = {0, 0, 0}, zv[6] = {0, 0, 0, 0, 0, 0}, zpe = 0.0f;
@@ -1550,8 +1567,9 @@ struct AngularForceBody {
         P[h] = Q[h] = 0.0f;
       LP c = cang + (t1 * m.T + t2) * cstride;
 #pragma unroll
-      for (int n = 0; n <= S::NAM; ++n) {
-        if (!S::fixed && n > NA)
+      for (int i = 0; i < NLOC; ++i) {
+        const int n = part + PARTS * i;
+        if (n > NA)
           break;
         float g = 0.0f, gp = 0.0f;
 #pragma unroll
@@ -1564,22 +1582,30 @@ struct AngularForceBody {
         }
 #pragma unroll
         for (int h = 0; h < kNumHarm; ++h) {
-          P[h] = fmaf(G[n * kNumHarm + h], g, P[h]);
-          Q[h] = fmaf(G[n * kNumHarm + h], gp, Q[h]);
+          P[h] = fmaf(G[i * kNumHarm + h], g, P[h]);
+          Q[h] = fmaf(G[i * kNumHarm + h], gp, Q[h]);
         }
       }
       const float ux = x * dinv, uy = y * dinv, uz = z * dinv;
       float w, vx, vy, vz;
       harmonics_contract(ux, uy, uz, P, Q, w, vx, vy, vz);
+      if (PARTS > 1) {
+        w += NEPMI_PAIR_XCHG(w);
+        vx += NEPMI_PAIR_XCHG(vx);
+        vy += NEPMI_PAIR_XCHG(vy);
+        vz += NEPMI_PAIR_XCHG(vz);
+      }
       const float udv = ux * vx + uy * vy + uz * vz;
       F4 out;
       out.x = ux * w + (vx - ux * udv) * dinv;
       out.y = uy * w + (vy - uy * udv) * dinv;
       out.z = uz * w + (vz - uz * udv) * dinv;
       out.w = 0;
-      f12[(int64_t)a * N] = out;
+      if (part == 0)
+        f12[(int64_t)a * N] = out;
 
-      if (m.zbl_enabled) {
+      // ZBL is per pair and independent of the channel split: the lanes take alternate neighbours
+      if (m.zbl_enabled && (PARTS == 1 || (a % PARTS) == part)) {
         const int zj = m.atomic_number[t2];
         const float a_inv = (pzi + powf((float)zj, 0.23f)) * 2.134563f;
         const float zizj = 14.399645f * (float)zi * (float)zj;
@@ -1605,7 +1631,16 @@ struct AngularForceBody {
         zpe += f * 0.5f;
       }
     }
-    if (m.zbl_enabled) {
+    if (m.zbl_enabled && PARTS > 1) {
+#pragma unroll
+      for (int d = 0; d < 3; ++d)
+        zf[d] += NEPMI_PAIR_XCHG(zf[d]);
+#pragma unroll
+      for (int d = 0; d < 6; ++d)
+        zv[d] += NEPMI_PAIR_XCHG(zv[d]);
+      zpe += NEPMI_PAIR_XCHG(zpe);
+    }
+    if (m.zbl_enabled && part == 0) {
 #pragma unroll
       for (int d = 0; d < 3; ++d)
         b.zbl[(int64_t)d * N + k] = zf[d];

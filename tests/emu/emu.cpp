@@ -85,6 +85,13 @@ struct HostLoopBackend {
       body.run(i, (const float*)lds.data());
   }
 
+  // the device runs these bodies with two lanes per atom; the host loop runs the one-lane form
+  template <int BLOCK, class Body>
+  void launch_lds_pairs(int slot, int64_t n, const Body& body)
+  {
+    launch_lds<BLOCK>(slot, n, body);
+  }
+
   void exclusive_scan(int* data, int64_t n, int*)
   {
     int run = 0;
