@@ -637,7 +637,7 @@ private:
   void small_force_kernels_shape(double* pe, double* force, double* virial)
   {
     be_.template launch<64>(kSlotRadial, N_, RadialFromRecordsBody<S>{md_, b_});
-    be_.template launch_lds<64>(kSlotAngular, N_, AngularDescBody<S>{md_, b_, recompute_s()});
+    launch_angular_desc<S>();
     be_.template launch_ann<S>(kSlotAnn, N_, md_, b_, false); // identity work order, no type groups
     launch_angular_force<S>();
     be_.template launch<64>(kSlotForce, N_, ForceAssembleBody<S>{md_, b_, pe, force, virial});
@@ -751,6 +751,16 @@ private:
   // kernel at one wavefront per SIMD; two lanes per atom (channels split between them) bring it to two.
   // With fewer channels the one-lane form already runs two wavefronts and the split only adds work.
   template <class S>
+  void launch_angular_desc()
+  {
+    // the descriptor kernel carries only the sums (no P/Q): it drops to one wavefront per SIMD from 9 channels on
+    if (S::fixed && S::NA + 1 >= 9)
+      be_.template launch_lds_pairs<64>(kSlotAngular, N_, AngularDescBody<S>{md_, b_, recompute_s()});
+    else
+      be_.template launch_lds<64>(kSlotAngular, N_, AngularDescBody<S>{md_, b_, recompute_s()});
+  }
+
+  template <class S>
   void launch_angular_force()
   {
     if (S::fixed && S::NA + 1 >= 7)
@@ -842,7 +852,7 @@ private:
       be_.launch_tile(kSlotRadial, num_bricks_, RadialTileBody<S>{box_, md_, b_, tile_, -1, records});
     else
       be_.template launch<64>(kSlotRadial, N_, RadialDescBody<S>{box_, md_, b_, 1});
-    be_.template launch_lds<64>(kSlotAngular, N_, AngularDescBody<S>{md_, b_, recompute_s()});
+    launch_angular_desc<S>();
     be_.template launch_ann<S>(kSlotAnn, N_, md_, b_, true);
     launch_angular_force<S>();
     if (force_tile)

@@ -1340,30 +1340,37 @@ struct AngularDescBody {
   template <class LP>
   NEPMI_HD void run(int64_t k, LP cang) const
   {
+    run_parts<1>(k, 0, cang);
+  }
+
+  // PARTS lanes share the atom, each owning the radial channels n = part, part + PARTS, ...: the sums
+  // and the invariants of a channel never leave its lane, so there is nothing to combine.
+  template <int PARTS, class LP>
+  NEPMI_HD void run_parts(int64_t k, int part, LP cang) const
+  {
+    constexpr int NLOC = (S::NAM + PARTS) / PARTS;
     const int64_t N = b.N;
     if (b.lvl[k] < 1)
       return;
     const int64_t gk = b.tpos[k]; // q / fp column of this atom (work order)
     const int NR = S::fixed ? S::NR : m.NR;
     const int NA = S::fixed ? S::NA : m.NA;
-    const int KA = S::fixed ? S::KA : m.KA;
     const int t1 = b.posq[k].type;
-    const float rc1 = m.rc_a[t1];
-    const int cstride = cang_stride(m);
-    float s[(S::NAM + 1) * kNumHarm];
-    angular_s_sums<S, 1>(m, b, k, t1, cang, 0, s);
+    float s[NLOC * kNumHarm];
+    angular_s_sums<S, PARTS>(m, b, k, t1, cang, part, s);
 
 #pragma unroll
-    for (int n = 0; n <= S::NAM; ++n) {
-      if (!S::fixed && n > NA)
+    for (int i = 0; i < NLOC; ++i) {
+      const int n = part + PARTS * i;
+      if (n > NA)
         break;
       if (!recompute_s) {
 #pragma unroll
         for (int h = 0; h < kNumHarm; ++h)
-          b.sbuf[(int64_t)(n * kNumHarm + h) * N + k] = s[n * kNumHarm + h];
+          b.sbuf[(int64_t)(n * kNumHarm + h) * N + k] = s[i * kNumHarm + h];
       }
       float qn[6];
-      invariants(m, &s[n * kNumHarm], qn, 1);
+      invariants(m, &s[i * kNumHarm], qn, 1);
       for (int L = 0; L < m.numL; ++L) {
         const int d = (NR + 1) + L * (NA + 1) + n;
         b.q[(int64_t)d * N + gk] = qn[L] * m.qscale[d];
