@@ -17,6 +17,8 @@
 // find_partial_force_angular, gpu_find_force_many_body, find_force_ZBL (src/force/nep.cu:436-975,
 // src/force/potential.cu:170-297).
 #pragma once
+#include <type_traits>
+
 #include "nep_dev.h"
 
 namespace nepmi {
@@ -1742,7 +1744,10 @@ struct ForceAssembleBody {
     constexpr int kStride = PARTS * G;
     if (nn > 0)
       src.begin(part * G, kStride, nn, na, st);
-    for (int s0 = part * G; s0 < nn; s0 += kStride) {
+    // one chunk of the walk; WITH_ANG = the chunk can still contain list-A entries (s0 < na): only
+    // those carry the f12 - f21 code, the long list-B tail runs a branch-free radial-only body
+    auto chunk = [&](const int s0, auto with_ang) {
+      constexpr bool WITH_ANG = decltype(with_ang)::value;
       F4 ee[G];
       float Aj[G][S::KRM + 1];
       src.template load<G>(s0, kStride, nn, na, st, ee);
@@ -1815,7 +1820,7 @@ struct ForceAssembleBody {
         W[4] -= x * bz;
         W[5] -= y * bz;
 
-        if (valid && idx < na) {
+        if (WITH_ANG && valid && idx < na) {
           const unsigned short a = amap[(int64_t)idx * N + k];
           if (a != kNoSlot) {
             const int rs = rev[(int64_t)idx * N];
@@ -1837,7 +1842,12 @@ struct ForceAssembleBody {
           }
         }
       }
-    }
+    };
+    int s0 = part * G;
+    for (; s0 < na; s0 += kStride)
+      chunk(s0, std::true_type{});
+    for (; s0 < nn; s0 += kStride)
+      chunk(s0, std::false_type{});
 
     if (PARTS > 1) {
 #pragma unroll
