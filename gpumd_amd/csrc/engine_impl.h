@@ -72,6 +72,13 @@ inline void box_from_h9(const double h9[9], const int pbc[3], BoxD& box)
   box.thickness[0] = box.volume / cross_norm(bb, c);
   box.thickness[1] = box.volume / cross_norm(c, a);
   box.thickness[2] = box.volume / cross_norm(a, bb);
+  // a displacement shorter than this has all fractional components below 1/2: the fractional minimum
+  // image leaves it where it is
+  double tmin = 1.0e30;
+  for (int d = 0; d < 3; ++d)
+    if (box.pbc[d] && box.thickness[d] < tmin)
+      tmin = box.thickness[d];
+  box.rfree2 = tmin < 1.0e29 ? (float)(0.49 * tmin * 0.49 * tmin) : 3.0e38f;
 }
 
 template <class B>

@@ -1944,7 +1944,7 @@ struct ForceTileBody {
 #pragma unroll
       for (int u = 0; u < G; ++u) {
         float x, y, z;
-        const float d2 = pair_geometry(box, p1, pp[u], x, y, z);
+        const float d2 = pair_geometry_fast(box, p1, pp[u], x, y, z);
         const int t2 = pp[u].type;
         const float rc = m.uniform_rc ? m.rc_r_max : (rc1 + m.rc_r[t2]) * 0.5f;
         ee[u].x = x;

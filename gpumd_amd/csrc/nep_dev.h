@@ -85,6 +85,7 @@ struct BoxD {
   double volume;
   int pbc[3];
   int ortho;
+  float rfree2; // (0.49 min periodic thickness)^2: shorter displacements need no periodic image
 };
 
 struct ModelD {
@@ -156,6 +157,27 @@ NEPMI_HD float pair_geometry(const BoxD& box, const PosQ& a, const PosQ& b, floa
   z = (float)(b.z - a.z);
   mic_f(box, x, y, z);
   return dot3f(x, x, y, y, z, z);
+}
+
+// The same pair vector for kernels that do not take list decisions (force assembly): in a triclinic
+// box the float minimum image is a fractional round trip H (H^-1 r - n) per pair; when no lane of the
+// wavefront has a displacement long enough to need an image (every brick away from the box faces) it
+// is skipped.  r12 then differs from pair_geometry's by the round trip's rounding (~1e-7 relative).
+NEPMI_HD float pair_geometry_fast(const BoxD& box, const PosQ& a, const PosQ& b, float& x, float& y, float& z)
+{
+  x = (float)(b.x - a.x);
+  y = (float)(b.y - a.y);
+  z = (float)(b.z - a.z);
+  if (box.ortho) {
+    mic_f(box, x, y, z);
+    return dot3f(x, x, y, y, z, z);
+  }
+  float d2 = dot3f(x, x, y, y, z, z);
+  if (NEPMI_WAVE_ANY(d2 >= box.rfree2)) {
+    mic_f(box, x, y, z);
+    d2 = dot3f(x, x, y, y, z, z);
+  }
+  return d2;
 }
 
 // gpu_apply_pbc, force.cu:424-459 (double; explicit non-fused ops so the CPU oracle, the device
