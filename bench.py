@@ -108,21 +108,19 @@ class _stdout_to_stderr:
         return False
 
 
-def cpu_baseline(seconds=12.0):
-    """NEP_CPU (reference, compiled in place into oracle/_ref) on a 16,000-atom PbTe replica; one
-    iteration = compute() + a host velocity-Verlet update, so that it is an atom-STEP."""
+def _cpu_loop(reps, seconds, max_calls):
+    """NEP_CPU (or the C oracle when oracle/_ref is absent) stepping a PbTe replica: one iteration =
+    compute() + a host velocity-Verlet update, i.e. one atom-STEP per atom -> (n, calls, seconds, kind)."""
     import helpers as H
     nep = H.golden("PbTe", "nep.txt")
-    h, typ, x, mass, vel = build_pbte((4, 4, 4))
+    h, typ, x, mass, vel = build_pbte(reps)
     n = len(typ)
     if H.ref_available():
         eng, kind = H.RefNepCpu(nep), "reference"
         compute = lambda xx: eng.compute(typ, h, xx)
-        cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
     else:
         eng, kind = H.Oracle(nep), "port"
         compute = lambda xx: eng.compute(typ, h, xx, precision=64, path=0)
-        cores = 1
     dt = 1.0 / H.TIME_UNIT
     x = H.oracle_apply_pbc(h, x)
     _, f, _ = compute(x)  # warm-up + initial force
@@ -135,11 +133,58 @@ def cpu_baseline(seconds=12.0):
         vel += 0.5 * dt * f * minv
         calls += 1
         el = time.perf_counter() - t0
-        if el > seconds or calls >= 50:
+        if el > seconds or calls >= max_calls:
             break
-    return {"value": n * calls / el, "unit": "atom-steps/s", "cores": cores, "kind": kind,
-            "sample": "PbTe %d atoms (replicate 4 4 4), %d NVE steps, %.1f s; NEP_CPU is serial outside its descriptor loop"
-                      % (n, calls, el)}
+    return n, calls, el, kind
+
+
+def cpu_worker(seconds):
+    """One of the P independent single-thread instances of the all-cores aggregate:
+    a 2,000-atom replica (NEP_CPU allocates ~224 KB of neighbour tables per atom)."""
+    n, calls, el, kind = _cpu_loop((2, 2, 2), seconds, 10 ** 9)
+    sys.stderr.write("CPUWORKER %d %d %.6f %s\n" % (n, calls, el, kind))
+
+
+def cpu_aggregate(seconds):
+    """P independent NEP_CPU instances, one thread each, every instance on its own replica: the fair
+    'all host cores' figure next to the stock (effectively serial) one."""
+    import subprocess
+    ncpu = os.cpu_count() or 1
+    P = max(1, min(64, ncpu // 2))
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(seconds)], env=env,
+                              stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True) for _ in range(P)]
+    t0 = time.perf_counter()
+    atoms_steps, done, n0 = 0.0, 0, 0
+    for pr in procs:
+        err = pr.communicate()[1]
+        for line in err.splitlines():
+            if line.startswith("CPUWORKER"):
+                _, n, calls, el, _kind = line.split()
+                atoms_steps += int(n) * int(calls) / float(el)
+                n0 = int(n)
+                done += 1
+    wall = time.perf_counter() - t0
+    if done == 0:
+        return None
+    return {"value": atoms_steps, "unit": "atom-steps/s", "instances": done, "threads_per_instance": 1,
+            "sample": "%d independent NEP_CPU instances, PbTe %d atoms each, %.0f s of stepping per instance "
+                      "(%.0f s wall incl. start-up)" % (done, n0, seconds, wall)}
+
+
+def cpu_baseline(seconds=12.0):
+    """NEP_CPU (reference, compiled in place into oracle/_ref) on a 16,000-atom PbTe replica; one
+    iteration = compute() + a host velocity-Verlet update, so that it is an atom-STEP."""
+    import helpers as H
+    n, calls, el, kind = _cpu_loop((4, 4, 4), seconds, 50)
+    cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1)) if kind == "reference" else 1
+    out = {"value": n * calls / el, "unit": "atom-steps/s", "cores": cores, "kind": kind,
+           "sample": "PbTe %d atoms (replicate 4 4 4), %d NVE steps, %.1f s; NEP_CPU is serial outside its descriptor loop"
+                     % (n, calls, el)}
+    agg = cpu_aggregate(max(4.0, 0.75 * seconds))
+    if agg:
+        out["all_cores_aggregate"] = agg
+    return out
 
 
 def kernel_report(st, info, n_atoms_per_launch):
@@ -221,7 +266,7 @@ def run_decomposed(args, world, rank, dev, model, h_block, typ, x, mass, vel, re
             "metric": "atom-steps/sec, NEP PbTe NVE (nep4 2 Te Pb, examples/nep_train/nep.txt)",
             "value": total * args.steps / elapsed, "unit": "atom-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32 kernels, f64 state/accumulation", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "dtype_note": "FP32 kernel arithmetic like the reference NEP path; FP64 positions, velocities and accumulated per-atom outputs", "data": "synthetic",
             "config": {"workload": "PbTe %d atoms/GPU (replicate %d %d %d of the 250-atom cell per GPU), NEP NVE, dt 1 fs, 300 K"
                                    % ((n,) + reps),
                        "atoms_total": total, "parallelism": "spatial decomposition %dx%dx%d, ghost shell 2(rc+skin), "
@@ -250,7 +295,11 @@ def main():
     ap.add_argument("--decomposed", action="store_true",
                     help="run the N > 1 code path (DomainMD) even on one GPU, to measure its host-side overhead")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-worker", type=float, default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_worker is not None:  # one instance of the all-cores CPU aggregate, no GPU involved
+        cpu_worker(args.cpu_worker)
+        return
 
     import torch
     import torch.distributed as dist
@@ -335,7 +384,7 @@ def main():
             "metric": "atom-steps/sec, NEP PbTe NVE (nep4 2 Te Pb, examples/nep_train/nep.txt)",
             "value": value, "unit": "atom-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32 kernels, f64 state/accumulation", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32", "dtype_note": "FP32 kernel arithmetic like the reference NEP path; FP64 positions, velocities and accumulated per-atom outputs", "data": "synthetic",
             "config": {"workload": label,
                        "atoms_total": total_atoms, "rebuilds_in_timed_region": int(st.num_rebuild - reb0),
                        "mean_nn_radial": st.mean_nn_radial, "mean_nn_angular": st.mean_nn_angular,
