@@ -321,6 +321,8 @@ int nepmi_engine_stats(nepmi_engine* e, int with_lists, nepmi_stats* out)
   return guarded([&] {
     auto& eng = *e->e;
     eng.backend().sync();
+    if (eng.num_compute > 0)
+      eng.check_flags_now(); // overflow flags of the force calls since the last read-back
     std::memset(out, 0, sizeof(*out));
     out->num_compute = eng.num_compute;
     out->num_rebuild = eng.num_rebuild;
@@ -370,6 +372,14 @@ int nepmi_engine_set_angular_recompute(nepmi_engine* e, int mode)
   if (!e)
     return fail(NEPMI_ERR_ARG, "null engine");
   e->e->set_angular_recompute(mode);
+  return NEPMI_OK;
+}
+
+int nepmi_engine_set_external_skin(nepmi_engine* e, int on)
+{
+  if (!e)
+    return fail(NEPMI_ERR_ARG, "null engine");
+  e->e->set_external_skin(on != 0);
   return NEPMI_OK;
 }
 

@@ -152,11 +152,13 @@ public:
       be_.memset(b_.flags + kFlagMoved, 0, sizeof(int));
       CheckGatherBody cg{box_, b_, pos, 0};
       be_.template launch<128>(kSlotGather, N_, cg);
-      int flags[kNumFlags];
-      be_.d2h(flags, b_.flags, sizeof(flags));
-      check_overflow(flags);
-      if (flags[kFlagMoved])
-        need_rebuild = true;
+      if (!external_skin_) { // the one host round trip of a step (neighbor.cu:752 does the same)
+        int flags[kNumFlags];
+        be_.d2h(flags, b_.flags, sizeof(flags));
+        check_overflow(flags);
+        if (flags[kFlagMoved])
+          need_rebuild = true;
+      }
     }
     if (need_rebuild)
       rebuild(type, pos);
@@ -209,10 +211,14 @@ public:
       throw EngineError{-4, "compute_levels_end: atom count differs from compute_levels_begin"};
     CheckGatherBody cg{box_, b_, pos, 2};
     be_.template launch<128>(kSlotGather, N_, cg);
-    int flags[kNumFlags];
-    be_.d2h(flags, b_.flags, sizeof(flags));
-    check_overflow(flags);
-    if (flags[kFlagMoved]) {
+    bool moved = false;
+    if (!external_skin_) {
+      int flags[kNumFlags];
+      be_.d2h(flags, b_.flags, sizeof(flags));
+      check_overflow(flags);
+      moved = flags[kFlagMoved] != 0;
+    }
+    if (moved) {
       rebuild(type, pos);
       force_kernels(pe, force, virial, kPhaseAll);
     } else {
@@ -818,6 +824,16 @@ public:
   int tile_mode_in_use() const { return tile_ok_ ? effective_tile_mode() : 0; }
   bool tiles_active() const { return tile_ok_; }
   void set_use_mfma(bool on) { be_.set_mfma(on); }
+  // The caller runs the skin policy itself (a domain-decomposed host votes on it globally and calls
+  // invalidate()): no per-step flag read-back, the force path is enqueued without a host round trip.
+  // List-capacity overflow is then reported at the next rebuild or stats() call.
+  void set_external_skin(bool on) { external_skin_ = on; }
+  void check_flags_now()
+  {
+    int flags[kNumFlags];
+    be_.d2h(flags, b_.flags, sizeof(flags));
+    check_overflow(flags);
+  }
   // angular s sums: -1 auto (recompute in the force kernel when the model has few angular
   // neighbours, MN_angular <= 16), 0 always through sbuf, 1 always recompute
   void set_angular_recompute(int mode) { recompute_mode_ = mode; }
@@ -930,6 +946,7 @@ private:
   double auto_ms_[2] = {0.0, 0.0};
   bool records_valid_ = false; // rstash holds the pair records of the last evaluated positions
   int recompute_mode_ = -1;
+  bool external_skin_ = false;
   bool split_pending_ = false;   // compute_levels_begin ran, compute_levels_end has not yet
   int64_t num_boundary_bricks_ = 0;
   int64_t num_bricks_ = 0;

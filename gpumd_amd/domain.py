@@ -260,6 +260,8 @@ class DomainMD:
         if self.engine is None or self.n_loc > self.capacity:
             self.capacity = int(self.n_loc * 1.15) + 1024
             self.engine = self.make_engine(self.capacity)
+            # the 0.5 A displacement vote below is the skin policy; the engine need not read its own flag back
+            self.engine.set_external_skin(True)
             self.plain_calls = 0
         self.engine.invalidate()
         n = self.n_loc

@@ -126,6 +126,9 @@ class NEP:
             self.handle, hp, pp, int(n), self._ptr(type), self._ptr(position), self._ptr(level),
             self._ptr(potential), self._ptr(force), self._ptr(virial)))
 
+    def set_external_skin(self, on=True):
+        self._ck(self.lib.nepmi_engine_set_external_skin(self.handle, 1 if on else 0))
+
     def invalidate(self):
         self._ck(self.lib.nepmi_engine_invalidate(self.handle))
 

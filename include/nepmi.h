@@ -106,6 +106,11 @@ int nepmi_potential_compute_levels(
   nepmi_engine* e, const double h[9], const int pbc[3], int64_t n, const int* type,
   const double* pos, const signed char* level, double* pe, double* force, double* virial);
 int nepmi_engine_invalidate(nepmi_engine* e);
+/* on != 0: the caller runs the skin policy itself (a domain-decomposed host votes on the 0.5 A
+ * displacement criterion across ranks and calls nepmi_engine_invalidate): the force calls then skip
+ * the per-step flag read-back and are enqueued without any host round trip.  List-capacity overflow
+ * is reported at the next rebuild or nepmi_engine_stats call instead of immediately. */
+int nepmi_engine_set_external_skin(nepmi_engine* e, int on);
 /* The same call in two halves, so that a domain-decomposed host can overlap its ghost-position
  * exchange (the RCCL send/recv that replaces NEP_MULTIGPU's staged copies) with compute:
  *   _begin: the OWNED (level 2) entries of pos are final; ghost entries may still be in flight and
