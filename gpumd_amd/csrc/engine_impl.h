@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <random>
 #include <vector>
 
 namespace nepmi {
@@ -349,6 +350,128 @@ public:
       velocity_verlet(false, n, dt, mass, force, pos, vel, nullptr);
       find_thermo(n, box.volume, mass, pe, vel, virial, thermo_dev_);
       nhc_half_step(n, target, dt, thermo_dev_, nhc_dev_, vel);
+      if (thermo_every > 0 && (step + 1) % thermo_every == 0) {
+        be_.d2h(thermo_host + 8 * rec, thermo_dev_, 8 * sizeof(double));
+        ++rec;
+      }
+    }
+    be_.sync();
+    int flags[kNumFlags];
+    be_.d2h(flags, b_.flags, sizeof(flags));
+    check_overflow(flags);
+  }
+
+  // ---- Bussi-Donadio-Parrinello stochastic velocity rescaling (Ensemble_BDP, ensemble_bdp.cu:71-104;
+  //      resamplekin & co., svr_utilities.cuh:28-122, after Bussi's reference code).  Like the
+  //      reference the noise is drawn on the host from std::mt19937 through
+  //      uniform_real_distribution<double>(0, 1), so a run is reproducible from its seed; this is the one
+  //      thermostat with a host round trip per step (the kinetic energy is needed to draw the factor). ----
+  void bdp_seed(uint64_t seed)
+  {
+    bdp_rng_ = std::mt19937((std::mt19937::result_type)seed);
+    bdp_iset_ = 0;
+    bdp_gset_ = 0.0;
+  }
+  double bdp_uniform()
+  {
+    std::uniform_real_distribution<double> rand1(0, 1);
+    return rand1(bdp_rng_);
+  }
+  double bdp_gauss() // polar Box-Muller with one cached deviate (gasdev)
+  {
+    if (bdp_iset_) {
+      bdp_iset_ = 0;
+      return bdp_gset_;
+    }
+    double v1, v2, rsq;
+    do {
+      v1 = 2.0 * bdp_uniform() - 1.0;
+      v2 = 2.0 * bdp_uniform() - 1.0;
+      rsq = v1 * v1 + v2 * v2;
+    } while (rsq >= 1.0 || rsq == 0.0);
+    const double fac = std::sqrt(-2.0 * std::log(rsq) / rsq);
+    bdp_gset_ = v1 * fac;
+    bdp_iset_ = 1;
+    return v2 * fac;
+  }
+  double bdp_gamma(int ia) // gamma deviate of integer order (gamdev)
+  {
+    double x;
+    if (ia < 6) {
+      x = 1.0;
+      for (int j = 1; j <= ia; ++j)
+        x *= bdp_uniform();
+      return -std::log(x);
+    }
+    double e, y;
+    do {
+      do {
+        double v1, v2;
+        do {
+          v1 = bdp_uniform();
+          v2 = 2.0 * bdp_uniform() - 1.0;
+        } while (v1 * v1 + v2 * v2 > 1.0);
+        y = v2 / v1;
+        const double am = ia - 1;
+        const double sq = std::sqrt(2.0 * am + 1.0);
+        x = sq * y + am;
+        if (x > 0.0)
+          e = (1.0 + y * y) * std::exp(am * std::log(x / am) - sq * y);
+      } while (x <= 0.0);
+    } while (bdp_uniform() > e);
+    return x;
+  }
+  double bdp_sum_noises(int nn) // sum of nn squared gaussian deviates
+  {
+    if (nn == 0)
+      return 0.0;
+    if (nn == 1) {
+      const double rr = bdp_gauss();
+      return rr * rr;
+    }
+    if (nn % 2 == 0)
+      return 2.0 * bdp_gamma(nn / 2);
+    const double rr = bdp_gauss();
+    return 2.0 * bdp_gamma((nn - 1) / 2) + rr * rr;
+  }
+  // new kinetic energy drawn from the canonical distribution's relaxation kernel (resamplekin)
+  double bdp_resample(double kk, double sigma, int ndeg, double taut)
+  {
+    const double factor = taut > 0.1 ? std::exp(-1.0 / taut) : 0.0;
+    const double rr = bdp_gauss();
+    return kk + (1.0 - factor) * (sigma * (bdp_sum_noises(ndeg - 1) + rr * rr) / ndeg - kk) +
+           2.0 * rr * std::sqrt(kk * sigma / ndeg * (1.0 - factor) * factor);
+  }
+  // integrate_nvt_bdp_2 after the velocity update: T = thermo8[0] (device) -> host, draw, rescale
+  double bdp_scale(int64_t n, double temperature, double t_coup, const double* thermo8, double* vel)
+  {
+    double T = 0.0;
+    be_.d2h(&T, thermo8, sizeof(double));
+    const int ndeg = 3 * (int)n;
+    const double ek = T * ndeg * kBoltzmann * 0.5;
+    const double sigma = ndeg * kBoltzmann * temperature * 0.5;
+    const double factor = std::sqrt(bdp_resample(ek, sigma, ndeg, t_coup) / ek);
+    be_.template launch<256>(kSlotMisc, n, ScaleVelocityConstBody{n, factor, vel});
+    return factor;
+  }
+
+  // Run::perform_a_run for `ensemble nvt_bdp T1 T2 Tcoup` (Ensemble_BDP::compute1/compute2)
+  void run_nvt_bdp(
+    const double h9[9], const int pbc[3], int64_t n, const int* type, const double* mass, double dt,
+    int64_t nsteps, double t1, double t2, double tcoup, double* pos, double* vel, double* pe, double* force,
+    double* virial, int64_t thermo_every, double* thermo_host)
+  {
+    BoxD box;
+    box_from_h9(h9, pbc, box);
+    int64_t rec = 0;
+    for (int64_t step = 0; step < nsteps; ++step) {
+      const double target = t1 + (t2 - t1) * ((double)step / (double)nsteps);
+      velocity_verlet(true, n, dt, mass, force, pos, vel, &box);
+      zero_properties(n, pe, force, virial);
+      potential_compute(h9, pbc, n, type, pos, pe, force, virial);
+      velocity_verlet(false, n, dt, mass, force, pos, vel, nullptr);
+      find_thermo(n, box.volume, mass, pe, vel, virial, thermo_dev_);
+      bdp_scale(n, target, tcoup, thermo_dev_, vel);
       if (thermo_every > 0 && (step + 1) % thermo_every == 0) {
         be_.d2h(thermo_host + 8 * rec, thermo_dev_, 8 * sizeof(double));
         ++rec;
@@ -961,6 +1084,9 @@ private:
   double* thermo_scratch_ = nullptr;
   double* thermo_dev_ = nullptr;
   double* nhc_dev_ = nullptr;
+  std::mt19937 bdp_rng_{12345678u};
+  int bdp_iset_ = 0;
+  double bdp_gset_ = 0.0;
   std::vector<void*> allocs_;
 };
 

@@ -334,6 +334,18 @@ struct ScaleVelocityBody { // scale_velocity_global, ensemble.cu (gpu_scale_velo
   }
 };
 
+struct ScaleVelocityConstBody { // scale_velocity_global with a host-computed factor (BDP thermostat)
+  int64_t N;
+  double factor;
+  double* vel;
+  NEPMI_HD void operator()(int64_t i) const
+  {
+    vel[i] *= factor;
+    vel[N + i] *= factor;
+    vel[2 * N + i] *= factor;
+  }
+};
+
 // ------------------------------------------------------------------------------------------------
 // neighbour rebuild (find_cell_list + gpu_find_neighbor_ON1, neighbor.cu:42-215)
 // ------------------------------------------------------------------------------------------------

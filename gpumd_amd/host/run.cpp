@@ -1,6 +1,7 @@
 #include "run.h"
 
 #include <chrono>
+#include <random>
 #include <cstring>
 #include <fstream>
 
@@ -101,7 +102,7 @@ void Run::parse_one_keyword(const std::vector<std::string>& p)
       input_error("ensemble should have at least 1 parameter.");
     if (p[1] == "nve") {
       std::printf("Use NVE ensemble for this run.\n");
-    } else if (p[1] == "nvt_ber" || p[1] == "nvt_nhc") { // Integrate::parse_ensemble, integrate.cu:424-432, 569-600
+    } else if (p[1] == "nvt_ber" || p[1] == "nvt_nhc" || p[1] == "nvt_bdp") { // Integrate::parse_ensemble, integrate.cu:424-432, 569-600
       if (p.size() != 5)
         input_error("ensemble " + p[1] + " should have 3 parameters.");
       temperature1 = std::atof(p[2].c_str());
@@ -113,9 +114,9 @@ void Run::parse_one_keyword(const std::vector<std::string>& p)
         input_error("Temperature coupling should >= 1.");
       std::printf("Use NVT ensemble for this run.\n    choose the %s method.\n    initial temperature is %g K.\n"
                   "    final temperature is %g K.\n    tau_T is %g time_step.\n",
-                  p[1] == "nvt_ber" ? "Berendsen" : "Nose-Hoover chain", temperature1, temperature2, temperature_coupling);
+                  p[1] == "nvt_ber" ? "Berendsen" : p[1] == "nvt_nhc" ? "Nose-Hoover chain" : "Bussi-Donadio-Parrinello", temperature1, temperature2, temperature_coupling);
     } else {
-      input_error("ensemble " + p[1] + " is not available in gpumd-mi yet (nve, nvt_ber, nvt_nhc; DESIGN.md section 8).");
+      input_error("ensemble " + p[1] + " is not available in gpumd-mi yet (nve, nvt_ber, nvt_nhc, nvt_bdp; DESIGN.md section 8).");
     }
     ensemble = p[1];
   } else if (k == "time_step") {
@@ -319,6 +320,11 @@ void Run::perform_a_run()
     if (nepmi_nhc_init(e, N, temperature1, temperature_coupling, time_step, nhc_state) != NEPMI_OK)
       input_error(nepmi_last_error());
   }
+  if (ensemble == "nvt_bdp") { // Ensemble_BDP::initialize_rng (ensemble_bdp.cu:32-39): seeded from the clock
+    const uint64_t seed = (uint64_t)std::chrono::system_clock::now().time_since_epoch().count();
+    nepmi_bdp_seed(e, seed);
+    std::printf("    BDP noise seed = %llu.\n", (unsigned long long)((std::mt19937::result_type)seed));
+  }
   for (int step = 0; step < number_of_steps; ++step) {
     global_time += time_step;
     const double target = temperature1 + (temperature2 - temperature1) * (double(step) / number_of_steps);
@@ -335,6 +341,8 @@ void Run::perform_a_run()
     find_thermo();
     if (ensemble == "nvt_ber") // Ensemble_BER::compute2, ensemble_ber.cu:195-235
       nepmi_berendsen_scale(e, N, target, 1.0 / temperature_coupling, thermo.data(), atom.velocity_per_atom.data());
+    else if (ensemble == "nvt_bdp") // integrate_nvt_bdp_2, ensemble_bdp.cu:71-104
+      nepmi_bdp_scale(e, N, target, temperature_coupling, thermo.data(), atom.velocity_per_atom.data());
     else if (ensemble == "nvt_nhc") // integrate_nvt_nhc_2, ensemble_nhc.cu:199-232
       nepmi_nhc_half_step(e, N, target, time_step, thermo.data(), nhc_state, atom.velocity_per_atom.data());
     // measure.process

@@ -188,6 +188,20 @@ int nepmi_run_nvt_nhc(
   const double* mass, double dt, int64_t nsteps, double t1, double t2, double t_coup, double* pos,
   double* vel, double* pe, double* force, double* virial, int64_t thermo_every, double* thermo_host);
 
+/* ---- Bussi-Donadio-Parrinello stochastic velocity rescaling: Ensemble_BDP
+ *      (src/integrate/ensemble_bdp.cu:71-104) with resamplekin / gasdev / gamdev of
+ *      src/integrate/svr_utilities.cuh:28-122, `ensemble nvt_bdp T1 T2 T_coup`.  The noise comes from a
+ *      host std::mt19937 read through uniform_real_distribution<double>(0,1), as in the reference (which
+ *      seeds it from the clock; here the seed is explicit, default 12345678 = the reference's DEBUG seed).
+ *      nepmi_bdp_scale: T = thermo8[0] (DEVICE) is read back, the new kinetic energy is drawn, the
+ *      velocities are rescaled.  A step of the ensemble: vv_step1, force, vv_step2, find_thermo, bdp_scale. ---- */
+int nepmi_bdp_seed(nepmi_engine* e, uint64_t seed);
+int nepmi_bdp_scale(nepmi_engine* e, int64_t n, double temperature, double t_coup, const double* thermo8, double* vel);
+int nepmi_run_nvt_bdp(
+  nepmi_engine* e, const double h[9], const int pbc[3], int64_t n, const int* type,
+  const double* mass, double dt, int64_t nsteps, double t1, double t2, double t_coup, double* pos,
+  double* vel, double* pe, double* force, double* virial, int64_t thermo_every, double* thermo_host);
+
 /* ---- diagnostics / parity hooks ---- */
 
 /* Per-step radial (which = 0) / angular (which = 1) neighbour lists of the LAST compute, in the

@@ -539,6 +539,129 @@ double nepo_nhc(double* st, double ek2, double kT, double dN, double dt2_particl
   return factor;
 }
 
+/* Bussi-Donadio-Parrinello thermostat (ensemble_bdp.cu:71-104) with the noise generators of
+ * svr_utilities.cuh:28-122.  The reference draws uniforms with std::mt19937 +
+ * std::uniform_real_distribution<double>(0, 1); both are restated here from their definitions
+ * (MT19937 of Matsumoto & Nishimura; libstdc++'s generate_canonical<double, 53>: two 32-bit words,
+ * sum = w0 + w1 * 2^32 in double, / 2^64) so that a seeded run can be checked draw for draw. */
+typedef struct {
+  unsigned int mt[624];
+  int idx;
+  int iset;
+  double gset;
+} nepo_bdp;
+
+void nepo_bdp_seed(void* state, unsigned int seed)
+{
+  nepo_bdp* g = (nepo_bdp*)state;
+  g->mt[0] = seed;
+  for (int i = 1; i < 624; ++i)
+    g->mt[i] = 1812433253u * (g->mt[i - 1] ^ (g->mt[i - 1] >> 30)) + (unsigned int)i;
+  g->idx = 624;
+  g->iset = 0;
+  g->gset = 0.0;
+}
+
+static unsigned int bdp_u32(nepo_bdp* g)
+{
+  if (g->idx >= 624) {
+    for (int i = 0; i < 624; ++i) {
+      const unsigned int y = (g->mt[i] & 0x80000000u) | (g->mt[(i + 1) % 624] & 0x7fffffffu);
+      g->mt[i] = g->mt[(i + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+    }
+    g->idx = 0;
+  }
+  unsigned int y = g->mt[g->idx++];
+  y ^= y >> 11;
+  y ^= (y << 7) & 0x9d2c5680u;
+  y ^= (y << 15) & 0xefc60000u;
+  y ^= y >> 18;
+  return y;
+}
+
+static double bdp_uniform(nepo_bdp* g)
+{
+  double sum = (double)bdp_u32(g);
+  sum += (double)bdp_u32(g) * 4294967296.0;
+  double r = sum / 18446744073709551616.0;
+  if (r >= 1.0)
+    r = nextafter(1.0, 0.0);
+  return r;
+}
+
+static double bdp_gauss(nepo_bdp* g)
+{
+  if (g->iset) {
+    g->iset = 0;
+    return g->gset;
+  }
+  double v1, v2, rsq;
+  do {
+    v1 = 2.0 * bdp_uniform(g) - 1.0;
+    v2 = 2.0 * bdp_uniform(g) - 1.0;
+    rsq = v1 * v1 + v2 * v2;
+  } while (rsq >= 1.0 || rsq == 0.0);
+  const double fac = sqrt(-2.0 * log(rsq) / rsq);
+  g->gset = v1 * fac;
+  g->iset = 1;
+  return v2 * fac;
+}
+
+static double bdp_gamma(nepo_bdp* g, int ia)
+{
+  if (ia < 6) {
+    double x = 1.0;
+    for (int j = 1; j <= ia; ++j)
+      x *= bdp_uniform(g);
+    return -log(x);
+  }
+  for (;;) {
+    double x, y, v1, v2;
+    const double am = ia - 1, sq = sqrt(2.0 * am + 1.0);
+    do {
+      do {
+        v1 = bdp_uniform(g);
+        v2 = 2.0 * bdp_uniform(g) - 1.0;
+      } while (v1 * v1 + v2 * v2 > 1.0);
+      y = v2 / v1;
+      x = sq * y + am;
+    } while (x <= 0.0);
+    const double e = (1.0 + y * y) * exp(am * log(x / am) - sq * y);
+    if (!(bdp_uniform(g) > e))
+      return x;
+  }
+}
+
+static double bdp_sum_noises(nepo_bdp* g, int nn)
+{
+  if (nn == 0)
+    return 0.0;
+  if (nn == 1) {
+    const double rr = bdp_gauss(g);
+    return rr * rr;
+  }
+  if (nn % 2 == 0)
+    return 2.0 * bdp_gamma(g, nn / 2);
+  const double rr = bdp_gauss(g);
+  return 2.0 * bdp_gamma(g, (nn - 1) / 2) + rr * rr;
+}
+
+/* velocity scale factor of one BDP step from the instantaneous temperature (ensemble_bdp.cu:94-101) */
+double nepo_bdp_factor(void* state, int n, double T_now, double T_target, double t_coup)
+{
+  nepo_bdp* g = (nepo_bdp*)state;
+  const double kB = 8.617343e-5;
+  const int ndeg = 3 * n;
+  const double kk = T_now * ndeg * kB * 0.5, sigma = ndeg * kB * T_target * 0.5;
+  const double f = t_coup > 0.1 ? exp(-1.0 / t_coup) : 0.0;
+  const double rr = bdp_gauss(g);
+  const double knew = kk + (1.0 - f) * (sigma * (bdp_sum_noises(g, ndeg - 1) + rr * rr) / ndeg - kk) +
+                      2.0 * rr * sqrt(kk * sigma / ndeg * (1.0 - f) * f);
+  return sqrt(knew / kk);
+}
+
+int nepo_bdp_sizeof(void) { return (int)sizeof(nepo_bdp); }
+
 /* Run::perform_a_run, run.cu:250-318 restricted to ensemble nve (ensemble_nve.cu:31-95). */
 int nepo_run_nve(
   const nepo_model* m, int precision, int n, const int* type, const double h[9],

@@ -89,6 +89,12 @@ void nepo_velocity_verlet(
 void nepo_nhc_init(int n, double temperature, double t_coup, double dt, double* st);
 double nepo_nhc(double* st, double ek2, double kT, double dN, double dt2_particle);
 
+/* Ensemble_BDP (ensemble_bdp.cu:71-104, svr_utilities.cuh:28-122): state = MT19937 + gasdev cache in an
+ * opaque buffer of nepo_bdp_sizeof() bytes */
+int nepo_bdp_sizeof(void);
+void nepo_bdp_seed(void* g, unsigned int seed);
+double nepo_bdp_factor(void* g, int n, double T_now, double T_target, double t_coup);
+
 void nepo_thermo(
   int n, double volume, const double* mass, const double* pe, const double* vel,
   const double* virial, double* thermo8);

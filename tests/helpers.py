@@ -141,6 +141,10 @@ def oracle_lib():
         L.nepo_nhc_init.argtypes = [C.c_int, C.c_double, C.c_double, C.c_double, _dp]
         L.nepo_nhc.argtypes = [_dp, C.c_double, C.c_double, C.c_double, C.c_double]
         L.nepo_nhc.restype = C.c_double
+        L.nepo_bdp_sizeof.restype = C.c_int
+        L.nepo_bdp_seed.argtypes = [C.c_void_p, C.c_uint]
+        L.nepo_bdp_factor.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_double]
+        L.nepo_bdp_factor.restype = C.c_double
         L.nepo_run_nve.argtypes = [C.c_void_p, C.c_int, C.c_int, _ip, _dp, _ip, _dp, C.c_double,
                                    C.c_int, _dp, _dp, _dp, _dp, _dp, _dp]
         _oracle_lib = L

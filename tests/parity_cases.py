@@ -379,6 +379,58 @@ def check_angular_recompute(drv):
             assert np.abs(a - b).max() <= 2e-6 * max(1.0, np.abs(a).max()), name
 
 
+def check_nvt_bdp(drv, nsteps=30, seed=20240924):
+    """`ensemble nvt_bdp 300 500 50` with a fixed seed: integrate_nvt_bdp_2 (ensemble_bdp.cu:71-104) against the
+    same loop built from oracle pieces; the oracle restates MT19937 and libstdc++'s canonical-double draw, so the
+    stochastic factors must agree draw for draw, not just statistically."""
+    import ctypes as C
+    nep = H.golden("PbTe", "nep.txt")
+    h, typ, x = H.pbte_supercell((2, 2, 2), rattle=0.01, seed=53)
+    n = len(typ)
+    orc = H.Oracle(nep)
+    mass = np.array([H.MASS[orc.symbols[t]] for t in typ])
+    vel = H.maxwell_velocities(mass, 300.0, seed=8)
+    dt = 1.0 / H.TIME_UNIT
+    t1, t2, tc = 300.0, 500.0, 50.0
+    vol = abs(np.linalg.det(np.asarray(h).reshape(3, 3)))
+    L = H.oracle_lib()
+    rng = C.create_string_buffer(L.nepo_bdp_sizeof())
+    L.nepo_bdp_seed(rng, seed)
+    xo, vo = x.copy(), vel.copy()
+    pe, f, w = orc.compute(typ, h, xo, precision=32, path=0)
+    th_ref, fac = [], []
+    for step in range(nsteps):
+        target = t1 + (t2 - t1) * (step / nsteps)
+        L.nepo_velocity_verlet(1, n, dt, H._p(mass, H._dp), H._p(f, H._dp), H._p(xo, H._dp), H._p(vo, H._dp))
+        xo = H.oracle_apply_pbc(h, xo)
+        pe, f, w = orc.compute(typ, h, xo, precision=32, path=0)
+        L.nepo_velocity_verlet(0, n, dt, H._p(mass, H._dp), H._p(f, H._dp), H._p(xo, H._dp), H._p(vo, H._dp))
+        th = H.oracle_thermo(vol, mass, pe, vo, w)
+        th_ref.append(th)
+        s = L.nepo_bdp_factor(rng, n, th[0], target, tc)
+        fac.append(s)
+        vo *= s
+    th_ref, fac = np.array(th_ref), np.array(fac)
+    assert np.abs(fac - 1.0).max() > 1e-4 and fac.min() < 1.0 < fac.max()  # noise of both signs
+
+    eng = drv.engine(drv.model(nep), n)
+    eng.bdp_seed(seed)
+    d_t, d_m, d_x, d_v = drv.dev(typ), drv.dev(mass), drv.dev(x), drv.dev(vel)
+    d_pe, d_f, d_w = drv.zeros(n), drv.zeros(3 * n), drv.zeros(9 * n)
+    eng.force_compute(h, d_t, d_x, d_pe, d_f, d_w)
+    th = eng.run_nvt_bdp(h, d_t, d_m, dt, nsteps, t1, t2, tc, d_x, d_v, d_pe, d_f, d_w, thermo_every=1)
+    np.testing.assert_allclose(th[:, 0], th_ref[:, 0], rtol=1e-6)
+    np.testing.assert_allclose(th[:, 1], th_ref[:, 1], rtol=1e-6)
+    assert np.abs(drv.host(d_v) - vo).max() < 1e-6
+    # another seed gives another trajectory
+    eng2 = drv.engine(drv.model(nep), n)
+    eng2.bdp_seed(seed + 1)
+    d_x, d_v = drv.dev(x), drv.dev(vel)
+    eng2.force_compute(h, d_t, d_x, d_pe, d_f, d_w)
+    th2 = eng2.run_nvt_bdp(h, d_t, d_m, dt, nsteps, t1, t2, tc, d_x, d_v, d_pe, d_f, d_w, thermo_every=1)
+    assert np.abs(th2[:, 0] - th[:, 0]).max() > 1e-3
+
+
 def check_error_paths(drv):
     import pytest
     from gpumd_amd import NepmiError

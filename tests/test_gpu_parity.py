@@ -95,6 +95,10 @@ def test_angular_sums_stored_or_recomputed(drv):
     P.check_angular_recompute(drv)
 
 
+def test_nvt_bussi_donadio_parrinello(drv):
+    P.check_nvt_bdp(drv)
+
+
 def test_small_box_branch(drv):
     P.check_small_box(drv)
 

@@ -38,7 +38,7 @@ def test_check_input_parses_run_in_and_model(tmp_path):
 
 
 @pytest.mark.parametrize("bad,msg", [("potential NEP\nfoo 1\nrun 1\n", "invalid keyword"),
-                                     ("potential NEP\nensemble nvt_bdp 300 300 100\nrun 1\n", "not available"),
+                                     ("potential NEP\nensemble nvt_lan 300 300 100\nrun 1\n", "not available"),
                                      ("potential NEP\nensemble nvt_nhc 300 300 0.5\nrun 1\n", "coupling should >= 1"),
                                      ("velocity 300\nrun 1\n", "no 'potential'")])
 def test_input_errors_exit_like_the_reference(tmp_path, bad, msg):
@@ -103,7 +103,7 @@ def test_nve_run_writes_thermo(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("ens", ["nvt_ber 300 600 20", "nvt_nhc 300 600 50"])
+@pytest.mark.parametrize("ens", ["nvt_ber 300 600 20", "nvt_nhc 300 600 50", "nvt_bdp 300 600 50"])
 def test_nvt_run_heats_towards_the_target(tmp_path, ens):
     """`ensemble nvt_ber|nvt_nhc T1 T2 Tc` through gpumd-mi: the temperature follows the ramp."""
     wd = _workdir(tmp_path, "replicate 2 2 2\npotential NEP\nvelocity 300 seed 42\nensemble %s\ntime_step 1\n"
