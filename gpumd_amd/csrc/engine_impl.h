@@ -644,7 +644,12 @@ private:
     b_.MN_acomp = m.MN_angular;
     b_.MN_skin = (int)(m.MN_radial * rcs * rcs * rcs / (m.rc_radial_max * m.rc_radial_max * m.rc_radial_max));
     const double ras = m.rc_angular_max + kSkin;
-    b_.MN_ang = (int)(m.MN_angular * ras * ras * ras / (m.rc_angular_max * m.rc_angular_max * m.rc_angular_max)) + 1;
+    // List A (the part of the Verlet list inside rc_a + skin) is this engine's own structure: its capacity
+    // must never bind before the reference's MN limits do, so the density-scaled estimate gets 50 % headroom
+    // (a thermalised crystal does put 21 atoms inside 5 A of a PbTe atom against a scaled estimate of 19.5).
+    b_.MN_ang = (int)(1.5 * m.MN_angular * ras * ras * ras / (m.rc_angular_max * m.rc_angular_max * m.rc_angular_max)) + 4;
+    if (b_.MN_ang > b_.MN_skin)
+      b_.MN_ang = b_.MN_skin;
     if (b_.MN_ang > 65000)
       throw EngineError{-3, "angular Verlet list capacity above 65000 slots is not supported"};
     b_.rc_skin_sq = (float)(rcs * rcs);

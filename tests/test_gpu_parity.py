@@ -166,3 +166,24 @@ def test_full_size_properties(drv):
     assert np.array_equal(f2, f) and np.array_equal(pe2, pe) and np.array_equal(v2, v)
     st = eng.stats(True)
     assert st.num_rebuild == 1 and st.num_compute == 2
+
+
+def test_long_nve_run_keeps_lists_and_energy(drv):
+    """600 steps of 250,000 thermalising PbTe atoms: several Verlet rebuilds, no list-capacity overflow
+    (the rattled crystal puts up to 21 atoms inside rc_a + skin), total energy conserved."""
+    nep = H.golden("PbTe", "nep.txt")
+    h, typ, x = H.pbte_supercell((10, 10, 10), rattle=0.02, seed=77)
+    n = len(typ)
+    model = drv.model(nep)
+    mass = np.where(typ == 0, H.MASS["Te"], H.MASS["Pb"]).astype(np.float64)
+    vel = H.maxwell_velocities(mass, 300.0, seed=9)
+    eng = drv.engine(model, n)
+    d_t, d_m, d_x, d_v = drv.dev(typ), drv.dev(mass), drv.dev(x), drv.dev(vel)
+    d_pe, d_f, d_w = drv.zeros(n), drv.zeros(3 * n), drv.zeros(9 * n)
+    eng.force_compute(h, d_t, d_x, d_pe, d_f, d_w)
+    th = eng.run_nve(h, d_t, d_m, 1.0 / H.TIME_UNIT, 600, d_x, d_v, d_pe, d_f, d_w, thermo_every=100)
+    st = eng.stats(with_lists=True)
+    assert st.num_rebuild >= 4
+    e = (th[:, 1] + 1.5 * n * H.K_B * th[:, 0]) / n
+    assert np.abs(e - e[0]).max() < 5e-6, e          # eV per atom
+    assert 300.0 < th[-1, 0] < 900.0  # model.xyz is a hot snapshot: potential energy flows into kinetic
