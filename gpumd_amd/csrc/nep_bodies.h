@@ -1836,9 +1836,15 @@ struct ForceAssembleBody {
           const unsigned short a = amap[(int64_t)idx * N + k];
           if (a != kNoSlot) {
             const int rs = rev[(int64_t)idx * N];
-            const unsigned short ap = amap[(int64_t)rs * N + j];
+            const unsigned short ap = rs != (int)kNoSlot ? amap[(int64_t)rs * N + j] : kNoSlot;
             const F4 fa = f12[(int64_t)a * N + k];
-            const F4 fb = f12[(int64_t)ap * N + j];
+            // j has no compact slot for this pair only if its per-step angular list overflowed
+            // (MN_angular): that is reported through the overflow flag; never index with kNoSlot
+            F4 fb;
+            fb.x = fb.y = fb.z = 0.0f;
+            fb.w = 0;
+            if (ap != kNoSlot)
+              fb = f12[(int64_t)ap * N + j];
             F[0] += fa.x - fb.x;
             F[1] += fa.y - fb.y;
             F[2] += fa.z - fb.z;

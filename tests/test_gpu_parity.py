@@ -187,3 +187,20 @@ def test_long_nve_run_keeps_lists_and_energy(drv):
     e = (th[:, 1] + 1.5 * n * H.K_B * th[:, 0]) / n
     assert np.abs(e - e[0]).max() < 5e-6, e          # eV per atom
     assert 300.0 < th[-1, 0] < 900.0  # model.xyz is a hot snapshot: potential energy flows into kinetic
+
+
+def test_angular_list_overflow_is_an_error_not_a_fault(drv):
+    """A run hot enough to put more than MN_angular atoms inside rc_a must end with the capacity error
+    (nep.txt's cutoff line decides the capacity, as in the reference), never with a memory fault."""
+    from gpumd_amd import NepmiError
+    nep = H.golden("PbTe", "nep.txt")
+    h, typ, x = H.pbte_supercell((4, 4, 4), rattle=0.02, seed=5)
+    n = len(typ)
+    mass = np.where(typ == 0, H.MASS["Te"], H.MASS["Pb"]).astype(np.float64)
+    vel = H.maxwell_velocities(mass, 2500.0, seed=3)
+    eng = drv.engine(drv.model(nep), n)
+    d_t, d_m, d_x, d_v = drv.dev(typ), drv.dev(mass), drv.dev(x), drv.dev(vel)
+    d_pe, d_f, d_w = drv.zeros(n), drv.zeros(3 * n), drv.zeros(9 * n)
+    eng.force_compute(h, d_t, d_x, d_pe, d_f, d_w)
+    with pytest.raises(NepmiError, match="capacity"):
+        eng.run_nve(h, d_t, d_m, 1.0 / H.TIME_UNIT, 1500, d_x, d_v, d_pe, d_f, d_w)
