@@ -708,6 +708,8 @@ private:
 
   void check_overflow(const int* flags)
   {
+    if (flags[kFlagOverflow] & 8)
+      throw EngineError{-4, "non-finite atom coordinates (the simulation has blown up, or the position array is not initialised)"};
     if (flags[kFlagOverflow]) {
       char msg[256];
       std::snprintf(

@@ -377,7 +377,10 @@ struct BinAtomsBody {
   NEPMI_HD void operator()(int64_t i) const
   {
     int cx, cy, cz;
-    cell_of(box, pos[i], pos[b.N + i], pos[2 * b.N + i], b.rc_inv_cell, b.nbx, b.nby, b.nbz, cx, cy, cz);
+    const double x = pos[i], y = pos[b.N + i], z = pos[2 * b.N + i];
+    cell_of(box, x, y, z, b.rc_inv_cell, b.nbx, b.nby, b.nbz, cx, cy, cz);
+    if (!(x - x == 0.0 && y - y == 0.0 && z - z == 0.0)) // NaN or infinity
+      NEPMI_ATOMIC_OR(&b.flags[kFlagOverflow], 8);
     const int c = cell_index(b, cx, cy, cz);
     b.cid[i] = c;
     NEPMI_ATOMIC_ADD(&b.cell_count[c], 1);
@@ -666,7 +669,7 @@ struct CheckGatherBody {
     float dz = (float)(z - b.x0s[2 * N + k]);
     mic_f(box, dx, dy, dz);
     const float d2 = (dx * dx + dy * dy) + dz * dz;
-    if ((double)d2 > 0.25) // skin^2/4, skin = 1 A (neighbor.cuh:212)
+    if (!((double)d2 <= 0.25)) // skin^2/4, skin = 1 A (neighbor.cuh:212); also true for NaN
       NEPMI_ATOMIC_OR(&b.flags[kFlagMoved], 1);
     b.posq[k].x = x;
     b.posq[k].y = y;

@@ -206,14 +206,19 @@ NEPMI_HD void cell_of(
   const double sx = h[9] * x + h[10] * y + h[11] * z;
   const double sy = h[12] * x + h[13] * y + h[14] * z;
   const double sz = h[15] * x + h[16] * y + h[17] * z;
-  cx = (int)floor(sx * box.thickness[0] * rc_inv);
-  cy = (int)floor(sy * box.thickness[1] * rc_inv);
-  cz = (int)floor(sz * box.thickness[2] * rc_inv);
-  if (box.pbc[0]) { while (cx < 0) cx += nbx; while (cx >= nbx) cx -= nbx; }
+  // the products are clamped before the conversion: a run that has blown up (NaN / astronomically large
+  // coordinates) must end in an error report, not in an out-of-range cell or an endless wrap loop
+  const double fx = sx * box.thickness[0] * rc_inv, fy = sy * box.thickness[1] * rc_inv,
+               fz = sz * box.thickness[2] * rc_inv;
+  const double lim = 1.0e9;
+  cx = (int)floor(fx > -lim ? (fx < lim ? fx : lim) : -lim); // NaN compares false -> -lim
+  cy = (int)floor(fy > -lim ? (fy < lim ? fy : lim) : -lim);
+  cz = (int)floor(fz > -lim ? (fz < lim ? fz : lim) : -lim);
+  if (box.pbc[0]) { cx %= nbx; if (cx < 0) cx += nbx; }
   else { cx = cx < 0 ? 0 : (cx >= nbx ? nbx - 1 : cx); }
-  if (box.pbc[1]) { while (cy < 0) cy += nby; while (cy >= nby) cy -= nby; }
+  if (box.pbc[1]) { cy %= nby; if (cy < 0) cy += nby; }
   else { cy = cy < 0 ? 0 : (cy >= nby ? nby - 1 : cy); }
-  if (box.pbc[2]) { while (cz < 0) cz += nbz; while (cz >= nbz) cz -= nbz; }
+  if (box.pbc[2]) { cz %= nbz; if (cz < 0) cz += nbz; }
   else { cz = cz < 0 ? 0 : (cz >= nbz ? nbz - 1 : cz); }
 }
 

@@ -440,6 +440,17 @@ def check_error_paths(drv):
     eng = drv.engine(model, len(typ) - 1)
     with pytest.raises(NepmiError):
         H.engine_force(drv, eng, h, typ, x)
+    # a blown-up simulation (NaN / huge coordinates) is reported, it neither hangs nor faults
+    for bad in (np.nan, np.inf):
+        eng = drv.engine(model, len(typ))
+        xb = np.array(x)
+        xb[7] = bad
+        with pytest.raises(NepmiError, match="non-finite|capacity"):
+            n = len(typ)
+            d_t, d_x = drv.dev(typ), drv.dev(xb)
+            d_pe, d_f, d_v = drv.zeros(n), drv.zeros(3 * n), drv.zeros(9 * n)
+            eng.compute(h, d_t, d_x, d_pe, d_f, d_v)
+            eng.stats()
     # unsupported / malformed model files
     with pytest.raises(NepmiError):
         drv.model(H.golden("PbTe", "model.xyz"))
