@@ -338,7 +338,16 @@ void Run::perform_a_run()
     force.compute(box, atom.position_per_atom, atom.type, atom.potential_per_atom, atom.force_per_atom, atom.virial_per_atom);
     // integrate.compute2 (ensemble_nve.cu:59-95)
     nepmi_vv_step2(e, N, time_step, atom.mass.data(), atom.force_per_atom.data(), atom.velocity_per_atom.data());
-    find_thermo();
+    {
+      // Ensemble_NVE::compute2 reduces the thermodynamic sums every step (ensemble_nve.cu:85-94); nobody
+      // reads them between outputs, so the NVE path reduces only when a dump of this step needs them
+      bool wanted = ensemble != "nve";
+      wanted = wanted || (dump_thermo_interval > 0 && (step + 1) % dump_thermo_interval == 0);
+      for (const auto& d : dump_xyzs)
+        wanted = wanted || (step + 1) % d.interval == 0;
+      if (wanted)
+        find_thermo();
+    }
     if (ensemble == "nvt_ber") // Ensemble_BER::compute2, ensemble_ber.cu:195-235
       nepmi_berendsen_scale(e, N, target, 1.0 / temperature_coupling, thermo.data(), atom.velocity_per_atom.data());
     else if (ensemble == "nvt_bdp") // integrate_nvt_bdp_2, ensemble_bdp.cu:71-104
