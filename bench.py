@@ -395,6 +395,12 @@ def main():
             "kernels": kern,
             "thermo_last": [float(v) for v in th[-1]] if len(th) else None,
         }
+        if args.workload == "pbte":
+            # the path is FP32-VALU/gather bound, so the step is also priced against the
+            # FP32 vector peak with the survey's FLOP count of the reference algorithm (8e4 per atom-step)
+            out["fp32_valu"] = {"flop_per_atom_step_survey": 8.0e4, "equivalent_tflops": value * 8.0e4 / 1e12,
+                                "peak_tflops": 157.3, "frac": value * 8.0e4 / 157.3e12,
+                                "note": "the engine's own algebra needs ~3e4 FLOP per atom-step (DESIGN.md section 3)"}
         if world == 1 and not args.no_cpu_baseline and args.workload == "pbte":
             with _stdout_to_stderr():
                 out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
