@@ -996,7 +996,7 @@ struct RadialDescBody {
           cnt += inside ? 1 : 0;
           float d, dinv;
           dist_and_inv(d2, d, dinv);
-          const float rcinv = m.uniform_rc ? m.rcinv_r : 1.0f / rc;
+          const float rcinv = m.uniform_rc ? m.rcinv_r : fast_rcp(rc);
           const float dc = inside ? d : rc;
           float fc;
           cutoff_fc(rcinv, dc, fc);
@@ -1015,7 +1015,7 @@ struct RadialDescBody {
           ++cnt;
           float d, dinv;
           dist_and_inv(d2, d, dinv);
-          const float rcinv = 1.0f / rc;
+          const float rcinv = fast_rcp(rc);
           float fc;
           cutoff_fc(rcinv, d, fc);
           float fn[S::KRM + 1];
@@ -1261,7 +1261,7 @@ struct RadialFromRecordsBody {
       const int t2 = (int)((unsigned)e.w >> kIdxBits);
       const float d = sqrtf(dot3f(e.x, e.x, e.y, e.y, e.z, e.z));
       const float rc = (rc1 + m.rc_r[t2]) * 0.5f;
-      const float rcinv = 1.0f / rc;
+      const float rcinv = fast_rcp(rc);
       float fc;
       cutoff_fc(rcinv, d, fc);
       float fn[S::KRM + 1];
@@ -1313,7 +1313,7 @@ NEPMI_HD void angular_s_sums(const ModelD& m, const Bufs& b, int64_t k, int t1, 
     float d, dinv;
     dist_and_inv(dot3f(x, x, y, y, z, z), d, dinv);
     const float rc = m.uniform_rc ? m.rc_a_max : (rc1 + m.rc_a[t2]) * 0.5f;
-    const float rcinv = 1.0f / rc;
+    const float rcinv = fast_rcp(rc);
     float fc;
     cutoff_fc(rcinv, d, fc);
     float fn[S::KAM + 1];
@@ -1577,7 +1577,7 @@ struct AngularForceBody {
       float d, dinv;
       dist_and_inv(dot3f(x, x, y, y, z, z), d, dinv);
       const float rc = m.uniform_rc ? m.rc_a_max : (rc1 + m.rc_a[t2]) * 0.5f;
-      const float rcinv = 1.0f / rc;
+      const float rcinv = fast_rcp(rc);
       float fc, fcp;
       cutoff_fc_fcp(rcinv, d, fc, fcp);
       float fn[S::KAM + 1], fnp[S::KAM + 1];
@@ -1790,7 +1790,7 @@ struct ForceAssembleBody {
         float d, dinv;
         dist_and_inv(dot3f(x, x, y, y, z, z), d, dinv);
         const float rc = m.uniform_rc ? m.rc_r_max : (rc1 + m.rc_r[t2]) * 0.5f;
-        const float rcinv = m.uniform_rc ? m.rcinv_r : 1.0f / rc;
+        const float rcinv = m.uniform_rc ? m.rcinv_r : fast_rcp(rc);
         const float dc = valid ? d : 0.5f * rc;
         float fc, fcp;
         cutoff_fc_fcp(rcinv, dc, fc, fcp);

@@ -249,6 +249,16 @@ NEPMI_HD void cospi_sinpi_unit(float t, float& c, float& s)
   s = fmaf(cp, y2, 1.0f);
 }
 
+// 1 / x by v_rcp_f32 (1 ulp) instead of the IEEE division sequence (~9 instructions per pair)
+NEPMI_HD float fast_rcp(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_rcpf(x);
+#else
+  return 1.0f / x;
+#endif
+}
+
 // d = sqrt(d2) and 1/d from one reciprocal-square-root (v_rsq_f32, 1 ulp)
 NEPMI_HD void dist_and_inv(float d2, float& d, float& dinv)
 {
