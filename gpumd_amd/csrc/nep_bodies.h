@@ -1386,11 +1386,14 @@ struct AngularDescBody {
         for (int h = 0; h < kNumHarm; ++h)
           b.sbuf[(int64_t)(n * kNumHarm + h) * N + k] = s[i * kNumHarm + h];
       }
-      float qn[6];
+      float qn[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
       invariants(m, &s[i * kNumHarm], qn, 1);
-      for (int L = 0; L < m.numL; ++L) {
-        const int d = (NR + 1) + L * (NA + 1) + n;
-        b.q[(int64_t)d * N + gk] = qn[L] * m.qscale[d];
+#pragma unroll
+      for (int L = 0; L < 6; ++L) { // constant trip count: qn stays in registers
+        if (L < m.numL) {
+          const int d = (NR + 1) + L * (NA + 1) + n;
+          b.q[(int64_t)d * N + gk] = qn[L] * m.qscale[d];
+        }
       }
     }
   }

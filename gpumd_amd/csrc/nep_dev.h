@@ -465,15 +465,19 @@ NEPMI_HD void invariants(const ModelD& m, const float* s, float* q, int stride)
       acc += C3B[st + k] * s[st + k] * s[st + k];
     q[(L - 1) * stride] = 2.0f * acc + C3B[st] * s[st] * s[st];
   }
-  int Lidx = 4;
+  // the 4-body row sits at index 4, the 5-body row behind it (index 4 when there is no 4-body row);
+  // written with constant indices so that q stays in registers
+  const float q4b = NEPMI_C4B_0 * s[3] * s[3] * s[3] + NEPMI_C4B_1 * s[3] * (s[4] * s[4] + s[5] * s[5]) +
+                    NEPMI_C4B_2 * s[3] * (s[6] * s[6] + s[7] * s[7]) +
+                    NEPMI_C4B_3 * s[6] * (s[5] * s[5] - s[4] * s[4]) + NEPMI_C4B_4 * s[4] * s[5] * s[7];
+  const float s0 = s[0] * s[0], s12 = s[1] * s[1] + s[2] * s[2];
+  const float q5b = NEPMI_C5B_0 * s0 * s0 + NEPMI_C5B_1 * s0 * s12 + NEPMI_C5B_2 * s12 * s12;
   if (m.has222) {
-    q[(Lidx++) * stride] = NEPMI_C4B_0 * s[3] * s[3] * s[3] + NEPMI_C4B_1 * s[3] * (s[4] * s[4] + s[5] * s[5]) +
-                           NEPMI_C4B_2 * s[3] * (s[6] * s[6] + s[7] * s[7]) +
-                           NEPMI_C4B_3 * s[6] * (s[5] * s[5] - s[4] * s[4]) + NEPMI_C4B_4 * s[4] * s[5] * s[7];
-  }
-  if (m.has1111) {
-    const float s0 = s[0] * s[0], s12 = s[1] * s[1] + s[2] * s[2];
-    q[(Lidx++) * stride] = NEPMI_C5B_0 * s0 * s0 + NEPMI_C5B_1 * s0 * s12 + NEPMI_C5B_2 * s12 * s12;
+    q[4 * stride] = q4b;
+    if (m.has1111)
+      q[5 * stride] = q5b;
+  } else if (m.has1111) {
+    q[4 * stride] = q5b;
   }
 }
 
@@ -483,9 +487,8 @@ NEPMI_HD void invariants_adjoint(const ModelD& m, const float* fp, int stride, f
 {
   const float C3B[kNumHarm] = NEPMI_C3B_INIT;
   float g4[5] = {0, 0, 0, 0, 0}, g5[3] = {0, 0, 0};
-  int Lidx = 4;
   if (m.has222) {
-    const float F = fp[(Lidx++) * stride];
+    const float F = fp[4 * stride];
     const float s0 = s[3], s1 = s[4], s2 = s[5], s3 = s[6], s4 = s[7];
     g4[0] = F * (3.0f * NEPMI_C4B_0 * s0 * s0 + NEPMI_C4B_1 * (s1 * s1 + s2 * s2) + NEPMI_C4B_2 * (s3 * s3 + s4 * s4));
     g4[1] = F * (2.0f * NEPMI_C4B_1 * s0 * s1 - 2.0f * NEPMI_C4B_3 * s3 * s1 + NEPMI_C4B_4 * s2 * s4);
@@ -494,7 +497,7 @@ NEPMI_HD void invariants_adjoint(const ModelD& m, const float* fp, int stride, f
     g4[4] = F * (2.0f * NEPMI_C4B_2 * s0 * s4 + NEPMI_C4B_4 * s1 * s2);
   }
   if (m.has1111) {
-    const float F = fp[(Lidx++) * stride];
+    const float F = m.has222 ? fp[5 * stride] : fp[4 * stride]; // constant indices: fp stays in registers
     const float s0 = s[0], s1 = s[1], s2 = s[2];
     const float s12 = s1 * s1 + s2 * s2;
     g5[0] = F * (4.0f * NEPMI_C5B_0 * s0 * s0 * s0 + 2.0f * NEPMI_C5B_1 * s0 * s12);
