@@ -49,6 +49,7 @@ SYMBOLS = {
     "nepmi_potential_compute_levels_end": (C.c_int, [VP, c_dp, c_ip, c_i64, VP, VP, VP, VP, VP, VP]),
     "nepmi_engine_invalidate": (C.c_int, [VP]),
     "nepmi_engine_set_external_skin": (C.c_int, [VP, C.c_int]),
+    "nepmi_engine_set_unwrapped": (C.c_int, [VP, VP]),
     "nepmi_apply_pbc": (C.c_int, [VP, c_dp, c_ip, c_i64, VP]),
     "nepmi_zero_properties": (C.c_int, [VP, c_i64, VP, VP, VP]),
     "nepmi_vv_step1": (C.c_int, [VP, c_i64, C.c_double, VP, VP, VP, VP]),

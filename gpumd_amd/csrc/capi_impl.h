@@ -415,6 +415,14 @@ int nepmi_engine_set_external_skin(nepmi_engine* e, int on)
   return NEPMI_OK;
 }
 
+int nepmi_engine_set_unwrapped(nepmi_engine* e, double* d_unwrapped)
+{
+  if (!e)
+    return fail(NEPMI_ERR_ARG, "null engine");
+  e->e->set_unwrapped(d_unwrapped);
+  return NEPMI_OK;
+}
+
 int nepmi_engine_set_generic(nepmi_engine* e, int on)
 {
   if (!e)

@@ -269,6 +269,7 @@ public:
     body.force = force;
     body.pos = pos;
     body.vel = vel;
+    body.unwrapped = step1 ? unwrapped_ : nullptr;
     be_.template launch<256>(kSlotVV, n, body);
   }
 
@@ -503,7 +504,7 @@ public:
       seam_done = !record && step + 1 < nsteps;
       if (seam_done) {
         // vv2 of this step + vv1/wrap/zero of the next in one pass (nothing reads v in between)
-        VerletSeamBody body{n, dt, box, mass, force, pos, vel, pe, virial};
+        VerletSeamBody body{n, dt, box, mass, force, pos, vel, pe, virial, unwrapped_};
         be_.template launch<256>(kSlotVV, n, body);
         continue;
       }
@@ -958,6 +959,8 @@ public:
   // invalidate()): no per-step flag read-back, the force path is enqueued without a host round trip.
   // List-capacity overflow is then reported at the next rebuild or stats() call.
   void set_external_skin(bool on) { external_skin_ = on; }
+  // caller-owned [3N] array that every first-half-step drift is also added to (atom.unwrapped_position)
+  void set_unwrapped(double* u) { unwrapped_ = u; }
   void check_flags_now()
   {
     int flags[kNumFlags];
@@ -1077,6 +1080,7 @@ private:
   bool records_valid_ = false; // rstash holds the pair records of the last evaluated positions
   int recompute_mode_ = -1;
   bool external_skin_ = false;
+  double* unwrapped_ = nullptr;
   bool split_pending_ = false;   // compute_levels_begin ran, compute_levels_end has not yet
   int64_t num_boundary_bricks_ = 0;
   int64_t num_bricks_ = 0;

@@ -154,6 +154,7 @@ struct VelocityVerletBody {
   const double* force;
   double* pos;
   double* vel;
+  double* unwrapped; // [3N] or nullptr: gpu_update_unwrapped_position, integrate.cu:312-372
   NEPMI_HD void operator()(int64_t i) const
   {
 #pragma clang fp contract(off) // v + (a * half): two roundings, as the oracle computes it
@@ -172,7 +173,10 @@ struct VelocityVerletBody {
 #pragma unroll
       for (int d = 0; d < 3; ++d) {
         const double drift = v[d] * dt;
-        r[d] = pos[d * N + i] + drift;
+        const double old = pos[d * N + i];
+        r[d] = old + drift;
+        if (unwrapped)
+          unwrapped[d * N + i] += r[d] - old; // new - old of the un-wrapped drift, like the reference
       }
       if (fuse_wrap)
         wrap_position(box, r[0], r[1], r[2]);
@@ -197,6 +201,7 @@ struct VerletSeamBody {
   double* vel;
   double* pe;
   double* virial;
+  double* unwrapped; // [3N] or nullptr
   NEPMI_HD void operator()(int64_t i) const
   {
 #pragma clang fp contract(off)
@@ -211,7 +216,10 @@ struct VerletSeamBody {
       const double v1 = v2 + kick;             // first call of step n + 1 (same force)
       vel[d * N + i] = v1;
       const double drift = v1 * dt;
-      r[d] = pos[d * N + i] + drift;
+      const double old = pos[d * N + i];
+      r[d] = old + drift;
+      if (unwrapped)
+        unwrapped[d * N + i] += r[d] - old;
       force[d * N + i] = 0.0;
     }
     wrap_position(box, r[0], r[1], r[2]);

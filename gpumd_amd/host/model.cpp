@@ -110,7 +110,28 @@ static bool find_key(const std::string& line, const std::string& key, std::strin
   return true;
 }
 
-bool read_xyz(const std::string& path, const std::vector<std::string>& elements, Box& box, Atom& atom)
+void Group::find_size_and_contents(int N, int k)
+{
+  cpu_size.assign(number, 0);
+  cpu_size_sum.assign(number, 0);
+  cpu_contents.resize(N);
+  if (number == 1)
+    std::printf("There is only one group of atoms in grouping method %d.\n", k);
+  else
+    std::printf("There are %d groups of atoms in grouping method %d.\n", number, k);
+  for (int n = 0; n < N; ++n)
+    cpu_size[cpu_label[n]]++;
+  for (int m = 0; m < number; ++m)
+    std::printf("    %d atoms in group %d.\n", cpu_size[m], m);
+  for (int m = 1; m < number; ++m)
+    cpu_size_sum[m] = cpu_size_sum[m - 1] + cpu_size[m - 1];
+  std::vector<int> fill(cpu_size_sum);
+  for (int n = 0; n < N; ++n)
+    cpu_contents[fill[cpu_label[n]]++] = n;
+}
+
+bool read_xyz(
+  const std::string& path, const std::vector<std::string>& elements, Box& box, Atom& atom, std::vector<Group>& groups)
 {
   std::ifstream in(path);
   if (!in)
@@ -157,7 +178,8 @@ bool read_xyz(const std::string& path, const std::vector<std::string>& elements,
     while (std::getline(ss, w, ':'))
       p.push_back(w);
   }
-  int off = 0, off_species = -1, off_pos = -1, off_mass = -1, off_vel = -1;
+  int off = 0, off_species = -1, off_pos = -1, off_mass = -1, off_vel = -1, off_charge = -1, off_group = -1;
+  int num_grouping_methods = 0;
   for (size_t k = 0; k + 3 <= p.size(); k += 3) {
     const std::string name = lower(p[k]);
     const int cnt = std::atoi(p[k + 2].c_str());
@@ -165,10 +187,25 @@ bool read_xyz(const std::string& path, const std::vector<std::string>& elements,
     else if (name == "pos") off_pos = off;
     else if (name == "mass") off_mass = off;
     else if (name == "vel") off_vel = off;
+    else if (name == "charge") off_charge = off;
+    else if (name == "group") { off_group = off; num_grouping_methods = cnt; }
     off += cnt;
   }
   if (off_species < 0 || off_pos < 0)
     input_error("'species' or 'pos' is missing in properties.");
+  std::printf(off_vel < 0 ? "Do not specify initial velocities here.\n" : "Specify initial velocities here.\n");
+  groups.clear();
+  groups.resize(off_group < 0 ? 0 : num_grouping_methods);
+  if (groups.empty())
+    std::printf("Have no grouping method.\n");
+  else
+    std::printf("Have %d grouping method(s).\n", (int)groups.size());
+  for (auto& g : groups) {
+    g.cpu_label.resize(N);
+    g.number = 0;
+  }
+  atom.has_charge = off_charge >= 0;
+  atom.cpu_charge.assign(N, 0.0f);
 
   atom.number_of_atoms = N;
   atom.cpu_atom_symbol.resize(N);
@@ -203,17 +240,31 @@ bool read_xyz(const std::string& path, const std::vector<std::string>& elements,
     if (off_vel >= 0)
       for (int d = 0; d < 3; ++d) // A/fs -> natural units (read_xyz.cu:380-386)
         atom.cpu_velocity_per_atom[n + (size_t)N * d] = std::atof(tok[off_vel + d].c_str()) * TIME_UNIT_CONVERSION;
+    if (off_charge >= 0)
+      atom.cpu_charge[n] = (float)std::atof(tok[off_charge].c_str());
+    for (size_t m = 0; m < groups.size(); ++m) { // read_xyz.cu:389-398
+      const int label = std::atoi(tok[off_group + m].c_str());
+      if (label < 0 || label >= N)
+        input_error("Group label should >= 0 and < N.");
+      groups[m].cpu_label[n] = label;
+      if (label + 1 > groups[m].number)
+        groups[m].number = label + 1;
+    }
   }
+  for (size_t m = 0; m < groups.size(); ++m)
+    groups[m].find_size_and_contents(N, (int)m);
   return off_vel >= 0;
 }
 
-void replicate(const int r[3], Box& box, Atom& atom)
+void replicate(const int r[3], Box& box, Atom& atom, std::vector<Group>& groups)
 {
   const int N0 = atom.number_of_atoms;
   const int N = N0 * r[0] * r[1] * r[2];
   std::vector<std::string> sym(N);
   std::vector<int> type(N);
   std::vector<double> mass(N), pos(3 * (size_t)N), vel(3 * (size_t)N, 0.0);
+  std::vector<float> charge(N);
+  std::vector<std::vector<int>> label(groups.size(), std::vector<int>(N));
   const double* h = box.cpu_h;
   int m = 0;
   for (int i = 0; i < r[0]; ++i)
@@ -223,6 +274,9 @@ void replicate(const int r[3], Box& box, Atom& atom)
           sym[m] = atom.cpu_atom_symbol[n];
           type[m] = atom.cpu_type[n];
           mass[m] = atom.cpu_mass[n];
+          charge[m] = atom.cpu_charge[n];
+          for (size_t g = 0; g < groups.size(); ++g)
+            label[g][m] = groups[g].cpu_label[n];
           const double d[3] = {h[0] * i + h[1] * j + h[2] * k, h[3] * i + h[4] * j + h[5] * k,
                                h[6] * i + h[7] * j + h[8] * k};
           for (int c = 0; c < 3; ++c) {
@@ -240,6 +294,11 @@ void replicate(const int r[3], Box& box, Atom& atom)
   atom.cpu_atom_symbol.swap(sym);
   atom.cpu_type.swap(type);
   atom.cpu_mass.swap(mass);
+  atom.cpu_charge.swap(charge);
+  for (size_t g = 0; g < groups.size(); ++g) { // labels repeat with the cell: sizes scale, numbers stay
+    groups[g].cpu_label.swap(label[g]);
+    groups[g].find_size_and_contents(N, (int)g);
+  }
   atom.cpu_position_per_atom.swap(pos);
   atom.cpu_velocity_per_atom.swap(vel);
   std::printf("Replicated the box: %d x %d x %d, %d atoms.\n", r[0], r[1], r[2], N);

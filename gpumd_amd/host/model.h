@@ -59,16 +59,29 @@ struct Box {
   double get_volume() const;
 };
 
+// Group (src/model/group.cuh, group.cu:25-72): one grouping method of model.xyz's group:I:k columns
+struct Group {
+  int number = 0;                // number of groups in this grouping method (largest label + 1)
+  std::vector<int> cpu_label;    // [N] group label of every atom
+  std::vector<int> cpu_size;     // [number] atoms per group
+  std::vector<int> cpu_size_sum; // [number] exclusive prefix of cpu_size
+  std::vector<int> cpu_contents; // [N] atom indices ordered by group, ascending inside a group
+  void find_size_and_contents(int N, int k);
+};
+
 // Atom (src/model/atom.cuh:32-42)
 struct Atom {
   int number_of_atoms = 0;
   std::vector<std::string> cpu_atom_symbol;
   std::vector<int> cpu_type;
   std::vector<double> cpu_mass;
+  std::vector<float> cpu_charge; // zeros unless model.xyz has a charge column
+  bool has_charge = false;
   std::vector<double> cpu_position_per_atom; // [x..|y..|z..]
   std::vector<double> cpu_velocity_per_atom;
   GPU_Vector<int> type;
   GPU_Vector<double> mass, position_per_atom, velocity_per_atom, force_per_atom, potential_per_atom, virial_per_atom;
+  GPU_Vector<double> unwrapped_position; // empty until a dump asks for it (dump_xyz.cu:60-63)
   void allocate_gpu(); // allocate_memory_gpu, read_xyz.cu:532-557
 };
 
@@ -77,9 +90,10 @@ std::vector<std::string> get_tokens(const std::string& line);
 
 // initialize_position (read_xyz.cu:482-530): model.xyz with the potential's element list
 // returns has_velocity_in_xyz
-bool read_xyz(const std::string& path, const std::vector<std::string>& elements, Box& box, Atom& atom);
+bool read_xyz(
+  const std::string& path, const std::vector<std::string>& elements, Box& box, Atom& atom, std::vector<Group>& groups);
 // Replicate (src/main_gpumd/replicate.cu:50-71): supercell, atom order i,j,k outer, basis inner
-void replicate(const int n[3], Box& box, Atom& atom);
+void replicate(const int n[3], Box& box, Atom& atom, std::vector<Group>& groups);
 // Velocity::initialize (velocity.cu:312-347): glibc rand() stream, momentum corrections, rescale
 void initialize_velocity(double temperature, bool use_seed, int seed, Atom& atom);
 void write_xyz_frame(FILE* f, const Box& box, const Atom& atom, const char* extra_props);

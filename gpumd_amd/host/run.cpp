@@ -1,3 +1,4 @@
+#include <cerrno>
 #include "run.h"
 
 #include <chrono>
@@ -6,6 +7,20 @@
 #include <fstream>
 
 namespace gmi {
+
+// is_valid_int (src/utilities/read_file.cu:26-41): the whole token must be one integer (any strtol base)
+static bool is_valid_int(const std::string& tok, int* result)
+{
+  if (tok.empty())
+    return false;
+  char* end = nullptr;
+  errno = 0;
+  const long v = std::strtol(tok.c_str(), &end, 0);
+  if (errno != 0 || end == tok.c_str() || *end != 0)
+    return false;
+  *result = (int)v;
+  return true;
+}
 
 static std::vector<std::string> strip(const std::string& line)
 {
@@ -39,7 +54,7 @@ Run::Run(bool check_only) : check_only_(check_only)
   if (potential_file.empty())
     input_error("There is no 'potential' keyword before run.");
   elements = potential_elements(potential_file);
-  has_velocity_in_xyz = read_xyz("model.xyz", elements, box, atom);
+  has_velocity_in_xyz = read_xyz("model.xyz", elements, box, atom, groups);
   if (!has_velocity_in_xyz)
     initialize_velocity(initial_temperature, false, 0, atom); // default 300 K (run.cu:155-160)
   thermo.resize(check_only_ ? 0 : 12);
@@ -67,7 +82,7 @@ void Run::parse_one_keyword(const std::vector<std::string>& p)
     const int n[3] = {std::atoi(p[1].c_str()), std::atoi(p[2].c_str()), std::atoi(p[3].c_str())};
     if (n[0] < 1 || n[1] < 1 || n[2] < 1)
       input_error("replicate numbers should be >= 1.");
-    replicate(n, box, atom);
+    replicate(n, box, atom, groups);
     if (!has_velocity_in_xyz)
       initialize_velocity(initial_temperature, false, 0, atom);
   } else if (k == "potential") {
@@ -136,29 +151,87 @@ void Run::parse_one_keyword(const std::vector<std::string>& p)
     if (p.size() != 2)
       input_error("dump_restart should have 1 parameter.");
     dump_restart_interval = std::atoi(p[1].c_str());
-  } else if (k == "dump_xyz") {
+  } else if (k == "dump_xyz") { // Dump_XYZ::parse, dump_xyz.cu:70-155
+    std::printf("Dump extended XYZ.\n");
     if (p.size() < 3)
       input_error("dump_xyz should have at least 2 parameters.");
+    int scratch;
+    if (p.size() >= 4 && is_valid_int(p[2], &scratch) && is_valid_int(p[3], &scratch))
+      input_error("dump_xyz no longer takes <grouping_method> <group_id> as its first two parameters. Use dump_xyz "
+                  "<interval> <filename> [group <grouping_method> <group_id>] instead.");
     DumpXyz d;
-    d.interval = std::atoi(p[1].c_str());
+    if (!is_valid_int(p[1], &d.interval))
+      input_error("dump interval should be an integer.");
     if (d.interval <= 0)
       input_error("dump interval should > 0.");
+    std::printf("    every %d steps.\n", d.interval);
+    std::printf("    into file %s.\n", p[2].c_str());
     d.filename = p[2];
-    for (size_t m = 3; m < p.size(); ++m) {
-      if (p[m] == "precision") {
-        if (m + 1 >= p.size())
-          input_error("precision should be followed by single or double.");
-        d.precision = p[m + 1] == "single" ? 1 : 2;
-        ++m;
-      } else if (p[m] == "mass") d.has_mass = true;
-      else if (p[m] == "velocity") d.has_velocity = true;
-      else if (p[m] == "force") d.has_force = true;
-      else if (p[m] == "potential") d.has_potential = true;
-      else if (p[m] == "virial") d.has_virial = true;
-      else input_error("Unrecognized argument in dump_xyz.");
+    if (d.filename.back() == '*') {
+      d.separated = true;
+      d.filename.pop_back();
     }
+    bool group_seen = false, precision_seen = false;
+    auto quantity = [&](bool& flag, const std::string& name, const char* what) { // set_quantity, parse_utilities.cu:83-95
+      if (flag)
+        input_error("Quantity '" + name + "' is specified more than once in dump_xyz.");
+      flag = true;
+      std::printf("    has %s.\n", what);
+    };
+    for (size_t m = 3; m < p.size(); ++m) {
+      if (p[m] == "group") { // parse_group, parse_utilities.cu:27-64
+        if (group_seen)
+          input_error("Option 'group' is specified more than once in dump_xyz.");
+        int probe;
+        if (m + 2 >= p.size() || !is_valid_int(p[m + 1], &probe) || !is_valid_int(p[m + 2], &probe))
+          input_error("Option 'group' should be followed by a grouping method and a group ID. The quantity that "
+                      "writes group labels as a column is now called 'group_labels'.");
+        d.grouping_method = std::atoi(p[m + 1].c_str());
+        d.group_id = std::atoi(p[m + 2].c_str());
+        if (d.grouping_method < 0)
+          input_error("Grouping method should >= 0.");
+        if (d.grouping_method >= (int)groups.size())
+          input_error("Grouping method should < number of grouping methods.");
+        if (d.group_id >= groups[d.grouping_method].number)
+          input_error("Group ID should < number of groups.");
+        if (d.group_id < 0)
+          input_error("group ID should >= 0.");
+        std::printf("    grouping method is %d and group ID is %d.\n", d.grouping_method, d.group_id);
+        group_seen = true;
+        m += 2;
+      } else if (p[m] == "precision") { // parse_precision, parse_utilities.cu:66-81
+        if (precision_seen)
+          input_error("Option 'precision' is specified more than once in dump_xyz.");
+        if (m + 1 >= p.size())
+          input_error("Not enough arguments for option 'precision'.");
+        if (p[m + 1] == "single") {
+          d.precision = 1;
+          std::printf("    with single precision.\n");
+        } else if (p[m + 1] == "double") {
+          d.precision = 2;
+          std::printf("    with double precision.\n");
+        } else {
+          input_error("Invalid precision.");
+        }
+        precision_seen = true;
+        ++m;
+      } else if (p[m] == "velocity") quantity(d.has_velocity, p[m], "velocity");
+      else if (p[m] == "force") quantity(d.has_force, p[m], "force");
+      else if (p[m] == "potential") quantity(d.has_potential, p[m], "potential");
+      else if (p[m] == "unwrapped_position") quantity(d.has_unwrapped_position, p[m], "unwrapped position");
+      else if (p[m] == "mass") quantity(d.has_mass, p[m], "mass");
+      else if (p[m] == "charge") quantity(d.has_charge, p[m], "charge specified in model.xyz");
+      else if (p[m] == "virial") quantity(d.has_virial, p[m], "virial");
+      else if (p[m] == "bec") input_error("Cannot output BEC for a non-NEP-charge model.");
+      else if (p[m] == "group_labels") {
+        if (groups.empty())
+          input_error("Cannot output group labels without a grouping method defined in model.xyz.");
+        quantity(d.has_group_labels, p[m], "group labels");
+      } else input_error("Unrecognized argument in dump_xyz.");
+    }
+    if (d.grouping_method < 0)
+      std::printf("    for the whole system.\n");
     dump_xyzs.push_back(d);
-    std::printf("Dump extended XYZ every %d steps into file %s.\n", d.interval, d.filename.c_str());
   } else if (k == "run") {
     if (p.size() != 2)
       input_error("run should have 1 parameter.");
@@ -209,21 +282,26 @@ void Run::dump_thermo(int step)
   std::fflush(fid);
 }
 
-// Dump_XYZ (src/measure/dump_xyz.cu:196-420)
+// Dump_XYZ::output_line2 + process (src/measure/dump_xyz.cu:196-440)
 void Run::dump_xyz(DumpXyz& d, int step)
 {
   if ((step + 1) % d.interval != 0)
     return;
-  if (!d.fid)
+  if (d.separated) // one frame per file, named by the step it belongs to
+    d.fid = std::fopen((d.filename + std::to_string(step + 1)).c_str(), "w");
+  else if (!d.fid)
     d.fid = std::fopen(d.filename.c_str(), "a");
+  if (!d.fid)
+    input_error("Cannot open " + d.filename + ".");
   const int N = atom.number_of_atoms;
   const char* fmt = d.precision == 1 ? " %.9g" : " %.17g";
-  std::vector<double> pos(3 * (size_t)N), vel, frc, pe, vir(9 * (size_t)N);
+  std::vector<double> pos(3 * (size_t)N), vel, frc, pe, unw, vir(9 * (size_t)N);
   atom.position_per_atom.copy_to_host(pos.data());
   atom.virial_per_atom.copy_to_host(vir.data());
   if (d.has_velocity) { vel.resize(3 * (size_t)N); atom.velocity_per_atom.copy_to_host(vel.data()); }
   if (d.has_force) { frc.resize(3 * (size_t)N); atom.force_per_atom.copy_to_host(frc.data()); }
   if (d.has_potential) { pe.resize(N); atom.potential_per_atom.copy_to_host(pe.data()); }
+  if (d.has_unwrapped_position) { unw.resize(3 * (size_t)N); atom.unwrapped_position.copy_to_host(unw.data()); }
   double t[8];
   thermo.copy_to_host(t, 8);
   double tv[6] = {0, 0, 0, 0, 0, 0};
@@ -236,7 +314,13 @@ void Run::dump_xyz(DumpXyz& d, int step)
       std::fprintf(d.fid, k == 0 ? fmt + 1 : fmt, v[k]);
     std::fprintf(d.fid, "\"");
   };
-  std::fprintf(d.fid, "%d\n", N);
+  // the header always describes the whole system, also when only one group's atoms follow
+  const int num_dump = d.grouping_method >= 0 ? groups[d.grouping_method].cpu_size[d.group_id] : N;
+  const int* contents =
+    d.grouping_method >= 0
+      ? groups[d.grouping_method].cpu_contents.data() + groups[d.grouping_method].cpu_size_sum[d.group_id]
+      : nullptr;
+  std::fprintf(d.fid, "%d\n", num_dump);
   std::fprintf(d.fid, "Time=%.8f", global_time * TIME_UNIT_CONVERSION);
   std::fprintf(d.fid, " pbc=\"%c %c %c\"", box.pbc_x ? 'T' : 'F', box.pbc_y ? 'T' : 'F', box.pbc_z ? 'T' : 'F');
   const double* h = box.cpu_h;
@@ -250,26 +334,40 @@ void Run::dump_xyz(DumpXyz& d, int step)
   tensor("stress", stress);
   std::fprintf(d.fid, " Properties=species:S:1:pos:R:3");
   if (d.has_mass) std::fprintf(d.fid, ":mass:R:1");
+  if (d.has_charge) std::fprintf(d.fid, ":charge:R:1");
   if (d.has_velocity) std::fprintf(d.fid, ":vel:R:3");
   if (d.has_force) std::fprintf(d.fid, ":forces:R:3");
   if (d.has_potential) std::fprintf(d.fid, ":energy_atom:R:1");
+  if (d.has_unwrapped_position) std::fprintf(d.fid, ":unwrapped_position:R:3");
   if (d.has_virial) std::fprintf(d.fid, ":virial:R:9");
+  if (d.has_group_labels) std::fprintf(d.fid, ":group:I:%d", (int)groups.size());
   std::fprintf(d.fid, "\n");
   const int vidx[9] = {0, 3, 4, 6, 1, 5, 7, 8, 2}; // dump_xyz.cu: xx xy xz yx yy yz zx zy zz
-  for (int n = 0; n < N; ++n) {
+  for (int k = 0; k < num_dump; ++k) {
+    const int n = contents ? contents[k] : k;
     std::fprintf(d.fid, "%s", atom.cpu_atom_symbol[n].c_str());
     for (int c = 0; c < 3; ++c) std::fprintf(d.fid, fmt, pos[n + (size_t)N * c]);
     if (d.has_mass) std::fprintf(d.fid, fmt, atom.cpu_mass[n]);
+    if (d.has_charge) std::fprintf(d.fid, fmt, atom.cpu_charge[n]);
     if (d.has_velocity)
       for (int c = 0; c < 3; ++c) std::fprintf(d.fid, fmt, vel[n + (size_t)N * c] / TIME_UNIT_CONVERSION);
     if (d.has_force)
       for (int c = 0; c < 3; ++c) std::fprintf(d.fid, fmt, frc[n + (size_t)N * c]);
     if (d.has_potential) std::fprintf(d.fid, fmt, pe[n]);
+    if (d.has_unwrapped_position)
+      for (int c = 0; c < 3; ++c) std::fprintf(d.fid, fmt, unw[n + (size_t)N * c]);
     if (d.has_virial)
       for (int c = 0; c < 9; ++c) std::fprintf(d.fid, fmt, vir[n + (size_t)N * vidx[c]]);
+    if (d.has_group_labels)
+      for (const auto& g : groups) std::fprintf(d.fid, " %d", g.cpu_label[n]);
     std::fprintf(d.fid, "\n");
   }
-  std::fflush(d.fid);
+  if (d.separated) {
+    std::fclose(d.fid);
+    d.fid = nullptr;
+  } else {
+    std::fflush(d.fid);
+  }
 }
 
 // Dump_Restart (src/measure/dump_restart.cu:66-136), full precision instead of %g
@@ -285,13 +383,20 @@ void Run::dump_restart(int step)
   const double* h = box.cpu_h;
   std::fprintf(fid, "%d\n", N);
   std::fprintf(fid, "pbc=\"%c %c %c\" Lattice=\"%.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g\" "
-                    "Properties=species:S:1:pos:R:3:mass:R:1:vel:R:3\n",
+                    "Properties=species:S:1:pos:R:3:mass:R:1:vel:R:3",
                box.pbc_x ? 'T' : 'F', box.pbc_y ? 'T' : 'F', box.pbc_z ? 'T' : 'F', h[0], h[3], h[6], h[1], h[4], h[7], h[2],
                h[5], h[8]);
-  for (int n = 0; n < N; ++n)
-    std::fprintf(fid, "%s %.17g %.17g %.17g %.17g %.17g %.17g %.17g\n", atom.cpu_atom_symbol[n].c_str(), pos[n],
+  if (!groups.empty()) // dump_restart.cu:111-115
+    std::fprintf(fid, ":group:I:%d", (int)groups.size());
+  std::fprintf(fid, "\n");
+  for (int n = 0; n < N; ++n) {
+    std::fprintf(fid, "%s %.17g %.17g %.17g %.17g %.17g %.17g %.17g", atom.cpu_atom_symbol[n].c_str(), pos[n],
                  pos[n + (size_t)N], pos[n + 2 * (size_t)N], atom.cpu_mass[n], vel[n] / TIME_UNIT_CONVERSION,
                  vel[n + (size_t)N] / TIME_UNIT_CONVERSION, vel[n + 2 * (size_t)N] / TIME_UNIT_CONVERSION);
+    for (const auto& g : groups)
+      std::fprintf(fid, " %d", g.cpu_label[n]);
+    std::fprintf(fid, "\n");
+  }
   std::fclose(fid);
 }
 
@@ -302,6 +407,19 @@ void Run::perform_a_run()
     input_error("No potential is defined before run.");
   const int N = atom.number_of_atoms;
   nepmi_engine* e = force.engine();
+  // Dump_XYZ's constructor (dump_xyz.cu:60-63): the first dump that asks for unwrapped positions starts the
+  // array from the coordinates as they are (not yet wrapped); from then on every first half-step adds its
+  // drift to it (integrate.cu:347-372), in this run and the following ones
+  bool want_unwrapped = false;
+  for (const auto& d : dump_xyzs)
+    want_unwrapped = want_unwrapped || d.has_unwrapped_position;
+  if (want_unwrapped && atom.unwrapped_position.size() == 0) {
+    atom.unwrapped_position.resize(3 * (size_t)N);
+    hip_check(hipMemcpy(atom.unwrapped_position.data(), atom.position_per_atom.data(), sizeof(double) * 3 * (size_t)N,
+                        hipMemcpyDeviceToDevice), "D2D");
+    if (nepmi_engine_set_unwrapped(e, atom.unwrapped_position.data()) != NEPMI_OK)
+      input_error(nepmi_last_error());
+  }
   if (dump_thermo_interval > 0) {
     FILE* fid = std::fopen("thermo.out", "a");
     std::fprintf(fid, "# dump_thermo %d\n# format_version 1\n# num_atoms %d\n# dt_output %.10e fs\n", dump_thermo_interval, N,

@@ -1,6 +1,6 @@
 // Run: the run.in interpreter and the MD loop (src/main_gpumd/run.{cu,cuh}), restricted to the
 // keywords of the hot path: potential, replicate, velocity, ensemble nve, time_step, dump_thermo,
-// dump_xyz, dump_restart, run.
+// dump_xyz (all options but the NEP-charge quantities), dump_restart, run.
 #pragma once
 #include "force.h"
 
@@ -10,7 +10,11 @@ struct DumpXyz {
   int interval = 0;
   std::string filename;
   int precision = 2; // 1 single (%.9g), 2 double (%.17g)   -- dump_xyz.cu:163-165
-  bool has_mass = false, has_velocity = false, has_force = false, has_potential = false, has_virial = false;
+  bool has_mass = false, has_charge = false, has_velocity = false, has_force = false, has_potential = false,
+       has_unwrapped_position = false, has_virial = false, has_group_labels = false; // parse_utilities.cu:97-147
+  bool separated = false;   // file name ended in '*': one file per frame, <name><step>  (dump_xyz.cu:104-110)
+  int grouping_method = -1; // `group <method> <id>`: only that group's atoms are written (dump_xyz.cu:368-372)
+  int group_id = 0;
   FILE* fid = nullptr;
 };
 
@@ -31,6 +35,7 @@ private:
   bool check_only_;
   Box box;
   Atom atom;
+  std::vector<Group> groups;
   Force force;
   bool has_velocity_in_xyz = false;
   bool gpu_allocated = false;

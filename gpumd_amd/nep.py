@@ -129,6 +129,11 @@ class NEP:
     def set_external_skin(self, on=True):
         self._ck(self.lib.nepmi_engine_set_external_skin(self.handle, 1 if on else 0))
 
+    def set_unwrapped(self, unwrapped=None):
+        """Atom::unwrapped_position: a [3N] f64 array that every first half-step adds its drift to (None: off)."""
+        self._unwrapped = unwrapped  # keep the storage alive while the engine points at it
+        self._ck(self.lib.nepmi_engine_set_unwrapped(self.handle, self._ptr(unwrapped) if unwrapped is not None else None))
+
     def invalidate(self):
         self._ck(self.lib.nepmi_engine_invalidate(self.handle))
 

@@ -111,6 +111,11 @@ int nepmi_engine_invalidate(nepmi_engine* e);
  * the per-step flag read-back and are enqueued without any host round trip.  List-capacity overflow
  * is reported at the next rebuild or nepmi_engine_stats call instead of immediately. */
 int nepmi_engine_set_external_skin(nepmi_engine* e, int on);
+/* Unwrapped coordinates (Atom::unwrapped_position; gpu_update_unwrapped_position,
+ * src/integrate/integrate.cu:312-372): a caller-owned device array [3N] that every first
+ * half-step (nepmi_vv_step1 and the fused nepmi_run_* loops) adds its un-wrapped drift
+ * (new - old position, before the periodic wrap) to.  NULL (the default) switches it off. */
+int nepmi_engine_set_unwrapped(nepmi_engine* e, double* d_unwrapped);
 /* The same call in two halves, so that a domain-decomposed host can overlap its ghost-position
  * exchange (the RCCL send/recv that replaces NEP_MULTIGPU's staged copies) with compute:
  *   _begin: the OWNED (level 2) entries of pos are final; ghost entries may still be in flight and

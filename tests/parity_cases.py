@@ -156,6 +156,50 @@ def check_nve_against_oracle(drv, nsteps=20, reps=(2, 2, 2)):
     assert np.abs(etot - etot[0]).max() < 2e-3 * (2.0 ** 2) * n
 
 
+def check_unwrapped_positions(drv, nsteps=24):
+    """Atom::unwrapped_position (integrate.cu:312-372): the fused loops add every un-wrapped drift to the
+    caller's array; bit-identical to new - old taken around the stand-alone first half-step."""
+    nep = H.golden("PbTe", "nep.txt")
+    h, typ, x = H.pbte_supercell((2, 2, 2), rattle=0.02, seed=77)
+    n = len(typ)
+    orc = H.Oracle(nep)
+    mass = np.array([H.MASS[orc.symbols[t]] for t in typ])
+    vel = H.maxwell_velocities(mass, 3000.0, seed=8)
+    dt = 2.0 / H.TIME_UNIT
+    model = drv.model(nep)
+
+    # fused run with the unwrapped array registered (records every 5 steps: seam and plain halves both run)
+    eng = drv.engine(model, n)
+    d_t, d_m, d_x, d_v = drv.dev(typ), drv.dev(mass), drv.dev(x), drv.dev(vel)
+    d_pe, d_f, d_w = drv.zeros(n), drv.zeros(3 * n), drv.zeros(9 * n)
+    d_u = drv.dev(x.copy())
+    eng.set_unwrapped(d_u)
+    eng.force_compute(h, d_t, d_x, d_pe, d_f, d_w)
+    eng.run_nve(h, d_t, d_m, dt, nsteps, d_x, d_v, d_pe, d_f, d_w, thermo_every=5)
+    unw, xs = drv.host(d_u), drv.host(d_x)
+    eng.set_unwrapped(None)
+
+    # the same trajectory through the stand-alone calls, unwrapped kept on the host
+    eng2 = drv.engine(model, n)
+    e_x, e_v = drv.dev(x), drv.dev(vel)
+    e_pe, e_f, e_w = drv.zeros(n), drv.zeros(3 * n), drv.zeros(9 * n)
+    eng2.force_compute(h, d_t, e_x, e_pe, e_f, e_w)
+    ref = x.copy()
+    for _ in range(nsteps):
+        old = drv.host(e_x)
+        eng2.vv_step1(dt, d_m, e_f, e_x, e_v)
+        ref += drv.host(e_x) - old
+        eng2.force_compute(h, d_t, e_x, e_pe, e_f, e_w)
+        eng2.vv_step2(dt, d_m, e_f, e_v)
+    assert np.array_equal(xs, drv.host(e_x))
+    assert np.array_equal(unw, ref)
+    # unwrapped - wrapped is a lattice vector, and some atoms did leave the cell
+    H3 = np.asarray(h).reshape(3, 3)
+    frac = np.linalg.solve(H3, (unw - xs).reshape(3, n))
+    assert np.abs(frac - np.rint(frac)).max() < 1e-9
+    assert np.abs(np.rint(frac)).max() >= 1
+
+
 def check_streaming_ops(drv):
     """apply_pbc, velocity-Verlet halves and find_thermo alone, against the oracle (FP64)."""
     h, typ, x = H.pbte_supercell((2, 2, 2), seed=41)

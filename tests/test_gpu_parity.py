@@ -83,6 +83,10 @@ def test_streaming_ops(drv):
     P.check_streaming_ops(drv)
 
 
+def test_unwrapped_positions(drv):
+    P.check_unwrapped_positions(drv)
+
+
 def test_nvt_berendsen(drv):
     P.check_nvt_berendsen(drv)
 

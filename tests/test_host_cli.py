@@ -18,6 +18,22 @@ def _workdir(tmp_path, run_in):
     return str(tmp_path)
 
 
+def _grouped_workdir(tmp_path, run_in, shift=0.0):
+    """PbTe model.xyz with a charge column and two grouping methods (by species; by index parity + a third group)."""
+    src = H.read_xyz_frames(H.golden("PbTe", "model.xyz"))[0]
+    lines = open(H.golden("PbTe", "model.xyz")).read().split("\n")
+    head = lines[1].split("Properties=")[0]
+    out = ["%d" % src["n"], head + "Properties=species:S:1:pos:R:3:charge:R:1:group:I:2"]
+    for k in range(src["n"]):
+        sp = src["species"][k]
+        x = src["pos"][k] + shift  # shift > 0 moves some atoms out of the cell: unwrapped != wrapped from step 0
+        out.append("%s %.17g %.17g %.17g %g %d %d" % (sp, x[0], x[1], x[2], 0.5 if sp == "Pb" else -0.5,
+                                                      0 if sp == "Te" else 1, 2 if k >= 240 else k % 2))
+    (tmp_path / "model.xyz").write_text("\n".join(out) + "\n")
+    (tmp_path / "run.in").write_text(run_in.replace("NEP", H.golden("PbTe", "nep.txt")))
+    return str(tmp_path), src
+
+
 @pytest.fixture(scope="module", autouse=True)
 def _build():
     if not os.path.exists(EXE):
@@ -35,6 +51,51 @@ def test_check_input_parses_run_in_and_model(tmp_path):
     assert "elements: Te Pb" in out.stdout
     assert "Time step for this run is 2 fs." in out.stdout
     assert "Run 10 steps." in out.stdout
+
+
+def test_check_input_groups_and_dump_xyz_options(tmp_path):
+    """read_xyz.cu:243-312 (charge, group:I:k), group.cu:25-72, replicate.cu:60-84, Dump_XYZ::parse."""
+    wd, _ = _grouped_workdir(tmp_path, "replicate 1 1 2\npotential NEP\nensemble nve\ntime_step 1\n"
+                                       "dump_xyz 5 frames/f_* group 1 2 precision single mass charge velocity force "
+                                       "potential unwrapped_position virial group_labels\nrun 10\n")
+    out = subprocess.run([EXE, "--check-input"], cwd=wd, capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    o = out.stdout
+    assert "Have 2 grouping method(s)." in o
+    assert "There are 2 groups of atoms in grouping method 0." in o
+    assert "There are 3 groups of atoms in grouping method 1." in o
+    assert "    250 atoms in group 0." in o and "    20 atoms in group 2." in o  # after replicate 1 1 2
+    for line in ("Dump extended XYZ.", "    every 5 steps.", "    into file frames/f_*.", "    with single precision.",
+                 "    grouping method is 1 and group ID is 2.", "    has unwrapped position.", "    has group labels.",
+                 "    has charge specified in model.xyz."):
+        assert line in o, line
+    assert "for the whole system" not in o
+
+
+@pytest.mark.parametrize("args,msg", [
+    ("0 2 5 d.xyz", "no longer takes <grouping_method> <group_id>"),
+    ("x d.xyz", "dump interval should be an integer"),
+    ("0 d.xyz", "dump interval should > 0"),
+    ("5 d.xyz force force", "Quantity 'force' is specified more than once"),
+    ("5 d.xyz group", "now called 'group_labels'"),
+    ("5 d.xyz group 2 0", "Grouping method should < number of grouping methods"),
+    ("5 d.xyz group 1 3", "Group ID should < number of groups"),
+    ("5 d.xyz group 0 0 group 0 1", "Option 'group' is specified more than once"),
+    ("5 d.xyz precision half", "Invalid precision"),
+    ("5 d.xyz precision", "Not enough arguments for option 'precision'"),
+    ("5 d.xyz bec", "Cannot output BEC"),
+    ("5 d.xyz pressure", "Unrecognized argument in dump_xyz")])
+def test_dump_xyz_input_errors(tmp_path, args, msg):
+    wd, _ = _grouped_workdir(tmp_path, "potential NEP\ndump_xyz %s\nrun 1\n" % args)
+    out = subprocess.run([EXE, "--check-input"], cwd=wd, capture_output=True, text=True)
+    assert out.returncode == 1
+    assert "Input Error" in out.stdout and msg in out.stdout, out.stdout
+
+
+def test_group_labels_need_a_grouping_method(tmp_path):
+    wd = _workdir(tmp_path, "potential NEP\ndump_xyz 5 d.xyz group_labels\nrun 1\n")
+    out = subprocess.run([EXE, "--check-input"], cwd=wd, capture_output=True, text=True)
+    assert out.returncode == 1 and "Cannot output group labels without a grouping method" in out.stdout
 
 
 @pytest.mark.parametrize("bad,msg", [("potential NEP\nfoo 1\nrun 1\n", "invalid keyword"),
@@ -115,3 +176,44 @@ def test_nvt_run_heats_towards_the_target(tmp_path, ens):
     # model.xyz is a thermalised snapshot (T settles near 500 K within the first records whatever the
     # initial velocities); the thermostat holds the last quarter near the ramp's 525-600 K
     assert 450.0 < th[-5:, 0].mean() < 680.0
+
+
+@pytest.mark.gpu
+def test_dump_xyz_full_option_set(tmp_path):
+    """dump_xyz with every quantity, a group selection and one file per frame (dump_xyz.cu:300-420), plus the
+    group columns of restart.xyz (dump_restart.cu:111-131)."""
+    wd, src = _grouped_workdir(
+        tmp_path, "replicate 2 2 2\npotential NEP\nvelocity 600 seed 7\nensemble nve\ntime_step 2\n"
+                  "dump_xyz 20 all.xyz mass charge velocity force potential unwrapped_position virial group_labels\n"
+                  "dump_xyz 20 f_* group 1 2 unwrapped_position group_labels precision single\n"
+                  "dump_restart 40\nrun 40\n", shift=-0.4)
+    out = subprocess.run([EXE], cwd=wd, capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    frames = H.read_xyz_frames(os.path.join(wd, "all.xyz"))
+    assert len(frames) == 2 and frames[0]["n"] == 2000
+    a = frames[1]
+    assert a["comment"]["properties"] == ("species:S:1:pos:R:3:mass:R:1:charge:R:1:vel:R:3:forces:R:3:energy_atom:R:1:"
+                                          "unwrapped_position:R:3:virial:R:9:group:I:2")
+    np.testing.assert_array_equal(a["charge"][:, 0], np.where(np.array(a["species"]) == "Pb", 0.5, -0.5))
+    np.testing.assert_array_equal(a["group"][:, 0], np.where(np.array(a["species"]) == "Te", 0, 1))
+    np.testing.assert_array_equal(a["group"][:250, 1], np.where(np.arange(250) >= 240, 2, np.arange(250) % 2))
+    # unwrapped - wrapped is a lattice vector; the cell was shifted, so atoms sit outside it from the start
+    lat = a["lattice"]  # rows a, b, c
+    frac = np.linalg.solve(lat.T, (a["unwrapped_position"] - a["pos"]).T)
+    assert np.abs(frac - np.rint(frac)).max() < 1e-9 and np.abs(np.rint(frac)).max() >= 1
+    # ... and stays the continuous trajectory: close to the (shifted, replicated) input coordinates
+    _, _, pos0 = H.replicate(src["h"], np.zeros(250, np.int32), src["pos"] - 0.4, (2, 2, 2))
+    assert np.abs(a["unwrapped_position"] - pos0).max() < 1.5
+    # one file per frame, atoms of group 2 of grouping method 1 only, ascending atom index
+    assert not os.path.exists(os.path.join(wd, "f_"))
+    g = H.read_xyz_frames(os.path.join(wd, "f_40"))
+    sel = np.nonzero(a["group"][:, 1] == 2)[0]
+    assert len(g) == 1 and g[0]["n"] == len(sel) == 80
+    assert g[0]["comment"]["properties"] == "species:S:1:pos:R:3:unwrapped_position:R:3:group:I:2"
+    np.testing.assert_allclose(g[0]["pos"], a["pos"][sel], rtol=2e-8)
+    np.testing.assert_allclose(g[0]["unwrapped_position"], a["unwrapped_position"][sel], rtol=2e-8)
+    assert g[0]["comment"]["energy"] == "%.9g" % float(a["comment"]["energy"])
+    r = H.read_xyz_frames(os.path.join(wd, "restart.xyz"))[0]
+    assert r["comment"]["properties"] == "species:S:1:pos:R:3:mass:R:1:vel:R:3:group:I:2"
+    np.testing.assert_array_equal(r["group"], a["group"])
+    np.testing.assert_array_equal(r["pos"], a["pos"])
