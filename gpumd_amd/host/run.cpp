@@ -151,6 +151,14 @@ void Run::parse_one_keyword(const std::vector<std::string>& p)
     if (p.size() != 2)
       input_error("dump_restart should have 1 parameter.");
     dump_restart_interval = std::atoi(p[1].c_str());
+  } else if (k == "dump_position") { // run.cu:396-431: the keywords dump_xyz replaced name their successor
+    input_error("dump_position has been removed. Use dump_xyz <interval> <filename> instead.");
+  } else if (k == "dump_velocity") {
+    input_error("dump_velocity has been removed. Use dump_xyz <interval> <filename> velocity instead.");
+  } else if (k == "dump_force") {
+    input_error("dump_force has been removed. Use dump_xyz <interval> <filename> force instead.");
+  } else if (k == "dump_exyz") {
+    input_error("dump_exyz has been removed. Use dump_xyz <interval> <filename> velocity force potential instead.");
   } else if (k == "dump_xyz") { // Dump_XYZ::parse, dump_xyz.cu:70-155
     std::printf("Dump extended XYZ.\n");
     if (p.size() < 3)

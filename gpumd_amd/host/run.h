@@ -9,7 +9,7 @@ namespace gmi {
 struct DumpXyz {
   int interval = 0;
   std::string filename;
-  int precision = 2; // 1 single (%.9g), 2 double (%.17g)   -- dump_xyz.cu:163-165
+  int precision = 1; // 1 single (%.9g, the default: dump_xyz.cuh:67), 2 double (%.17g)   -- dump_xyz.cu:163-165
   bool has_mass = false, has_charge = false, has_velocity = false, has_force = false, has_potential = false,
        has_unwrapped_position = false, has_virial = false, has_group_labels = false; // parse_utilities.cu:97-147
   bool separated = false;   // file name ended in '*': one file per frame, <name><step>  (dump_xyz.cu:104-110)

@@ -184,7 +184,8 @@ def test_dump_xyz_full_option_set(tmp_path):
     group columns of restart.xyz (dump_restart.cu:111-131)."""
     wd, src = _grouped_workdir(
         tmp_path, "replicate 2 2 2\npotential NEP\nvelocity 600 seed 7\nensemble nve\ntime_step 2\n"
-                  "dump_xyz 20 all.xyz mass charge velocity force potential unwrapped_position virial group_labels\n"
+                  "dump_xyz 20 all.xyz mass charge velocity force potential unwrapped_position virial group_labels "
+                  "precision double\n"
                   "dump_xyz 20 f_* group 1 2 unwrapped_position group_labels precision single\n"
                   "dump_restart 40\nrun 40\n", shift=-0.4)
     out = subprocess.run([EXE], cwd=wd, capture_output=True, text=True)
