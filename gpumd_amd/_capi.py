@@ -52,6 +52,7 @@ SYMBOLS = {
     "nepmi_engine_set_unwrapped": (C.c_int, [VP, VP]),
     "nepmi_apply_pbc": (C.c_int, [VP, c_dp, c_ip, c_i64, VP]),
     "nepmi_zero_properties": (C.c_int, [VP, c_i64, VP, VP, VP]),
+    "nepmi_average_properties": (C.c_int, [VP, c_i64, C.c_double, VP, VP, VP]),
     "nepmi_vv_step1": (C.c_int, [VP, c_i64, C.c_double, VP, VP, VP, VP]),
     "nepmi_vv_step2": (C.c_int, [VP, c_i64, C.c_double, VP, VP, VP]),
     "nepmi_find_thermo": (C.c_int, [VP, c_i64, C.c_double, VP, VP, VP, VP, VP]),

@@ -199,6 +199,16 @@ int nepmi_zero_properties(nepmi_engine* e, int64_t n, double* pe, double* force,
   return guarded([&] { e->e->zero_properties(n, pe, force, virial); });
 }
 
+int nepmi_average_properties(
+  nepmi_engine* e, int64_t n, double denominator, double* pe, double* force, double* virial)
+{
+  if (!e)
+    return fail(NEPMI_ERR_ARG, "null engine");
+  if (!(denominator > 0.0))
+    return fail(NEPMI_ERR_ARG, "average_properties: denominator should be positive");
+  return guarded([&] { e->e->average_properties(n, denominator, pe, force, virial); });
+}
+
 int nepmi_vv_step1(
   nepmi_engine* e, int64_t n, double dt, const double* mass, const double* force, double* pos, double* vel)
 {

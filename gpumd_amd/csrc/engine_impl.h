@@ -253,6 +253,12 @@ public:
     be_.template launch<256>(kSlotMisc, n, body);
   }
 
+  void average_properties(int64_t n, double denominator, double* pe, double* force, double* virial)
+  {
+    AveragePropsBody body{n, denominator, pe, force, virial};
+    be_.template launch<256>(kSlotMisc, n, body);
+  }
+
   void velocity_verlet(
     bool step1, int64_t n, double dt, const double* mass, const double* force, double* pos, double* vel,
     const BoxD* wrap_box)

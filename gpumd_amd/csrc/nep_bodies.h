@@ -143,6 +143,23 @@ struct ZeroPropsBody {
   }
 };
 
+// gpu_average_properties, force.cu:461-480 (a division, as there: bit-identical averages)
+struct AveragePropsBody {
+  int64_t N;
+  double denominator;
+  double *pe, *force, *virial;
+  NEPMI_HD void operator()(int64_t i) const
+  {
+    pe[i] /= denominator;
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+      force[d * N + i] /= denominator;
+#pragma unroll
+    for (int d = 0; d < 9; ++d)
+      virial[d * N + i] /= denominator;
+  }
+};
+
 // gpu_velocity_verlet, ensemble.cu:176-214 (+ optional fused wrap for step 1 of the fused loop)
 struct VelocityVerletBody {
   int64_t N;

@@ -103,7 +103,7 @@ std::vector<std::string> potential_elements(const std::string& file_potential)
   return std::vector<std::string>(tok.begin() + 2, tok.end());
 }
 
-void Force::parse_potential(const std::vector<std::string>& param, const Box&, int number_of_atoms)
+void Force::parse_potential(const std::vector<std::string>& param, const Box&, int number_of_atoms, bool create)
 {
   if (param.size() != 2 && param.size() != 3)
     input_error("potential should have 1 or 2 parameters.");
@@ -112,12 +112,21 @@ void Force::parse_potential(const std::vector<std::string>& param, const Box&, i
     input_error("Failed to open " + param[1] + ".");
   std::string name;
   in >> name;
-  if (name.rfind("nep", 0) == 0 || name == "tersoff_1989") { // both live in libnepmi.so
-    potentials.clear();
-    potentials.emplace_back(new NEP_MI(param[1].c_str(), number_of_atoms));
-  } else {
+  if (name.rfind("nep", 0) != 0 && name != "tersoff_1989") // both live in libnepmi.so
     input_error("illegal potential model: " + name + " (this host carries NEP only; see DESIGN.md section 8).");
-  }
+  // check_types (force.cu:55-73): every further potential must list the same species in the same order
+  const std::vector<std::string> types = potential_elements(param[1]);
+  if (num_potentials_ == 0)
+    atom_types_ = types;
+  else if (types != atom_types_)
+    input_error("The atomic species and/or the order of the species are not consistent between the multiple "
+                "potentials.");
+  if (create) // --check-input stops short of the device
+    potentials.emplace_back(new NEP_MI(param[1].c_str(), number_of_atoms));
+  ++num_potentials_;
+  has_non_nep_ = has_non_nep_ || name.rfind("nep", 0) != 0;
+  if (num_potentials_ > 1 && has_non_nep_) // force.cu:213-217
+    input_error("Multiple potentials may only be used with NEP potentials.");
 }
 
 nepmi_engine* Force::engine() const
@@ -137,7 +146,16 @@ void Force::compute(
   nepmi_engine* e = engine();
   die_on(nepmi_apply_pbc(e, box.cpu_h, pbc, n, position.data()), "gpu_apply_pbc");
   die_on(nepmi_zero_properties(e, n, potential.data(), force.data(), virial.data()), "initialize_properties");
-  potentials[0]->compute(box, type, position, potential, force, virial);
+  if (multiple_potentials_mode_ == "observe") { // the main potential only
+    potentials[0]->compute(box, type, position, potential, force, virial);
+  } else if (multiple_potentials_mode_ == "average") { // every compute adds; then one division
+    for (auto& p : potentials)
+      p->compute(box, type, position, potential, force, virial);
+    die_on(nepmi_average_properties(e, n, (double)potentials.size(), potential.data(), force.data(), virial.data()),
+           "gpu_average_properties");
+  } else {
+    input_error("Invalid mode for multiple potentials.");
+  }
 }
 
 } // namespace gmi

@@ -45,13 +45,23 @@ class Force
 {
 public:
   // `potential <file>`: factory keyed on the first token of the file (force.cu:75-218)
-  void parse_potential(const std::vector<std::string>& param, const Box& box, int number_of_atoms);
+  void parse_potential(const std::vector<std::string>& param, const Box& box, int number_of_atoms, bool create = true);
   // wrap, zero, dispatch (force.cu:771-855)
   void compute(
     Box& box, GPU_Vector<double>& position, GPU_Vector<int>& type, GPU_Vector<double>& potential,
     GPU_Vector<double>& force, GPU_Vector<double>& virial);
   std::vector<std::unique_ptr<Potential>> potentials;
-  nepmi_engine* engine() const;
+  nepmi_engine* engine() const; // the main (first) potential's engine
+  // several `potential` lines (NEP only): "observe" = the first one drives the run, the others are only
+  // evaluated by dump_observer; "average" = the run uses their mean (force.cu:514-565, force.cuh:81)
+  void set_multiple_potentials_mode(const std::string& mode) { multiple_potentials_mode_ = mode; }
+  const std::string& multiple_potentials_mode() const { return multiple_potentials_mode_; }
+
+private:
+  std::string multiple_potentials_mode_ = "observe";
+  std::vector<std::string> atom_types_; // check_types, force.cu:55-73
+  bool has_non_nep_ = false;
+  int num_potentials_ = 0;
 };
 
 // element list of a potential file (read_xyz.cu:427-480 reads it before model.xyz)

@@ -91,6 +91,7 @@ void Run::parse_one_keyword(const std::vector<std::string>& p)
       for (auto& e : elements)
         std::printf(" %s", e.c_str());
       std::printf(")\n");
+      force.parse_potential(p, box, atom.number_of_atoms, false);
       return;
     }
     if (!gpu_allocated) {
@@ -240,6 +241,37 @@ void Run::parse_one_keyword(const std::vector<std::string>& p)
     if (d.grouping_method < 0)
       std::printf("    for the whole system.\n");
     dump_xyzs.push_back(d);
+  } else if (k == "dump_observer") { // Dump_Observer::parse, dump_observer.cu:82-139
+    std::printf("Dump observer.\n");
+    if (p.size() != 6)
+      input_error("dump_observer should have 5 parameters.");
+    DumpObserver o;
+    o.mode = p[1];
+    if (o.mode != "observe" && o.mode != "average")
+      input_error("observer mode should be 'observe' or 'average'");
+    if (!is_valid_int(p[2], &o.interval_thermo))
+      input_error("dump interval thermo should be an integer.");
+    if (o.interval_thermo <= 0)
+      input_error("dump interval thermo should > 0.");
+    if (!is_valid_int(p[3], &o.interval_exyz))
+      input_error("dump interval exyz should be an integer.");
+    if (o.interval_exyz <= 0)
+      input_error("dump interval exyz should > 0.");
+    std::printf("    .out every %d steps.\n    .exyz every %d steps.\n", o.interval_thermo, o.interval_exyz);
+    if (!is_valid_int(p[4], &o.has_velocity))
+      input_error("has_velocity should be an integer.");
+    std::printf(o.has_velocity ? "    with velocity data.\n" : "    without velocity data.\n");
+    if (!is_valid_int(p[5], &o.has_force))
+      input_error("has_force should be an integer.");
+    std::printf(o.has_force ? "    with force data.\n" : "    without force data.\n");
+    if (o.mode == "observe")
+      std::printf("    evaluate all potentials, dumping .out every %d and .exyz every %d steps.\n", o.interval_thermo,
+                  o.interval_exyz);
+    else
+      std::printf("    use the average potential in the molecular dynamics run, and dump .out every %d and .exyz every "
+                  "%d steps.\n", o.interval_thermo, o.interval_exyz);
+    o.active = true;
+    observer = o;
   } else if (k == "run") {
     if (p.size() != 2)
       input_error("run should have 1 parameter.");
@@ -254,6 +286,7 @@ void Run::parse_one_keyword(const std::vector<std::string>& p)
     dump_thermo_interval = 0;
     dump_restart_interval = 0;
     dump_xyzs.clear();
+    observer.active = false;
   } else {
     input_error("'" + k + "' is invalid keyword (or outside the path gpumd-mi covers).");
   }
@@ -378,6 +411,110 @@ void Run::dump_xyz(DumpXyz& d, int step)
   }
 }
 
+// Dump_Observer::preprocess (dump_observer.cu:141-166): the mode reaches Force before the first force call
+void Run::dump_observer_open()
+{
+  if (!observer.active)
+    return;
+  force.set_multiple_potentials_mode(observer.mode);
+  const int files = observer.mode == "observe" ? (int)force.potentials.size() : 1;
+  for (int i = 0; i < files; ++i) {
+    const std::string number = files == 1 ? "" : std::to_string(i);
+    observer.exyz_files.push_back(std::fopen(("observer" + number + ".xyz").c_str(), "a"));
+    observer.thermo_files.push_back(std::fopen(("observer" + number + ".out").c_str(), "a"));
+    if (!observer.exyz_files.back() || !observer.thermo_files.back())
+      input_error("Cannot open the observer files.");
+  }
+}
+
+// Dump_Observer::process (dump_observer.cu:168-262)
+void Run::dump_observer_process(int step)
+{
+  if (!observer.active)
+    return;
+  if ((step + 1) % observer.interval_thermo != 0 && (step + 1) % observer.interval_exyz != 0)
+    return;
+  if (observer.mode == "observe") {
+    // every potential on the current (already wrapped) coordinates; the main one last, so that the arrays
+    // the integrator continues with hold its values again
+    const int64_t N = atom.number_of_atoms;
+    for (int k = (int)force.potentials.size() - 1; k >= 0; --k) {
+      if (nepmi_zero_properties(force.engine(), N, atom.potential_per_atom.data(), atom.force_per_atom.data(),
+                                atom.virial_per_atom.data()) != NEPMI_OK)
+        input_error(nepmi_last_error());
+      force.potentials[k]->compute(box, atom.type, atom.position_per_atom, atom.potential_per_atom, atom.force_per_atom,
+                                   atom.virial_per_atom);
+      find_thermo();
+      dump_observer_write(step, k);
+    }
+  } else { // average: what the run itself computed
+    dump_observer_write(step, 0);
+  }
+}
+
+// write_exyz + write_thermo (dump_observer.cu:264-442): fixed %.8f columns, unlike dump_xyz
+void Run::dump_observer_write(int step, int file_index)
+{
+  const int N = atom.number_of_atoms;
+  double t[8];
+  thermo.copy_to_host(t, 8);
+  const double* h = box.cpu_h;
+  if ((step + 1) % observer.interval_exyz == 0) {
+    FILE* fid = observer.exyz_files[file_index];
+    std::vector<double> pos(3 * (size_t)N), vel, frc, vir(9 * (size_t)N);
+    atom.position_per_atom.copy_to_host(pos.data());
+    atom.virial_per_atom.copy_to_host(vir.data());
+    if (observer.has_velocity) { vel.resize(3 * (size_t)N); atom.velocity_per_atom.copy_to_host(vel.data()); }
+    if (observer.has_force) { frc.resize(3 * (size_t)N); atom.force_per_atom.copy_to_host(frc.data()); }
+    double tv[6] = {0, 0, 0, 0, 0, 0};
+    for (int c = 0; c < 6; ++c)
+      for (int n = 0; n < N; ++n)
+        tv[c] += vir[(size_t)c * N + n];
+    std::fprintf(fid, "%d\n", N);
+    std::fprintf(fid, "Time=%.8f", global_time * TIME_UNIT_CONVERSION);
+    std::fprintf(fid, " pbc=\"%c %c %c\"", box.pbc_x ? 'T' : 'F', box.pbc_y ? 'T' : 'F', box.pbc_z ? 'T' : 'F');
+    std::fprintf(fid, " Lattice=\"%.8f %.8f %.8f %.8f %.8f %.8f %.8f %.8f %.8f\"", h[0], h[3], h[6], h[1], h[4], h[7], h[2],
+                 h[5], h[8]);
+    std::fprintf(fid, " energy=%.8f", t[1]);
+    std::fprintf(fid, " virial=\"%.8f %.8f %.8f %.8f %.8f %.8f %.8f %.8f %.8f\"", tv[0], tv[3], tv[4], tv[3], tv[1], tv[5],
+                 tv[4], tv[5], tv[2]);
+    std::fprintf(fid, " stress=\"%.8f %.8f %.8f %.8f %.8f %.8f %.8f %.8f %.8f\"", t[2], t[5], t[6], t[5], t[3], t[7], t[6],
+                 t[7], t[4]);
+    std::fprintf(fid, " Properties=species:S:1:pos:R:3");
+    if (observer.has_velocity) std::fprintf(fid, ":vel:R:3");
+    if (observer.has_force) std::fprintf(fid, ":forces:R:3");
+    std::fprintf(fid, "\n");
+    for (int n = 0; n < N; ++n) {
+      std::fprintf(fid, "%s", atom.cpu_atom_symbol[n].c_str());
+      for (int c = 0; c < 3; ++c) std::fprintf(fid, " %.8f", pos[n + (size_t)N * c]);
+      if (observer.has_velocity)
+        for (int c = 0; c < 3; ++c) std::fprintf(fid, " %.8f", vel[n + (size_t)N * c] / TIME_UNIT_CONVERSION);
+      if (observer.has_force)
+        for (int c = 0; c < 3; ++c) std::fprintf(fid, " %.8f", frc[n + (size_t)N * c]);
+      std::fprintf(fid, "\n");
+    }
+    std::fflush(fid);
+  }
+  if ((step + 1) % observer.interval_thermo == 0) {
+    FILE* fid = observer.thermo_files[file_index];
+    const double ke = 1.5 * N * K_B * t[0];
+    std::fprintf(fid, "%20.10e%20.10e%20.10e%20.10e%20.10e%20.10e%20.10e%20.10e%20.10e", t[0], ke, t[1],
+                 t[2] * PRESSURE_UNIT_CONVERSION, t[3] * PRESSURE_UNIT_CONVERSION, t[4] * PRESSURE_UNIT_CONVERSION,
+                 t[7] * PRESSURE_UNIT_CONVERSION, t[6] * PRESSURE_UNIT_CONVERSION, t[5] * PRESSURE_UNIT_CONVERSION);
+    std::fprintf(fid, "%20.10e%20.10e%20.10e%20.10e%20.10e%20.10e%20.10e%20.10e%20.10e\n", h[0], h[3], h[6], h[1], h[4],
+                 h[7], h[2], h[5], h[8]);
+    std::fflush(fid);
+  }
+}
+
+void Run::dump_observer_close()
+{
+  for (FILE* f : observer.exyz_files) std::fclose(f);
+  for (FILE* f : observer.thermo_files) std::fclose(f);
+  observer.exyz_files.clear();
+  observer.thermo_files.clear();
+}
+
 // Dump_Restart (src/measure/dump_restart.cu:66-136), full precision instead of %g
 void Run::dump_restart(int step)
 {
@@ -435,6 +572,7 @@ void Run::perform_a_run()
     std::fprintf(fid, "# columns T KE PE sxx syy szz syz sxz sxy ax ay az bx by bz cx cy cz\n");
     std::fclose(fid);
   }
+  dump_observer_open(); // measure.initialize precedes the first force call (run.cu:215)
   // initial force (run.cu:220-232)
   force.compute(box, atom.position_per_atom, atom.type, atom.potential_per_atom, atom.force_per_atom, atom.virial_per_atom);
   hip_check(hipDeviceSynchronize(), "sync");
@@ -471,6 +609,7 @@ void Run::perform_a_run()
       wanted = wanted || (dump_thermo_interval > 0 && (step + 1) % dump_thermo_interval == 0);
       for (const auto& d : dump_xyzs)
         wanted = wanted || (step + 1) % d.interval == 0;
+      wanted = wanted || (observer.active && ((step + 1) % observer.interval_thermo == 0 || (step + 1) % observer.interval_exyz == 0));
       if (wanted)
         find_thermo();
     }
@@ -485,12 +624,14 @@ void Run::perform_a_run()
     for (auto& d : dump_xyzs)
       dump_xyz(d, step);
     dump_restart(step);
+    dump_observer_process(step);
     if (number_of_steps >= 10 && (step + 1) % (number_of_steps / 10) == 0)
       std::printf("    %d steps completed.\n", step + 1);
   }
   hip_check(hipDeviceSynchronize(), "sync");
   if (nhc_state)
     (void)hipFree(nhc_state);
+  dump_observer_close();
   const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   std::printf("Time used for this run = %g second.\n", sec);
   std::printf("Speed of this run = %g atom*step/second.\n", (double)N * number_of_steps / sec); // run.cu:325-326

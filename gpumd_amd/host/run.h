@@ -18,6 +18,14 @@ struct DumpXyz {
   FILE* fid = nullptr;
 };
 
+// Dump_Observer (src/measure/dump_observer.cuh): `dump_observer <mode> <thermo> <exyz> <has_vel> <has_force>`
+struct DumpObserver {
+  bool active = false;
+  std::string mode = "observe"; // observe: every potential re-evaluated at the output steps; average: the run's own
+  int interval_thermo = 1, interval_exyz = 1, has_velocity = 0, has_force = 0;
+  std::vector<FILE*> exyz_files, thermo_files; // observer<i>.xyz / observer<i>.out (no index when there is one)
+};
+
 class Run
 {
 public:
@@ -31,6 +39,10 @@ private:
   void dump_thermo(int step);
   void dump_xyz(DumpXyz& d, int step);
   void dump_restart(int step);
+  void dump_observer_open();
+  void dump_observer_process(int step);
+  void dump_observer_write(int step, int file_index);
+  void dump_observer_close();
 
   bool check_only_;
   Box box;
@@ -48,6 +60,7 @@ private:
   int dump_thermo_interval = 0;
   int dump_restart_interval = 0;
   std::vector<DumpXyz> dump_xyzs;
+  DumpObserver observer;
   GPU_Vector<double> thermo; // 8 doubles
   std::vector<std::string> elements;
   std::string potential_file;

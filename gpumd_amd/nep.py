@@ -150,6 +150,16 @@ class NEP:
         _, pp = _pbc3(self.pbc)
         self._ck(self.lib.nepmi_apply_pbc(self.handle, hp, pp, self.n, self._ptr(position)))
 
+    def zero_properties(self, potential, force, virial):
+        """initialize_properties (force.cu:314-333)."""
+        self._ck(self.lib.nepmi_zero_properties(self.handle, self.n, self._ptr(potential), self._ptr(force),
+                                                self._ptr(virial)))
+
+    def average_properties(self, denominator, potential, force, virial):
+        """gpu_average_properties (force.cu:461-480): the closing division of the "average" multi-potential mode."""
+        self._ck(self.lib.nepmi_average_properties(self.handle, self.n, float(denominator), self._ptr(potential),
+                                                   self._ptr(force), self._ptr(virial)))
+
     def vv_step1(self, dt, mass, force, position, velocity):
         self._ck(self.lib.nepmi_vv_step1(self.handle, self.n, float(dt), self._ptr(mass), self._ptr(force),
                                          self._ptr(position), self._ptr(velocity)))

@@ -137,6 +137,10 @@ int nepmi_potential_compute_levels_end(
 /* gpu_apply_pbc (force.cu:424-459) and initialize_properties (force.cu:314-333) on their own. */
 int nepmi_apply_pbc(nepmi_engine* e, const double h[9], const int pbc[3], int64_t n, double* pos);
 int nepmi_zero_properties(nepmi_engine* e, int64_t n, double* pe, double* force, double* virial);
+/* gpu_average_properties (force.cu:461-480): pe, force, virial /= denominator -- the last step of
+ * Force::compute in the "average" mode of several NEP potentials (force.cu:533-562). */
+int nepmi_average_properties(
+  nepmi_engine* e, int64_t n, double denominator, double* pe, double* force, double* virial);
 
 /* ---- Ensemble::velocity_verlet, src/integrate/ensemble.cu:176-214,348-397
  *      (Ensemble_NVE::compute1/compute2, ensemble_nve.cu:31-95).  dt in natural units. ---- */

@@ -43,6 +43,15 @@ def test_invariances(drv):
     P.check_translation_and_wrap(drv)
 
 
+@pytest.mark.parametrize("name", ["PbTe-A", "C-2022", "Si-5body"])
+def test_rotation_permutation_and_finite_differences(drv, name):
+    P.check_rotation_permutation_and_finite_differences(drv, name)
+
+
+def test_average_of_two_potentials(drv):
+    P.check_average_of_two_potentials(drv)
+
+
 def test_nve_run(drv):
     P.check_nve_against_oracle(drv)
 
