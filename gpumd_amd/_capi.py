@@ -20,7 +20,8 @@ class NepmiInfo(C.Structure):
         ("n_max_radial", C.c_int), ("n_max_angular", C.c_int),
         ("basis_size_radial", C.c_int), ("basis_size_angular", C.c_int),
         ("L_max", C.c_int), ("has_q_222", C.c_int), ("has_q_1111", C.c_int), ("num_L", C.c_int),
-        ("dim", C.c_int), ("num_neurons", C.c_int), ("num_para", C.c_int)]
+        ("dim", C.c_int), ("num_neurons", C.c_int), ("num_para", C.c_int),
+        ("has_q_112", C.c_int), ("has_q_123", C.c_int), ("has_q_233", C.c_int), ("has_q_134", C.c_int)]
 
 
 class NepmiStats(C.Structure):

@@ -92,6 +92,10 @@ int nepmi_model_info(const nepmi_model* mm, nepmi_info* o)
   o->dim = m.dim;
   o->num_neurons = m.num_neurons;
   o->num_para = m.num_para;
+  o->has_q_112 = m.has_q_112;
+  o->has_q_123 = m.has_q_123;
+  o->has_q_233 = m.has_q_233;
+  o->has_q_134 = m.has_q_134;
   return NEPMI_OK;
 }
 

@@ -49,7 +49,8 @@ struct Shape {
   static constexpr int KRM = KR_ >= 0 ? KR_ : 19;
   static constexpr int NAM = NA_ >= 0 ? NA_ : 19;
   static constexpr int KAM = KA_ >= 0 ? KA_ : 19;
-  static constexpr int NLM = NL_ >= 0 ? NL_ : 6;
+  static constexpr int NLM = NL_ >= 0 ? NL_ : 10; // L = 1..4, 222, 1111 and the four extra 4-body rows
+  static constexpr int kRows = NR_ >= 0 ? 6 : 10;  // invariant rows a kernel of this shape can meet
   static constexpr int DIMM = (NRM + 1) + (NAM + 1) * NLM;
 };
 using ShapeGeneric = Shape<-1, -1, -1, -1, -1, 0>;
@@ -1411,10 +1412,13 @@ struct AngularDescBody {
         for (int h = 0; h < kNumHarm; ++h)
           b.sbuf[(int64_t)(n * kNumHarm + h) * N + k] = s[i * kNumHarm + h];
       }
-      float qn[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-      invariants(m, &s[i * kNumHarm], qn, 1);
+      float qn[S::kRows];
 #pragma unroll
-      for (int L = 0; L < 6; ++L) { // constant trip count: qn stays in registers
+      for (int L = 0; L < S::kRows; ++L)
+        qn[L] = 0.0f;
+      invariants<!S::fixed>(m, &s[i * kNumHarm], qn, 1);
+#pragma unroll
+      for (int L = 0; L < S::kRows; ++L) { // constant trip count: qn stays in registers
         if (L < m.numL) {
           const int d = (NR + 1) + L * (NA + 1) + n;
           b.q[(int64_t)d * N + gk] = qn[L] * m.qscale[d];
@@ -1570,16 +1574,16 @@ struct AngularForceBody {
       const int n = part + PARTS * i;
       if (n > NA)
         break;
-      float fpn[6];
+      float fpn[S::kRows];
 #pragma unroll
-      for (int L = 0; L < 6; ++L)
+      for (int L = 0; L < S::kRows; ++L)
         fpn[L] = L < m.numL ? b.fp[(int64_t)((NR + 1) + L * (NA + 1) + n) * N + gk] : 0.0f;
       if (!recompute_s) {
 #pragma unroll
         for (int h = 0; h < kNumHarm; ++h)
           G[i * kNumHarm + h] = b.sbuf[(int64_t)(n * kNumHarm + h) * N + k];
       }
-      invariants_adjoint(m, fpn, 1, &G[i * kNumHarm]);
+      invariants_adjoint<!S::fixed>(m, fpn, 1, &G[i * kNumHarm]);
     }
 
     float zf[3] = {0, 0, 0}, zv[6] = {0, 0, 0, 0, 0, 0}, zpe = 0.0f;

@@ -11,6 +11,8 @@
 #include <cmath>
 #include <cstdint>
 
+#include "nep_invariants_extra.h"
+
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #define NEPMI_HD __host__ __device__ __forceinline__
@@ -91,6 +93,7 @@ struct BoxD {
 struct ModelD {
   int T, NR, KR, NA, KA;
   int has222, has1111, numL, dim, nneu, version;
+  int extra; // bit 0..3: has_q_112, _123, _233, _134 (generic shape only)
   int zbl_enabled, zbl_flexible;
   float zbl_rc_inner, zbl_rc_outer;
   float b1;
@@ -453,6 +456,32 @@ NEPMI_HD void harmonics_contract(
 
 // 3-/4-/5-body invariants of one radial order from its 24 sums (find_q, nep_utilities.cuh:
 // 1758-1770, 1859-1872).  q is strided by `stride` (= n_max_angular + 1).
+template <int NT>
+NEPMI_HD float cubic_value(const CubicTerm (&t)[NT], const float* s)
+{
+  float v = 0.0f;
+#pragma unroll
+  for (int a = 0; a < NT; ++a)
+    v += t[a].w * s[t[a].i] * s[t[a].j] * s[t[a].k];
+  return v;
+}
+
+// g[abc] += F d(row)/ds[abc]
+template <int NT>
+NEPMI_HD void cubic_gradient(const CubicTerm (&t)[NT], float F, const float* s, float* g)
+{
+#pragma unroll
+  for (int a = 0; a < NT; ++a) {
+    const float w = F * t[a].w;
+    g[t[a].i] += w * s[t[a].j] * s[t[a].k];
+    g[t[a].j] += w * s[t[a].i] * s[t[a].k];
+    g[t[a].k] += w * s[t[a].i] * s[t[a].j];
+  }
+}
+
+// EXTRAS: also the optional rows 112 / 123 / 233 / 134 behind 222 and 1111 (:1874-1945); q then has up to 10 rows.
+// Only the generic shape instantiates it, so the shapes of the shipped models compile exactly as without.
+template <bool EXTRAS = false>
 NEPMI_HD void invariants(const ModelD& m, const float* s, float* q, int stride)
 {
   const float C3B[kNumHarm] = NEPMI_C3B_INIT;
@@ -479,13 +508,40 @@ NEPMI_HD void invariants(const ModelD& m, const float* s, float* q, int stride)
   } else if (m.has1111) {
     q[4 * stride] = q5b;
   }
+  if (EXTRAS && m.extra) {
+    int row = 4 + (m.has222 ? 1 : 0) + (m.has1111 ? 1 : 0);
+    const CubicTerm t112[] = NEPMI_Q112_TERMS;
+    const CubicTerm t123[] = NEPMI_Q123_TERMS;
+    const CubicTerm t233[] = NEPMI_Q233_TERMS;
+    const CubicTerm t134[] = NEPMI_Q134_TERMS;
+    if (m.extra & 1) q[(row++) * stride] = cubic_value(t112, s);
+    if (m.extra & 2) q[(row++) * stride] = cubic_value(t123, s);
+    if (m.extra & 4) q[(row++) * stride] = cubic_value(t233, s);
+    if (m.extra & 8) q[(row++) * stride] = cubic_value(t134, s);
+  }
 }
 
 // Adjoint of `invariants`: G[abc] = sum_L Fp_L dq_L/ds_abc (+ 4-/5-body), in place of s.
 // fp is strided like q.
+template <bool EXTRAS = false>
 NEPMI_HD void invariants_adjoint(const ModelD& m, const float* fp, int stride, float* s /* in: s, out: G */)
 {
   const float C3B[kNumHarm] = NEPMI_C3B_INIT;
+  float gx[EXTRAS ? kNumHarm : 1];
+  if (EXTRAS && m.extra) {
+#pragma unroll
+    for (int k = 0; k < kNumHarm; ++k)
+      gx[EXTRAS ? k : 0] = 0.0f;
+    int row = 4 + (m.has222 ? 1 : 0) + (m.has1111 ? 1 : 0);
+    const CubicTerm t112[] = NEPMI_Q112_TERMS;
+    const CubicTerm t123[] = NEPMI_Q123_TERMS;
+    const CubicTerm t233[] = NEPMI_Q233_TERMS;
+    const CubicTerm t134[] = NEPMI_Q134_TERMS;
+    if (m.extra & 1) cubic_gradient(t112, fp[(row++) * stride], s, gx);
+    if (m.extra & 2) cubic_gradient(t123, fp[(row++) * stride], s, gx);
+    if (m.extra & 4) cubic_gradient(t233, fp[(row++) * stride], s, gx);
+    if (m.extra & 8) cubic_gradient(t134, fp[(row++) * stride], s, gx);
+  }
   float g4[5] = {0, 0, 0, 0, 0}, g5[3] = {0, 0, 0};
   if (m.has222) {
     const float F = fp[4 * stride];
@@ -519,6 +575,11 @@ NEPMI_HD void invariants_adjoint(const ModelD& m, const float* fp, int stride, f
 #pragma unroll
   for (int k = 0; k < 3; ++k)
     s[k] += g5[k];
+  if (EXTRAS && m.extra) {
+#pragma unroll
+    for (int k = 0; k < kNumHarm; ++k)
+      s[k] += gx[EXTRAS ? k : 0];
+  }
 }
 
 // find_f_and_fp_zbl, nep_utilities.cuh:433-508.  para10 == nullptr: universal ZBL.

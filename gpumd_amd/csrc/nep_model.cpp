@@ -178,12 +178,13 @@ std::string load_nep_model(const std::string& path, NepModel& m, bool* unsupport
   m.L_max = std::atoi(tok[1].c_str());
   m.has_q_222 = std::atoi(tok[2].c_str()) != 0;
   m.has_q_1111 = std::atoi(tok[3].c_str()) != 0;
-  for (size_t k = 4; k < tok.size(); ++k)
-    if (std::atoi(tok[k].c_str()) != 0)
-      return unsup("extra 4-body invariants (112/123/233/134) are not supported by this engine.");
+  m.has_q_112 = tok.size() >= 5 && std::atoi(tok[4].c_str()) != 0;
+  m.has_q_123 = tok.size() >= 6 && std::atoi(tok[5].c_str()) != 0;
+  m.has_q_233 = tok.size() >= 7 && std::atoi(tok[6].c_str()) != 0;
+  m.has_q_134 = tok.size() >= 8 && std::atoi(tok[7].c_str()) != 0;
   if (m.L_max != 4)
     return unsup("only l_max = 4 models are supported by this engine.");
-  m.num_L = m.L_max + m.has_q_222 + m.has_q_1111;
+  m.num_L = m.L_max + m.has_q_222 + m.has_q_1111 + m.has_q_112 + m.has_q_123 + m.has_q_233 + m.has_q_134;
   tok = next_tokens(in);
   if (tok.size() != 3 || tok[0] != "ANN")
     return "This line should be ANN num_neurons 0.";

@@ -29,6 +29,7 @@ struct NepModel {
   int MN_radial = 0, MN_angular = 0; // enlarged by 1.25 (nep.cu:234-235)
   int n_max_radial = 0, n_max_angular = 0, basis_size_radial = 0, basis_size_angular = 0;
   int L_max = 0, has_q_222 = 0, has_q_1111 = 0, num_L = 0, dim = 0, num_neurons = 0;
+  int has_q_112 = 0, has_q_123 = 0, has_q_233 = 0, has_q_134 = 0; // optional trailing l_max flags (nep.cu:275-310)
   int num_para_ann = 0, num_para = 0, num_c_radial = 0;
 
   // raw parameters in file order (ANN, descriptor c, then q_scaler[dim])

@@ -48,6 +48,9 @@ NEP_MI::NEP_MI(const char* file_potential, int num_atoms)
   std::printf("    basis_size_radial = %d.\n    basis_size_angular = %d.\n", info.basis_size_radial, info.basis_size_angular);
   std::printf("    l_max_3body = %d.\n    l_max_4body = %d.\n    l_max_5body = %d.\n", info.L_max, info.has_q_222 ? 2 : 0,
               info.has_q_1111 ? 1 : 0);
+  if (info.has_q_112 || info.has_q_123 || info.has_q_233 || info.has_q_134)
+    std::printf("    has_q_112 = %d.\n    has_q_123 = %d.\n    has_q_233 = %d.\n    has_q_134 = %d.\n", info.has_q_112,
+                info.has_q_123, info.has_q_233, info.has_q_134);
   std::printf("    ANN = %d-%d-1.\n", info.dim, info.num_neurons);
   engine_ = nepmi_engine_create(model_, num_atoms, nullptr);
   if (!engine_) {

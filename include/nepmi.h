@@ -63,6 +63,7 @@ typedef struct {
   int L_max, has_q_222, has_q_1111, num_L;
   int dim, num_neurons;
   int num_para; /* ANN + descriptor parameters, without q_scaler */
+  int has_q_112, has_q_123, has_q_233, has_q_134; /* optional extra 4-body rows (nep.cu:275-310) */
 } nepmi_info;
 
 const char* nepmi_last_error(void);

@@ -26,6 +26,7 @@ static const double NEPO_C3B[NEPO_NABC] = {
   1.566681471060845, 1.566681471060845, 0.195835183882606, 0.195835183882606};
 static const double NEPO_C4B[5] = {
   -0.007499480826664, -0.134990654879954, 0.067495327439977, 0.404971964639861, -0.809943929279723};
+#include "nep_invariants_extra.inc"
 static const double NEPO_C5B[3] = {0.026596810706114, 0.053193621412227, 0.026596810706114};
 
 /* Z[L][n1][n2]: coefficient of z^n2 in the (unnormalised) associated Legendre factor that
@@ -57,6 +58,7 @@ struct nepo_model {
   int MN_radial, MN_angular;
   int n_max_radial, n_max_angular, basis_size_radial, basis_size_angular;
   int L_max, has_222, has_1111, num_L, dim, num_neurons;
+  int has_112, has_123, has_233, has_134; /* extra 4-body rows, nep.cu:275-310 */
   int num_para_ann, num_para, num_c_radial;
   int off_w0[NEPO_MAX_TYPES], off_b0[NEPO_MAX_TYPES], off_w1[NEPO_MAX_TYPES], off_b1;
   double* params; /* num_para + dim (q_scaler at the end) */
@@ -224,14 +226,16 @@ nepo_model* nepo_model_load(const char* path, char* err, int errlen)
   m->L_max = atoi(tok[1]);
   m->has_222 = atoi(tok[2]);
   m->has_1111 = atoi(tok[3]);
-  for (int k = 4; k < nt; ++k)
-    if (atoi(tok[k]) != 0)
-      NEPO_FAIL("extra 4-body invariants (112/123/233/134) are outside the oracle's scope");
+  m->has_112 = nt >= 5 ? atoi(tok[4]) : 0; /* optional trailing flags, nep.cu:275-286 */
+  m->has_123 = nt >= 6 ? atoi(tok[5]) : 0;
+  m->has_233 = nt >= 7 ? atoi(tok[6]) : 0;
+  m->has_134 = nt >= 8 ? atoi(tok[7]) : 0;
   if (m->L_max < 1 || m->L_max > NEPO_LMAX)
     NEPO_FAIL("l_max must be 1..%d in the oracle", NEPO_LMAX);
   if ((m->has_222 && m->L_max < 2))
     NEPO_FAIL("has_q_222 needs l_max >= 2");
-  m->num_L = m->L_max + (m->has_222 ? 1 : 0) + (m->has_1111 ? 1 : 0);
+  m->num_L = m->L_max + (m->has_222 ? 1 : 0) + (m->has_1111 ? 1 : 0) + (m->has_112 ? 1 : 0) + (m->has_123 ? 1 : 0) +
+             (m->has_233 ? 1 : 0) + (m->has_134 ? 1 : 0);
   if (!fgets(line, sizeof line, fp) || nepo_tokens(line, tok, 256) != 3)
     NEPO_FAIL("This line should be ANN num_neurons 0.");
   m->num_neurons = atoi(tok[1]);
@@ -342,6 +346,36 @@ double nepo_model_param(const nepo_model* m, int idx) { return m->params[idx]; }
 #undef NEPO_LIT
 
 /* ---- public API -------------------------------------------------------------------------- */
+
+/* The angular rows on their own (FP64), so that tests/test_oracle_golden.py can hold them against the reference's
+ * find_q / accumulate_f12 (oracle/ref_utils_wrap.cpp).  has[6] = has_q_222, _1111, _112, _123, _233, _134. */
+static void nepo_rows_model(nepo_model* m, int L_max, const int has[6])
+{
+  memset(m, 0, sizeof(*m));
+  m->L_max = L_max;
+  m->has_222 = has[0]; m->has_1111 = has[1]; m->has_112 = has[2];
+  m->has_123 = has[3]; m->has_233 = has[4]; m->has_134 = has[5];
+  m->num_L = L_max;
+  for (int k = 0; k < 6; ++k)
+    m->num_L += has[k] ? 1 : 0;
+}
+
+void nepo_rows_find_q(int L_max, const int has[6], int nA1, int n, const double* s, double* q)
+{
+  nepo_model m;
+  nepo_rows_model(&m, L_max, has);
+  find_q_f64(&m, nA1, n, s, q);
+}
+
+void nepo_rows_accumulate_f12(
+  int L_max, const int has[6], int n, int nA1, double d12, const double* r12, double fn, double fnp, const double* Fp,
+  const double* sums_n, double* f12)
+{
+  nepo_model m;
+  nepo_rows_model(&m, L_max, has);
+  accumulate_f12_f64(&m, n, nA1, d12, r12, fn, fnp, Fp, sums_n, f12);
+}
+
 
 struct nepo_lists {
   int n;

@@ -57,6 +57,13 @@ double nepo_model_param(const nepo_model* m, int idx);
  * Lists are returned sorted ascending by neighbour index (neighbor.cuh:112-136); for the
  * small-box path an entry may repeat with a different periodic image.
  * nl is column-major nl[slot*n + atom] with ld slots; returns max count, or <0 on error. */
+/* the angular rows alone (FP64): find_q and accumulate_f12 of nep_utilities.cuh for one radial order n;
+ * has[6] = has_q_222, _1111, _112, _123, _233, _134; s / sums_n = the 24 sums of that order */
+void nepo_rows_find_q(int L_max, const int has[6], int nA1, int n, const double* s, double* q);
+void nepo_rows_accumulate_f12(
+  int L_max, const int has[6], int n, int nA1, double d12, const double* r12, double fn, double fnp, const double* Fp,
+  const double* sums_n, double* f12);
+
 typedef struct nepo_lists nepo_lists;
 nepo_lists* nepo_lists_build(
   const nepo_model* m, int n, const int* type, const double h[9], const int pbc[3],

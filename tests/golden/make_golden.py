@@ -62,7 +62,47 @@ def main():
     os.makedirs(os.path.join(OUT, "C"), exist_ok=True)
     with open(os.path.join(OUT, "C", "carbon_64000_header.txt"), "w") as f:
         f.writelines(head)
+    angular_rows()
     print("golden fixtures written to", OUT)
+
+
+def angular_rows(out=None):
+    """Known answers of the reference's OWN find_q / accumulate_f12 (src/utilities/nep_utilities.cuh, compiled
+    for the host by oracle/Makefile's _ref target) on seeded random input, for every invariant row including the
+    extra 4-body ones (112/123/233/134) that no shipped model and no NEP_CPU covers."""
+    import ctypes as C
+    lib = C.CDLL(os.path.join(os.path.dirname(OUT), "..", "oracle", "_ref", "libnep_utils_ref.so"))
+    nabc = lib.nepref_num_abc()
+    fp = C.POINTER(C.c_float)
+    rng = np.random.default_rng(20240924)
+    flags = [[1, 1, 1, 1, 1, 1], [0, 0, 1, 0, 0, 0], [0, 0, 0, 1, 0, 0], [0, 0, 0, 0, 1, 0], [0, 0, 0, 0, 0, 1],
+             [1, 0, 0, 1, 1, 0], [0, 1, 1, 0, 0, 1], [1, 1, 0, 0, 0, 0]]
+    ncase, nA1 = 6, 3
+    rec = dict(flags=np.array(flags, np.int32), s=[], Fp=[], r12=[], fn=[], fnp=[], q=[], f12=[])
+    for c in range(ncase):
+        s = np.zeros((nA1, nabc), np.float32)
+        s[:, :24] = rng.normal(0, 0.7, (nA1, 24))
+        Fp = rng.normal(0, 1, (10, nA1)).astype(np.float32)       # [row][n]
+        r12 = rng.normal(0, 1.5, 3).astype(np.float32)
+        fn, fnp = np.float32(rng.normal()), np.float32(rng.normal())
+        d12 = np.float32(np.sqrt((r12.astype(np.float64) ** 2).sum()))
+        qs, fs = [], []
+        for fl in flags:
+            num_L = 4 + sum(fl)
+            q = np.zeros((10, nA1), np.float32)
+            f = np.zeros((nA1, 3), np.float32)
+            for n in range(nA1):
+                lib.nepref_find_q(4, *fl, nA1, n, s[n].ctypes.data_as(fp), q.ctypes.data_as(fp))
+                lib.nepref_accumulate_f12(4, *fl, num_L, n, nA1, C.c_float(d12), r12.ctypes.data_as(fp), C.c_float(fn),
+                                          C.c_float(fnp), Fp.ctypes.data_as(fp), s.ctypes.data_as(fp),
+                                          f[n].ctypes.data_as(fp))
+            qs.append(q)
+            fs.append(f)
+        for k, v in (("s", s[:, :24]), ("Fp", Fp), ("r12", r12), ("fn", fn), ("fnp", fnp), ("q", qs), ("f12", fs)):
+            rec[k].append(v)
+    out = out or os.path.join(OUT, "rows", "angular_rows_ref.npz")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    np.savez(out, **{k: np.array(v) for k, v in rec.items()})
 
 
 if __name__ == "__main__":

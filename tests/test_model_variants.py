@@ -43,11 +43,53 @@ def make_per_type_cutoff(tmp_path):
     return _write(tmp_path, "pertype.txt", out)
 
 
+def make_extra_rows(flags):
+    """l_max 4 <222> <1111> <112> <123> <233> <134>: the PbTe descriptor with the optional 4-body rows switched on
+    (nep.cu:262-312).  No shipped model has them, so the ANN is seeded random (the descriptor coefficients and the
+    scalers of the first rows stay those of the PbTe file)."""
+    def maker(tmp_path):
+        L = _pbte_lines()
+        head, par = L[:6], [x for x in L[6:] if x.strip()]
+        old_dim, nneu, nA1 = 42, 30, 7
+        num_L = 4 + sum(flags)
+        dim = 7 + nA1 * num_L
+        n_c = len(par) - (2 * (old_dim + 2) * nneu + 1) - old_dim
+        c = par[2 * (old_dim + 2) * nneu + 1: 2 * (old_dim + 2) * nneu + 1 + n_c]
+        scaler = par[-old_dim:]
+        rng = np.random.default_rng(sum(b << k for k, b in enumerate(flags)))
+        ann = []
+        for _ in range(2):
+            ann += list(rng.normal(0, 0.4, dim * nneu)) + list(rng.normal(0, 0.3, nneu)) + list(rng.normal(0, 0.5, nneu))
+        ann.append(-3.21)
+        rows = scaler[:7 + 4 * nA1] + ["%.8e" % v for v in rng.uniform(0.5, 3.0, nA1 * (num_L - 4))]
+        out = head[:4] + ["l_max 4 " + " ".join(str(b) for b in flags), "ANN %d 0" % nneu]
+        out += ["%.8e" % v for v in ann] + c + rows
+        return _write(tmp_path, "extra_%s.txt" % "".join(str(b) for b in flags), out)
+    return maker
+
+
+def _oracle_finite_differences(orc, h, typ, x):
+    """F = -dE/dx of the oracle itself (FP64, 1e-4 A central differences): the only end-to-end check available for
+    rows that NEP_CPU does not carry; the rows themselves are pinned in test_oracle_golden.py."""
+    pe, f, _ = orc.compute(typ, h, x, precision=64, path=0)
+    n = len(typ)
+    rng = np.random.default_rng(1)
+    for k in rng.integers(0, 3 * n, 4):
+        xp, xm = x.copy(), x.copy()
+        xp[k] += 1e-4
+        xm[k] -= 1e-4
+        num = -(orc.compute(typ, h, xp, precision=64, path=0)[0].sum() -
+                orc.compute(typ, h, xm, precision=64, path=0)[0].sum()) / 2e-4
+        assert abs(num - f[k]) < 1e-6 * (1 + abs(f[k])), (k, num, f[k])
+
+
 def _check(drv, nep, ref_cpu):
     h, typ, x = H.pbte_supercell((2, 2, 2), seed=17)
     n = len(typ)
     orc = H.Oracle(nep)
     pe64, f64, v64 = orc.compute(typ, h, x, precision=64, path=0)
+    if "extra_" in nep:
+        _oracle_finite_differences(orc, h, typ, x)
     if ref_cpu and H.ref_available():
         pe_r, f_r, v_r = H.RefNepCpu(nep).compute(typ, h, x)
         np.testing.assert_allclose(f64, f_r, rtol=1e-9, atol=1e-10)
@@ -64,7 +106,10 @@ def _check(drv, nep, ref_cpu):
         H.assert_lists_equal(nn, nl, onn, onl)
 
 
-VARIANTS = [("nep5", make_nep5, True), ("nep3-2types", make_nep3, True), ("per-type-cutoff", make_per_type_cutoff, False)]
+VARIANTS = [("nep5", make_nep5, True), ("nep3-2types", make_nep3, True), ("per-type-cutoff", make_per_type_cutoff, False),
+            # the optional 4-body rows 112 / 123 / 233 / 134 (flags: 222 1111 112 123 233 134)
+            ("rows-all", make_extra_rows([1, 1, 1, 1, 1, 1]), False), ("rows-112", make_extra_rows([1, 0, 1, 0, 0, 0]), False),
+            ("rows-123-233", make_extra_rows([0, 0, 0, 1, 1, 0]), False), ("rows-134", make_extra_rows([0, 1, 0, 0, 0, 1]), False)]
 
 
 @pytest.mark.parametrize("name,maker,ref_cpu", VARIANTS)

@@ -93,3 +93,57 @@ def test_small_box_path_choice():
     assert orc.lists(typ, fr["h"], H.soa(fr["pos"]))["path"] == 1
     h, typ2, x = H.pbte_supercell((2, 2, 2))
     assert orc.lists(typ2, h, x)["path"] == 0
+
+
+def _oracle_rows(L, flags, s, Fp, r12, fn, fnp):
+    """The oracle's find_q / accumulate_f12 (FP64) for every radial order of one case."""
+    import ctypes as C
+    dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
+    nA1 = s.shape[0]
+    has = np.ascontiguousarray(flags, np.int32)
+    s64, Fp64, r64 = (np.ascontiguousarray(a, np.float64) for a in (s, Fp, r12))
+    d12 = float(np.float32(np.sqrt((r12.astype(np.float64) ** 2).sum())))
+    q = np.zeros((10, nA1))
+    f = np.zeros((nA1, 3))
+    for n in range(nA1):
+        L.nepo_rows_find_q(4, has.ctypes.data_as(ip), nA1, n, s64[n].ctypes.data_as(dp), q.ctypes.data_as(dp))
+        L.nepo_rows_accumulate_f12(4, has.ctypes.data_as(ip), n, nA1, C.c_double(d12), r64.ctypes.data_as(dp),
+                                   C.c_double(float(fn)), C.c_double(float(fnp)), Fp64.ctypes.data_as(dp),
+                                   s64[n].ctypes.data_as(dp), f[n].ctypes.data_as(dp))
+    return q, f
+
+
+def test_angular_rows_against_the_reference_functions():
+    """Every invariant row -- 3-body L = 1..4, 222, 1111 and the extra 4-body rows 112 / 123 / 233 / 134 -- and
+    its partial force against known answers of the reference's own find_q / accumulate_f12
+    (nep_utilities.cuh:1523-1672, 1819-1947, compiled for the host; tests/golden/make_golden.py angular_rows).
+    The reference computes in FP32: |dq| <= 2e-6 (1 + |q|), |df| <= 3e-5 (1 + |f|) on O(1..30) values."""
+    g = np.load(H.golden("rows", "angular_rows_ref.npz"))
+    L = H.oracle_lib()
+    worst_q = worst_f = 0.0
+    for c in range(g["s"].shape[0]):
+        for k, fl in enumerate(g["flags"]):
+            q, f = _oracle_rows(L, fl, g["s"][c], g["Fp"][c], g["r12"][c], g["fn"][c], g["fnp"][c])
+            rows = 4 + int(fl.sum())
+            qr, fr = g["q"][c, k].astype(np.float64), g["f12"][c, k].astype(np.float64)
+            assert np.all(qr[rows:] == 0) and np.all(q[rows:] == 0)
+            worst_q = max(worst_q, (np.abs(q - qr) / (1 + np.abs(qr))).max())
+            worst_f = max(worst_f, (np.abs(f - fr) / (1 + np.abs(fr))).max())
+    assert worst_q < 2e-6 and worst_f < 3e-5, (worst_q, worst_f)
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(H.ORACLE_DIR, "_ref", "libnep_utils_ref.so")),
+                    reason="oracle/_ref not built (no /root/reference here)")
+def test_angular_rows_fixture_is_what_the_reference_functions_return():
+    """The committed vectors are reproduced by the live reference build (guards the fixture itself)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", H.golden("make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        mg.angular_rows(os.path.join(tmp, "rows.npz"))
+        new = np.load(os.path.join(tmp, "rows.npz"))
+        ref = np.load(H.golden("rows", "angular_rows_ref.npz"))
+        for k in ref.files:
+            np.testing.assert_array_equal(new[k], ref[k])
