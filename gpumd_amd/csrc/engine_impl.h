@@ -608,6 +608,7 @@ private:
     md_.has222 = m.has_q_222;
     md_.has1111 = m.has_q_1111;
     md_.numL = m.num_L;
+    md_.Lmax = m.L_max;
     md_.extra = (m.has_q_112 ? 1 : 0) | (m.has_q_123 ? 2 : 0) | (m.has_q_233 ? 4 : 0) | (m.has_q_134 ? 8 : 0);
     md_.dim = m.dim;
     md_.nneu = m.num_neurons;
@@ -933,8 +934,8 @@ private:
     const NepModel& m = model_;
     if (!S::fixed)
       return true;
-    if (m.has_q_112 || m.has_q_123 || m.has_q_233 || m.has_q_134)
-      return false; // the extra 4-body rows live in the generic shape only
+    if (m.L_max != 4 || m.has_q_112 || m.has_q_123 || m.has_q_233 || m.has_q_134)
+      return false; // l_max_3body < 4 and the extra 4-body rows live in the generic shape only
     return S::NR == m.n_max_radial && S::KR == m.basis_size_radial && S::NA == m.n_max_angular &&
            S::KA == m.basis_size_angular && S::NL == m.num_L && (S::TS == 0 || S::TS == m.num_types);
   }

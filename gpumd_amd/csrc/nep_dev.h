@@ -94,6 +94,7 @@ struct ModelD {
   int T, NR, KR, NA, KA;
   int has222, has1111, numL, dim, nneu, version;
   int extra; // bit 0..3: has_q_112, _123, _233, _134 (generic shape only)
+  int Lmax;  // l_max_3body, 1..4 (anything but 4: generic shape only)
   int zbl_enabled, zbl_flexible;
   float zbl_rc_inner, zbl_rc_outer;
   float b1;
@@ -479,11 +480,107 @@ NEPMI_HD void cubic_gradient(const CubicTerm (&t)[NT], float F, const float* s, 
   }
 }
 
-// EXTRAS: also the optional rows 112 / 123 / 233 / 134 behind 222 and 1111 (:1874-1945); q then has up to 10 rows.
-// Only the generic shape instantiates it, so the shapes of the shipped models compile exactly as without.
+// The general form of find_q (:1819-1947) for the generic shape: l_max_3body = 1..4 (sums of higher L do not exist for
+// the model: taken as zero), the 222 / 1111 rows right behind the 3-body rows, then the optional rows 112 / 123 / 233 /
+// 134; up to 10 rows.
+NEPMI_HD void invariants_generic(const ModelD& m, const float* s_in, float* q, int stride)
+{
+  const float C3B[kNumHarm] = NEPMI_C3B_INIT;
+  const int nh = (m.Lmax + 1) * (m.Lmax + 1) - 1;
+  float s[kNumHarm];
+#pragma unroll
+  for (int k = 0; k < kNumHarm; ++k)
+    s[k] = k < nh ? s_in[k] : 0.0f;
+#pragma unroll
+  for (int L = 1; L <= 4; ++L) {
+    const int st = L * L - 1;
+    float acc = 0.0f;
+#pragma unroll
+    for (int k = 1; k < 2 * L + 1; ++k)
+      acc += C3B[st + k] * s[st + k] * s[st + k];
+    if (L <= m.Lmax)
+      q[(L - 1) * stride] = 2.0f * acc + C3B[st] * s[st] * s[st];
+  }
+  int row = m.Lmax;
+  if (m.has222)
+    q[(row++) * stride] = NEPMI_C4B_0 * s[3] * s[3] * s[3] + NEPMI_C4B_1 * s[3] * (s[4] * s[4] + s[5] * s[5]) +
+                          NEPMI_C4B_2 * s[3] * (s[6] * s[6] + s[7] * s[7]) +
+                          NEPMI_C4B_3 * s[6] * (s[5] * s[5] - s[4] * s[4]) + NEPMI_C4B_4 * s[4] * s[5] * s[7];
+  if (m.has1111) {
+    const float s0 = s[0] * s[0], s12 = s[1] * s[1] + s[2] * s[2];
+    q[(row++) * stride] = NEPMI_C5B_0 * s0 * s0 + NEPMI_C5B_1 * s0 * s12 + NEPMI_C5B_2 * s12 * s12;
+  }
+  const CubicTerm t112[] = NEPMI_Q112_TERMS;
+  const CubicTerm t123[] = NEPMI_Q123_TERMS;
+  const CubicTerm t233[] = NEPMI_Q233_TERMS;
+  const CubicTerm t134[] = NEPMI_Q134_TERMS;
+  if (m.extra & 1) q[(row++) * stride] = cubic_value(t112, s);
+  if (m.extra & 2) q[(row++) * stride] = cubic_value(t123, s);
+  if (m.extra & 4) q[(row++) * stride] = cubic_value(t233, s);
+  if (m.extra & 8) q[(row++) * stride] = cubic_value(t134, s);
+}
+
+// Adjoint of invariants_generic: G[abc] = sum_rows Fp_row dq_row/ds_abc, in place of s (zero for L > l_max_3body).
+NEPMI_HD void invariants_adjoint_generic(const ModelD& m, const float* fp, int stride, float* s)
+{
+  const float C3B[kNumHarm] = NEPMI_C3B_INIT;
+  const int nh = (m.Lmax + 1) * (m.Lmax + 1) - 1;
+  float g[kNumHarm];
+#pragma unroll
+  for (int k = 0; k < kNumHarm; ++k) {
+    g[k] = 0.0f;
+    if (k >= nh)
+      s[k] = 0.0f;
+  }
+  int row = m.Lmax;
+  if (m.has222) {
+    const float F = fp[(row++) * stride];
+    const float s0 = s[3], s1 = s[4], s2 = s[5], s3 = s[6], s4 = s[7];
+    g[3] += F * (3.0f * NEPMI_C4B_0 * s0 * s0 + NEPMI_C4B_1 * (s1 * s1 + s2 * s2) + NEPMI_C4B_2 * (s3 * s3 + s4 * s4));
+    g[4] += F * (2.0f * NEPMI_C4B_1 * s0 * s1 - 2.0f * NEPMI_C4B_3 * s3 * s1 + NEPMI_C4B_4 * s2 * s4);
+    g[5] += F * (2.0f * NEPMI_C4B_1 * s0 * s2 + 2.0f * NEPMI_C4B_3 * s3 * s2 + NEPMI_C4B_4 * s1 * s4);
+    g[6] += F * (2.0f * NEPMI_C4B_2 * s0 * s3 + NEPMI_C4B_3 * (s2 * s2 - s1 * s1));
+    g[7] += F * (2.0f * NEPMI_C4B_2 * s0 * s4 + NEPMI_C4B_4 * s1 * s2);
+  }
+  if (m.has1111) {
+    const float F = fp[(row++) * stride];
+    const float s0 = s[0], s1 = s[1], s2 = s[2];
+    const float s12 = s1 * s1 + s2 * s2;
+    g[0] += F * (4.0f * NEPMI_C5B_0 * s0 * s0 * s0 + 2.0f * NEPMI_C5B_1 * s0 * s12);
+    g[1] += F * (2.0f * NEPMI_C5B_1 * s0 * s0 * s1 + 4.0f * NEPMI_C5B_2 * s12 * s1);
+    g[2] += F * (2.0f * NEPMI_C5B_1 * s0 * s0 * s2 + 4.0f * NEPMI_C5B_2 * s12 * s2);
+  }
+  const CubicTerm t112[] = NEPMI_Q112_TERMS;
+  const CubicTerm t123[] = NEPMI_Q123_TERMS;
+  const CubicTerm t233[] = NEPMI_Q233_TERMS;
+  const CubicTerm t134[] = NEPMI_Q134_TERMS;
+  if (m.extra & 1) cubic_gradient(t112, fp[(row++) * stride], s, g);
+  if (m.extra & 2) cubic_gradient(t123, fp[(row++) * stride], s, g);
+  if (m.extra & 4) cubic_gradient(t233, fp[(row++) * stride], s, g);
+  if (m.extra & 8) cubic_gradient(t134, fp[(row++) * stride], s, g);
+#pragma unroll
+  for (int L = 1; L <= 4; ++L) {
+    const int st = L * L - 1;
+    const float F = L <= m.Lmax ? fp[(L - 1) * stride] : 0.0f;
+    s[st] = 2.0f * C3B[st] * F * s[st];
+#pragma unroll
+    for (int k = 1; k < 2 * L + 1; ++k)
+      s[st + k] = 4.0f * C3B[st + k] * F * s[st + k];
+  }
+#pragma unroll
+  for (int k = 0; k < kNumHarm; ++k)
+    s[k] = k < nh ? s[k] + g[k] : 0.0f;
+}
+
+// The shapes of the shipped models (l_max 4, rows 222 / 1111 only) keep the form below with constant row indices;
+// EXTRAS (the generic shape) takes the general form above.
 template <bool EXTRAS = false>
 NEPMI_HD void invariants(const ModelD& m, const float* s, float* q, int stride)
 {
+  if (EXTRAS) {
+    invariants_generic(m, s, q, stride);
+    return;
+  }
   const float C3B[kNumHarm] = NEPMI_C3B_INIT;
 #pragma unroll
   for (int L = 1; L <= 4; ++L) {
@@ -508,17 +605,6 @@ NEPMI_HD void invariants(const ModelD& m, const float* s, float* q, int stride)
   } else if (m.has1111) {
     q[4 * stride] = q5b;
   }
-  if (EXTRAS && m.extra) {
-    int row = 4 + (m.has222 ? 1 : 0) + (m.has1111 ? 1 : 0);
-    const CubicTerm t112[] = NEPMI_Q112_TERMS;
-    const CubicTerm t123[] = NEPMI_Q123_TERMS;
-    const CubicTerm t233[] = NEPMI_Q233_TERMS;
-    const CubicTerm t134[] = NEPMI_Q134_TERMS;
-    if (m.extra & 1) q[(row++) * stride] = cubic_value(t112, s);
-    if (m.extra & 2) q[(row++) * stride] = cubic_value(t123, s);
-    if (m.extra & 4) q[(row++) * stride] = cubic_value(t233, s);
-    if (m.extra & 8) q[(row++) * stride] = cubic_value(t134, s);
-  }
 }
 
 // Adjoint of `invariants`: G[abc] = sum_L Fp_L dq_L/ds_abc (+ 4-/5-body), in place of s.
@@ -527,20 +613,9 @@ template <bool EXTRAS = false>
 NEPMI_HD void invariants_adjoint(const ModelD& m, const float* fp, int stride, float* s /* in: s, out: G */)
 {
   const float C3B[kNumHarm] = NEPMI_C3B_INIT;
-  float gx[EXTRAS ? kNumHarm : 1];
-  if (EXTRAS && m.extra) {
-#pragma unroll
-    for (int k = 0; k < kNumHarm; ++k)
-      gx[EXTRAS ? k : 0] = 0.0f;
-    int row = 4 + (m.has222 ? 1 : 0) + (m.has1111 ? 1 : 0);
-    const CubicTerm t112[] = NEPMI_Q112_TERMS;
-    const CubicTerm t123[] = NEPMI_Q123_TERMS;
-    const CubicTerm t233[] = NEPMI_Q233_TERMS;
-    const CubicTerm t134[] = NEPMI_Q134_TERMS;
-    if (m.extra & 1) cubic_gradient(t112, fp[(row++) * stride], s, gx);
-    if (m.extra & 2) cubic_gradient(t123, fp[(row++) * stride], s, gx);
-    if (m.extra & 4) cubic_gradient(t233, fp[(row++) * stride], s, gx);
-    if (m.extra & 8) cubic_gradient(t134, fp[(row++) * stride], s, gx);
+  if (EXTRAS) {
+    invariants_adjoint_generic(m, fp, stride, s);
+    return;
   }
   float g4[5] = {0, 0, 0, 0, 0}, g5[3] = {0, 0, 0};
   if (m.has222) {
@@ -575,11 +650,6 @@ NEPMI_HD void invariants_adjoint(const ModelD& m, const float* fp, int stride, f
 #pragma unroll
   for (int k = 0; k < 3; ++k)
     s[k] += g5[k];
-  if (EXTRAS && m.extra) {
-#pragma unroll
-    for (int k = 0; k < kNumHarm; ++k)
-      s[k] += gx[EXTRAS ? k : 0];
-  }
 }
 
 // find_f_and_fp_zbl, nep_utilities.cuh:433-508.  para10 == nullptr: universal ZBL.

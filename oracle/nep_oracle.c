@@ -232,8 +232,9 @@ nepo_model* nepo_model_load(const char* path, char* err, int errlen)
   m->has_134 = nt >= 8 ? atoi(tok[7]) : 0;
   if (m->L_max < 1 || m->L_max > NEPO_LMAX)
     NEPO_FAIL("l_max must be 1..%d in the oracle", NEPO_LMAX);
-  if ((m->has_222 && m->L_max < 2))
-    NEPO_FAIL("has_q_222 needs l_max >= 2");
+  if ((m->has_222 && m->L_max < 2) || (m->has_112 && m->L_max < 2) || ((m->has_123 || m->has_233) && m->L_max < 3) ||
+      (m->has_134 && m->L_max < 4))
+    NEPO_FAIL("a 4-body row needs sums of a higher l than l_max_3body provides");
   m->num_L = m->L_max + (m->has_222 ? 1 : 0) + (m->has_1111 ? 1 : 0) + (m->has_112 ? 1 : 0) + (m->has_123 ? 1 : 0) +
              (m->has_233 ? 1 : 0) + (m->has_134 ? 1 : 0);
   if (!fgets(line, sizeof line, fp) || nepo_tokens(line, tok, 256) != 3)

@@ -248,6 +248,7 @@ def check_unwrapped_positions(drv, nsteps=24):
     d_t, d_m, d_x, d_v = drv.dev(typ), drv.dev(mass), drv.dev(x), drv.dev(vel)
     d_pe, d_f, d_w = drv.zeros(n), drv.zeros(3 * n), drv.zeros(9 * n)
     d_u = drv.dev(x.copy())
+    eng.set_tiles(2)  # both engines on one force-assembly variant: the comparison below is bit for bit
     eng.set_unwrapped(d_u)
     eng.force_compute(h, d_t, d_x, d_pe, d_f, d_w)
     eng.run_nve(h, d_t, d_m, dt, nsteps, d_x, d_v, d_pe, d_f, d_w, thermo_every=5)
@@ -256,6 +257,7 @@ def check_unwrapped_positions(drv, nsteps=24):
 
     # the same trajectory through the stand-alone calls, unwrapped kept on the host
     eng2 = drv.engine(model, n)
+    eng2.set_tiles(2)
     e_x, e_v = drv.dev(x), drv.dev(vel)
     e_pe, e_f, e_w = drv.zeros(n), drv.zeros(3 * n), drv.zeros(9 * n)
     eng2.force_compute(h, d_t, e_x, e_pe, e_f, e_w)

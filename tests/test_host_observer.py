@@ -74,7 +74,9 @@ def test_observe_mode_evaluates_every_potential_and_keeps_the_main_one_driving(t
     thermo = np.loadtxt(tmp_path / "thermo.out")
     obs0, obs1 = np.loadtxt(tmp_path / "observer0.out"), np.loadtxt(tmp_path / "observer1.out")
     assert thermo.shape == obs0.shape == obs1.shape == (2, 18)
-    np.testing.assert_allclose(obs0, thermo, rtol=1e-9, atol=1e-12)  # the main potential, evaluated again
+    # the main potential, evaluated again (while the engine is still timing its two force-assembly variants the second
+    # evaluation may take the other one: FP32 summation order, not bits)
+    np.testing.assert_allclose(obs0, thermo, rtol=2e-6, atol=1e-7)
     assert np.abs(obs1[:, 2] - obs0[:, 2]).min() > 1e-3              # the other model really is another model
     np.testing.assert_array_equal(obs1[:, 0], obs0[:, 0])           # same velocities: same temperature
     main = H.read_xyz_frames(str(tmp_path / "main.xyz"))
@@ -83,7 +85,7 @@ def test_observe_mode_evaluates_every_potential_and_keeps_the_main_one_driving(t
     assert f1[0]["comment"]["properties"] == "species:S:1:pos:R:3:vel:R:3:forces:R:3"
     for k in range(2):
         # the run continues with the main potential's forces although the observer overwrote the arrays in between
-        np.testing.assert_allclose(f0[k]["forces"], main[k]["forces"], atol=1e-8)
+        np.testing.assert_allclose(f0[k]["forces"], main[k]["forces"], atol=2e-6)
         e_b, f_b = _oracle_on_frame(NEP_B, main[k])
         np.testing.assert_allclose(float(f1[k]["comment"]["energy"]), e_b, rtol=1e-5)
         np.testing.assert_allclose(f1[k]["forces"], f_b, rtol=1e-4, atol=3e-5)
@@ -93,7 +95,7 @@ def test_observe_mode_evaluates_every_potential_and_keeps_the_main_one_driving(t
     sub.mkdir()
     out = _run(sub, text.replace("potential %s\n" % NEP_B, "").replace("dump_observer observe 2 2 1 1\n", ""))
     assert out.returncode == 0, out.stdout
-    np.testing.assert_allclose(np.loadtxt(sub / "thermo.out"), thermo, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(np.loadtxt(sub / "thermo.out"), thermo, rtol=2e-6, atol=1e-7)
 
 
 @pytest.mark.gpu
@@ -104,7 +106,7 @@ def test_average_mode_runs_on_the_mean_of_the_potentials(tmp_path):
     assert out.returncode == 0, out.stdout + out.stderr
     assert not os.path.exists(tmp_path / "observer0.out")
     thermo, obs = np.loadtxt(tmp_path / "thermo.out"), np.loadtxt(tmp_path / "observer.out")
-    np.testing.assert_allclose(obs, thermo, rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose(obs, thermo, rtol=1e-9, atol=1e-12)  # the very same arrays, written twice
     main, fo = H.read_xyz_frames(str(tmp_path / "main.xyz")), H.read_xyz_frames(str(tmp_path / "observer.xyz"))
     assert fo[0]["comment"]["properties"] == "species:S:1:pos:R:3:forces:R:3"
     for k in range(2):

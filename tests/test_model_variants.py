@@ -43,7 +43,7 @@ def make_per_type_cutoff(tmp_path):
     return _write(tmp_path, "pertype.txt", out)
 
 
-def make_extra_rows(flags):
+def make_extra_rows(flags, l_max=4):
     """l_max 4 <222> <1111> <112> <123> <233> <134>: the PbTe descriptor with the optional 4-body rows switched on
     (nep.cu:262-312).  No shipped model has them, so the ANN is seeded random (the descriptor coefficients and the
     scalers of the first rows stay those of the PbTe file)."""
@@ -51,7 +51,7 @@ def make_extra_rows(flags):
         L = _pbte_lines()
         head, par = L[:6], [x for x in L[6:] if x.strip()]
         old_dim, nneu, nA1 = 42, 30, 7
-        num_L = 4 + sum(flags)
+        num_L = l_max + sum(flags)
         dim = 7 + nA1 * num_L
         n_c = len(par) - (2 * (old_dim + 2) * nneu + 1) - old_dim
         c = par[2 * (old_dim + 2) * nneu + 1: 2 * (old_dim + 2) * nneu + 1 + n_c]
@@ -61,10 +61,12 @@ def make_extra_rows(flags):
         for _ in range(2):
             ann += list(rng.normal(0, 0.4, dim * nneu)) + list(rng.normal(0, 0.3, nneu)) + list(rng.normal(0, 0.5, nneu))
         ann.append(-3.21)
-        rows = scaler[:7 + 4 * nA1] + ["%.8e" % v for v in rng.uniform(0.5, 3.0, nA1 * (num_L - 4))]
-        out = head[:4] + ["l_max 4 " + " ".join(str(b) for b in flags), "ANN %d 0" % nneu]
+        rows = scaler[:7 + l_max * nA1] + ["%.8e" % v for v in rng.uniform(0.5, 3.0, nA1 * (num_L - l_max))]
+        # the 222 flag is written the way nep.txt files carry it (l_max_4body = 2; NEP_CPU tests == 2, nep.cu != 0)
+        toks = [str(2 * b if k == 0 else b) for k, b in enumerate(flags)]
+        out = head[:4] + ["l_max %d " % l_max + " ".join(toks), "ANN %d 0" % nneu]
         out += ["%.8e" % v for v in ann] + c + rows
-        return _write(tmp_path, "extra_%s.txt" % "".join(str(b) for b in flags), out)
+        return _write(tmp_path, "extra_%d_%s.txt" % (l_max, "".join(str(b) for b in flags)), out)
     return maker
 
 
@@ -109,7 +111,11 @@ def _check(drv, nep, ref_cpu):
 VARIANTS = [("nep5", make_nep5, True), ("nep3-2types", make_nep3, True), ("per-type-cutoff", make_per_type_cutoff, False),
             # the optional 4-body rows 112 / 123 / 233 / 134 (flags: 222 1111 112 123 233 134)
             ("rows-all", make_extra_rows([1, 1, 1, 1, 1, 1]), False), ("rows-112", make_extra_rows([1, 0, 1, 0, 0, 0]), False),
-            ("rows-123-233", make_extra_rows([0, 0, 0, 1, 1, 0]), False), ("rows-134", make_extra_rows([0, 1, 0, 0, 0, 1]), False)]
+            ("rows-123-233", make_extra_rows([0, 0, 0, 1, 1, 0]), False), ("rows-134", make_extra_rows([0, 1, 0, 0, 0, 1]), False),
+            # l_max_3body below 4 (generic shape).  NEP_CPU carries these too -- except a 1111 row without a 222 row, which
+            # it reads as the 222 row (nep.cpp:642-660) -- so the oracle is held against it where it can be
+            ("lmax-2-222-1111", make_extra_rows([1, 1], 2), True), ("lmax-1-1111", make_extra_rows([0, 1], 1), False),
+            ("lmax-3", make_extra_rows([0, 0], 3), True), ("lmax-3-222-112-233", make_extra_rows([1, 0, 1, 0, 1], 3), False)]
 
 
 @pytest.mark.parametrize("name,maker,ref_cpu", VARIANTS)
