@@ -1032,11 +1032,16 @@ private:
   // Tile mode -1 (default): the two force-assembly variants (pair records written by the radial pass
   // vs. geometry rebuilt from a second LDS window) are equivalent; which one is faster depends on the
   // model (angular work per atom, registers).  The engine times the whole force path of its 2nd call
-  // in mode 2 and of its 4th call in mode 1 and keeps the faster one.
+  // in mode 2 and of its 4th call in mode 1 and keeps the faster one.  Below kAutoProbeMinAtoms the timing
+  // says nothing (a force call is tens of microseconds) and a choice that depends on it would make small runs
+  // differ from one execution to the next in the last FP32 bits: those systems simply take mode 2.
+  static constexpr int64_t kAutoProbeMinAtoms = 100000;
   int effective_tile_mode() const
   {
     if (tile_mode_ >= 0)
       return tile_mode_;
+    if (N_ < kAutoProbeMinAtoms)
+      return 2;
     if (auto_choice_ >= 0)
       return auto_choice_;
     return auto_calls_ < 2 ? 2 : 1;
@@ -1044,7 +1049,8 @@ private:
 
   void force_kernels(double* pe, double* force, double* virial, int phase)
   {
-    const bool probing = phase == kPhaseAll && tile_mode_ < 0 && auto_choice_ < 0 && tile_ok_ && model_.kind == 0;
+    const bool probing = phase == kPhaseAll && tile_mode_ < 0 && auto_choice_ < 0 && tile_ok_ && model_.kind == 0 &&
+                         N_ >= kAutoProbeMinAtoms;
     if (probing && (auto_calls_ == 1 || auto_calls_ == 3))
       be_.probe_start();
     force_kernels_dispatch(pe, force, virial, phase);
