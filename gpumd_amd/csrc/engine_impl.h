@@ -812,31 +812,44 @@ private:
   {
     const NepModel& m = model_;
     const double rc_list = m.rc_radial_max + kSkin;
-    const double rc_cell = 0.5 * rc_list;
+    double rc_cell = 0.5 * rc_list;
     int nb[3];
-    for (int d = 0; d < 3; ++d) {
-      if (box_.pbc[d]) {
-        if (box_.thickness[d] <= 2.5 * rc_list) { // NEP::compute -> small box (nep.cu:1305-1314)
-          char msg[200];
-          std::snprintf(
-            msg, sizeof msg,
-            "box thickness %.3f A in periodic direction %d is <= 2.5*(rc+skin) = %.3f A: small-box path "
-            "is not implemented on the device",
-            box_.thickness[d], d, 2.5 * rc_list);
-          throw EngineError{-7, msg};
+    auto bin_grid = [&]() {
+      for (int d = 0; d < 3; ++d) {
+        if (box_.pbc[d]) {
+          if (box_.thickness[d] <= 2.5 * rc_list) { // NEP::compute -> small box (nep.cu:1305-1314)
+            char msg[200];
+            std::snprintf(
+              msg, sizeof msg,
+              "box thickness %.3f A in periodic direction %d is <= 2.5*(rc+skin) = %.3f A: small-box path "
+              "is not implemented on the device",
+              box_.thickness[d], d, 2.5 * rc_list);
+            throw EngineError{-7, msg};
+          }
+          nb[d] = (int)std::floor(box_.thickness[d] / rc_cell);
+        } else {
+          // The reference uses ONE bin in a non-periodic direction (box.cu:80-91), i.e. an O(N^2)
+          // sweep along it; the neighbour SETS do not depend on the binning, so bin it as well
+          // (edge bins absorb atoms outside the box).  Needed for the ghost-padded local boxes.
+          nb[d] = (int)std::floor(box_.thickness[d] / rc_cell);
+          if (nb[d] < 1)
+            nb[d] = 1;
         }
-        nb[d] = (int)std::floor(box_.thickness[d] / rc_cell);
-      } else {
-        // The reference uses ONE bin in a non-periodic direction (box.cu:80-91), i.e. an O(N^2)
-        // sweep along it; the neighbour SETS do not depend on the binning, so bin it as well
-        // (edge bins absorb atoms outside the box).  Needed for the ghost-padded local boxes.
-        nb[d] = (int)std::floor(box_.thickness[d] / rc_cell);
-        if (nb[d] < 1)
-          nb[d] = 1;
       }
-    }
-    const int gb[3] = {(nb[0] + kBrick - 1) / kBrick, (nb[1] + kBrick - 1) / kBrick, (nb[2] + kBrick - 1) / kBrick};
-    const int64_t ncell = (int64_t)gb[0] * gb[1] * gb[2] * (kBrick * kBrick * kBrick); // padded to whole bricks
+    };
+    // cells per direction -> Bufs; returns the number of cells padded to whole bricks
+    auto set_grid = [&]() -> int64_t {
+      b_.nbx = nb[0];
+      b_.nby = nb[1];
+      b_.nbz = nb[2];
+      b_.gbx = (nb[0] + kBrick - 1) / kBrick;
+      b_.gby = (nb[1] + kBrick - 1) / kBrick;
+      b_.gbz = (nb[2] + kBrick - 1) / kBrick;
+      b_.rc_inv_cell = 1.0 / rc_cell;
+      return (int64_t)b_.gbx * b_.gby * b_.gbz * (kBrick * kBrick * kBrick);
+    };
+    bin_grid();
+    int64_t ncell = set_grid(); // the finest grid: the largest cell arrays this box needs
     if (ncell > ((int64_t)1 << 30))
       throw EngineError{-3, "too many cells"};
     if (ncell > ncell_cap_) {
@@ -849,13 +862,44 @@ private:
       scan_scratch_ = dalloc<int>(ncell / 1024 + 1024);
       ncell_cap_ = ncell;
     }
-    b_.nbx = nb[0];
-    b_.nby = nb[1];
-    b_.nbz = nb[2];
-    b_.gbx = gb[0];
-    b_.gby = gb[1];
-    b_.gbz = gb[2];
-    b_.rc_inv_cell = 2.0 / rc_list;
+    // Cell size.  The reference's edge (rc + skin) / 2 is the smallest that works (neighbour SETS do not depend on
+    // it); the window kernels give every 4x4x4-cell brick 256 atom slots per pass, so a brick that holds 170-220
+    // atoms leaves a fifth of the lanes idle.  Among the grids with 0..6 fewer cells along the first direction
+    // (the others follow the same edge) take the coarsest whose fullest brick still fits one pass with a margin;
+    // counted, not timed: the same input always gives the same grid.  Redone when the box or the atom count changes.
+    if (model_.kind == 0 && use_tiles_ && tile_mode_ != 0 && nb[0] >= 8 && nb[1] >= 8 && nb[2] >= 8) {
+      bool same = grid_n_ == N_;
+      for (int k = 0; k < 9; ++k)
+        same = same && grid_h_[k] == box_.h[k];
+      if (!same) {
+        const double edge0 = rc_cell;
+        const int nb0 = nb[0];
+        double best = edge0;
+        for (int k = 1; k <= 6 && nb0 - k >= 8; ++k) {
+          rc_cell = box_.thickness[0] / (nb0 - k) * (1.0 - 1.0e-12);
+          if (rc_cell < edge0)
+            continue;
+          bin_grid();
+          const int64_t nc = set_grid();
+          be_.memset(b_.cell_count, 0, sizeof(int) * (nc + 1));
+          be_.memset(b_.flags + kFlagMaxBrick, 0, sizeof(int));
+          be_.template launch<256>(kSlotMisc, N_, BinAtomsBody{box_, b_, pos});
+          be_.template launch<64>(kSlotMisc, nc / 64, BrickMaxBody{b_});
+          int fullest = 0;
+          be_.sync();
+          be_.d2h(&fullest, b_.flags + kFlagMaxBrick, sizeof(int));
+          if (fullest <= kBrickFill)
+            best = rc_cell;
+        }
+        grid_edge_ = best;
+        grid_n_ = N_;
+        for (int k = 0; k < 9; ++k)
+          grid_h_[k] = box_.h[k];
+      }
+      rc_cell = grid_edge_;
+      bin_grid();
+      ncell = set_grid();
+    }
     be_.memset(b_.cell_count, 0, sizeof(int) * (ncell + 1));
     be_.memset(b_.cell_fill, 0, sizeof(int) * ncell);
     be_.memset(b_.cell_ghost, 0, sizeof(int) * ncell);
@@ -876,7 +920,7 @@ private:
     be_.template launch<128>(kSlotMisc, N_, BuildListsBody{box_, b_});
     be_.template launch<128>(kSlotMisc, N_, ReverseSlotsBody{b_});
     be_.memset(b_.flags + kFlagMaxWindow, 0, 3 * sizeof(int));
-    num_bricks_ = (int64_t)gb[0] * gb[1] * gb[2];
+    num_bricks_ = (int64_t)b_.gbx * b_.gby * b_.gbz;
     if (b_.level)
       be_.template launch<256>(kSlotMisc, N_, MarkGhostCellsBody{b_});
     be_.template launch<64>(kSlotMisc, num_bricks_, TileStatsBody{box_, b_});
@@ -1096,6 +1140,10 @@ private:
   bool records_valid_ = false; // rstash holds the pair records of the last evaluated positions
   int recompute_mode_ = -1;
   bool external_skin_ = false;
+  static constexpr int kBrickFill = 253; // of the 256 atom slots of a window-kernel pass (atoms drift between rebuilds;
+                                         // a brick that does overflow just takes a second pass)
+  double grid_edge_ = 0.0, grid_h_[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}; // cell edge chosen for this box and atom count
+  int64_t grid_n_ = -1;
   double* unwrapped_ = nullptr;
   bool split_pending_ = false;   // compute_levels_begin ran, compute_levels_end has not yet
   int64_t num_boundary_bricks_ = 0;

@@ -413,6 +413,18 @@ struct BinAtomsBody {
   }
 };
 
+// atoms of the fullest brick, from the per-cell counts BinAtomsBody left (before the scan); used to size the cells
+struct BrickMaxBody {
+  Bufs b;
+  NEPMI_HD void operator()(int64_t brick) const
+  {
+    int n = 0;
+    for (int c = 0; c < 64; ++c)
+      n += b.cell_count[brick * 64 + c];
+    NEPMI_ATOMIC_MAX(&b.flags[kFlagMaxBrick], n);
+  }
+};
+
 struct FillCellsBody {
   Bufs b; // cell_count already scanned (cell_start)
   NEPMI_HD void operator()(int64_t i) const

@@ -20,6 +20,9 @@ MODELS = {
     "PbTe-A": ("PbTe/nep.txt", lambda: H.pbte_supercell((2, 2, 2)), None),
     "PbTe-B": ("PbTe/nep_B.txt", lambda: H.pbte_supercell((2, 2, 2), seed=2), None),
     "PbTe-ortho": ("PbTe/nep.txt", lambda: H.rocksalt_orthogonal((4, 4, 5)), None),
+    # 12 cells per direction: large enough for the engine to coarsen its cell grid towards full bricks
+    "PbTe-3x3x3": ("PbTe/nep.txt", lambda: H.pbte_supercell((3, 3, 3), rattle=0.03, seed=6), None),
+    "PbTe-ortho-big": ("PbTe/nep.txt", lambda: H.rocksalt_orthogonal((7, 8, 7)), None),
     "C-2022": ("C/nep.txt", lambda: H.diamond((6, 6, 7), 3.57), 1),
     "C-nep3": ("C/nep3.txt", lambda: H.diamond((6, 7, 6), 3.57, seed=10), 1),
     "UNEP-v1": ("UNEP/nep.txt", lambda: H.fcc_alloy((5, 5, 6), 3.9, 16), 16),
