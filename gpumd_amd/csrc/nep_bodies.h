@@ -851,6 +851,8 @@ struct ReverseSlotsSmallBody {
 };
 
 constexpr int kGather = 4; // neighbour entries whose gathers are issued together
+constexpr int kGatherR = 6; // the same for the radial pass: its chunk carries fewer live values (measured: 6 beats 2 and 4 there,
+                            // 2 per lane beats 1 and 3 in the force assembly)
 
 // c_ang staged in LDS: [T*T pairs][stride] with an odd stride so that lanes of different type
 // pairs land on different banks (lanes of the same pair read one address: broadcast).
@@ -884,7 +886,7 @@ struct RadialDescBody {
     const PosQ* posq;
     int64_t N;
     struct Tok {
-      int jj[kGather];
+      int jj[kGatherR];
     };
     // global loads of a chunk's neighbour indices; issued one chunk ahead, i.e. BEFORE the stores
     // of the chunk being processed (vmcnt retires in order: a load issued behind stores cannot be
@@ -893,7 +895,7 @@ struct RadialDescBody {
     {
       // entries past the end re-read the last valid slot (no branches around the loads)
 #pragma unroll
-      for (int u = 0; u < kGather; ++u) {
+      for (int u = 0; u < kGatherR; ++u) {
         const int idx = s0 + u < nn ? s0 + u : nn - 1;
         t.jj[u] = idx < na ? nlA[(int64_t)idx * N] : nlB[(int64_t)(idx - na) * N];
       }
@@ -901,7 +903,7 @@ struct RadialDescBody {
     NEPMI_HD void resolve(const Tok& t, int* jj, PosQ* pp) const
     {
 #pragma unroll
-      for (int u = 0; u < kGather; ++u) {
+      for (int u = 0; u < kGatherR; ++u) {
         jj[u] = t.jj[u];
         pp[u] = posq[jj[u]];
       }
@@ -954,31 +956,31 @@ struct RadialDescBody {
     const int na = b.nn_ang[k], nb = b.nn_skin[k];
     const int nn = na + nb;
     int cnt = 0, ca = 0;
-    // The lists are walked in chunks of kGather entries: all index loads of a chunk, then all
-    // position gathers, then the arithmetic -- kGather independent gathers in flight per lane.
+    // The lists are walked in chunks of kGatherR entries: all index loads of a chunk, then all
+    // position gathers, then the arithmetic -- kGatherR independent gathers in flight per lane.
     F4* __restrict__ rstash = b.rstash + k;
     F4* __restrict__ acomp = b.acomp + k;
     unsigned short* __restrict__ amap = b.amap + k;
-    constexpr int kStride = PARTS * kGather;
+    constexpr int kStride = PARTS * kGatherR;
     const int nrounds = (nn + kStride - 1) / kStride; // the same for every lane that shares the atom
     typename Fetch::Tok cur, nxt;
     if (nn > 0)
-      fetch.prefetch(part * kGather < nn ? part * kGather : 0, nn, na, cur);
+      fetch.prefetch(part * kGatherR < nn ? part * kGatherR : 0, nn, na, cur);
     for (int r = 0; r < nrounds; ++r) {
-      const int s0 = r * kStride + part * kGather;
-      int jj[kGather];
-      PosQ pp[kGather];
+      const int s0 = r * kStride + part * kGatherR;
+      int jj[kGatherR];
+      PosQ pp[kGatherR];
       nxt = cur;
       if (s0 + kStride < nn)
         fetch.prefetch(s0 + kStride, nn, na, nxt); // next chunk's loads go out before this chunk's stores
       fetch.resolve(cur, jj, pp);
       cur = nxt;
-      float xs[kGather], ys[kGather], zs[kGather], d2s[kGather];
-      int t2s[kGather];
-      bool ins[kGather], angs[kGather];
+      float xs[kGatherR], ys[kGatherR], zs[kGatherR], d2s[kGatherR];
+      int t2s[kGatherR];
+      bool ins[kGatherR], angs[kGatherR];
       int mine = 0; // angular members among this lane's entries of the round
 #pragma unroll
-      for (int u = 0; u < kGather; ++u) {
+      for (int u = 0; u < kGatherR; ++u) {
         const int idx = s0 + u;
         const PosQ p2 = pp[u];
         d2s[u] = pair_geometry(box, p1, p2, xs[u], ys[u], zs[u]);
@@ -998,7 +1000,7 @@ struct RadialDescBody {
         ca += mine;
       }
 #pragma unroll
-      for (int u = 0; u < kGather; ++u) {
+      for (int u = 0; u < kGatherR; ++u) {
         const int idx = s0 + u;
         if (idx >= nn)
           continue;
@@ -1029,7 +1031,7 @@ struct RadialDescBody {
         }
         if (S::TS > 0) {
           // branch-free: entries outside the cutoff run the same arithmetic with weight 0, so the
-          // kGather candidates of a chunk are independent instruction streams the scheduler can
+          // kGatherR candidates of a chunk are independent instruction streams the scheduler can
           // interleave (the envelope fc is evaluated at min(d, rc) to stay finite)
           cnt += inside ? 1 : 0;
           float d, dinv;
@@ -1222,7 +1224,7 @@ struct RadialTileBody {
     }
   }
 
-  template <class LC, int G = kGather>
+  template <class LC, int G = kGatherR>
   struct TileFetch {
     const unsigned short* cA;
     const unsigned short* cB;
