@@ -87,9 +87,10 @@ class EngineT
 {
 public:
   static constexpr double kSkin = 1.0; // neighbor.cuh:212
-  // workgroup of the angular descriptor kernel: the coefficient table is staged once per workgroup, 256 threads
-  // amortise it best (0.160 -> 0.145 ms on PbTe 1M); the angular force kernel does not care (64)
-  static constexpr int kAngDescBlock = 256;
+  // workgroup of the angular descriptor kernel: the coefficient table is staged once per workgroup; measured on PbTe 1M
+  // 64: 0.160, 128: 0.162, 256: 0.150, 512: 0.137 ms (1024 would halve the register budget: 1.0 ms); the angular force
+  // kernel does not care (64)
+  static constexpr int kAngDescBlock = 512;
 
   EngineT(const NepModel& model, int64_t n_atoms, B backend) : model_(model), be_(backend), cap_(n_atoms), N_(n_atoms)
   {
