@@ -187,13 +187,18 @@ def cpu_baseline(seconds=12.0):
     return out
 
 
-def kernel_report(st, info, n_atoms_per_launch):
-    """per-kernel mean durations (HIP events) + the roofline object of the dominant force kernel"""
+def kernel_report(st, info, n_atoms_per_launch, st_all=None):
+    """per-kernel mean durations (HIP events) + the roofline object of the dominant force kernel.
+    st: stats of the timed region (timing mode 2: only the force-assembly slot is filled); st_all: stats of the
+    instrumented pass after it (every slot) -- the timed region's own figure wins where both exist."""
     per_kernel, b_step = algorithmic_bytes(info, st.mean_nn_radial, st.mean_nn_angular)
     kern = {}
-    for k, name in enumerate(KERNEL_NAMES):
-        if st.launches[k] > 0:
-            kern[name] = {"launches": int(st.launches[k]), "avg_ms": st.ms_kernel_sum[k] / st.launches[k]}
+    for src in (st_all, st):
+        if src is None:
+            continue
+        for k, name in enumerate(KERNEL_NAMES):
+            if src.launches[k] > 0 and src.ms_kernel_sum[k] > 0.0:
+                kern[name] = {"launches": int(src.launches[k]), "avg_ms": src.ms_kernel_sum[k] / src.launches[k]}
     force_kernels = [k for k in kern if k in per_kernel and k not in ("velocity_verlet", "gather_skin_check")]
     dom = max(force_kernels, key=lambda k: kern[k]["avg_ms"] * kern[k]["launches"]) if force_kernels else None
     roofline = None
@@ -240,7 +245,7 @@ def run_decomposed(args, world, rank, dev, model, h_block, typ, x, mass, vel, re
     dt = 1.0 / H.TIME_UNIT
     md.initial_forces()
     md.run(args.warmup, dt)
-    md.engine.set_timing(True)
+    md.engine.set_timing(2)  # the dominant kernel only inside the timed region (see the single-GPU path)
     dec0 = md.num_decompositions
     if world > 1:
         dist.barrier()
@@ -253,6 +258,10 @@ def run_decomposed(args, world, rank, dev, model, h_block, typ, x, mass, vel, re
     elapsed = time.perf_counter() - t0
     st = md.engine.stats(with_lists=True)
     th = md.thermo()
+    md.engine.set_timing(1)
+    md.run(max(10, min(args.steps, 40)), dt)  # instrumented pass for the per-kernel table, outside the clock
+    st_all = md.engine.stats(with_lists=False)
+    md.engine.set_timing(0)
     t_el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     n_loc = torch.tensor([md.n_loc], dtype=torch.float64, device=dev)
     if world > 1:
@@ -260,7 +269,7 @@ def run_decomposed(args, world, rank, dev, model, h_block, typ, x, mass, vel, re
         md._all_reduce(n_loc, dist.ReduceOp.MAX)
     elapsed = float(t_el.item())
     if rank == 0:
-        kern, roofline, b_step = kernel_report(st, model.info, md.n_loc)
+        kern, roofline, b_step = kernel_report(st, model.info, md.n_loc, st_all)
         total = md.n_total
         out = {
             "metric": "atom-steps/sec, NEP PbTe NVE (nep4 2 Te Pb, examples/nep_train/nep.txt)",
@@ -361,7 +370,10 @@ def main():
     eng.force_compute(h, t_type, t_x, t_pe, t_f, t_w)
     if args.warmup > 0:
         eng.run_nve(h, t_type, t_mass, dt, args.warmup, t_x, t_v, t_pe, t_f, t_w)
-    eng.set_timing(True)
+    # Inside the timed region only the dominant kernel (force assembly) carries HIP events -- two records per step; a
+    # record around EVERY kernel stops them from running back to back and costs about 5 % of the step.  The full
+    # per-kernel table comes from an instrumented pass of further steps after the clock has stopped.
+    eng.set_timing(2)
     reb0 = eng.stats().num_rebuild
     barrier()
     t0 = time.perf_counter()
@@ -369,7 +381,11 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     st = eng.stats(with_lists=True)
-    eng.set_timing(False)
+    eng.set_timing(1)
+    extra = max(10, min(args.steps, 60))
+    eng.run_nve(h, t_type, t_mass, dt, extra, t_x, t_v, t_pe, t_f, t_w, thermo_every=extra)
+    st_all = eng.stats(with_lists=False)
+    eng.set_timing(0)
 
     t_el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
@@ -379,7 +395,7 @@ def main():
     value = total_atoms * args.steps / elapsed
 
     if rank == 0:
-        kern, roofline, b_step = kernel_report(st, model.info, n)
+        kern, roofline, b_step = kernel_report(st, model.info, n, st_all)
         out = {
             "metric": "atom-steps/sec, NEP PbTe NVE (nep4 2 Te Pb, examples/nep_train/nep.txt)",
             "value": value, "unit": "atom-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -393,6 +409,7 @@ def main():
             "step_algorithmic_bytes_per_atom": b_step,
             "step_hbm_frac": b_step * (n * args.steps / elapsed) / (HBM_PEAK_GBS * 1e9),
             "kernels": kern,
+            "kernels_note": "force_assemble: HIP events inside the timed region; the others: an instrumented pass of %d further steps" % extra,
             "thermo_last": [float(v) for v in th[-1]] if len(th) else None,
         }
         if args.workload == "pbte":

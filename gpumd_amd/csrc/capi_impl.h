@@ -393,7 +393,7 @@ int nepmi_engine_set_timing(nepmi_engine* e, int on)
 {
   if (!e)
     return fail(NEPMI_ERR_ARG, "null engine");
-  e->e->backend().set_timing(on != 0);
+  e->e->backend().set_timing(on < 0 ? 0 : (on > 2 ? 1 : on));
   return NEPMI_OK;
 }
 

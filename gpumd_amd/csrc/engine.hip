@@ -519,7 +519,9 @@ struct HipBackend {
   hipStream_t stream = nullptr;
   HipTiming* timing = nullptr; // shared by copies of the backend
   int* pinned = nullptr;       // 64-byte pinned staging for flag read-back
-  bool timing_on = false;
+  bool timing_on = false; // any timing
+  int timing_mode = 0;    // 1: every kernel and region; 2: the force-assembly kernel only (two events per step)
+  bool timed(int slot) const { return timing_mode == 1 ? slot != kSlotMisc : (timing_mode == 2 && slot == kSlotForce); }
   hipEvent_t probe_ev[2] = {nullptr, nullptr};
   bool mfma_on = true; // per-atom ANN on the matrix cores when the model shape allows it
 
@@ -582,7 +584,7 @@ struct HipBackend {
     NEPMI_HIP_CHECK(hipEventRecord(t.stop[t.used], stream));
     ++t.used;
   }
-  void set_timing(bool on)
+  void set_timing(int mode)
   {
     for (int k = 0; k < 16; ++k) {
       timer_drain(timing->slot[k]);
@@ -594,7 +596,8 @@ struct HipBackend {
       timing->reg[k].sum_ms = 0.0;
       timing->reg[k].count = 0;
     }
-    timing_on = on;
+    timing_mode = mode;
+    timing_on = mode != 0;
   }
   // stand-alone stopwatch on the engine's stream (independent of set_timing): used once per engine
   // to choose between equivalent kernel variants
@@ -616,12 +619,12 @@ struct HipBackend {
   }
   void begin_region(int r)
   {
-    if (timing_on)
+    if (timing_mode == 1)
       timer_start(timing->reg[r]);
   }
   void end_region(int r)
   {
-    if (timing_on)
+    if (timing_mode == 1)
       timer_stop(timing->reg[r]);
   }
   double region_ms(int r) { timer_drain(timing->reg[r]); return timing->reg[r].last_ms; }
@@ -637,7 +640,7 @@ struct HipBackend {
     if (n <= 0)
       return;
     const int64_t grid = ((n + BLOCK - 1) / BLOCK + 7) / 8 * 8;
-    const bool t = timing_on && slot != kSlotMisc;
+    const bool t = timed(slot);
     if (t)
       timer_start(timing->slot[slot]);
     hipLaunchKernelGGL((nepmi_kernel<BLOCK, Body>), dim3((unsigned)grid), dim3(BLOCK), 0, stream, body, n);
@@ -690,7 +693,7 @@ struct HipBackend {
     const size_t lds_bytes = a.img_floats * sizeof(float);
     const int64_t nchunks = (n >> kTypeChunkShift) + 1;
     const int64_t grid = (nchunks * kAnnSplit + 7) / 8 * 8;
-    const bool t = timing_on;
+    const bool t = timed(slot);
     if (t)
       timer_start(timing->slot[slot]);
     if (a.KS <= 24) {
@@ -725,7 +728,7 @@ struct HipBackend {
       NEPMI_HIP_CHECK(hipFuncSetAttribute(
         reinterpret_cast<const void*>(&nepmi_tile_kernel<Body>), hipFuncAttributeMaxDynamicSharedMemorySize,
         (int)lds_bytes));
-    const bool t = timing_on;
+    const bool t = timed(slot);
     if (t)
       timer_start(timing->slot[slot]);
     hipLaunchKernelGGL((nepmi_tile_kernel<Body>), dim3((unsigned)grid), dim3(kTileThreads), lds_bytes, stream, body, nbricks);
@@ -745,7 +748,7 @@ struct HipBackend {
       NEPMI_HIP_CHECK(hipFuncSetAttribute(
         reinterpret_cast<const void*>(&nepmi_kernel_lds<BLOCK, Body>), hipFuncAttributeMaxDynamicSharedMemorySize,
         (int)lds_bytes));
-    const bool t = timing_on;
+    const bool t = timed(slot);
     if (t)
       timer_start(timing->slot[slot]);
     hipLaunchKernelGGL((nepmi_kernel_lds<BLOCK, Body>), dim3((unsigned)grid), dim3(BLOCK), lds_bytes, stream, body, n);
@@ -765,7 +768,7 @@ struct HipBackend {
       NEPMI_HIP_CHECK(hipFuncSetAttribute(
         reinterpret_cast<const void*>(&nepmi_kernel_lds_pairs<BLOCK, Body>),
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-    const bool t = timing_on;
+    const bool t = timed(slot);
     if (t)
       timer_start(timing->slot[slot]);
     hipLaunchKernelGGL((nepmi_kernel_lds_pairs<BLOCK, Body>), dim3((unsigned)grid), dim3(BLOCK), lds_bytes, stream,

@@ -256,7 +256,8 @@ class NEP:
         return st
 
     def set_timing(self, on=True):
-        self._ck(self.lib.nepmi_engine_set_timing(self.handle, 1 if on else 0))
+        """False/0 off, True/1 every kernel, 2 the force-assembly kernel only (see include/nepmi.h)."""
+        self._ck(self.lib.nepmi_engine_set_timing(self.handle, int(on)))
 
     def set_tiles(self, mode=-1):
         """0/False: no LDS-window kernels; 1: radial pass only; 2/True: radial pass + force assembly;

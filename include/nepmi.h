@@ -241,7 +241,9 @@ typedef struct {
 } nepmi_stats;
 /* Synchronises the stream.  with_lists != 0 also recounts the per-step list lengths. */
 int nepmi_engine_stats(nepmi_engine* e, int with_lists, nepmi_stats* out);
-/* Enable per-kernel HIP-event timing (adds event records on the engine's stream). */
+/* HIP-event timing on the engine's stream.  on = 1: every kernel and region (two event records per launch: the
+ * kernels no longer run back to back, about 5 % slower steps); on = 2: the force-assembly kernel only (what bench.py
+ * keeps inside its timed region for the roofline figure); 0: off. */
 int nepmi_engine_set_timing(nepmi_engine* e, int on);
 /* Force the run-time-shaped (generic) kernel instantiation instead of a model-shape-specialised
  * one; used by the parity tests to cover both code paths with one model. */

@@ -30,7 +30,7 @@ struct HostLoopBackend {
   int64_t slot_count(int) { return 0; }
   double region_sum(int) { return 0.0; }
   int64_t region_count(int) { return 0; }
-  void set_timing(bool) {}
+  void set_timing(int) {}
 
   template <int BLOCK, class Body>
   void launch(int, int64_t n, const Body& body)
