@@ -245,7 +245,8 @@ int nepmi_run_nve(
   if (!e)
     return fail(NEPMI_ERR_ARG, "null engine");
   return guarded([&] {
-    e->e->run_nve(h, pbc, n, type, mass, dt, nsteps, pos, vel, pe, force, virial, thermo_every, thermo_host);
+    e->e->run_md(e->e->kNve, h, pbc, n, type, mass, dt, nsteps, 0.0, 0.0, 1.0, pos, vel, pe, force, virial, thermo_every,
+                 thermo_host);
   });
 }
 
@@ -267,8 +268,8 @@ int nepmi_run_nvt_ber(
   if (t_coup < 1.0)
     return fail(NEPMI_ERR_ARG, "Temperature coupling should >= 1.");
   return guarded([&] {
-    e->e->run_nvt_ber(h, pbc, n, type, mass, dt, nsteps, t1, t2, t_coup, pos, vel, pe, force, virial, thermo_every,
-                      thermo_host);
+    e->e->run_md(e->e->kBer, h, pbc, n, type, mass, dt, nsteps, t1, t2, t_coup, pos, vel, pe, force, virial, thermo_every,
+                 thermo_host);
   });
 }
 
@@ -300,8 +301,8 @@ int nepmi_run_nvt_nhc(
   if (t_coup < 1.0)
     return fail(NEPMI_ERR_ARG, "Temperature coupling should >= 1.");
   return guarded([&] {
-    e->e->run_nvt_nhc(h, pbc, n, type, mass, dt, nsteps, t1, t2, t_coup, pos, vel, pe, force, virial, thermo_every,
-                      thermo_host);
+    e->e->run_md(e->e->kNhc, h, pbc, n, type, mass, dt, nsteps, t1, t2, t_coup, pos, vel, pe, force, virial, thermo_every,
+                 thermo_host);
   });
 }
 
@@ -332,8 +333,8 @@ int nepmi_run_nvt_bdp(
   if (t_coup < 1.0)
     return fail(NEPMI_ERR_ARG, "Temperature coupling should >= 1.");
   return guarded([&] {
-    e->e->run_nvt_bdp(h, pbc, n, type, mass, dt, nsteps, t1, t2, t_coup, pos, vel, pe, force, virial, thermo_every,
-                      thermo_host);
+    e->e->run_md(e->e->kBdp, h, pbc, n, type, mass, dt, nsteps, t1, t2, t_coup, pos, vel, pe, force, virial, thermo_every,
+                 thermo_host);
   });
 }
 

@@ -30,9 +30,13 @@ namespace nepmi {
 // contiguous tile range [x * gridDim/8, (x+1) * gridDim/8).  With the brick-major atom order this
 // keeps each XCD's private 4 MiB L2 on one compact slab of the crystal instead of the whole box.
 // gridDim.x is always a multiple of 8 (surplus tiles exit).
+// `frozen` (may be null): device word of the fused run loops; non-zero = a list rebuild is pending and the
+// force path of this (speculatively enqueued) step must not run.
 template <int BLOCK, class Body>
-__global__ void __launch_bounds__(BLOCK) nepmi_kernel(const Body body, const int64_t n)
+__global__ void __launch_bounds__(BLOCK) nepmi_kernel(const Body body, const int64_t n, const int* frozen)
 {
+  if (frozen && *frozen != 0)
+    return;
   const unsigned per_xcd = gridDim.x >> 3;
   const unsigned tile = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
   const int64_t i = (int64_t)tile * BLOCK + threadIdx.x;
@@ -42,9 +46,11 @@ __global__ void __launch_bounds__(BLOCK) nepmi_kernel(const Body body, const int
 
 // Same mapping, for bodies that stage a read-only table (descriptor coefficients) in LDS first.
 template <int BLOCK, class Body>
-__global__ void __launch_bounds__(BLOCK) nepmi_kernel_lds(const Body body, const int64_t n)
+__global__ void __launch_bounds__(BLOCK) nepmi_kernel_lds(const Body body, const int64_t n, const int* frozen)
 {
   extern __shared__ __attribute__((aligned(16))) float nepmi_lds[];
+  if (frozen && *frozen != 0)
+    return;
   body.lds_stage(nepmi_lds, (int)threadIdx.x, BLOCK);
   __syncthreads();
   const unsigned per_xcd = gridDim.x >> 3;
@@ -132,9 +138,11 @@ __global__ void __launch_bounds__(256) nepmi_ann_pack(const ModelD m, const Bufs
 
 template <int MT, int DT, int QB>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ann_mfma_waves(MT, DT, QB))))
-nepmi_ann_mfma(const ModelD m, const Bufs b, const int64_t nchunks)
+nepmi_ann_mfma(const ModelD m, const Bufs b, const int64_t nchunks, const int* frozen)
 {
   extern __shared__ __attribute__((aligned(16))) float nepmi_ann_lds[];
+  if (frozen && *frozen != 0)
+    return;
   const int dim = m.dim, T = m.T, KRP = b.KRP;
   const int KS = (dim + 1) >> 1;
   const int img_floats = (KS * MT + MT * 16 * DT) * 64 + 2 * MT * 32;
@@ -284,9 +292,11 @@ nepmi_ann_mfma(const ModelD m, const Bufs b, const int64_t nchunks)
 // Two adjacent lanes per atom (Body::run_parts<2>): for bodies whose per-atom register table is what
 // limits them to one wavefront per SIMD (angular force).
 template <int BLOCK, class Body>
-__global__ void __launch_bounds__(BLOCK) nepmi_kernel_lds_pairs(const Body body, const int64_t n)
+__global__ void __launch_bounds__(BLOCK) nepmi_kernel_lds_pairs(const Body body, const int64_t n, const int* frozen)
 {
   extern __shared__ __attribute__((aligned(16))) float nepmi_lds_pairs[];
+  if (frozen && *frozen != 0)
+    return;
   body.lds_stage(nepmi_lds_pairs, (int)threadIdx.x, BLOCK);
   __syncthreads();
   const unsigned per_xcd = gridDim.x >> 3;
@@ -300,44 +310,44 @@ __global__ void __launch_bounds__(BLOCK) nepmi_kernel_lds_pairs(const Body body,
 template <int BLOCK>
 __device__ __forceinline__ int block_exclusive_scan(int v, int* total);
 
-// One 512-thread workgroup per brick (RadialTileBody, ForceTileBody): stage the brick's 8x8x8-cell
-// window in LDS, then TWO adjacent lanes per atom of the brick (~205 atoms), each walking every other
-// chunk of the atom's pair list (run_parts<2>): the window limits a CU to two workgroups, so the lane
-// pair is what gives it 16 wavefronts to hide the table gathers and LDS look-ups behind.
+// One 256-thread workgroup per brick (RadialWinBody, ForceWinBody; nep_window.h): stage the brick's
+// 8x8x8-cell window in LDS (cell counts -> block scan -> fixed-point records), then one lane per atom of the
+// brick.  The 16-byte records keep the window at ~30 KB, so four workgroups share a CU (16 wavefronts).
 // XCD-aware brick order as in nepmi_kernel.
-constexpr int kTileParts = 2;
 template <class Body>
-__global__ void __launch_bounds__(kTileThreads) __attribute__((amdgpu_waves_per_eu(Body::kMinWavesPerEu)))
-nepmi_tile_kernel(const Body body, const int64_t nbricks)
+__global__ void __launch_bounds__(kWinThreads) __attribute__((amdgpu_waves_per_eu(Body::kMinWavesPerEu)))
+nepmi_win_kernel(const Body body, const int64_t nbricks)
 {
-  extern __shared__ __attribute__((aligned(16))) char nepmi_tile_lds[];
-  NEPMI_LDS(char)* lds = (NEPMI_LDS(char)*)nepmi_tile_lds;
+  extern __shared__ __attribute__((aligned(16))) char nepmi_win_lds[];
+  NEPMI_LDS(char)* lds = (NEPMI_LDS(char)*)nepmi_win_lds;
+  if (body.skip())
+    return;
   const unsigned per_xcd = gridDim.x >> 3;
   const int64_t wg = (int64_t)(blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
   if (wg >= nbricks)
     return; // the whole workgroup leaves before the first barrier
   const int64_t brick = body.map_brick(wg);
   const int tid = (int)threadIdx.x;
-  body.stage_cells(brick, lds, tid, kTileThreads);
+  body.stage_cells(brick, lds, tid, kWinThreads);
   __syncthreads();
   {
-    static_assert(kTileThreads == 512, "one window cell per thread");
+    static_assert(kWinThreads * 2 == kWinCells, "two window cells per thread");
     NEPMI_LDS(int)* woff = (NEPMI_LDS(int)*)lds;
-    const int v = woff[tid];
+    const int v0 = woff[2 * tid], v1 = woff[2 * tid + 1];
     int total;
-    const int ex = block_exclusive_scan<kTileThreads>(v, &total);
-    woff[tid] = ex;
+    const int ex = block_exclusive_scan<kWinThreads>(v0 + v1, &total);
+    woff[2 * tid] = ex;
+    woff[2 * tid + 1] = ex + v0;
     if (tid == 0)
-      woff[512] = total;
+      woff[kWinCells] = total;
   }
   __syncthreads();
-  body.stage_copy(lds, tid, kTileThreads);
+  body.stage_copy(brick, lds, tid, kWinThreads);
   __syncthreads();
   int64_t a0, a1;
   body.brick_range(brick, a0, a1);
-  const int part = tid % kTileParts;
-  for (int64_t k = a0 + tid / kTileParts; k < a1; k += kTileThreads / kTileParts)
-    body.template compute<kTileParts>(k, part, lds);
+  for (int64_t k = a0 + tid; k < a1; k += kWinThreads)
+    body.compute(brick, k, lds);
 }
 
 constexpr int kScanBlock = 256;
@@ -445,10 +455,12 @@ __device__ __forceinline__ double wave_sum(double v)
 
 __global__ void __launch_bounds__(kThermoBlock) nepmi_thermo_partial(
   int64_t n, const double* __restrict__ mass, const double* __restrict__ pe, const double* __restrict__ vel,
-  const double* __restrict__ virial, double* __restrict__ partial)
+  const double* __restrict__ virial, const signed char* __restrict__ lvl, double* __restrict__ partial)
 {
   double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   for (int64_t i = (int64_t)blockIdx.x * kThermoBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThermoBlock) {
+    if (lvl && lvl[i] < 2)
+      continue; // domain decomposition: ghosts carry no state
     const double m = mass[i];
     const double vx = vel[i], vy = vel[n + i], vz = vel[2 * n + i];
     s[0] += (vx * vx + vy * vy + vz * vz) * m;
@@ -478,8 +490,9 @@ __global__ void __launch_bounds__(kThermoBlock) nepmi_thermo_partial(
   }
 }
 
+// raw != 0: the eight sums as they are (a decomposed run all-reduces them before normalising)
 __global__ void __launch_bounds__(64) nepmi_thermo_final(
-  int nblocks, int64_t n, double volume, const double* __restrict__ partial, double* __restrict__ thermo8)
+  int nblocks, int64_t n, double volume, const double* __restrict__ partial, double* __restrict__ thermo8, int raw)
 {
   // 8 quantities x 8 lanes each; fixed order => deterministic
   const int q = threadIdx.x >> 3, sub = threadIdx.x & 7;
@@ -490,7 +503,9 @@ __global__ void __launch_bounds__(64) nepmi_thermo_final(
   t += __shfl_down(t, 2, 8);
   t += __shfl_down(t, 1, 8);
   if (sub == 0) {
-    if (q == 0)
+    if (raw)
+      thermo8[q] = t;
+    else if (q == 0)
       thermo8[0] = t / (3.0 * (double)n * 8.617343e-5); // K_B, src/utilities/common.cuh:22
     else if (q == 1)
       thermo8[1] = t;
@@ -524,6 +539,30 @@ struct HipBackend {
   bool timed(int slot) const { return timing_mode == 1 ? slot != kSlotMisc : (timing_mode == 2 && slot == kSlotForce); }
   hipEvent_t probe_ev[2] = {nullptr, nullptr};
   bool mfma_on = true; // per-atom ANN on the matrix cores when the model shape allows it
+  // device word the launches of the force path look at first (null: always run); set by the engine around the force
+  // path of a speculatively enqueued step
+  const int* frozen = nullptr;
+  // flag snapshots of the speculative run loops: pinned slots + events
+  static constexpr int kPollRing = 8;
+  int* poll_pinned = nullptr; // [kPollRing][8]
+  hipEvent_t poll_ev[kPollRing] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  void poll_record(int ring, const int* dev_flags)
+  {
+    if (!poll_pinned) {
+      void* p = nullptr;
+      NEPMI_HIP_CHECK(hipHostMalloc(&p, sizeof(int) * 8 * kPollRing, hipHostMallocDefault));
+      poll_pinned = (int*)p;
+      for (int k = 0; k < kPollRing; ++k)
+        NEPMI_HIP_CHECK(hipEventCreateWithFlags(&poll_ev[k], hipEventDisableTiming));
+    }
+    NEPMI_HIP_CHECK(hipMemcpyAsync(poll_pinned + 8 * ring, dev_flags, sizeof(int) * 8, hipMemcpyDeviceToHost, stream));
+    NEPMI_HIP_CHECK(hipEventRecord(poll_ev[ring], stream));
+  }
+  void poll_wait(int ring, int* out8)
+  {
+    NEPMI_HIP_CHECK(hipEventSynchronize(poll_ev[ring]));
+    std::memcpy(out8, poll_pinned + 8 * ring, sizeof(int) * 8);
+  }
 
   void* alloc(size_t bytes)
   {
@@ -643,7 +682,7 @@ struct HipBackend {
     const bool t = timed(slot);
     if (t)
       timer_start(timing->slot[slot]);
-    hipLaunchKernelGGL((nepmi_kernel<BLOCK, Body>), dim3((unsigned)grid), dim3(BLOCK), 0, stream, body, n);
+    hipLaunchKernelGGL((nepmi_kernel<BLOCK, Body>), dim3((unsigned)grid), dim3(BLOCK), 0, stream, body, n, frozen);
     NEPMI_HIP_CHECK(hipGetLastError());
     if (t)
       timer_stop(timing->slot[slot]);
@@ -660,7 +699,7 @@ struct HipBackend {
       NEPMI_HIP_CHECK(hipFuncSetAttribute(                                                          \
         reinterpret_cast<const void*>(&nepmi_ann_mfma<MT, D, QB>), hipFuncAttributeMaxDynamicSharedMemorySize, \
         (int)lds_bytes));                                                                           \
-    hipLaunchKernelGGL((nepmi_ann_mfma<MT, D, QB>), dim3((unsigned)grid), dim3(256), lds_bytes, stream, m, b, nchunks); \
+    hipLaunchKernelGGL((nepmi_ann_mfma<MT, D, QB>), dim3((unsigned)grid), dim3(256), lds_bytes, stream, m, b, nchunks, frozen); \
     break;
     switch (DT) {
       NEPMI_ANN_CASE(1)
@@ -718,7 +757,7 @@ struct HipBackend {
   void set_mfma(bool on) { mfma_on = on; }
 
   template <class Body>
-  void launch_tile(int slot, int64_t nbricks, const Body& body)
+  void launch_win(int slot, int64_t nbricks, const Body& body)
   {
     if (nbricks <= 0)
       return;
@@ -726,12 +765,12 @@ struct HipBackend {
     const size_t lds_bytes = ((size_t)body.lds_bytes() + 15) / 16 * 16;
     if (lds_bytes > 64 * 1024)
       NEPMI_HIP_CHECK(hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&nepmi_tile_kernel<Body>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        reinterpret_cast<const void*>(&nepmi_win_kernel<Body>), hipFuncAttributeMaxDynamicSharedMemorySize,
         (int)lds_bytes));
     const bool t = timed(slot);
     if (t)
       timer_start(timing->slot[slot]);
-    hipLaunchKernelGGL((nepmi_tile_kernel<Body>), dim3((unsigned)grid), dim3(kTileThreads), lds_bytes, stream, body, nbricks);
+    hipLaunchKernelGGL((nepmi_win_kernel<Body>), dim3((unsigned)grid), dim3(kWinThreads), lds_bytes, stream, body, nbricks);
     NEPMI_HIP_CHECK(hipGetLastError());
     if (t)
       timer_stop(timing->slot[slot]);
@@ -751,7 +790,7 @@ struct HipBackend {
     const bool t = timed(slot);
     if (t)
       timer_start(timing->slot[slot]);
-    hipLaunchKernelGGL((nepmi_kernel_lds<BLOCK, Body>), dim3((unsigned)grid), dim3(BLOCK), lds_bytes, stream, body, n);
+    hipLaunchKernelGGL((nepmi_kernel_lds<BLOCK, Body>), dim3((unsigned)grid), dim3(BLOCK), lds_bytes, stream, body, n, frozen);
     NEPMI_HIP_CHECK(hipGetLastError());
     if (t)
       timer_stop(timing->slot[slot]);
@@ -772,7 +811,7 @@ struct HipBackend {
     if (t)
       timer_start(timing->slot[slot]);
     hipLaunchKernelGGL((nepmi_kernel_lds_pairs<BLOCK, Body>), dim3((unsigned)grid), dim3(BLOCK), lds_bytes, stream,
-                       body, n);
+                       body, n, frozen);
     NEPMI_HIP_CHECK(hipGetLastError());
     if (t)
       timer_stop(timing->slot[slot]);
@@ -792,14 +831,16 @@ struct HipBackend {
 
   void thermo(
     int slot, int64_t n, double volume, const double* mass, const double* pe, const double* vel,
-    const double* virial, double* thermo8, double* scratch)
+    const double* virial, double* thermo8, double* scratch, const signed char* lvl = nullptr, int raw = 0,
+    int64_t n_norm = 0)
   {
     int64_t nb = (n + kThermoBlock - 1) / kThermoBlock;
     if (nb > kThermoMaxBlocks)
       nb = kThermoMaxBlocks;
     hipLaunchKernelGGL(
-      nepmi_thermo_partial, dim3((unsigned)nb), dim3(kThermoBlock), 0, stream, n, mass, pe, vel, virial, scratch);
-    hipLaunchKernelGGL(nepmi_thermo_final, dim3(1), dim3(64), 0, stream, (int)nb, n, volume, scratch, thermo8);
+      nepmi_thermo_partial, dim3((unsigned)nb), dim3(kThermoBlock), 0, stream, n, mass, pe, vel, virial, lvl, scratch);
+    hipLaunchKernelGGL(nepmi_thermo_final, dim3(1), dim3(64), 0, stream, (int)nb, n_norm > 0 ? n_norm : n, volume, scratch,
+                       thermo8, raw);
     NEPMI_HIP_CHECK(hipGetLastError());
     (void)slot;
   }

@@ -6,7 +6,9 @@
 // (neighbor.cu:741-833), NEP::compute_large_box (nep.cu:996-1137).
 #pragma once
 #include "nep_bodies.h"
+#include "nep_md.h"
 #include "nep_model.h"
+#include "nep_window.h"
 #include "tersoff_bodies.h"
 
 #include <cmath>
@@ -97,8 +99,14 @@ public:
     std::memset(&b_, 0, sizeof(b_));
     std::memset(&md_, 0, sizeof(md_));
     std::memset(&box_, 0, sizeof(box_));
-    upload_model();
-    allocate();
+    try {
+      upload_model();
+      allocate();
+    } catch (...) { // no destructor runs for a throwing constructor
+      for (void* p : allocs_)
+        be_.free(p);
+      throw;
+    }
   }
 
   ~EngineT()
@@ -130,6 +138,23 @@ public:
     const double h9[9], const int pbc[3], int64_t n, const int* type, const double* pos,
     const signed char* level, double* pe, double* force, double* virial)
   {
+    if (!prepare_lists(h9, pbc, n, type, pos, level)) { // small box: NEP::compute -> compute_small_box
+      small_box_compute(type, pos);
+      scatter_add(pe, force, virial);
+      ++num_compute;
+      return;
+    }
+    force_kernels(kPhaseAll);
+    scatter_add(pe, force, virial);
+    ++num_compute;
+  }
+
+  // Neighbor::find_neighbor_global (neighbor.cu:741-800): gather the caller's positions into internal order,
+  // run the skin check, rebuild the Verlet lists when needed.  Returns false when the box takes the small-box
+  // branch (no lists kept).
+  bool prepare_lists(
+    const double h9[9], const int pbc[3], int64_t n, const int* type, const double* pos, const signed char* level)
+  {
     split_pending_ = false;
     if (n < 1 || n > cap_)
       throw EngineError{-4, "number of atoms exceeds the engine's capacity"};
@@ -143,11 +168,9 @@ public:
       throw EngineError{-7, "Tersoff-1989: box thickness <= 2.5 (rc + skin) in a periodic direction is not supported"};
     if (is_small_box(box)) { // NEP::compute -> compute_small_box (nep.cu:1356-1389)
       box_ = box;
-      small_box_compute(type, pos, pe, force, virial);
       have_list_ = false;
       last_small_ = true;
-      ++num_compute;
-      return;
+      return false;
     }
     last_small_ = false;
     if (have_list_ && !same_box(box))
@@ -157,7 +180,7 @@ public:
       be_.memset(b_.flags + kFlagMoved, 0, sizeof(int));
       CheckGatherBody cg{box_, b_, pos, 0};
       be_.template launch<128>(kSlotGather, N_, cg);
-      if (!external_skin_) { // the one host round trip of a step (neighbor.cu:752 does the same)
+      if (!external_skin_) { // the one host round trip of a per-call force evaluation (neighbor.cu:752 does the same)
         int flags[kNumFlags];
         be_.d2h(flags, b_.flags, sizeof(flags));
         check_overflow(flags);
@@ -167,8 +190,13 @@ public:
     }
     if (need_rebuild)
       rebuild(type, pos);
-    force_kernels(pe, force, virial, kPhaseAll);
-    ++num_compute;
+    return true;
+  }
+
+  // Potential::compute adds to the caller's arrays: caller[perm[k]] += internal[k]
+  void scatter_add(double* pe, double* force, double* virial)
+  {
+    be_.template launch<256>(kSlotMisc, N_, ScatterAddBody{b_, pe, force, virial});
   }
 
   // Split form for a domain-decomposed host that overlaps its ghost exchange with compute:
@@ -198,7 +226,7 @@ public:
     be_.memset(b_.flags + kFlagMoved, 0, sizeof(int));
     CheckGatherBody cg{box_, b_, pos, 1};
     be_.template launch<128>(kSlotGather, N_, cg);
-    force_kernels(nullptr, nullptr, nullptr, kPhaseInterior);
+    force_kernels(kPhaseInterior);
     split_pending_ = true;
     return true;
   }
@@ -225,10 +253,11 @@ public:
     }
     if (moved) {
       rebuild(type, pos);
-      force_kernels(pe, force, virial, kPhaseAll);
+      force_kernels(kPhaseAll);
     } else {
-      force_kernels(pe, force, virial, kPhaseBoundary);
+      force_kernels(kPhaseBoundary);
     }
+    scatter_add(pe, force, virial);
     ++num_compute;
   }
 
@@ -298,35 +327,6 @@ public:
     }
   }
 
-  // Run::perform_a_run for `ensemble nvt_ber T1 T2 Tcoup` (Ensemble_BER, ensemble_ber.cu:195-235;
-  // target temperature ramp of Integrate::compute2, integrate.cu:341-344)
-  void run_nvt_ber(
-    const double h9[9], const int pbc[3], int64_t n, const int* type, const double* mass, double dt,
-    int64_t nsteps, double t1, double t2, double tcoup, double* pos, double* vel, double* pe, double* force,
-    double* virial, int64_t thermo_every, double* thermo_host)
-  {
-    BoxD box;
-    box_from_h9(h9, pbc, box);
-    int64_t rec = 0;
-    for (int64_t step = 0; step < nsteps; ++step) {
-      const double target = t1 + (t2 - t1) * ((double)step / (double)nsteps);
-      velocity_verlet(true, n, dt, mass, force, pos, vel, &box);
-      zero_properties(n, pe, force, virial);
-      potential_compute(h9, pbc, n, type, pos, pe, force, virial);
-      velocity_verlet(false, n, dt, mass, force, pos, vel, nullptr);
-      find_thermo(n, box.volume, mass, pe, vel, virial, thermo_dev_);
-      berendsen(n, target, 1.0 / tcoup, thermo_dev_, vel);
-      if (thermo_every > 0 && (step + 1) % thermo_every == 0) {
-        be_.d2h(thermo_host + 8 * rec, thermo_dev_, 8 * sizeof(double));
-        ++rec;
-      }
-    }
-    be_.sync();
-    int flags[kNumFlags];
-    be_.d2h(flags, b_.flags, sizeof(flags));
-    check_overflow(flags);
-  }
-
   // Ensemble_NHC (ensemble_nhc.cu): chain state in caller-owned device memory (kNhcStateSize doubles)
   void nhc_init(int64_t n, double temperature, double t_coup, double dt, double* state)
   {
@@ -337,39 +337,6 @@ public:
   {
     be_.template launch<64>(kSlotMisc, 1, NhcChainBody{n, temperature, 0.5 * dt, thermo8, state});
     be_.template launch<256>(kSlotMisc, n, ScaleVelocityBody{n, state + 3 * kNhcLinks, vel});
-  }
-
-  // Run::perform_a_run for `ensemble nvt_nhc T1 T2 Tcoup` (integrate_nvt_nhc_1/2, ensemble_nhc.cu:166-232)
-  void run_nvt_nhc(
-    const double h9[9], const int pbc[3], int64_t n, const int* type, const double* mass, double dt,
-    int64_t nsteps, double t1, double t2, double tcoup, double* pos, double* vel, double* pe, double* force,
-    double* virial, int64_t thermo_every, double* thermo_host)
-  {
-    BoxD box;
-    box_from_h9(h9, pbc, box);
-    if (!nhc_dev_)
-      nhc_dev_ = dalloc<double>(kNhcStateSize);
-    nhc_init(n, t1, tcoup, dt, nhc_dev_);
-    int64_t rec = 0;
-    for (int64_t step = 0; step < nsteps; ++step) {
-      const double target = t1 + (t2 - t1) * ((double)step / (double)nsteps);
-      find_thermo(n, box.volume, mass, pe, vel, virial, thermo_dev_);
-      nhc_half_step(n, target, dt, thermo_dev_, nhc_dev_, vel);
-      velocity_verlet(true, n, dt, mass, force, pos, vel, &box);
-      zero_properties(n, pe, force, virial);
-      potential_compute(h9, pbc, n, type, pos, pe, force, virial);
-      velocity_verlet(false, n, dt, mass, force, pos, vel, nullptr);
-      find_thermo(n, box.volume, mass, pe, vel, virial, thermo_dev_);
-      nhc_half_step(n, target, dt, thermo_dev_, nhc_dev_, vel);
-      if (thermo_every > 0 && (step + 1) % thermo_every == 0) {
-        be_.d2h(thermo_host + 8 * rec, thermo_dev_, 8 * sizeof(double));
-        ++rec;
-      }
-    }
-    be_.sync();
-    int flags[kNumFlags];
-    be_.d2h(flags, b_.flags, sizeof(flags));
-    check_overflow(flags);
   }
 
   // ---- Bussi-Donadio-Parrinello stochastic velocity rescaling (Ensemble_BDP, ensemble_bdp.cu:71-104;
@@ -454,73 +421,228 @@ public:
            2.0 * rr * std::sqrt(kk * sigma / ndeg * (1.0 - factor) * factor);
   }
   // integrate_nvt_bdp_2 after the velocity update: T = thermo8[0] (device) -> host, draw, rescale
+  double bdp_factor(int64_t n_total, double T, double temperature, double t_coup)
+  {
+    const int ndeg = 3 * (int)n_total;
+    const double ek = T * ndeg * kBoltzmann * 0.5;
+    const double sigma = ndeg * kBoltzmann * temperature * 0.5;
+    return std::sqrt(bdp_resample(ek, sigma, ndeg, t_coup) / ek);
+  }
   double bdp_scale(int64_t n, double temperature, double t_coup, const double* thermo8, double* vel)
   {
     double T = 0.0;
     be_.d2h(&T, thermo8, sizeof(double));
-    const int ndeg = 3 * (int)n;
-    const double ek = T * ndeg * kBoltzmann * 0.5;
-    const double sigma = ndeg * kBoltzmann * temperature * 0.5;
-    const double factor = std::sqrt(bdp_resample(ek, sigma, ndeg, t_coup) / ek);
+    const double factor = bdp_factor(n, T, temperature, t_coup);
     be_.template launch<256>(kSlotMisc, n, ScaleVelocityConstBody{n, factor, vel});
     return factor;
   }
 
-  // Run::perform_a_run for `ensemble nvt_bdp T1 T2 Tcoup` (Ensemble_BDP::compute1/compute2)
-  void run_nvt_bdp(
-    const double h9[9], const int pbc[3], int64_t n, const int* type, const double* mass, double dt,
+  // ---------------------------------------------------------------------------------------------
+  // Fused run loops == Run::perform_a_run (src/main_gpumd/run.cu:250-318) for `ensemble nve`,
+  // `nvt_ber` (ensemble_ber.cu:195-235), `nvt_nhc` (ensemble_nhc.cu:166-232) and `nvt_bdp`
+  // (ensemble_bdp.cu:71-104); target temperature ramp of Integrate::compute2 (integrate.cu:341-344).
+  //
+  // While the loop runs the state lives in internal order (nep_md.h) and the steps are enqueued
+  // speculatively: the skin check is a device-side word that freezes the state when it fires; the host looks
+  // at it only every kPollEvery steps (and at thermo records), rebuilds the lists and resumes from the frozen
+  // step.  The caller's arrays are read at entry and written at exit.
+  // ---------------------------------------------------------------------------------------------
+  enum Ensemble { kNve = 0, kBer = 1, kNhc = 2, kBdp = 3 };
+  static constexpr int kPollEvery = 4; // steps between two snapshots of the device flags
+  static constexpr int kPollDepth = 2; // snapshots in flight: the host runs 8-12 steps ahead of the device
+
+  void run_md(
+    int ens, const double h9[9], const int pbc[3], int64_t n, const int* type, const double* mass, double dt,
     int64_t nsteps, double t1, double t2, double tcoup, double* pos, double* vel, double* pe, double* force,
     double* virial, int64_t thermo_every, double* thermo_host)
   {
     BoxD box;
     box_from_h9(h9, pbc, box);
-    int64_t rec = 0;
-    for (int64_t step = 0; step < nsteps; ++step) {
-      const double target = t1 + (t2 - t1) * ((double)step / (double)nsteps);
-      velocity_verlet(true, n, dt, mass, force, pos, vel, &box);
-      zero_properties(n, pe, force, virial);
-      potential_compute(h9, pbc, n, type, pos, pe, force, virial);
-      velocity_verlet(false, n, dt, mass, force, pos, vel, nullptr);
-      find_thermo(n, box.volume, mass, pe, vel, virial, thermo_dev_);
-      bdp_scale(n, target, tcoup, thermo_dev_, vel);
-      if (thermo_every > 0 && (step + 1) % thermo_every == 0) {
-        be_.d2h(thermo_host + 8 * rec, thermo_dev_, 8 * sizeof(double));
-        ++rec;
-      }
+    if (n < 1 || n > cap_)
+      throw EngineError{-4, "number of atoms exceeds the engine's capacity"};
+    if (is_small_box(box) && model_.kind == 0) {
+      run_md_small_box(ens, h9, pbc, n, type, mass, dt, nsteps, t1, t2, tcoup, pos, vel, pe, force, virial, thermo_every,
+                       thermo_host);
+      return;
     }
-    be_.sync();
+    if (nsteps <= 0)
+      return;
+    // entry: lists valid for the caller's positions, state imported
+    prepare_lists(h9, pbc, n, type, pos, nullptr);
+    resident_alloc();
+    resident_import(vel, mass, pe, force, virial);
+    if (ens == kNhc) {
+      if (!nhc_dev_)
+        nhc_dev_ = dalloc<double>(kNhcStateSize);
+      nhc_init(n, t1, tcoup, dt, nhc_dev_);
+    }
+    if (!factor_dev_)
+      factor_dev_ = dalloc<double>(1);
+    const int* frozen = b_.flags + kFlagMoved;
+    be_.memset(b_.flags + kFlagMoved, 0, sizeof(int));
+    const int64_t compute0 = num_compute;
+    auto tag_of = [](int64_t step) { return (int)(step % 1000000000) + 1; };
+    auto target_of = [&](int64_t step) { return t1 + (t2 - t1) * ((double)step / (double)nsteps); };
+    auto thermo_now = [&]() {
+      be_.thermo(kSlotThermo, N_, box.volume, b_.mi, b_.fo, b_.vi, b_.fo + (int64_t)kOutW * N_, thermo_dev_, thermo_scratch_);
+    };
+    auto nhc_half = [&](double target) { // one thermostat half-step on the internal velocities
+      thermo_now();
+      be_.template launch<64>(kSlotMisc, 1, NhcChainBody{N_, target, 0.5 * dt, thermo_dev_, nhc_dev_, frozen});
+      be_.template launch<256>(kSlotVV, N_, ResidentScaleBody{b_, nhc_dev_ + 3 * kNhcLinks, 1.0});
+    };
+    struct Snapshot {
+      int ring;
+    };
+    std::vector<Snapshot> pending;
+    int ring_next = 0;
+    // a trip of the skin check at (0-based) step m, found at a sync or in a snapshot: the device state is frozen
+    // right after that step's first half-step; rebuild the lists on it
+    auto handle_trip = [&](int moved_tag) -> int64_t {
+      be_.sync();
+      pending.clear();
+      resident_export(pos, vel, nullptr, nullptr, nullptr);
+      rebuild(type, pos);
+      resident_import(vel, mass, nullptr, nullptr, nullptr);
+      return (int64_t)moved_tag - 1;
+    };
     int flags[kNumFlags];
+    auto sync_and_check = [&]() -> int { // returns the trip tag (0: none)
+      be_.sync();
+      pending.clear();
+      be_.d2h(flags, b_.flags, sizeof(flags));
+      check_overflow(flags);
+      return flags[kFlagMoved];
+    };
+
+    int64_t step = 0;
+    bool resume_after_vv1 = false; // the pre-force phase of `step` has already run (replay after a rebuild)
+    bool kick2_pending = false;    // NVE: the second half-kick of step - 1 rides on this step's first pass
+    while (step < nsteps) {
+      const double target = target_of(step);
+      if (!resume_after_vv1) {
+        if (ens == kNhc)
+          nhc_half(target); // integrate_nvt_nhc_1: thermostat half-step before the first velocity-Verlet half
+        be_.template launch<256>(kSlotVV, N_, ResidentStepBody{box_, b_, dt, kick2_pending ? 1 : 0, 1, tag_of(step)});
+      }
+      resume_after_vv1 = false;
+      kick2_pending = false;
+      force_kernels(kPhaseAll, frozen);
+      const bool record = thermo_every > 0 && (step + 1) % thermo_every == 0;
+      const bool last = step + 1 == nsteps;
+      bool need_sync = record || last;
+      if (ens == kNve && !record && !last) {
+        kick2_pending = true; // fused into the next step's pass over the atoms
+      } else {
+        be_.template launch<256>(kSlotVV, N_, ResidentStepBody{box_, b_, dt, 1, 0, 0});
+        if (ens == kBer) {
+          thermo_now();
+          if (1.0 / tcoup > 1.0e-5) { // ensemble_ber.cu:223
+            be_.template launch<64>(kSlotMisc, 1, BerendsenFactorBody{b_.flags, target, 1.0 / tcoup, thermo_dev_, factor_dev_});
+            be_.template launch<256>(kSlotVV, N_, ResidentScaleBody{b_, factor_dev_, 1.0});
+          }
+        } else if (ens == kNhc) {
+          nhc_half(target);
+        } else if (ens == kBdp) {
+          thermo_now();
+          need_sync = true; // the noise is drawn on the host from the kinetic energy, as in the reference
+        } else if (record) {
+          thermo_now();
+        }
+      }
+      int trip = 0;
+      if (need_sync) {
+        trip = sync_and_check();
+        if (!trip) {
+          if (ens == kBdp) {
+            double T = 0.0;
+            be_.d2h(&T, thermo_dev_, sizeof(double));
+            be_.template launch<256>(kSlotVV, N_, ResidentScaleBody{b_, nullptr, bdp_factor(N_, T, target, tcoup)});
+          }
+          if (record)
+            be_.d2h(thermo_host + 8 * ((step + 1) / thermo_every - 1), thermo_dev_, 8 * sizeof(double));
+        }
+      } else if ((step + 1) % kPollEvery == 0) {
+        be_.poll_record(ring_next, b_.flags);
+        pending.push_back(Snapshot{ring_next});
+        ring_next = (ring_next + 1) % 8;
+        if ((int)pending.size() > kPollDepth) {
+          int snap[8];
+          be_.poll_wait(pending.front().ring, snap);
+          pending.erase(pending.begin());
+          if (snap[kFlagMoved])
+            trip = sync_and_check();
+        }
+      }
+      if (trip) {
+        step = handle_trip(trip);
+        resume_after_vv1 = true;
+        continue;
+      }
+      ++step;
+    }
+    num_compute = compute0 + nsteps;
+    resident_export(pos, vel, pe, force, virial);
+    be_.sync();
     be_.d2h(flags, b_.flags, sizeof(flags));
     check_overflow(flags);
   }
 
-  // Run::perform_a_run for `ensemble nve` (run.cu:250-318)
-  void run_nve(
-    const double h9[9], const int pbc[3], int64_t n, const int* type, const double* mass, double dt,
-    int64_t nsteps, double* pos, double* vel, double* pe, double* force, double* virial,
-    int64_t thermo_every, double* thermo_host)
+  // internal-order integrator state (allocated at the first fused run)
+  void resident_alloc()
+  {
+    if (!b_.vi) {
+      b_.vi = dalloc<double>(3 * cap_);
+      b_.mi = dalloc<double>(cap_);
+    }
+    if (unwrapped_ && !ui_alloc_)
+      ui_alloc_ = dalloc<double>(3 * cap_);
+    b_.ui = unwrapped_ ? ui_alloc_ : nullptr;
+  }
+  void resident_import(const double* vel, const double* mass, const double* pe, const double* force, const double* virial)
+  {
+    be_.template launch<256>(kSlotMisc, N_, ImportStateBody{b_, vel, mass, pe, force, virial, unwrapped_});
+  }
+  void resident_export(double* pos, double* vel, double* pe, double* force, double* virial, int owned_only = 0)
+  {
+    be_.template launch<256>(kSlotMisc, N_, ExportStateBody{b_, pos, vel, pe, force, virial, unwrapped_, owned_only});
+  }
+
+  // The small-box branch has no Verlet lists and no internal order (every call rebuilds all image pairs): its run
+  // loop is the plain sequence of the per-call entry points on the caller's arrays.
+  void run_md_small_box(
+    int ens, const double h9[9], const int pbc[3], int64_t n, const int* type, const double* mass, double dt,
+    int64_t nsteps, double t1, double t2, double tcoup, double* pos, double* vel, double* pe, double* force,
+    double* virial, int64_t thermo_every, double* thermo_host)
   {
     BoxD box;
     box_from_h9(h9, pbc, box);
+    if (ens == kNhc) {
+      if (!nhc_dev_)
+        nhc_dev_ = dalloc<double>(kNhcStateSize);
+      nhc_init(n, t1, tcoup, dt, nhc_dev_);
+    }
     int64_t rec = 0;
-    bool seam_done = false; // the previous iteration already did this step's vv1 + wrap + zero
     for (int64_t step = 0; step < nsteps; ++step) {
-      if (!seam_done) {
-        velocity_verlet(true, n, dt, mass, force, pos, vel, &box); // vv1 + gpu_apply_pbc
-        zero_properties(n, pe, force, virial);
-      }
-      potential_compute(h9, pbc, n, type, pos, pe, force, virial);
-      const bool record = thermo_every > 0 && (step + 1) % thermo_every == 0;
-      seam_done = !record && step + 1 < nsteps;
-      if (seam_done) {
-        // vv2 of this step + vv1/wrap/zero of the next in one pass (nothing reads v in between)
-        VerletSeamBody body{n, dt, box, mass, force, pos, vel, pe, virial, unwrapped_};
-        be_.template launch<256>(kSlotVV, n, body);
-        continue;
-      }
-      velocity_verlet(false, n, dt, mass, force, pos, vel, nullptr);
-      if (record) {
+      const double target = t1 + (t2 - t1) * ((double)step / (double)nsteps);
+      if (ens == kNhc) {
         find_thermo(n, box.volume, mass, pe, vel, virial, thermo_dev_);
+        nhc_half_step(n, target, dt, thermo_dev_, nhc_dev_, vel);
+      }
+      velocity_verlet(true, n, dt, mass, force, pos, vel, &box);
+      zero_properties(n, pe, force, virial);
+      potential_compute(h9, pbc, n, type, pos, pe, force, virial);
+      velocity_verlet(false, n, dt, mass, force, pos, vel, nullptr);
+      const bool record = thermo_every > 0 && (step + 1) % thermo_every == 0;
+      if (ens != kNve || record)
+        find_thermo(n, box.volume, mass, pe, vel, virial, thermo_dev_);
+      if (ens == kBer)
+        berendsen(n, target, 1.0 / tcoup, thermo_dev_, vel);
+      else if (ens == kNhc)
+        nhc_half_step(n, target, dt, thermo_dev_, nhc_dev_, vel);
+      else if (ens == kBdp)
+        bdp_scale(n, target, tcoup, thermo_dev_, vel);
+      if (record) {
         be_.d2h(thermo_host + 8 * rec, thermo_dev_, 8 * sizeof(double));
         ++rec;
       }
@@ -541,7 +663,7 @@ public:
       // the per-step radial/angular lists are read off the pair records; in tile mode 2 the force
       // path does not write them, so rerun the (idempotent) radial pass with record writing on
       if (which != 2 && !records_valid_ && have_list_)
-        force_kernels(nullptr, nullptr, nullptr, kPhaseRecords);
+        force_kernels(kPhaseRecords);
       ExportListsBody body{b_, which, nn, nl, ld};
       be_.template launch<64>(kSlotMisc, N_, body);
     }
@@ -694,6 +816,9 @@ private:
       b_.ann_img = as.ok ? dalloc<float>(as.img_floats * m.num_types) : nullptr;
       be_.ann_prepare(md_, b_);
       b_.pe_i = dalloc<float>(N);
+      b_.MN_rad = m.MN_radial;
+      b_.ccode = dalloc<unsigned short>((size_t)b_.MN_rad * N);
+      b_.aidx = dalloc<unsigned short>((size_t)b_.MN_acomp * N);
     } else { // Tersoff-1989: Tersoff1989::Tersoff1989 allocations (tersoff1989.cu:141-149)
       tb_.rec = dalloc<D4>((size_t)b_.MN_ang * N);
       tb_.bb = dalloc<double>((size_t)b_.MN_ang * N);
@@ -707,6 +832,7 @@ private:
       }
       tp_.rc_sq = (float)(m.rc_radial_max * m.rc_radial_max);
     }
+    b_.fo = dalloc<double>((size_t)kOutPlanes * N);
     b_.zbl = dalloc<float>(m.zbl_enabled ? (size_t)10 * N : 1);
     b_.lvl = dalloc<signed char>(N);
     b_.tperm = dalloc<int>(N);
@@ -744,13 +870,16 @@ private:
     return false;
   }
 
-  void small_box_compute(const int* type, const double* pos, double* pe, double* force, double* virial)
+  void small_box_compute(const int* type, const double* pos)
   {
     const double rc = model_.rc_radial_max;
+    // the reference refuses a box that is thin in one periodic direction and very thick in another
+    // (get_expanded_box, nep.cu:1316-1324): "The box has a thickness < 2.5 radial cutoffs in a periodic direction
+    // and is too large in another"
     for (int d = 0; d < 3; ++d)
-      if (box_.thickness[d] > 10.0 * rc && is_small_box(box_)) {
-        // same refusal as the reference (nep.cu:1316-1324)
-      }
+      if (box_.thickness[d] > 10.0 * rc)
+        throw EngineError{-7, "small-box branch: a periodic thickness <= 2.5 (rc+1) while another direction is thicker than "
+                              "10 rc (the reference refuses this box too, nep.cu:1316-1324)"};
     if (N_ > 20000)
       throw EngineError{-7, "small-box branch (a periodic thickness <= 2.5 (rc+1)) is limited to 20000 atoms"};
     if (!b_.sh_ang)
@@ -782,7 +911,7 @@ private:
     be_.begin_region(kRegionForce);
     be_.template launch<64>(kSlotRadial, N_, sb);
     be_.template launch<64>(kSlotMisc, N_, ReverseSlotsSmallBody{b_});
-    small_force_kernels(pe, force, virial);
+    small_force_kernels();
     be_.end_region(kRegionForce);
     int flags[kNumFlags];
     be_.d2h(flags, b_.flags, sizeof(flags));
@@ -790,24 +919,24 @@ private:
   }
 
   template <class S>
-  void small_force_kernels_shape(double* pe, double* force, double* virial)
+  void small_force_kernels_shape()
   {
     be_.template launch<64>(kSlotRadial, N_, RadialFromRecordsBody<S>{md_, b_});
     launch_angular_desc<S>();
     be_.template launch_ann<S>(kSlotAnn, N_, md_, b_, false); // identity work order, no type groups
     launch_angular_force<S>();
-    be_.template launch<64>(kSlotForce, N_, ForceAssembleBody<S>{md_, b_, pe, force, virial});
+    be_.template launch<64>(kSlotForce, N_, ForceAssembleBody<S>{md_, b_});
   }
 
-  void small_force_kernels(double* pe, double* force, double* virial)
+  void small_force_kernels()
   {
     switch (shape_) {
-      case 1: small_force_kernels_shape<S_PbTeA>(pe, force, virial); break;
-      case 2: small_force_kernels_shape<S_PbTeB>(pe, force, virial); break;
-      case 3: small_force_kernels_shape<S_C2022>(pe, force, virial); break;
-      case 4: small_force_kernels_shape<S_UNEP>(pe, force, virial); break;
-      case 5: small_force_kernels_shape<S_BZO>(pe, force, virial); break;
-      default: small_force_kernels_shape<ShapeGeneric>(pe, force, virial); break;
+      case 1: small_force_kernels_shape<S_PbTeA>(); break;
+      case 2: small_force_kernels_shape<S_PbTeB>(); break;
+      case 3: small_force_kernels_shape<S_C2022>(); break;
+      case 4: small_force_kernels_shape<S_UNEP>(); break;
+      case 5: small_force_kernels_shape<S_BZO>(); break;
+      default: small_force_kernels_shape<ShapeGeneric>(); break;
     }
   }
 
@@ -908,6 +1037,8 @@ private:
     be_.memset(b_.cell_fill, 0, sizeof(int) * ncell);
     be_.memset(b_.cell_ghost, 0, sizeof(int) * ncell);
     be_.memset(b_.flags + kFlagMaxSkin, 0, 2 * sizeof(int));
+    be_.memset(b_.flags + kFlagMoved, 0, sizeof(int)); // the rebuild this flag asked for is happening
+    be_.memset(b_.flags + kFlagOutlier, 0, sizeof(int));
     be_.begin_region(kRegionRebuild);
     be_.template launch<256>(kSlotMisc, N_, BinAtomsBody{box_, b_, pos});
     be_.exclusive_scan(b_.cell_count, ncell + 1, scan_scratch_);
@@ -938,11 +1069,36 @@ private:
     num_boundary_bricks_ = flags[kFlagNumBoundary];
     // LDS-window radial pass: unique window cells (>= 8 cells per periodic direction), 7-bit rank
     // in cell, window fits the LDS budget
-    tile_ok_ = use_tiles_ && model_.kind == 0 && flags[kFlagMaxCell] <= 127 && flags[kFlagMaxWindow] <= 5000;
+    tile_ok_ = use_tiles_ && model_.kind == 0 && flags[kFlagMaxCell] <= 127 && flags[kFlagMaxWindow] <= kWinMaxAtoms &&
+               !flags[kFlagOutlier];
     for (int d = 0; d < 3; ++d)
       if (box_.pbc[d] && nb[d] < 8)
         tile_ok_ = false;
-    tile_.wmax = (flags[kFlagMaxWindow] + 63) / 64 * 64;
+    win_.wmax = (flags[kFlagMaxWindow] + 63) / 64 * 64;
+    {
+      // fixed-point frame of the windows: +-R covers the 8x8x8-cell window seen from its centre (the widened edge
+      // cells of an open direction and half a cell of outliers included) plus the drift between two rebuilds
+      double R = 0.0, lmax = 0.0;
+      for (int c = 0; c < 3; ++c) {
+        double r = 0.0;
+        for (int d = 0; d < 3; ++d)
+          r += 6.5 * std::fabs(box_.h[3 * c + d]) / nb[d];
+        R = r > R ? r : R;
+      }
+      R += 2.0;
+      for (int d = 0; d < 3; ++d) {
+        const double len = std::sqrt(box_.h[d] * box_.h[d] + box_.h[3 + d] * box_.h[3 + d] + box_.h[6 + d] * box_.h[6 + d]);
+        if (box_.pbc[d] && len > lmax)
+          lmax = len;
+        wing_.cell_frac[d] = 1.0 / (box_.thickness[d] * b_.rc_inv_cell);
+      }
+      wing_.inv_unit = 1073741824.0 / R;
+      wing_.unit = (float)(R / 1073741824.0);
+      wing_.unit2 = wing_.unit * wing_.unit;
+      // The reference forms r12 in FP32 with an FP32 minimum image: across a periodic face that carries rounding of
+      // the order of ulp(box length).  A list decision closer to a cutoff than this band is retaken exactly.
+      wing_.band = (float)(1.0e-4 + 4.0 * model_.rc_radial_max * lmax * 1.2e-7);
+    }
     have_list_ = true;
     ++num_rebuild;
   }
@@ -1002,15 +1158,16 @@ private:
 
 public:
   void invalidate() { have_list_ = false; }
-  // 0: no LDS-window kernels; 1: radial pass only (pair records written for the force assembly);
-  // 2 (default): radial pass and force assembly both work from an LDS position window
+  // 0: no LDS-window kernels (gather kernels + pair records); anything else (default): the radial pass and the
+  // force assembly both work from the LDS position window.  A counted rule, never a timing: the same input
+  // always runs the same kernels.
   void set_tile_mode(int mode)
   {
     use_tiles_ = mode != 0;
     tile_mode_ = mode;
     have_list_ = false;
   }
-  int tile_mode_in_use() const { return tile_ok_ ? effective_tile_mode() : 0; }
+  int tile_mode_in_use() const { return tile_ok_ ? 2 : 0; }
   bool tiles_active() const { return tile_ok_; }
   void set_use_mfma(bool on) { be_.set_mfma(on); }
   // The caller runs the skin policy itself (a domain-decomposed host votes on it globally and calls
@@ -1041,91 +1198,62 @@ public:
 
 private:
   template <class S>
-  void force_kernels_shape(double* pe, double* force, double* virial, int phase)
+  void force_kernels_shape(int phase, const int* frozen)
   {
-    // tile mode 2: the force assembly rebuilds the pair geometry from its own LDS window, so the
-    // radial pass writes no pair records (the compact angular records are written in any case)
-    const bool force_tile = tile_ok_ && effective_tile_mode() >= 2;
-    const int records = force_tile ? 0 : 1;
+    const WinStage ws{box_, b_, win_, wing_};
     if (phase == kPhaseRecords) { // diagnostics: materialise the pair records of the current positions
-      be_.launch_tile(kSlotMisc, num_bricks_, RadialTileBody<S>{box_, md_, b_, tile_, -1, 1});
+      be_.template launch<64>(kSlotMisc, N_, RadialDescBody<S>{box_, md_, b_, 1});
       records_valid_ = true;
       return;
     }
-    if (phase != kPhaseInterior)
-      records_valid_ = records != 0;
     if (phase == kPhaseInterior) { // radial pass of the bricks whose window holds no ghost
-      be_.launch_tile(kSlotRadial, num_bricks_ - num_boundary_bricks_, RadialTileBody<S>{box_, md_, b_, tile_, 0, records});
+      be_.launch_win(kSlotRadial, num_bricks_ - num_boundary_bricks_, RadialWinBody<S>{ws, md_, 0, frozen});
       return;
     }
+    records_valid_ = !tile_ok_;
     be_.begin_region(kRegionForce);
     if (phase == kPhaseBoundary)
-      be_.launch_tile(kSlotRadial, num_boundary_bricks_,
-                      RadialTileBody<S>{box_, md_, b_, tile_, (int)(num_bricks_ - num_boundary_bricks_), records});
+      be_.launch_win(kSlotRadial, num_boundary_bricks_,
+                     RadialWinBody<S>{ws, md_, (int)(num_bricks_ - num_boundary_bricks_), frozen});
     else if (tile_ok_)
-      be_.launch_tile(kSlotRadial, num_bricks_, RadialTileBody<S>{box_, md_, b_, tile_, -1, records});
+      be_.launch_win(kSlotRadial, num_bricks_, RadialWinBody<S>{ws, md_, -1, frozen});
     else
       be_.template launch<64>(kSlotRadial, N_, RadialDescBody<S>{box_, md_, b_, 1});
     launch_angular_desc<S>();
     be_.template launch_ann<S>(kSlotAnn, N_, md_, b_, true);
     launch_angular_force<S>();
-    if (force_tile)
-      be_.launch_tile(kSlotForce, num_bricks_,
-                      ForceTileBody<S>{RadialTileBody<S>{box_, md_, b_, tile_, -1, 0}, pe, force, virial});
+    if (tile_ok_)
+      be_.launch_win(kSlotForce, num_bricks_, ForceWinBody<S>{ws, md_, frozen});
     else
-      be_.template launch<64>(kSlotForce, N_, ForceAssembleBody<S>{md_, b_, pe, force, virial});
+      be_.template launch<64>(kSlotForce, N_, ForceAssembleBody<S>{md_, b_});
     be_.end_region(kRegionForce);
   }
 
-  // Tile mode -1 (default): the two force-assembly variants (pair records written by the radial pass
-  // vs. geometry rebuilt from a second LDS window) are equivalent; which one is faster depends on the
-  // model (angular work per atom, registers).  The engine times the whole force path of its 2nd call
-  // in mode 2 and of its 4th call in mode 1 and keeps the faster one.  Below kAutoProbeMinAtoms the timing
-  // says nothing (a force call is tens of microseconds) and a choice that depends on it would make small runs
-  // differ from one execution to the next in the last FP32 bits: those systems simply take mode 2.
-  static constexpr int64_t kAutoProbeMinAtoms = 100000;
-  int effective_tile_mode() const
+  // frozen != nullptr: a speculatively enqueued step of a fused run loop -- every kernel of the force path looks at
+  // that device word first and returns when a list rebuild is pending
+  void force_kernels(int phase, const int* frozen = nullptr)
   {
-    if (tile_mode_ >= 0)
-      return tile_mode_;
-    if (N_ < kAutoProbeMinAtoms)
-      return 2;
-    if (auto_choice_ >= 0)
-      return auto_choice_;
-    return auto_calls_ < 2 ? 2 : 1;
+    be_.frozen = frozen;
+    force_kernels_dispatch(phase, frozen);
+    be_.frozen = nullptr;
   }
 
-  void force_kernels(double* pe, double* force, double* virial, int phase)
-  {
-    const bool probing = phase == kPhaseAll && tile_mode_ < 0 && auto_choice_ < 0 && tile_ok_ && model_.kind == 0 &&
-                         N_ >= kAutoProbeMinAtoms;
-    if (probing && (auto_calls_ == 1 || auto_calls_ == 3))
-      be_.probe_start();
-    force_kernels_dispatch(pe, force, virial, phase);
-    if (probing) {
-      if (auto_calls_ == 1 || auto_calls_ == 3)
-        auto_ms_[auto_calls_ == 1 ? 0 : 1] = be_.probe_stop_ms();
-      if (++auto_calls_ == 4)
-        auto_choice_ = auto_ms_[1] < 0.97 * auto_ms_[0] ? 1 : 2; // mode 2 moves 3x less data: it wins ties
-    }
-  }
-
-  void force_kernels_dispatch(double* pe, double* force, double* virial, int phase)
+  void force_kernels_dispatch(int phase, const int* frozen)
   {
     if (model_.kind == 1) { // Tersoff1989::compute, tersoff1989.cu:508-586
       be_.begin_region(kRegionForce);
       be_.template launch<64>(kSlotRadial, N_, TersoffPartialBody{box_, tp_, b_, tb_});
-      be_.template launch<64>(kSlotForce, N_, TersoffAssembleBody{b_, tb_, pe, force, virial});
+      be_.template launch<64>(kSlotForce, N_, TersoffAssembleBody{b_, tb_});
       be_.end_region(kRegionForce);
       return;
     }
     switch (shape_) {
-      case 1: force_kernels_shape<S_PbTeA>(pe, force, virial, phase); break;
-      case 2: force_kernels_shape<S_PbTeB>(pe, force, virial, phase); break;
-      case 3: force_kernels_shape<S_C2022>(pe, force, virial, phase); break;
-      case 4: force_kernels_shape<S_UNEP>(pe, force, virial, phase); break;
-      case 5: force_kernels_shape<S_BZO>(pe, force, virial, phase); break;
-      default: force_kernels_shape<ShapeGeneric>(pe, force, virial, phase); break;
+      case 1: force_kernels_shape<S_PbTeA>(phase, frozen); break;
+      case 2: force_kernels_shape<S_PbTeB>(phase, frozen); break;
+      case 3: force_kernels_shape<S_C2022>(phase, frozen); break;
+      case 4: force_kernels_shape<S_UNEP>(phase, frozen); break;
+      case 5: force_kernels_shape<S_BZO>(phase, frozen); break;
+      default: force_kernels_shape<ShapeGeneric>(phase, frozen); break;
     }
   }
 
@@ -1136,11 +1264,12 @@ private:
   ModelD md_;
   Bufs b_;
   BoxD box_;
-  TileLayout tile_{0};
+  WinLayout win_{0};
+  WinGeom wing_{};
+  double* ui_alloc_ = nullptr;
+  double* factor_dev_ = nullptr;
   bool tile_ok_ = false, use_tiles_ = true;
   int tile_mode_ = -1;           // -1 auto, 0 none, 1 radial window only, 2 radial + force windows
-  int auto_choice_ = -1, auto_calls_ = 0;
-  double auto_ms_[2] = {0.0, 0.0};
   bool records_valid_ = false; // rstash holds the pair records of the last evaluated positions
   int recompute_mode_ = -1;
   bool external_skin_ = false;

@@ -57,7 +57,9 @@ using ShapeGeneric = Shape<-1, -1, -1, -1, -1, 0>;
 
 enum FlagSlot {
   kFlagMoved = 0, kFlagOverflow = 1, kFlagMaxSkin = 2, kFlagMaxAng = 3,
-  kFlagMaxWindow = 4, kFlagMaxBrick = 5, kFlagMaxCell = 6, kFlagNumBoundary = 7, kNumFlags = 8
+  kFlagMaxWindow = 4, kFlagMaxBrick = 5, kFlagMaxCell = 6, kFlagNumBoundary = 7,
+  kFlagOutlier = 8, // an atom sits more than half a cell outside the box along an open direction
+  kNumFlags = 12
 };
 
 struct Bufs {
@@ -105,7 +107,24 @@ struct Bufs {
   int* tpos;                // [N] inverse of tperm: q and fp are stored in work order, [dim][tpos]
   int* tcount;              // [(nchunks * T) + 1] histogram / offsets of that order
   int* sh_ang;              // small-box path only: packed periodic-image shift of each list-A entry
+  // Outputs of the force path in INTERNAL order, assigned (not accumulated): 13 planes of N doubles,
+  // pe | fx fy fz | virial xx yy zz xy xz yz yx zx zy.  The per-call entry points add them to the caller's
+  // arrays through perm (ScatterAddBody); the fused run loops integrate on them directly.
+  double* fo;
+  // per-step compact list of the LDS-window path: window slots of the pairs inside the radial cutoff, written by
+  // the radial pass and walked by the force assembly (no out-of-cutoff candidates there), and the list-A index of
+  // every compact angular slot
+  int MN_rad;
+  unsigned short* ccode; // [MN_rad][N]
+  unsigned short* aidx;  // [MN_acomp][N]
+  // integrator state in internal order while a fused run loop owns the step (positions live in posq)
+  double* vi; // [3][N]
+  double* mi; // [N]
+  double* ui; // [3][N] unwrapped positions, or nullptr
 };
+
+// planes of Bufs::fo
+constexpr int kOutPe = 0, kOutF = 1, kOutW = 4, kOutPlanes = 13;
 
 constexpr unsigned short kNoSlot = 0xFFFF;
 
@@ -298,9 +317,10 @@ struct NhcChainBody { // nhc(), ensemble_nhc.cu:102-164, with Ek2 = T * 3N * k_B
   double temperature, dt2_particle;
   const double* thermo; // thermo[0] = instantaneous T (find_thermo)
   double* st;
+  const int* frozen = nullptr; // fused run loops: non-zero = a list rebuild is pending, the chain must not advance
   NEPMI_HD void operator()(int64_t i) const
   {
-    if (i != 0)
+    if (i != 0 || (frozen && *frozen != 0))
       return;
     constexpr int M = kNhcLinks;
     double pos[M], vel[M], mas[M];
@@ -407,6 +427,17 @@ struct BinAtomsBody {
     cell_of(box, x, y, z, b.rc_inv_cell, b.nbx, b.nby, b.nbz, cx, cy, cz);
     if (!(x - x == 0.0 && y - y == 0.0 && z - z == 0.0)) // NaN or infinity
       NEPMI_ATOMIC_OR(&b.flags[kFlagOverflow], 8);
+    if (!(box.pbc[0] && box.pbc[1] && box.pbc[2])) {
+      // open directions: the edge cells absorb atoms outside the box; the fixed-point windows of the LDS-window
+      // kernels only reach half a cell beyond it
+      const double* h = box.h;
+      const double f[3] = {(h[9] * x + h[10] * y + h[11] * z) * box.thickness[0] * b.rc_inv_cell,
+                           (h[12] * x + h[13] * y + h[14] * z) * box.thickness[1] * b.rc_inv_cell,
+                           (h[15] * x + h[16] * y + h[17] * z) * box.thickness[2] * b.rc_inv_cell};
+      for (int d = 0; d < 3; ++d)
+        if (!box.pbc[d] && (f[d] < -0.5 || f[d] > box.thickness[d] * b.rc_inv_cell + 0.5))
+          b.flags[kFlagOutlier] = 1; // benign race: all writers store 1
+    }
     const int c = cell_index(b, cx, cy, cz);
     b.cid[i] = c;
     NEPMI_ATOMIC_ADD(&b.cell_count[c], 1);
@@ -687,6 +718,43 @@ struct BrickOrderBody {
   }
 };
 
+// PosQ::pad: how many lattice vectors the stored (wrapped) position has jumped since the list rebuild, two bits
+// per direction (two's complement: -1, 0, 1).  The LDS-window kernels undo the jump when they place an atom
+// relative to its cell of the rebuild-time grid; everything that applies a minimum image per pair ignores it.
+NEPMI_HD int pack_img(int n0, int n1, int n2) { return (n0 & 3) | ((n1 & 3) << 2) | ((n2 & 3) << 4); }
+NEPMI_HD int img_of(int pad, int d) { return (((pad >> (2 * d)) & 3) ^ 2) - 2; }
+
+// apply_mic (float) that also reports the lattice-vector multiples it removed
+NEPMI_HD void mic_f_img(const BoxD& box, float& x, float& y, float& z, int& n0, int& n1, int& n2)
+{
+  const float* H = box.hf;
+  n0 = n1 = n2 = 0;
+  if (box.ortho) {
+    if (box.pbc[0]) {
+      const float L = H[0], hl = L * 0.5f;
+      if (x < -hl) { x += L; n0 = -1; } else if (x > hl) { x -= L; n0 = 1; }
+    }
+    if (box.pbc[1]) {
+      const float L = H[4], hl = L * 0.5f;
+      if (y < -hl) { y += L; n1 = -1; } else if (y > hl) { y -= L; n1 = 1; }
+    }
+    if (box.pbc[2]) {
+      const float L = H[8], hl = L * 0.5f;
+      if (z < -hl) { z += L; n2 = -1; } else if (z > hl) { z -= L; n2 = 1; }
+    }
+  } else {
+    float sx = dot3f(H[9], x, H[10], y, H[11], z);
+    float sy = dot3f(H[12], x, H[13], y, H[14], z);
+    float sz = dot3f(H[15], x, H[16], y, H[17], z);
+    if (box.pbc[0]) { const float r = nearbyintf(sx); sx -= r; n0 = (int)r; }
+    if (box.pbc[1]) { const float r = nearbyintf(sy); sy -= r; n1 = (int)r; }
+    if (box.pbc[2]) { const float r = nearbyintf(sz); sz -= r; n2 = (int)r; }
+    x = dot3f(H[0], sx, H[1], sy, H[2], sz);
+    y = dot3f(H[3], sx, H[4], sy, H[5], sz);
+    z = dot3f(H[6], sx, H[7], sy, H[8], sz);
+  }
+}
+
 // gpu_check_atom_distance (neighbor.cu:646-684) fused with the per-step gather of the caller's
 // positions into internal order.  which: 0 all atoms, 1 owned only (level 2), 2 ghosts only.
 struct CheckGatherBody {
@@ -705,13 +773,15 @@ struct CheckGatherBody {
     float dx = (float)(x - b.x0s[k]);
     float dy = (float)(y - b.x0s[N + k]);
     float dz = (float)(z - b.x0s[2 * N + k]);
-    mic_f(box, dx, dy, dz);
+    int n0, n1, n2;
+    mic_f_img(box, dx, dy, dz, n0, n1, n2);
     const float d2 = (dx * dx + dy * dy) + dz * dz;
     if (!((double)d2 <= 0.25)) // skin^2/4, skin = 1 A (neighbor.cuh:212); also true for NaN
       NEPMI_ATOMIC_OR(&b.flags[kFlagMoved], 1);
     b.posq[k].x = x;
     b.posq[k].y = y;
     b.posq[k].z = z;
+    b.posq[k].pad = pack_img(n0, n1, n2);
   }
 };
 
@@ -812,7 +882,7 @@ struct SmallBoxPairsBody {
     NEPMI_ATOMIC_MAX(&b.flags[kFlagMaxSkin], cnta + cntb);
     NEPMI_ATOMIC_MAX(&b.flags[kFlagMaxAng], cnta);
     if (cnta > b.MN_ang || cnta > b.MN_acomp || cntb > b.MN_skin) {
-      NEPMI_ATOMIC_OR(&b.flags[kFlagOverflow], 8);
+      NEPMI_ATOMIC_OR(&b.flags[kFlagOverflow], 1); // list capacity (bit 8 is reserved for non-finite coordinates)
       cnta = cnta > b.MN_ang ? b.MN_ang : cnta;
       cnta = cnta > b.MN_acomp ? b.MN_acomp : cnta;
       cntb = cntb > b.MN_skin ? b.MN_skin : cntb;
@@ -1128,155 +1198,6 @@ struct RadialDescBody {
   }
 };
 
-
-// The LDS-window variant of the radial pass.  One 256-thread workgroup per brick (4x4x4 cells,
-// ~200 atoms): it stages the positions of every atom of the brick's 8x8x8-cell window (~1,700
-// atoms, FP64 x,y,z + packed index/type = 28 B each) in LDS ONCE, and the Verlet entries, stored as
-// 16-bit window codes (window cell << 7 | rank in cell), are resolved against that copy.  The default
-// path issues one L2 request per (atom, neighbour) -- 86 per atom, ~20x redundant across the lanes
-// of a wavefront, and is L2-request-rate bound; here the window is read from
-// L2 once per workgroup (~8 positions per atom).
-//
-// LDS layout (bytes): [0, 2052) int woff[513] | [2052+, ...) int wstart[512] | double wx[W] wy[W] wz[W]
-// | int wword[W] (global index | type << 25).
-constexpr int kTileThreads = 512; // workgroup of the window kernels (engine.hip: nepmi_tile_kernel)
-constexpr int kWinCells = 512;
-
-#if defined(__HIP_DEVICE_COMPILE__)
-#define NEPMI_LDS(T) __attribute__((address_space(3))) T
-#else
-#define NEPMI_LDS(T) T
-#endif
-
-struct TileLayout {
-  int wmax; // capacity of the window arrays (atoms)
-  NEPMI_HD int off_woff() const { return 0; }
-  NEPMI_HD int off_wstart() const { return 2064; } // 513 ints, padded to 16 B
-  NEPMI_HD int off_x() const { return 2064 + 2048; }
-  NEPMI_HD int off_y() const { return off_x() + 8 * wmax; }
-  NEPMI_HD int off_z() const { return off_y() + 8 * wmax; }
-  NEPMI_HD int off_word() const { return off_z() + 8 * wmax; }
-  NEPMI_HD int bytes() const { return off_word() + 4 * wmax; }
-};
-
-template <class S>
-struct RadialTileBody {
-  BoxD box;
-  ModelD m;
-  Bufs b;
-  TileLayout lay;
-  int first; // workgroup w runs brick_order[first + w] (first < 0: brick w)
-  int write_records;
-  static constexpr int kMinWavesPerEu = 1; // no register cap (it already fits two workgroups per CU)
-
-  NEPMI_HD int lds_bytes() const { return lay.bytes(); }
-  NEPMI_HD int64_t map_brick(int64_t w) const { return first < 0 ? w : (int64_t)b.brick_order[first + w]; }
-
-  // phase 1 (all threads): count and first atom of each of the 512 window cells
-  template <class LC>
-  NEPMI_HD void stage_cells(int64_t brick, LC lds, int tid, int nth) const
-  {
-    NEPMI_LDS(int)* woff = (NEPMI_LDS(int)*)(lds + lay.off_woff());
-    NEPMI_LDS(int)* wstart = (NEPMI_LDS(int)*)(lds + lay.off_wstart());
-    const int bx = (int)(brick % b.gbx), by = (int)((brick / b.gbx) % b.gby), bz = (int)(brick / ((int64_t)b.gbx * b.gby));
-    for (int wc = tid; wc < kWinCells; wc += nth) {
-      int cx = 4 * bx - 2 + (wc & 7), cy = 4 * by - 2 + ((wc >> 3) & 7), cz = 4 * bz - 2 + (wc >> 6);
-      bool ok = true;
-      if (box.pbc[0]) cx = ((cx % b.nbx) + b.nbx) % b.nbx; else ok = ok && cx >= 0 && cx < b.nbx;
-      if (box.pbc[1]) cy = ((cy % b.nby) + b.nby) % b.nby; else ok = ok && cy >= 0 && cy < b.nby;
-      if (box.pbc[2]) cz = ((cz % b.nbz) + b.nbz) % b.nbz; else ok = ok && cz >= 0 && cz < b.nbz;
-      int cnt = 0, st = 0;
-      if (ok) {
-        const int c = cell_index(b, cx, cy, cz);
-        st = b.cell_count[c];
-        cnt = b.cell_count[c + 1] - st;
-      }
-      woff[wc] = cnt; // turned into the exclusive prefix by the backend's scan (woff[512] = total)
-      wstart[wc] = st;
-    }
-    if (tid == 0)
-      woff[kWinCells] = 0;
-  }
-
-  // phase 3 (all threads, after the scan of woff): copy the window atoms
-  template <class LC>
-  NEPMI_HD void stage_copy(LC lds, int tid, int nth) const
-  {
-    NEPMI_LDS(const int)* woff = (NEPMI_LDS(const int)*)(lds + lay.off_woff());
-    NEPMI_LDS(const int)* wstart = (NEPMI_LDS(const int)*)(lds + lay.off_wstart());
-    NEPMI_LDS(double)* wx = (NEPMI_LDS(double)*)(lds + lay.off_x());
-    NEPMI_LDS(double)* wy = (NEPMI_LDS(double)*)(lds + lay.off_y());
-    NEPMI_LDS(double)* wz = (NEPMI_LDS(double)*)(lds + lay.off_z());
-    NEPMI_LDS(int)* wword = (NEPMI_LDS(int)*)(lds + lay.off_word());
-    const int W = woff[kWinCells] < lay.wmax ? woff[kWinCells] : lay.wmax;
-    for (int w = tid; w < W; w += nth) {
-      int lo = 0, hi = kWinCells - 1; // largest wc with woff[wc] <= w
-      while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (woff[mid] <= w) lo = mid; else hi = mid - 1;
-      }
-      const int j = wstart[lo] + (w - woff[lo]);
-      const PosQ p = b.posq[j];
-      wx[w] = p.x;
-      wy[w] = p.y;
-      wz[w] = p.z;
-      wword[w] = (int)((unsigned)j | ((unsigned)p.type << kIdxBits));
-    }
-  }
-
-  template <class LC, int G = kGatherR>
-  struct TileFetch {
-    const unsigned short* cA;
-    const unsigned short* cB;
-    int64_t N;
-    LC lds;
-    TileLayout lay;
-    struct Tok {
-      unsigned code[G];
-    };
-    NEPMI_HD void prefetch(int s0, int nn, int na, Tok& t) const
-    {
-#pragma unroll
-      for (int u = 0; u < G; ++u) {
-        const int idx = s0 + u < nn ? s0 + u : nn - 1;
-        t.code[u] = idx < na ? cA[(int64_t)idx * N] : cB[(int64_t)(idx - na) * N];
-      }
-    }
-    NEPMI_HD void resolve(const Tok& t, int* jj, PosQ* pp) const
-    {
-      NEPMI_LDS(const int)* woff = (NEPMI_LDS(const int)*)(lds + lay.off_woff());
-      NEPMI_LDS(const double)* wx = (NEPMI_LDS(const double)*)(lds + lay.off_x());
-      NEPMI_LDS(const double)* wy = (NEPMI_LDS(const double)*)(lds + lay.off_y());
-      NEPMI_LDS(const double)* wz = (NEPMI_LDS(const double)*)(lds + lay.off_z());
-      NEPMI_LDS(const int)* wword = (NEPMI_LDS(const int)*)(lds + lay.off_word());
-#pragma unroll
-      for (int u = 0; u < G; ++u) {
-        const int w = woff[t.code[u] >> 7] + (int)(t.code[u] & 127u);
-        const unsigned word = (unsigned)wword[w];
-        jj[u] = (int)(word & (unsigned)kIdxMask);
-        pp[u].x = wx[w];
-        pp[u].y = wy[w];
-        pp[u].z = wz[w];
-        pp[u].type = (int)(word >> kIdxBits);
-        pp[u].pad = 0;
-      }
-    }
-  };
-
-  // phase 4: the atoms of the brick
-  NEPMI_HD void brick_range(int64_t brick, int64_t& a0, int64_t& a1) const
-  {
-    a0 = b.cell_count[brick * 64];
-    a1 = b.cell_count[brick * 64 + 64];
-  }
-
-  template <int PARTS, class LC>
-  NEPMI_HD void compute(int64_t k, int part, LC lds) const
-  {
-    const RadialDescBody<S> body{box, m, b, write_records};
-    body.template run_parts<PARTS>(k, part, TileFetch<LC>{b.code_ang + k, b.code_skin + k, b.N, lds, lay});
-  }
-};
 
 // radial part of find_descriptor from pair records that already exist (small-box path)
 template <class S>
@@ -1722,8 +1643,9 @@ struct AngularForceBody {
   }
 };
 
-// find_force_radial (nep.cu:661-772) + gpu_find_force_many_body (potential.cu:170-297) + the
-// accumulation into the caller's FP64 per-atom arrays (potential += , force +=, virial +=).
+// find_force_radial (nep.cu:661-772) + gpu_find_force_many_body (potential.cu:170-297); the 13 output planes
+// are written in internal order (Bufs::fo).  Gather form: used when the LDS-window kernels do not apply
+// (fewer than 8 cells in a periodic direction, oversized windows) and by the small-box branch.
 // One walk over the pair records (list A rows, then list B rows): every record inside rc_r gives
 // the radial pair force from the two per-atom tables A_i, A_j; records of list A that are angular
 // members this step (amap) add f12 - f21, with f21 found through the static reverse slot.
@@ -1731,9 +1653,6 @@ template <class S>
 struct ForceAssembleBody {
   ModelD m;
   Bufs b;
-  double* pe;     // caller order
-  double* force;  // [3][N]
-  double* virial; // [9][N]
   // pair records straight from the radial pass (rows [A slots | MN_ang + B slots] of rstash)
   struct RecordSource {
     const F4* rstash; // + k
@@ -1953,83 +1872,14 @@ struct ForceAssembleBody {
       Wd[8] += (double)b.zbl[(int64_t)(3 + 5) * N + k];
       E += (double)b.zbl[(int64_t)9 * N + k];
     }
-    const int64_t i = b.perm[k];
-    pe[i] += E;
+    double* __restrict__ fo = b.fo + k;
+    fo[0] = E;
 #pragma unroll
     for (int d = 0; d < 3; ++d)
-      force[d * N + i] += Fd[d];
+      fo[(int64_t)(kOutF + d) * N] = Fd[d];
 #pragma unroll
     for (int d = 0; d < 9; ++d)
-      virial[d * N + i] += Wd[d];
-  }
-};
-
-// Force assembly without pair records: one 256-thread workgroup per brick stages the same 8x8x8-cell
-// position window as the radial pass and rebuilds every pair's r12 and cutoff decision from it (the
-// identical exact FP64 -> FP32 minimum-image arithmetic, so both passes agree on every pair), instead
-// of the radial pass writing 16 bytes per Verlet entry and this pass reading them back (2 x 1.4 KB
-// per atom and step for PbTe).  Tables of the neighbours are still gathered from L2 by index.
-template <class S>
-struct ForceTileBody {
-  static constexpr int kMinWavesPerEu = 4; // two 512-thread workgroups per CU: <= 128 VGPRs
-  RadialTileBody<S> rt; // staging (stage_cells / stage_copy / brick_range / map_brick), box, model, buffers
-  double* pe;
-  double* force;
-  double* virial;
-
-  NEPMI_HD int lds_bytes() const { return rt.lds_bytes(); }
-  NEPMI_HD int64_t map_brick(int64_t w) const { return rt.map_brick(w); }
-  template <class LC>
-  NEPMI_HD void stage_cells(int64_t brick, LC lds, int tid, int nth) const { rt.stage_cells(brick, lds, tid, nth); }
-  template <class LC>
-  NEPMI_HD void stage_copy(LC lds, int tid, int nth) const { rt.stage_copy(lds, tid, nth); }
-  NEPMI_HD void brick_range(int64_t brick, int64_t& a0, int64_t& a1) const { rt.brick_range(brick, a0, a1); }
-
-  template <class LC, int G>
-  struct WindowSource {
-    typedef typename RadialTileBody<S>::template TileFetch<LC, G> Fetch;
-    Fetch fetch;
-    BoxD box;
-    ModelD m;
-    PosQ p1;
-    float rc1;
-    struct State {
-      typename Fetch::Tok cur;
-    };
-    NEPMI_HD void begin(int s0, int, int nn, int na, State& st) const { fetch.prefetch(s0, nn, na, st.cur); }
-    template <int GG>
-    NEPMI_HD void load(int s0, int stride, int nn, int na, State& st, F4* ee) const
-    {
-      static_assert(GG == G, "chunk size of the source and of the walk differ");
-      int jj[G];
-      PosQ pp[G];
-      typename Fetch::Tok nxt = st.cur;
-      if (s0 + stride < nn)
-        fetch.prefetch(s0 + stride, nn, na, nxt);
-      fetch.resolve(st.cur, jj, pp);
-      st.cur = nxt;
-#pragma unroll
-      for (int u = 0; u < G; ++u) {
-        float x, y, z;
-        const float d2 = pair_geometry_fast(box, p1, pp[u], x, y, z);
-        const int t2 = pp[u].type;
-        const float rc = m.uniform_rc ? m.rc_r_max : (rc1 + m.rc_r[t2]) * 0.5f;
-        ee[u].x = x;
-        ee[u].y = y;
-        ee[u].z = z;
-        ee[u].w = d2 < rc * rc ? (int)((unsigned)jj[u] | ((unsigned)t2 << kIdxBits)) : -1;
-      }
-    }
-  };
-
-  template <int PARTS, class LC>
-  NEPMI_HD void compute(int64_t k, int part, LC lds) const
-  {
-    const ForceAssembleBody<S> fa{rt.m, rt.b, pe, force, virial};
-    const PosQ p1 = rt.b.posq[k];
-    constexpr int G = kGather / PARTS;
-    fa.template run_parts<PARTS, G>(k, part, WindowSource<LC, G>{{rt.b.code_ang + k, rt.b.code_skin + k, rt.b.N, lds, rt.lay}, rt.box, rt.m, p1,
-                                    rt.m.rc_r[p1.type]});
+      fo[(int64_t)(kOutW + d) * N] = Wd[d];
   }
 };
 

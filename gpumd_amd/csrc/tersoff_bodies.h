@@ -8,7 +8,7 @@
 //                        (step 2, :408-505); pair geometry (double + double MIC) is computed once
 //                        and kept in a per-slot record.
 //   TersoffAssembleBody  F_i = sum_j f12 - f21, virial, through the reverse slot (the reference
-//                        searches j's list linearly, potential.cu:86-92); scatter-add to the caller.
+//                        searches j's list linearly, potential.cu:86-92); output planes in internal order.
 #pragma once
 #include "nep_bodies.h"
 
@@ -198,9 +198,6 @@ struct TersoffPartialBody {
 struct TersoffAssembleBody {
   Bufs b;
   TersoffBufs tb;
-  double* pe;
-  double* force;
-  double* virial;
   NEPMI_HD void operator()(int64_t k) const
   {
     const int64_t N = b.N;
@@ -229,14 +226,14 @@ struct TersoffAssembleBody {
       W[7] += r.z * f21.x;
       W[8] += r.z * f21.y;
     }
-    const int64_t i = b.perm[k];
-    pe[i] += tb.pe_d[k];
+    double* __restrict__ fo = b.fo + k;
+    fo[0] = tb.pe_d[k];
 #pragma unroll
     for (int d = 0; d < 3; ++d)
-      force[d * N + i] += F[d];
+      fo[(int64_t)(kOutF + d) * N] = F[d];
 #pragma unroll
     for (int d = 0; d < 9; ++d)
-      virial[d * N + i] += W[d];
+      fo[(int64_t)(kOutW + d) * N] = W[d];
   }
 };
 

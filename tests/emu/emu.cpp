@@ -12,6 +12,8 @@
 #include <vector>
 
 #include "../../gpumd_amd/csrc/nep_bodies.h"
+#include "../../gpumd_amd/csrc/nep_md.h"
+#include "../../gpumd_amd/csrc/nep_window.h"
 
 namespace nepmi {
 
@@ -32,12 +34,20 @@ struct HostLoopBackend {
   int64_t region_count(int) { return 0; }
   void set_timing(int) {}
 
+  const int* frozen = nullptr; // see HipBackend::frozen
+  bool is_frozen() const { return frozen && *frozen != 0; }
   template <int BLOCK, class Body>
   void launch(int, int64_t n, const Body& body)
   {
+    if (is_frozen())
+      return;
     for (int64_t i = 0; i < n; ++i)
       body(i);
   }
+  // flag snapshots of the speculative run loops: the host loops have already finished when they are taken
+  int snapshots[8][8];
+  void poll_record(int ring, const int* flags) { std::memcpy(snapshots[ring], flags, sizeof(int) * 8); }
+  void poll_wait(int ring, int* out8) { std::memcpy(out8, snapshots[ring], sizeof(int) * 8); }
 
   // the product's MFMA ANN kernel is device-only; the emulator runs the per-atom body
   template <class S>
@@ -50,10 +60,12 @@ struct HostLoopBackend {
   double probe_stop_ms() { return 0.0; } // no clock on the CPU tier: the engine keeps its default variant
   void ann_prepare(const ModelD&, const Bufs&) {}
 
-  // one "workgroup" per brick, phases run back to back (the LDS-window radial pass)
+  // one "workgroup" per brick, phases run back to back (the LDS-window kernels of nep_window.h)
   template <class Body>
-  void launch_tile(int, int64_t nbricks, const Body& body)
+  void launch_win(int, int64_t nbricks, const Body& body)
   {
+    if (body.skip())
+      return;
     std::vector<double> raw((size_t)body.lds_bytes() / 8 + 8);
     char* lds = reinterpret_cast<char*>(raw.data());
     for (int64_t wg = 0; wg < nbricks; ++wg) {
@@ -67,11 +79,11 @@ struct HostLoopBackend {
         run += v;
       }
       woff[512] = run;
-      body.stage_copy(lds, 0, 1);
+      body.stage_copy(brick, lds, 0, 1);
       int64_t a0, a1;
       body.brick_range(brick, a0, a1);
       for (int64_t k = a0; k < a1; ++k)
-        body.template compute<1>(k, 0, lds);
+        body.compute(brick, k, lds);
     }
   }
 
@@ -79,6 +91,8 @@ struct HostLoopBackend {
   template <int BLOCK, class Body>
   void launch_lds(int, int64_t n, const Body& body)
   {
+    if (is_frozen())
+      return;
     std::vector<float> lds((size_t)body.lds_floats() + 1);
     body.lds_stage(lds.data(), 0, 1);
     for (int64_t i = 0; i < n; ++i)
@@ -104,11 +118,13 @@ struct HostLoopBackend {
 
   void thermo(
     int, int64_t n, double volume, const double* mass, const double* pe, const double* vel,
-    const double* virial, double* th, double*)
+    const double* virial, double* th, double*, const signed char* lvl = nullptr, int raw = 0, int64_t n_norm = 0)
   {
     double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const double *vx = vel, *vy = vel + n, *vz = vel + 2 * n;
     for (int64_t i = 0; i < n; ++i) {
+      if (lvl && lvl[i] < 2)
+        continue;
       const double m = mass[i];
       s[0] += (vx[i] * vx[i] + vy[i] * vy[i] + vz[i] * vz[i]) * m;
       s[1] += pe[i];
@@ -119,7 +135,12 @@ struct HostLoopBackend {
       s[6] += virial[4 * n + i] + vx[i] * vz[i] * m;
       s[7] += virial[5 * n + i] + vy[i] * vz[i] * m;
     }
-    th[0] = s[0] / (3.0 * (double)n * 8.617343e-5);
+    if (raw) {
+      for (int k = 0; k < 8; ++k)
+        th[k] = s[k];
+      return;
+    }
+    th[0] = s[0] / (3.0 * (double)(n_norm > 0 ? n_norm : n) * 8.617343e-5);
     th[1] = s[1];
     for (int k = 2; k < 8; ++k)
       th[k] = s[k] / volume;
