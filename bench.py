@@ -198,7 +198,11 @@ def kernel_report(st, info, n_atoms_per_launch, st_all=None):
             continue
         for k, name in enumerate(KERNEL_NAMES):
             if src.launches[k] > 0 and src.ms_kernel_sum[k] > 0.0:
-                kern[name] = {"launches": int(src.launches[k]), "avg_ms": src.ms_kernel_sum[k] / src.launches[k]}
+                # launches of speculatively enqueued steps that were re-run after a list rebuild returned at once:
+                # they are not work, the mean is over the launches that ran
+                ran = int(src.launches[k]) - (int(src.discarded_steps) if 1 <= k <= 6 else 0)
+                ran = max(ran, 1)
+                kern[name] = {"launches": ran, "avg_ms": src.ms_kernel_sum[k] / ran}
     force_kernels = [k for k in kern if k in per_kernel and k not in ("velocity_verlet", "gather_skin_check")]
     dom = max(force_kernels, key=lambda k: kern[k]["avg_ms"] * kern[k]["launches"]) if force_kernels else None
     roofline = None

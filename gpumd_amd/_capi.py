@@ -30,7 +30,8 @@ class NepmiStats(C.Structure):
         ("max_nn_skin", C.c_int), ("max_nn_radial", C.c_int), ("max_nn_angular", C.c_int),
         ("mean_nn_radial", C.c_double), ("mean_nn_angular", C.c_double),
         ("ms_force_last", C.c_double), ("ms_kernel", C.c_double * 8),
-        ("ms_kernel_sum", C.c_double * 8), ("launches", c_i64 * 8), ("radial_tiles", C.c_int)]
+        ("ms_kernel_sum", C.c_double * 8), ("launches", c_i64 * 8), ("radial_tiles", C.c_int),
+        ("discarded_steps", c_i64)]
 
 
 # every symbol include/nepmi.h declares: name -> (restype, argtypes)

@@ -384,6 +384,7 @@ int nepmi_engine_stats(nepmi_engine* e, int with_lists, nepmi_stats* out)
       out->launches[k] = eng.backend().slot_count(slots[k]);
     }
     out->radial_tiles = eng.tile_mode_in_use();
+    out->discarded_steps = eng.num_discarded;
     out->ms_kernel_sum[7] = eng.backend().region_sum(nepmi::kRegionRebuild);
     out->launches[7] = eng.backend().region_count(nepmi::kRegionRebuild);
     out->ms_kernel[7] = eng.backend().region_ms(nepmi::kRegionRebuild);
@@ -395,6 +396,7 @@ int nepmi_engine_set_timing(nepmi_engine* e, int on)
   if (!e)
     return fail(NEPMI_ERR_ARG, "null engine");
   e->e->backend().set_timing(on < 0 ? 0 : (on > 2 ? 1 : on));
+  e->e->num_discarded = 0; // counted over the same window as the kernel sums
   return NEPMI_OK;
 }
 

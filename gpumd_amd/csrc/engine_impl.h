@@ -119,7 +119,7 @@ public:
   const NepModel& model() const { return model_; }
   const Bufs& bufs() const { return b_; }
   int64_t num_atoms() const { return N_; }
-  int64_t num_compute = 0, num_rebuild = 0;
+  int64_t num_compute = 0, num_rebuild = 0, num_discarded = 0;
   enum Phase { kPhaseAll = 0, kPhaseInterior = 1, kPhaseBoundary = 2, kPhaseRecords = 3 };
 
   // Potential::compute (adds to pe/force/virial; positions already wrapped)
@@ -498,7 +498,8 @@ public:
     int ring_next = 0;
     // a trip of the skin check at (0-based) step m, found at a sync or in a snapshot: the device state is frozen
     // right after that step's first half-step; rebuild the lists on it
-    auto handle_trip = [&](int moved_tag) -> int64_t {
+    auto handle_trip = [&](int moved_tag, int64_t enqueued_through) -> int64_t {
+      num_discarded += enqueued_through - ((int64_t)moved_tag - 1) + 1; // steps m .. enqueued_through ran as no-ops
       be_.sync();
       pending.clear();
       resident_export(pos, vel, nullptr, nullptr, nullptr);
@@ -575,7 +576,7 @@ public:
         }
       }
       if (trip) {
-        step = handle_trip(trip);
+        step = handle_trip(trip, step);
         resume_after_vv1 = true;
         continue;
       }
@@ -790,6 +791,7 @@ private:
     b_.rc_skin_sq = (float)(rcs * rcs);
     b_.rc_askin_sq = (float)(ras * ras);
     b_.cid = dalloc<int>(N);
+    b_.kcell = dalloc<int>(N);
     b_.perm = dalloc<int>(N);
     b_.posq = dalloc<PosQ>(N);
     b_.x0s = dalloc<double>(3 * N);
@@ -818,6 +820,8 @@ private:
       b_.pe_i = dalloc<float>(N);
       b_.MN_rad = m.MN_radial;
       b_.ccode = dalloc<unsigned short>((size_t)b_.MN_rad * N);
+      b_.nn_t0 = dalloc<int>(N);
+      b_.prec = dalloc<WinRec>(N);
       b_.aidx = dalloc<unsigned short>((size_t)b_.MN_acomp * N);
     } else { // Tersoff-1989: Tersoff1989::Tersoff1989 allocations (tersoff1989.cu:141-149)
       tb_.rec = dalloc<D4>((size_t)b_.MN_ang * N);
@@ -1033,6 +1037,35 @@ private:
       bin_grid();
       ncell = set_grid();
     }
+    {
+      // fixed-point frame of the window kernels: +-R covers the 8x8x8-cell window seen from its centre (the widened
+      // edge cells of an open direction and half a cell of outliers included) plus the drift between two rebuilds
+      double R = 0.0, lmax = 0.0;
+      for (int c = 0; c < 3; ++c) {
+        double r = 0.0;
+        for (int d = 0; d < 3; ++d)
+          r += 6.5 * std::fabs(box_.h[3 * c + d]) / nb[d];
+        R = r > R ? r : R;
+      }
+      R += 2.0;
+      WinGeom& g = b_.wg;
+      g.inv_unit = 1073741824.0 / R;
+      g.unit = (float)(R / 1073741824.0);
+      g.unit2 = g.unit * g.unit;
+      for (int d = 0; d < 3; ++d) {
+        const double len = std::sqrt(box_.h[d] * box_.h[d] + box_.h[3 + d] * box_.h[3 + d] + box_.h[6 + d] * box_.h[6 + d]);
+        if (box_.pbc[d] && len > lmax)
+          lmax = len;
+        g.cell_frac[d] = 1.0 / (box_.thickness[d] * b_.rc_inv_cell);
+        for (int c = 0; c < 3; ++c) {
+          g.cv[3 * c + d] = (int)std::llround(box_.h[3 * c + d] * g.cell_frac[d] * g.inv_unit);
+          g.sv[3 * c + d] = (int)std::llround(box_.h[3 * c + d] * (1.0 - nb[d] * g.cell_frac[d]) * g.inv_unit);
+        }
+      }
+      // The reference forms r12 in FP32 with an FP32 minimum image: across a periodic face that carries rounding of
+      // the order of ulp(box length).  A list decision closer to a cutoff than this band is retaken exactly.
+      g.band = (float)(1.0e-4 + 4.0 * model_.rc_radial_max * lmax * 1.2e-7);
+    }
     be_.memset(b_.cell_count, 0, sizeof(int) * (ncell + 1));
     be_.memset(b_.cell_fill, 0, sizeof(int) * ncell);
     be_.memset(b_.cell_ghost, 0, sizeof(int) * ncell);
@@ -1044,7 +1077,7 @@ private:
     be_.exclusive_scan(b_.cell_count, ncell + 1, scan_scratch_);
     be_.template launch<256>(kSlotMisc, N_, FillCellsBody{b_});
     be_.template launch<256>(kSlotMisc, ncell, SortCellsBody{b_});
-    be_.template launch<256>(kSlotMisc, N_, GatherSortedBody{b_, pos, type});
+    be_.template launch<256>(kSlotMisc, N_, GatherSortedBody{box_, b_, pos, type});
     {
       const int64_t nkeys = ((N_ >> kTypeChunkShift) + 1) * model_.num_types;
       be_.memset(b_.tcount, 0, sizeof(int) * (nkeys + 1));
@@ -1075,30 +1108,6 @@ private:
       if (box_.pbc[d] && nb[d] < 8)
         tile_ok_ = false;
     win_.wmax = (flags[kFlagMaxWindow] + 63) / 64 * 64;
-    {
-      // fixed-point frame of the windows: +-R covers the 8x8x8-cell window seen from its centre (the widened edge
-      // cells of an open direction and half a cell of outliers included) plus the drift between two rebuilds
-      double R = 0.0, lmax = 0.0;
-      for (int c = 0; c < 3; ++c) {
-        double r = 0.0;
-        for (int d = 0; d < 3; ++d)
-          r += 6.5 * std::fabs(box_.h[3 * c + d]) / nb[d];
-        R = r > R ? r : R;
-      }
-      R += 2.0;
-      for (int d = 0; d < 3; ++d) {
-        const double len = std::sqrt(box_.h[d] * box_.h[d] + box_.h[3 + d] * box_.h[3 + d] + box_.h[6 + d] * box_.h[6 + d]);
-        if (box_.pbc[d] && len > lmax)
-          lmax = len;
-        wing_.cell_frac[d] = 1.0 / (box_.thickness[d] * b_.rc_inv_cell);
-      }
-      wing_.inv_unit = 1073741824.0 / R;
-      wing_.unit = (float)(R / 1073741824.0);
-      wing_.unit2 = wing_.unit * wing_.unit;
-      // The reference forms r12 in FP32 with an FP32 minimum image: across a periodic face that carries rounding of
-      // the order of ulp(box length).  A list decision closer to a cutoff than this band is retaken exactly.
-      wing_.band = (float)(1.0e-4 + 4.0 * model_.rc_radial_max * lmax * 1.2e-7);
-    }
     have_list_ = true;
     ++num_rebuild;
   }
@@ -1200,7 +1209,7 @@ private:
   template <class S>
   void force_kernels_shape(int phase, const int* frozen)
   {
-    const WinStage ws{box_, b_, win_, wing_};
+    const WinStage ws{box_, b_, win_};
     if (phase == kPhaseRecords) { // diagnostics: materialise the pair records of the current positions
       be_.template launch<64>(kSlotMisc, N_, RadialDescBody<S>{box_, md_, b_, 1});
       records_valid_ = true;
@@ -1265,7 +1274,6 @@ private:
   Bufs b_;
   BoxD box_;
   WinLayout win_{0};
-  WinGeom wing_{};
   double* ui_alloc_ = nullptr;
   double* factor_dev_ = nullptr;
   bool tile_ok_ = false, use_tiles_ = true;

@@ -28,6 +28,25 @@ struct alignas(16) F4 {
   int w; // packed integer payload (never interpreted as a float)
 };
 
+// Fixed-point position record of the LDS-window kernels (nep_window.h): x, y, z in grid units of WinGeom::unit,
+// relative to the corner of the atom's cell of the rebuild-time grid (global array Bufs::prec) or, once staged,
+// relative to the centre of a brick's window (LDS); w = internal index | type << kIdxBits.
+struct alignas(16) WinRec {
+  int x, y, z;
+  int w;
+};
+
+// geometry of the fixed-point frame, set at every list rebuild
+struct WinGeom {
+  double inv_unit;     // grid points per Angstrom
+  double cell_frac[3]; // fractional width of a cell along each lattice direction
+  int cv[9];           // the three cell edge vectors in grid units: cv[3 * c + d] = component c of edge d
+  int sv[9];           // lattice vector minus (cells per direction) cell edges: what a periodic wrap adds on top
+  float unit;          // Angstrom per grid point
+  float unit2;         // unit^2
+  float band;          // |d^2 - rc^2| below this (A^2): the list decision is retaken exactly
+};
+
 #if defined(__HIP_DEVICE_COMPILE__)
 #define NEPMI_ATOMIC_ADD(ptr, v) atomicAdd((ptr), (v))
 #define NEPMI_ATOMIC_OR(ptr, v) atomicOr((ptr), (v))
@@ -112,15 +131,20 @@ struct Bufs {
   // arrays through perm (ScatterAddBody); the fused run loops integrate on them directly.
   double* fo;
   // per-step compact list of the LDS-window path: window slots of the pairs inside the radial cutoff, written by
-  // the radial pass and walked by the force assembly (no out-of-cutoff candidates there), and the list-A index of
-  // every compact angular slot
+  // the radial pass and walked by the force assembly (no out-of-cutoff candidates there), and the reverse
+  // slot (in the neighbour's list A) of every compact angular slot
   int MN_rad;
-  unsigned short* ccode; // [MN_rad][N]
-  unsigned short* aidx;  // [MN_acomp][N]
+  unsigned short* ccode; // [MN_rad][N]; two-type shapes: neighbours of type 0 from row 0 up, of type 1 from row MN_rad-1 down
+  int* nn_t0;            // [N] entries at the front of ccode (all of them unless the shape has two types)
+  unsigned short* aidx;  // [MN_acomp][N] reverse slot (rev_ang) of every compact angular slot's pair
   // integrator state in internal order while a fused run loop owns the step (positions live in posq)
   double* vi; // [3][N]
   double* mi; // [N]
   double* ui; // [3][N] unwrapped positions, or nullptr
+  // fixed-point records of the current positions (written wherever posq is written) and the cell of every atom
+  WinRec* prec; // [N]
+  int* kcell;   // [N] cell index (brick-major numbering) at the last rebuild
+  WinGeom wg;
 };
 
 // planes of Bufs::fo
@@ -416,6 +440,73 @@ NEPMI_HD void cell_coords(const Bufs& b, int c, int& cx, int& cy, int& cz)
   cz = (bz << 2) | (l >> 4);
 }
 
+// PosQ::pad: how many lattice vectors the stored (wrapped) position has jumped since the list rebuild, two bits
+// per direction (two's complement: -1, 0, 1).  The LDS-window kernels undo the jump when they place an atom
+// relative to its cell of the rebuild-time grid; everything that applies a minimum image per pair ignores it.
+NEPMI_HD int pack_img(int n0, int n1, int n2) { return (n0 & 3) | ((n1 & 3) << 2) | ((n2 & 3) << 4); }
+NEPMI_HD int img_of(int pad, int d) { return (((pad >> (2 * d)) & 3) ^ 2) - 2; }
+
+// apply_mic (float) that also reports the lattice-vector multiples it removed
+NEPMI_HD void mic_f_img(const BoxD& box, float& x, float& y, float& z, int& n0, int& n1, int& n2)
+{
+  const float* H = box.hf;
+  n0 = n1 = n2 = 0;
+  if (box.ortho) {
+    if (box.pbc[0]) {
+      const float L = H[0], hl = L * 0.5f;
+      if (x < -hl) { x += L; n0 = -1; } else if (x > hl) { x -= L; n0 = 1; }
+    }
+    if (box.pbc[1]) {
+      const float L = H[4], hl = L * 0.5f;
+      if (y < -hl) { y += L; n1 = -1; } else if (y > hl) { y -= L; n1 = 1; }
+    }
+    if (box.pbc[2]) {
+      const float L = H[8], hl = L * 0.5f;
+      if (z < -hl) { z += L; n2 = -1; } else if (z > hl) { z -= L; n2 = 1; }
+    }
+  } else {
+    float sx = dot3f(H[9], x, H[10], y, H[11], z);
+    float sy = dot3f(H[12], x, H[13], y, H[14], z);
+    float sz = dot3f(H[15], x, H[16], y, H[17], z);
+    if (box.pbc[0]) { const float r = nearbyintf(sx); sx -= r; n0 = (int)r; }
+    if (box.pbc[1]) { const float r = nearbyintf(sy); sy -= r; n1 = (int)r; }
+    if (box.pbc[2]) { const float r = nearbyintf(sz); sz -= r; n2 = (int)r; }
+    x = dot3f(H[0], sx, H[1], sy, H[2], sz);
+    y = dot3f(H[3], sx, H[4], sy, H[5], sz);
+    z = dot3f(H[6], sx, H[7], sy, H[8], sz);
+  }
+}
+
+// Fixed-point record of atom k from its current (wrapped) position: the lattice-vector jumps since the rebuild are
+// undone, the periodic image next to the atom's cell of the rebuild-time grid is taken (this also puts the atoms of
+// the thin top layer that find_cell_id folds into cell 0 next to that cell), and the offset from the cell's corner
+// is rounded to the grid.  FP64 once per atom and step; the window kernels then only add integers.
+NEPMI_HD WinRec make_prec(const BoxD& box, const Bufs& b, int64_t k, const PosQ& p)
+{
+  const double* h = box.h;
+  int cx, cy, cz;
+  cell_coords(b, b.kcell[k], cx, cy, cz);
+  double sx = h[9] * p.x + h[10] * p.y + h[11] * p.z;
+  double sy = h[12] * p.x + h[13] * p.y + h[14] * p.z;
+  double sz = h[15] * p.x + h[16] * p.y + h[17] * p.z;
+  sx -= (double)img_of(p.pad, 0);
+  sy -= (double)img_of(p.pad, 1);
+  sz -= (double)img_of(p.pad, 2);
+  const double fx = (double)cx * b.wg.cell_frac[0], fy = (double)cy * b.wg.cell_frac[1], fz = (double)cz * b.wg.cell_frac[2];
+  if (box.pbc[0]) sx += nearbyint(fx + 0.5 * b.wg.cell_frac[0] - sx);
+  if (box.pbc[1]) sy += nearbyint(fy + 0.5 * b.wg.cell_frac[1] - sy);
+  if (box.pbc[2]) sz += nearbyint(fz + 0.5 * b.wg.cell_frac[2] - sz);
+  sx -= fx;
+  sy -= fy;
+  sz -= fz;
+  WinRec r;
+  r.x = (int)nearbyint((h[0] * sx + h[1] * sy + h[2] * sz) * b.wg.inv_unit);
+  r.y = (int)nearbyint((h[3] * sx + h[4] * sy + h[5] * sz) * b.wg.inv_unit);
+  r.z = (int)nearbyint((h[6] * sx + h[7] * sy + h[8] * sz) * b.wg.inv_unit);
+  r.w = (int)((unsigned)k | ((unsigned)p.type << kIdxBits));
+  return r;
+}
+
 struct BinAtomsBody {
   BoxD box;
   Bufs b;
@@ -486,6 +577,7 @@ struct SortCellsBody {
 
 // internal k <- caller perm[k]: packed position/type and the rebuild snapshot x0
 struct GatherSortedBody {
+  BoxD box;
   Bufs b;
   const double* pos;
   const int* type;
@@ -503,6 +595,9 @@ struct GatherSortedBody {
     b.x0s[b.N + k] = p.y;
     b.x0s[2 * b.N + k] = p.z;
     b.lvl[k] = b.level ? b.level[i] : (signed char)2;
+    b.kcell[k] = b.cid[i];
+    if (b.prec)
+      b.prec[k] = make_prec(box, b, k, p);
   }
 };
 
@@ -517,7 +612,7 @@ struct BuildListsBody {
   {
     const int64_t N = b.N;
     const PosQ p1 = b.posq[k];
-    const int c = b.cid[b.perm[k]];
+    const int c = b.kcell[k];
     int cx, cy, cz;
     cell_coords(b, c, cx, cy, cz);
     // periodic directions wrap (>= 5 bins guaranteed), non-periodic ones stop at the box edge
@@ -698,7 +793,7 @@ struct MarkGhostCellsBody {
   NEPMI_HD void operator()(int64_t k) const
   {
     if (b.lvl[k] < 2)
-      b.cell_ghost[b.cid[b.perm[k]]] = 1; // benign race: all writers store 1
+      b.cell_ghost[b.kcell[k]] = 1; // benign race: all writers store 1
   }
 };
 struct BrickOrderBody {
@@ -717,43 +812,6 @@ struct BrickOrderBody {
       b.flags[kFlagNumBoundary] = nbound;
   }
 };
-
-// PosQ::pad: how many lattice vectors the stored (wrapped) position has jumped since the list rebuild, two bits
-// per direction (two's complement: -1, 0, 1).  The LDS-window kernels undo the jump when they place an atom
-// relative to its cell of the rebuild-time grid; everything that applies a minimum image per pair ignores it.
-NEPMI_HD int pack_img(int n0, int n1, int n2) { return (n0 & 3) | ((n1 & 3) << 2) | ((n2 & 3) << 4); }
-NEPMI_HD int img_of(int pad, int d) { return (((pad >> (2 * d)) & 3) ^ 2) - 2; }
-
-// apply_mic (float) that also reports the lattice-vector multiples it removed
-NEPMI_HD void mic_f_img(const BoxD& box, float& x, float& y, float& z, int& n0, int& n1, int& n2)
-{
-  const float* H = box.hf;
-  n0 = n1 = n2 = 0;
-  if (box.ortho) {
-    if (box.pbc[0]) {
-      const float L = H[0], hl = L * 0.5f;
-      if (x < -hl) { x += L; n0 = -1; } else if (x > hl) { x -= L; n0 = 1; }
-    }
-    if (box.pbc[1]) {
-      const float L = H[4], hl = L * 0.5f;
-      if (y < -hl) { y += L; n1 = -1; } else if (y > hl) { y -= L; n1 = 1; }
-    }
-    if (box.pbc[2]) {
-      const float L = H[8], hl = L * 0.5f;
-      if (z < -hl) { z += L; n2 = -1; } else if (z > hl) { z -= L; n2 = 1; }
-    }
-  } else {
-    float sx = dot3f(H[9], x, H[10], y, H[11], z);
-    float sy = dot3f(H[12], x, H[13], y, H[14], z);
-    float sz = dot3f(H[15], x, H[16], y, H[17], z);
-    if (box.pbc[0]) { const float r = nearbyintf(sx); sx -= r; n0 = (int)r; }
-    if (box.pbc[1]) { const float r = nearbyintf(sy); sy -= r; n1 = (int)r; }
-    if (box.pbc[2]) { const float r = nearbyintf(sz); sz -= r; n2 = (int)r; }
-    x = dot3f(H[0], sx, H[1], sy, H[2], sz);
-    y = dot3f(H[3], sx, H[4], sy, H[5], sz);
-    z = dot3f(H[6], sx, H[7], sy, H[8], sz);
-  }
-}
 
 // gpu_check_atom_distance (neighbor.cu:646-684) fused with the per-step gather of the caller's
 // positions into internal order.  which: 0 all atoms, 1 owned only (level 2), 2 ghosts only.
@@ -778,10 +836,14 @@ struct CheckGatherBody {
     const float d2 = (dx * dx + dy * dy) + dz * dz;
     if (!((double)d2 <= 0.25)) // skin^2/4, skin = 1 A (neighbor.cuh:212); also true for NaN
       NEPMI_ATOMIC_OR(&b.flags[kFlagMoved], 1);
-    b.posq[k].x = x;
-    b.posq[k].y = y;
-    b.posq[k].z = z;
-    b.posq[k].pad = pack_img(n0, n1, n2);
+    PosQ p = b.posq[k];
+    p.x = x;
+    p.y = y;
+    p.z = z;
+    p.pad = pack_img(n0, n1, n2);
+    b.posq[k] = p;
+    if (b.prec)
+      b.prec[k] = make_prec(box, b, k, p);
   }
 };
 

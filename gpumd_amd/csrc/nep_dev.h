@@ -226,6 +226,46 @@ NEPMI_HD void cell_of(
   else { cz = cz < 0 ? 0 : (cz >= nbz ? nbz - 1 : cz); }
 }
 
+// ---- two-wide FP32 values -------------------------------------------------------------------------
+// gfx950 issues v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 (two FP32 operations per lane) at the rate of their
+// one-wide forms, and the per-pair arithmetic of the list-walking kernels is what bounds them (VALU issue, see
+// DESIGN.md): those kernels run two pairs of a lane side by side in one f2.  clang's ext_vector_type maps onto the
+// packed instructions (scalar operands are broadcast through op_sel); g++ (the test-only emulator) gets a plain
+// struct with the same interface.
+#if defined(__clang__)
+typedef float f2 __attribute__((ext_vector_type(2)));
+NEPMI_HD f2 mk2(float a, float b)
+{
+  f2 r;
+  r.x = a;
+  r.y = b;
+  return r;
+}
+NEPMI_HD f2 vfma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+#else
+struct f2 {
+  float x, y;
+};
+NEPMI_HD f2 mk2(float a, float b) { return f2{a, b}; }
+NEPMI_HD f2 operator+(f2 a, f2 b) { return f2{a.x + b.x, a.y + b.y}; }
+NEPMI_HD f2 operator-(f2 a, f2 b) { return f2{a.x - b.x, a.y - b.y}; }
+NEPMI_HD f2 operator*(f2 a, f2 b) { return f2{a.x * b.x, a.y * b.y}; }
+NEPMI_HD f2 operator-(f2 a) { return f2{-a.x, -a.y}; }
+NEPMI_HD f2 operator+(f2 a, float b) { return f2{a.x + b, a.y + b}; }
+NEPMI_HD f2 operator-(f2 a, float b) { return f2{a.x - b, a.y - b}; }
+NEPMI_HD f2 operator*(f2 a, float b) { return f2{a.x * b, a.y * b}; }
+NEPMI_HD f2 operator*(float a, f2 b) { return f2{a * b.x, a * b.y}; }
+NEPMI_HD f2 vfma(f2 a, f2 b, f2 c) { return f2{fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y)}; }
+#endif
+NEPMI_HD f2 bc2(float a) { return mk2(a, a); }
+NEPMI_HD float vfma(float a, float b, float c) { return fmaf(a, b, c); }
+template <class T>
+NEPMI_HD T vbc(float a);
+template <>
+NEPMI_HD float vbc<float>(float a) { return a; }
+template <>
+NEPMI_HD f2 vbc<f2>(float a) { return bc2(a); }
+
 // ---- radial functions -----------------------------------------------------------------------
 
 // cos(pi t) and sin(pi t) for t in [0, 1]: with y = t - 1/2, cos(pi t) = -sin(pi y) and
@@ -334,6 +374,97 @@ NEPMI_HD void basis_fn_fnp(float rcinv, float d, float fc, float fcp, float* fn,
     fnp[k] = ((float)k * u1) * dxdr * hfc + (t + 1.0f) * hfcp;
     fn[k] = (t + 1.0f) * hfc;
     const float u2 = 2.0f * x * u1 - u0;
+    u0 = u1;
+    u1 = u2;
+  }
+}
+
+// The same envelope and basis for a value type T = float or f2 (two pairs side by side); rcinv is a T as well
+// (per-pair cutoffs).  Arithmetic identical to the scalar functions above, element by element.
+template <class T>
+NEPMI_HD void cospi_sinpi_unit_v(T t, T& c, T& s)
+{
+  const T y = t - 0.5f, y2 = y * y;
+  T sp = vbc<T>(4.663028058e-04f);
+  sp = vfma(sp, y2, vbc<T>(-7.370430946e-03f));
+  sp = vfma(sp, y2, vbc<T>(8.214588661e-02f));
+  sp = vfma(sp, y2, vbc<T>(-5.992645293e-01f));
+  sp = vfma(sp, y2, vbc<T>(2.550164040e+00f));
+  sp = vfma(sp, y2, vbc<T>(-5.167712780e+00f));
+  sp = vfma(sp, y2, vbc<T>(3.141592654e+00f));
+  T cp = vbc<T>(-1.046381049e-04f);
+  cp = vfma(cp, y2, vbc<T>(1.929574309e-03f));
+  cp = vfma(cp, y2, vbc<T>(-2.580689139e-02f));
+  cp = vfma(cp, y2, vbc<T>(2.353306304e-01f));
+  cp = vfma(cp, y2, vbc<T>(-1.335262769e+00f));
+  cp = vfma(cp, y2, vbc<T>(4.058712126e+00f));
+  cp = vfma(cp, y2, vbc<T>(-4.934802201e+00f));
+  c = -(sp * y);
+  s = vfma(cp, y2, vbc<T>(1.0f));
+}
+// fc only (radial descriptor pass): the sine polynomial of cos(pi t)
+template <class T>
+NEPMI_HD void cutoff_fc_v(T rcinv, T d, T& fc)
+{
+  const T y = d * rcinv - 0.5f, y2 = y * y;
+  T sp = vbc<T>(4.663028058e-04f);
+  sp = vfma(sp, y2, vbc<T>(-7.370430946e-03f));
+  sp = vfma(sp, y2, vbc<T>(8.214588661e-02f));
+  sp = vfma(sp, y2, vbc<T>(-5.992645293e-01f));
+  sp = vfma(sp, y2, vbc<T>(2.550164040e+00f));
+  sp = vfma(sp, y2, vbc<T>(-5.167712780e+00f));
+  sp = vfma(sp, y2, vbc<T>(3.141592654e+00f));
+  fc = vfma(sp * y, vbc<T>(-0.5f), vbc<T>(0.5f));
+}
+template <class T>
+NEPMI_HD void cutoff_fc_fcp_v(T rcinv, T d, T& fc, T& fcp)
+{
+  T c, s;
+  cospi_sinpi_unit_v(d * rcinv, c, s);
+  fc = vfma(c, vbc<T>(0.5f), vbc<T>(0.5f));
+  fcp = s * rcinv * (-NEPMI_HALF_PI);
+}
+template <int K, class T>
+NEPMI_HD void basis_fn_v(T rcinv, T d, T fc, T* fn)
+{
+  const T dr = d * rcinv - 1.0f;
+  const T x = vfma(dr * 2.0f, dr, vbc<T>(-1.0f));
+  const T hfc = fc * 0.5f;
+  fn[0] = fc;
+  if (K >= 1)
+    fn[1] = vfma(x, hfc, hfc);
+  const T x2 = x * 2.0f;
+  T tm2 = vbc<T>(1.0f), tm1 = x;
+#pragma unroll
+  for (int k = 2; k <= K; ++k) {
+    const T t = vfma(x2, tm1, -tm2);
+    tm2 = tm1;
+    tm1 = t;
+    fn[k] = vfma(t, hfc, hfc);
+  }
+}
+// derivatives only (the force assembly never needs the values)
+template <int K, class T>
+NEPMI_HD void basis_fnp_v(T rcinv, T d, T fc, T fcp, T* fnp)
+{
+  const T dr = d * rcinv - 1.0f;
+  const T x = vfma(dr * 2.0f, dr, vbc<T>(-1.0f));
+  const T hfc = fc * 0.5f, hfcp = fcp * 0.5f;
+  const T a = dr * rcinv * 4.0f * hfc; // dx/dr * fc / 2
+  fnp[0] = fcp;
+  if (K >= 1)
+    fnp[1] = vfma(x, hfcp, a + hfcp);
+  const T x2 = x * 2.0f;
+  T tm2 = vbc<T>(1.0f), tm1 = x;
+  T u0 = vbc<T>(1.0f), u1 = x2; // U_0, U_1
+#pragma unroll
+  for (int k = 2; k <= K; ++k) {
+    const T t = vfma(x2, tm1, -tm2);
+    tm2 = tm1;
+    tm1 = t;
+    // dT_k/dx = k U_{k-1}
+    fnp[k] = vfma(u1 * (float)k, a, vfma(t, hfcp, hfcp));
+    const T u2 = vfma(x2, u1, -u0);
     u0 = u1;
     u1 = u2;
   }

@@ -180,6 +180,8 @@ struct ResidentStepBody {
     p.z = r[2];
     p.pad = pack_img(n0, n1, n2);
     b.posq[k] = p;
+    if (b.prec)
+      b.prec[k] = make_prec(box, b, k, p);
   }
 };
 

@@ -30,11 +30,6 @@ constexpr int kWinThreads = 256;
 constexpr int kWinCells = 512;
 constexpr int kWinMaxAtoms = 5000; // window capacity (LDS budget); larger windows take the gather path
 
-struct alignas(16) WinRec {
-  int x, y, z;
-  int w; // internal index | type << kIdxBits
-};
-
 #if defined(__HIP_DEVICE_COMPILE__)
 #define NEPMI_LDS(T) __attribute__((address_space(3))) T
 #else
@@ -50,21 +45,13 @@ struct WinLayout {
   NEPMI_HD int bytes() const { return off_rec() + 16 * wmax; }
 };
 
-// geometry of the fixed-point window, set at every list rebuild
-struct WinGeom {
-  double inv_unit;     // grid points per Angstrom
-  double cell_frac[3]; // fractional width of a cell along each lattice direction
-  float unit;          // Angstrom per grid point
-  float unit2;         // unit^2
-  float band;          // |d^2 - rc^2| below this (A^2): the list decision is retaken exactly
-};
-
-// Staging, shared by the two passes (identical window contents and slot order in both).
+// Staging, shared by the two passes (identical window contents and slot order in both): the records of the window
+// cells' atoms are copied from Bufs::prec (fixed point, relative to the corner of the atom's own cell) with the
+// integer offset of that cell from the window centre added -- no FP64, no search.
 struct WinStage {
   BoxD box;
   Bufs b;
   WinLayout lay;
-  WinGeom g;
 
   NEPMI_HD void brick_coords(int64_t brick, int& bx, int& by, int& bz) const
   {
@@ -100,43 +87,25 @@ struct WinStage {
       woff[kWinCells] = 0;
   }
 
-  // fixed-point position of an atom placed next to the point with fractional coordinates (fx, fy, fz)
-  // (a cell centre for window atoms, the window centre for the brick's own atoms), relative to the
-  // window centre c0
-  NEPMI_HD void place(const PosQ& p, const double* c0, double fx, double fy, double fz, int& qx, int& qy, int& qz) const
+  // offset of window cell (wx, wy, wz) of brick (bx, by, bz) from the window centre (the corner shared by window
+  // cells 3 and 4), grid units.  The cells do not tile the box exactly (the last one is wider, find_cell_id folds
+  // the remainder into cell 0): a cell reached through a periodic wrap sits one lattice vector away, which is the
+  // uniform cell spacing plus WinGeom::sv.
+  NEPMI_HD void cell_offset(int bx, int by, int bz, int wx, int wy, int wz, int& qx, int& qy, int& qz) const
   {
-    const double* h = box.h;
-    double sx = h[9] * p.x + h[10] * p.y + h[11] * p.z;
-    double sy = h[12] * p.x + h[13] * p.y + h[14] * p.z;
-    double sz = h[15] * p.x + h[16] * p.y + h[17] * p.z;
-    // undo the lattice-vector jumps since the rebuild, then take the image nearest to the reference point
-    sx -= (double)img_of(p.pad, 0);
-    sy -= (double)img_of(p.pad, 1);
-    sz -= (double)img_of(p.pad, 2);
-    if (box.pbc[0]) sx += nearbyint(fx - sx);
-    if (box.pbc[1]) sy += nearbyint(fy - sy);
-    if (box.pbc[2]) sz += nearbyint(fz - sz);
-    sx -= c0[0];
-    sy -= c0[1];
-    sz -= c0[2];
-    const double rx = h[0] * sx + h[1] * sy + h[2] * sz;
-    const double ry = h[3] * sx + h[4] * sy + h[5] * sz;
-    const double rz = h[6] * sx + h[7] * sy + h[8] * sz;
-    qx = (int)nearbyint(rx * g.inv_unit);
-    qy = (int)nearbyint(ry * g.inv_unit);
-    qz = (int)nearbyint(rz * g.inv_unit);
+    const int* cv = b.wg.cv;
+    const int* sv = b.wg.sv;
+    const int ux = wx - 4, uy = wy - 4, uz = wz - 4;
+    const int cx = 4 * bx - 2 + wx, cy = 4 * by - 2 + wy, cz = 4 * bz - 2 + wz;
+    const int sx = box.pbc[0] ? (cx < 0 ? -1 : (cx >= b.nbx ? 1 : 0)) : 0;
+    const int sy = box.pbc[1] ? (cy < 0 ? -1 : (cy >= b.nby ? 1 : 0)) : 0;
+    const int sz = box.pbc[2] ? (cz < 0 ? -1 : (cz >= b.nbz ? 1 : 0)) : 0;
+    qx = ux * cv[0] + uy * cv[1] + uz * cv[2] + sx * sv[0] + sy * sv[1] + sz * sv[2];
+    qy = ux * cv[3] + uy * cv[4] + uz * cv[5] + sx * sv[3] + sy * sv[4] + sz * sv[5];
+    qz = ux * cv[6] + uy * cv[7] + uz * cv[8] + sx * sv[6] + sy * sv[7] + sz * sv[8];
   }
 
-  NEPMI_HD void window_centre(int64_t brick, double* c0) const
-  {
-    int bx, by, bz;
-    brick_coords(brick, bx, by, bz);
-    c0[0] = (double)(4 * bx + 2) * g.cell_frac[0];
-    c0[1] = (double)(4 * by + 2) * g.cell_frac[1];
-    c0[2] = (double)(4 * bz + 2) * g.cell_frac[2];
-  }
-
-  // phase 3 (all threads, after the scan of woff): copy the window atoms
+  // phase 3 (all threads, after the scan of woff): copy the window atoms, one cell per thread and turn
   template <class LC>
   NEPMI_HD void stage_copy(int64_t brick, LC lds, int tid, int nth) const
   {
@@ -145,25 +114,21 @@ struct WinStage {
     NEPMI_LDS(WinRec)* rec = (NEPMI_LDS(WinRec)*)(lds + lay.off_rec());
     int bx, by, bz;
     brick_coords(brick, bx, by, bz);
-    double c0[3];
-    window_centre(brick, c0);
-    const int W = woff[kWinCells] < lay.wmax ? woff[kWinCells] : lay.wmax;
-    for (int w = tid; w < W; w += nth) {
-      int lo = 0, hi = kWinCells - 1; // largest wc with woff[wc] <= w
-      while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (woff[mid] <= w) lo = mid; else hi = mid - 1;
+    for (int wc = tid; wc < kWinCells; wc += nth) {
+      const int w0 = woff[wc];
+      int cnt = woff[wc + 1] - w0;
+      if (w0 + cnt > lay.wmax)
+        cnt = lay.wmax - w0; // never beyond the LDS capacity (the engine sizes wmax from the fullest window)
+      const int j0 = wstart[wc];
+      int qx, qy, qz;
+      cell_offset(bx, by, bz, wc & 7, (wc >> 3) & 7, wc >> 6, qx, qy, qz);
+      for (int a = 0; a < cnt; ++a) {
+        WinRec r = b.prec[j0 + a];
+        r.x += qx;
+        r.y += qy;
+        r.z += qz;
+        rec[w0 + a] = r;
       }
-      const int j = wstart[lo] + (w - woff[lo]);
-      const PosQ p = b.posq[j];
-      // centre of the (unwrapped) window cell in fractional coordinates
-      const double fx = ((double)(4 * bx - 2 + (lo & 7)) + 0.5) * g.cell_frac[0];
-      const double fy = ((double)(4 * by - 2 + ((lo >> 3) & 7)) + 0.5) * g.cell_frac[1];
-      const double fz = ((double)(4 * bz - 2 + (lo >> 6)) + 0.5) * g.cell_frac[2];
-      WinRec r;
-      place(p, c0, fx, fy, fz, r.x, r.y, r.z);
-      r.w = (int)((unsigned)j | ((unsigned)p.type << kIdxBits));
-      rec[w] = r;
     }
   }
 
@@ -173,16 +138,30 @@ struct WinStage {
     a1 = b.cell_count[brick * 64 + 64];
   }
 
-  // the brick's own atom k in the same fixed-point frame
-  NEPMI_HD void place_own(int64_t brick, const PosQ& p, int& qx, int& qy, int& qz) const
+  // the brick's own atom k in the same frame: its cell is one of the 4x4x4 cells in the middle of the window
+  NEPMI_HD void place_own(int64_t k, int& qx, int& qy, int& qz) const
   {
-    double c0[3];
-    window_centre(brick, c0);
-    place(p, c0, c0[0], c0[1], c0[2], qx, qy, qz);
+    const int l = b.kcell[k] & 63;
+    cell_offset(0, 0, 0, (l & 3) + 2, ((l >> 2) & 3) + 2, (l >> 4) + 2, qx, qy, qz); // never through a wrap
+    const WinRec r = b.prec[k];
+    qx += r.x;
+    qy += r.y;
+    qz += r.z;
   }
 };
 
 constexpr int kWinG = 4; // candidates whose LDS look-ups and arithmetic are interleaved
+
+// build-time switches for A/B measurements (profiles/ab_variants.sh); the defaults are the product
+#ifndef NEPMI_RW_PACK
+#define NEPMI_RW_PACK 1
+#endif
+#ifndef NEPMI_FW_PACK
+#define NEPMI_FW_PACK 1
+#endif
+#ifndef NEPMI_FW_WAVES
+#define NEPMI_FW_WAVES 4
+#endif
 
 template <class S>
 struct RadialWinBody {
@@ -218,9 +197,9 @@ struct RadialWinBody {
     const PosQ p1 = b.posq[k];
     const int t1 = p1.type;
     int ox, oy, oz;
-    st.place_own(brick, p1, ox, oy, oz);
+    st.place_own(k, ox, oy, oz);
     const float rc1 = m.rc_r[t1], rca1 = m.rc_a[t1];
-    const float unit = st.g.unit, unit2 = st.g.unit2, band = st.g.band;
+    const float unit = st.b.wg.unit, unit2 = st.b.wg.unit2, band = st.b.wg.band;
     constexpr int TSM = S::TS > 0 ? S::TS : 1;
     float Ssum[TSM][S::KRM + 1];
     float q[S::NRM + 1];
@@ -234,26 +213,37 @@ struct RadialWinBody {
       q[n] = 0.0f;
 
     const int na = b.nn_ang[k], nbn = b.nn_skin[k];
-    int cnt = 0, ca = 0;
+    int cnt = 0, cnt1 = 0, ca = 0; // cnt: entries at the front of ccode, cnt1: at its back (type-1 neighbours)
     F4* __restrict__ acomp = b.acomp + k;
     unsigned short* __restrict__ amap = b.amap + k;
     unsigned short* __restrict__ aidx = b.aidx + k;
     unsigned short* __restrict__ ccode = b.ccode + k;
 
-    // one candidate: window slot -> pair vector, list decisions, accumulation
-    auto candidate = [&](const unsigned code, const int idx, const bool live, auto in_list_a) {
+    // list decisions and bookkeeping of one candidate (scalar): LDS slot -> integer pair vector, d^2, cutoff tests
+    // (retaken exactly inside the band), compact angular record, compact radial entry
+    struct Cand {
+      float fx, fy, fz, d2;
+      int t2;
+      bool inside;
+    };
+    auto decide = [&](const unsigned code, const int idx, const bool live, auto in_list_a) -> Cand {
       constexpr bool LIST_A = decltype(in_list_a)::value;
+      Cand c;
       const int slot = woff[code >> 7] + (int)(code & 127u);
       const WinRec r = wrec[slot];
-      const float fx = (float)(r.x - ox), fy = (float)(r.y - oy), fz = (float)(r.z - oz);
-      const float d2 = dot3f(fx, fx, fy, fy, fz, fz) * unit2;
-      const int t2 = (int)((unsigned)r.w >> kIdxBits);
-      const float rc = m.uniform_rc ? m.rc_r_max : (rc1 + m.rc_r[t2]) * 0.5f;
-      const float rca = m.uniform_rc ? m.rc_a_max : (rca1 + m.rc_a[t2]) * 0.5f;
-      bool inside = d2 < rc * rc;
-      bool ang = LIST_A && d2 < rca * rca;
+      c.fx = (float)(r.x - ox);
+      c.fy = (float)(r.y - oy);
+      c.fz = (float)(r.z - oz);
+      c.d2 = dot3f(c.fx, c.fx, c.fy, c.fy, c.fz, c.fz) * unit2;
+      c.t2 = (int)((unsigned)r.w >> kIdxBits);
+      const float rc = m.uniform_rc ? m.rc_r_max : (rc1 + m.rc_r[c.t2]) * 0.5f;
+      const float rca = m.uniform_rc ? m.rc_a_max : (rca1 + m.rc_a[c.t2]) * 0.5f;
+      const float er = c.d2 - rc * rc, ea = c.d2 - rca * rca;
+      bool inside = er < 0.0f;
+      bool ang = LIST_A && ea < 0.0f;
       // within the band of a cutoff the decision is retaken with the reference's arithmetic (rare)
-      if (live && (fabsf(d2 - rc * rc) < band || (LIST_A && fabsf(d2 - rca * rca) < band))) {
+      const float near = LIST_A ? fminf(fabsf(er), fabsf(ea)) : fabsf(er);
+      if (live && near < band) {
         float ex, ey, ez;
         const float d2e = pair_geometry(st.box, p1, b.posq[(unsigned)r.w & (unsigned)kIdxMask], ex, ey, ez);
         inside = d2e < rc * rc;
@@ -266,12 +256,12 @@ struct RadialWinBody {
         if (ang) {
           if (ca < b.MN_acomp) {
             F4 e;
-            e.x = fx * unit;
-            e.y = fy * unit;
-            e.z = fz * unit;
+            e.x = c.fx * unit;
+            e.y = c.fy * unit;
+            e.z = c.fz * unit;
             e.w = r.w;
             acomp[(int64_t)ca * N] = e;
-            aidx[(int64_t)ca * N] = (unsigned short)idx;
+            aidx[(int64_t)ca * N] = b.rev_ang[(int64_t)idx * N + k]; // reverse slot of this pair in j's list A
             cs = (unsigned short)ca;
           }
           ++ca;
@@ -279,46 +269,102 @@ struct RadialWinBody {
         amap[(int64_t)idx * N] = cs;
       }
       if (inside) {
-        if (cnt < b.MN_rad)
-          ccode[(int64_t)cnt * N] = (unsigned short)slot;
-        ++cnt;
+        // two-type shapes: the compact list is partitioned by the neighbour's type (front / back), so that the force
+        // assembly walks type-pure segments with one row of its own table in registers
+        int pos;
+        if (S::TS == 2 && c.t2 == 1) {
+          pos = b.MN_rad - 1 - cnt1;
+          ++cnt1;
+        } else {
+          pos = cnt;
+          ++cnt;
+        }
+        if (cnt + cnt1 <= b.MN_rad)
+          ccode[(int64_t)pos * N] = (unsigned short)slot;
       }
-      if (S::TS > 0) {
-        // branch-free accumulation: entries outside the cutoff run the same arithmetic with weight 0 (the
-        // envelope is evaluated at min(d, rc) to stay finite)
+      c.inside = inside;
+      return c;
+    };
+
+    // accumulation of one candidate, one-wide: shapes without register-resident per-type sums (many types,
+    // run-time shape) contract the coefficients per pair
+    auto accumulate1 = [&](const Cand& c) {
+      if (S::TS > 0) { // one-wide form of accumulate2 (kept for A/B measurements)
+        const float rc = m.uniform_rc ? m.rc_r_max : (rc1 + m.rc_r[c.t2]) * 0.5f;
         float d, dinv;
-        dist_and_inv(d2, d, dinv);
+        dist_and_inv(c.d2, d, dinv);
         const float rcinv = m.uniform_rc ? m.rcinv_r : fast_rcp(rc);
-        const float dc = inside ? d : rc;
+        const float dc = d < rc ? d : rc;
         float fc;
         cutoff_fc(rcinv, dc, fc);
         float fn[S::KRM + 1];
         basis_fn<S::KRM>(rcinv, dc, fc, fn);
 #pragma unroll
         for (int t = 0; t < TSM; ++t) {
-          const float w = (inside && (TSM == 1 || t2 == t)) ? 1.0f : 0.0f;
+          const float w = (c.inside && (TSM == 1 || c.t2 == t)) ? 1.0f : 0.0f;
 #pragma unroll
           for (int kk = 0; kk <= S::KRM; ++kk)
             Ssum[t][kk] = fmaf(w, fn[kk], Ssum[t][kk]);
         }
-      } else if (inside) {
-        float d, dinv;
-        dist_and_inv(d2, d, dinv);
-        const float rcinv = fast_rcp(rc);
-        float fc;
-        cutoff_fc(rcinv, d, fc);
-        float fn[S::KRM + 1];
-        if (S::fixed)
-          basis_fn<S::KRM>(rcinv, d, fc, fn);
-        else
-          basis_fn_rt(KR, rcinv, d, fc, fn);
-        const float* c = m.c_rad + (size_t)(t1 * m.T + t2) * (NR + 1) * (KR + 1);
-        for (int n = 0; n <= NR; ++n) {
-          float gsum = 0.0f;
-          for (int kk = 0; kk <= KR; ++kk)
-            gsum += fn[kk] * c[n * (KR + 1) + kk];
-          q[n] += gsum;
-        }
+        return;
+      }
+      if (!c.inside)
+        return;
+      const float rc = m.uniform_rc ? m.rc_r_max : (rc1 + m.rc_r[c.t2]) * 0.5f;
+      float d, dinv;
+      dist_and_inv(c.d2, d, dinv);
+      const float rcinv = fast_rcp(rc);
+      const float dc = d < rc ? d : rc;
+      float fc;
+      cutoff_fc(rcinv, dc, fc);
+      float fn[S::KRM + 1];
+      if (S::fixed)
+        basis_fn<S::KRM>(rcinv, dc, fc, fn);
+      else
+        basis_fn_rt(KR, rcinv, dc, fc, fn);
+      const float* cc = m.c_rad + (size_t)(t1 * m.T + c.t2) * (NR + 1) * (KR + 1);
+      for (int n = 0; n <= NR; ++n) {
+        float gsum = 0.0f;
+        for (int kk = 0; kk <= KR; ++kk)
+          gsum += fn[kk] * cc[n * (KR + 1) + kk];
+        q[n] += gsum;
+      }
+    };
+    // accumulation of two candidates side by side (f2: packed FP32), branch-free: entries outside the cutoff run
+    // the same arithmetic with weight 0 (the envelope is evaluated at min(d, rc) and stays finite)
+    f2 Ssum2[TSM][S::KRM + 1];
+#pragma unroll
+    for (int t = 0; t < TSM; ++t)
+#pragma unroll
+      for (int kk = 0; kk <= S::KRM; ++kk)
+        Ssum2[t][kk] = bc2(0.0f);
+    auto accumulate2 = [&](const Cand& c0, const Cand& c1) {
+      float rc0, rc1v, ri0, ri1;
+      if (m.uniform_rc) {
+        rc0 = rc1v = m.rc_r_max;
+        ri0 = ri1 = m.rcinv_r;
+      } else {
+        rc0 = (rc1 + m.rc_r[c0.t2]) * 0.5f;
+        rc1v = (rc1 + m.rc_r[c1.t2]) * 0.5f;
+        ri0 = fast_rcp(rc0);
+        ri1 = fast_rcp(rc1v);
+      }
+      float d0, d1, i0, i1;
+      dist_and_inv(c0.d2, d0, i0);
+      dist_and_inv(c1.d2, d1, i1);
+      const f2 dc = mk2(d0 < rc0 ? d0 : rc0, d1 < rc1v ? d1 : rc1v);
+      const f2 rcinv = mk2(ri0, ri1);
+      f2 fc;
+      cutoff_fc_v(rcinv, dc, fc);
+      f2 fn[S::KRM + 1];
+      basis_fn_v<S::KRM>(rcinv, dc, fc, fn);
+#pragma unroll
+      for (int t = 0; t < TSM; ++t) {
+        const f2 w = mk2((c0.inside && (TSM == 1 || c0.t2 == t)) ? 1.0f : 0.0f,
+                         (c1.inside && (TSM == 1 || c1.t2 == t)) ? 1.0f : 0.0f);
+#pragma unroll
+        for (int kk = 0; kk <= S::KRM; ++kk)
+          Ssum2[t][kk] = vfma(w, fn[kk], Ssum2[t][kk]);
       }
     };
 
@@ -334,9 +380,19 @@ struct RadialWinBody {
           const int idx = s0 + kWinG + u;
           nxt[u] = codes[(int64_t)(idx < nn ? idx : nn - 1) * N];
         }
+        Cand c[kWinG];
 #pragma unroll
         for (int u = 0; u < kWinG; ++u)
-          candidate(cur[u], s0 + u, s0 + u < nn, in_list_a);
+          c[u] = decide(cur[u], s0 + u, s0 + u < nn, in_list_a);
+        if (S::TS > 0 && NEPMI_RW_PACK) {
+#pragma unroll
+          for (int u = 0; u < kWinG; u += 2)
+            accumulate2(c[u], c[u + 1]);
+        } else {
+#pragma unroll
+          for (int u = 0; u < kWinG; ++u)
+            accumulate1(c[u]);
+        }
 #pragma unroll
         for (int u = 0; u < kWinG; ++u)
           cur[u] = nxt[u];
@@ -344,12 +400,20 @@ struct RadialWinBody {
     };
     walk(b.code_ang + k, na, std::true_type{});
     walk(b.code_skin + k, nbn, std::false_type{});
+    if (S::TS > 0 && NEPMI_RW_PACK) {
+#pragma unroll
+      for (int t = 0; t < TSM; ++t)
+#pragma unroll
+        for (int kk = 0; kk <= S::KRM; ++kk)
+          Ssum[t][kk] = Ssum2[t][kk].x + Ssum2[t][kk].y;
+    }
 
-    if (ca > b.MN_acomp || cnt > b.MN_rad) {
+    if (ca > b.MN_acomp || cnt + cnt1 > b.MN_rad) {
       NEPMI_ATOMIC_OR(&b.flags[kFlagOverflow], 4);
       ca = ca > b.MN_acomp ? b.MN_acomp : ca;
     }
-    b.nn_rad[k] = cnt;
+    b.nn_rad[k] = cnt + cnt1;
+    b.nn_t0[k] = cnt;
     b.nn_angstep[k] = ca;
 
     if (S::TS > 0) {
@@ -383,12 +447,144 @@ struct RadialWinBody {
   }
 };
 
+// Angular part of the force assembly: F_i += f12 - f21, W_i += r12 (x) f21 over this step's angular pairs (compact
+// records), f21 found through the reverse slot the radial pass stored next to the record (arev) and j's slot map.
+// The chain arev -> amap[.][j] -> f12[.][j] is two dependent gathers per pair: four pairs are kept in flight.
+template <int LANES>
+NEPMI_HD void win_force_angular(const Bufs& b, int64_t k, int part, float* F, float* Wa)
+{
+  const int64_t N = b.N;
+  const int nang = b.nn_angstep[k];
+  const F4* __restrict__ acomp = b.acomp + k;
+  const F4* __restrict__ f12o = b.f12 + k;
+  const unsigned short* __restrict__ arev = b.aidx + k;
+  constexpr int C = 4;
+  for (int a0 = part; a0 < nang; a0 += C * LANES) {
+    F4 e[C], fa[C], fb[C];
+    int rs[C];
+    unsigned short ap[C];
+#pragma unroll
+    for (int u = 0; u < C; ++u) {
+      const int a = a0 + u * LANES;
+      const int aa = a < nang ? a : part; // a valid slot (a0 = part < nang); its contribution is dropped below
+      e[u] = acomp[(int64_t)aa * N];
+      fa[u] = f12o[(int64_t)aa * N];
+      rs[u] = arev[(int64_t)aa * N];
+    }
+#pragma unroll
+    for (int u = 0; u < C; ++u) {
+      const int j = (int)((unsigned)e[u].w & (unsigned)kIdxMask);
+      ap[u] = rs[u] != (int)kNoSlot ? b.amap[(int64_t)rs[u] * N + j] : kNoSlot;
+    }
+#pragma unroll
+    for (int u = 0; u < C; ++u) {
+      // j has no compact slot for this pair only if its per-step angular list overflowed (MN_angular): that is
+      // reported through the overflow flag; never index with kNoSlot
+      const int j = (int)((unsigned)e[u].w & (unsigned)kIdxMask);
+      fb[u].x = fb[u].y = fb[u].z = 0.0f;
+      fb[u].w = 0;
+      if (ap[u] != kNoSlot)
+        fb[u] = b.f12[(int64_t)ap[u] * N + j];
+    }
+#pragma unroll
+    for (int u = 0; u < C; ++u) {
+      const float w = a0 + u * LANES < nang ? 1.0f : 0.0f;
+      const float gx = w * fb[u].x, gy = w * fb[u].y, gz = w * fb[u].z;
+      F[0] += w * fa[u].x - gx;
+      F[1] += w * fa[u].y - gy;
+      F[2] += w * fa[u].z - gz;
+      Wa[0] += e[u].x * gx;
+      Wa[1] += e[u].y * gy;
+      Wa[2] += e[u].z * gz;
+      Wa[3] += e[u].x * gy;
+      Wa[4] += e[u].x * gz;
+      Wa[5] += e[u].y * gz;
+      Wa[6] += e[u].y * gx;
+      Wa[7] += e[u].z * gx;
+      Wa[8] += e[u].z * gy;
+    }
+  }
+}
+
+// Radial pair forces of one type-pure segment of the compact list, two pairs side by side in f2 values (packed
+// FP32): envelope, Chebyshev derivatives, the two table contractions and the force / virial sums.  `lanes` lanes
+// share the atom, lane `part` takes every lanes-th chunk of two entries; entry i of the segment sits at row
+// row0 + i * row_step of ccode.  rows(slot, Aj): the neighbours' table rows for the own type (gathered from L2 or
+// read from LDS).  Sums are in grid units.
+template <class S, class LC, class Rows>
+NEPMI_HD void win_force_segment(
+  const ModelD& m, const unsigned short* __restrict__ ccode, int64_t N, LC wrec, const Rows& rows, const float* Aown,
+  int count, int row0, int row_step, int part, int lanes, int ox, int oy, int oz, float rc1, float unit2, f2* Fr2, f2* W2)
+{
+  auto load_codes = [&](int s0, unsigned& c0, unsigned& c1) {
+    const int i0 = s0 < count ? s0 : count - 1, i1 = s0 + 1 < count ? s0 + 1 : count - 1;
+    c0 = ccode[(int64_t)(row0 + i0 * row_step) * N];
+    c1 = ccode[(int64_t)(row0 + i1 * row_step) * N];
+  };
+  const int stride = 2 * lanes;
+  unsigned cur0 = 0, cur1 = 0, nxt0 = 0, nxt1 = 0;
+  if (2 * part < count)
+    load_codes(2 * part, cur0, cur1);
+  for (int s0 = 2 * part; s0 < count; s0 += stride) {
+    if (s0 + stride < count)
+      load_codes(s0 + stride, nxt0, nxt1); // in flight while this chunk is processed
+    const WinRec r0 = wrec[cur0], r1 = wrec[cur1];
+    f2 Aj[S::KRM + 1];
+    rows(cur0, cur1, r0, r1, Aj);
+    const f2 fx = mk2((float)(r0.x - ox), (float)(r1.x - ox));
+    const f2 fy = mk2((float)(r0.y - oy), (float)(r1.y - oy));
+    const f2 fz = mk2((float)(r0.z - oz), (float)(r1.z - oz));
+    const f2 d2 = vfma(fz, fz, vfma(fy, fy, fx * fx)) * unit2;
+    float d0, d1, i0, i1;
+    dist_and_inv(d2.x, d0, i0);
+    dist_and_inv(d2.y, d1, i1);
+    float rc0, rc1v, ri0, ri1;
+    if (m.uniform_rc) {
+      rc0 = rc1v = m.rc_r_max;
+      ri0 = ri1 = m.rcinv_r;
+    } else {
+      rc0 = (rc1 + m.rc_r[(unsigned)r0.w >> kIdxBits]) * 0.5f;
+      rc1v = (rc1 + m.rc_r[(unsigned)r1.w >> kIdxBits]) * 0.5f;
+      ri0 = fast_rcp(rc0);
+      ri1 = fast_rcp(rc1v);
+    }
+    // a pair the exact test admitted can sit a rounding above rc here: the envelope is clamped there
+    const f2 dc = mk2(d0 < rc0 ? d0 : rc0, d1 < rc1v ? d1 : rc1v);
+    const f2 rcinv = mk2(ri0, ri1);
+    f2 fc, fcp;
+    cutoff_fc_fcp_v(rcinv, dc, fc, fcp);
+    f2 fnp[S::KRM + 1];
+    basis_fnp_v<S::KRM>(rcinv, dc, fc, fcp, fnp);
+    f2 s12 = bc2(0.0f), s21 = bc2(0.0f);
+#pragma unroll
+    for (int kk = 0; kk <= S::KRM; ++kk) {
+      s12 = vfma(fnp[kk], bc2(Aown[kk]), s12);
+      s21 = vfma(fnp[kk], Aj[kk], s21);
+    }
+    const f2 wgt = mk2(i0, s0 + 1 < count ? i1 : 0.0f); // the entry past the end re-read the last slot
+    const f2 fs = (s12 + s21) * wgt; // f12 - f21 = fs * r12
+    const f2 bb = s21 * wgt;         // f21 = -bb * r12
+    Fr2[0] = vfma(fs, fx, Fr2[0]);
+    Fr2[1] = vfma(fs, fy, Fr2[1]);
+    Fr2[2] = vfma(fs, fz, Fr2[2]);
+    const f2 bx = bb * fx, by = bb * fy, bz = bb * fz;
+    W2[0] = vfma(-fx, bx, W2[0]);
+    W2[1] = vfma(-fy, by, W2[1]);
+    W2[2] = vfma(-fz, bz, W2[2]);
+    W2[3] = vfma(-fx, by, W2[3]);
+    W2[4] = vfma(-fx, bz, W2[4]);
+    W2[5] = vfma(-fy, bz, W2[5]);
+    cur0 = nxt0;
+    cur1 = nxt1;
+  }
+}
+
 template <class S>
 struct ForceWinBody {
   WinStage st;
   ModelD m;
   const int* frozen;
-  static constexpr int kMinWavesPerEu = 4; // <= 128 VGPRs: four 256-thread workgroups per CU
+  static constexpr int kMinWavesPerEu = NEPMI_FW_WAVES; // 4: <= 128 VGPRs, four 256-thread workgroups per CU
 
   NEPMI_HD int lds_bytes() const { return st.lay.bytes(); }
   NEPMI_HD int64_t map_brick(int64_t w) const { return w; }
@@ -411,9 +607,9 @@ struct ForceWinBody {
     const PosQ p1 = b.posq[k];
     const int t1 = p1.type;
     int ox, oy, oz;
-    st.place_own(brick, p1, ox, oy, oz);
+    st.place_own(k, ox, oy, oz);
     const float rc1 = m.rc_r[t1];
-    const float unit = st.g.unit, unit2 = st.g.unit2;
+    const float unit = st.b.wg.unit, unit2 = st.b.wg.unit2;
     const int KRP = b.KRP;
     const int arow = m.T * KRP;
     const float* __restrict__ atab = b.atab;
@@ -421,140 +617,116 @@ struct ForceWinBody {
     // ---- angular part: f12 - f21 of this step's angular pairs (compact records) ----
     float F[3] = {0, 0, 0};
     float Wa[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}; // xx yy zz xy xz yz yx zx zy
-    {
-      const int nang = b.nn_angstep[k];
-      const F4* __restrict__ acomp = b.acomp + k;
-      const F4* __restrict__ f12o = b.f12 + k;
-      const unsigned short* __restrict__ aidx = b.aidx + k;
-      const unsigned short* __restrict__ rev = b.rev_ang + k;
-      for (int a = 0; a < nang; ++a) {
-        const F4 e = acomp[(int64_t)a * N];
-        const F4 fa = f12o[(int64_t)a * N];
-        const int idx = aidx[(int64_t)a * N];
-        const int rs = rev[(int64_t)idx * N];
-        const int j = (int)((unsigned)e.w & (unsigned)kIdxMask);
-        const unsigned short ap = rs != (int)kNoSlot ? b.amap[(int64_t)rs * N + j] : kNoSlot;
-        // j has no compact slot for this pair only if its per-step angular list overflowed (MN_angular):
-        // that is reported through the overflow flag; never index with kNoSlot
-        F4 fb;
-        fb.x = fb.y = fb.z = 0.0f;
-        fb.w = 0;
-        if (ap != kNoSlot)
-          fb = b.f12[(int64_t)ap * N + j];
-        F[0] += fa.x - fb.x;
-        F[1] += fa.y - fb.y;
-        F[2] += fa.z - fb.z;
-        Wa[0] += e.x * fb.x;
-        Wa[1] += e.y * fb.y;
-        Wa[2] += e.z * fb.z;
-        Wa[3] += e.x * fb.y;
-        Wa[4] += e.x * fb.z;
-        Wa[5] += e.y * fb.z;
-        Wa[6] += e.y * fb.x;
-        Wa[7] += e.z * fb.x;
-        Wa[8] += e.z * fb.y;
-      }
-    }
+    win_force_angular<1>(b, k, 0, F, Wa);
 
     // ---- radial part over the compact list: every entry is a pair inside the cutoff ----
     constexpr int TSM = S::TS > 0 ? S::TS : 1;
-    float Aown[TSM][S::KRM + 1];
-    if (S::TS > 0) {
-#pragma unroll
-      for (int t = 0; t < TSM; ++t)
-#pragma unroll
-        for (int kk = 0; kk <= S::KRM; ++kk)
-          Aown[t][kk] = atab[(size_t)k * arow + t * KRP + kk];
-    }
     // accumulated in grid units (x, y, z of a pair are integers times `unit`): Fr = unit * sum, W = unit^2 * sum
     float Fr[3] = {0, 0, 0};
     float W[6] = {0, 0, 0, 0, 0, 0}; // symmetric: xx yy zz xy xz yz
     const int nrad = b.nn_rad[k] < b.MN_rad ? b.nn_rad[k] : b.MN_rad;
     const unsigned short* __restrict__ ccode = b.ccode + k;
-    constexpr int G = 2;
-    unsigned cur[G], nxt[G];
+    if (S::TS > 0 && NEPMI_FW_PACK) {
+      // type-pure segments of the compact list (front: neighbours of type 0, back: of type 1), packed arithmetic
+      f2 Fr2[3] = {bc2(0.0f), bc2(0.0f), bc2(0.0f)};
+      f2 W2[6] = {bc2(0.0f), bc2(0.0f), bc2(0.0f), bc2(0.0f), bc2(0.0f), bc2(0.0f)};
+      auto rows = [&](unsigned, unsigned, const WinRec& r0, const WinRec& r1, f2* Aj) {
+        const float* row0 = atab + (size_t)((unsigned)r0.w & (unsigned)kIdxMask) * arow + t1 * KRP;
+        const float* row1 = atab + (size_t)((unsigned)r1.w & (unsigned)kIdxMask) * arow + t1 * KRP;
 #pragma unroll
-    for (int u = 0; u < G; ++u)
-      cur[u] = nrad > 0 ? ccode[(int64_t)(u < nrad ? u : nrad - 1) * N] : 0u;
-    for (int s0 = 0; s0 < nrad; s0 += G) {
+        for (int kk = 0; kk <= S::KRM; ++kk)
+          Aj[kk] = mk2(row0[kk], row1[kk]);
+      };
+      const int n0 = b.nn_t0[k] < nrad ? b.nn_t0[k] : nrad;
 #pragma unroll
-      for (int u = 0; u < G; ++u) {
-        const int idx = s0 + G + u;
-        nxt[u] = ccode[(int64_t)(idx < nrad ? idx : nrad - 1) * N];
+      for (int t = 0; t < TSM; ++t) {
+        float Aown[S::KRM + 1];
+#pragma unroll
+        for (int kk = 0; kk <= S::KRM; ++kk)
+          Aown[kk] = atab[(size_t)k * arow + t * KRP + kk];
+        win_force_segment<S>(m, ccode, N, wrec, rows, Aown, t == 0 ? n0 : nrad - n0, t == 0 ? 0 : b.MN_rad - 1,
+                             t == 0 ? 1 : -1, 0, 1, ox, oy, oz, rc1, unit2, Fr2, W2);
       }
-      WinRec rr[G];
-      float Aj[G][S::KRM + 1];
 #pragma unroll
-      for (int u = 0; u < G; ++u) {
-        rr[u] = wrec[cur[u]];
-        const int j = (int)((unsigned)rr[u].w & (unsigned)kIdxMask);
-        const float* row = atab + (size_t)j * arow + t1 * KRP;
+      for (int d = 0; d < 3; ++d)
+        Fr[d] = Fr2[d].x + Fr2[d].y;
 #pragma unroll
-        for (int kk = 0; kk <= S::KRM; ++kk) {
-          if (!S::fixed && kk > KR)
-            break;
-          Aj[u][kk] = row[kk];
+      for (int d = 0; d < 6; ++d)
+        W[d] = W2[d].x + W2[d].y;
+    } else {
+      // one-wide form: the neighbour-type row of the own table is gathered per pair (many types / run-time shape)
+      constexpr int G = 2;
+      unsigned cur[G], nxt[G];
+#pragma unroll
+      for (int u = 0; u < G; ++u)
+        cur[u] = nrad > 0 ? ccode[(int64_t)(u < nrad ? u : nrad - 1) * N] : 0u;
+      for (int s0 = 0; s0 < nrad; s0 += G) {
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+          const int idx = s0 + G + u;
+          nxt[u] = ccode[(int64_t)(idx < nrad ? idx : nrad - 1) * N];
         }
-      }
+        WinRec rr[G];
+        float Aj[G][S::KRM + 1];
 #pragma unroll
-      for (int u = 0; u < G; ++u) {
-        const bool live = s0 + u < nrad;
-        const WinRec r = rr[u];
-        const float fx = (float)(r.x - ox), fy = (float)(r.y - oy), fz = (float)(r.z - oz);
-        const float d2 = dot3f(fx, fx, fy, fy, fz, fz) * unit2;
-        const int t2 = (int)((unsigned)r.w >> kIdxBits);
-        float d, dinv;
-        dist_and_inv(d2, d, dinv);
-        const float rc = m.uniform_rc ? m.rc_r_max : (rc1 + m.rc_r[t2]) * 0.5f;
-        const float rcinv = m.uniform_rc ? m.rcinv_r : fast_rcp(rc);
-        // a pair the exact test admitted can sit a rounding above rc here: the envelope is clamped there
-        const float dc = d < rc ? d : rc;
-        float fc, fcp;
-        cutoff_fc_fcp(rcinv, dc, fc, fcp);
-        float fn[S::KRM + 1], fnp[S::KRM + 1];
-        if (S::fixed)
-          basis_fn_fnp<S::KRM>(rcinv, dc, fc, fcp, fn, fnp);
-        else
-          basis_fn_fnp_rt(KR, rcinv, dc, fc, fcp, fn, fnp);
-        float s12 = 0.0f, s21 = 0.0f;
-        if (S::TS > 0) {
+        for (int u = 0; u < G; ++u) {
+          rr[u] = wrec[cur[u]];
+          const int j = (int)((unsigned)rr[u].w & (unsigned)kIdxMask);
+          const float* row = atab + (size_t)j * arow + t1 * KRP;
 #pragma unroll
-          for (int t = 0; t < TSM; ++t) {
-            float a = 0.0f;
-#pragma unroll
-            for (int kk = 0; kk <= S::KRM; ++kk)
-              a = fmaf(fnp[kk], Aown[t][kk], a);
-            if (TSM == 1 || t2 == t)
-              s12 = a;
+          for (int kk = 0; kk <= S::KRM; ++kk) {
+            if (!S::fixed && kk > KR)
+              break;
+            Aj[u][kk] = row[kk];
           }
-        } else {
+        }
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+          const bool live = s0 + u < nrad;
+          const WinRec r = rr[u];
+          const float fx = (float)(r.x - ox), fy = (float)(r.y - oy), fz = (float)(r.z - oz);
+          const float d2 = dot3f(fx, fx, fy, fy, fz, fz) * unit2;
+          const int t2 = (int)((unsigned)r.w >> kIdxBits);
+          float d, dinv;
+          dist_and_inv(d2, d, dinv);
+          const float rc = m.uniform_rc ? m.rc_r_max : (rc1 + m.rc_r[t2]) * 0.5f;
+          const float rcinv = m.uniform_rc ? m.rcinv_r : fast_rcp(rc);
+          const float dc = d < rc ? d : rc;
+          float fc, fcp;
+          cutoff_fc_fcp(rcinv, dc, fc, fcp);
+          float fn[S::KRM + 1], fnp[S::KRM + 1];
+          if (S::fixed)
+            basis_fn_fnp<S::KRM>(rcinv, dc, fc, fcp, fn, fnp);
+          else
+            basis_fn_fnp_rt(KR, rcinv, dc, fc, fcp, fn, fnp);
+          float s12 = 0.0f, s21 = 0.0f;
           const float* Ai = atab + (size_t)k * arow + t2 * KRP;
           for (int kk = 0; kk <= KR; ++kk)
             s12 = fmaf(fnp[kk], Ai[kk], s12);
+#pragma unroll
+          for (int kk = 0; kk <= S::KRM; ++kk) {
+            if (!S::fixed && kk > KR)
+              break;
+            s21 = fmaf(fnp[kk], Aj[u][kk], s21);
+          }
+          const float wgt = live ? dinv : 0.0f;
+          const float fs = (s12 + s21) * wgt;
+          const float bb = s21 * wgt;
+          Fr[0] = fmaf(fs, fx, Fr[0]);
+          Fr[1] = fmaf(fs, fy, Fr[1]);
+          Fr[2] = fmaf(fs, fz, Fr[2]);
+          const float bx = bb * fx, by = bb * fy, bz = bb * fz;
+          W[0] = fmaf(-fx, bx, W[0]);
+          W[1] = fmaf(-fy, by, W[1]);
+          W[2] = fmaf(-fz, bz, W[2]);
+          W[3] = fmaf(-fx, by, W[3]);
+          W[4] = fmaf(-fx, bz, W[4]);
+          W[5] = fmaf(-fy, bz, W[5]);
         }
 #pragma unroll
-        for (int kk = 0; kk <= S::KRM; ++kk) {
-          if (!S::fixed && kk > KR)
-            break;
-          s21 = fmaf(fnp[kk], Aj[u][kk], s21);
-        }
-        const float wgt = live ? dinv : 0.0f;
-        const float fs = (s12 + s21) * wgt; // f12 - f21 = fs * r12
-        const float bb = s21 * wgt;         // f21 = -bb * r12
-        Fr[0] = fmaf(fs, fx, Fr[0]);
-        Fr[1] = fmaf(fs, fy, Fr[1]);
-        Fr[2] = fmaf(fs, fz, Fr[2]);
-        const float bx = bb * fx, by = bb * fy, bz = bb * fz;
-        W[0] = fmaf(-fx, bx, W[0]);
-        W[1] = fmaf(-fy, by, W[1]);
-        W[2] = fmaf(-fz, bz, W[2]);
-        W[3] = fmaf(-fx, by, W[3]);
-        W[4] = fmaf(-fx, bz, W[4]);
-        W[5] = fmaf(-fy, bz, W[5]);
+        for (int u = 0; u < G; ++u)
+          cur[u] = nxt[u];
       }
-#pragma unroll
-      for (int u = 0; u < G; ++u)
-        cur[u] = nxt[u];
     }
 
     // ---- outputs, internal order ----

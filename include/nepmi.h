@@ -237,7 +237,10 @@ typedef struct {
                             6 velocity-Verlet, 7 list rebuild (whole) */
   double ms_kernel_sum[8]; /* same slots: sum over all launches since timing was (re)enabled */
   int64_t launches[8];     /* ... and their number (slot 7: rebuilds)                       */
-  int radial_tiles;        /* LDS-window mode of the last force call: 0 none, 1 radial pass, 2 radial pass + force assembly */
+  int radial_tiles;        /* LDS-window kernels in the last force call: 0 no (gather kernels), 2 yes */
+  int64_t discarded_steps; /* steps of the fused run loops that were enqueued speculatively and then re-run after a list
+                              rebuild: their launches returned at once; launches[] counts them, so a mean kernel time is
+                              ms_kernel_sum[k] / (launches[k] - discarded_steps) for the per-step kernels (slots 1..5) */
 } nepmi_stats;
 /* Synchronises the stream.  with_lists != 0 also recounts the per-step list lengths. */
 int nepmi_engine_stats(nepmi_engine* e, int with_lists, nepmi_stats* out);
