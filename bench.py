@@ -28,47 +28,51 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+METRIC = {"pbte": "atom-steps/sec, NEP PbTe NVE (nep4 2 Te Pb, examples/nep_train/nep.txt)",
+          "pbte_ortho": "atom-steps/sec, NEP PbTe NVE, orthogonal rock-salt cell (examples/nep_train/nep.txt)",
+          "carbon": "atom-steps/sec, NEP carbon (potentials/nep/C_2022_NEP4.txt)",
+          "unep": "atom-steps/sec, NEP UNEP-v1 16-metal alloy (potentials/nep/Song-2024-UNEP-v1)"}
 KERNEL_NAMES = ["gather_skin_check", "radial_descriptor", "angular_descriptor", "ann", "angular_partial_force",
                 "force_assemble", "velocity_verlet", "list_rebuild"]
 
 
-def build_pbte(reps, rattle=0.02, seed=42, temperature=300.0):
-    import helpers as H
-    fr = H.read_xyz_frames(H.golden("PbTe", "model.xyz"))[0]
-    typ0 = H.types_from_species(fr["species"], ["Te", "Pb"])
-    h, typ, pos = H.replicate(fr["h"], typ0, fr["pos"], reps)
-    rng = np.random.default_rng(seed)
-    pos = pos + rng.normal(0.0, rattle, pos.shape)
-    typ = typ.astype(np.int32)
-    mass = np.where(typ == 0, H.MASS["Te"], H.MASS["Pb"]).astype(np.float64)
-    vel = H.maxwell_velocities(mass, temperature, seed=seed + 1)
-    return h, typ, H.soa(pos), mass, vel
+def _oracle_helpers():
+    """tests/helpers.py holds the loaders of the CPU checkers (oracle/, oracle/_ref): only the cpu_baseline leg may
+    touch them."""
+    tests = os.path.join(ROOT, "tests")
+    if tests not in sys.path:
+        sys.path.insert(0, tests)
+    import helpers
+    return helpers
 
 
 def build_workload(name, reps, seed):
     """-> (label, nep.txt, h, type, x_soa, mass, vel).  `pbte` is BASELINE config 3 (the bench line);
-    `carbon` (C_2022_NEP4, diamond) and `unep` (UNEP-v1, 16-metal fcc alloy) are the model families of
-    configs 5 and 4, offered for single-GPU kernel measurements."""
-    import helpers as H
+    `pbte_ortho` its orthogonal-cell variant; `carbon` (C_2022_NEP4, diamond) and `unep` (UNEP-v1,
+    16-metal fcc alloy) are the model families of configs 5 and 4."""
+    from gpumd_amd import structures as S
     if name == "pbte":
-        h, typ, x, mass, vel = build_pbte(reps, seed=seed)
-        return ("PbTe %d atoms/GPU (replicate %d %d %d of the 250-atom cell), NEP NVE, dt 1 fs, 300 K"
-                % ((len(typ),) + tuple(reps)), H.golden("PbTe", "nep.txt"), h, typ, x, mass, vel)
+        h, typ, x, mass, vel = S.pbte_block(reps, seed=seed)
+        return ("PbTe %d atoms (replicate %d %d %d of the 250-atom cell), NEP, dt 1 fs, velocities drawn at 300 K "
+                "(the hot model.xyz snapshot equilibrates near 570 K)" % ((len(typ),) + tuple(reps)),
+                S.golden("PbTe", "nep.txt"), h, typ, x, mass, vel)
+    if name == "pbte_ortho":
+        cells = (int(2.5 * reps[0]), int(2.5 * reps[1]), 5 * reps[2])  # 16 16 16 -> 40 x 40 x 80 cells = 1,024,000 atoms
+        h, typ, x, mass, vel = S.rocksalt_block(cells, seed=seed)
+        return ("PbTe rock-salt %d atoms (%dx%dx%d conventional cells, orthogonal), NEP, dt 1 fs, 300 K" % ((len(typ),) + cells),
+                S.golden("PbTe", "nep.txt"), h, typ, x, mass, vel)
     if name == "carbon":
         cells = tuple(5 * r for r in reps)  # 16 16 16 -> 80^3 diamond cells = 4,096,000 atoms; use --reps 10 10 10 for 1 M
-        h, typ, x = H.diamond(cells, 3.57, rattle=0.02, seed=seed)
-        mass = np.full(len(typ), H.MASS["C"])
-        return ("diamond C %d atoms/GPU (%dx%dx%d cells), C_2022_NEP4, NVE" % ((len(typ),) + cells),
-                H.golden("C", "nep.txt"), h, typ, x, mass, H.maxwell_velocities(mass, 300.0, seed=seed + 1))
+        h, typ, x, mass, vel = S.diamond_block(cells, seed=seed)
+        return ("diamond C %d atoms (%dx%dx%d cells), C_2022_NEP4, 300 K" % ((len(typ),) + cells),
+                S.golden("C", "nep.txt"), h, typ, x, mass, vel)
     if name == "unep":
         cells = tuple(4 * r for r in reps)
-        h, typ, x = H.fcc_alloy(cells, 3.9, 16, rattle=0.02, seed=seed)
-        mass = np.full(len(typ), 100.0)
-        return ("fcc 16-metal alloy %d atoms/GPU (%dx%dx%d cells), UNEP-v1 + ZBL, NVE" % ((len(typ),) + cells),
-                H.golden("UNEP", "nep.txt"), h, typ, x, mass, H.maxwell_velocities(mass, 300.0, seed=seed + 1))
+        h, typ, x, mass, vel = S.fcc_alloy_block(cells, seed=seed)
+        return ("fcc 16-metal alloy %d atoms (%dx%dx%d cells), UNEP-v1 + ZBL, 300 K" % ((len(typ),) + cells),
+                S.golden("UNEP", "nep.txt"), h, typ, x, mass, vel)
     raise SystemExit("unknown workload " + name)
 
 
@@ -86,6 +90,25 @@ def algorithmic_bytes(info, nn_r, nn_a):
     }
     total = 232.0 + 160.0 + 8.0 * (nn_r + nn_a) + 8.0 * dim + 24.0 * nn_a
     return per_kernel, total
+
+
+def own_flops(info, nn_cand, nn_r, nn_a):
+    """FP32 operations per atom-step the ENGINE executes (fma = 2), counted from the kernel bodies for the model's
+    shape (DESIGN.md section 5 lists the terms): not the reference's count (8e4 for PbTe)."""
+    kr, nr1 = info.basis_size_radial + 1, info.n_max_radial + 1
+    ka, na1 = info.basis_size_angular + 1, info.n_max_angular + 1
+    T, dim, nneu = info.num_types, info.dim, info.num_neurons
+    ts = T if T <= 2 else 1
+    poly1, poly2 = 18.0, 34.0   # envelope: sine polynomial / sine + cosine polynomials
+    radial = nn_cand * (12.0 + 3.0 + poly1 + (5.0 + 2.0 * 2 * (kr - 2) + 2.0 * kr) + 2.0 * kr * ts) + 2.0 * nr1 * kr * ts
+    force = nn_r * (12.0 + 4.0 + poly2 + (8.0 + 10.0 * (kr - 2) + 6.0) + 2.0 * 2.0 * kr + 27.0)
+    harm = 45.0
+    adesc = nn_a * (10.0 + poly1 + 4.0 * ka + harm + 2.0 * na1 * ka + 2.0 * 24.0 * na1) + na1 * 160.0
+    ann = 2.0 * nneu * dim + 2.0 * nneu * (dim + T * ((kr + 3) // 4 * 4)) + 12.0 * nneu
+    recompute = adesc - na1 * 160.0 if info.MN_angular <= 16 else 0.0
+    aforce = recompute + na1 * 200.0 + nn_a * (10.0 + poly2 + 10.0 * ka + 2.0 * 2.0 * na1 * ka + 2.0 * 2.0 * 24.0 * na1 + 160.0 + 20.0)
+    return {"radial_descriptor": radial, "force_assemble": force, "angular_descriptor": adesc, "ann": ann,
+            "angular_partial_force": aforce, "total": radial + force + adesc + ann + aforce}
 
 
 class _stdout_to_stderr:
@@ -111,9 +134,10 @@ class _stdout_to_stderr:
 def _cpu_loop(reps, seconds, max_calls):
     """NEP_CPU (or the C oracle when oracle/_ref is absent) stepping a PbTe replica: one iteration =
     compute() + a host velocity-Verlet update, i.e. one atom-STEP per atom -> (n, calls, seconds, kind)."""
-    import helpers as H
-    nep = H.golden("PbTe", "nep.txt")
-    h, typ, x, mass, vel = build_pbte(reps)
+    H = _oracle_helpers()
+    from gpumd_amd import structures as S
+    nep = S.golden("PbTe", "nep.txt")
+    h, typ, x, mass, vel = S.pbte_block(reps)
     n = len(typ)
     if H.ref_available():
         eng, kind = H.RefNepCpu(nep), "reference"
@@ -175,7 +199,6 @@ def cpu_aggregate(seconds):
 def cpu_baseline(seconds=12.0):
     """NEP_CPU (reference, compiled in place into oracle/_ref) on a 16,000-atom PbTe replica; one
     iteration = compute() + a host velocity-Verlet update, so that it is an atom-STEP."""
-    import helpers as H
     n, calls, el, kind = _cpu_loop((4, 4, 4), seconds, 50)
     cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1)) if kind == "reference" else 1
     out = {"value": n * calls / el, "unit": "atom-steps/s", "cores": cores, "kind": kind,
@@ -207,7 +230,7 @@ def kernel_report(st, info, n_atoms_per_launch, st_all=None):
     dom = max(force_kernels, key=lambda k: kern[k]["avg_ms"] * kern[k]["launches"]) if force_kernels else None
     roofline = None
     if dom:
-        traffic = None
+        traffic, tj = None, {}
         tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tfile):
             # HBM-side bytes per launch from a separate rocprofv3 PMC pass of this same command
@@ -218,79 +241,111 @@ def kernel_report(st, info, n_atoms_per_launch, st_all=None):
         achieved = per_kernel[dom] * n_atoms_per_launch / (kern[dom]["avg_ms"] * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                    "traffic_source": (tj.get("source", "profiles/traffic_latest.json") + " (builder's rocprofv3 PMC pass, replayed "
+                                       "here: not measured in this run)") if traffic is not None else None,
                     "algorithmic_bytes_per_launch": per_kernel[dom] * n_atoms_per_launch,
                     "algorithmic_bytes_per_atom": per_kernel[dom], "avg_launch_ms": kern[dom]["avg_ms"],
                     "note": "FP32-VALU/gather bound stage (SURVEY.md 8d); see step_hbm_frac for the whole step"}
     return kern, roofline, b_step
 
 
-def run_decomposed(args, world, rank, dev, model, h_block, typ, x, mass, vel, reps):
-    """N > 1: spatial decomposition (gpumd_amd/domain.py), one rank per GPU, ghost positions over RCCL."""
+def run_decomposed(args, world, rank, dev, model, label, h_block, typ, x, mass, vel):
+    """N > 1 (or --decomposed on one GPU): the C++ domain-decomposed driver of libnepmi (nepmi_dist_*), one rank per
+    GPU, ghost positions over RCCL/xGMI.  Python only builds the synthetic block and passes pointers."""
     import torch
     import torch.distributed as dist
     import gpumd_amd
-    import helpers as H
-    from gpumd_amd.domain import DomainMD, choose_grid
+    from gpumd_amd import structures as H
+    from gpumd_amd.dist import DistMD, Transport, choose_grid
 
+    lib = gpumd_amd.load_library()
     grid = choose_grid(world)
     Hb = np.asarray(h_block).reshape(3, 3)
-    Hg = Hb * np.asarray(grid, dtype=np.float64)[None, :]       # global cell = grid x block
-    coords = (rank % grid[0], (rank // grid[0]) % grid[1], rank // (grid[0] * grid[1]))
     n = len(typ)
-    offset = Hb @ np.asarray(coords, dtype=np.float64)            # this rank's block of the global crystal
-    X = torch.from_numpy(x.reshape(3, n) + offset[:, None]).to(dev)
-    V = torch.from_numpy(vel.reshape(3, n).copy()).to(dev)
-    T = torch.from_numpy(typ).to(dev)
-    M = torch.from_numpy(mass).to(dev)
-    staged = os.environ.get("NEPMI_DIST_BACKEND", "nccl") != "nccl"
-    md = DomainMD(lambda cap: gpumd_amd.NEP(model, cap), model.info.rc_radial, Hg.reshape(9), (1, 1, 1), grid, rank,
-                  world, dev, stage_through_host=staged)
-    md.setup(X, V, T, M)
+    if args.scaling == "strong":
+        # the SAME global system on every N: rank r contributes a slice of it (setup migrates the atoms to their owners)
+        Hg = Hb
+        mine = np.arange(n) % world == rank
+        X = np.ascontiguousarray(x.reshape(3, n)[:, mine])
+        V = np.ascontiguousarray(vel.reshape(3, n)[:, mine])
+        T, M = typ[mine], mass[mine]
+    else:
+        # weak scaling: every rank generates its own block of the global crystal (grid x block)
+        Hg = Hb * np.asarray(grid, dtype=np.float64)[None, :]
+        coords = (rank % grid[0], (rank // grid[0]) % grid[1], rank // (grid[0] * grid[1]))
+        X = x.reshape(3, n) + (Hb @ np.asarray(coords, dtype=np.float64))[:, None]
+        V, T, M = vel.reshape(3, n), typ, mass
+    if world > 1 and os.environ.get("NEPMI_DIST_BACKEND", "nccl") == "nccl":
+        def bcast(ident):
+            t = torch.zeros(128, dtype=torch.uint8, device=dev)
+            if ident is not None:
+                t.copy_(torch.frombuffer(bytearray(ident), dtype=torch.uint8))
+            dist.broadcast(t, src=0)
+            return bytes(t.cpu().numpy().tobytes())
+        tr = Transport.rccl(lib, rank, world, bcast)
+        transport = "RCCL send/recv of ghost positions over xGMI, skin vote all-reduced on the device"
+    else:
+        # functional check on a box with fewer GPUs than ranks (or one rank): host sockets, never a performance run
+        tr = Transport.tcp(lib, os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29400")) + 1,
+                           rank, world)
+        transport = "TCP sockets (host staging)" if world > 1 else "single rank"
+    md = DistMD(model, tr, Hg.reshape(9), (1, 1, 1), grid)
+    md.setup(torch.from_numpy(np.ascontiguousarray(T)).to(dev), torch.from_numpy(np.ascontiguousarray(M)).to(dev),
+             torch.from_numpy(np.ascontiguousarray(X).reshape(-1)).to(dev),
+             torch.from_numpy(np.ascontiguousarray(V).reshape(-1)).to(dev))
     dt = 1.0 / H.TIME_UNIT
-    md.initial_forces()
-    md.run(args.warmup, dt)
-    md.engine.set_timing(2)  # the dominant kernel only inside the timed region (see the single-GPU path)
-    dec0 = md.num_decompositions
+    ens = args.ensemble
+    t_args = (300.0, 300.0, 100.0)
+    md.compute()
+    if args.warmup > 0:
+        md.run(ens, dt, args.warmup, *t_args)
+    md.engine_set_timing(2)  # the dominant kernel only inside the timed region (see the single-GPU path)
+    dec0 = md.info().num_decompositions
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    md.run(args.steps, dt)
+    md.run(ens, dt, args.steps, *t_args)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    st = md.engine.stats(with_lists=True)
+    st = md.engine_stats(with_lists=True)
     th = md.thermo()
-    md.engine.set_timing(1)
-    md.run(max(10, min(args.steps, 40)), dt)  # instrumented pass for the per-kernel table, outside the clock
-    st_all = md.engine.stats(with_lists=False)
-    md.engine.set_timing(0)
+    md.engine_set_timing(1)
+    md.run(ens, dt, max(10, min(args.steps, 40)), *t_args)  # instrumented pass for the per-kernel table, outside the clock
+    st_all = md.engine_stats(with_lists=False)
+    md.engine_set_timing(0)
+    info = md.info()
     t_el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    n_loc = torch.tensor([md.n_loc], dtype=torch.float64, device=dev)
+    n_loc = torch.tensor([float(info.n_local)], dtype=torch.float64, device=dev)
     if world > 1:
-        md._all_reduce(t_el, dist.ReduceOp.MAX)
-        md._all_reduce(n_loc, dist.ReduceOp.MAX)
+        dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
+        dist.all_reduce(n_loc, op=dist.ReduceOp.MAX)
     elapsed = float(t_el.item())
     if rank == 0:
-        kern, roofline, b_step = kernel_report(st, model.info, md.n_loc, st_all)
-        total = md.n_total
+        kern, roofline, b_step = kernel_report(st, model.info, info.n_local, st_all)
+        total = info.n_total
         out = {
-            "metric": "atom-steps/sec, NEP PbTe NVE (nep4 2 Te Pb, examples/nep_train/nep.txt)",
+            "metric": METRIC[args.workload] + (", " + ens if ens != "nve" else ""),
             "value": total * args.steps / elapsed, "unit": "atom-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "dtype_note": "FP32 kernel arithmetic like the reference NEP path; FP64 positions, velocities and accumulated per-atom outputs", "data": "synthetic",
-            "config": {"workload": "PbTe %d atoms/GPU (replicate %d %d %d of the 250-atom cell per GPU), NEP NVE, dt 1 fs, 300 K"
-                                   % ((n,) + reps),
-                       "atoms_total": total, "parallelism": "spatial decomposition %dx%dx%d, ghost shell 2(rc+skin), "
-                       "RCCL send/recv of ghost positions" % grid,
-                       "local_atoms_max": int(n_loc.item()), "decompositions_in_timed_region": md.num_decompositions - dec0,
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f32",
+            "dtype_note": "FP32 kernel arithmetic like the reference NEP path; FP64 positions, velocities and accumulated per-atom outputs",
+            "data": "synthetic",
+            "config": {"workload": label + (" (per GPU)" if args.scaling == "weak" else " (whole system, strong scaling)"),
+                       "ensemble": ens, "atoms_total": total,
+                       "parallelism": "spatial decomposition %dx%dx%d, ghost shell 2(rc+skin), %s" % (grid + (transport,)),
+                       "local_atoms_max": int(n_loc.item()), "decompositions_in_timed_region": int(info.num_decompositions - dec0),
+                       "steps_with_overlapped_exchange": int(info.num_overlapped),
                        "mean_nn_radial": st.mean_nn_radial, "mean_nn_angular": st.mean_nn_angular},
             "roofline": roofline, "step_algorithmic_bytes_per_atom": b_step,
             "step_hbm_frac": b_step * (total * args.steps / elapsed) / (HBM_PEAK_GBS * 1e9 * world),
             "kernels": kern, "thermo_last": [float(v) for v in th],
         }
         print(json.dumps(out))
+    md.close()
+    tr.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -302,11 +357,16 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--reps", type=int, nargs=3, default=[16, 16, 16], help="replicate na nb nc of the 250-atom cell")
-    ap.add_argument("--workload", default="pbte", choices=["pbte", "carbon", "unep"],
+    ap.add_argument("--workload", default="pbte", choices=["pbte", "pbte_ortho", "carbon", "unep"],
                     help="pbte = BASELINE config 3 (the bench line); the others are extra single-GPU measurements")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--decomposed", action="store_true",
-                    help="run the N > 1 code path (DomainMD) even on one GPU, to measure its host-side overhead")
+                    help="run the N > 1 code path (the C++ domain-decomposed driver) even on one GPU, to measure its overhead")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1: weak = every GPU gets its own block of --reps cells (default); strong = the --reps system is "
+                         "shared by all GPUs (SURVEY.md 8e: >= 6x at 8 GPUs on the 1 M-atom config)")
+    ap.add_argument("--ensemble", default="nve", choices=["nve", "nvt_ber", "nvt_nhc", "nvt_bdp"],
+                    help="decomposed runs: the ensemble (config 5 is NVT); the single-GPU bench line is NVE")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--cpu-worker", type=float, default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -317,7 +377,7 @@ def main():
     import torch
     import torch.distributed as dist
     import gpumd_amd
-    import helpers as H
+    from gpumd_amd import structures as H
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -342,12 +402,12 @@ def main():
 
     # ---- workload: every rank generates its own block of `reps` cells (weak scaling) ----
     reps = tuple(args.reps)
-    label, nep_txt, h, typ, x, mass, vel = build_workload(args.workload, reps, 42 + rank)
+    label, nep_txt, h, typ, x, mass, vel = build_workload(args.workload, reps, 42 + (rank if args.scaling == "weak" else 0))
     n = len(typ)
     model = gpumd_amd.Model(nep_txt)
     dt = 1.0 / H.TIME_UNIT
     if world > 1 or args.decomposed:
-        run_decomposed(args, world, rank, dev, model, h, typ, x, mass, vel, reps)
+        run_decomposed(args, world, rank, dev, model, label, h, typ, x, mass, vel)
         return
     eng = gpumd_amd.NEP(model, n)
     t_type = torch.from_numpy(typ).to(dev)
@@ -401,7 +461,7 @@ def main():
     if rank == 0:
         kern, roofline, b_step = kernel_report(st, model.info, n, st_all)
         out = {
-            "metric": "atom-steps/sec, NEP PbTe NVE (nep4 2 Te Pb, examples/nep_train/nep.txt)",
+            "metric": METRIC[args.workload],
             "value": value, "unit": "atom-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "dtype_note": "FP32 kernel arithmetic like the reference NEP path; FP64 positions, velocities and accumulated per-atom outputs", "data": "synthetic",
@@ -419,9 +479,14 @@ def main():
         if args.workload == "pbte":
             # the path is FP32-VALU/gather bound, so the step is also priced against the
             # FP32 vector peak with the survey's FLOP count of the reference algorithm (8e4 per atom-step)
-            out["fp32_valu"] = {"flop_per_atom_step_survey": 8.0e4, "equivalent_tflops": value * 8.0e4 / 1e12,
-                                "peak_tflops": 157.3, "frac": value * 8.0e4 / 157.3e12,
-                                "note": "the engine's own algebra needs ~3e4 FLOP per atom-step (DESIGN.md section 3)"}
+            fl = own_flops(model.info, st.max_nn_skin and (st.mean_nn_radial * 1.31), st.mean_nn_radial, st.mean_nn_angular)
+            out["fp32_valu"] = {"flop_per_atom_step_own": fl["total"], "frac_own": value * fl["total"] / 157.3e12,
+                                "own_flop_by_kernel": {k: round(v) for k, v in fl.items() if k != "total"},
+                                "peak_tflops": 157.3,
+                                "flop_per_atom_step_survey": 8.0e4, "frac_survey_equivalent": value * 8.0e4 / 157.3e12,
+                                "note": "frac_own prices the operations this engine executes (counted from its kernels for "
+                                        "this model shape; ~1.31 Verlet candidates per radial neighbour); the survey figure is "
+                                        "the reference algorithm's count and only says how much of it was avoided"}
         if world == 1 and not args.no_cpu_baseline and args.workload == "pbte":
             with _stdout_to_stderr():
                 out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)

@@ -34,6 +34,25 @@ class NepmiStats(C.Structure):
         ("discarded_steps", c_i64)]
 
 
+class NepmiMsg(C.Structure):
+    _fields_ = [("buf", C.c_void_p), ("bytes", c_i64), ("peer", C.c_int)]
+
+
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(NepmiMsg), C.c_int, C.POINTER(NepmiMsg), C.c_void_p)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, c_i64, C.c_int, C.c_int, C.c_void_p)
+DESTROY_FN = C.CFUNCTYPE(None, C.c_void_p)
+
+
+class NepmiTransport(C.Structure):
+    _fields_ = [("ctx", C.c_void_p), ("rank", C.c_int), ("nranks", C.c_int), ("device_buffers", C.c_int),
+                ("exchange", EXCHANGE_FN), ("allreduce", ALLREDUCE_FN), ("destroy", DESTROY_FN)]
+
+
+class NepmiDistInfo(C.Structure):
+    _fields_ = [("n_owned", c_i64), ("n_local", c_i64), ("n_total", c_i64), ("num_decompositions", c_i64),
+                ("num_steps", c_i64), ("num_overlapped", c_i64)]
+
+
 # every symbol include/nepmi.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "nepmi_last_error": (C.c_char_p, []),
@@ -79,6 +98,21 @@ SYMBOLS = {
     "nepmi_engine_set_tiles": (C.c_int, [VP, C.c_int]),
     "nepmi_engine_set_mfma": (C.c_int, [VP, C.c_int]),
     "nepmi_engine_set_angular_recompute": (C.c_int, [VP, C.c_int]),
+    "nepmi_transport_rccl_id": (C.c_int, [C.c_char_p]),
+    "nepmi_transport_rccl": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(NepmiTransport)]),
+    "nepmi_transport_tcp": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(NepmiTransport)]),
+    "nepmi_transport_destroy": (None, [C.POINTER(NepmiTransport)]),
+    "nepmi_dist_create": (VP, [VP, C.POINTER(NepmiTransport), c_dp, c_ip, c_ip, VP]),
+    "nepmi_dist_destroy": (None, [VP]),
+    "nepmi_dist_setup": (C.c_int, [VP, c_i64, VP, VP, VP, VP, VP]),
+    "nepmi_dist_compute": (C.c_int, [VP]),
+    "nepmi_dist_run": (C.c_int, [VP, C.c_int, C.c_double, c_i64, C.c_double, C.c_double, C.c_double, c_i64, c_dp]),
+    "nepmi_dist_thermo": (C.c_int, [VP, c_dp]),
+    "nepmi_dist_bdp_seed": (C.c_int, [VP, C.c_uint64]),
+    "nepmi_dist_set_overlap": (C.c_int, [VP, C.c_int]),
+    "nepmi_dist_get_info": (C.c_int, [VP, C.POINTER(NepmiDistInfo)]),
+    "nepmi_dist_gather_owned": (C.c_int, [VP, VP, VP, VP, VP, VP, VP]),
+    "nepmi_dist_engine": (VP, [VP]),
 }
 
 

@@ -1,0 +1,794 @@
+// Spatial domain decomposition of the NEP MD step over the GPUs of one node: the multi-GPU host of libnepmi.
+//
+// Replaces NEP_MULTIGPU (src/force/nep_multigpu.cu:1416-1803, chosen by Force::parse_potential, force.cu:139-160):
+// the reference keeps the whole system on GPU 0, cuts it into slabs along ONE direction every step, copies slab +
+// halo positions to every GPU, rebuilds each GPU's neighbour lists from scratch every step and gathers the forces
+// back through blocking peer copies; the integrator runs on GPU 0.  Here:
+//   * one process per GPU, a Cartesian process grid over the fractional coordinates of the global cell; every rank
+//     OWNS the atoms inside its sub-box and their integrator state for the whole run;
+//   * ghost shell 2 (rc + skin) with the reference's semantics (nep_multigpu.cuh:42-50, ranges N1..N5): positions
+//     only travel (forward communication), descriptors of the inner ring rc + skin are recomputed redundantly
+//     (level 1), forces are produced for owned atoms only (level 2), no reverse communication;
+//   * per step ONE ghost-position exchange, staged over the decomposed directions (2 messages per direction; edges
+//     and corners are forwarded: 6 messages instead of 26), and one all-reduce of the skin flag;  every ensemble of
+//     the fused run loops (NVE, Berendsen, Nose-Hoover chain, Bussi-Donadio-Parrinello) on top of one all-reduce
+//     of the eight thermodynamic sums;
+//   * migration + ghost-list rebuild only when some atom of some rank has moved more than skin/2 since the last
+//     decomposition (the criterion of Neighbor::find_neighbor_global, neighbor.cu:741-800, made global).
+//
+// The transport is a small table of function pointers (include/nepmi.h: nepmi_transport): RCCL over xGMI on device
+// buffers, everything enqueued on HIP streams with the skin flag reduced on the device (no host round trip per
+// step), or a host transport (TCP sockets; a caller's own callbacks) whose payloads are staged through pinned
+// memory -- the same driver code, used by the CPU test tier and by ranks that share one GPU.
+#pragma once
+#include "../../include/nepmi.h"
+#include "dist_bodies.h"
+#include "engine_impl.h"
+
+#include <algorithm>
+#include <memory>
+
+namespace nepmi {
+
+using TransportMsg = nepmi_msg;        // include/nepmi.h
+using TransportView = nepmi_transport;
+enum { kDtF64 = 0, kDtI32 = 1, kDtI64 = 2 };
+enum { kOpSum = 0, kOpMax = 1 };
+
+template <class B>
+class DistT
+{
+public:
+  using Engine = EngineT<B>;
+  static constexpr double kSkin = Engine::kSkin;
+
+  DistT(const NepModel& model, const TransportView& tr, const double h9[9], const int pbc[3], const int grid[3], B backend)
+    : model_(model), tr_(tr), be_(backend)
+  {
+    if (grid[0] * grid[1] * grid[2] != tr.nranks)
+      throw EngineError{-4, "process grid does not match the number of ranks"};
+    BoxD gb;
+    box_from_h9(h9, pbc, gb);
+    DomainGeom& g = geom_;
+    for (int k = 0; k < 9; ++k) {
+      g.H[k] = gb.h[k];
+      g.G[k] = gb.h[9 + k];
+      hg_[k] = h9[k];
+    }
+    volume_ = gb.volume;
+    const double rc = model.rc_radial_max;
+    const int r = tr.rank;
+    g.coords[0] = r % grid[0];
+    g.coords[1] = (r / grid[0]) % grid[1];
+    g.coords[2] = r / (grid[0] * grid[1]);
+    double ext[3] = {1, 1, 1}, org[3] = {0, 0, 0};
+    for (int d = 0; d < 3; ++d) {
+      g.grid[d] = grid[d];
+      g.pbc[d] = pbc[d] ? 1 : 0;
+      g.decomposed[d] = grid[d] > 1;
+      g.lo[d] = (double)g.coords[d] / grid[d];
+      g.hi[d] = (double)(g.coords[d] + 1) / grid[d];
+      g.wfrac[d] = (2.0 * rc + 2.0 * kSkin) / gb.thickness[d];
+      g.ifrac[d] = (rc + kSkin) / gb.thickness[d];
+      if (g.decomposed[d]) {
+        if (g.wfrac[d] > 1.0 / grid[d])
+          throw EngineError{-3, "domain thinner than the ghost shell 2 (rc + skin) in a decomposed direction"};
+        ext[d] = (g.hi[d] - g.lo[d]) + 2.0 * g.wfrac[d];
+        org[d] = g.lo[d] - g.wfrac[d];
+      }
+      pbc_loc_[d] = g.decomposed[d] ? 0 : g.pbc[d];
+    }
+    // local box handed to the engine: the ghost-padded sub-box, open in the decomposed directions
+    for (int c = 0; c < 3; ++c) {
+      g.origin[c] = 0.0;
+      for (int d = 0; d < 3; ++d) {
+        h_loc_[3 * c + d] = g.H[3 * c + d] * ext[d];
+        g.origin[c] += g.H[3 * c + d] * org[d];
+      }
+    }
+    flag_dev_ = (int*)be_.alloc(sizeof(int) * 4);
+    sums_dev_ = (double*)be_.alloc(sizeof(double) * 8);
+    thermo_dev_ = (double*)be_.alloc(sizeof(double) * 8);
+    nhc_dev_ = (double*)be_.alloc(sizeof(double) * kNhcStateSize);
+    factor_dev_ = (double*)be_.alloc(sizeof(double));
+  }
+
+  ~DistT()
+  {
+    for (void* p : {(void*)flag_dev_, (void*)sums_dev_, (void*)thermo_dev_, (void*)nhc_dev_, (void*)factor_dev_})
+      be_.free(p);
+    free_state(cur_);
+    free_state(nxt_);
+    for (auto& st : stages_)
+      free_stage(st);
+    for (void* p : scratch_)
+      be_.free(p);
+  }
+
+  // ---- setup: the atoms this rank starts with (DEVICE arrays, any position: they are migrated to their owners) ----
+  void setup(int64_t n, const int* type, const double* mass, const double* pos, const double* vel, const int64_t* ids)
+  {
+    // global ids default to a running number over the ranks
+    std::vector<int64_t> all((size_t)tr_.nranks, 0);
+    all[tr_.rank] = n;
+    host_allreduce(all.data(), tr_.nranks, kDtI64, kOpSum);
+    int64_t base = 0;
+    n_total_ = 0;
+    for (int r = 0; r < tr_.nranks; ++r) {
+      if (r < tr_.rank)
+        base += all[r];
+      n_total_ += all[r];
+    }
+    alloc_state(cur_, n > 0 ? n : 1);
+    cur_.n = n;
+    cur_.n_own = n;
+    if (n > 0) {
+      // global -> local coordinates
+      std::vector<double> hx(3 * (size_t)n);
+      be_.d2h(hx.data(), pos, sizeof(double) * 3 * n);
+      for (int d = 0; d < 3; ++d)
+        for (int64_t i = 0; i < n; ++i)
+          hx[d * n + i] -= geom_.origin[d];
+      be_.h2d(cur_.x, hx.data(), sizeof(double) * 3 * n);
+      copy_dev(cur_.v, vel, sizeof(double) * 3 * n);
+      copy_dev(cur_.m, mass, sizeof(double) * n);
+      copy_dev(cur_.t, type, sizeof(int) * n);
+      if (ids) {
+        copy_dev(cur_.id, ids, sizeof(int64_t) * n);
+      } else {
+        std::vector<int64_t> hid((size_t)n);
+        for (int64_t i = 0; i < n; ++i)
+          hid[i] = base + i;
+        be_.h2d(cur_.id, hid.data(), sizeof(int64_t) * n);
+      }
+    }
+    resident_ = false;
+    have_force_ = false;
+    decompose();
+  }
+
+  int64_t num_owned() const { return cur_.n_own; }
+  int64_t num_local() const { return cur_.n; }
+  int64_t num_total() const { return n_total_; }
+  int64_t num_decompositions = 0, num_steps = 0;
+  Engine* engine() { return eng_.get(); }
+
+  // ---- Force::compute on the decomposed system (the initial force of Run::perform_a_run) ----
+  void compute()
+  {
+    halo_exchange();
+    eng_->force_kernels(Engine::kPhaseAll);
+    ++eng_->num_compute;
+    have_force_ = true;
+  }
+
+  // ---- the run loop (Run::perform_a_run, run.cu:250-318) for the ensembles of EngineT::run_md ----
+  void run(int ens, double dt, int64_t nsteps, double t1, double t2, double tcoup, int64_t thermo_every, double* thermo_host)
+  {
+    if (!have_force_)
+      compute();
+    Engine& e = *eng_;
+    if (ens == Engine::kNhc)
+      be_.template launch<64>(kSlotMisc, 1, NhcInitBody{n_total_, t1, tcoup, dt, nhc_dev_});
+    const bool spec = tr_.device_buffers != 0 && ens != Engine::kBdp; // speculative enqueue needs a device-side vote
+    auto tag_of = [](int64_t step) { return (int)(step % 1000000000) + 1; };
+    auto target_of = [&](int64_t step) { return t1 + (t2 - t1) * ((double)step / (double)nsteps); };
+    auto nhc_half = [&](double target) {
+      thermo_global();
+      be_.template launch<64>(kSlotMisc, 1, NhcChainBody{n_total_, target, 0.5 * dt, thermo_dev_, nhc_dev_, frozen()});
+      be_.template launch<256>(kSlotVV, e.num_atoms(), ResidentScaleBody{e.bufs(), nhc_dev_ + 3 * kNhcLinks, 1.0});
+    };
+    std::vector<int> pending;
+    int ring_next = 0;
+    int64_t step = 0;
+    bool resume_after_vv1 = false, kick2_pending = false;
+    while (step < nsteps) {
+      const double target = target_of(step);
+      if (!resume_after_vv1) {
+        if (ens == Engine::kNhc)
+          nhc_half(target);
+        be_.template launch<256>(kSlotVV, e.num_atoms(),
+                                 ResidentStepBody{e.box(), e.bufs(), dt, kick2_pending ? 1 : 0, 1, tag_of(step)});
+      }
+      resume_after_vv1 = false;
+      kick2_pending = false;
+      // The vote (every rank's skin flag -> the same word on all ranks) and the ghost positions travel on the
+      // communication stream; meanwhile the radial pass of the interior bricks -- those whose window holds no ghost --
+      // runs on the compute stream.  Host transports block: the interior pass simply runs first, which proves its
+      // independence of this step's ghosts (tests/test_dist.py compares both orders bit for bit).
+      const bool split = overlap_ && e.tiles_active() && tr_.nranks > 1;
+      B& comm = (split && tr_.device_buffers) ? comm_backend() : be_;
+      if (&comm != &be_)
+        be_.fork_to(comm);
+      if (split) {
+        e.force_kernels(Engine::kPhaseInterior);
+        ++num_overlapped;
+      }
+      int trip = vote(spec, comm);
+      if (!trip)
+        halo_exchange_on(comm);
+      if (&comm != &be_)
+        be_.join_from(comm);
+      if (!trip) {
+        e.force_kernels(split ? Engine::kPhaseBoundary : Engine::kPhaseAll, frozen());
+        const bool record = thermo_every > 0 && (step + 1) % thermo_every == 0;
+        const bool last = step + 1 == nsteps;
+        bool need_sync = record || last;
+        if (ens == Engine::kNve && !record && !last) {
+          kick2_pending = true;
+        } else {
+          be_.template launch<256>(kSlotVV, e.num_atoms(), ResidentStepBody{e.box(), e.bufs(), dt, 1, 0, 0});
+          if (ens == Engine::kBer) {
+            thermo_global();
+            if (1.0 / tcoup > 1.0e-5) {
+              be_.template launch<64>(kSlotMisc, 1,
+                                      BerendsenFactorBody{e.bufs().flags, target, 1.0 / tcoup, thermo_dev_, factor_dev_});
+              be_.template launch<256>(kSlotVV, e.num_atoms(), ResidentScaleBody{e.bufs(), factor_dev_, 1.0});
+            }
+          } else if (ens == Engine::kNhc) {
+            nhc_half(target);
+          } else if (ens == Engine::kBdp) {
+            thermo_global();
+            need_sync = true;
+          } else if (record) {
+            thermo_global();
+          }
+        }
+        if (need_sync) {
+          trip = sync_flags();
+          pending.clear();
+          if (!trip) {
+            if (ens == Engine::kBdp) {
+              double T = 0.0;
+              be_.d2h(&T, thermo_dev_, sizeof(double));
+              be_.template launch<256>(kSlotVV, e.num_atoms(),
+                                       ResidentScaleBody{e.bufs(), nullptr, e.bdp_factor(n_total_, T, target, tcoup)});
+            }
+            if (record && thermo_host)
+              be_.d2h(thermo_host + 8 * ((step + 1) / thermo_every - 1), thermo_dev_, 8 * sizeof(double));
+          }
+        } else if (spec && (step + 1) % Engine::kPollEvery == 0) {
+          be_.poll_record(ring_next, e.bufs().flags);
+          pending.push_back(ring_next);
+          ring_next = (ring_next + 1) % 8;
+          if ((int)pending.size() > Engine::kPollDepth) {
+            int snap[8];
+            be_.poll_wait(pending.front(), snap);
+            pending.erase(pending.begin());
+            if (snap[kFlagMoved])
+              trip = sync_flags();
+          }
+        }
+      }
+      if (trip) {
+        // frozen right after the first half-step of step `trip - 1` on every rank: re-decompose and resume there
+        be_.sync();
+        pending.clear();
+        e.num_discarded += step - ((int64_t)trip - 1) + 1;
+        step = (int64_t)trip - 1;
+        decompose();
+        resume_after_vv1 = true;
+        kick2_pending = false;
+        continue;
+      }
+      ++step;
+    }
+    num_steps += nsteps;
+    be_.sync();
+    e.check_flags_now();
+  }
+
+  // T, U and the six stress components of the whole system -> thermo8 (HOST)
+  void thermo(double* thermo8_host)
+  {
+    thermo_global();
+    be_.d2h(thermo8_host, thermo_dev_, 8 * sizeof(double));
+  }
+
+  // owned atoms -> the caller's DEVICE arrays (n_own entries per plane, global coordinates, local order)
+  void gather_owned(int64_t* ids, double* pos, double* vel, double* force, double* pe, double* virial)
+  {
+    Engine& e = *eng_;
+    be_.template launch<256>(kSlotMisc, e.num_atoms(),
+                             GatherOwnedBody{e.bufs(), geom_, cur_.n_own, cur_.id, ids, pos, vel, force, pe, virial});
+    be_.sync();
+  }
+
+  void bdp_seed(uint64_t seed) { seed_ = seed; if (eng_) eng_->bdp_seed(seed); }
+  void set_overlap(bool on) { overlap_ = on; }
+  int64_t num_overlapped = 0; // steps whose interior radial pass ran before / while the ghosts travelled
+
+private:
+  struct State { // owned + ghost atoms in local order, stride = n (DEVICE)
+    int64_t cap = 0, n = 0, n_own = 0;
+    double *x = nullptr, *v = nullptr, *m = nullptr;
+    int* t = nullptr;
+    int64_t* id = nullptr;
+    signed char* lvl = nullptr;
+  };
+  struct Stage {
+    int d = 0;
+    int peer_send[2] = {0, 0}, peer_recv[2] = {0, 0}; // [0]: to lower / from upper, [1]: to upper / from lower
+    int64_t cnt_send[2] = {0, 0}, cnt_recv[2] = {0, 0};
+    int64_t off_recv[2] = {0, 0};
+    double shift[2][3] = {{0, 0, 0}, {0, 0, 0}};
+    int* send_idx = nullptr;     // local indices, cnt_send[0] + cnt_send[1]
+    int* send_int = nullptr;     // the same, internal indices of the engine
+    int* recv_int = nullptr;     // internal indices of the received ghosts
+    double* sendbuf = nullptr;   // device [3][cnt0] | [3][cnt1]
+    double* recvbuf = nullptr;
+  };
+
+  const int* frozen() const { return eng_->bufs().flags + kFlagMoved; }
+  B& comm_backend()
+  {
+    if (!side_ready_) {
+      side_ = be_.make_side_stream();
+      side_ready_ = true;
+    }
+    return side_;
+  }
+
+  void copy_dev(void* dst, const void* src, size_t bytes) { be_.d2d(dst, src, bytes); }
+
+  void alloc_state(State& s, int64_t cap)
+  {
+    free_state(s);
+    s.cap = cap;
+    s.x = (double*)be_.alloc(sizeof(double) * 3 * cap);
+    s.v = (double*)be_.alloc(sizeof(double) * 3 * cap);
+    s.m = (double*)be_.alloc(sizeof(double) * cap);
+    s.t = (int*)be_.alloc(sizeof(int) * cap);
+    s.id = (int64_t*)be_.alloc(sizeof(int64_t) * cap);
+    s.lvl = (signed char*)be_.alloc(cap);
+  }
+  void free_state(State& s)
+  {
+    for (void* p : {(void*)s.x, (void*)s.v, (void*)s.m, (void*)s.t, (void*)s.id, (void*)s.lvl})
+      if (p)
+        be_.free(p);
+    s = State();
+  }
+  void free_stage(Stage& st)
+  {
+    for (void* p : {(void*)st.send_idx, (void*)st.send_int, (void*)st.recv_int, (void*)st.sendbuf, (void*)st.recvbuf})
+      if (p)
+        be_.free(p);
+    st = Stage();
+  }
+  int* iscratch(int which, int64_t count) // grow-only int scratch arrays
+  {
+    if ((int)iscr_.size() <= which) {
+      iscr_.resize(which + 1, nullptr);
+      iscr_cap_.resize(which + 1, 0);
+    }
+    if (iscr_cap_[which] < count) {
+      iscr_[which] = (int*)be_.alloc(sizeof(int) * (count + 1024));
+      scratch_.push_back(iscr_[which]);
+      iscr_cap_[which] = count + 1024;
+    }
+    return iscr_[which];
+  }
+
+  int neighbor(int d, int step) const
+  {
+    int c[3] = {geom_.coords[0], geom_.coords[1], geom_.coords[2]};
+    c[d] = (c[d] + step + geom_.grid[d]) % geom_.grid[d];
+    return c[0] + geom_.grid[0] * (c[1] + geom_.grid[1] * c[2]);
+  }
+
+  // ---- transport helpers: device buffers go straight to the transport, host transports are staged ----
+  void host_allreduce(void* buf, int64_t count, int dtype, int op)
+  {
+    if (tr_.nranks == 1)
+      return;
+    if (tr_.device_buffers) { // a host buffer through a device transport: bounce through device memory
+      const size_t bytes = (size_t)count * (dtype == kDtI32 ? 4 : 8);
+      void* d = be_.alloc(bytes);
+      be_.h2d(d, buf, bytes);
+      if (tr_.allreduce(tr_.ctx, d, count, dtype, op, be_.stream_handle()) != 0)
+        throw EngineError{-5, "transport all-reduce failed"};
+      be_.d2h(buf, d, bytes);
+      be_.free(d);
+    } else if (tr_.allreduce(tr_.ctx, buf, count, dtype, op, nullptr) != 0) {
+      throw EngineError{-5, "transport all-reduce failed"};
+    }
+  }
+  void device_allreduce(void* dbuf, int64_t count, int dtype, int op) { device_allreduce_on(be_, dbuf, count, dtype, op); }
+  void device_allreduce_on(B& on, void* dbuf, int64_t count, int dtype, int op)
+  {
+    if (tr_.nranks == 1)
+      return;
+    if (tr_.device_buffers) {
+      if (tr_.allreduce(tr_.ctx, dbuf, count, dtype, op, on.stream_handle()) != 0)
+        throw EngineError{-5, "transport all-reduce failed"};
+    } else {
+      char tmp[64];
+      const size_t bytes = (size_t)count * (dtype == kDtI32 ? 4 : 8);
+      be_.d2h(tmp, dbuf, bytes); // synchronises the stream
+      if (tr_.allreduce(tr_.ctx, tmp, count, dtype, op, nullptr) != 0)
+        throw EngineError{-5, "transport all-reduce failed"};
+      be_.h2d(dbuf, tmp, bytes);
+    }
+  }
+  // grouped exchange of DEVICE buffers
+  void exchange(int ns, TransportMsg* sends, int nr, TransportMsg* recvs) { exchange_on(be_, ns, sends, nr, recvs); }
+  void exchange_on(B& on, int ns, TransportMsg* sends, int nr, TransportMsg* recvs)
+  {
+    if (tr_.nranks == 1)
+      return;
+    if (tr_.device_buffers) {
+      if (tr_.exchange(tr_.ctx, ns, sends, nr, recvs, on.stream_handle()) != 0)
+        throw EngineError{-5, "transport exchange failed"};
+      return;
+    }
+    std::vector<std::vector<char>> hs(ns), hr(nr);
+    std::vector<TransportMsg> s2(ns), r2(nr);
+    for (int k = 0; k < ns; ++k) {
+      hs[k].resize((size_t)sends[k].bytes);
+      if (sends[k].bytes)
+        be_.d2h(hs[k].data(), sends[k].buf, (size_t)sends[k].bytes);
+      s2[k] = TransportMsg{hs[k].data(), sends[k].bytes, sends[k].peer};
+    }
+    for (int k = 0; k < nr; ++k) {
+      hr[k].resize((size_t)recvs[k].bytes);
+      r2[k] = TransportMsg{hr[k].data(), recvs[k].bytes, recvs[k].peer};
+    }
+    if (tr_.exchange(tr_.ctx, ns, s2.data(), nr, r2.data(), nullptr) != 0)
+      throw EngineError{-5, "transport exchange failed"};
+    for (int k = 0; k < nr; ++k)
+      if (recvs[k].bytes)
+        be_.h2d(recvs[k].buf, hr[k].data(), (size_t)recvs[k].bytes);
+  }
+
+  // the global skin vote after a first half-step: returns the trip tag when it can be known now (host transports
+  // and non-speculative ensembles), 0 otherwise (device transports: the kernels look at the reduced word themselves)
+  int vote(bool spec, B& on)
+  {
+    int* word = eng_->bufs().flags + kFlagMoved;
+    device_allreduce_on(on, word, 1, kDtI32, kOpMax);
+    if (spec)
+      return 0;
+    int w = 0;
+    be_.d2h(&w, word, sizeof(int));
+    return w;
+  }
+  int sync_flags()
+  {
+    be_.sync();
+    int flags[kNumFlags];
+    be_.d2h(flags, eng_->bufs().flags, sizeof(flags));
+    eng_->check_overflow_public(flags);
+    return flags[kFlagMoved];
+  }
+
+  // eight raw sums over the owned atoms -> all-reduce -> thermo_dev_
+  void thermo_global()
+  {
+    Engine& e = *eng_;
+    const Bufs& b = e.bufs();
+    be_.thermo(kSlotThermo, e.num_atoms(), volume_, b.mi, b.fo, b.vi, b.fo + (int64_t)kOutW * e.num_atoms(), sums_dev_,
+               e.thermo_scratch(), b.lvl, 1, 0);
+    device_allreduce(sums_dev_, 8, kDtF64, kOpSum);
+    be_.template launch<64>(kSlotMisc, 1, ThermoNormBody{sums_dev_, (double)n_total_, volume_, thermo_dev_});
+  }
+
+  // ---- per-step forward communication of the ghost positions ----
+  void halo_exchange() { halo_exchange_on(be_); }
+  void halo_exchange_on(B& on)
+  {
+    Engine& e = *eng_;
+    for (Stage& st : stages_) {
+      const int64_t c0 = st.cnt_send[0], c1 = st.cnt_send[1], r0 = st.cnt_recv[0], r1 = st.cnt_recv[1];
+      if (c0 + c1 > 0) {
+        HaloPackBody pk;
+        pk.b = e.bufs();
+        pk.idx = st.send_int;
+        pk.cnt0 = c0;
+        pk.cnt1 = c1;
+        for (int k = 0; k < 3; ++k) {
+          pk.shift0[k] = st.shift[0][k];
+          pk.shift1[k] = st.shift[1][k];
+        }
+        pk.out0 = st.sendbuf;
+        pk.out1 = st.sendbuf + 3 * c0;
+        on.template launch<256>(kSlotMisc, c0 + c1, pk);
+      }
+      TransportMsg s[2], r[2];
+      int ns = 0, nr = 0;
+      if (c0) s[ns++] = TransportMsg{st.sendbuf, (int64_t)sizeof(double) * 3 * c0, st.peer_send[0]};
+      if (c1) s[ns++] = TransportMsg{st.sendbuf + 3 * c0, (int64_t)sizeof(double) * 3 * c1, st.peer_send[1]};
+      if (r0) r[nr++] = TransportMsg{st.recvbuf, (int64_t)sizeof(double) * 3 * r0, st.peer_recv[0]};
+      if (r1) r[nr++] = TransportMsg{st.recvbuf + 3 * r0, (int64_t)sizeof(double) * 3 * r1, st.peer_recv[1]};
+      exchange_on(on, ns, s, nr, r);
+      if (r0 + r1 > 0)
+        on.template launch<256>(kSlotMisc, r0 + r1,
+                                HaloUnpackBody{e.box(), e.bufs(), st.recv_int, r0, r1, st.recvbuf, st.recvbuf + 3 * r0});
+    }
+  }
+
+  // ---- migration + ghost construction + list rebuild ----
+  void decompose()
+  {
+    const int me = tr_.rank, P = tr_.nranks;
+    if (resident_) {
+      // owned state back to local order (positions in local coordinates, velocities)
+      Engine& e = *eng_;
+      e.resident_export(cur_.x, cur_.v, nullptr, nullptr, nullptr, 1);
+      be_.sync();
+    }
+    const int64_t n_old = cur_.n, n_own = cur_.n_own;
+    // 1. owners
+    int* dest = iscratch(0, n_own + 1);
+    int* stay = iscratch(1, n_own + 1);
+    int* scan = iscratch(2, n_old + 2);
+    int* sidx = iscratch(3, n_old + 2);
+    int* sscr = iscratch(4, n_old / 512 + 2048);
+    int64_t n_stay = 0;
+    std::vector<int> h_dest, h_leave;
+    if (n_own > 0) {
+      be_.template launch<256>(kSlotMisc, n_own, OwnerBody{geom_, n_old, n_own, me, cur_.x, dest, stay});
+      n_stay = compact(stay, n_own, scan, sidx, sscr);
+    }
+    const int64_t n_leave = n_own - n_stay;
+    int* lidx = iscratch(5, n_leave + 1);
+    if (n_leave > 0) {
+      int* leave = iscratch(6, n_own + 1);
+      be_.template launch<256>(kSlotMisc, n_own, InvertFlagBody{stay, leave});
+      compact(leave, n_own, scan, lidx, sscr);
+      h_leave.resize((size_t)n_leave);
+      be_.d2h(h_leave.data(), lidx, sizeof(int) * n_leave);
+      h_dest.resize((size_t)n_own);
+      be_.d2h(h_dest.data(), dest, sizeof(int) * n_own);
+    }
+    // 2. who sends how many to whom (all ranks learn the whole matrix)
+    std::vector<int64_t> mat((size_t)P * P, 0);
+    std::vector<std::vector<int>> by_dest(P);
+    for (int64_t q = 0; q < n_leave; ++q)
+      by_dest[h_dest[h_leave[q]]].push_back(h_leave[q]);
+    for (int r = 0; r < P; ++r)
+      mat[(size_t)me * P + r] = (int64_t)by_dest[r].size();
+    host_allreduce(mat.data(), (int64_t)P * P, kDtI64, kOpSum);
+    int64_t n_arrive = 0;
+    for (int r = 0; r < P; ++r)
+      n_arrive += mat[(size_t)r * P + me];
+    // 3. migration payloads
+    std::vector<double*> sbuf, rbuf;
+    std::vector<TransportMsg> sends, recvs;
+    std::vector<int64_t> rcount;
+    for (int r = 0; r < P; ++r) {
+      const int64_t c = (int64_t)by_dest[r].size();
+      if (r != me && c > 0) {
+        int* di = iscratch(7, c + 1);
+        be_.h2d(di, by_dest[r].data(), sizeof(int) * c);
+        double* buf = (double*)be_.alloc(sizeof(double) * 9 * c);
+        be_.template launch<256>(kSlotMisc, c, PackStateBody{geom_, n_old, c, di, cur_.x, cur_.v, cur_.m, cur_.t, cur_.id, buf});
+        be_.sync();
+        sbuf.push_back(buf);
+        sends.push_back(TransportMsg{buf, (int64_t)sizeof(double) * 9 * c, r});
+      }
+      const int64_t a = mat[(size_t)r * P + me];
+      if (r != me && a > 0) {
+        double* buf = (double*)be_.alloc(sizeof(double) * 9 * a);
+        rbuf.push_back(buf);
+        rcount.push_back(a);
+        recvs.push_back(TransportMsg{buf, (int64_t)sizeof(double) * 9 * a, r});
+      }
+    }
+    exchange((int)sends.size(), sends.data(), (int)recvs.size(), recvs.data());
+    // 4. new owned set: stayers in their order, then the arrivals by source rank
+    const int64_t n_own_new = n_stay + n_arrive;
+    // capacity of the local system: the ghost shell's share of the padded sub-box at uniform density, with 30 % headroom
+    double grow = 1.3;
+    for (int d = 0; d < 3; ++d)
+      if (geom_.decomposed[d])
+        grow *= 1.0 + 2.0 * geom_.wfrac[d] * geom_.grid[d];
+    const int64_t cap_need = (int64_t)((double)(n_own_new > 1024 ? n_own_new : 1024) * grow) + 4096;
+    State& N = nxt_;
+    if (N.cap < cap_need)
+      alloc_state(N, cap_need);
+    // the gather uses stride n_new, which is only known after the ghost stages: build owned arrays with a
+    // provisional stride = N.cap and repack at the end
+    const int64_t S = N.cap;
+    if (n_stay > 0)
+      be_.template launch<256>(kSlotMisc, n_stay,
+                               GatherStateBody{n_old, S, n_stay, sidx, cur_.x, cur_.v, cur_.m, cur_.t, cur_.id, N.x, N.v, N.m,
+                                               N.t, N.id});
+    int64_t off = n_stay;
+    for (size_t k = 0; k < rbuf.size(); ++k) {
+      be_.template launch<256>(kSlotMisc, rcount[k], UnpackStateBody{geom_, S, off, rcount[k], rbuf[k], N.x, N.v, N.m, N.t, N.id});
+      off += rcount[k];
+    }
+    be_.sync();
+    for (double* p : sbuf) be_.free(p);
+    for (double* p : rbuf) be_.free(p);
+    // 5. ghost stages over the decomposed directions
+    for (auto& st : stages_)
+      free_stage(st);
+    stages_.clear();
+    int64_t n_loc = n_own_new;
+    for (int d = 0; d < 3; ++d) {
+      if (!geom_.decomposed[d])
+        continue;
+      Stage st;
+      st.d = d;
+      int* gflag = iscratch(1, n_loc + 1);
+      int* gscan = iscratch(2, n_loc + 2);
+      int* gidx[2] = {iscratch(8, n_loc + 1), iscratch(9, n_loc + 1)};
+      int* gscr = iscratch(4, n_loc / 512 + 2048);
+      for (int dir = 0; dir < 2; ++dir) { // 0: to the lower neighbour, 1: to the upper one
+        const bool edge = dir == 0 ? geom_.coords[d] == 0 : geom_.coords[d] == geom_.grid[d] - 1;
+        st.peer_send[dir] = neighbor(d, dir == 0 ? -1 : +1);
+        st.peer_recv[dir] = neighbor(d, dir == 0 ? +1 : -1); // message 0 arrives from the upper neighbour (its "to lower")
+        st.cnt_send[dir] = 0;
+        if (!(edge && !geom_.pbc[d]) && n_loc > 0) {
+          be_.template launch<256>(kSlotMisc, n_loc, GhostFlagBody{geom_, S, d, dir, N.x, gflag});
+          st.cnt_send[dir] = compact(gflag, n_loc, gscan, gidx[dir], gscr);
+        }
+        // receiver-local coordinates: + periodic image (edge ranks) + (sender origin - receiver origin)
+        // the receiver's origin sits one sub-box below (dir 0) / above (dir 1) this rank's; across the periodic face
+        // the lattice-vector image and the jump of the origin cancel, so the shift is the same for edge ranks
+        const double dorg = (dir == 0 ? 1.0 : -1.0) / geom_.grid[d];
+        for (int c = 0; c < 3; ++c)
+          st.shift[dir][c] = geom_.H[3 * c + d] * dorg;
+      }
+      // counts, then payloads (position in the receiver's local coordinates + type)
+      int64_t cs[2] = {st.cnt_send[0], st.cnt_send[1]}, cr[2] = {0, 0};
+      exchange_counts(st, cs, cr);
+      st.cnt_recv[0] = cr[0];
+      st.cnt_recv[1] = cr[1];
+      const int64_t cst = cs[0] + cs[1], crt = cr[0] + cr[1];
+      if (n_loc + crt > N.cap)
+        throw EngineError{-6, "domain decomposition: more ghost atoms than the density-based capacity of the local system "
+                              "(strongly non-uniform density across the sub-boxes)"};
+      st.send_idx = (int*)be_.alloc(sizeof(int) * (cst + 1));
+      st.send_int = (int*)be_.alloc(sizeof(int) * (cst + 1));
+      st.recv_int = (int*)be_.alloc(sizeof(int) * (crt + 1));
+      st.sendbuf = (double*)be_.alloc(sizeof(double) * 4 * (cst + 1));
+      st.recvbuf = (double*)be_.alloc(sizeof(double) * 4 * (crt + 1));
+      if (cs[0]) copy_dev(st.send_idx, gidx[0], sizeof(int) * cs[0]);
+      if (cs[1]) copy_dev(st.send_idx + cs[0], gidx[1], sizeof(int) * cs[1]);
+      TransportMsg s[2], r[2];
+      int ns = 0, nr = 0;
+      for (int dir = 0; dir < 2; ++dir) {
+        const int64_t c = cs[dir];
+        if (c == 0)
+          continue;
+        double* out = st.sendbuf + (dir == 0 ? 0 : 4 * cs[0]);
+        PackGhostBody pg;
+        pg.n = S;
+        pg.cnt = c;
+        pg.idx = st.send_idx + (dir == 0 ? 0 : cs[0]);
+        pg.x = N.x;
+        pg.type = N.t;
+        for (int k = 0; k < 3; ++k)
+          pg.shift[k] = st.shift[dir][k];
+        pg.out = out;
+        be_.template launch<256>(kSlotMisc, c, pg);
+        s[ns++] = TransportMsg{out, (int64_t)sizeof(double) * 4 * c, st.peer_send[dir]};
+      }
+      for (int dir = 0; dir < 2; ++dir)
+        if (cr[dir])
+          r[nr++] = TransportMsg{st.recvbuf + (dir == 0 ? 0 : 4 * cr[0]), (int64_t)sizeof(double) * 4 * cr[dir], st.peer_recv[dir]};
+      be_.sync();
+      exchange(ns, s, nr, r);
+      for (int dir = 0; dir < 2; ++dir) {
+        st.off_recv[dir] = n_loc;
+        if (cr[dir])
+          be_.template launch<256>(kSlotMisc, cr[dir],
+                                   UnpackGhostBody{S, n_loc, cr[dir], st.recvbuf + (dir == 0 ? 0 : 4 * cr[0]), N.x, N.t});
+        n_loc += cr[dir];
+      }
+      be_.sync();
+      stages_.push_back(st);
+    }
+    // 6. repack to stride n_loc, levels
+    State& C = cur_;
+    if (C.cap < n_loc + 1)
+      alloc_state(C, n_loc + n_loc / 4 + 1024);
+    repack(N, S, C, n_loc, n_own_new);
+    C.n = n_loc;
+    C.n_own = n_own_new;
+    if (n_loc > 0)
+      be_.template launch<256>(kSlotMisc, n_loc, LevelBody{geom_, n_loc, n_own_new, C.x, C.lvl});
+    // 7. engine: lists on the local system, internal index lists of the halo, integrator state
+    if (!eng_ || n_loc > eng_cap_) {
+      eng_cap_ = n_loc + n_loc / 7 + 1024;
+      eng_.reset(new Engine(model_, eng_cap_, be_));
+      eng_->set_external_skin(true); // the global vote is the skin policy
+      eng_->bdp_seed(seed_);
+    }
+    Engine& e = *eng_;
+    e.invalidate();
+    e.prepare_lists(h_loc_, pbc_loc_, n_loc, C.t, C.x, C.lvl);
+    e.resident_alloc();
+    e.resident_import(C.v, C.m, nullptr, nullptr, nullptr);
+    int* inv = iscratch(10, n_loc + 1);
+    be_.template launch<256>(kSlotMisc, n_loc, InversePermBody{e.bufs().perm, inv});
+    for (Stage& st : stages_) {
+      const int64_t cst = st.cnt_send[0] + st.cnt_send[1];
+      if (cst)
+        be_.template launch<256>(kSlotMisc, cst, MapIndexBody{inv, st.send_idx, 0, st.send_int});
+      if (st.cnt_recv[0])
+        be_.template launch<256>(kSlotMisc, st.cnt_recv[0], MapIndexBody{inv, nullptr, st.off_recv[0], st.recv_int});
+      if (st.cnt_recv[1])
+        be_.template launch<256>(kSlotMisc, st.cnt_recv[1],
+                                 MapIndexBody{inv, nullptr, st.off_recv[1], st.recv_int + st.cnt_recv[0]});
+    }
+    be_.sync();
+    resident_ = true;
+    ++num_decompositions;
+  }
+
+  // stable compaction of the indices with flag set; returns their number
+  int64_t compact(int* flag, int64_t n, int* scan, int* idx_out, int* scr)
+  {
+    copy_dev(scan, flag, sizeof(int) * n);
+    int zero = 0;
+    be_.h2d(scan + n, &zero, sizeof(int));
+    be_.exclusive_scan(scan, n + 1, scr);
+    be_.template launch<256>(kSlotMisc, n, CompactBody{flag, scan, idx_out});
+    int total = 0;
+    be_.sync();
+    be_.d2h(&total, scan + n, sizeof(int));
+    return total;
+  }
+
+  void exchange_counts(const Stage& st, const int64_t cs[2], int64_t cr[2])
+  {
+    if (tr_.nranks == 1) {
+      cr[0] = cr[1] = 0;
+      return;
+    }
+    // counts travel through the host-side path of the transport (8 bytes each)
+    int64_t* d = (int64_t*)be_.alloc(sizeof(int64_t) * 4);
+    be_.h2d(d, cs, sizeof(int64_t) * 2);
+    TransportMsg s[2] = {{d, 8, st.peer_send[0]}, {d + 1, 8, st.peer_send[1]}};
+    TransportMsg r[2] = {{d + 2, 8, st.peer_recv[0]}, {d + 3, 8, st.peer_recv[1]}};
+    exchange(2, s, 2, r);
+    be_.sync();
+    be_.d2h(cr, d + 2, sizeof(int64_t) * 2);
+    be_.free(d);
+  }
+
+  // [3][S] staging arrays -> [3][n] arrays of the current state
+  void repack(const State& from, int64_t S, State& to, int64_t n, int64_t n_own)
+  {
+    for (int d = 0; d < 3; ++d) {
+      if (n)
+        copy_dev(to.x + d * n, from.x + d * S, sizeof(double) * n);
+      if (n_own)
+        copy_dev(to.v + d * n, from.v + d * S, sizeof(double) * n_own);
+    }
+    if (n_own) {
+      copy_dev(to.m, from.m, sizeof(double) * n_own);
+      copy_dev(to.id, from.id, sizeof(int64_t) * n_own);
+    }
+    if (n)
+      copy_dev(to.t, from.t, sizeof(int) * n);
+  }
+
+  NepModel model_;
+  TransportView tr_;
+  B be_;
+  DomainGeom geom_;
+  double hg_[9], h_loc_[9], volume_ = 0.0;
+  int pbc_loc_[3];
+  int64_t n_total_ = 0;
+  State cur_, nxt_;
+  std::vector<Stage> stages_;
+  std::unique_ptr<Engine> eng_;
+  int64_t eng_cap_ = 0;
+  bool resident_ = false, have_force_ = false;
+  bool overlap_ = true;  // interior bricks' radial pass while the ghost positions travel
+  B side_;               // the backend on the communication stream (device transports)
+  bool side_ready_ = false;
+  uint64_t seed_ = 12345678u;
+  int* flag_dev_ = nullptr;
+  double *sums_dev_ = nullptr, *thermo_dev_ = nullptr, *nhc_dev_ = nullptr, *factor_dev_ = nullptr;
+  std::vector<int*> iscr_;
+  std::vector<int64_t> iscr_cap_;
+  std::vector<void*> scratch_;
+};
+
+} // namespace nepmi

@@ -588,6 +588,39 @@ struct HipBackend {
       NEPMI_HIP_CHECK(hipStreamSynchronize(stream));
     }
   }
+  void d2d(void* dst, const void* src, size_t bytes)
+  {
+    NEPMI_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, stream));
+  }
+  void* stream_handle() { return (void*)stream; }
+  // a second stream for communication that overlaps compute (domain decomposition): same device, own events
+  hipEvent_t fork_ev = nullptr, join_ev = nullptr;
+  HipBackend make_side_stream()
+  {
+    HipBackend s = *this;
+    hipStream_t st = nullptr;
+    NEPMI_HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    s.stream = st;
+    s.timing_on = false;
+    s.timing_mode = 0;
+    s.frozen = nullptr;
+    s.fork_ev = s.join_ev = nullptr;
+    return s;
+  }
+  void fork_to(HipBackend& side) // side continues after everything enqueued here so far
+  {
+    if (!fork_ev)
+      NEPMI_HIP_CHECK(hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming));
+    NEPMI_HIP_CHECK(hipEventRecord(fork_ev, stream));
+    NEPMI_HIP_CHECK(hipStreamWaitEvent(side.stream, fork_ev, 0));
+  }
+  void join_from(HipBackend& side) // this stream continues after everything enqueued on side so far
+  {
+    if (!join_ev)
+      NEPMI_HIP_CHECK(hipEventCreateWithFlags(&join_ev, hipEventDisableTiming));
+    NEPMI_HIP_CHECK(hipEventRecord(join_ev, side.stream));
+    NEPMI_HIP_CHECK(hipStreamWaitEvent(stream, join_ev, 0));
+  }
   void sync() { NEPMI_HIP_CHECK(hipStreamSynchronize(stream)); }
 
   // ---- HIP-event timing on the engine's own stream (bench.py's roofline leg) ----
@@ -870,4 +903,76 @@ static NepmiBackend nepmi_make_backend(void* stream)
   return b;
 }
 
-#include "capi_impl.h"
+#include "dist_capi_impl.h"
+
+// ---- RCCL transport (device buffers over xGMI): nepmi_transport_rccl ---------------------------------------
+#include <rccl/rccl.h>
+
+namespace {
+
+struct RcclCtx {
+  ncclComm_t comm;
+};
+
+int rccl_exchange(void* vctx, int ns, const nepmi_msg* sends, int nr, const nepmi_msg* recvs, void* stream)
+{
+  RcclCtx* c = (RcclCtx*)vctx;
+  bool ok = ncclGroupStart() == ncclSuccess;
+  for (int k = 0; k < ns && ok; ++k)
+    ok = ncclSend(sends[k].buf, (size_t)sends[k].bytes, ncclChar, sends[k].peer, c->comm, (hipStream_t)stream) == ncclSuccess;
+  for (int k = 0; k < nr && ok; ++k)
+    ok = ncclRecv(recvs[k].buf, (size_t)recvs[k].bytes, ncclChar, recvs[k].peer, c->comm, (hipStream_t)stream) == ncclSuccess;
+  ok = (ncclGroupEnd() == ncclSuccess) && ok;
+  return ok ? 0 : -1;
+}
+
+int rccl_allreduce(void* vctx, void* buf, int64_t count, int dtype, int op, void* stream)
+{
+  RcclCtx* c = (RcclCtx*)vctx;
+  const ncclDataType_t dt = dtype == 0 ? ncclFloat64 : (dtype == 1 ? ncclInt32 : ncclInt64);
+  const ncclRedOp_t ro = op == 0 ? ncclSum : ncclMax;
+  return ncclAllReduce(buf, buf, (size_t)count, dt, ro, c->comm, (hipStream_t)stream) == ncclSuccess ? 0 : -1;
+}
+
+void rccl_destroy(void* vctx)
+{
+  RcclCtx* c = (RcclCtx*)vctx;
+  if (c) {
+    ncclCommDestroy(c->comm);
+    delete c;
+  }
+}
+
+} // namespace
+
+extern "C" int nepmi_transport_rccl_id(char id[NEPMI_RCCL_ID_BYTES])
+{
+  static_assert(sizeof(ncclUniqueId) <= NEPMI_RCCL_ID_BYTES, "ncclUniqueId does not fit the id buffer");
+  ncclUniqueId u;
+  if (ncclGetUniqueId(&u) != ncclSuccess)
+    return fail(NEPMI_ERR_HIP, "ncclGetUniqueId failed");
+  std::memset(id, 0, NEPMI_RCCL_ID_BYTES);
+  std::memcpy(id, &u, sizeof u);
+  return NEPMI_OK;
+}
+
+extern "C" int nepmi_transport_rccl(const char id[NEPMI_RCCL_ID_BYTES], int rank, int nranks, nepmi_transport* out)
+{
+  if (!id || !out || rank < 0 || rank >= nranks)
+    return fail(NEPMI_ERR_ARG, "bad argument");
+  ncclUniqueId u;
+  std::memcpy(&u, id, sizeof u);
+  RcclCtx* c = new RcclCtx();
+  if (ncclCommInitRank(&c->comm, nranks, u, rank) != ncclSuccess) {
+    delete c;
+    return fail(NEPMI_ERR_HIP, "ncclCommInitRank failed (one process per GPU: two ranks cannot share a device)");
+  }
+  out->ctx = c;
+  out->rank = rank;
+  out->nranks = nranks;
+  out->device_buffers = 1;
+  out->exchange = rccl_exchange;
+  out->allreduce = rccl_allreduce;
+  out->destroy = rccl_destroy;
+  return NEPMI_OK;
+}

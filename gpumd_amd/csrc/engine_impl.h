@@ -116,6 +116,9 @@ public:
   }
 
   B& backend() { return be_; }
+  const BoxD& box() const { return box_; }
+  double* thermo_scratch() { return thermo_scratch_; }
+  void check_overflow_public(const int* flags) { check_overflow(flags); }
   const NepModel& model() const { return model_; }
   const Bufs& bufs() const { return b_; }
   int64_t num_atoms() const { return N_; }
@@ -1238,6 +1241,7 @@ private:
     be_.end_region(kRegionForce);
   }
 
+public:
   // frozen != nullptr: a speculatively enqueued step of a fused run loop -- every kernel of the force path looks at
   // that device word first and returns when a list rebuild is pending
   void force_kernels(int phase, const int* frozen = nullptr)
@@ -1247,6 +1251,7 @@ private:
     be_.frozen = nullptr;
   }
 
+private:
   void force_kernels_dispatch(int phase, const int* frozen)
   {
     if (model_.kind == 1) { // Tersoff1989::compute, tersoff1989.cu:508-586

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define NEPMI_VERSION 100
+#define NEPMI_VERSION 200
 
 typedef enum {
   NEPMI_OK = 0,
@@ -43,8 +43,9 @@ typedef enum {
   NEPMI_ERR_HIP = -5,         /* HIP runtime error or no gfx950 device */
   NEPMI_ERR_CAPACITY = -6,    /* a neighbour list exceeded its MN capacity (the reference corrupts
                                  memory silently here, src/force/nep.cu:234-235,1014-1034) */
-  NEPMI_ERR_SMALL_BOX = -7    /* a periodic thickness <= 2.5*(rc+skin): reference takes
-                                 nep_small_box.cuh; not implemented on the device yet */
+  NEPMI_ERR_SMALL_BOX = -7    /* a box the small-box branch (a periodic thickness <= 2.5*(rc+skin), reference:
+                                 nep_small_box.cuh) cannot take: more than 20000 atoms, or thicker than 10 rc in
+                                 another direction (the reference refuses that one too, nep.cu:1316-1324) */
 } nepmi_status;
 
 typedef struct nepmi_model nepmi_model;   /* parsed nep.txt (host)            */
@@ -212,6 +213,83 @@ int nepmi_run_nvt_bdp(
   const double* mass, double dt, int64_t nsteps, double t1, double t2, double t_coup, double* pos,
   double* vel, double* pe, double* force, double* virial, int64_t thermo_every, double* thermo_host);
 
+/* ---- multi-GPU: spatial domain decomposition, one process per GPU ----
+ *      Replaces NEP_MULTIGPU (src/force/nep_multigpu.cuh:42-50 ranges, nep_multigpu.cu:1416-1803 compute) and
+ *      Force::parse_potential's choice of it for `potential <file> [x|y|z]` (src/force/force.cu:122-160).  Every
+ *      rank owns the atoms of its sub-box of a Cartesian process grid (grid[0] * grid[1] * grid[2] ranks over the
+ *      fractional coordinates of the global cell) and their integrator state; ghost positions travel once per step
+ *      (shell 2 (rc + skin), descriptors of the inner ring recomputed, forces for owned atoms only, no reverse
+ *      communication -- the reference's semantics); migration and ghost lists are rebuilt only when some atom of
+ *      some rank moved more than skin/2 (neighbor.cu:741-800, voted globally).  DESIGN.md section 7.
+ *
+ *      The transport is a table of function pointers.  device_buffers = 1: buffers are DEVICE memory and the calls
+ *      enqueue on `stream` (RCCL over xGMI: nepmi_transport_rccl) -- the step then runs without host round trips,
+ *      the skin vote is reduced on the device; device_buffers = 0: buffers are HOST memory, calls block
+ *      (nepmi_transport_tcp, or the caller's own functions, e.g. over MPI): the driver stages through the host. ---- */
+typedef struct {
+  void* buf;
+  int64_t bytes;
+  int peer;
+} nepmi_msg;
+typedef struct {
+  void* ctx;
+  int rank, nranks;
+  int device_buffers;
+  /* all sends and receives of one call may progress concurrently (ncclGroupStart/End semantics); several messages
+     to / from the same peer match in order */
+  int (*exchange)(void* ctx, int nsend, const nepmi_msg* sends, int nrecv, const nepmi_msg* recvs, void* stream);
+  /* in place; dtype 0 = f64, 1 = i32, 2 = i64; op 0 = sum, 1 = max; every rank must end with identical bits */
+  int (*allreduce)(void* ctx, void* buf, int64_t count, int dtype, int op, void* stream);
+  void (*destroy)(void* ctx);
+} nepmi_transport;
+
+#define NEPMI_RCCL_ID_BYTES 128
+/* RCCL: rank 0 creates the id (ncclGetUniqueId) and hands it to the others by any means (a file, MPI, torch's
+ * store); then every rank builds its communicator (ncclCommInitRank) on the current HIP device. */
+int nepmi_transport_rccl_id(char id[NEPMI_RCCL_ID_BYTES]);
+int nepmi_transport_rccl(const char id[NEPMI_RCCL_ID_BYTES], int rank, int nranks, nepmi_transport* out);
+/* TCP sockets on one node (rank 0 listens on master_addr:port, the MASTER_ADDR / MASTER_PORT of a torchrun-style
+ * launch); host buffers. */
+int nepmi_transport_tcp(const char* master_addr, int port, int rank, int nranks, nepmi_transport* out);
+void nepmi_transport_destroy(nepmi_transport* t);
+
+typedef struct nepmi_dist nepmi_dist;
+/* h, pbc: the GLOBAL cell.  The transport is used (not owned) until nepmi_dist_destroy. */
+nepmi_dist* nepmi_dist_create(
+  const nepmi_model* m, const nepmi_transport* t, const double h[9], const int pbc[3], const int grid[3],
+  void* hip_stream);
+void nepmi_dist_destroy(nepmi_dist* d);
+/* The atoms this rank contributes (DEVICE arrays as in the conventions above, n may be 0; any positions: they are
+ * migrated to their owners).  ids: global atom numbers, or NULL for a running number over the ranks. */
+int nepmi_dist_setup(
+  nepmi_dist* d, int64_t n, const int* type, const double* mass, const double* pos, const double* vel,
+  const int64_t* ids);
+/* Force::compute on the decomposed system (the initial force of Run::perform_a_run). */
+int nepmi_dist_compute(nepmi_dist* d);
+/* The run loop for ensemble 0 = nve, 1 = nvt_ber, 2 = nvt_nhc, 3 = nvt_bdp (see nepmi_run_*); thermo_host (HOST,
+ * 8 doubles per record, may be NULL) receives the GLOBAL T, U and stresses on every rank. */
+int nepmi_dist_run(
+  nepmi_dist* d, int ensemble, double dt, int64_t nsteps, double t1, double t2, double t_coup,
+  int64_t thermo_every, double* thermo_host);
+int nepmi_dist_thermo(nepmi_dist* d, double thermo8_host[8]);
+int nepmi_dist_bdp_seed(nepmi_dist* d, uint64_t seed);
+/* on (default): the radial pass of the interior bricks (no ghost in their 8x8x8-cell window) is enqueued on the
+ * compute stream while the skin vote and the ghost positions travel on a communication stream; off: the plain
+ * exchange-then-compute order.  Both orders give bit-identical results. */
+int nepmi_dist_set_overlap(nepmi_dist* d, int on);
+typedef struct {
+  int64_t n_owned, n_local, n_total; /* atoms owned by this rank, owned + ghosts, in the whole system */
+  int64_t num_decompositions, num_steps;
+  int64_t num_overlapped; /* steps whose interior radial pass was enqueued before the ghost exchange completed */
+} nepmi_dist_info;
+int nepmi_dist_get_info(nepmi_dist* d, nepmi_dist_info* out);
+/* The owned atoms of this rank (n_owned entries per plane, global coordinates) into the caller's DEVICE arrays;
+ * any pointer may be NULL. */
+int nepmi_dist_gather_owned(
+  nepmi_dist* d, int64_t* ids, double* pos, double* vel, double* force, double* pe, double* virial);
+/* The engine of the local (owned + ghost) system, e.g. for nepmi_engine_stats / nepmi_engine_set_timing. */
+nepmi_engine* nepmi_dist_engine(nepmi_dist* d);
+
 /* ---- diagnostics / parity hooks ---- */
 
 /* Per-step radial (which = 0) / angular (which = 1) neighbour lists of the LAST compute, in the
@@ -252,10 +330,11 @@ int nepmi_engine_set_timing(nepmi_engine* e, int on);
  * one; used by the parity tests to cover both code paths with one model. */
 int nepmi_engine_set_generic(nepmi_engine* e, int on);
 /* LDS-window kernels: 0 = none (plain gather kernel for the radial pass, pair records for the force
- * assembly), 1 = radial pass only, 2 = radial pass and force assembly, -1 (default) = the engine times
- * modes 2 and 1 once on its first four force calls and keeps the faster; the window kernels are
- * also dropped automatically when a periodic direction has fewer than 8 cells or a brick's window
- * does not fit LDS.  All give identical lists and forces to f32 rounding. */
+ * assembly); anything else (the default) = the radial pass and the force assembly both work from the LDS position
+ * window.  The choice is a rule, never a timing: the same input always runs the same kernels.  The window
+ * kernels are dropped automatically when a periodic direction has fewer than 8 cells, a brick's window does not
+ * fit LDS or an atom sits far outside the box along an open direction.  Both give identical lists and forces to
+ * f32 rounding. */
 int nepmi_engine_set_tiles(nepmi_engine* e, int on);
 /* Allow (default) or forbid the matrix-core (v_mfma_f32_32x32x2_f32) ANN kernel; forbidding selects
  * the per-atom ANN kernel, which is also taken automatically for models with more than 4 types,

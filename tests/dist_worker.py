@@ -1,0 +1,77 @@
+"""Worker of tests/test_dist.py: one rank of the C++ domain-decomposed driver (nepmi_dist_*, include/nepmi.h) over
+the TCP transport.  "cpu": kernel logic from the test-only emulator library; "gpu": the product library, all ranks
+sharing cuda:0 of a 1-GPU test box (RCCL refuses two ranks on one device, so payloads are staged through the host)."""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import helpers as H  # noqa: E402
+import parity_cases as P  # noqa: E402
+from gpumd_amd.dist import DistMD, Transport  # noqa: E402
+
+
+def main():
+    out_dir, spec = sys.argv[1], json.loads(sys.argv[2])
+    on_gpu = spec["device"] == "gpu"
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    drv = H.GpuDriver() if on_gpu else H.EmuDriver()
+    nep_rel, build, _ = P.MODELS[spec["model"]] if spec["model"] in P.MODELS else (None, None, None)
+    if spec["model"] == "PbTe-reps":
+        nep = H.golden("PbTe", "nep.txt")
+        h, typ, x = H.pbte_supercell(tuple(spec["reps"]), rattle=0.02, seed=31)
+        masses = {0: H.MASS["Te"], 1: H.MASS["Pb"]}
+    elif spec["model"] == "C-2022":
+        nep = H.golden("C", "nep.txt")
+        h, typ, x = H.diamond(tuple(spec["reps"]), 3.57, rattle=0.02, seed=32)
+        masses = {0: H.MASS["C"]}
+    elif spec["model"] == "UNEP-v1":
+        nep = H.golden("UNEP", "nep.txt")
+        h, typ, x = H.fcc_alloy(tuple(spec["reps"]), 3.9, 16, rattle=0.02, seed=33)
+        masses = {t: 60.0 + 7.0 * t for t in range(16)}
+    else:
+        raise SystemExit("unknown model")
+    model = drv.model(nep)
+    n = len(typ)
+    typ = typ.astype(np.int32)
+    mass = np.array([masses[int(t)] for t in typ], dtype=np.float64)
+    vel = H.maxwell_velocities(mass, spec["temp"], seed=5)
+    mine = np.arange(n) % world == rank  # arbitrary initial distribution; setup() migrates
+    ids = np.arange(n, dtype=np.int64)[mine]
+    tr = Transport.tcp(drv.lib, "127.0.0.1", int(os.environ["MASTER_PORT"]), rank, world)
+    md = DistMD(model, tr, h, (1, 1, 1), spec["grid"])
+    md.setup(drv.dev(typ[mine]), drv.dev(mass[mine]), drv.dev(np.ascontiguousarray(x.reshape(3, n)[:, mine]).reshape(-1)),
+             drv.dev(np.ascontiguousarray(vel.reshape(3, n)[:, mine]).reshape(-1)), drv.dev(ids))
+    if "overlap" in spec:
+        md.set_overlap(spec["overlap"])
+    if spec.get("seed") is not None:
+        md.bdp_seed(spec["seed"])
+    md.compute()
+
+    def snapshot():
+        no = md.info().n_owned
+        d_id = drv.dev(np.zeros(no, dtype=np.int64))
+        d_x, d_v, d_f = drv.zeros(3 * no), drv.zeros(3 * no), drv.zeros(3 * no)
+        md.gather_owned(d_id, d_x, d_v, d_f)
+        return drv.host(d_id), drv.host(d_x).reshape(3, no), drv.host(d_v).reshape(3, no), drv.host(d_f).reshape(3, no)
+
+    i0, x0, v0, f0 = snapshot()
+    th0 = md.thermo()
+    dt = spec["dt_fs"] / H.TIME_UNIT
+    th = md.run(spec["ensemble"], dt, spec["nsteps"], spec.get("t1", 0.0), spec.get("t2", 0.0), spec.get("tcoup", 1.0),
+                thermo_every=spec.get("thermo_every", 0))
+    i1, x1, v1, f1 = snapshot()
+    th1 = md.thermo()
+    info = md.info()
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), i0=i0, f0=f0, th0=th0, i1=i1, x1=x1, v1=v1, f1=f1, th1=th1, th=th,
+             n_loc=info.n_local, n_own=info.n_owned, ndec=info.num_decompositions, nover=info.num_overlapped)
+    md.close()
+    tr.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -23,6 +23,11 @@ struct HostLoopBackend {
   void memset(void* p, int v, size_t bytes) { std::memset(p, v, bytes); }
   void h2d(void* dst, const void* src, size_t bytes) { std::memcpy(dst, src, bytes); }
   void d2h(void* dst, const void* src, size_t bytes) { std::memcpy(dst, src, bytes); }
+  void d2d(void* dst, const void* src, size_t bytes) { std::memmove(dst, src, bytes); }
+  void* stream_handle() { return nullptr; }
+  HostLoopBackend make_side_stream() { return *this; }
+  void fork_to(HostLoopBackend&) {}
+  void join_from(HostLoopBackend&) {}
   void sync() {}
   void begin_region(int) {}
   void end_region(int) {}
@@ -152,4 +157,11 @@ struct HostLoopBackend {
 using NepmiBackend = nepmi::HostLoopBackend;
 static NepmiBackend nepmi_make_backend(void*) { return NepmiBackend(); }
 
-#include "../../gpumd_amd/csrc/capi_impl.h"
+#include "../../gpumd_amd/csrc/dist_capi_impl.h"
+
+// the emulator has no devices: the RCCL entry points exist (same C ABI) and refuse
+extern "C" int nepmi_transport_rccl_id(char*) { return fail(NEPMI_ERR_HIP, "no RCCL in the kernel-logic emulator"); }
+extern "C" int nepmi_transport_rccl(const char*, int, int, nepmi_transport*)
+{
+  return fail(NEPMI_ERR_HIP, "no RCCL in the kernel-logic emulator");
+}

@@ -22,73 +22,8 @@ def _p(a, t):
     return a.ctypes.data_as(t) if a is not None else None
 
 
-# --------------------------------------------------------------------------------------------
-# extended XYZ (the subset of read_xyz.cu:141-400 the fixtures use)
-# --------------------------------------------------------------------------------------------
-def read_xyz_frames(path):
-    frames = []
-    with open(path) as f:
-        lines = f.read().split("\n")
-    i = 0
-    while i < len(lines) and lines[i].strip():
-        n = int(lines[i].split()[0])
-        comment = lines[i + 1]
-        kv = {}
-        for m in re.finditer(r'(\w+)=("([^"]*)"|(\S+))', comment):
-            kv[m.group(1).lower()] = m.group(3) if m.group(3) is not None else m.group(4)
-        lat = np.array([float(x) for x in kv["lattice"].split()]).reshape(3, 3)  # rows a,b,c
-        props = kv["properties"].split(":")
-        cols = []
-        off = 0
-        for k in range(0, len(props), 3):
-            name, typ, cnt = props[k].lower(), props[k + 1], int(props[k + 2])
-            cols.append((name, typ, cnt, off))
-            off += cnt
-        body = [lines[i + 2 + a].split() for a in range(n)]
-        fr = {"n": n, "lattice": lat, "comment": kv}
-        # GPUMD stores h = [a b c] as columns: h[0]=ax h[1]=bx h[2]=cx h[3]=ay ... (read_xyz.cu:208-216)
-        fr["h"] = np.ascontiguousarray(lat.T.reshape(9))
-        pbc = kv.get("pbc", "T T T").split()
-        fr["pbc"] = np.array([1 if p.upper().startswith("T") else 0 for p in pbc], dtype=np.int32)
-        for name, typ, cnt, o in cols:
-            if typ == "S":
-                fr[name] = [b[o] for b in body]
-            else:
-                fr[name] = np.array([[float(x) for x in b[o:o + cnt]] for b in body])
-        for key in ("energy",):
-            if key in kv:
-                fr[key] = float(kv[key])
-        if "virial" in kv:
-            fr["virial"] = np.array([float(x) for x in kv["virial"].split()])
-        frames.append(fr)
-        i += 2 + n
-    return frames
-
-
-def types_from_species(species, symbols):
-    idx = {s: k for k, s in enumerate(symbols)}
-    return np.array([idx[s] for s in species], dtype=np.int32)
-
-
-def soa(pos_nx3):
-    """(N,3) -> GPUMD SoA [x..|y..|z..]"""
-    return np.ascontiguousarray(np.asarray(pos_nx3, dtype=np.float64).T.reshape(-1))
-
-
-def replicate(h, species_or_type, pos_nx3, reps):
-    """Supercell with GPUMD's atom order (replicate.cu:50-71): i, j, k outer loops, basis inner."""
-    H = np.asarray(h, dtype=np.float64).reshape(3, 3)  # columns a,b,c
-    a, b, c = H[:, 0], H[:, 1], H[:, 2]
-    pos = np.asarray(pos_nx3, dtype=np.float64)
-    out = []
-    typ = []
-    for i in range(reps[0]):
-        for j in range(reps[1]):
-            for k in range(reps[2]):
-                out.append(pos + i * a + j * b + k * c)
-                typ.append(np.asarray(species_or_type))
-    Hn = H * np.array(reps, dtype=np.float64)[None, :]
-    return np.ascontiguousarray(Hn.reshape(9)), np.concatenate(typ), np.concatenate(out)
+# input construction lives in the package (bench.py uses it without importing anything from tests/)
+from gpumd_amd.structures import read_xyz_frames, replicate, soa, types_from_species  # noqa: E402,F401
 
 
 # --------------------------------------------------------------------------------------------
@@ -380,26 +315,9 @@ def diamond(cells, a, rattle=0.03, seed=9):
     return h, typ.astype(np.int32), x
 
 
-MASS = {"Te": 127.6, "Pb": 207.2, "C": 12.011, "Ba": 137.327, "Zr": 91.224, "O": 15.999, "H": 1.008}
-K_B = 8.617343e-5
-TIME_UNIT = 10.18051  # fs per natural time unit (src/utilities/common.cuh:26)
+from gpumd_amd.structures import K_B, MASS, TIME_UNIT, maxwell_velocities  # noqa: E402,F401
 
 
-def maxwell_velocities(mass, temperature, seed=11):
-    """Gaussian velocities at `temperature`, zero net momentum, SoA [vx|vy|vz] in natural units."""
-    rng = np.random.default_rng(seed)
-    n = len(mass)
-    v = rng.normal(0.0, 1.0, (3, n)) * np.sqrt(K_B * temperature / mass)[None, :]
-    v -= (v * mass[None, :]).sum(axis=1, keepdims=True) / mass.sum()
-    t_now = (mass[None, :] * v * v).sum() / (3.0 * n * K_B)
-    v *= np.sqrt(temperature / t_now)
-    return np.ascontiguousarray(v.reshape(-1))
-
-
-# --------------------------------------------------------------------------------------------
-# drivers for the C ABI: `EmuDriver` = tests/emu host-loop emulator (CPU tier, kernel logic),
-# `GpuDriver` = the product library on cuda:0.  Both go through gpumd_amd.nep.NEP.
-# --------------------------------------------------------------------------------------------
 class EmuDriver:
     name = "emu"
 

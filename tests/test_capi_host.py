@@ -32,7 +32,7 @@ def test_header_and_bindings_agree(lib):
     assert declared == set(_capi.SYMBOLS), declared ^ set(_capi.SYMBOLS)
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.nepmi_version() == 100
+    assert lib.nepmi_version() == 200
 
 
 @pytest.mark.parametrize("rel", ["PbTe/nep.txt", "PbTe/nep_B.txt", "C/nep.txt", "C/nep3.txt", "UNEP/nep.txt",

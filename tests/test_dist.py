@@ -1,0 +1,151 @@
+"""The N > 1 path: the C++ domain-decomposed driver of libnepmi (nepmi_dist_*: spatial decomposition, ghost exchange,
+migration, the global skin vote, every ensemble) with world_size 2 and 4 over the TCP transport, against the
+single-domain run of the same system.  CPU tier: kernel logic from the emulator library; GPU tier: the product
+library with the ranks sharing the test box's one GPU (what is NOT covered is only the RCCL transport itself)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+import helpers as H
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run_ranks(world, spec):
+    out = tempfile.mkdtemp(prefix="nepmi_dist_")
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(H.ROOT, "tests", "dist_worker.py"), out, json.dumps(spec)],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    logs = [p.communicate(timeout=900)[0].decode() for p in procs]
+    for p, log in zip(procs, logs):
+        assert p.returncode == 0, log[-3000:]
+    return [np.load(os.path.join(out, "rank%d.npz" % r)) for r in range(world)]
+
+
+def _merge(ranks, n):
+    ids = np.concatenate([r["i1"] for r in ranks])
+    assert len(ids) == n and len(np.unique(ids)) == n  # every atom owned exactly once
+    order = np.argsort(ids)
+    x = np.concatenate([r["x1"] for r in ranks], axis=1)[:, order]
+    v = np.concatenate([r["v1"] for r in ranks], axis=1)[:, order]
+    f = np.concatenate([r["f1"] for r in ranks], axis=1)[:, order]
+    ids0 = np.concatenate([r["i0"] for r in ranks])
+    f0 = np.concatenate([r["f0"] for r in ranks], axis=1)[:, np.argsort(ids0)]
+    return x, v, f, f0
+
+
+def _check(world, spec, n, f_tol=3e-5, traj_tol=2e-6):
+    multi = _run_ranks(world, spec)
+    single = _run_ranks(1, dict(spec, grid=[1, 1, 1]))
+    xs, vs, fs, f0s = _merge(single, n)
+    xm, vm, fm, f0m = _merge(multi, n)
+    # initial forces: the decomposed evaluation equals the single-domain one to FP32 summation order
+    assert np.abs(f0m - f0s).max() < f_tol + 1e-5 * np.abs(f0s).max()
+    # trajectory: positions modulo lattice vectors, velocities, forces
+    assert np.abs(vm - vs).max() < traj_tol
+    assert np.abs(fm - fs).max() < 30 * f_tol + 1e-4 * np.abs(fs).max()
+    # global thermodynamic sums agree on every rank and with the single-domain run
+    for r in multi:
+        np.testing.assert_allclose(r["th1"], multi[0]["th1"], rtol=0, atol=0)
+        np.testing.assert_allclose(r["th1"][:2], single[0]["th1"][:2], rtol=1e-6)
+        if len(r["th"]):
+            np.testing.assert_allclose(r["th"][:, :2], single[0]["th"][:, :2], rtol=1e-6)
+    return multi, single
+
+
+CASES = [
+    # (world, model, reps, grid, ensemble, nsteps, temperature): hot enough for re-decompositions inside the run
+    (2, "PbTe-reps", (4, 2, 2), (2, 1, 1), "nve", 20, 3000.0),
+    (4, "PbTe-reps", (3, 3, 2), (2, 2, 1), "nve", 20, 3000.0),
+    (2, "PbTe-reps", (4, 2, 2), (2, 1, 1), "nvt_ber", 16, 2000.0),
+    (2, "PbTe-reps", (4, 2, 2), (2, 1, 1), "nvt_nhc", 16, 2000.0),
+    (2, "PbTe-reps", (4, 2, 2), (2, 1, 1), "nvt_bdp", 16, 2000.0),
+    (2, "C-2022", (12, 6, 6), (2, 1, 1), "nve", 10, 3000.0),       # config 5's model through the ghost levels
+    (2, "C-2022", (12, 6, 6), (2, 1, 1), "nvt_ber", 10, 3000.0),   # config 5: NVT on the decomposed path
+    (2, "UNEP-v1", (10, 5, 5), (2, 1, 1), "nve", 8, 3000.0),       # config 4's model (16 types, ZBL)
+]
+
+
+def _spec(device, model, reps, grid, ensemble, nsteps, temp):
+    return {"device": device, "model": model, "reps": list(reps), "grid": list(grid), "ensemble": ensemble, "nsteps": nsteps,
+            "temp": temp, "dt_fs": 2.0, "t1": temp, "t2": 0.5 * temp, "tcoup": 20.0, "thermo_every": 4, "seed": 777}
+
+
+def _natoms(model, reps):
+    per = {"PbTe-reps": 250, "C-2022": 8, "UNEP-v1": 4}[model]
+    return per * reps[0] * reps[1] * reps[2]
+
+
+@pytest.mark.parametrize("world,model,reps,grid,ensemble,nsteps,temp", CASES)
+def test_decomposed_run_matches_single_domain(world, model, reps, grid, ensemble, nsteps, temp):
+    multi, _ = _check(world, _spec("cpu", model, reps, grid, ensemble, nsteps, temp), _natoms(model, reps))
+    if model == "PbTe-reps" and ensemble == "nve":
+        assert max(int(r["ndec"]) for r in multi) >= 2  # atoms really moved past skin/2: migration + new ghosts
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,model,reps,grid,ensemble,nsteps,temp", [
+    (2, "PbTe-reps", (4, 2, 2), (2, 1, 1), "nve", 20, 3000.0),
+    (4, "PbTe-reps", (4, 4, 2), (2, 2, 1), "nve", 20, 3000.0),
+    (2, "PbTe-reps", (4, 2, 2), (2, 1, 1), "nvt_nhc", 16, 2000.0),
+    (2, "C-2022", (12, 6, 6), (2, 1, 1), "nvt_ber", 10, 3000.0),
+    (2, "UNEP-v1", (10, 5, 5), (2, 1, 1), "nve", 8, 3000.0),
+])
+def test_decomposed_run_on_gpu_kernels(world, model, reps, grid, ensemble, nsteps, temp):
+    _check(world, _spec("gpu", model, reps, grid, ensemble, nsteps, temp), _natoms(model, reps))
+
+
+def test_decomposed_nve_matches_the_fused_single_gpu_loop():
+    """The decomposed driver against nepmi_run_nve of the plain engine (not just against itself on one rank)."""
+    spec = _spec("cpu", "PbTe-reps", (4, 2, 2), (2, 1, 1), "nve", 12, 3000.0)
+    multi = _run_ranks(2, spec)
+    n = _natoms("PbTe-reps", (4, 2, 2))
+    xm, vm, fm, f0m = _merge(multi, n)
+    drv = H.EmuDriver()
+    nep = H.golden("PbTe", "nep.txt")
+    h, typ, x = H.pbte_supercell((4, 2, 2), rattle=0.02, seed=31)
+    typ = typ.astype(np.int32)
+    mass = np.where(typ == 0, H.MASS["Te"], H.MASS["Pb"]).astype(np.float64)
+    vel = H.maxwell_velocities(mass, 3000.0, seed=5)
+    eng = drv.engine(drv.model(nep), n)
+    d_t, d_m, d_x, d_v = drv.dev(typ), drv.dev(mass), drv.dev(x), drv.dev(vel)
+    d_pe, d_f, d_w = drv.zeros(n), drv.zeros(3 * n), drv.zeros(9 * n)
+    eng.force_compute(h, d_t, d_x, d_pe, d_f, d_w)
+    f0 = drv.host(d_f).reshape(3, n)
+    assert np.abs(f0m - f0).max() < 3e-5 + 1e-5 * np.abs(f0).max()
+    th = eng.run_nve(h, d_t, d_m, 2.0 / H.TIME_UNIT, 12, d_x, d_v, d_pe, d_f, d_w, thermo_every=4)
+    assert np.abs(vm - drv.host(d_v).reshape(3, n)).max() < 2e-6
+    H3 = np.asarray(h).reshape(3, 3)
+    frac = np.linalg.solve(H3, xm - drv.host(d_x).reshape(3, n))
+    frac -= np.rint(frac)
+    assert np.abs(H3 @ frac).max() < 2e-6
+    np.testing.assert_allclose(multi[0]["th"][:, :2], th[:, :2], rtol=1e-6)
+    np.testing.assert_allclose(multi[0]["th"][:, 2:], th[:, 2:], rtol=1e-4, atol=1e-6)
+
+
+def test_overlapped_exchange_is_bit_identical_to_the_plain_order():
+    """Interior bricks' radial pass BEFORE this step's ghosts arrive + boundary bricks after == the plain
+    exchange-then-compute order, bit for bit; and the split path is really taken."""
+    spec = _spec("cpu", "PbTe-reps", (8, 2, 2), (2, 1, 1), "nve", 12, 3000.0)
+    a = _run_ranks(2, dict(spec, overlap=True))
+    b = _run_ranks(2, dict(spec, overlap=False))
+    assert all(int(r["nover"]) >= 6 for r in a) and all(int(r["nover"]) == 0 for r in b)
+    for ra, rb in zip(a, b):
+        assert np.array_equal(ra["i1"], rb["i1"])
+        assert np.array_equal(ra["x1"], rb["x1"]) and np.array_equal(ra["v1"], rb["v1"]) and np.array_equal(ra["f1"], rb["f1"])
