@@ -86,6 +86,7 @@ SYMBOLS = {
     "nepmi_nhc_half_step": (C.c_int, [VP, c_i64, C.c_double, C.c_double, VP, VP, VP]),
     "nepmi_run_nvt_nhc": (C.c_int, [VP, c_dp, c_ip, c_i64, VP, VP, C.c_double, c_i64, C.c_double, C.c_double,
                                     C.c_double, VP, VP, VP, VP, VP, c_i64, c_dp]),
+    "nepmi_engine_reset_thermostat": (C.c_int, [VP]),
     "nepmi_bdp_seed": (C.c_int, [VP, C.c_uint64]),
     "nepmi_bdp_scale": (C.c_int, [VP, c_i64, C.c_double, C.c_double, VP, VP]),
     "nepmi_run_nvt_bdp": (C.c_int, [VP, c_dp, c_ip, c_i64, VP, VP, C.c_double, c_i64, C.c_double, C.c_double,
@@ -112,6 +113,8 @@ SYMBOLS = {
     "nepmi_dist_set_overlap": (C.c_int, [VP, C.c_int]),
     "nepmi_dist_get_info": (C.c_int, [VP, C.POINTER(NepmiDistInfo)]),
     "nepmi_dist_gather_owned": (C.c_int, [VP, VP, VP, VP, VP, VP, VP]),
+    "nepmi_dist_gather_global": (C.c_int, [VP, C.c_int, VP, VP, VP, VP, VP]),
+    "nepmi_dist_reset_thermostat": (C.c_int, [VP]),
     "nepmi_dist_engine": (VP, [VP]),
 }
 

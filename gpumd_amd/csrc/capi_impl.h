@@ -306,6 +306,14 @@ int nepmi_run_nvt_nhc(
   });
 }
 
+int nepmi_engine_reset_thermostat(nepmi_engine* e)
+{
+  if (!e)
+    return fail(NEPMI_ERR_ARG, "null engine");
+  e->e->reset_thermostat();
+  return NEPMI_OK;
+}
+
 int nepmi_bdp_seed(nepmi_engine* e, uint64_t seed)
 {
   if (!e)

@@ -362,4 +362,60 @@ struct GatherOwnedBody {
   }
 };
 
+// owned atoms as 20 doubles per atom (id, global position, velocity, force, pe, 9 virial planes): [20][n_own]
+struct PackGlobalBody {
+  Bufs b;
+  DomainGeom g;
+  int64_t n_own;
+  const int64_t* id_local;
+  double* out;
+  NEPMI_HD void operator()(int64_t k) const
+  {
+    const int64_t N = b.N;
+    const int64_t i = b.perm[k];
+    if (i >= n_own)
+      return;
+    const PosQ p = b.posq[k];
+    out[i] = (double)id_local[i];
+    out[1 * n_own + i] = p.x + g.origin[0];
+    out[2 * n_own + i] = p.y + g.origin[1];
+    out[3 * n_own + i] = p.z + g.origin[2];
+    for (int d = 0; d < 3; ++d) {
+      out[(4 + d) * n_own + i] = b.vi[d * N + k];
+      out[(7 + d) * n_own + i] = b.fo[(kOutF + d) * N + k];
+    }
+    out[10 * n_own + i] = b.fo[k];
+    for (int d = 0; d < 9; ++d)
+      out[(11 + d) * n_own + i] = b.fo[(kOutW + d) * N + k];
+  }
+};
+// one rank's payload -> the global arrays (stride n_total), by atom id
+struct ScatterGlobalBody {
+  int64_t cnt, n_total;
+  const double* in; // [20][cnt]
+  double* pos;
+  double* vel;
+  double* force;
+  double* pe;
+  double* virial;
+  int* bad; // set when an id is out of range
+  NEPMI_HD void operator()(int64_t q) const
+  {
+    const int64_t id = (int64_t)in[q];
+    if (id < 0 || id >= n_total) {
+      *bad = 1;
+      return;
+    }
+    for (int d = 0; d < 3; ++d) {
+      if (pos) pos[d * n_total + id] = in[(1 + d) * cnt + q];
+      if (vel) vel[d * n_total + id] = in[(4 + d) * cnt + q];
+      if (force) force[d * n_total + id] = in[(7 + d) * cnt + q];
+    }
+    if (pe) pe[id] = in[10 * cnt + q];
+    if (virial)
+      for (int d = 0; d < 9; ++d)
+        virial[d * n_total + id] = in[(11 + d) * cnt + q];
+  }
+};
+
 } // namespace nepmi

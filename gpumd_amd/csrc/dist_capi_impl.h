@@ -114,6 +114,21 @@ int nepmi_dist_gather_owned(nepmi_dist* d, int64_t* ids, double* pos, double* ve
   return guarded([&] { d->d->gather_owned(ids, pos, vel, force, pe, virial); });
 }
 
+int nepmi_dist_gather_global(nepmi_dist* d, int root, double* pos, double* vel, double* force, double* pe, double* virial)
+{
+  if (!d)
+    return fail(NEPMI_ERR_ARG, "null handle");
+  return guarded([&] { d->d->gather_global(root, pos, vel, force, pe, virial); });
+}
+
+int nepmi_dist_reset_thermostat(nepmi_dist* d)
+{
+  if (!d)
+    return fail(NEPMI_ERR_ARG, "null handle");
+  d->d->reset_thermostat();
+  return NEPMI_OK;
+}
+
 nepmi_engine* nepmi_dist_engine(nepmi_dist* d)
 {
   if (!d || !d->d->engine())

@@ -168,8 +168,10 @@ public:
     if (!have_force_)
       compute();
     Engine& e = *eng_;
-    if (ens == Engine::kNhc)
+    if (ens == Engine::kNhc && nhc_fresh_) { // a fresh chain per `run` (integrate.cu:85-92), kept across the calls of one
       be_.template launch<64>(kSlotMisc, 1, NhcInitBody{n_total_, t1, tcoup, dt, nhc_dev_});
+      nhc_fresh_ = false;
+    }
     const bool spec = tr_.device_buffers != 0 && ens != Engine::kBdp; // speculative enqueue needs a device-side vote
     auto tag_of = [](int64_t step) { return (int)(step % 1000000000) + 1; };
     auto target_of = [&](int64_t step) { return t1 + (t2 - t1) * ((double)step / (double)nsteps); };
@@ -293,6 +295,52 @@ public:
                              GatherOwnedBody{e.bufs(), geom_, cur_.n_own, cur_.id, ids, pos, vel, force, pe, virial});
     be_.sync();
   }
+
+  // Every atom of the system to rank `root`, in the order of the global ids 0 .. n_total-1 (DEVICE arrays with
+  // n_total entries per plane on the root, ignored elsewhere): what dump_xyz / dump_restart of a multi-GPU run write.
+  void gather_global(int root, double* pos, double* vel, double* force, double* pe, double* virial)
+  {
+    Engine& e = *eng_;
+    const int P = tr_.nranks, me = tr_.rank;
+    const int64_t no = cur_.n_own;
+    std::vector<int64_t> cnt((size_t)P, 0);
+    cnt[me] = no;
+    host_allreduce(cnt.data(), P, kDtI64, kOpSum);
+    double* mine = (double*)be_.alloc(sizeof(double) * 20 * (no > 0 ? no : 1));
+    if (no > 0)
+      be_.template launch<256>(kSlotMisc, e.num_atoms(), PackGlobalBody{e.bufs(), geom_, no, cur_.id, mine});
+    be_.sync();
+    int* bad = iscratch(11, 1);
+    int zero = 0;
+    be_.h2d(bad, &zero, sizeof(int));
+    if (me != root) {
+      TransportMsg s{mine, (int64_t)sizeof(double) * 20 * no, root};
+      if (no > 0)
+        exchange(1, &s, 0, nullptr);
+    } else {
+      for (int r = 0; r < P; ++r) {
+        const int64_t c = cnt[r];
+        if (c == 0)
+          continue;
+        double* buf = mine;
+        if (r != me) {
+          buf = (double*)be_.alloc(sizeof(double) * 20 * c);
+          TransportMsg m{buf, (int64_t)sizeof(double) * 20 * c, r};
+          exchange(0, nullptr, 1, &m);
+        }
+        be_.template launch<256>(kSlotMisc, c, ScatterGlobalBody{c, n_total_, buf, pos, vel, force, pe, virial, bad});
+        be_.sync();
+        if (r != me)
+          be_.free(buf);
+      }
+      int hb = 0;
+      be_.d2h(&hb, bad, sizeof(int));
+      if (hb)
+        throw EngineError{-4, "gather_global: atom ids must be 0 .. n_total - 1"};
+    }
+    be_.free(mine);
+  }
+  void reset_thermostat() { nhc_fresh_ = true; }
 
   void bdp_seed(uint64_t seed) { seed_ = seed; if (eng_) eng_->bdp_seed(seed); }
   void set_overlap(bool on) { overlap_ = on; }
@@ -780,6 +828,7 @@ private:
   std::unique_ptr<Engine> eng_;
   int64_t eng_cap_ = 0;
   bool resident_ = false, have_force_ = false;
+  bool nhc_fresh_ = true;
   bool overlap_ = true;  // interior bricks' radial pass while the ghost positions travel
   B side_;               // the backend on the communication stream (device transports)
   bool side_ready_ = false;

@@ -477,7 +477,9 @@ public:
     if (ens == kNhc) {
       if (!nhc_dev_)
         nhc_dev_ = dalloc<double>(kNhcStateSize);
-      nhc_init(n, t1, tcoup, dt, nhc_dev_);
+      if (nhc_fresh_) // a fresh chain per `run` (integrate.cu:85-92); it continues across the calls of one run
+        nhc_init(n, t1, tcoup, dt, nhc_dev_);
+      nhc_fresh_ = false;
     }
     if (!factor_dev_)
       factor_dev_ = dalloc<double>(1);
@@ -624,7 +626,9 @@ public:
     if (ens == kNhc) {
       if (!nhc_dev_)
         nhc_dev_ = dalloc<double>(kNhcStateSize);
-      nhc_init(n, t1, tcoup, dt, nhc_dev_);
+      if (nhc_fresh_)
+        nhc_init(n, t1, tcoup, dt, nhc_dev_);
+      nhc_fresh_ = false;
     }
     int64_t rec = 0;
     for (int64_t step = 0; step < nsteps; ++step) {
@@ -1186,6 +1190,7 @@ public:
   // invalidate()): no per-step flag read-back, the force path is enqueued without a host round trip.
   // List-capacity overflow is then reported at the next rebuild or stats() call.
   void set_external_skin(bool on) { external_skin_ = on; }
+  void reset_thermostat() { nhc_fresh_ = true; }
   // caller-owned [3N] array that every first-half-step drift is also added to (atom.unwrapped_position)
   void set_unwrapped(double* u) { unwrapped_ = u; }
   void check_flags_now()
@@ -1305,6 +1310,7 @@ private:
   double* thermo_scratch_ = nullptr;
   double* thermo_dev_ = nullptr;
   double* nhc_dev_ = nullptr;
+  bool nhc_fresh_ = true;
   std::mt19937 bdp_rng_{12345678u};
   int bdp_iset_ = 0;
   double bdp_gset_ = 0.0;

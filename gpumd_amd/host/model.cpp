@@ -375,6 +375,33 @@ static void zero_angular_momentum(int N, const double* m, const double* x, const
   }
 }
 
+void correct_velocity(int N, const std::vector<double>& mass, const std::vector<double>& pos, std::vector<double>& vel,
+                      const int* contents, int count)
+{
+  if (!contents) {
+    zero_linear_momentum(N, mass.data(), vel.data(), vel.data() + N, vel.data() + 2 * (size_t)N);
+    zero_angular_momentum(N, mass.data(), pos.data(), pos.data() + N, pos.data() + 2 * (size_t)N, vel.data(), vel.data() + N,
+                          vel.data() + 2 * (size_t)N);
+    return;
+  }
+  // one group: the same on the group's own copies (velocity.cu:284-305)
+  std::vector<double> m(count), x(3 * (size_t)count), v(3 * (size_t)count);
+  for (int k = 0; k < count; ++k) {
+    const int n = contents[k];
+    m[k] = mass[n];
+    for (int d = 0; d < 3; ++d) {
+      x[k + (size_t)d * count] = pos[n + (size_t)d * N];
+      v[k + (size_t)d * count] = vel[n + (size_t)d * N];
+    }
+  }
+  zero_linear_momentum(count, m.data(), v.data(), v.data() + count, v.data() + 2 * (size_t)count);
+  zero_angular_momentum(count, m.data(), x.data(), x.data() + count, x.data() + 2 * (size_t)count, v.data(), v.data() + count,
+                        v.data() + 2 * (size_t)count);
+  for (int k = 0; k < count; ++k)
+    for (int d = 0; d < 3; ++d)
+      vel[contents[k] + (size_t)d * N] = v[k + (size_t)d * count];
+}
+
 void initialize_velocity(double temperature, bool use_seed, int seed, Atom& atom)
 {
   const int N = atom.number_of_atoms;

@@ -36,7 +36,11 @@ public:
     if (n) hip_check(hipMalloc((void**)&data_, n * sizeof(T)), "hipMalloc");
   }
   void fill_zero() { if (size_) hip_check(hipMemset(data_, 0, size_ * sizeof(T)), "hipMemset"); }
-  void copy_from_host(const T* h) { if (size_) hip_check(hipMemcpy(data_, h, size_ * sizeof(T), hipMemcpyHostToDevice), "H2D"); }
+  void copy_from_host(const T* h, size_t n = 0)
+  {
+    if (n == 0) n = size_;
+    if (n) hip_check(hipMemcpy(data_, h, n * sizeof(T), hipMemcpyHostToDevice), "H2D");
+  }
   void copy_to_host(T* h, size_t n = 0) const
   {
     if (n == 0) n = size_;
@@ -96,6 +100,10 @@ bool read_xyz(
 void replicate(const int n[3], Box& box, Atom& atom, std::vector<Group>& groups);
 // Velocity::initialize (velocity.cu:312-347): glibc rand() stream, momentum corrections, rescale
 void initialize_velocity(double temperature, bool use_seed, int seed, Atom& atom);
+// Velocity::correct_velocity (velocity.cu:210-271): zero the linear and angular momentum of the listed atoms
+// (all atoms when contents == nullptr); host arrays, SoA with stride N
+void correct_velocity(int N, const std::vector<double>& mass, const std::vector<double>& pos, std::vector<double>& vel,
+                      const int* contents, int count);
 void write_xyz_frame(FILE* f, const Box& box, const Atom& atom, const char* extra_props);
 
 } // namespace gmi

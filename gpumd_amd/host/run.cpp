@@ -1,6 +1,7 @@
 #include <cerrno>
 #include "run.h"
 
+#include <algorithm>
 #include <chrono>
 #include <random>
 #include <cstring>
@@ -34,7 +35,27 @@ static std::vector<std::string> strip(const std::string& line)
   return out;
 }
 
-Run::Run(bool check_only) : check_only_(check_only)
+static void die_on(int status, const char* where)
+{
+  if (status < 0) {
+    std::printf("%s: %s\n", where, nepmi_last_error());
+    std::exit(1);
+  }
+}
+
+Run::~Run()
+{
+  if (dist_)
+    nepmi_dist_destroy(dist_);
+  if (dist_model_)
+    nepmi_model_free(dist_model_);
+  if (have_rccl_)
+    nepmi_transport_destroy(&rccl_);
+  if (have_boot_)
+    nepmi_transport_destroy(&boot_);
+}
+
+Run::Run(bool check_only, const Parallel& par) : check_only_(check_only), par_(par)
 {
   // initialize_position (src/model/read_xyz.cu:427-530): run.in is scanned first for the
   // potential file (its element list fixes the type indices), then model.xyz is read.
@@ -94,11 +115,19 @@ void Run::parse_one_keyword(const std::vector<std::string>& p)
       force.parse_potential(p, box, atom.number_of_atoms, false);
       return;
     }
+    if (p.size() == 3 && p[2] != "x" && p[2] != "y" && p[2] != "z") // force.cu:122-123: the partition direction
+      input_error("The partition direction of a multi-GPU potential should be x, y or z.");
     if (!gpu_allocated) {
       atom.allocate_gpu();
       gpu_allocated = true;
     }
-    force.parse_potential(p, box, atom.number_of_atoms);
+    if (par_.world > 1) {
+      setup_dist(p);
+      return;
+    }
+    if (p.size() == 3)
+      std::printf("    (one GPU: the partition direction %s is not used)\n", p[2].c_str());
+    force.parse_potential(std::vector<std::string>(p.begin(), p.begin() + 2), box, atom.number_of_atoms);
   } else if (k == "velocity") {
     if (p.size() != 2 && p.size() != 4)
       input_error("velocity should have 1 or 2 parameters.");
@@ -113,6 +142,27 @@ void Run::parse_one_keyword(const std::vector<std::string>& p)
     }
     if (gpu_allocated)
       atom.velocity_per_atom.copy_from_host(atom.cpu_velocity_per_atom.data());
+  } else if (k == "correct_velocity") { // Run::parse_correct_velocity, run.cu:610-647
+    std::printf("Correct linear and angular momenta.\n");
+    if (p.size() != 2 && p.size() != 3)
+      input_error("correct_velocity should have 1 or 2 parameters.");
+    if (!is_valid_int(p[1], &correct_interval_))
+      input_error("velocity correction interval should be an integer.");
+    if (correct_interval_ < 10)
+      input_error("velocity correction interval should >= 10.");
+    std::printf("    every %d steps.\n", correct_interval_);
+    correct_group_method_ = -1;
+    if (p.size() == 3) {
+      if (!is_valid_int(p[2], &correct_group_method_))
+        input_error("velocity correction group method should be an integer.");
+      if (correct_group_method_ < 0)
+        input_error("grouping method should >= 0.");
+      if (correct_group_method_ >= (int)groups.size())
+        input_error("grouping method should < maximum number of grouping methods.");
+      std::printf("    for individual groups in group method %d.\n", correct_group_method_);
+    } else {
+      std::printf("    for the whole system.\n");
+    }
   } else if (k == "ensemble") {
     if (p.size() < 2)
       input_error("ensemble should have at least 1 parameter.");
@@ -294,9 +344,10 @@ void Run::parse_one_keyword(const std::vector<std::string>& p)
 
 void Run::find_thermo()
 {
-  nepmi_find_thermo(
-    force.engine(), atom.number_of_atoms, box.get_volume(), atom.mass.data(), atom.potential_per_atom.data(),
-    atom.velocity_per_atom.data(), atom.virial_per_atom.data(), thermo.data());
+  die_on(nepmi_find_thermo(
+           force.engine(), atom.number_of_atoms, box.get_volume(), atom.mass.data(), atom.potential_per_atom.data(),
+           atom.velocity_per_atom.data(), atom.virial_per_atom.data(), thermo.data()),
+         "find_thermo");
 }
 
 // Dump_Thermo (src/measure/dump_thermo.cu:56-132)
@@ -545,9 +596,57 @@ void Run::dump_restart(int step)
   std::fclose(fid);
 }
 
-// Run::perform_a_run (run.cu:211-341) for ensemble nve
+// Velocity::correct_velocity(step, group, atom), velocity.cu:273-310 (host side, like the reference)
+void Run::correct_velocity_now()
+{
+  const int N = atom.number_of_atoms;
+  atom.position_per_atom.copy_to_host(atom.cpu_position_per_atom.data());
+  atom.velocity_per_atom.copy_to_host(atom.cpu_velocity_per_atom.data());
+  if (correct_group_method_ < 0) {
+    correct_velocity(N, atom.cpu_mass, atom.cpu_position_per_atom, atom.cpu_velocity_per_atom, nullptr, 0);
+  } else {
+    const Group& g = groups[correct_group_method_];
+    for (int k = 0; k < g.number; ++k)
+      correct_velocity(N, atom.cpu_mass, atom.cpu_position_per_atom, atom.cpu_velocity_per_atom,
+                       g.cpu_contents.data() + g.cpu_size_sum[k], g.cpu_size[k]);
+  }
+  atom.velocity_per_atom.copy_from_host(atom.cpu_velocity_per_atom.data());
+}
+
+// `steps` steps of the current ensemble through the fused run loops of libnepmi (state in internal order, steps
+// enqueued speculatively); the thermodynamic sums of the last step end up in `thermo`
+void Run::run_segment(int steps, double t_a, double t_b)
+{
+  const int N = atom.number_of_atoms;
+  const int pbc[3] = {box.pbc_x, box.pbc_y, box.pbc_z};
+  nepmi_engine* e = force.engine();
+  double th[8];
+  int st;
+  double *x = atom.position_per_atom.data(), *v = atom.velocity_per_atom.data(), *pe = atom.potential_per_atom.data(),
+         *f = atom.force_per_atom.data(), *w = atom.virial_per_atom.data();
+  if (ensemble == "nve")
+    st = nepmi_run_nve(e, box.cpu_h, pbc, N, atom.type.data(), atom.mass.data(), time_step, steps, x, v, pe, f, w, steps, th);
+  else if (ensemble == "nvt_ber")
+    st = nepmi_run_nvt_ber(e, box.cpu_h, pbc, N, atom.type.data(), atom.mass.data(), time_step, steps, t_a, t_b,
+                           temperature_coupling, x, v, pe, f, w, steps, th);
+  else if (ensemble == "nvt_nhc")
+    st = nepmi_run_nvt_nhc(e, box.cpu_h, pbc, N, atom.type.data(), atom.mass.data(), time_step, steps, t_a, t_b,
+                           temperature_coupling, x, v, pe, f, w, steps, th);
+  else
+    st = nepmi_run_nvt_bdp(e, box.cpu_h, pbc, N, atom.type.data(), atom.mass.data(), time_step, steps, t_a, t_b,
+                           temperature_coupling, x, v, pe, f, w, steps, th);
+  die_on(st, "run");
+  thermo.copy_from_host(th, 8);
+}
+
+// Run::perform_a_run (run.cu:211-341).  The steps between two outputs are one call of a fused run loop; the loop
+// body below is what the reference does at an output step (measure.process) plus correct_velocity.
 void Run::perform_a_run()
 {
+  if (par_.world > 1) {
+    perform_a_run_dist();
+    return;
+  }
   if (!gpu_allocated || force.potentials.empty())
     input_error("No potential is defined before run.");
   const int N = atom.number_of_atoms;
@@ -562,8 +661,7 @@ void Run::perform_a_run()
     atom.unwrapped_position.resize(3 * (size_t)N);
     hip_check(hipMemcpy(atom.unwrapped_position.data(), atom.position_per_atom.data(), sizeof(double) * 3 * (size_t)N,
                         hipMemcpyDeviceToDevice), "D2D");
-    if (nepmi_engine_set_unwrapped(e, atom.unwrapped_position.data()) != NEPMI_OK)
-      input_error(nepmi_last_error());
+    die_on(nepmi_engine_set_unwrapped(e, atom.unwrapped_position.data()), "set_unwrapped");
   }
   if (dump_thermo_interval > 0) {
     FILE* fid = std::fopen("thermo.out", "a");
@@ -577,48 +675,47 @@ void Run::perform_a_run()
   force.compute(box, atom.position_per_atom, atom.type, atom.potential_per_atom, atom.force_per_atom, atom.virial_per_atom);
   hip_check(hipDeviceSynchronize(), "sync");
   const auto t0 = std::chrono::steady_clock::now();
-  // Ensemble_NHC: a fresh chain per run (integrate.cu:85-92), state in device memory
-  double* nhc_state = nullptr;
-  if (ensemble == "nvt_nhc") {
-    hip_check(hipMalloc((void**)&nhc_state, sizeof(double) * NEPMI_NHC_STATE_SIZE), "hipMalloc");
-    if (nepmi_nhc_init(e, N, temperature1, temperature_coupling, time_step, nhc_state) != NEPMI_OK)
-      input_error(nepmi_last_error());
-  }
+  die_on(nepmi_engine_reset_thermostat(e), "reset_thermostat"); // Ensemble_NHC: a fresh chain per run (integrate.cu:85-92)
   if (ensemble == "nvt_bdp") { // Ensemble_BDP::initialize_rng (ensemble_bdp.cu:32-39): seeded from the clock
     const uint64_t seed = (uint64_t)std::chrono::system_clock::now().time_since_epoch().count();
-    nepmi_bdp_seed(e, seed);
+    die_on(nepmi_bdp_seed(e, seed), "bdp_seed");
     std::printf("    BDP noise seed = %llu.\n", (unsigned long long)((std::mt19937::result_type)seed));
   }
-  for (int step = 0; step < number_of_steps; ++step) {
-    global_time += time_step;
-    const double target = temperature1 + (temperature2 - temperature1) * (double(step) / number_of_steps);
-    if (ensemble == "nvt_nhc") { // integrate_nvt_nhc_1, ensemble_nhc.cu:166-197
-      find_thermo();
-      nepmi_nhc_half_step(e, N, target, time_step, thermo.data(), nhc_state, atom.velocity_per_atom.data());
+  auto temperature_at = [&](int step) { return temperature1 + (temperature2 - temperature1) * (double(step) / number_of_steps); };
+  // the next step (1-based count of finished steps) at which something is written
+  auto next_output = [&](int done) {
+    int nxt = number_of_steps;
+    auto upto = [&](int interval) {
+      if (interval > 0) {
+        const int k = (done / interval + 1) * interval;
+        nxt = k < nxt ? k : nxt;
+      }
+    };
+    upto(dump_thermo_interval);
+    upto(dump_restart_interval);
+    for (const auto& d : dump_xyzs)
+      upto(d.interval);
+    if (observer.active) {
+      upto(observer.interval_thermo);
+      upto(observer.interval_exyz);
     }
-    // integrate.compute1: Ensemble_NVE::compute1 (ensemble_nve.cu:31-57)
-    nepmi_vv_step1(e, N, time_step, atom.mass.data(), atom.force_per_atom.data(), atom.position_per_atom.data(),
-                   atom.velocity_per_atom.data());
-    force.compute(box, atom.position_per_atom, atom.type, atom.potential_per_atom, atom.force_per_atom, atom.virial_per_atom);
-    // integrate.compute2 (ensemble_nve.cu:59-95)
-    nepmi_vv_step2(e, N, time_step, atom.mass.data(), atom.force_per_atom.data(), atom.velocity_per_atom.data());
-    {
-      // Ensemble_NVE::compute2 reduces the thermodynamic sums every step (ensemble_nve.cu:85-94); nobody
-      // reads them between outputs, so the NVE path reduces only when a dump of this step needs them
-      bool wanted = ensemble != "nve";
-      wanted = wanted || (dump_thermo_interval > 0 && (step + 1) % dump_thermo_interval == 0);
-      for (const auto& d : dump_xyzs)
-        wanted = wanted || (step + 1) % d.interval == 0;
-      wanted = wanted || (observer.active && ((step + 1) % observer.interval_thermo == 0 || (step + 1) % observer.interval_exyz == 0));
-      if (wanted)
-        find_thermo();
+    if (number_of_steps >= 10)
+      upto(number_of_steps / 10); // progress lines
+    if (correct_interval_ > 0) { // the correction precedes the steps 0, k, 2k, ...: a segment ends right before them
+      const int k = (done / correct_interval_ + 1) * correct_interval_;
+      nxt = k < nxt ? k : nxt;
     }
-    if (ensemble == "nvt_ber") // Ensemble_BER::compute2, ensemble_ber.cu:195-235
-      nepmi_berendsen_scale(e, N, target, 1.0 / temperature_coupling, thermo.data(), atom.velocity_per_atom.data());
-    else if (ensemble == "nvt_bdp") // integrate_nvt_bdp_2, ensemble_bdp.cu:71-104
-      nepmi_bdp_scale(e, N, target, temperature_coupling, thermo.data(), atom.velocity_per_atom.data());
-    else if (ensemble == "nvt_nhc") // integrate_nvt_nhc_2, ensemble_nhc.cu:199-232
-      nepmi_nhc_half_step(e, N, target, time_step, thermo.data(), nhc_state, atom.velocity_per_atom.data());
+    return nxt;
+  };
+  int done = 0;
+  while (done < number_of_steps) {
+    if (correct_interval_ > 0 && done % correct_interval_ == 0)
+      correct_velocity_now(); // velocity.correct_velocity(step, ...) at the top of step `done` (run.cu:252)
+    const int upto = next_output(done);
+    run_segment(upto - done, temperature_at(done), temperature_at(upto));
+    global_time += time_step * (upto - done);
+    done = upto;
+    const int step = done - 1; // the reference's 0-based step index of the step just finished
     // measure.process
     dump_thermo(step);
     for (auto& d : dump_xyzs)
@@ -629,14 +726,206 @@ void Run::perform_a_run()
       std::printf("    %d steps completed.\n", step + 1);
   }
   hip_check(hipDeviceSynchronize(), "sync");
-  if (nhc_state)
-    (void)hipFree(nhc_state);
   dump_observer_close();
   const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   std::printf("Time used for this run = %g second.\n", sec);
   std::printf("Speed of this run = %g atom*step/second.\n", (double)N * number_of_steps / sec); // run.cu:325-326
   if (auto* p = dynamic_cast<NEP_MI*>(force.potentials[0].get()))
     p->write_neighbor_out();
+  for (auto& d : dump_xyzs)
+    if (d.fid) {
+      std::fclose(d.fid);
+      d.fid = nullptr;
+    }
+}
+
+// ---- one process per GPU ---------------------------------------------------------------------------------------
+
+// `potential <file> [x|y|z]` with more than one rank: the transport, the process grid and the decomposed driver;
+// every rank has read the whole model.xyz and contributes a slice of the atoms (the driver migrates them to their
+// owners).  With a direction the grid is one-dimensional along it (the reference's slab partition, force.cu:122-160),
+// without one it is as cubic as the number of ranks allows.
+void Run::setup_dist(const std::vector<std::string>& p)
+{
+  if (force.potentials.size() > 0 || dist_)
+    input_error("Several potentials are not available in multi-GPU runs.");
+  std::ifstream in(p[1]);
+  std::string name;
+  if (!(in >> name))
+    input_error("Failed to open " + p[1] + ".");
+  if (name.rfind("nep", 0) != 0)
+    input_error("multi-GPU runs carry NEP potentials only.");
+  dist_model_ = nepmi_model_load(p[1].c_str());
+  if (!dist_model_)
+    input_error(nepmi_last_error());
+  const int P = par_.world;
+  int grid[3] = {1, 1, 1};
+  if (p.size() == 3) {
+    grid[p[2] == "x" ? 0 : (p[2] == "y" ? 1 : 2)] = P;
+  } else { // as cubic as possible: every peer of a 2x2x2 grid is a direct xGMI link on an 8-GPU node
+    int best[3] = {P, 1, 1};
+    for (int a = 1; a <= P; ++a)
+      for (int b = 1; a * b <= P; ++b)
+        if (P % (a * b) == 0) {
+          int g[3] = {a, b, P / (a * b)};
+          std::sort(g, g + 3);
+          if (g[2] - g[0] < best[0] - best[2]) {
+            best[0] = g[2];
+            best[1] = g[1];
+            best[2] = g[0];
+          }
+        }
+    for (int d = 0; d < 3; ++d)
+      grid[d] = best[d];
+  }
+  // rendezvous over TCP; RCCL (one GPU per rank) gets its id through it
+  die_on(nepmi_transport_tcp(par_.master_addr.c_str(), par_.master_port, par_.rank, P, &boot_), "transport (tcp)");
+  have_boot_ = true;
+  const nepmi_transport* tr = &boot_;
+  if (par_.use_rccl) {
+    int id[NEPMI_RCCL_ID_BYTES / 4];
+    std::memset(id, 0, sizeof id);
+    if (par_.rank == 0)
+      die_on(nepmi_transport_rccl_id((char*)id), "rccl id");
+    boot_.allreduce(boot_.ctx, id, NEPMI_RCCL_ID_BYTES / 4, 1, 0, nullptr); // the other ranks contribute zeros
+    die_on(nepmi_transport_rccl((const char*)id, par_.rank, P, &rccl_), "transport (rccl)");
+    have_rccl_ = true;
+    tr = &rccl_;
+  }
+  const int pbc[3] = {box.pbc_x, box.pbc_y, box.pbc_z};
+  dist_ = nepmi_dist_create(dist_model_, tr, box.cpu_h, pbc, grid, nullptr);
+  if (!dist_)
+    input_error(nepmi_last_error());
+  std::printf("Use %d GPUs: process grid %d x %d x %d, ghost exchange over %s.\n", P, grid[0], grid[1], grid[2],
+              par_.use_rccl ? "RCCL" : "TCP sockets");
+}
+
+// this rank's share of the atoms goes to the driver at the first run (the velocity keyword may follow potential)
+void Run::dist_setup_atoms()
+{
+  // this rank's slice of the atoms (any split will do: the driver migrates)
+  const int P = par_.world;
+  const int N = atom.number_of_atoms;
+  std::vector<int> ty;
+  std::vector<double> ms, xs, vs;
+  std::vector<int64_t> ids;
+  for (int i = par_.rank; i < N; i += P)
+    ids.push_back(i);
+  const size_t n = ids.size();
+  ty.resize(n);
+  ms.resize(n);
+  xs.resize(3 * n);
+  vs.resize(3 * n);
+  for (size_t q = 0; q < n; ++q) {
+    const int i = (int)ids[q];
+    ty[q] = atom.cpu_type[i];
+    ms[q] = atom.cpu_mass[i];
+    for (int d = 0; d < 3; ++d) {
+      xs[q + d * n] = atom.cpu_position_per_atom[i + (size_t)d * N];
+      vs[q + d * n] = atom.cpu_velocity_per_atom[i + (size_t)d * N];
+    }
+  }
+  GPU_Vector<int> d_t(n ? n : 1);
+  GPU_Vector<double> d_m(n ? n : 1), d_x(3 * n ? 3 * n : 1), d_v(3 * n ? 3 * n : 1);
+  GPU_Vector<int64_t> d_i(n ? n : 1);
+  if (n) {
+    d_t.copy_from_host(ty.data());
+    d_m.copy_from_host(ms.data());
+    d_x.copy_from_host(xs.data());
+    d_v.copy_from_host(vs.data());
+    d_i.copy_from_host(ids.data());
+  }
+  die_on(nepmi_dist_setup(dist_, (int64_t)n, d_t.data(), d_m.data(), d_x.data(), d_v.data(), d_i.data()), "dist setup");
+  dist_ready_ = true;
+}
+
+void Run::perform_a_run_dist()
+{
+  if (!dist_)
+    input_error("No potential is defined before run.");
+  if (!dist_ready_)
+    dist_setup_atoms();
+  if (observer.active)
+    input_error("dump_observer is not available in multi-GPU runs.");
+  if (correct_interval_ > 0)
+    input_error("correct_velocity is not available in multi-GPU runs.");
+  for (const auto& d : dump_xyzs)
+    if (d.has_unwrapped_position)
+      input_error("unwrapped positions are not tracked in multi-GPU runs.");
+  const int N = atom.number_of_atoms;
+  const bool root = par_.rank == 0;
+  const int ens = ensemble == "nve" ? 0 : ensemble == "nvt_ber" ? 1 : ensemble == "nvt_nhc" ? 2 : 3;
+  if (root && dump_thermo_interval > 0) {
+    FILE* fid = std::fopen("thermo.out", "a");
+    std::fprintf(fid, "# dump_thermo %d\n# format_version 1\n# num_atoms %d\n# dt_output %.10e fs\n", dump_thermo_interval, N,
+                 time_step * dump_thermo_interval * TIME_UNIT_CONVERSION);
+    std::fprintf(fid, "# columns T KE PE sxx syy szz syz sxz sxy ax ay az bx by bz cx cy cz\n");
+    std::fclose(fid);
+  }
+  die_on(nepmi_dist_compute(dist_), "dist compute"); // the initial force
+  hip_check(hipDeviceSynchronize(), "sync");
+  const auto t0 = std::chrono::steady_clock::now();
+  die_on(nepmi_dist_reset_thermostat(dist_), "reset_thermostat");
+  if (ens == 3) {
+    // every rank must draw the same noise: the seed comes from rank 0's clock
+    int64_t seed = root ? (int64_t)std::chrono::system_clock::now().time_since_epoch().count() : 0;
+    boot_.allreduce(boot_.ctx, &seed, 1, 2, 0, nullptr);
+    die_on(nepmi_dist_bdp_seed(dist_, (uint64_t)seed), "bdp_seed");
+    std::printf("    BDP noise seed = %llu.\n", (unsigned long long)((std::mt19937::result_type)seed));
+  }
+  auto temperature_at = [&](int step) { return temperature1 + (temperature2 - temperature1) * (double(step) / number_of_steps); };
+  auto next_output = [&](int done) {
+    int nxt = number_of_steps;
+    auto upto = [&](int interval) {
+      if (interval > 0) {
+        const int k = (done / interval + 1) * interval;
+        nxt = k < nxt ? k : nxt;
+      }
+    };
+    upto(dump_thermo_interval);
+    upto(dump_restart_interval);
+    for (const auto& d : dump_xyzs)
+      upto(d.interval);
+    if (number_of_steps >= 10)
+      upto(number_of_steps / 10);
+    return nxt;
+  };
+  int done = 0;
+  while (done < number_of_steps) {
+    const int upto = next_output(done);
+    double th[8];
+    die_on(nepmi_dist_run(dist_, ens, time_step, upto - done, temperature_at(done), temperature_at(upto), temperature_coupling,
+                          upto - done, th),
+           "dist run");
+    global_time += time_step * (upto - done);
+    done = upto;
+    const int step = done - 1;
+    bool need_atoms = dump_restart_interval > 0 && (step + 1) % dump_restart_interval == 0;
+    for (const auto& d : dump_xyzs)
+      need_atoms = need_atoms || (step + 1) % d.interval == 0;
+    if (need_atoms) // every atom to rank 0, in file order: the dumps below are the single-GPU code
+      die_on(nepmi_dist_gather_global(dist_, 0, root ? atom.position_per_atom.data() : nullptr,
+                                      root ? atom.velocity_per_atom.data() : nullptr, root ? atom.force_per_atom.data() : nullptr,
+                                      root ? atom.potential_per_atom.data() : nullptr, root ? atom.virial_per_atom.data() : nullptr),
+             "gather");
+    if (root) {
+      thermo.copy_from_host(th, 8);
+      dump_thermo(step);
+      for (auto& d : dump_xyzs)
+        dump_xyz(d, step);
+      dump_restart(step);
+      if (number_of_steps >= 10 && (step + 1) % (number_of_steps / 10) == 0)
+        std::printf("    %d steps completed.\n", step + 1);
+    }
+  }
+  hip_check(hipDeviceSynchronize(), "sync");
+  const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  nepmi_dist_info info;
+  nepmi_dist_get_info(dist_, &info);
+  std::printf("Time used for this run = %g second.\n", sec);
+  std::printf("Speed of this run = %g atom*step/second.\n", (double)N * number_of_steps / sec);
+  std::printf("    (%d GPUs; this rank: %lld owned + %lld ghost atoms, %lld decompositions)\n", par_.world,
+              (long long)info.n_owned, (long long)(info.n_local - info.n_owned), (long long)info.num_decompositions);
   for (auto& d : dump_xyzs)
     if (d.fid) {
       std::fclose(d.fid);

@@ -26,15 +26,31 @@ struct DumpObserver {
   std::vector<FILE*> exyz_files, thermo_files; // observer<i>.xyz / observer<i>.out (no index when there is one)
 };
 
+// One process per GPU (torchrun / mpirun style launch: RANK, WORLD_SIZE, LOCAL_RANK, MASTER_ADDR, MASTER_PORT or
+// OMPI_COMM_WORLD_*): the run is domain-decomposed by libnepmi's nepmi_dist_* driver (RCCL over xGMI when every
+// rank has its own GPU, TCP sockets otherwise); rank 0 writes the output files.
+struct Parallel {
+  int rank = 0, world = 1, local_rank = 0;
+  bool use_rccl = false;
+  std::string master_addr = "127.0.0.1";
+  int master_port = 29400;
+};
+
 class Run
 {
 public:
-  explicit Run(bool check_only);
+  Run(bool check_only, const Parallel& par);
+  ~Run();
   void execute_run_in();
 
 private:
   void parse_one_keyword(const std::vector<std::string>& tokens);
   void perform_a_run();
+  void perform_a_run_dist();
+  void run_segment(int steps, double t_a, double t_b);
+  void correct_velocity_now();
+  void setup_dist(const std::vector<std::string>& potential_line);
+  void dist_setup_atoms();
   void find_thermo();
   void dump_thermo(int step);
   void dump_xyz(DumpXyz& d, int step);
@@ -45,6 +61,14 @@ private:
   void dump_observer_close();
 
   bool check_only_;
+  Parallel par_;
+  nepmi_transport boot_{};      // TCP: the rendezvous, and the transport itself when RCCL is not used
+  nepmi_transport rccl_{};
+  bool have_boot_ = false, have_rccl_ = false;
+  nepmi_model* dist_model_ = nullptr;
+  nepmi_dist* dist_ = nullptr;
+  bool dist_ready_ = false;
+  int correct_interval_ = 0, correct_group_method_ = -1; // correct_velocity (run.cu:610-647)
   Box box;
   Atom atom;
   std::vector<Group> groups;

@@ -187,7 +187,7 @@ int nepmi_run_nvt_ber(
  *      chain on the host after copying the temperature back; here nepmi_nhc_half_step advances it on
  *      the device from thermo8[0] (DEVICE, find_thermo) and rescales the velocities -- no host round
  *      trip.  A step of the ensemble is: find_thermo, half_step, vv_step1, force, vv_step2,
- *      find_thermo, half_step.  nepmi_run_nvt_nhc is the whole loop (fresh chain, T ramps T1 -> T2,
+ *      find_thermo, half_step.  nepmi_run_nvt_nhc is the whole loop (T ramps T1 -> T2,
  *      integrate.cu:341-344); thermo_host records the second find_thermo of each recorded step. ---- */
 #define NEPMI_NHC_STATE_SIZE 13
 int nepmi_nhc_init(nepmi_engine* e, int64_t n, double temperature, double t_coup, double dt, double* chain_state);
@@ -198,6 +198,9 @@ int nepmi_run_nvt_nhc(
   nepmi_engine* e, const double h[9], const int pbc[3], int64_t n, const int* type,
   const double* mass, double dt, int64_t nsteps, double t1, double t2, double t_coup, double* pos,
   double* vel, double* pe, double* force, double* virial, int64_t thermo_every, double* thermo_host);
+/* The chain of nepmi_run_nvt_nhc is fresh at an engine's first call and after this call (a new `run` keyword,
+ * integrate.cu:85-92); otherwise it continues, so that a host can run in segments between its output steps. */
+int nepmi_engine_reset_thermostat(nepmi_engine* e);
 
 /* ---- Bussi-Donadio-Parrinello stochastic velocity rescaling: Ensemble_BDP
  *      (src/integrate/ensemble_bdp.cu:71-104) with resamplekin / gasdev / gamdev of
@@ -287,6 +290,13 @@ int nepmi_dist_get_info(nepmi_dist* d, nepmi_dist_info* out);
  * any pointer may be NULL. */
 int nepmi_dist_gather_owned(
   nepmi_dist* d, int64_t* ids, double* pos, double* vel, double* force, double* pe, double* virial);
+/* Every atom of the system on rank `root`, ordered by global id (which must be 0 .. n_total-1, the default): DEVICE
+ * arrays with n_total entries per plane on the root (any may be NULL), ignored on the other ranks.  Collective. */
+int nepmi_dist_gather_global(
+  nepmi_dist* d, int root, double* pos, double* vel, double* force, double* pe, double* virial);
+/* The next nepmi_dist_run starts a fresh Nose-Hoover chain (a new `run` keyword; the chain otherwise continues
+ * across the calls, so that a host can run in segments between its output steps). */
+int nepmi_dist_reset_thermostat(nepmi_dist* d);
 /* The engine of the local (owned + ghost) system, e.g. for nepmi_engine_stats / nepmi_engine_set_timing. */
 nepmi_engine* nepmi_dist_engine(nepmi_dist* d);
 
