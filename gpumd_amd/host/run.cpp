@@ -45,6 +45,8 @@ static void die_on(int status, const char* where)
 
 Run::~Run()
 {
+  if (nhc_state_)
+    (void)hipFree(nhc_state_);
   if (dist_)
     nepmi_dist_destroy(dist_);
   if (dist_model_)
@@ -620,6 +622,35 @@ void Run::run_segment(int steps, double t_a, double t_b)
   const int N = atom.number_of_atoms;
   const int pbc[3] = {box.pbc_x, box.pbc_y, box.pbc_z};
   nepmi_engine* e = force.engine();
+  if (force.potentials.size() > 1 && force.multiple_potentials_mode() == "average") {
+    // the run follows the MEAN of several potentials (force.cu:533-562): every step goes through Force::compute
+    if (ensemble == "nvt_nhc" && !nhc_state_) {
+      hip_check(hipMalloc((void**)&nhc_state_, sizeof(double) * NEPMI_NHC_STATE_SIZE), "hipMalloc");
+      die_on(nepmi_nhc_init(e, N, t_a, temperature_coupling, time_step, nhc_state_), "nhc_init");
+    }
+    for (int s = 0; s < steps; ++s) {
+      const double target = t_a + (t_b - t_a) * (double(s) / steps);
+      if (ensemble == "nvt_nhc") { // integrate_nvt_nhc_1, ensemble_nhc.cu:166-197
+        find_thermo();
+        die_on(nepmi_nhc_half_step(e, N, target, time_step, thermo.data(), nhc_state_, atom.velocity_per_atom.data()), "nhc");
+      }
+      die_on(nepmi_vv_step1(e, N, time_step, atom.mass.data(), atom.force_per_atom.data(), atom.position_per_atom.data(),
+                            atom.velocity_per_atom.data()),
+             "vv_step1");
+      force.compute(box, atom.position_per_atom, atom.type, atom.potential_per_atom, atom.force_per_atom, atom.virial_per_atom);
+      die_on(nepmi_vv_step2(e, N, time_step, atom.mass.data(), atom.force_per_atom.data(), atom.velocity_per_atom.data()),
+             "vv_step2");
+      if (ensemble != "nve" || s + 1 == steps)
+        find_thermo();
+      if (ensemble == "nvt_ber")
+        die_on(nepmi_berendsen_scale(e, N, target, 1.0 / temperature_coupling, thermo.data(), atom.velocity_per_atom.data()), "ber");
+      else if (ensemble == "nvt_bdp")
+        die_on(nepmi_bdp_scale(e, N, target, temperature_coupling, thermo.data(), atom.velocity_per_atom.data()), "bdp");
+      else if (ensemble == "nvt_nhc")
+        die_on(nepmi_nhc_half_step(e, N, target, time_step, thermo.data(), nhc_state_, atom.velocity_per_atom.data()), "nhc");
+    }
+    return;
+  }
   double th[8];
   int st;
   double *x = atom.position_per_atom.data(), *v = atom.velocity_per_atom.data(), *pe = atom.potential_per_atom.data(),
@@ -676,6 +707,10 @@ void Run::perform_a_run()
   hip_check(hipDeviceSynchronize(), "sync");
   const auto t0 = std::chrono::steady_clock::now();
   die_on(nepmi_engine_reset_thermostat(e), "reset_thermostat"); // Ensemble_NHC: a fresh chain per run (integrate.cu:85-92)
+  if (nhc_state_) {
+    (void)hipFree(nhc_state_);
+    nhc_state_ = nullptr;
+  }
   if (ensemble == "nvt_bdp") { // Ensemble_BDP::initialize_rng (ensemble_bdp.cu:32-39): seeded from the clock
     const uint64_t seed = (uint64_t)std::chrono::system_clock::now().time_since_epoch().count();
     die_on(nepmi_bdp_seed(e, seed), "bdp_seed");

@@ -68,6 +68,7 @@ private:
   nepmi_model* dist_model_ = nullptr;
   nepmi_dist* dist_ = nullptr;
   bool dist_ready_ = false;
+  double* nhc_state_ = nullptr; // stepwise path (several potentials averaged): the chain of this run
   int correct_interval_ = 0, correct_group_method_ = -1; // correct_velocity (run.cu:610-647)
   Box box;
   Atom atom;
