@@ -770,6 +770,7 @@ private:
     md_.rc_r = upload(m.rc_radial_f);
     md_.rc_a = upload(m.rc_angular_f);
     md_.zbl_para = upload(m.zbl_para_f);
+    md_.zbl_rco = m.zbl_typewise ? upload(m.zbl_rc_outer_pair) : nullptr;
     md_.atomic_number = upload(m.atomic_numbers);
   }
 

@@ -1667,6 +1667,8 @@ struct AngularForceBody {
           const int ta = t1 < t2 ? t1 : t2, tb = t1 < t2 ? t2 : t1;
           const int zidx = ta * m.T - (ta * (ta - 1)) / 2 + (tb - ta);
           zbl_pair(m.zbl_para + 10 * zidx, zizj, a_inv, 0.0f, 0.0f, d, dinv, f, fp);
+        } else if (m.zbl_rco) { // type-wise outer cutoff, inner cutoff 0 (nep.cu:935-941)
+          zbl_pair(nullptr, zizj, a_inv, 0.0f, m.zbl_rco[t1 * m.T + t2], d, dinv, f, fp);
         } else {
           zbl_pair(nullptr, zizj, a_inv, m.zbl_rc_inner, m.zbl_rc_outer, d, dinv, f, fp);
         }

@@ -111,6 +111,7 @@ struct ModelD {
   const float* rc_r;   // [T]
   const float* rc_a;   // [T]
   const float* zbl_para;   // [T(T+1)/2][10]
+  const float* zbl_rco;    // [T*T] type-wise outer cutoff of the universal ZBL (inner cutoff 0 then), or nullptr
   const int* atomic_number; // [T]
 };
 

@@ -141,8 +141,33 @@ std::string load_nep_model(const std::string& path, NepModel& m, bool* unsupport
     m.zbl_rc_outer = std::atof(tok[2].c_str());
     if (m.zbl_rc_inner == 0 && m.zbl_rc_outer == 0)
       m.zbl_flexible = true;
-    else if (tok.size() == 4)
-      return unsup("type-wise ZBL cutoff factor is not supported by this engine.");
+    else if (tok.size() == 4) { // universal ZBL with a type-wise outer cutoff (nep.cu:183-186, :935-941)
+      m.zbl_typewise = true;
+      m.zbl_typewise_factor = std::atof(tok[3].c_str());
+      // covalent radii (Angstrom) by atomic number, the constant table of src/utilities/nep_utilities.cuh:143-154
+      static const float kCovalentRadius[94] = {
+        0.426667f, 0.613333f, 1.6f, 1.25333f, 1.02667f, 1.0f, 0.946667f, 0.84f,
+        0.853333f, 0.893333f, 1.86667f, 1.66667f, 1.50667f, 1.38667f, 1.46667f, 1.36f,
+        1.32f, 1.28f, 2.34667f, 2.05333f, 1.77333f, 1.62667f, 1.61333f, 1.46667f,
+        1.42667f, 1.38667f, 1.33333f, 1.32f, 1.34667f, 1.45333f, 1.49333f, 1.45333f,
+        1.53333f, 1.46667f, 1.52f, 1.56f, 2.52f, 2.22667f, 1.96f, 1.85333f,
+        1.76f, 1.65333f, 1.53333f, 1.50667f, 1.50667f, 1.44f, 1.53333f, 1.64f,
+        1.70667f, 1.68f, 1.68f, 1.64f, 1.76f, 1.74667f, 2.78667f, 2.34667f,
+        2.16f, 1.96f, 2.10667f, 2.09333f, 2.08f, 2.06667f, 2.01333f, 2.02667f,
+        2.01333f, 2.0f, 1.98667f, 1.98667f, 1.97333f, 2.04f, 1.94667f, 1.82667f,
+        1.74667f, 1.64f, 1.57333f, 1.54667f, 1.48f, 1.49333f, 1.50667f, 1.76f,
+        1.73333f, 1.73333f, 1.81333f, 1.74667f, 1.84f, 1.89333f, 2.68f, 2.41333f,
+        2.22667f, 2.10667f, 2.02667f, 2.04f, 2.05333f, 2.06667f};
+      m.zbl_rc_outer_pair.assign((size_t)T * T, (float)m.zbl_rc_outer);
+      for (int t1 = 0; t1 < T; ++t1)
+        for (int t2 = 0; t2 < T; ++t2) {
+          const int z1 = m.atomic_numbers[t1], z2 = m.atomic_numbers[t2];
+          if (z1 < 1 || z1 > 94 || z2 < 1 || z2 > 94)
+            return unsup("type-wise ZBL cutoff: element beyond Z = 94");
+          const float rc = (kCovalentRadius[z1 - 1] + kCovalentRadius[z2 - 1]) * (float)m.zbl_typewise_factor;
+          m.zbl_rc_outer_pair[(size_t)t1 * T + t2] = rc < (float)m.zbl_rc_outer ? rc : (float)m.zbl_rc_outer;
+        }
+    }
   }
 
   tok = next_tokens(in);

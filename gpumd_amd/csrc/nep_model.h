@@ -21,6 +21,9 @@ struct NepModel {
   int version = 0; // 3, 4, 5
   bool zbl_enabled = false, zbl_flexible = false;
   double zbl_rc_inner = 0, zbl_rc_outer = 0;
+  bool zbl_typewise = false;            // zbl <rc_inner> <rc_outer> <factor> (nep.cu:183-186)
+  double zbl_typewise_factor = 0;
+  std::vector<float> zbl_rc_outer_pair; // [T*T] min((R_cov(Z1) + R_cov(Z2)) * factor, rc_outer), when zbl_typewise
   int num_types = 0;
   std::vector<std::string> symbols;
   std::vector<int> atomic_numbers;

@@ -26,6 +26,13 @@ int main(int argc, char* argv[])
   for (int k = 1; k < argc; ++k)
     if (std::strcmp(argv[k], "--check-input") == 0)
       check_only = true;
+  if (argc == 4 && std::strcmp(argv[1], "--rand-check") == 0) { // the velocity stream's generator, for the tests
+    const int n = std::atoi(argv[2]);
+    const unsigned seed = (unsigned)std::strtoul(argv[3], nullptr, 10);
+    for (int k = 0; k < n; ++k)
+      std::printf("%d\n", gmi::host_rand_for_tests(seed, k == 0));
+    return 0;
+  }
   gmi::Parallel par;
   par.rank = env_int("RANK", "OMPI_COMM_WORLD_RANK", 0);
   par.world = env_int("WORLD_SIZE", "OMPI_COMM_WORLD_SIZE", 1);

@@ -1,5 +1,7 @@
 #include "model.h"
 
+#include <cstdint>
+
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -375,6 +377,54 @@ static void zero_angular_momentum(int N, const double* m, const double* x, const
   }
 }
 
+// glibc's rand() / srand() (the TYPE_3 additive feedback generator of random_r.c: r[i] = r[i-3] + r[i-31], seeded by
+// the Lehmer generator 16807 mod 2^31-1, first 310 outputs discarded), restated here so that the velocity stream of
+// Velocity::initialize (velocity.cu:40-75) is reproduced independently of whatever else in the process -- the HIP
+// runtime, RCCL -- calls the C library's rand().  Checked against the C library in tests/test_host_cli.py.
+struct GlibcRand {
+  std::vector<uint32_t> ring; // the last 34 values
+  size_t pos = 0;
+  explicit GlibcRand(unsigned seed = 1) { reseed(seed); }
+  void reseed(unsigned seed)
+  {
+    if (seed == 0)
+      seed = 1;
+    std::vector<int32_t> s(34);
+    s[0] = (int32_t)seed;
+    for (int i = 1; i < 31; ++i) {
+      const int64_t hi = s[i - 1] / 127773, lo = s[i - 1] % 127773;
+      int64_t w = 16807 * lo - 2836 * hi;
+      if (w < 0)
+        w += 2147483647;
+      s[i] = (int32_t)w;
+    }
+    ring.assign(34, 0);
+    for (int i = 0; i < 31; ++i)
+      ring[i] = (uint32_t)s[i];
+    for (int i = 31; i < 34; ++i)
+      ring[i] = ring[i - 31];
+    pos = 34;
+    for (int i = 34; i < 344; ++i)
+      next_raw();
+  }
+  uint32_t next_raw()
+  {
+    const uint32_t v = ring[(pos - 31) % 34] + ring[(pos - 3) % 34];
+    ring[pos % 34] = v;
+    ++pos;
+    return v;
+  }
+  int next() { return (int)(next_raw() >> 1); }
+};
+static GlibcRand g_rand; // the process-wide stream of rand(), default seed 1 like the C library's
+
+int host_rand_for_tests(unsigned seed, bool reseed)
+{
+  if (reseed)
+    g_rand.reseed(seed);
+  return g_rand.next();
+}
+
 void correct_velocity(int N, const std::vector<double>& mass, const std::vector<double>& pos, std::vector<double>& vel,
                       const int* contents, int count)
 {
@@ -408,21 +458,22 @@ void initialize_velocity(double temperature, bool use_seed, int seed, Atom& atom
   double* vx = atom.cpu_velocity_per_atom.data();
   double* vy = vx + N;
   double* vz = vy + N;
+  constexpr double kRandMax = 2147483647.0; // RAND_MAX of glibc
   if (use_seed) {
     const unsigned int s = (unsigned int)seed;
     for (int n = 0; n < N; ++n) {
-      srand(s + n * 3);
-      vx[n] = -1.0 + (rand() * 2.0) / RAND_MAX;
-      srand(s + n * 3 + 1);
-      vy[n] = -1.0 + (rand() * 2.0) / RAND_MAX;
-      srand(s + n * 3 + 2);
-      vz[n] = -1.0 + (rand() * 2.0) / RAND_MAX;
+      g_rand.reseed(s + n * 3);
+      vx[n] = -1.0 + (g_rand.next() * 2.0) / kRandMax;
+      g_rand.reseed(s + n * 3 + 1);
+      vy[n] = -1.0 + (g_rand.next() * 2.0) / kRandMax;
+      g_rand.reseed(s + n * 3 + 2);
+      vz[n] = -1.0 + (g_rand.next() * 2.0) / kRandMax;
     }
   } else {
     for (int n = 0; n < N; ++n) {
-      vx[n] = -1.0 + (rand() * 2.0) / RAND_MAX;
-      vy[n] = -1.0 + (rand() * 2.0) / RAND_MAX;
-      vz[n] = -1.0 + (rand() * 2.0) / RAND_MAX;
+      vx[n] = -1.0 + (g_rand.next() * 2.0) / kRandMax;
+      vy[n] = -1.0 + (g_rand.next() * 2.0) / kRandMax;
+      vz[n] = -1.0 + (g_rand.next() * 2.0) / kRandMax;
     }
   }
   const double* x = atom.cpu_position_per_atom.data();

@@ -49,6 +49,8 @@ static const char* NEPO_ELEMENTS[NEPO_MAX_TYPES] = {
 struct nepo_model {
   int version;
   int zbl_enabled, zbl_flexible;
+  int zbl_typewise;
+  double zbl_typewise_factor;
   double zbl_rc_inner, zbl_rc_outer;
   int num_types;
   char symbols[NEPO_MAX_TYPES][4];
@@ -184,8 +186,10 @@ nepo_model* nepo_model_load(const char* path, char* err, int errlen)
     m->zbl_rc_outer = atof(tok[2]);
     if (m->zbl_rc_inner == 0 && m->zbl_rc_outer == 0)
       m->zbl_flexible = 1;
-    else if (nt == 4)
-      NEPO_FAIL("typewise ZBL cutoff is outside the oracle's scope");
+    else if (nt == 4) { /* universal ZBL with a type-wise outer cutoff, nep.cu:183-186 */
+      m->zbl_typewise = 1;
+      m->zbl_typewise_factor = atof(tok[3]);
+    }
   }
 
   if (!fgets(line, sizeof line, fp))
@@ -321,6 +325,21 @@ const char* nepo_model_symbol(const nepo_model* m, int t) { return m->symbols[t]
 double nepo_model_param(const nepo_model* m, int idx) { return m->params[idx]; }
 
 /* ---- the two precision instantiations ---------------------------------------------------- */
+
+/* covalent radii (Angstrom) by atomic number: the constant table of src/utilities/nep_utilities.cuh:143-154 */
+static const float nepo_covalent_radius[94] = {
+  0.426667f, 0.613333f, 1.6f, 1.25333f, 1.02667f, 1.0f, 0.946667f, 0.84f,
+  0.853333f, 0.893333f, 1.86667f, 1.66667f, 1.50667f, 1.38667f, 1.46667f, 1.36f,
+  1.32f, 1.28f, 2.34667f, 2.05333f, 1.77333f, 1.62667f, 1.61333f, 1.46667f,
+  1.42667f, 1.38667f, 1.33333f, 1.32f, 1.34667f, 1.45333f, 1.49333f, 1.45333f,
+  1.53333f, 1.46667f, 1.52f, 1.56f, 2.52f, 2.22667f, 1.96f, 1.85333f,
+  1.76f, 1.65333f, 1.53333f, 1.50667f, 1.50667f, 1.44f, 1.53333f, 1.64f,
+  1.70667f, 1.68f, 1.68f, 1.64f, 1.76f, 1.74667f, 2.78667f, 2.34667f,
+  2.16f, 1.96f, 2.10667f, 2.09333f, 2.08f, 2.06667f, 2.01333f, 2.02667f,
+  2.01333f, 2.0f, 1.98667f, 1.98667f, 1.97333f, 2.04f, 1.94667f, 1.82667f,
+  1.74667f, 1.64f, 1.57333f, 1.54667f, 1.48f, 1.49333f, 1.50667f, 1.76f,
+  1.73333f, 1.73333f, 1.81333f, 1.74667f, 1.84f, 1.89333f, 2.68f, 2.41333f,
+  2.22667f, 2.10667f, 2.02667f, 2.04f, 2.05333f, 2.06667f};
 
 #define REAL float
 #define SFX(name) name##_f32

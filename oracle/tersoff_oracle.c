@@ -82,6 +82,17 @@ tersoff_model* terso_load(const char* path)
 }
 
 void terso_free(tersoff_model* m) { free(m); }
+/* the three parameter sets (type 0-0, type 1-1, mixed), 16 doubles each in the order of ters_par: what the pin against
+ * the reference's own kernels (oracle/ref_tersoff_wrap.cpp) feeds them */
+void terso_params(const tersoff_model* m, double out[48])
+{
+  for (int s = 0; s < 3; ++s) {
+    const ters_par* p = &m->p[s];
+    const double v[16] = {p->a, p->b, p->lambda, p->mu, p->beta, p->n, p->c, p->d, p->h, p->r1, p->r2,
+                          p->c2, p->d2, p->one_plus_c2overd2, p->pi_factor, p->minus_half_over_n};
+    memcpy(out + 16 * s, v, sizeof v);
+  }
+}
 double terso_rc(const tersoff_model* m) { return m->rc; }
 
 static const ters_par* pair_par(const tersoff_model* m, int t1, int t2)

@@ -45,23 +45,28 @@ def main():
         os.makedirs(os.path.dirname(d), exist_ok=True)
         shutil.copyfile(os.path.join(REF, src), d)
         os.chmod(d, 0o644)
-    # nep_prediction known answers: first 2 of the 25 frames (250 atoms each)
+    # nep_prediction known answers: all 25 frames (250 atoms each) of examples/nep_prediction
     pdir = os.path.join(OUT, "PbTe")
-    with open(os.path.join(REF, "examples/nep_prediction/train.xyz")) as f:
-        lines = f.readlines()
-    n = int(lines[0].split()[0])
-    with open(os.path.join(pdir, "train_2frames.xyz"), "w") as f:
-        f.writelines(lines[: 2 * (n + 2)])
-    e = np.loadtxt(os.path.join(REF, "examples/nep_prediction/energy_train.out"))[:2]
-    fo = np.loadtxt(os.path.join(REF, "examples/nep_prediction/force_train.out"))[: 2 * n]
-    v = np.loadtxt(os.path.join(REF, "examples/nep_prediction/virial_train.out"))[:2]
-    np.savez(os.path.join(pdir, "train_2frames_out.npz"), energy=e, force=fo, virial=v)
-    # first frame of the 64k-atom carbon test cell is too big to ship; keep its header only
+    shutil.copyfile(os.path.join(REF, "examples/nep_prediction/train.xyz"), os.path.join(pdir, "train_25frames.xyz"))
+    os.chmod(os.path.join(pdir, "train_25frames.xyz"), 0o644)
+    e = np.loadtxt(os.path.join(REF, "examples/nep_prediction/energy_train.out"))
+    fo = np.loadtxt(os.path.join(REF, "examples/nep_prediction/force_train.out"))
+    v = np.loadtxt(os.path.join(REF, "examples/nep_prediction/virial_train.out"))
+    np.savez_compressed(os.path.join(pdir, "train_25frames_out.npz"), energy=e, force=fo, virial=v)
+    # the reference's one trajectory-level golden: tests/gpumd/carbon (64,000-atom amorphous carbon, NEP4, 100 NVE steps,
+    # thermo1.out from a DEBUG build = glibc's default rand() stream).  model.xyz (4 MB of text) is kept as the parsed
+    # doubles; the test writes it back with %.17g, which reproduces the same bits.
     with open(os.path.join(REF, "tests/gpumd/carbon/model.xyz")) as f:
-        head = [next(f) for _ in range(2)]
+        lines = f.read().split("\n")
+    n = int(lines[0])
+    pos = np.array([[float(t) for t in ln.split()[1:4]] for ln in lines[2:2 + n]])
+    assert all(ln.split()[0] == "C" for ln in lines[2:2 + n])
     os.makedirs(os.path.join(OUT, "C"), exist_ok=True)
-    with open(os.path.join(OUT, "C", "carbon_64000_header.txt"), "w") as f:
-        f.writelines(head)
+    np.savez_compressed(os.path.join(OUT, "C", "carbon_64000.npz"), pos=pos, header=np.array(lines[1]))
+    shutil.copyfile(os.path.join(REF, "tests/gpumd/carbon/thermo1.out"), os.path.join(OUT, "C", "carbon_thermo1.out"))
+    shutil.copyfile(os.path.join(REF, "tests/gpumd/carbon/run.in"), os.path.join(OUT, "C", "carbon_run.in"))
+    for fn in ("carbon_thermo1.out", "carbon_run.in"):
+        os.chmod(os.path.join(OUT, "C", fn), 0o644)
     angular_rows()
     print("golden fixtures written to", OUT)
 

@@ -428,6 +428,7 @@ def terso_lib():
         L.terso_rc.restype = C.c_double
         L.terso_rc.argtypes = [C.c_void_p]
         L.terso_compute.argtypes = [C.c_void_p, C.c_int, _ip, _dp, _ip, _dp, _dp, _dp, _dp, _ip, _ip, C.c_int]
+        L.terso_params.argtypes = [C.c_void_p, _dp]
         _terso_lib = L
     return _terso_lib
 

@@ -218,3 +218,44 @@ def test_dump_xyz_full_option_set(tmp_path):
     assert r["comment"]["properties"] == "species:S:1:pos:R:3:mass:R:1:vel:R:3:group:I:2"
     np.testing.assert_array_equal(r["group"], a["group"])
     np.testing.assert_array_equal(r["pos"], a["pos"])
+
+
+@pytest.mark.gpu
+def test_reference_carbon_trajectory_golden(tmp_path):
+    """The reference's one trajectory-level golden (tests/gpumd/carbon: 64,000-atom amorphous carbon, C_2022_NEP4, 100 NVE
+    steps of 1 fs, `velocity 300` on glibc's default rand() stream, thermo1.out written by a DEBUG build of the CUDA
+    code): gpumd-mi on the same run.in / model.xyz reproduces all ten thermo rows -- velocity initialisation,
+    velocity-Verlet, the NEP force path and find_thermo pinned at the MD level against the reference itself."""
+    g = np.load(H.golden("C", "carbon_64000.npz"))
+    pos = g["pos"]
+    with open(tmp_path / "model.xyz", "w") as f:
+        f.write("%d\n%s\n" % (len(pos), str(g["header"])))
+        for p in pos:
+            f.write("C %.17g %.17g %.17g\n" % (p[0], p[1], p[2]))
+    run_in = open(H.golden("C", "carbon_run.in")).read()
+    assert "potentials/nep/C_2022_NEP4.txt" in run_in and "velocity        300" in run_in
+    (tmp_path / "run.in").write_text(run_in.replace("../../../potentials/nep/C_2022_NEP4.txt", H.golden("C", "nep.txt")))
+    out = subprocess.run([EXE], cwd=str(tmp_path), capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    got, ref = np.loadtxt(tmp_path / "thermo.out"), np.loadtxt(H.golden("C", "carbon_thermo1.out"))
+    assert got.shape == ref.shape == (10, 18)
+    # measured on MI355X: T and KE agree to 2e-7, PE to 3e-7 (0.05 eV of 1.6e5: FP32 summation order), stresses to 1e-4 GPa
+    np.testing.assert_allclose(got[:, 0], ref[:, 0], rtol=2e-6)            # T
+    np.testing.assert_allclose(got[:, 1], ref[:, 1], rtol=2e-6)            # KE
+    np.testing.assert_allclose(got[:, 2], ref[:, 2], rtol=2e-6)            # PE
+    np.testing.assert_allclose(got[:, 3:9], ref[:, 3:9], rtol=1e-3, atol=5e-4)  # stresses (GPa)
+    np.testing.assert_allclose(got[:, 9:], ref[:, 9:], rtol=1e-12)         # box
+
+
+def test_velocity_stream_is_glibc_rand(tmp_path):
+    """Velocity::initialize draws from rand() (velocity.cu:40-75); the host restates glibc's generator so that nothing
+    else in the process (HIP runtime, RCCL) can disturb the stream: it must BE glibc's, number for number."""
+    import ctypes
+    exe = os.path.join(H.ROOT, "tests", "emu", "gpumd-mi-emu")
+    subprocess.run(["make", "-s", "-C", os.path.join(H.ROOT, "tests", "emu"), "all"], check=True)
+    libc = ctypes.CDLL("libc.so.6")
+    for seed in (1, 42, 123456789, 2 ** 31 + 5):
+        libc.srand(ctypes.c_uint(seed))
+        ref = [libc.rand() for _ in range(2000)]
+        out = subprocess.run([exe, "--rand-check", "2000", str(seed)], capture_output=True, text=True)
+        assert [int(x) for x in out.stdout.split()] == ref, seed

@@ -43,6 +43,59 @@ def make_per_type_cutoff(tmp_path):
     return _write(tmp_path, "pertype.txt", out)
 
 
+def make_flexible_zbl(tmp_path):
+    """nep4_zbl with `zbl 0 0`: the flexible ZBL (nep.cu:176-178, :925-932) -- ten parameters per type pair
+    (rc_inner, rc_outer, then four (a, b) pairs of the screening function) behind q_scaler.  The pair is brought close
+    enough (rattled PbTe has 2.9-3.3 A bonds; outer cutoffs 3.4-3.8 A) for the repulsion to act."""
+    L = [x for x in _pbte_lines() if x.strip()]
+    out = ["nep4_zbl 2 Te Pb", "zbl 0 0"] + L[1:]
+    rng = np.random.default_rng(3)
+    for pair in range(3):  # Te-Te, Te-Pb, Pb-Pb
+        a = rng.uniform(0.1, 0.5, 4)
+        a /= a.sum()
+        b = np.array([3.2, 0.94, 0.40, 0.20]) * rng.uniform(0.9, 1.1, 4)
+        vals = [1.2 + 0.1 * pair, 3.4 + 0.2 * pair]
+        for k in range(4):
+            vals += [a[k], b[k]]
+        out += ["%.8e" % v for v in vals]
+    return _write(tmp_path, "flexzbl.txt", out)
+
+
+def make_typewise_zbl(tmp_path, factor=1.15, name="typewise.txt"):
+    """`zbl rc_inner rc_outer factor`: the universal ZBL with a type-wise outer cutoff
+    min((R_cov(Z1) + R_cov(Z2)) * factor, rc_outer) and inner cutoff 0 (nep.cu:179-186, :935-941)."""
+    L = [x for x in _pbte_lines() if x.strip()]
+    return _write(tmp_path, name, ["nep4_zbl 2 Te Pb", "zbl 1.0 3.6 %g" % factor] + L[1:])
+
+
+@pytest.mark.skipif(not H.ref_available(), reason="oracle/_ref not built (no /root/reference here)")
+def test_typewise_zbl_oracle_against_nep_cpu(tmp_path):
+    """The vendored NEP_CPU takes rc_inner = rc_outer / 2 under a type-wise ZBL cutoff (nep.cpp:1397-1402) where the
+    GPU code this engine follows takes 0 (nep.cu:935-941), so it cannot evaluate the variant itself -- but it can
+    evaluate the universal ZBL that the type-wise rule reduces to: (1) a factor so large that every pair keeps
+    rc_outer == `zbl 0 rc_outer`; (2) an all-Te structure, where the one pair cutoff is (2 R_cov(Te)) * factor
+    == `zbl 0 <that>`.  The oracle must agree with NEP_CPU on both."""
+    h, typ, x = H.pbte_supercell((2, 2, 2), seed=17)
+    L = [ln for ln in _pbte_lines() if ln.strip()]
+
+    def universal(rc_outer, name):
+        return _write(tmp_path, name, ["nep4_zbl 2 Te Pb", "zbl 0.0 %.9g" % rc_outer] + L[1:])
+
+    pe, f, _ = H.Oracle(make_typewise_zbl(tmp_path, 100.0, "tw_big.txt")).compute(typ, h, x, precision=64, path=0)
+    pe_r, f_r, _ = H.RefNepCpu(universal(3.6, "uni36.txt")).compute(typ, h, x)
+    np.testing.assert_allclose(f, f_r, rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(pe, pe_r, rtol=1e-10, atol=1e-10)
+    te = np.zeros_like(typ)
+    r_te = 1.64  # covalent radius of Te (Z = 52) in the reference's table, nep_utilities.cuh:143-154
+    pe, f, _ = H.Oracle(make_typewise_zbl(tmp_path, 1.05, "tw_105.txt")).compute(te, h, x, precision=64, path=0)
+    pe_r, f_r, _ = H.RefNepCpu(universal(np.float32(2 * np.float32(r_te)) * np.float32(1.05), "uni_te.txt")).compute(te, h, x)
+    np.testing.assert_allclose(f, f_r, rtol=1e-6, atol=1e-7)   # the cutoff itself is an FP32 product in the reference
+    np.testing.assert_allclose(pe, pe_r, rtol=1e-7, atol=1e-7)
+    # and the repulsion really acts inside 2 R_cov(Te) * 1.05 = 3.44 A
+    pe0, _, _ = H.Oracle(make_typewise_zbl(tmp_path, 1.0e-3, "tw_off.txt")).compute(te, h, x, precision=64, path=0)
+    assert abs(pe.sum() - pe0.sum()) > 1e-3
+
+
 def make_extra_rows(flags, l_max=4):
     """l_max 4 <222> <1111> <112> <123> <233> <134>: the PbTe descriptor with the optional 4-body rows switched on
     (nep.cu:262-312).  No shipped model has them, so the ANN is seeded random (the descriptor coefficients and the
@@ -90,7 +143,7 @@ def _check(drv, nep, ref_cpu):
     n = len(typ)
     orc = H.Oracle(nep)
     pe64, f64, v64 = orc.compute(typ, h, x, precision=64, path=0)
-    if "extra_" in nep:
+    if "extra_" in nep or "typewise" in nep:
         _oracle_finite_differences(orc, h, typ, x)
     if ref_cpu and H.ref_available():
         pe_r, f_r, v_r = H.RefNepCpu(nep).compute(typ, h, x)
@@ -108,7 +161,8 @@ def _check(drv, nep, ref_cpu):
         H.assert_lists_equal(nn, nl, onn, onl)
 
 
-VARIANTS = [("nep5", make_nep5, True), ("nep3-2types", make_nep3, True), ("per-type-cutoff", make_per_type_cutoff, False),
+VARIANTS = [("flexible-zbl", make_flexible_zbl, True), ("typewise-zbl", make_typewise_zbl, False),
+            ("nep5", make_nep5, True), ("nep3-2types", make_nep3, True), ("per-type-cutoff", make_per_type_cutoff, False),
             # the optional 4-body rows 112 / 123 / 233 / 134 (flags: 222 1111 112 123 233 134)
             ("rows-all", make_extra_rows([1, 1, 1, 1, 1, 1]), False), ("rows-112", make_extra_rows([1, 0, 1, 0, 0, 0]), False),
             ("rows-123-233", make_extra_rows([0, 0, 0, 1, 1, 0]), False), ("rows-134", make_extra_rows([0, 1, 0, 0, 0, 1]), False),

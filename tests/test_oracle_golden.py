@@ -33,10 +33,11 @@ def test_pbte250_cuda_known_answer():
 
 
 def test_nep_prediction_frames():
-    """examples/nep_prediction/*_train.out (written by the `nep` executable), first 2 frames."""
+    """examples/nep_prediction/*_train.out (written by the `nep` executable), all 25 frames."""
     orc = H.Oracle(H.golden("PbTe", "nep.txt"))
-    frames = H.read_xyz_frames(H.golden("PbTe", "train_2frames.xyz"))
-    out = np.load(H.golden("PbTe", "train_2frames_out.npz"))
+    frames = H.read_xyz_frames(H.golden("PbTe", "train_25frames.xyz"))
+    out = np.load(H.golden("PbTe", "train_25frames_out.npz"))
+    assert len(frames) == 25 and out["energy"].shape[0] == 25
     for k, fr in enumerate(frames):
         typ = H.types_from_species(fr["species"], orc.symbols)
         pe, f, v = orc.compute(typ, fr["h"], H.soa(fr["pos"]), precision=64)
@@ -147,3 +148,67 @@ def test_angular_rows_fixture_is_what_the_reference_functions_return():
         ref = np.load(H.golden("rows", "angular_rows_ref.npz"))
         for k in ref.files:
             np.testing.assert_array_equal(new[k], ref[k])
+
+
+_THERMO_REF = os.path.join(H.ROOT, "oracle", "_ref", "libthermo_ref.so")
+
+
+@pytest.mark.skipif(not os.path.exists(_THERMO_REF), reason="oracle/_ref not built (no /root/reference here)")
+def test_nose_hoover_chain_vs_reference_nhc():
+    """oracle nepo_nhc == the reference's own nhc() (src/integrate/ensemble_nhc.cu:102-164, compiled in place by
+    oracle/ref_thermo_wrap.cpp): scale factors and the chain state over a driven sequence of kinetic energies."""
+    import ctypes as C
+    R = C.CDLL(_THERMO_REF)
+    R.nepref_nhc.restype = C.c_double
+    R.nepref_nhc.argtypes = [C.c_int, H._dp, H._dp, H._dp, C.c_double, C.c_double, C.c_double, C.c_double]
+    L = H.oracle_lib()
+    n, t_coup, dt = 2000, 50.0, 1.0 / H.TIME_UNIT
+    st = np.zeros(12)
+    L.nepo_nhc_init(n, 300.0, t_coup, dt, H._p(st, H._dp))
+    pos, vel, mas = st[0:4].copy(), st[4:8].copy(), st[8:12].copy()
+    rng = np.random.default_rng(5)
+    dN = 3.0 * n
+    for step in range(200):
+        T_now = 300.0 + 150.0 * np.sin(0.07 * step) + rng.normal(0, 5)
+        target = 300.0 + 0.5 * step
+        ek2, kT = T_now * dN * H.K_B, H.K_B * target
+        f_o = L.nepo_nhc(H._p(st, H._dp), ek2, kT, dN, 0.5 * dt)
+        f_r = R.nepref_nhc(4, H._p(pos, H._dp), H._p(vel, H._dp), H._p(mas, H._dp), ek2, kT, dN, 0.5 * dt)
+        assert f_o == f_r, (step, f_o, f_r)  # the same double arithmetic in the same order: bit for bit
+    assert np.array_equal(st[0:4], pos) and np.array_equal(st[4:8], vel) and np.array_equal(st[8:12], mas)
+    assert np.abs(vel).max() > 0 and abs(f_o - 1.0) > 1e-9  # the chain really acted
+
+
+@pytest.mark.skipif(not os.path.exists(_THERMO_REF), reason="oracle/_ref not built (no /root/reference here)")
+def test_bdp_draws_vs_reference_resamplekin():
+    """oracle nepo_bdp_factor == the reference's own resamplekin / gasdev / gamdev (src/integrate/svr_utilities.cuh)
+    driven by std::mt19937 with the same seed, draw for draw.  gasdev keeps a function-local cache in the reference,
+    so the comparison runs in a process of its own."""
+    code = r'''
+import ctypes as C, sys
+import numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import helpers as H
+R = C.CDLL(%r)
+L = H.oracle_lib()
+n, seed, tc = 250, 20240924, 25.0
+T = 300.0 + 80.0 * np.sin(0.3 * np.arange(64))
+out = np.zeros(64)
+R.nepref_bdp_factors(C.c_uint(seed), 64, n, H._p(T, H._dp), C.c_double(350.0), C.c_double(tc), H._p(out, H._dp))
+rng = C.create_string_buffer(L.nepo_bdp_sizeof())
+L.nepo_bdp_seed(rng, seed)
+L.nepo_bdp_factor.restype = C.c_double
+got = np.array([L.nepo_bdp_factor(rng, n, C.c_double(t), C.c_double(350.0), C.c_double(tc)) for t in T])
+assert np.array_equal(got, out), np.abs(got - out).max()
+assert np.abs(out - 1.0).max() > 1e-3
+# small systems take the other branches of gamdev / resamplekin_sumnoises (ia < 6, odd / even degrees of freedom)
+print("ok")
+''' % (H.ROOT, os.path.join(H.ROOT, "tests"), _THERMO_REF)
+    import subprocess
+    import sys
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    assert res.returncode == 0 and "ok" in res.stdout, res.stdout + res.stderr
+    for n_atoms in (1, 2, 3, 4, 5):  # 3, 6, ... 15 degrees of freedom: the ia < 6 product branch and both parities
+        code2 = code.replace("n, seed, tc = 250, 20240924, 25.0", "n, seed, tc = %d, 77, 3.0" % n_atoms)
+        res = subprocess.run([sys.executable, "-c", code2], capture_output=True, text=True)
+        assert res.returncode == 0 and "ok" in res.stdout, (n_atoms, res.stdout + res.stderr)

@@ -1,9 +1,10 @@
 """Tersoff-1989 (BASELINE config 2: Si, classical pair-force + Verlet path, FP64).
 
-There is no force-level golden vector for this potential in the reference tree, so the oracle
-(oracle/tersoff_oracle.c, restating src/force/tersoff1989.cu) is validated by finite differences,
-Newton's third law and the strain derivative of its own energy; the engine is then compared with
-the oracle (FP64: agreement ~1e-10) -- CPU tier through the kernel emulator, GPU tier on the device."""
+There is no force-level golden vector for this potential in the reference tree; the oracle
+(oracle/tersoff_oracle.c, restating src/force/tersoff1989.cu) is pinned against the reference's OWN kernels
+(find_force_tersoff_step1/2 and gpu_find_force_many_body compiled for the host by oracle/ref_tersoff_wrap.cpp) and
+checked by finite differences, Newton's third law and the strain derivative of its own energy; the engine is then
+compared with the oracle (FP64: agreement ~1e-10) -- CPU tier through the kernel emulator, GPU tier on the device."""
 import os
 import subprocess
 
@@ -43,6 +44,51 @@ def test_oracle_self_consistency():
     for (a, b), comp in (((0, 0), 0), ((1, 1), 1), ((2, 2), 2), ((0, 1), 3)):
         dE = (e_strain(eps, a, b) - e_strain(-eps, a, b)) / (2 * eps)
         assert abs(dE + W[comp]) < 1e-5 * max(1.0, abs(W[comp]))
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(H.ROOT, "oracle", "_ref", "libtersoff_ref.so")),
+                    reason="oracle/_ref not built (no /root/reference here)")
+@pytest.mark.parametrize("case", ["Si-ortho", "Si-triclinic", "two-types"])
+def test_oracle_vs_reference_kernels(case, tmp_path):
+    """oracle/tersoff_oracle.c == the reference's own Tersoff kernels (tersoff1989.cu:157-505, potential.cu:35-134)
+    compiled for the host, on the same local neighbour list: energies, forces and all nine virial planes to 1e-11."""
+    import ctypes as C
+    pot = POT
+    h, typ, x = H.diamond((3, 3, 4), 5.432, rattle=0.08, seed=12)
+    n = len(typ)
+    if case == "Si-triclinic":
+        S = np.array([[1.0, 0.07, -0.04], [0.0, 1.0, 0.05], [0.0, 0.0, 1.0]])
+        h = (S @ np.asarray(h).reshape(3, 3)).reshape(9)
+        x = (S @ x.reshape(3, n)).reshape(-1)
+    if case == "two-types":  # a synthetic SiC-like file: two parameter sets + the mixing factor chi
+        lines = open(POT).read().split("\n")
+        assert lines[0].split()[:2] == ["tersoff_1989", "1"]
+        p0 = lines[1].split()
+        p1 = [("%.10g" % (float(v) * f)) for v, f in zip(p0, (0.8, 0.9, 1.05, 1.1, 1.3, 0.95, 1.0, 1.0, 1.0, 0.95, 0.97))]
+        pot = str(tmp_path / "two.txt")
+        open(pot, "w").write("tersoff_1989 2 Si C\n%s\n%s\n0.98\n" % (" ".join(p0), " ".join(p1)))
+        typ = (np.arange(n) % 2).astype(np.int32)
+    o = H.TersoffOracle(pot)
+    pe_o, f_o, v_o, nn, nl = o.compute(typ, h, x, lists=True)
+    par = np.zeros(48)
+    o.L.terso_params(o.h, H._p(par, H._dp))
+    H3 = np.asarray(h, dtype=np.float64).reshape(3, 3)
+    h18 = np.ascontiguousarray(np.concatenate([H3.reshape(9), np.linalg.inv(H3).reshape(9)]))
+    ortho = int(np.count_nonzero(H3 - np.diag(np.diag(H3))) == 0)
+    L = C.CDLL(os.path.join(H.ROOT, "oracle", "_ref", "libtersoff_ref.so"))
+    nl_full = np.ascontiguousarray(np.where(nl < 0, 0, nl).astype(np.int32))  # [slot][atom], stride n
+    pe, f, v = np.zeros(n), np.zeros(3 * n), np.zeros(9 * n)
+    pbc = np.array([1, 1, 1], dtype=np.int32)
+    xw = H.oracle_apply_pbc(h, x)
+    L.nepref_tersoff(C.c_int(n), H._p(h18, H._dp), H._p(pbc, H._ip), C.c_int(ortho), H._p(par, H._dp),
+                     H._p(np.ascontiguousarray(nn.astype(np.int32)), H._ip), H._p(nl_full, H._ip),
+                     H._p(np.ascontiguousarray(typ.astype(np.int32)), H._ip), H._p(np.ascontiguousarray(xw), H._dp),
+                     H._p(pe, H._dp), H._p(f, H._dp), H._p(v, H._dp))
+    pe_o, f_o, v_o, _, _ = o.compute(typ, h, xw, lists=True)
+    assert nn.max() >= 4
+    np.testing.assert_allclose(pe, pe_o, rtol=1e-11, atol=1e-11)
+    np.testing.assert_allclose(f, f_o, rtol=1e-10, atol=1e-11)
+    np.testing.assert_allclose(v, v_o, rtol=1e-10, atol=1e-11)
 
 
 def _check_engine(drv, cells=(4, 4, 5), nve_steps=40):
