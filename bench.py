@@ -33,7 +33,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 METRIC = {"pbte": "atom-steps/sec, NEP PbTe NVE (nep4 2 Te Pb, examples/nep_train/nep.txt)",
           "pbte_ortho": "atom-steps/sec, NEP PbTe NVE, orthogonal rock-salt cell (examples/nep_train/nep.txt)",
           "carbon": "atom-steps/sec, NEP carbon (potentials/nep/C_2022_NEP4.txt)",
-          "unep": "atom-steps/sec, NEP UNEP-v1 16-metal alloy (potentials/nep/Song-2024-UNEP-v1)"}
+          "unep": "atom-steps/sec, NEP UNEP-v1 16-metal alloy (potentials/nep/Song-2024-UNEP-v1)",
+          "si_tersoff": "atom-steps/sec, Tersoff-1989 Si NVE (BASELINE config 2: examples/gpumd_benchmark/Si_Tersoff)"}
 KERNEL_NAMES = ["gather_skin_check", "radial_descriptor", "angular_descriptor", "ann", "angular_partial_force",
                 "force_assemble", "velocity_verlet", "list_rebuild"]
 
@@ -73,6 +74,11 @@ def build_workload(name, reps, seed):
         h, typ, x, mass, vel = S.fcc_alloy_block(cells, seed=seed)
         return ("fcc 16-metal alloy %d atoms (%dx%dx%d cells), UNEP-v1 + ZBL, 300 K" % ((len(typ),) + cells),
                 S.golden("UNEP", "nep.txt"), h, typ, x, mass, vel)
+    if name == "si_tersoff":
+        cells = tuple(max(1, (3 * r) // 4) for r in reps)  # 16 16 16 -> 12 12 12 diamond cells = 13,824 atoms (config 2)
+        h, typ, x, mass, vel = S.diamond_block(cells, a=5.432, rattle=0.0, seed=seed, mass=28.085)
+        return ("diamond Si %d atoms (%dx%dx%d cells, a = 5.432 A), Tersoff-1989, dt 1 fs, 300 K" % ((len(typ),) + cells),
+                S.golden("Si", "Si_Tersoff_1989.txt"), h, typ, x, mass, vel)
     raise SystemExit("unknown workload " + name)
 
 
@@ -89,6 +95,19 @@ def algorithmic_bytes(info, nn_r, nn_a):
         "force_assemble": 28.0 + 4.0 * nn_r + 4.0 * nr1 + 12.0 * nn_a + 24.0 + 72.0,  # x, list, Fp, f12 in; f, virial out
     }
     total = 232.0 + 160.0 + 8.0 * (nn_r + nn_a) + 8.0 * dim + 24.0 * nn_a
+    return per_kernel, total
+
+
+def tersoff_bytes(nn):
+    """Tersoff-1989: compulsory HBM bytes per atom-step with FP64 throughout.  The two
+    force kernels occupy the engine's radial and force-assembly slots."""
+    per_kernel = {
+        "velocity_verlet": 128.0 + 80.0,
+        "gather_skin_check": 24.0,
+        "radial_descriptor": 28.0 + 4.0 * nn + 8.0 + 40.0 * nn,        # x+type, list; pe, (b, b', f12[3]) per bond out
+        "force_assemble": 28.0 + 4.0 * nn + 2 * 24.0 * nn + 24.0 + 72.0,  # x, list, f12 own + gathered reverse; f, virial
+    }
+    total = 232.0 + 160.0 + 8.0 * nn + 88.0 * nn
     return per_kernel, total
 
 
@@ -210,11 +229,40 @@ def cpu_baseline(seconds=12.0):
     return out
 
 
-def kernel_report(st, info, n_atoms_per_launch, st_all=None):
+def cpu_baseline_tersoff(pot, h, typ, x, mass, vel, seconds=12.0):
+    """The C restatement of tersoff1989.cu (oracle/tersoff_oracle.c, pinned against the reference's own kernels by
+    tests/test_tersoff.py) stepping the SAME 13,824-atom Si system: one iteration = compute() + host velocity-Verlet."""
+    H = _oracle_helpers()
+    o = H.TersoffOracle(pot)
+    n = len(typ)
+    dt = 1.0 / H.TIME_UNIT
+    x = H.oracle_apply_pbc(h, x.copy())
+    vel = vel.copy()
+    _, f, _ = o.compute(typ, h, x)
+    minv = np.tile(1.0 / mass, 3)
+    calls, t0 = 0, time.perf_counter()
+    while True:
+        vel += 0.5 * dt * f * minv
+        x = H.oracle_apply_pbc(h, x + dt * vel)
+        _, f, _ = o.compute(typ, h, x)
+        vel += 0.5 * dt * f * minv
+        calls += 1
+        el = time.perf_counter() - t0
+        if el > seconds or calls >= 2000:
+            break
+    return {"value": n * calls / el, "unit": "atom-steps/s", "cores": 1, "kind": "port",
+            "sample": "Si %d atoms (the bench system itself), %d NVE steps of the C Tersoff oracle incl. its O(N) cell-list "
+                      "neighbour search every call, %.1f s" % (n, calls, el)}
+
+
+def kernel_report(st, info, n_atoms_per_launch, st_all=None, tersoff=False):
     """per-kernel mean durations (HIP events) + the roofline object of the dominant force kernel.
     st: stats of the timed region (timing mode 2: only the force-assembly slot is filled); st_all: stats of the
     instrumented pass after it (every slot) -- the timed region's own figure wins where both exist."""
-    per_kernel, b_step = algorithmic_bytes(info, st.mean_nn_radial, st.mean_nn_angular)
+    if tersoff:
+        per_kernel, b_step = tersoff_bytes(st.mean_nn_radial)
+    else:
+        per_kernel, b_step = algorithmic_bytes(info, st.mean_nn_radial, st.mean_nn_angular)
     kern = {}
     for src in (st_all, st):
         if src is None:
@@ -357,7 +405,7 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--reps", type=int, nargs=3, default=[16, 16, 16], help="replicate na nb nc of the 250-atom cell")
-    ap.add_argument("--workload", default="pbte", choices=["pbte", "pbte_ortho", "carbon", "unep"],
+    ap.add_argument("--workload", default="pbte", choices=["pbte", "pbte_ortho", "carbon", "unep", "si_tersoff"],
                     help="pbte = BASELINE config 3 (the bench line); the others are extra single-GPU measurements")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--decomposed", action="store_true",
@@ -404,6 +452,7 @@ def main():
     reps = tuple(args.reps)
     label, nep_txt, h, typ, x, mass, vel = build_workload(args.workload, reps, 42 + (rank if args.scaling == "weak" else 0))
     n = len(typ)
+    x0, vel0 = x.copy(), vel.copy()
     model = gpumd_amd.Model(nep_txt)
     dt = 1.0 / H.TIME_UNIT
     if world > 1 or args.decomposed:
@@ -459,12 +508,24 @@ def main():
     value = total_atoms * args.steps / elapsed
 
     if rank == 0:
-        kern, roofline, b_step = kernel_report(st, model.info, n, st_all)
+        tersoff = args.workload == "si_tersoff"
+        kern, roofline, b_step = kernel_report(st, model.info, n, st_all, tersoff=tersoff)
+        if tersoff:
+            # the two Tersoff kernels sit in the radial and force-assembly slots of the engine's timing table
+            kern = {{"radial_descriptor": "tersoff_bond_order", "force_assemble": "tersoff_force"}.get(k, k): v
+                    for k, v in kern.items()}
+            if roofline:
+                roofline["kernel"] = {"radial_descriptor": "tersoff_bond_order", "force_assemble": "tersoff_force"}[roofline["kernel"]]
+                roofline["note"] = ("13,824 atoms = 54 atoms per CU: the step is launch-latency bound (7 kernels of 3-8 us "
+                                    "each), far from any throughput roofline; FP64 arithmetic like the reference's Tersoff")
         out = {
             "metric": METRIC[args.workload],
             "value": value, "unit": "atom-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "dtype_note": "FP32 kernel arithmetic like the reference NEP path; FP64 positions, velocities and accumulated per-atom outputs", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f64" if tersoff else "f32",
+            "dtype_note": ("FP64 throughout like the reference's Tersoff kernels" if tersoff else
+                           "FP32 kernel arithmetic like the reference NEP path; FP64 positions, velocities and accumulated per-atom outputs"),
+            "data": "synthetic",
             "config": {"workload": label,
                        "atoms_total": total_atoms, "rebuilds_in_timed_region": int(st.num_rebuild - reb0),
                        "mean_nn_radial": st.mean_nn_radial, "mean_nn_angular": st.mean_nn_angular,
@@ -490,6 +551,9 @@ def main():
         if world == 1 and not args.no_cpu_baseline and args.workload == "pbte":
             with _stdout_to_stderr():
                 out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+        if world == 1 and not args.no_cpu_baseline and tersoff:
+            with _stdout_to_stderr():
+                out["cpu_baseline"] = cpu_baseline_tersoff(nep_txt, h, typ, x0, mass, vel0, args.cpu_seconds)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -46,6 +46,28 @@ def test_oracle_self_consistency():
         assert abs(dE + W[comp]) < 1e-5 * max(1.0, abs(W[comp]))
 
 
+def test_oracle_cell_candidates_equal_full_scan():
+    """the oracle's O(N) candidate narrowing (used above 512 atoms) gives bit-identical lists and outputs to its
+    defining all-pairs scan, orthogonal and triclinic"""
+    o = H.TersoffOracle(POT)
+    for tri in (False, True):
+        h, typ, x = H.diamond((5, 4, 6), 5.432, rattle=0.08, seed=9)
+        if tri:
+            Hm = np.asarray(h).reshape(3, 3).copy()
+            Hm[0, 1], Hm[0, 2], Hm[1, 2] = 0.9, -0.7, 1.1
+            frac = np.linalg.solve(np.asarray(h).reshape(3, 3), x.reshape(3, -1))
+            h, x = Hm.reshape(9), (Hm @ frac).reshape(-1)
+        x = x + np.repeat(np.asarray(h).reshape(3, 3)[:, 0] * 2.0, len(typ))      # some atoms outside the cell
+        o.L.terso_full_scan(1)
+        try:
+            a = o.compute(typ, h, x, lists=True)
+        finally:
+            o.L.terso_full_scan(0)
+        b = o.compute(typ, h, x, lists=True)
+        for u, v in zip(a, b):
+            assert np.array_equal(u, v)
+
+
 @pytest.mark.skipif(not os.path.exists(os.path.join(H.ROOT, "oracle", "_ref", "libtersoff_ref.so")),
                     reason="oracle/_ref not built (no /root/reference here)")
 @pytest.mark.parametrize("case", ["Si-ortho", "Si-triclinic", "two-types"])
