@@ -46,7 +46,8 @@ __global__ void __launch_bounds__(BLOCK) nepmi_kernel(const Body body, const int
 
 // Same mapping, for bodies that stage a read-only table (descriptor coefficients) in LDS first.
 template <int BLOCK, class Body>
-__global__ void __launch_bounds__(BLOCK) nepmi_kernel_lds(const Body body, const int64_t n, const int* frozen)
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(Body::kMinWavesPerEu)))
+nepmi_kernel_lds(const Body body, const int64_t n, const int* frozen)
 {
   extern __shared__ __attribute__((aligned(16))) float nepmi_lds[];
   if (frozen && *frozen != 0)
@@ -292,7 +293,8 @@ nepmi_ann_mfma(const ModelD m, const Bufs b, const int64_t nchunks, const int* f
 // Two adjacent lanes per atom (Body::run_parts<2>): for bodies whose per-atom register table is what
 // limits them to one wavefront per SIMD (angular force).
 template <int BLOCK, class Body>
-__global__ void __launch_bounds__(BLOCK) nepmi_kernel_lds_pairs(const Body body, const int64_t n, const int* frozen)
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(Body::kMinWavesPerEuPairs)))
+nepmi_kernel_lds_pairs(const Body body, const int64_t n, const int* frozen)
 {
   extern __shared__ __attribute__((aligned(16))) float nepmi_lds_pairs[];
   if (frozen && *frozen != 0)

@@ -1309,7 +1309,7 @@ struct RadialFromRecordsBody {
 // (find_descriptor, nep.cu:588-610 + accumulate_s).  Shared by the angular descriptor kernel and by
 // the angular force kernel's recompute path, so that both see bit-identical sums.
 template <class S, int PARTS, class LP>
-NEPMI_HD void angular_s_sums(const ModelD& m, const Bufs& b, int64_t k, int t1, LP cang, int part, float* s)
+NEPMI_HD void angular_s_sums_scalar(const ModelD& m, const Bufs& b, int64_t k, int t1, LP cang, int part, float* s)
 {
   // PARTS lanes share the atom: lane `part` owns the radial channels n = part, part + PARTS, ... and
   // keeps them at local rows i = 0, 1, ... of s (PARTS == 1: all channels, row i = n)
@@ -1366,6 +1366,71 @@ NEPMI_HD void angular_s_sums(const ModelD& m, const Bufs& b, int64_t k, int t1, 
   }
 }
 
+// Fixed shapes: the same sums held as 12 register pairs per channel (harmonics_pairs): one v_pk_fma_f32 per pair
+// and channel instead of two v_fma_f32.  Every sum sees the same operations in the same order as in the scalar
+// form, so the two are bit-identical.
+template <class S, int PARTS, class LP>
+NEPMI_HD void angular_s_sums(const ModelD& m, const Bufs& b, int64_t k, int t1, LP cang, int part, float* s)
+{
+  if constexpr (!S::fixed) {
+    angular_s_sums_scalar<S, PARTS>(m, b, k, t1, cang, part, s);
+  } else {
+    constexpr int NLOC = (S::NAM + PARTS) / PARTS;
+    const int64_t N = b.N;
+    const float rc1 = m.rc_a[t1];
+    const int cstride = cang_stride(m);
+    f2 s2[NLOC * kHarmPairs];
+#pragma unroll
+    for (int a = 0; a < NLOC * kHarmPairs; ++a)
+      s2[a] = bc2(0.0f);
+    const int na = b.nn_angstep[k];
+    const F4* __restrict__ acomp = b.acomp + k;
+    F4 e_next;
+    if (na > 0)
+      e_next = acomp[0];
+    for (int a = 0; a < na; ++a) {
+      const F4 e = e_next;
+      if (a + 1 < na)
+        e_next = acomp[(int64_t)(a + 1) * N]; // in flight while this record is processed
+      const int t2 = (int)((unsigned)e.w >> kIdxBits);
+      const float x = e.x, y = e.y, z = e.z;
+      float d, dinv;
+      dist_and_inv(dot3f(x, x, y, y, z, z), d, dinv);
+      const float rc = m.uniform_rc ? m.rc_a_max : (rc1 + m.rc_a[t2]) * 0.5f;
+      const float rcinv = fast_rcp(rc);
+      float fc;
+      cutoff_fc(rcinv, d, fc);
+      float fn[S::KAM + 1];
+      basis_fn<S::KAM>(rcinv, d, fc, fn);
+      f2 bh[kHarmPairs];
+      harmonics_pairs(x * dinv, y * dinv, z * dinv, bh);
+      LP c = cang + (t1 * m.T + t2) * cstride;
+#pragma unroll
+      for (int i = 0; i < NLOC; ++i) {
+        const int n = part + PARTS * i;
+        if (n > S::NA)
+          break;
+        float g = 0.0f;
+#pragma unroll
+        for (int kk = 0; kk <= S::KAM; ++kk)
+          g = fmaf(fn[kk], c[n * (S::KA + 1) + kk], g);
+        const f2 g2 = bc2(g);
+#pragma unroll
+        for (int q = 0; q < kHarmPairs; ++q)
+          s2[i * kHarmPairs + q] = vfma(g2, bh[q], s2[i * kHarmPairs + q]);
+      }
+    }
+    const int hp[kNumHarm] = NEPMI_HARM_PAIR_INIT;
+#pragma unroll
+    for (int i = 0; i < NLOC; ++i)
+#pragma unroll
+      for (int q = 0; q < kHarmPairs; ++q) {
+        s[i * kNumHarm + hp[2 * q]] = s2[i * kHarmPairs + q].x;
+        s[i * kNumHarm + hp[2 * q + 1]] = s2[i * kHarmPairs + q].y;
+      }
+  }
+}
+
 // angular part of find_descriptor (nep.cu:549-640) on the compacted angular pair records:
 // no gathers, no geometry, every lane of the wavefront has real work in every iteration.
 template <class S>
@@ -1374,6 +1439,7 @@ struct AngularDescBody {
   Bufs b;
   int recompute_s; // the force kernel rebuilds s from the records: do not write sbuf
   static constexpr bool kUsesLds = true;
+  static constexpr int kMinWavesPerEu = 1, kMinWavesPerEuPairs = 1;
   NEPMI_HD int lds_floats() const { return cang_floats(m); }
   NEPMI_HD void lds_stage(float* dst, int tid, int nth) const { cang_stage(m, dst, tid, nth); }
 
@@ -1534,6 +1600,13 @@ struct AngularForceBody {
   int recompute_s; // few angular neighbours: rebuilding s (a second walk over <= MN_a records) is
                    // cheaper than the (n_a+1)*24 floats per atom written and read back through HBM
   static constexpr bool kUsesLds = true;
+#ifndef NEPMI_AF_WAVES
+#define NEPMI_AF_WAVES 2
+#endif
+  // one-lane form: the per-atom table G and the P/Q sums sit a few registers above 256; held to two wavefronts per SIMD
+  static constexpr int kMinWavesPerEu = (S::fixed && S::NA + 1 < 7) ? NEPMI_AF_WAVES : 1;
+  // lane-pair form: half the table per lane; two wavefronts per SIMD is what it exists for
+  static constexpr int kMinWavesPerEuPairs = S::fixed ? 2 : 1;
   NEPMI_HD int lds_floats() const { return cang_floats(m); }
   NEPMI_HD void lds_stage(float* dst, int tid, int nth) const { cang_stage(m, dst, tid, nth); }
 
@@ -1582,6 +1655,17 @@ struct AngularForceBody {
       }
       invariants_adjoint<!S::fixed>(m, fpn, 1, &G[i * kNumHarm]);
     }
+    // fixed shapes: the table as register pairs (harmonics_pairs order), P and Q as pairs as well
+    constexpr int NG2 = S::fixed ? NLOC * kHarmPairs : 1;
+    f2 G2[NG2];
+    if constexpr (S::fixed) {
+      const int hp[kNumHarm] = NEPMI_HARM_PAIR_INIT;
+#pragma unroll
+      for (int i = 0; i < NLOC; ++i)
+#pragma unroll
+        for (int q = 0; q < kHarmPairs; ++q)
+          G2[i * kHarmPairs + q] = mk2(G[i * kNumHarm + hp[2 * q]], G[i * kNumHarm + hp[2 * q + 1]]);
+    }
 
     float zf[3] = {0, 0, 0}, zv[6] = {0, 0, 0, 0, 0, 0}, zpe = 0.0f;
     float pzi = 0.0f;
@@ -1614,34 +1698,64 @@ struct AngularForceBody {
         basis_fn_fnp<S::KAM>(rcinv, d, fc, fcp, fn, fnp);
       else
         basis_fn_fnp_rt(KA, rcinv, d, fc, fcp, fn, fnp);
-      float P[kNumHarm], Q[kNumHarm];
-#pragma unroll
-      for (int h = 0; h < kNumHarm; ++h)
-        P[h] = Q[h] = 0.0f;
       LP c = cang + (t1 * m.T + t2) * cstride;
-#pragma unroll
-      for (int i = 0; i < NLOC; ++i) {
-        const int n = part + PARTS * i;
-        if (n > NA)
-          break;
-        float g = 0.0f, gp = 0.0f;
-#pragma unroll
-        for (int kk = 0; kk <= S::KAM; ++kk) {
-          if (!S::fixed && kk > KA)
-            break;
-          const float cc = c[n * (KA + 1) + kk];
-          g = fmaf(fn[kk], cc, g);
-          gp = fmaf(fnp[kk], cc, gp);
-        }
-#pragma unroll
-        for (int h = 0; h < kNumHarm; ++h) {
-          P[h] = fmaf(G[i * kNumHarm + h], g, P[h]);
-          Q[h] = fmaf(G[i * kNumHarm + h], gp, Q[h]);
-        }
-      }
       const float ux = x * dinv, uy = y * dinv, uz = z * dinv;
       float w, vx, vy, vz;
-      harmonics_contract(ux, uy, uz, P, Q, w, vx, vy, vz);
+      if constexpr (S::fixed) {
+        // (g_n, g_n') side by side: one packed fma per basis function and channel; then P += G g, Q += G g' on the
+        // register pairs of G
+        f2 ffp[S::KAM + 1];
+#pragma unroll
+        for (int kk = 0; kk <= S::KAM; ++kk)
+          ffp[kk] = mk2(fn[kk], fnp[kk]);
+        f2 P2[kHarmPairs], Q2[kHarmPairs];
+#pragma unroll
+        for (int q = 0; q < kHarmPairs; ++q)
+          P2[q] = Q2[q] = bc2(0.0f);
+#pragma unroll
+        for (int i = 0; i < NLOC; ++i) {
+          const int n = part + PARTS * i;
+          if (n > S::NA)
+            break;
+          f2 ggp = bc2(0.0f);
+#pragma unroll
+          for (int kk = 0; kk <= S::KAM; ++kk)
+            ggp = vfma(ffp[kk], bc2(c[n * (S::KA + 1) + kk]), ggp);
+          const f2 g2 = bc2(ggp.x), gp2 = bc2(ggp.y);
+#pragma unroll
+          for (int q = 0; q < kHarmPairs; ++q) {
+            P2[q] = vfma(G2[i * kHarmPairs + q], g2, P2[q]);
+            Q2[q] = vfma(G2[i * kHarmPairs + q], gp2, Q2[q]);
+          }
+        }
+        harmonics_contract_pairs(ux, uy, uz, P2, Q2, w, vx, vy, vz);
+      } else {
+        float P[kNumHarm], Q[kNumHarm];
+#pragma unroll
+        for (int h = 0; h < kNumHarm; ++h)
+          P[h] = Q[h] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NLOC; ++i) {
+          const int n = part + PARTS * i;
+          if (n > NA)
+            break;
+          float g = 0.0f, gp = 0.0f;
+#pragma unroll
+          for (int kk = 0; kk <= S::KAM; ++kk) {
+            if (!S::fixed && kk > KA)
+              break;
+            const float cc = c[n * (KA + 1) + kk];
+            g = fmaf(fn[kk], cc, g);
+            gp = fmaf(fnp[kk], cc, gp);
+          }
+#pragma unroll
+          for (int h = 0; h < kNumHarm; ++h) {
+            P[h] = fmaf(G[i * kNumHarm + h], g, P[h]);
+            Q[h] = fmaf(G[i * kNumHarm + h], gp, Q[h]);
+          }
+        }
+        harmonics_contract(ux, uy, uz, P, Q, w, vx, vy, vz);
+      }
       if (PARTS > 1) {
         w += NEPMI_PAIR_XCHG(w);
         vx += NEPMI_PAIR_XCHG(vx);

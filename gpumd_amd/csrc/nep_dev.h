@@ -553,6 +553,84 @@ NEPMI_HD void harmonics(float x, float y, float z, float* b)
   b[23] = y4;
 }
 
+// ---- the same 24 harmonics as 12 register pairs (packed-FP32 angular kernels) --------------------------------
+// Pair q holds harmonics kHarmPair[2q], kHarmPair[2q+1]: the m = 0 polynomials two by two (L = 1,2 and L = 3,4),
+// then the ten (Re, Im) pairs z-polynomial * (x+iy)^m.  A v_pk_fma_f32 then updates two sums at once, and the
+// gradient contraction factors through the complex powers C_m = (x+iy)^m and their rotations i C_m.
+constexpr int kHarmPairs = 12;
+#define NEPMI_HARM_PAIR_INIT {0, 3, 8, 15, 1, 2, 4, 5, 6, 7, 9, 10, 11, 12, 13, 14, 16, 17, 18, 19, 20, 21, 22, 23}
+
+NEPMI_HD void harmonics_pairs(float x, float y, float z, f2* B)
+{
+  const float z2 = z * z;
+  const float x2y2 = x * x - y * y, xy2 = 2.0f * x * y;
+  const float x3 = x * x2y2 - y * xy2, y3 = x * xy2 + y * x2y2;
+  const float x4 = x * x3 - y * y3, y4 = x * y3 + y * x3;
+  const float p31 = 5.0f * z2 - 1.0f;
+  const float p41 = (7.0f * z2 - 3.0f) * z, p42 = 7.0f * z2 - 1.0f;
+  const f2 C1 = mk2(x, y), C2 = mk2(x2y2, xy2), C3 = mk2(x3, y3);
+  B[0] = mk2(z, 3.0f * z2 - 1.0f);
+  B[1] = mk2((5.0f * z2 - 3.0f) * z, (35.0f * z2 - 30.0f) * z2 + 3.0f);
+  B[2] = C1;
+  B[3] = C1 * z;
+  B[4] = C2;
+  B[5] = C1 * p31;
+  B[6] = C2 * z;
+  B[7] = C3;
+  B[8] = C1 * p41;
+  B[9] = C2 * p42;
+  B[10] = C3 * z;
+  B[11] = mk2(x4, y4);
+}
+
+// harmonics_contract on the paired sums: w = sum Q b, v = sum P grad b.  With U_m = the P pairs that multiply
+// m C_{m-1} in d/dx (and m i C_{m-1} in d/dy), the (x, y) gradient is three packed products per direction.
+NEPMI_HD void harmonics_contract_pairs(
+  float x, float y, float z, const f2* P, const f2* Q, float& w, float& vx, float& vy, float& vz)
+{
+  const float z2 = z * z;
+  const float x2y2 = x * x - y * y, xy2 = 2.0f * x * y;
+  const float x3 = x * x2y2 - y * xy2, y3 = x * xy2 + y * x2y2;
+  const float x4 = x * x3 - y * y3, y4 = x * y3 + y * x3;
+  const float p31 = 5.0f * z2 - 1.0f;
+  const float p41 = (7.0f * z2 - 3.0f) * z, p42 = 7.0f * z2 - 1.0f;
+  const f2 C1 = mk2(x, y), C2 = mk2(x2y2, xy2), C3 = mk2(x3, y3);
+  // values
+  f2 ws = Q[0] * mk2(z, 3.0f * z2 - 1.0f);
+  ws = vfma(Q[1], mk2((5.0f * z2 - 3.0f) * z, (35.0f * z2 - 30.0f) * z2 + 3.0f), ws);
+  ws = vfma(Q[2], C1, ws);
+  ws = vfma(Q[3] * z, C1, ws);
+  ws = vfma(Q[4], C2, ws);
+  ws = vfma(Q[5] * p31, C1, ws);
+  ws = vfma(Q[6] * z, C2, ws);
+  ws = vfma(Q[7], C3, ws);
+  ws = vfma(Q[8] * p41, C1, ws);
+  ws = vfma(Q[9] * p42, C2, ws);
+  ws = vfma(Q[10] * z, C3, ws);
+  ws = vfma(Q[11], mk2(x4, y4), ws);
+  w = ws.x + ws.y;
+  // d/dz
+  f2 zs = P[0] * mk2(1.0f, 6.0f * z);
+  zs = vfma(P[1], mk2(15.0f * z2 - 3.0f, (140.0f * z2 - 60.0f) * z), zs);
+  const f2 Z1 = vfma(P[8], bc2(21.0f * z2 - 3.0f), vfma(P[5], bc2(10.0f * z), P[3]));
+  const f2 Z2 = vfma(P[9], bc2(14.0f * z), P[6]);
+  zs = vfma(Z1, C1, zs);
+  zs = vfma(Z2, C2, zs);
+  zs = vfma(P[10], C3, zs);
+  vz = zs.x + zs.y;
+  // d/dx, d/dy of the m = 1 pairs: (d/dx Re, d/dy Im) = the z-polynomial itself
+  const f2 v1 = vfma(P[8], bc2(p41), vfma(P[5], bc2(p31), vfma(P[3], bc2(z), P[2])));
+  // m >= 2: d/dx (Re, Im)_m = m (Re, Im)_{m-1}, d/dy (Re, Im)_m = m (-Im, Re)_{m-1}
+  const f2 U1 = vfma(P[9], bc2(p42), vfma(P[6], bc2(z), P[4])) * 2.0f;
+  const f2 U2 = vfma(P[10], bc2(z), P[7]) * 3.0f;
+  const f2 U3 = P[11] * 4.0f;
+  const f2 R1 = mk2(-y, x), R2 = mk2(-xy2, x2y2), R3 = mk2(-y3, x3);
+  const f2 xs = vfma(U3, C3, vfma(U2, C2, U1 * C1));
+  const f2 ys = vfma(U3, R3, vfma(U2, R2, U1 * R1));
+  vx = v1.x + (xs.x + xs.y);
+  vy = v1.y + (ys.x + ys.y);
+}
+
 // w = sum_abc Q[abc] b_abc ,  v = sum_abc P[abc] grad_u b_abc   (grad over unconstrained x,y,z)
 NEPMI_HD void harmonics_contract(
   float x, float y, float z, const float* P, const float* Q, float& w, float& vx, float& vy, float& vz)
