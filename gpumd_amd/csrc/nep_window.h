@@ -162,6 +162,12 @@ constexpr int kWinG = 4; // candidates whose LDS look-ups and arithmetic are int
 #ifndef NEPMI_FW_WAVES
 #define NEPMI_FW_WAVES 4
 #endif
+#ifndef NEPMI_RW_WAVES
+#define NEPMI_RW_WAVES 1
+#endif
+#ifndef NEPMI_RW_PIPE
+#define NEPMI_RW_PIPE 0 // 1: the window records of the next chunk are read while this chunk is processed (measured: no gain)
+#endif
 
 template <class S>
 struct RadialWinBody {
@@ -169,7 +175,7 @@ struct RadialWinBody {
   ModelD m;
   int first;          // workgroup w runs brick_order[first + w] (first < 0: brick w)
   const int* frozen;  // fused run loops: a non-zero value means "a list rebuild is pending": do nothing
-  static constexpr int kMinWavesPerEu = 1;
+  static constexpr int kMinWavesPerEu = NEPMI_RW_WAVES;
 
   NEPMI_HD int lds_bytes() const { return st.lay.bytes(); }
   NEPMI_HD int64_t map_brick(int64_t w) const { return first < 0 ? w : (int64_t)st.b.brick_order[first + w]; }
@@ -226,11 +232,9 @@ struct RadialWinBody {
       int t2;
       bool inside;
     };
-    auto decide = [&](const unsigned code, const int idx, const bool live, auto in_list_a) -> Cand {
+    auto decide = [&](const int slot, const WinRec r, const int idx, const bool live, auto in_list_a) -> Cand {
       constexpr bool LIST_A = decltype(in_list_a)::value;
       Cand c;
-      const int slot = woff[code >> 7] + (int)(code & 127u);
-      const WinRec r = wrec[slot];
       c.fx = (float)(r.x - ox);
       c.fy = (float)(r.y - oy);
       c.fz = (float)(r.z - oz);
@@ -368,22 +372,40 @@ struct RadialWinBody {
       }
     };
 
-    // walk a list in chunks of kWinG: the codes of the next chunk are requested before this chunk's stores
+    // walk a list in chunks of kWinG: the codes of chunk c + 2 are on their way from the list while chunk c is
+    // decided and accumulated; the window records of a chunk (slot offset, then the record: two dependent LDS reads)
+    // are issued together, ahead of the branchy bookkeeping -- one LDS latency per chunk instead of two per candidate.
+    // NEPMI_RW_PIPE = 1 additionally reads chunk c + 1's records before chunk c is processed (16 more registers).
     auto walk = [&](const unsigned short* __restrict__ codes, const int nn, auto in_list_a) {
-      unsigned cur[kWinG], nxt[kWinG];
-#pragma unroll
-      for (int u = 0; u < kWinG; ++u)
-        cur[u] = nn > 0 ? codes[(int64_t)(u < nn ? u : nn - 1) * N] : 0u;
-      for (int s0 = 0; s0 < nn; s0 += kWinG) {
+      auto load_codes = [&](int s0, unsigned* cc) {
 #pragma unroll
         for (int u = 0; u < kWinG; ++u) {
-          const int idx = s0 + kWinG + u;
-          nxt[u] = codes[(int64_t)(idx < nn ? idx : nn - 1) * N];
+          const int idx = s0 + u;
+          cc[u] = nn > 0 ? codes[(int64_t)(idx < nn ? idx : nn - 1) * N] : 0u;
         }
+      };
+      auto load_recs = [&](const unsigned* cc, int* sl, WinRec* rr) {
+#pragma unroll
+        for (int u = 0; u < kWinG; ++u)
+          sl[u] = woff[cc[u] >> 7] + (int)(cc[u] & 127u);
+#pragma unroll
+        for (int u = 0; u < kWinG; ++u)
+          rr[u] = wrec[sl[u]];
+      };
+      unsigned c1[kWinG], c2[kWinG];
+      int sl0[kWinG], sl1[kWinG];
+      WinRec r0[kWinG], r1[kWinG];
+      load_codes(0, c1);
+      load_recs(c1, sl0, r0);
+      load_codes(kWinG, c1);
+      for (int s0 = 0; s0 < nn; s0 += kWinG) {
+        load_codes(s0 + 2 * kWinG, c2);
+        if (NEPMI_RW_PIPE)
+          load_recs(c1, sl1, r1);
         Cand c[kWinG];
 #pragma unroll
         for (int u = 0; u < kWinG; ++u)
-          c[u] = decide(cur[u], s0 + u, s0 + u < nn, in_list_a);
+          c[u] = decide(sl0[u], r0[u], s0 + u, s0 + u < nn, in_list_a);
         if (S::TS > 0 && NEPMI_RW_PACK) {
 #pragma unroll
           for (int u = 0; u < kWinG; u += 2)
@@ -393,9 +415,14 @@ struct RadialWinBody {
           for (int u = 0; u < kWinG; ++u)
             accumulate1(c[u]);
         }
+        if (!NEPMI_RW_PIPE)
+          load_recs(c1, sl1, r1);
 #pragma unroll
-        for (int u = 0; u < kWinG; ++u)
-          cur[u] = nxt[u];
+        for (int u = 0; u < kWinG; ++u) {
+          sl0[u] = sl1[u];
+          r0[u] = r1[u];
+          c1[u] = c2[u];
+        }
       }
     };
     walk(b.code_ang + k, na, std::true_type{});
