@@ -1771,21 +1771,34 @@ struct AngularForceBody {
       if (part == 0)
         f12[(int64_t)a * N] = out;
 
-      // ZBL is per pair and independent of the channel split: the lanes take alternate neighbours
-      if (m.zbl_enabled && (PARTS == 1 || (a % PARTS) == part)) {
+      // ZBL is per pair and independent of the channel split: the lanes take alternate neighbours.  A pair beyond
+      // the outer cutoff contributes exact zeros (fc = 0): it is skipped, and with it four exponentials, a sine, a
+      // cosine and a power -- for the alloy models that is nearly every angular pair.
+      float zbl_r2 = 0.0f;
+      const float* zbl_p10 = nullptr;
+      if (m.zbl_enabled) {
+        if (m.zbl_flexible) {
+          const int ta = t1 < t2 ? t1 : t2, tb = t1 < t2 ? t2 : t1;
+          const int zidx = ta * m.T - (ta * (ta - 1)) / 2 + (tb - ta);
+          zbl_p10 = m.zbl_para + 10 * zidx;
+          zbl_r2 = zbl_p10[1];
+        } else if (m.zbl_rco) { // type-wise outer cutoff, inner cutoff 0 (nep.cu:935-941)
+          zbl_r2 = m.zbl_rco[t1 * m.T + t2];
+        } else {
+          zbl_r2 = m.zbl_rc_outer;
+        }
+      }
+      if (m.zbl_enabled && d < zbl_r2 && (PARTS == 1 || (a % PARTS) == part)) {
         const int zj = m.atomic_number[t2];
         const float a_inv = (pzi + powf((float)zj, 0.23f)) * 2.134563f;
         const float zizj = 14.399645f * (float)zi * (float)zj;
         float f, fp;
-        if (m.zbl_flexible) {
-          const int ta = t1 < t2 ? t1 : t2, tb = t1 < t2 ? t2 : t1;
-          const int zidx = ta * m.T - (ta * (ta - 1)) / 2 + (tb - ta);
-          zbl_pair(m.zbl_para + 10 * zidx, zizj, a_inv, 0.0f, 0.0f, d, dinv, f, fp);
-        } else if (m.zbl_rco) { // type-wise outer cutoff, inner cutoff 0 (nep.cu:935-941)
-          zbl_pair(nullptr, zizj, a_inv, 0.0f, m.zbl_rco[t1 * m.T + t2], d, dinv, f, fp);
-        } else {
+        if (m.zbl_flexible)
+          zbl_pair(zbl_p10, zizj, a_inv, 0.0f, 0.0f, d, dinv, f, fp);
+        else if (m.zbl_rco)
+          zbl_pair(nullptr, zizj, a_inv, 0.0f, zbl_r2, d, dinv, f, fp);
+        else
           zbl_pair(nullptr, zizj, a_inv, m.zbl_rc_inner, m.zbl_rc_outer, d, dinv, f, fp);
-        }
         const float f2 = fp * dinv * 0.5f;
         const float fx = x * f2, fy = y * f2, fz = z * f2; // f12; f21 = -f12
         zf[0] += fx + fx;
