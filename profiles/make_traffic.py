@@ -9,7 +9,8 @@ import csv
 import json
 import sys
 
-NAMES = [("CheckGatherBody", "gather_skin_check"), ("RadialTileBody", "radial_descriptor"),
+NAMES = [("CheckGatherBody", "gather_skin_check"), ("RadialWinBody", "radial_descriptor"), ("ForceWinBody", "force_assemble"),
+         ("ResidentStepBody", "velocity_verlet"), ("RadialTileBody", "radial_descriptor"),
          ("RadialDescBody", "radial_descriptor"), ("AngularDescBody", "angular_descriptor"),
          ("nepmi_ann_mfma", "ann"), ("AnnBody", "ann"), ("AngularForceBody", "angular_partial_force"),
          ("ForceTileBody", "force_assemble"), ("ForceAssembleBody", "force_assemble"), ("VerletSeamBody", "velocity_verlet"),
@@ -41,7 +42,7 @@ def main():
     for name in fetch:
         w = write.get(name, 0.0)
         kern[name] = {"fetch_kb": fetch[name], "write_kb": w, "hbm_bytes_per_launch": (2.0 * fetch[name] + w) * 1024.0}
-    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `bench.py --steps 5 --warmup 2`; "
+    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `bench.py --steps 6 --warmup 2`; "
                          "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch (gfx950 FETCH_SIZE correction, "
                          "MI355X_MICROARCH.md)", "atoms": int(sys.argv[3]), "kernels": kern},
               open(sys.argv[4], "w"), indent=1)
