@@ -739,12 +739,18 @@ struct ReverseSlotsBody {
     for (int s = 0; s < nn; ++s) {
       const int j = b.nl_ang[(int64_t)s * N + k];
       const int nj = b.nn_ang[j];
+      // Both lists follow the same sweep over the cells, so k sits in j's list about where the mirror image of
+      // slot s falls; the search starts there and widens (each probe of the [slot][atom] array is a cache line of
+      // its own: a scan from slot 0 cost ~30 of them per pair)
       int r = kNoSlot;
-      for (int s2 = 0; s2 < nj; ++s2)
-        if (b.nl_ang[(int64_t)s2 * N + j] == (int)k) {
-          r = s2;
-          break;
-        }
+      const int g = nn > 1 ? (nj - 1) - (s * (nj - 1)) / (nn - 1) : 0;
+      for (int w = 0; w < nj && r == kNoSlot; ++w) {
+        const int lo = g - w, hi = g + w;
+        if (lo >= 0 && lo < nj && b.nl_ang[(int64_t)lo * N + j] == (int)k)
+          r = lo;
+        else if (w > 0 && hi < nj && hi >= 0 && b.nl_ang[(int64_t)hi * N + j] == (int)k)
+          r = hi;
+      }
       if (r == kNoSlot)
         NEPMI_ATOMIC_OR(&b.flags[kFlagOverflow], 2);
       b.rev_ang[(int64_t)s * N + k] = (unsigned short)r;
