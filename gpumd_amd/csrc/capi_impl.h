@@ -420,7 +420,7 @@ int nepmi_engine_set_mfma(nepmi_engine* e, int on)
 {
   if (!e)
     return fail(NEPMI_ERR_ARG, "null engine");
-  e->e->set_use_mfma(on != 0);
+  e->e->set_use_mfma(on);
   return NEPMI_OK;
 }
 

@@ -93,6 +93,7 @@ public:
   // 64: 0.160, 128: 0.162, 256: 0.150, 512: 0.137 ms (1024 would halve the register budget: 1.0 ms); the angular force
   // kernel does not care (64)
   static constexpr int kAngDescBlock = 512;
+  static constexpr int kAngFusedBlock = 256; // descriptor + ANN: ~150 registers per lane
 
   EngineT(const NepModel& model, int64_t n_atoms, B backend) : model_(model), be_(backend), cap_(n_atoms), N_(n_atoms)
   {
@@ -688,6 +689,18 @@ public:
       throw EngineError{-4, "no force evaluation has been performed yet"};
     if (model_.kind != 0)
       throw EngineError{-4, "descriptors exist for NEP models only"};
+    if (q && !last_small_ && fuse_ann_active()) {
+      // the fused descriptor + ANN kernel keeps the angular descriptor in registers: write it out now (the compact
+      // angular records of the last evaluation are still in place)
+      switch (shape_) {
+        case 1: launch_angular_desc<S_PbTeA>(); break;
+        case 2: launch_angular_desc<S_PbTeB>(); break;
+        case 3: launch_angular_desc<S_C2022>(); break;
+        case 4: launch_angular_desc<S_UNEP>(); break;
+        case 5: launch_angular_desc<S_BZO>(); break;
+        default: break;
+      }
+    }
     ExportDescBody body{b_, model_.dim, q, fp};
     be_.template launch<64>(kSlotMisc, N_, body);
   }
@@ -1086,7 +1099,9 @@ private:
     be_.template launch<256>(kSlotMisc, N_, FillCellsBody{b_});
     be_.template launch<256>(kSlotMisc, ncell, SortCellsBody{b_});
     be_.template launch<256>(kSlotMisc, N_, GatherSortedBody{box_, b_, pos, type});
-    {
+    if (fuse_ann_active()) {
+      be_.template launch<256>(kSlotMisc, N_, IdentityOrderBody{b_}); // no type groups: the ANN runs per atom, in place
+    } else {
       const int64_t nkeys = ((N_ >> kTypeChunkShift) + 1) * model_.num_types;
       be_.memset(b_.tcount, 0, sizeof(int) * (nkeys + 1));
       be_.template launch<64>(kSlotMisc, nkeys, TypeCountBody{b_, model_.num_types});
@@ -1124,13 +1139,30 @@ private:
   // kernel at one wavefront per SIMD; two lanes per atom (channels split between them) bring it to two.
   // With fewer channels the one-lane form already runs two wavefronts and the split only adds work.
   template <class S>
-  void launch_angular_desc()
+  void launch_angular_desc(bool fuse = false)
   {
     // the descriptor kernel carries only the sums (no P/Q): it drops to one wavefront per SIMD from 9 channels on
     if (S::fixed && S::NA + 1 >= 9)
-      be_.template launch_lds_pairs<kAngDescBlock>(kSlotAngular, N_, AngularDescBody<S>{md_, b_, recompute_s()});
+      be_.template launch_lds_pairs<kAngDescBlock>(kSlotAngular, N_, AngularDescBody<S>{md_, b_, recompute_s(), 0});
+    else if (fuse && S::fixed)
+      be_.template launch_lds<kAngFusedBlock>(kSlotAngular, N_, AngularDescBody<S>{md_, b_, recompute_s(), 1});
     else
-      be_.template launch_lds<kAngDescBlock>(kSlotAngular, N_, AngularDescBody<S>{md_, b_, recompute_s()});
+      be_.template launch_lds<kAngDescBlock>(kSlotAngular, N_, AngularDescBody<S>{md_, b_, recompute_s(), 0});
+  }
+
+  // Descriptor + ANN in one kernel (AngularDescBody::fuse_ann): the one-lane descriptor form, few types (the
+  // weight image of all types sits in LDS), default ANN mode.  Decided per engine, so that the lists' work order
+  // (identity instead of type groups) can follow it.
+  bool fuse_ann_active() const
+  {
+    if (model_.kind != 0 || shape_ == 0 || ann_mode_ != 1 || model_.n_max_angular + 1 >= 9 || model_.num_types > 4)
+      return false;
+    const int dp = (model_.dim + 3) / 4 * 4;
+    const size_t floats = (size_t)model_.num_types * (model_.num_neurons * dp + 40 + 2 * model_.num_neurons) +
+                          (size_t)model_.num_types * model_.num_types *
+                            ((model_.n_max_radial + 1) * (model_.basis_size_radial + 1) +
+                             (model_.n_max_angular + 1) * (model_.basis_size_angular + 1) + 1);
+    return floats * sizeof(float) <= 60 * 1024;
   }
 
   template <class S>
@@ -1186,7 +1218,14 @@ public:
   }
   int tile_mode_in_use() const { return tile_ok_ ? 2 : 0; }
   bool tiles_active() const { return tile_ok_; }
-  void set_use_mfma(bool on) { be_.set_mfma(on); }
+  // 0: per-atom ANN kernel; 1 (default): descriptor + ANN fused where the shape allows it, else the matrix-core
+  // kernel; 2: the matrix-core kernel wherever it applies (no fusion)
+  void set_use_mfma(int mode)
+  {
+    ann_mode_ = mode < 0 ? 1 : (mode > 2 ? 2 : mode);
+    be_.set_mfma(ann_mode_ != 0);
+    have_list_ = false; // the work order of q / fp follows the mode
+  }
   // The caller runs the skin policy itself (a domain-decomposed host votes on it globally and calls
   // invalidate()): no per-step flag read-back, the force path is enqueued without a host round trip.
   // List-capacity overflow is then reported at the next rebuild or stats() call.
@@ -1237,8 +1276,12 @@ private:
       be_.launch_win(kSlotRadial, num_bricks_, RadialWinBody<S>{ws, md_, -1, frozen});
     else
       be_.template launch<64>(kSlotRadial, N_, RadialDescBody<S>{box_, md_, b_, 1});
-    launch_angular_desc<S>();
-    be_.template launch_ann<S>(kSlotAnn, N_, md_, b_, true);
+    if (fuse_ann_active()) {
+      launch_angular_desc<S>(true);
+    } else {
+      launch_angular_desc<S>();
+      be_.template launch_ann<S>(kSlotAnn, N_, md_, b_, true);
+    }
     launch_angular_force<S>();
     if (tile_ok_)
       be_.launch_win(kSlotForce, num_bricks_, ForceWinBody<S>{ws, md_, frozen});
@@ -1291,6 +1334,7 @@ private:
   int tile_mode_ = -1;           // -1 auto, 0 none, 1 radial window only, 2 radial + force windows
   bool records_valid_ = false; // rstash holds the pair records of the last evaluated positions
   int recompute_mode_ = -1;
+  int ann_mode_ = 1;
   bool external_skin_ = false;
   static constexpr int kBrickFill = 253; // of the 256 atom slots of a window-kernel pass (atoms drift between rebuilds;
                                          // a brick that does overflow just takes a second pass)

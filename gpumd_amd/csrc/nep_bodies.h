@@ -695,6 +695,14 @@ inline AnnMfmaShape ann_mfma_shape(int T, int dim, int nneu, int KRP)
   a.ok = T <= 4 && a.MT <= 4 && a.DT <= 4 && a.KS <= 40 && a.img_floats * sizeof(float) <= 144 * 1024;
   return a;
 }
+struct IdentityOrderBody { // q / fp columns in internal atom order (fused descriptor + ANN kernel)
+  Bufs b;
+  NEPMI_HD void operator()(int64_t k) const
+  {
+    b.tperm[k] = (int)k;
+    b.tpos[k] = (int)k;
+  }
+};
 struct TypeCountBody { // one work-item per (chunk, type): no atomics, deterministic
   Bufs b;
   int T;
@@ -1439,15 +1447,64 @@ NEPMI_HD void angular_s_sums(const ModelD& m, const Bufs& b, int64_t k, int t1, 
 
 // angular part of find_descriptor (nep.cu:549-640) on the compacted angular pair records:
 // no gathers, no geometry, every lane of the wavefront has real work in every iteration.
+// LDS image of the per-atom ANN for the fused descriptor + ANN kernel (AngularDescBody::fuse_ann), behind c_ang:
+//   W[t][neuron][DP] (DP = dim rounded up to 4, zero padded) | b0[t][neuron] | w1[t][neuron] | c_rad[t1 t2][n][k]
+// The type stride of W is padded to 8 mod 32 words, so that lanes of two types read different banks.
+struct AnnLdsLayout {
+  int DP, wstride, off_w, off_b0, off_w1, off_c, total;
+};
+NEPMI_HD AnnLdsLayout ann_lds_layout(const ModelD& m)
+{
+  AnnLdsLayout a;
+  a.DP = (m.dim + 3) / 4 * 4;
+  a.wstride = m.nneu * a.DP;
+  a.wstride += (8 - (a.wstride & 31) + 32) & 31;
+  a.off_w = (cang_floats(m) + 3) / 4 * 4;
+  a.off_b0 = a.off_w + m.T * a.wstride;
+  a.off_w1 = a.off_b0 + m.T * m.nneu;
+  a.off_c = a.off_w1 + m.T * m.nneu;
+  a.total = a.off_c + m.T * m.T * (m.NR + 1) * (m.KR + 1);
+  return a;
+}
+NEPMI_HD float ann_tanh(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  // 1 - 2 / (exp(2x) + 1), branch-free (v_exp_f32 + v_rcp_f32), as in the matrix-core kernel
+  const float e = __expf(2.0f * x);
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+#else
+  return tanhf(x);
+#endif
+}
+
 template <class S>
 struct AngularDescBody {
   ModelD m;
   Bufs b;
   int recompute_s; // the force kernel rebuilds s from the records: do not write sbuf
+  int fuse_ann;    // one-lane form only: run the per-atom ANN right here (q never leaves the registers): writes
+                   // pe_i, fp and the radial force table instead of q
   static constexpr bool kUsesLds = true;
   static constexpr int kMinWavesPerEu = 1, kMinWavesPerEuPairs = 1;
-  NEPMI_HD int lds_floats() const { return cang_floats(m); }
-  NEPMI_HD void lds_stage(float* dst, int tid, int nth) const { cang_stage(m, dst, tid, nth); }
+  NEPMI_HD int lds_floats() const { return fuse_ann ? ann_lds_layout(m).total : cang_floats(m); }
+  NEPMI_HD void lds_stage(float* dst, int tid, int nth) const
+  {
+    cang_stage(m, dst, tid, nth);
+    if (!fuse_ann)
+      return;
+    const AnnLdsLayout a = ann_lds_layout(m);
+    for (int idx = tid; idx < m.T * m.nneu * a.DP; idx += nth) {
+      const int t = idx / (m.nneu * a.DP), r = idx - t * (m.nneu * a.DP);
+      const int j = r / a.DP, d = r - j * a.DP;
+      dst[a.off_w + t * a.wstride + j * a.DP + d] = d < m.dim ? m.w0[((size_t)t * m.nneu + j) * m.dim + d] : 0.0f;
+    }
+    for (int idx = tid; idx < m.T * m.nneu; idx += nth) {
+      dst[a.off_b0 + idx] = m.b0[idx];
+      dst[a.off_w1 + idx] = m.w1[idx];
+    }
+    for (int idx = tid; idx < m.T * m.T * (m.NR + 1) * (m.KR + 1); idx += nth)
+      dst[a.off_c + idx] = m.c_rad[idx];
+  }
 
   template <class LP>
   NEPMI_HD void run(int64_t k, LP cang) const
@@ -1468,6 +1525,8 @@ struct AngularDescBody {
     const int NR = S::fixed ? S::NR : m.NR;
     const int NA = S::fixed ? S::NA : m.NA;
     const int t1 = b.posq[k].type;
+    constexpr int kQ = (S::fixed && PARTS == 1) ? (S::DIMM + 3) / 4 * 4 : 1;
+    float qfull[kQ]; // fuse_ann: the scaled descriptor of this atom
     float s[NLOC * kNumHarm];
     angular_s_sums<S, PARTS>(m, b, k, t1, cang, part, s);
 
@@ -1490,8 +1549,79 @@ struct AngularDescBody {
       for (int L = 0; L < S::kRows; ++L) { // constant trip count: qn stays in registers
         if (L < m.numL) {
           const int d = (NR + 1) + L * (NA + 1) + n;
-          b.q[(int64_t)d * N + gk] = qn[L] * m.qscale[d];
+          if (S::fixed && PARTS == 1 && fuse_ann)
+            qfull[(S::fixed ? d : 0)] = qn[L] * m.qscale[d];
+          else
+            b.q[(int64_t)d * N + gk] = qn[L] * m.qscale[d];
         }
+      }
+    }
+    if constexpr (S::fixed && PARTS == 1) {
+      if (fuse_ann)
+        ann_tail(k, gk, t1, cang, qfull);
+    }
+  }
+
+  // apply_ann_one_layer (nep_utilities.cuh:169-194) + the radial force table, for the atom of this lane, with the
+  // weights of its type read from LDS (two types in a wavefront read different banks).  Per neuron: one pass over
+  // its 16-byte weight groups feeds both the forward dot product and the backward axpy (packed FP32).
+  template <class LP>
+  NEPMI_HD void ann_tail(int64_t k, int64_t gk, int t1, LP lds, float* q) const
+  {
+    constexpr int DP = (S::DIMM + 3) / 4 * 4;
+    const int64_t N = b.N;
+    const AnnLdsLayout a = ann_lds_layout(m);
+    const int NR = S::NR, KR = S::KR;
+#pragma unroll
+    for (int n = 0; n <= S::NR; ++n)
+      q[n] = b.q[(int64_t)n * N + gk]; // radial part, written (scaled) by the radial pass
+#pragma unroll
+    for (int d = S::DIMM; d < DP; ++d)
+      q[d] = 0.0f;
+    f2 g2[DP / 2];
+#pragma unroll
+    for (int i = 0; i < DP / 2; ++i)
+      g2[i] = bc2(0.0f);
+    float e = 0.0f;
+    LP W = lds + a.off_w + t1 * a.wstride;
+    LP B0 = lds + a.off_b0 + t1 * m.nneu;
+    LP W1 = lds + a.off_w1 + t1 * m.nneu;
+    for (int j = 0; j < m.nneu; ++j) {
+      LP w = W + j * DP;
+      f2 w2[DP / 2];
+#pragma unroll
+      for (int i = 0; i < DP / 2; ++i)
+        w2[i] = mk2(w[2 * i], w[2 * i + 1]);
+      f2 acc = bc2(0.0f);
+#pragma unroll
+      for (int i = 0; i < DP / 2; ++i)
+        acc = vfma(w2[i], mk2(q[2 * i], q[2 * i + 1]), acc);
+      const float h = ann_tanh(acc.x + acc.y - B0[j]);
+      const float wj = W1[j];
+      e = fmaf(wj, h, e);
+      const f2 coef = bc2(wj * (1.0f - h * h));
+#pragma unroll
+      for (int i = 0; i < DP / 2; ++i)
+        g2[i] = vfma(coef, w2[i], g2[i]);
+    }
+    b.pe_i[k] = e - (m.b1 + m.b1t[t1]);
+    float Fp[S::DIMM];
+#pragma unroll
+    for (int d = 0; d < S::DIMM; ++d) {
+      Fp[d] = ((d & 1) ? g2[d >> 1].y : g2[d >> 1].x) * m.qscale[d];
+      b.fp[(int64_t)d * N + gk] = Fp[d];
+    }
+    // radial force table A[t2][k] = sum_n Fp[n] c[t1][t2][n][k] (AnnBody)
+    const int KRP = b.KRP;
+    for (int t2 = 0; t2 < m.T; ++t2) {
+      LP c = lds + a.off_c + (t1 * m.T + t2) * (NR + 1) * (KR + 1);
+#pragma unroll
+      for (int kk = 0; kk <= S::KR; ++kk) {
+        float v = 0.0f;
+#pragma unroll
+        for (int n = 0; n <= S::NR; ++n)
+          v = fmaf(Fp[n], c[n * (KR + 1) + kk], v);
+        b.atab[(size_t)k * (m.T * KRP) + t2 * KRP + kk] = v;
       }
     }
   }

@@ -266,7 +266,9 @@ class NEP:
         self._ck(self.lib.nepmi_engine_set_tiles(self.handle, mode))
 
     def set_mfma(self, on=True):
-        self._ck(self.lib.nepmi_engine_set_mfma(self.handle, 1 if on else 0))
+        """False / 0: per-atom ANN kernel; True / 1 (default): descriptor + ANN fused where the shape allows it, else the
+        matrix-core ANN kernel; 2: the matrix-core kernel wherever it applies (no fusion)"""
+        self._ck(self.lib.nepmi_engine_set_mfma(self.handle, int(on)))
 
     def set_angular_recompute(self, mode=-1):
         self._ck(self.lib.nepmi_engine_set_angular_recompute(self.handle, int(mode)))

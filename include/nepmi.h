@@ -346,10 +346,12 @@ int nepmi_engine_set_generic(nepmi_engine* e, int on);
  * fit LDS or an atom sits far outside the box along an open direction.  Both give identical lists and forces to
  * f32 rounding. */
 int nepmi_engine_set_tiles(nepmi_engine* e, int on);
-/* Allow (default) or forbid the matrix-core (v_mfma_f32_32x32x2_f32) ANN kernel; forbidding selects
- * the per-atom ANN kernel, which is also taken automatically for models with more than 4 types,
- * more than 128 neurons or more than 128 descriptor + radial-table rows.  The two differ by f32
- * summation order only. */
+/* How the per-atom ANN runs.  on = 1 (default): inside the angular-descriptor kernel where the shape allows it (one
+ * lane per atom, at most 4 types: the descriptor never leaves the registers), else the matrix-core
+ * (v_mfma_f32_32x32x2_f32) ANN kernel; on = 2: the matrix-core kernel wherever it applies; on = 0: the per-atom ANN
+ * kernel, which is also taken automatically for models with more than 4 types, more than 128 neurons or more than
+ * 128 descriptor + radial-table rows.  The three differ by f32 summation order only.  Forces a list rebuild (the
+ * work order of the descriptor columns follows the mode). */
 int nepmi_engine_set_mfma(nepmi_engine* e, int on);
 /* Angular s_{n,lm} sums between the angular descriptor and angular force kernels: mode 0 = stored
  * ((n_a+1)*24 floats per atom through HBM), 1 = rebuilt in the force kernel from the compact pair

@@ -38,14 +38,15 @@ def test_force_parity_without_mfma(drv, name):
 
 @pytest.mark.parametrize("name", ["PbTe-A", "PbTe-B", "C-2022", "BaZrO3"])
 def test_mfma_ann_matches_per_atom_ann(drv, name):
-    """Matrix-core ANN vs per-atom ANN: same contractions, different f32 summation order."""
+    """Matrix-core ANN (mode 2) and the fused descriptor + ANN kernel (mode 1, where the shape allows it) vs the per-atom
+    ANN kernel (mode 0): same contractions, different f32 summation order."""
     nep_rel, build, _ = P.MODELS[name]
     nep = H.golden(*nep_rel.split("/"))
     h, typ, x = build()
     n = len(typ)
     model = drv.model(nep)
     out = []
-    for on in (True, False):
+    for on in (2, 0, 1):
         eng = drv.engine(model, n)
         eng.set_mfma(on)
         _, pe, f, v = H.engine_force(drv, eng, h, typ, x)
@@ -53,11 +54,12 @@ def test_mfma_ann_matches_per_atom_ann(drv, name):
         fp = drv.zeros(model.info.dim * n, dtype=np.float32)
         eng.descriptors(q, fp)
         out.append((pe, f, v, drv.host(fp).reshape(-1, n)))
-    (pe1, f1, v1, fp1), (pe0, f0, v0, fp0) = out
-    np.testing.assert_allclose(fp1, fp0, rtol=1e-4, atol=2e-6 * np.abs(fp0).max())
-    np.testing.assert_allclose(pe1, pe0, rtol=1e-5, atol=5e-6)
-    assert np.abs(f1 - f0).max() <= 1e-5 * max(1.0, np.abs(f0).max())
-    assert np.abs(v1 - v0).max() <= 2e-5 * max(1.0, np.abs(v0).max())
+    pe0, f0, v0, fp0 = out[1]
+    for pe1, f1, v1, fp1 in (out[0], out[2]):
+        np.testing.assert_allclose(fp1, fp0, rtol=1e-4, atol=2e-6 * np.abs(fp0).max())
+        np.testing.assert_allclose(pe1, pe0, rtol=1e-5, atol=5e-6)
+        assert np.abs(f1 - f0).max() <= 1e-5 * max(1.0, np.abs(f0).max())
+        assert np.abs(v1 - v0).max() <= 2e-5 * max(1.0, np.abs(v0).max())
 
 
 @pytest.mark.parametrize("name", ["PbTe-A", "C-2022"])
