@@ -149,3 +149,61 @@ def test_overlapped_exchange_is_bit_identical_to_the_plain_order():
     for ra, rb in zip(a, b):
         assert np.array_equal(ra["i1"], rb["i1"])
         assert np.array_equal(ra["x1"], rb["x1"]) and np.array_equal(ra["v1"], rb["v1"]) and np.array_equal(ra["f1"], rb["f1"])
+
+
+@pytest.mark.gpu
+def test_rccl_transport_on_one_rank():
+    """What a one-GPU box can exercise of the RCCL transport (two ranks on one device are refused by RCCL as a duplicate
+    GPU): communicator set-up from the unique id, grouped send/recv (to the own rank, two messages to the same peer
+    matched in order), the in-place all-reduces of every dtype the driver uses, and a decomposed run over it against
+    the plain engine."""
+    import ctypes as C
+    import torch
+    import gpumd_amd
+    from gpumd_amd import _capi
+    from gpumd_amd.dist import DistMD, Transport
+
+    lib = gpumd_amd.load_library()
+    dev = torch.device("cuda", 0)
+    tr = Transport.rccl(lib, 0, 1, lambda ident: ident)
+    t = tr.struct
+    assert t.device_buffers == 1 and t.nranks == 1
+    a = torch.arange(4096, dtype=torch.float64, device=dev)
+    b = torch.zeros(4096, dtype=torch.float64, device=dev)
+    sends = (_capi.NepmiMsg * 2)(_capi.NepmiMsg(a.data_ptr(), 8 * 1000, 0), _capi.NepmiMsg(a.data_ptr() + 8 * 1000, 8 * 3096, 0))
+    recvs = (_capi.NepmiMsg * 2)(_capi.NepmiMsg(b.data_ptr(), 8 * 1000, 0), _capi.NepmiMsg(b.data_ptr() + 8 * 1000, 8 * 3096, 0))
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert t.exchange(t.ctx, 2, sends, 2, recvs, stream) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    d = torch.tensor([1.5, -2.0], dtype=torch.float64, device=dev)
+    i = torch.tensor([3, 7, -1], dtype=torch.int32, device=dev)
+    l = torch.tensor([1 << 40], dtype=torch.int64, device=dev)
+    assert t.allreduce(t.ctx, d.data_ptr(), 2, 0, 0, stream) == 0
+    assert t.allreduce(t.ctx, i.data_ptr(), 3, 1, 1, stream) == 0
+    assert t.allreduce(t.ctx, l.data_ptr(), 1, 2, 0, stream) == 0
+    torch.cuda.synchronize()
+    assert d.tolist() == [1.5, -2.0] and i.tolist() == [3, 7, -1] and l.tolist() == [1 << 40]
+
+    # a run of the decomposed driver over this transport == the plain fused loop
+    drv = H.GpuDriver()
+    nep = H.golden("PbTe", "nep.txt")
+    h, typ, x = H.pbte_supercell((4, 4, 4), rattle=0.02, seed=31)
+    typ = typ.astype(np.int32)
+    n = len(typ)
+    mass = np.where(typ == 0, H.MASS["Te"], H.MASS["Pb"]).astype(np.float64)
+    vel = H.maxwell_velocities(mass, 1000.0, seed=5)
+    model = drv.model(nep)
+    md = DistMD(model, tr, h, (1, 1, 1), (1, 1, 1))
+    md.setup(torch.from_numpy(typ).to(dev), torch.from_numpy(mass).to(dev), torch.from_numpy(x).to(dev),
+             torch.from_numpy(vel).to(dev))
+    md.compute()
+    th_d = md.run("nve", 1.0 / H.TIME_UNIT, 40, 0.0, 0.0, 100.0, thermo_every=10)
+    md.close()
+    tr.close()
+    eng = drv.engine(model, n)
+    d_t, d_m, d_x, d_v = drv.dev(typ), drv.dev(mass), drv.dev(x), drv.dev(vel)
+    d_pe, d_f, d_w = drv.zeros(n), drv.zeros(3 * n), drv.zeros(9 * n)
+    eng.force_compute(h, d_t, d_x, d_pe, d_f, d_w)
+    th = eng.run_nve(h, d_t, d_m, 1.0 / H.TIME_UNIT, 40, d_x, d_v, d_pe, d_f, d_w, thermo_every=10)
+    np.testing.assert_allclose(np.asarray(th_d)[:, :2], th[:, :2], rtol=1e-7)
