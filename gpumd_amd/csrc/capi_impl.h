@@ -408,6 +408,14 @@ int nepmi_engine_set_timing(nepmi_engine* e, int on)
   return NEPMI_OK;
 }
 
+int nepmi_engine_set_win_lanes(nepmi_engine* e, int lanes)
+{
+  if (!e)
+    return fail(NEPMI_ERR_ARG, "null engine");
+  e->e->set_win_lanes(lanes);
+  return NEPMI_OK;
+}
+
 int nepmi_engine_set_tiles(nepmi_engine* e, int on)
 {
   if (!e)

@@ -1216,6 +1216,18 @@ public:
     tile_mode_ = mode;
     have_list_ = false;
   }
+  // Lanes per atom of the window kernels: one when the bricks fill the chip (more than ~1.5 workgroups per CU); below that a
+  // window kernel takes as long as ONE workgroup does, and 2 or 4 lanes share each atom's list (counted rule:
+  // the same input always runs the same kernels).  set_win_lanes(1 | 2 | 4) pins it, 0 = this rule.
+  int win_lanes() const
+  {
+    if (!B::kSplitLanes)
+      return 1;
+    if (win_lanes_ > 0)
+      return win_lanes_;
+    return num_bricks_ <= 256 ? 4 : (num_bricks_ <= 400 ? 2 : 1);
+  }
+  void set_win_lanes(int lanes) { win_lanes_ = (lanes == 1 || lanes == 2 || lanes == 4) ? lanes : 0; }
   int tile_mode_in_use() const { return tile_ok_ ? 2 : 0; }
   bool tiles_active() const { return tile_ok_; }
   // 0: per-atom ANN kernel; 1 (default): descriptor + ANN fused where the shape allows it, else the matrix-core
@@ -1263,17 +1275,25 @@ private:
       records_valid_ = true;
       return;
     }
+    const int lanes = win_lanes();
+    auto radial = [&](int64_t nb, int first) {
+      if (lanes == 4)
+        be_.launch_win_split(kSlotRadial, nb, RadialWinSplitBody<S, 4>{ws, md_, first, frozen});
+      else if (lanes == 2)
+        be_.launch_win_split(kSlotRadial, nb, RadialWinSplitBody<S, 2>{ws, md_, first, frozen});
+      else
+        be_.launch_win(kSlotRadial, nb, RadialWinBody<S>{ws, md_, first, frozen});
+    };
     if (phase == kPhaseInterior) { // radial pass of the bricks whose window holds no ghost
-      be_.launch_win(kSlotRadial, num_bricks_ - num_boundary_bricks_, RadialWinBody<S>{ws, md_, 0, frozen});
+      radial(num_bricks_ - num_boundary_bricks_, 0);
       return;
     }
     records_valid_ = !tile_ok_;
     be_.begin_region(kRegionForce);
     if (phase == kPhaseBoundary)
-      be_.launch_win(kSlotRadial, num_boundary_bricks_,
-                     RadialWinBody<S>{ws, md_, (int)(num_bricks_ - num_boundary_bricks_), frozen});
+      radial(num_boundary_bricks_, (int)(num_bricks_ - num_boundary_bricks_));
     else if (tile_ok_)
-      be_.launch_win(kSlotRadial, num_bricks_, RadialWinBody<S>{ws, md_, -1, frozen});
+      radial(num_bricks_, -1);
     else
       be_.template launch<64>(kSlotRadial, N_, RadialDescBody<S>{box_, md_, b_, 1});
     if (fuse_ann_active()) {
@@ -1283,10 +1303,14 @@ private:
       be_.template launch_ann<S>(kSlotAnn, N_, md_, b_, true);
     }
     launch_angular_force<S>();
-    if (tile_ok_)
-      be_.launch_win(kSlotForce, num_bricks_, ForceWinBody<S>{ws, md_, frozen});
-    else
+    if (!tile_ok_)
       be_.template launch<64>(kSlotForce, N_, ForceAssembleBody<S>{md_, b_});
+    else if (lanes == 4)
+      be_.launch_win_split(kSlotForce, num_bricks_, ForceWinBody<S, 4>{ws, md_, frozen});
+    else if (lanes == 2)
+      be_.launch_win_split(kSlotForce, num_bricks_, ForceWinBody<S, 2>{ws, md_, frozen});
+    else
+      be_.launch_win(kSlotForce, num_bricks_, ForceWinBody<S>{ws, md_, frozen});
     be_.end_region(kRegionForce);
   }
 
@@ -1335,6 +1359,7 @@ private:
   bool records_valid_ = false; // rstash holds the pair records of the last evaluated positions
   int recompute_mode_ = -1;
   int ann_mode_ = 1;
+  int win_lanes_ = 0;
   bool external_skin_ = false;
   static constexpr int kBrickFill = 253; // of the 256 atom slots of a window-kernel pass (atoms drift between rebuilds;
                                          // a brick that does overflow just takes a second pass)

@@ -122,12 +122,19 @@ struct WinStage {
       const int j0 = wstart[wc];
       int qx, qy, qz;
       cell_offset(bx, by, bz, wc & 7, (wc >> 3) & 7, wc >> 6, qx, qy, qz);
-      for (int a = 0; a < cnt; ++a) {
-        WinRec r = b.prec[j0 + a];
-        r.x += qx;
-        r.y += qy;
-        r.z += qz;
-        rec[w0 + a] = r;
+      for (int a = 0; a < cnt; a += 4) { // four records per round trip (a cell holds 3-4 atoms on average)
+        WinRec r[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          r[u] = b.prec[j0 + (a + u < cnt ? a + u : cnt - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          r[u].x += qx;
+          r[u].y += qy;
+          r[u].z += qz;
+          if (a + u < cnt)
+            rec[w0 + a + u] = r[u];
+        }
       }
     }
   }
@@ -474,6 +481,291 @@ struct RadialWinBody {
   }
 };
 
+// The radial pass with L = 2 or 4 adjacent lanes per atom (workgroups of 256 L threads): for systems with too few
+// bricks to fill the chip, where the kernel's run time is the latency of ONE workgroup walking ~86 candidates per lane.
+// A round covers 2 L candidates of the atom's list, two per lane (side by side in the packed accumulation).  The
+// compact lists keep exactly the order and density of the one-lane form -- a candidate's slot is the running count
+// plus the number of admitted candidates before it in the round, found from the lanes' flag bits (shuffles) -- so the
+// downstream kernels and the results are the same; the basis sums are added across the lanes at the end.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define NEPMI_SHFL_XOR(v, mask) (__shfl_xor((v), (mask)))
+#else
+#define NEPMI_SHFL_XOR(v, mask) (v) // host loops run one lane per atom: the split bodies are never selected there
+#endif
+
+template <class S, int L>
+struct RadialWinSplitBody {
+  WinStage st;
+  ModelD m;
+  int first;
+  const int* frozen;
+  static constexpr int kMinWavesPerEu = 1;
+  static constexpr int kLanes = L;
+
+  NEPMI_HD int lds_bytes() const { return st.lay.bytes(); }
+  template <class LC>
+  NEPMI_HD void stage_lists(int64_t, LC, int, int) const {}
+  NEPMI_HD int64_t map_brick(int64_t w) const { return first < 0 ? w : (int64_t)st.b.brick_order[first + w]; }
+  NEPMI_HD bool skip() const { return frozen && *frozen != 0; }
+  template <class LC>
+  NEPMI_HD void stage_cells(int64_t brick, LC lds, int tid, int nth) const { st.stage_cells(brick, lds, tid, nth); }
+  template <class LC>
+  NEPMI_HD void stage_copy(int64_t brick, LC lds, int tid, int nth) const { st.stage_copy(brick, lds, tid, nth); }
+  NEPMI_HD void brick_range(int64_t brick, int64_t& a0, int64_t& a1) const { st.brick_range(brick, a0, a1); }
+
+  template <class LC>
+  NEPMI_HD void compute(int64_t brick, int64_t k, LC lds, int sub) const
+  {
+    const Bufs& b = st.b;
+    const int64_t N = b.N;
+    if (b.lvl[k] < 1) { // outer ghost: lends its position only
+      if (sub == 0) {
+        b.nn_rad[k] = 0;
+        b.nn_angstep[k] = 0;
+      }
+      return;
+    }
+    NEPMI_LDS(const int)* woff = (NEPMI_LDS(const int)*)(lds + st.lay.off_woff());
+    NEPMI_LDS(const WinRec)* wrec = (NEPMI_LDS(const WinRec)*)(lds + st.lay.off_rec());
+    const int NR = S::fixed ? S::NR : m.NR;
+    const int KR = S::fixed ? S::KR : m.KR;
+    const PosQ p1 = b.posq[k];
+    const int t1 = p1.type;
+    int ox, oy, oz;
+    st.place_own(k, ox, oy, oz);
+    const float rc1 = m.rc_r[t1], rca1 = m.rc_a[t1];
+    const float unit = st.b.wg.unit, unit2 = st.b.wg.unit2, band = st.b.wg.band;
+    constexpr int TSM = S::TS > 0 ? S::TS : 1;
+    f2 Ssum2[TSM][S::KRM + 1];
+    float q[S::NRM + 1];
+#pragma unroll
+    for (int t = 0; t < TSM; ++t)
+#pragma unroll
+      for (int kk = 0; kk <= S::KRM; ++kk)
+        Ssum2[t][kk] = bc2(0.0f);
+#pragma unroll
+    for (int n = 0; n <= S::NRM; ++n)
+      q[n] = 0.0f;
+
+    const int na = b.nn_ang[k], nbn = b.nn_skin[k];
+    int cnt = 0, cnt1 = 0, ca = 0; // the same on every lane of the atom
+    F4* __restrict__ acomp = b.acomp + k;
+    unsigned short* __restrict__ amap = b.amap + k;
+    unsigned short* __restrict__ aidx = b.aidx + k;
+    unsigned short* __restrict__ ccode = b.ccode + k;
+
+    struct Cand {
+      float fx, fy, fz, d2;
+      int t2, slot, rw;
+      bool inside, ang;
+    };
+    // the list decisions of one candidate (RadialWinBody::decide without the bookkeeping)
+    auto judge = [&](const unsigned code, const bool live, const bool list_a) -> Cand {
+      Cand c;
+      c.slot = woff[code >> 7] + (int)(code & 127u);
+      const WinRec r = wrec[c.slot];
+      c.rw = r.w;
+      c.fx = (float)(r.x - ox);
+      c.fy = (float)(r.y - oy);
+      c.fz = (float)(r.z - oz);
+      c.d2 = dot3f(c.fx, c.fx, c.fy, c.fy, c.fz, c.fz) * unit2;
+      c.t2 = (int)((unsigned)r.w >> kIdxBits);
+      const float rc = m.uniform_rc ? m.rc_r_max : (rc1 + m.rc_r[c.t2]) * 0.5f;
+      const float rca = m.uniform_rc ? m.rc_a_max : (rca1 + m.rc_a[c.t2]) * 0.5f;
+      const float er = c.d2 - rc * rc, ea = c.d2 - rca * rca;
+      bool inside = er < 0.0f;
+      bool ang = list_a && ea < 0.0f;
+      const float near = list_a ? fminf(fabsf(er), fabsf(ea)) : fabsf(er);
+      if (live && near < band) { // within the band of a cutoff: the reference's arithmetic decides (rare)
+        float ex, ey, ez;
+        const float d2e = pair_geometry(st.box, p1, b.posq[(unsigned)r.w & (unsigned)kIdxMask], ex, ey, ez);
+        inside = d2e < rc * rc;
+        ang = list_a && d2e < rca * rca;
+      }
+      c.inside = inside && live;
+      c.ang = ang && live;
+      return c;
+    };
+    // bit s of the result: `flag` of lane s of this atom
+    auto gather_bits = [&](bool flag) -> unsigned {
+      unsigned w = (flag ? 1u : 0u) << sub;
+#pragma unroll
+      for (int msk = 1; msk < L; msk <<= 1)
+        w |= (unsigned)NEPMI_SHFL_XOR((int)w, msk);
+      return w;
+    };
+    const unsigned below = (1u << sub) - 1u;
+
+    auto walk = [&](const unsigned short* __restrict__ codes, const int nn, const bool list_a) {
+      auto load_code = [&](int idx) -> unsigned { return nn > 0 ? codes[(int64_t)(idx < nn ? idx : nn - 1) * N] : 0u; };
+      unsigned nxt0 = load_code(sub), nxt1 = load_code(L + sub);
+      for (int s0 = 0; s0 < nn; s0 += 2 * L) {
+        const int i0 = s0 + sub, i1 = s0 + L + sub;
+        const bool live0 = i0 < nn, live1 = i1 < nn;
+        const unsigned code0 = nxt0, code1 = nxt1;
+        nxt0 = load_code(i0 + 2 * L); // the next round's codes travel while this round is decided
+        nxt1 = load_code(i1 + 2 * L);
+        const Cand c0 = judge(code0, live0, list_a), c1 = judge(code1, live1, list_a);
+        // slots in candidate order: first halves of all lanes, then second halves
+        const bool b0 = S::TS == 2 && c0.t2 == 1, b1 = S::TS == 2 && c1.t2 == 1;
+        const unsigned f0 = gather_bits(c0.inside && !b0), f1 = gather_bits(c1.inside && !b1);
+        const unsigned k0 = S::TS == 2 ? gather_bits(c0.inside && b0) : 0u, k1 = S::TS == 2 ? gather_bits(c1.inside && b1) : 0u;
+        const int nf = __builtin_popcount(f0) + __builtin_popcount(f1);
+        const int nk = __builtin_popcount(k0) + __builtin_popcount(k1);
+        const bool room = cnt + cnt1 + nf + nk <= b.MN_rad;
+        if (c0.inside && room) {
+          const int pos = b0 ? b.MN_rad - 1 - (cnt1 + __builtin_popcount(k0 & below))
+                             : cnt + __builtin_popcount(f0 & below);
+          ccode[(int64_t)pos * N] = (unsigned short)c0.slot;
+        }
+        if (c1.inside && room) {
+          const int pos = b1 ? b.MN_rad - 1 - (cnt1 + __builtin_popcount(k0) + __builtin_popcount(k1 & below))
+                             : cnt + __builtin_popcount(f0) + __builtin_popcount(f1 & below);
+          ccode[(int64_t)pos * N] = (unsigned short)c1.slot;
+        }
+        cnt += nf;
+        cnt1 += nk;
+        if (list_a) {
+          const unsigned a0 = gather_bits(c0.ang), a1 = gather_bits(c1.ang);
+          const int s_a0 = ca + __builtin_popcount(a0 & below);
+          const int s_a1 = ca + __builtin_popcount(a0) + __builtin_popcount(a1 & below);
+          auto commit = [&](const Cand& c, int idx, bool live, int sa) {
+            if (!live)
+              return;
+            unsigned short cs = kNoSlot;
+            if (c.ang && sa < b.MN_acomp) {
+              F4 e;
+              e.x = c.fx * unit;
+              e.y = c.fy * unit;
+              e.z = c.fz * unit;
+              e.w = c.rw;
+              acomp[(int64_t)sa * N] = e;
+              aidx[(int64_t)sa * N] = b.rev_ang[(int64_t)idx * N + k];
+              cs = (unsigned short)sa;
+            }
+            amap[(int64_t)idx * N] = cs;
+          };
+          commit(c0, i0, live0, s_a0);
+          commit(c1, i1, live1, s_a1);
+          ca += __builtin_popcount(a0) + __builtin_popcount(a1);
+        }
+        // accumulation (RadialWinBody::accumulate2 / accumulate1)
+        if (S::TS > 0) {
+          float rc0, rc1v, ri0, ri1;
+          if (m.uniform_rc) {
+            rc0 = rc1v = m.rc_r_max;
+            ri0 = ri1 = m.rcinv_r;
+          } else {
+            rc0 = (rc1 + m.rc_r[c0.t2]) * 0.5f;
+            rc1v = (rc1 + m.rc_r[c1.t2]) * 0.5f;
+            ri0 = fast_rcp(rc0);
+            ri1 = fast_rcp(rc1v);
+          }
+          float d0, d1, iv0, iv1;
+          dist_and_inv(c0.d2, d0, iv0);
+          dist_and_inv(c1.d2, d1, iv1);
+          const f2 dc = mk2(d0 < rc0 ? d0 : rc0, d1 < rc1v ? d1 : rc1v);
+          const f2 rcinv = mk2(ri0, ri1);
+          f2 fc;
+          cutoff_fc_v(rcinv, dc, fc);
+          f2 fn[S::KRM + 1];
+          basis_fn_v<S::KRM>(rcinv, dc, fc, fn);
+#pragma unroll
+          for (int t = 0; t < TSM; ++t) {
+            const f2 w = mk2((c0.inside && (TSM == 1 || c0.t2 == t)) ? 1.0f : 0.0f,
+                             (c1.inside && (TSM == 1 || c1.t2 == t)) ? 1.0f : 0.0f);
+#pragma unroll
+            for (int kk = 0; kk <= S::KRM; ++kk)
+              Ssum2[t][kk] = vfma(w, fn[kk], Ssum2[t][kk]);
+          }
+        } else {
+          auto acc1 = [&](const Cand& c) {
+            if (!c.inside)
+              return;
+            const float rc = m.uniform_rc ? m.rc_r_max : (rc1 + m.rc_r[c.t2]) * 0.5f;
+            float d, dinv;
+            dist_and_inv(c.d2, d, dinv);
+            const float rcinv = fast_rcp(rc);
+            const float dc = d < rc ? d : rc;
+            float fc;
+            cutoff_fc(rcinv, dc, fc);
+            float fn[S::KRM + 1];
+            if (S::fixed)
+              basis_fn<S::KRM>(rcinv, dc, fc, fn);
+            else
+              basis_fn_rt(KR, rcinv, dc, fc, fn);
+            const float* cc = m.c_rad + (size_t)(t1 * m.T + c.t2) * (NR + 1) * (KR + 1);
+            for (int n = 0; n <= NR; ++n) {
+              float gsum = 0.0f;
+              for (int kk = 0; kk <= KR; ++kk)
+                gsum += fn[kk] * cc[n * (KR + 1) + kk];
+              q[n] += gsum;
+            }
+          };
+          acc1(c0);
+          acc1(c1);
+        }
+      }
+    };
+    walk(b.code_ang + k, na, true);
+    walk(b.code_skin + k, nbn, false);
+
+    if (sub == 0) {
+      if (ca > b.MN_acomp || cnt + cnt1 > b.MN_rad)
+        NEPMI_ATOMIC_OR(&b.flags[kFlagOverflow], 4);
+      b.nn_rad[k] = cnt + cnt1;
+      b.nn_t0[k] = cnt;
+      b.nn_angstep[k] = ca > b.MN_acomp ? b.MN_acomp : ca;
+    }
+    if (S::TS > 0) {
+      float Ssum[TSM][S::KRM + 1];
+#pragma unroll
+      for (int t = 0; t < TSM; ++t)
+#pragma unroll
+        for (int kk = 0; kk <= S::KRM; ++kk) {
+          float v = Ssum2[t][kk].x + Ssum2[t][kk].y;
+#pragma unroll
+          for (int msk = 1; msk < L; msk <<= 1)
+            v += NEPMI_SHFL_XOR(v, msk);
+          Ssum[t][kk] = v;
+        }
+      for (int tu = 0; tu < m.T; ++tu) {
+        if (!NEPMI_WAVE_ANY(t1 == tu))
+          continue;
+        float qq[S::NRM + 1];
+#pragma unroll
+        for (int n = 0; n <= S::NRM; ++n)
+          qq[n] = 0.0f;
+#pragma unroll
+        for (int t2 = 0; t2 < TSM; ++t2) {
+          cfloat_ptr c = as_const(m.c_rad) + (size_t)(tu * m.T + t2) * (S::NRM + 1) * (S::KRM + 1);
+#pragma unroll
+          for (int n = 0; n <= S::NRM; ++n)
+#pragma unroll
+            for (int kk = 0; kk <= S::KRM; ++kk)
+              qq[n] = fmaf(c[n * (S::KRM + 1) + kk], Ssum[t2][kk], qq[n]);
+        }
+        if (t1 == tu) {
+#pragma unroll
+          for (int n = 0; n <= S::NRM; ++n)
+            q[n] = qq[n];
+        }
+      }
+    } else {
+#pragma unroll
+      for (int n = 0; n <= S::NRM; ++n)
+#pragma unroll
+        for (int msk = 1; msk < L; msk <<= 1)
+          q[n] += NEPMI_SHFL_XOR(q[n], msk);
+    }
+    if (sub == 0) {
+      const int64_t gk = b.tpos[k];
+      for (int n = 0; n <= NR; ++n)
+        b.q[(int64_t)n * N + gk] = q[n] * m.qscale[n];
+    }
+  }
+};
+
 // Angular part of the force assembly: F_i += f12 - f21, W_i += r12 (x) f21 over this step's angular pairs (compact
 // records), f21 found through the reverse slot the radial pass stored next to the record (arev) and j's slot map.
 // The chain arev -> amap[.][j] -> f12[.][j] is two dependent gathers per pair: four pairs are kept in flight.
@@ -606,14 +898,20 @@ NEPMI_HD void win_force_segment(
   }
 }
 
-template <class S>
+// L = 1: one lane per atom.  L = 2, 4 (small systems, see RadialWinSplitBody): L adjacent lanes share the atom, lane
+// `sub` takes every L-th chunk of two entries of the compact radial list and every L-th group of angular records; the
+// sums are linear in the pairs and are added across the lanes at the end, lane 0 writes.
+template <class S, int L = 1>
 struct ForceWinBody {
   WinStage st;
   ModelD m;
   const int* frozen;
-  static constexpr int kMinWavesPerEu = NEPMI_FW_WAVES; // 4: <= 128 VGPRs, four 256-thread workgroups per CU
+  static constexpr int kMinWavesPerEu = L == 1 ? NEPMI_FW_WAVES : 1; // 4: <= 128 VGPRs, four 256-thread workgroups per CU
+  static constexpr int kLanes = L;
 
   NEPMI_HD int lds_bytes() const { return st.lay.bytes(); }
+  template <class LC>
+  NEPMI_HD void stage_lists(int64_t, LC, int, int) const {}
   NEPMI_HD int64_t map_brick(int64_t w) const { return w; }
   NEPMI_HD bool skip() const { return frozen && *frozen != 0; }
   template <class LC>
@@ -623,7 +921,7 @@ struct ForceWinBody {
   NEPMI_HD void brick_range(int64_t brick, int64_t& a0, int64_t& a1) const { st.brick_range(brick, a0, a1); }
 
   template <class LC>
-  NEPMI_HD void compute(int64_t brick, int64_t k, LC lds) const
+  NEPMI_HD void compute(int64_t brick, int64_t k, LC lds, int sub = 0) const
   {
     const Bufs& b = st.b;
     const int64_t N = b.N;
@@ -644,7 +942,7 @@ struct ForceWinBody {
     // ---- angular part: f12 - f21 of this step's angular pairs (compact records) ----
     float F[3] = {0, 0, 0};
     float Wa[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}; // xx yy zz xy xz yz yx zx zy
-    win_force_angular<1>(b, k, 0, F, Wa);
+    win_force_angular<L>(b, k, sub, F, Wa);
 
     // ---- radial part over the compact list: every entry is a pair inside the cutoff ----
     constexpr int TSM = S::TS > 0 ? S::TS : 1;
@@ -672,7 +970,7 @@ struct ForceWinBody {
         for (int kk = 0; kk <= S::KRM; ++kk)
           Aown[kk] = atab[(size_t)k * arow + t * KRP + kk];
         win_force_segment<S>(m, ccode, N, wrec, rows, Aown, t == 0 ? n0 : nrad - n0, t == 0 ? 0 : b.MN_rad - 1,
-                             t == 0 ? 1 : -1, 0, 1, ox, oy, oz, rc1, unit2, Fr2, W2);
+                             t == 0 ? 1 : -1, sub, L, ox, oy, oz, rc1, unit2, Fr2, W2);
       }
 #pragma unroll
       for (int d = 0; d < 3; ++d)
@@ -686,11 +984,11 @@ struct ForceWinBody {
       unsigned cur[G], nxt[G];
 #pragma unroll
       for (int u = 0; u < G; ++u)
-        cur[u] = nrad > 0 ? ccode[(int64_t)(u < nrad ? u : nrad - 1) * N] : 0u;
-      for (int s0 = 0; s0 < nrad; s0 += G) {
+        cur[u] = nrad > 0 ? ccode[(int64_t)(G * sub + u < nrad ? G * sub + u : nrad - 1) * N] : 0u;
+      for (int s0 = G * sub; s0 < nrad; s0 += G * L) {
 #pragma unroll
         for (int u = 0; u < G; ++u) {
-          const int idx = s0 + G + u;
+          const int idx = s0 + G * L + u;
           nxt[u] = ccode[(int64_t)(idx < nrad ? idx : nrad - 1) * N];
         }
         WinRec rr[G];
@@ -756,6 +1054,24 @@ struct ForceWinBody {
       }
     }
 
+    if (L > 1) {
+#pragma unroll
+      for (int msk = 1; msk < L; msk <<= 1) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          F[d] += NEPMI_SHFL_XOR(F[d], msk);
+          Fr[d] += NEPMI_SHFL_XOR(Fr[d], msk);
+        }
+#pragma unroll
+        for (int d = 0; d < 9; ++d)
+          Wa[d] += NEPMI_SHFL_XOR(Wa[d], msk);
+#pragma unroll
+        for (int d = 0; d < 6; ++d)
+          W[d] += NEPMI_SHFL_XOR(W[d], msk);
+      }
+      if (sub != 0)
+        return;
+    }
     // ---- outputs, internal order ----
     double E = (double)b.pe_i[k];
     double Fd[3], Wd[9];

@@ -265,6 +265,10 @@ class NEP:
         mode = 2 if mode is True else 0 if mode is False else int(mode)
         self._ck(self.lib.nepmi_engine_set_tiles(self.handle, mode))
 
+    def set_win_lanes(self, lanes=0):
+        """lanes per atom of the LDS-window kernels: 0 = by the number of bricks, or 1 / 2 / 4"""
+        self._ck(self.lib.nepmi_engine_set_win_lanes(self.handle, int(lanes)))
+
     def set_mfma(self, on=True):
         """False / 0: per-atom ANN kernel; True / 1 (default): descriptor + ANN fused where the shape allows it, else the
         matrix-core ANN kernel; 2: the matrix-core kernel wherever it applies (no fusion)"""

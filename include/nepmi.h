@@ -346,6 +346,9 @@ int nepmi_engine_set_generic(nepmi_engine* e, int on);
  * fit LDS or an atom sits far outside the box along an open direction.  Both give identical lists and forces to
  * f32 rounding. */
 int nepmi_engine_set_tiles(nepmi_engine* e, int on);
+/* Lanes per atom of the LDS-window kernels: 0 (default) = by the number of bricks (4 up to 256 bricks, 2 up to 400,
+ * else 1: small systems are bound by the latency of one workgroup); 1, 2, 4 pin it. */
+int nepmi_engine_set_win_lanes(nepmi_engine* e, int lanes);
 /* How the per-atom ANN runs.  on = 1 (default): inside the angular-descriptor kernel where the shape allows it (one
  * lane per atom, at most 4 types: the descriptor never leaves the registers), else the matrix-core
  * (v_mfma_f32_32x32x2_f32) ANN kernel; on = 2: the matrix-core kernel wherever it applies; on = 0: the per-atom ANN

@@ -66,6 +66,12 @@ struct HostLoopBackend {
   void ann_prepare(const ModelD&, const Bufs&) {}
 
   // one "workgroup" per brick, phases run back to back (the LDS-window kernels of nep_window.h)
+  static constexpr bool kSplitLanes = false; // host loops run one lane per atom
+  template <class Body>
+  void launch_win_split(int, int64_t, const Body&)
+  {
+    std::abort(); // never selected: the engine asks kSplitLanes first
+  }
   template <class Body>
   void launch_win(int, int64_t nbricks, const Body& body)
   {

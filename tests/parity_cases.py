@@ -36,7 +36,7 @@ MODELS = {
 }
 
 
-def check_force_parity(drv, name, generic=False, check_lists=True, tiles=True, mfma=True):
+def check_force_parity(drv, name, generic=False, check_lists=True, tiles=True, mfma=True, lanes=None):
     nep_rel, build, _ = MODELS[name]
     nep = H.golden(*nep_rel.split("/"))
     h, typ, x = build()
@@ -53,6 +53,8 @@ def check_force_parity(drv, name, generic=False, check_lists=True, tiles=True, m
     eng.set_tiles(tiles)
     if not mfma:
         eng.set_mfma(False)
+    if lanes is not None:
+        eng.set_win_lanes(lanes)
     xw, pe, f, v = H.engine_force(drv, eng, h, typ, x)
     if not tiles:
         assert eng.stats().radial_tiles == 0

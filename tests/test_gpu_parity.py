@@ -62,6 +62,14 @@ def test_mfma_ann_matches_per_atom_ann(drv, name):
         assert np.abs(v1 - v0).max() <= 2e-5 * max(1.0, np.abs(v0).max())
 
 
+@pytest.mark.parametrize("lanes", [1, 2, 4])
+@pytest.mark.parametrize("name", ["PbTe-A", "PbTe-B", "C-2022", "UNEP-v1", "BaZrO3"])
+def test_force_parity_lanes_per_atom(drv, name, lanes):
+    """The LDS-window kernels with 1, 2 or 4 lanes per atom (the engine picks by the number of bricks; these systems
+    are small, so the default is 4): same lists bit for bit, same forces within the FP32 tolerance."""
+    P.check_force_parity(drv, name, lanes=lanes)
+
+
 @pytest.mark.parametrize("name", ["PbTe-A", "C-2022"])
 def test_force_parity_with_pair_records(drv, name):
     """Tile mode 1: LDS-window radial pass that writes pair records + the record-reading force assembly."""
