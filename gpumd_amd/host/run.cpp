@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cstdlib>
 #include <random>
 #include <cstring>
 #include <fstream>
@@ -105,9 +106,9 @@ void Run::parse_one_keyword(const std::vector<std::string>& p)
     const int n[3] = {std::atoi(p[1].c_str()), std::atoi(p[2].c_str()), std::atoi(p[3].c_str())};
     if (n[0] < 1 || n[1] < 1 || n[2] < 1)
       input_error("replicate numbers should be >= 1.");
+    // like Replicate() (replicate.cu:51-72) the velocities of the cell are repeated with it: no new draw from the
+    // rand() stream here, so a later `velocity` keyword sees the stream where the reference's does
     replicate(n, box, atom, groups);
-    if (!has_velocity_in_xyz)
-      initialize_velocity(initial_temperature, false, 0, atom);
   } else if (k == "potential") {
     if (check_only_) {
       std::printf("potential %s (elements:", p[1].c_str());
@@ -712,7 +713,9 @@ void Run::perform_a_run()
     nhc_state_ = nullptr;
   }
   if (ensemble == "nvt_bdp") { // Ensemble_BDP::initialize_rng (ensemble_bdp.cu:32-39): seeded from the clock
-    const uint64_t seed = (uint64_t)std::chrono::system_clock::now().time_since_epoch().count();
+    // GPUMD_MI_DEBUG=1 is the run-time counterpart of the reference's -DDEBUG build: the fixed seed 12345678
+    const uint64_t seed = std::getenv("GPUMD_MI_DEBUG") ? 12345678u
+                                                        : (uint64_t)std::chrono::system_clock::now().time_since_epoch().count();
     die_on(nepmi_bdp_seed(e, seed), "bdp_seed");
     std::printf("    BDP noise seed = %llu.\n", (unsigned long long)((std::mt19937::result_type)seed));
   }
@@ -903,7 +906,9 @@ void Run::perform_a_run_dist()
   die_on(nepmi_dist_reset_thermostat(dist_), "reset_thermostat");
   if (ens == 3) {
     // every rank must draw the same noise: the seed comes from rank 0's clock
-    int64_t seed = root ? (int64_t)std::chrono::system_clock::now().time_since_epoch().count() : 0;
+    int64_t seed = !root ? 0
+                         : (std::getenv("GPUMD_MI_DEBUG") ? (int64_t)12345678
+                                                          : (int64_t)std::chrono::system_clock::now().time_since_epoch().count());
     boot_.allreduce(boot_.ctx, &seed, 1, 2, 0, nullptr);
     die_on(nepmi_dist_bdp_seed(dist_, (uint64_t)seed), "bdp_seed");
     std::printf("    BDP noise seed = %llu.\n", (unsigned long long)((std::mt19937::result_type)seed));

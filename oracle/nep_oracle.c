@@ -61,6 +61,8 @@ struct nepo_model {
   int n_max_radial, n_max_angular, basis_size_radial, basis_size_angular;
   int L_max, has_222, has_1111, num_L, dim, num_neurons;
   int has_112, has_123, has_233, has_134; /* extra 4-body rows, nep.cu:275-310 */
+  int temperature_model; /* nep4[_zbl]_temperature (nep.cu:125-130, model_type 3): the last ANN input is the temperature */
+  double temperature;    /* what Force::compute hands to NEP::compute(temperature, ...) (force.cu:516-525) */
   int num_para_ann, num_para, num_c_radial;
   int off_w0[NEPO_MAX_TYPES], off_b0[NEPO_MAX_TYPES], off_w1[NEPO_MAX_TYPES], off_b1;
   double* params; /* num_para + dim (q_scaler at the end) */
@@ -164,6 +166,8 @@ nepo_model* nepo_model_load(const char* path, char* err, int errlen)
   else if (!strcmp(tok[0], "nep4_zbl")) { m->version = 4; m->zbl_enabled = 1; }
   else if (!strcmp(tok[0], "nep5")) { m->version = 5; }
   else if (!strcmp(tok[0], "nep5_zbl")) { m->version = 5; m->zbl_enabled = 1; }
+  else if (!strcmp(tok[0], "nep4_temperature")) { m->version = 4; m->temperature_model = 1; }
+  else if (!strcmp(tok[0], "nep4_zbl_temperature")) { m->version = 4; m->zbl_enabled = 1; m->temperature_model = 1; }
   else NEPO_FAIL("%s is an unsupported NEP model.", tok[0]);
   m->num_types = atoi(tok[1]);
   if (m->num_types < 1 || m->num_types > NEPO_MAX_TYPES || nt != 2 + m->num_types)
@@ -245,6 +249,8 @@ nepo_model* nepo_model_load(const char* path, char* err, int errlen)
     NEPO_FAIL("This line should be ANN num_neurons 0.");
   m->num_neurons = atoi(tok[1]);
   m->dim = (m->n_max_radial + 1) + (m->n_max_angular + 1) * m->num_L;
+  if (m->temperature_model)
+    m->dim += 1; /* nep.cu:322-325 */
 
   const int T = m->num_types;
   const int per_type = (m->dim + 2) * m->num_neurons;
@@ -322,6 +328,8 @@ void nepo_model_info(const nepo_model* m, nepo_info* o)
 }
 
 const char* nepo_model_symbol(const nepo_model* m, int t) { return m->symbols[t]; }
+int nepo_model_is_temperature(const nepo_model* m) { return m->temperature_model; }
+void nepo_model_set_temperature(nepo_model* m, double temperature) { m->temperature = temperature; }
 double nepo_model_param(const nepo_model* m, int idx) { return m->params[idx]; }
 
 /* ---- the two precision instantiations ---------------------------------------------------- */

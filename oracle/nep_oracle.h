@@ -49,6 +49,10 @@ void nepo_model_free(nepo_model* m);
 void nepo_model_info(const nepo_model* m, nepo_info* out);
 const char* nepo_model_symbol(const nepo_model* m, int t);
 double nepo_model_param(const nepo_model* m, int idx);
+/* temperature-dependent NEP (nep4[_zbl]_temperature, nep.cu:125-130): the ANN has one more input, the temperature
+ * that Force::compute passes to NEP::compute(temperature, ...) (force.cu:516-525; nep.cu:1483 q[dim-1] = temperature). */
+int nepo_model_is_temperature(const nepo_model* m);
+void nepo_model_set_temperature(nepo_model* m, double temperature);
 
 /* Neighbour lists of one configuration.
  * path: -1 = choose like NEP::compute (small box iff a periodic thickness <= 2.5*(rc+1)),

@@ -1,0 +1,58 @@
+"""MD-level parity against the REFERENCE ITSELF on the same GPU: the reference's own `gpumd`, compiled for gfx950 from
+/root/reference/src by oracle/ref_gpumd.mk (oracle/_ref/gpumd_ref: test infrastructure, travels to the GPU box as a
+prebuilt binary), and `gpumd-mi` run the same run.in / model.xyz / potential for 20 steps with thermo.out written every
+step.  Velocities come from model.xyz (vel:R:3): the ROCm runtime consumes draws of the process-wide glibc rand()
+stream, so the reference's HIP build is not reproducible run to run through the `velocity` keyword.
+
+Covers in one go what the oracle covers piecewise: read_xyz, Force::compute (NEP large box / Tersoff), the integrators
+(NVE, Berendsen, Nose-Hoover chain, BDP), find_thermo and dump_thermo -- rows a1-a9, a11-a14, a16, f1, H of SURVEY.md section 8.
+Tolerances: FP64 Tersoff agrees in every printed digit; the NEP paths compute in FP32 with a different summation order,
+so T and U agree to 1e-6 relative over 20 steps (measured: 3e-7), pressures to 1e-3 GPa (measured: 4e-5).
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "profiles"))
+
+pytestmark = pytest.mark.gpu
+
+CASES = {
+    # case: (rtol T/K, rtol U, atol P [GPa])
+    "si_tersoff": (1e-10, 1e-10, 1e-8),
+    "pbte_16k": (1e-6, 1e-6, 1e-3),
+    "carbon_nve": (2e-6, 2e-6, 1e-3),
+    "carbon_nvt": (2e-6, 2e-6, 1e-3),   # Berendsen
+    "carbon_nhc": (2e-6, 2e-6, 1e-3),   # Nose-Hoover chain
+    "carbon_bdp": (2e-6, 2e-6, 1e-3),   # Bussi-Donadio-Parrinello, both programs with the fixed DEBUG seed
+    "unep": (2e-6, 2e-6, 1e-3),
+}
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_thermo_rows_match_reference_gpumd(case, tmp_path):
+    import ref_compare as R
+    if not os.path.exists(R.REF):
+        pytest.skip("oracle/_ref/gpumd_ref not built (needs /root/reference at build time)")
+    assert os.path.exists(R.MI), "gpumd-mi is not built"
+    R.FINE = 20
+    try:
+        th = {}
+        for tag, exe in (("ref", R.REF), ("mi", R.MI)):
+            d = str(tmp_path / tag)
+            R.case_inputs(case, d)
+            res, th[tag] = R.run_binary(exe, d, 300.0)
+            assert res["rc"] == 0, open(os.path.join(d, "stdout.txt")).read()[-2000:]
+    finally:
+        R.FINE = 0
+    a, b = th["ref"], th["mi"]
+    assert a is not None and b is not None and a.shape == b.shape and a.shape[0] == 20
+    rt, ru, ap = CASES[case]
+    np.testing.assert_allclose(b[:, 0], a[:, 0], rtol=rt)            # temperature
+    np.testing.assert_allclose(b[:, 1], a[:, 1], rtol=rt)            # kinetic energy
+    np.testing.assert_allclose(b[:, 2], a[:, 2], rtol=ru)            # potential energy
+    np.testing.assert_allclose(b[:, 3:9], a[:, 3:9], rtol=0, atol=ap)  # stress components, GPa
+    np.testing.assert_allclose(b[:, 9:], a[:, 9:], rtol=1e-12)       # box
