@@ -21,6 +21,7 @@ import argparse
 import datetime
 import json
 import os
+import re
 import sys
 import time
 
@@ -227,6 +228,32 @@ def cpu_baseline(seconds=12.0):
     if agg:
         out["all_cores_aggregate"] = agg
     return out
+
+
+def reference_gpu_baseline(steps=200, timeout=180.0):
+    """The reference's OWN `gpumd` (its HIP build compiled for gfx950 from /root/reference/src by oracle/ref_gpumd.mk ->
+    oracle/_ref/gpumd_ref, a prebuilt comparator that travels with the repository) on the bench workload itself
+    (model.xyz of the 250-atom PbTe cell, `replicate 16 16 16`, NVE, dt 1 fs) on THIS GPU, after the timed region: the
+    "Speed of this run" line it prints (src/main_gpumd/run.cu:324-326).  Part of the baseline leg: never the thing
+    measured.  None when the binary is absent."""
+    import subprocess
+    import tempfile
+    exe = os.path.join(ROOT, "oracle", "_ref", "gpumd_ref")
+    if not os.path.exists(exe):
+        return None
+    sys.path.insert(0, os.path.join(ROOT, "profiles"))
+    import ref_compare as R
+    with tempfile.TemporaryDirectory() as d:
+        n = R.case_inputs("pbte_1m", d)
+        with open(os.path.join(d, "run.in")) as f:
+            run = f.read()
+        with open(os.path.join(d, "run.in"), "w") as f:
+            f.write(re.sub(r"\nrun \d+", "\nrun %d" % steps, re.sub(r"dump_thermo \d+", "dump_thermo %d" % steps, run)))
+        res, _ = R.run_binary(exe, d, timeout)
+    if not res.get("speed"):
+        return None
+    return {"value": res["speed"], "unit": "atom-steps/s", "kind": "reference gpumd (src/makefile.hip flags, gfx950), same GPU",
+            "sample": "PbTe %d atoms (replicate 16 16 16), %d NVE steps, %.2f s in its run block" % (n, steps, res["run_seconds"])}
 
 
 def cpu_baseline_tersoff(pot, h, typ, x, mass, vel, seconds=12.0):
@@ -551,6 +578,12 @@ def main():
         if world == 1 and not args.no_cpu_baseline and args.workload == "pbte":
             with _stdout_to_stderr():
                 out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+                del eng  # the reference needs the HBM of a 1 M-atom run of its own
+                torch.cuda.empty_cache()
+                ref_gpu = reference_gpu_baseline()
+                if ref_gpu:
+                    ref_gpu["speedup_of_this_engine"] = value / ref_gpu["value"]
+                    out["cpu_baseline"]["reference_gpu_same_box"] = ref_gpu
         if world == 1 and not args.no_cpu_baseline and tersoff:
             with _stdout_to_stderr():
                 out["cpu_baseline"] = cpu_baseline_tersoff(nep_txt, h, typ, x0, mass, vel0, args.cpu_seconds)

@@ -21,7 +21,8 @@ class NepmiInfo(C.Structure):
         ("basis_size_radial", C.c_int), ("basis_size_angular", C.c_int),
         ("L_max", C.c_int), ("has_q_222", C.c_int), ("has_q_1111", C.c_int), ("num_L", C.c_int),
         ("dim", C.c_int), ("num_neurons", C.c_int), ("num_para", C.c_int),
-        ("has_q_112", C.c_int), ("has_q_123", C.c_int), ("has_q_233", C.c_int), ("has_q_134", C.c_int)]
+        ("has_q_112", C.c_int), ("has_q_123", C.c_int), ("has_q_233", C.c_int), ("has_q_134", C.c_int),
+        ("model_type", C.c_int)]
 
 
 class NepmiStats(C.Structure):
@@ -100,6 +101,7 @@ SYMBOLS = {
     "nepmi_engine_set_win_lanes": (C.c_int, [VP, C.c_int]),
     "nepmi_engine_set_mfma": (C.c_int, [VP, C.c_int]),
     "nepmi_engine_set_angular_recompute": (C.c_int, [VP, C.c_int]),
+    "nepmi_engine_set_temperature": (C.c_int, [VP, C.c_double]),
     "nepmi_transport_rccl_id": (C.c_int, [C.c_char_p]),
     "nepmi_transport_rccl": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(NepmiTransport)]),
     "nepmi_transport_tcp": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(NepmiTransport)]),

@@ -96,6 +96,7 @@ int nepmi_model_info(const nepmi_model* mm, nepmi_info* o)
   o->has_q_123 = m.has_q_123;
   o->has_q_233 = m.has_q_233;
   o->has_q_134 = m.has_q_134;
+  o->model_type = m.temperature_model ? 3 : 0;
   return NEPMI_OK;
 }
 
@@ -438,6 +439,13 @@ int nepmi_engine_set_angular_recompute(nepmi_engine* e, int mode)
     return fail(NEPMI_ERR_ARG, "null engine");
   e->e->set_angular_recompute(mode);
   return NEPMI_OK;
+}
+
+int nepmi_engine_set_temperature(nepmi_engine* e, double temperature)
+{
+  if (!e)
+    return fail(NEPMI_ERR_ARG, "null engine");
+  return guarded([&] { e->e->set_temperature(temperature); });
 }
 
 int nepmi_engine_set_external_skin(nepmi_engine* e, int on)

@@ -180,12 +180,18 @@ public:
       be_.template launch<64>(kSlotMisc, 1, NhcChainBody{n_total_, target, 0.5 * dt, thermo_dev_, nhc_dev_, frozen()});
       be_.template launch<256>(kSlotVV, e.num_atoms(), ResidentScaleBody{e.bufs(), nhc_dev_ + 3 * kNhcLinks, 1.0});
     };
+    // temperature-dependent NEP: as in EngineT::run_md (every rank sets the same value)
+    const bool temp_ramp = e.temperature_model() && ens != Engine::kNve && t1 != t2;
+    if (e.temperature_model() && ens != Engine::kNve && e.temperature() != t1)
+      e.set_temperature(t1);
     std::vector<int> pending;
     int ring_next = 0;
     int64_t step = 0;
     bool resume_after_vv1 = false, kick2_pending = false;
     while (step < nsteps) {
       const double target = target_of(step);
+      if (temp_ramp)
+        e.set_temperature(t1 + (t2 - t1) * ((double)(step + 2) / (double)nsteps));
       if (!resume_after_vv1) {
         if (ens == Engine::kNhc)
           nhc_half(target);

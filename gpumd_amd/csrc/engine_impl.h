@@ -523,6 +523,13 @@ public:
     };
 
     int64_t step = 0;
+    // Temperature-dependent NEP under a thermostat: Force::temperature starts at t1 (run.cu:679-681) and EVERY
+    // Force::compute of the run adds delta_T = (t2 - t1) / nsteps first (force.cu:803) -- the initial one included
+    // (run.cu:232-241 calls the same overload), so the compute of step s sees t1 + (s + 2) delta_T.  NVE keeps what
+    // set_temperature said.
+    const bool temp_ramp = model_.temperature_model && ens != kNve && t1 != t2;
+    if (model_.temperature_model && ens != kNve && temperature_ != t1)
+      set_temperature(t1);
     bool resume_after_vv1 = false; // the pre-force phase of `step` has already run (replay after a rebuild)
     bool kick2_pending = false;    // NVE: the second half-kick of step - 1 rides on this step's first pass
     while (step < nsteps) {
@@ -534,6 +541,8 @@ public:
       }
       resume_after_vv1 = false;
       kick2_pending = false;
+      if (temp_ramp)
+        set_temperature(t1 + (t2 - t1) * ((double)(step + 2) / (double)nsteps));
       force_kernels(kPhaseAll, frozen);
       const bool record = thermo_every > 0 && (step + 1) % thermo_every == 0;
       const bool last = step + 1 == nsteps;
@@ -640,6 +649,8 @@ public:
       }
       velocity_verlet(true, n, dt, mass, force, pos, vel, &box);
       zero_properties(n, pe, force, virial);
+      if (model_.temperature_model && ens != kNve) // as in run_md
+        set_temperature(t1 + (t2 - t1) * ((double)(step + 2) / (double)nsteps));
       potential_compute(h9, pbc, n, type, pos, pe, force, virial);
       velocity_verlet(false, n, dt, mass, force, pos, vel, nullptr);
       const bool record = thermo_every > 0 && (step + 1) % thermo_every == 0;
@@ -1254,6 +1265,26 @@ public:
   // angular s sums: -1 auto (recompute in the force kernel when the model has few angular
   // neighbours, MN_angular <= 16), 0 always through sbuf, 1 always recompute
   void set_angular_recompute(int mode) { recompute_mode_ = mode; }
+  // NEP::compute(temperature, ...) of a temperature-dependent model (nep.cu:1483-1486: q[dim] = temperature *
+  // q_scaler[dim] is one more ANN input).  That input is the same for every atom, so its product with the last column
+  // of w0 is a constant per (type, neuron): it is folded into the hidden-layer bias the ANN kernels read,
+  //   tanh(sum_d w0[j][d] q[d] + w0[j][dim] qT - b0[j]) = tanh(sum_d w0[j][d] q[d] - (b0[j] - w0[j][dim] qT)),
+  // and every kernel runs as for a plain model (the two forms differ by one f32 rounding of the neuron input).
+  void set_temperature(double temperature)
+  {
+    const NepModel& m = model_;
+    if (!m.temperature_model || m.kind != 0 || temperature == temperature_) // (the uploaded bias is the one of 0 K)
+      return;
+    temperature_ = temperature;
+    const float qT = (float)temperature * m.q_scaler_temp;
+    b0_eff_.resize(m.b0.size());
+    for (size_t k = 0; k < m.b0.size(); ++k)
+      b0_eff_[k] = m.b0[k] - m.w0_temp[k] * qT;
+    be_.h2d(const_cast<float*>(md_.b0), b0_eff_.data(), sizeof(float) * b0_eff_.size());
+    be_.ann_prepare(md_, b_); // the matrix-core weight image carries the bias as well
+  }
+  double temperature() const { return temperature_; }
+  bool temperature_model() const { return model_.temperature_model; }
   int recompute_s() const
   {
     return recompute_mode_ < 0 ? (model_.MN_angular <= 16 ? 1 : 0) : (recompute_mode_ ? 1 : 0);
@@ -1358,6 +1389,8 @@ private:
   int tile_mode_ = -1;           // -1 auto, 0 none, 1 radial window only, 2 radial + force windows
   bool records_valid_ = false; // rstash holds the pair records of the last evaluated positions
   int recompute_mode_ = -1;
+  double temperature_ = 0.0;  // set_temperature (temperature-dependent models)
+  std::vector<float> b0_eff_; // hidden-layer bias with the temperature input folded in
   int ann_mode_ = 1;
   int win_lanes_ = 0;
   bool external_skin_ = false;

@@ -109,19 +109,23 @@ std::string load_nep_model(const std::string& path, NepModel& m, bool* unsupport
   if (tok[0] == "tersoff_1989")
     return load_tersoff(in, tok, m);
   const std::string& head = tok[0];
-  // header: nep{3,4,5}[_zbl]; every other suffix (charge, dipole, polarizability, temperature)
+  // header: nep{3,4,5}[_zbl] and nep4[_zbl]_temperature; every other suffix (charge, dipole, polarizability)
   // is a different model_type in the reference (nep.cu:113-143) and outside this engine.
   if (head == "nep3" || head == "nep3_zbl")
     m.version = 3;
   else if (head == "nep4" || head == "nep4_zbl")
     m.version = 4;
+  else if (head == "nep4_temperature" || head == "nep4_zbl_temperature") { // nep.cu:125-130
+    m.version = 4;
+    m.temperature_model = true;
+  }
   else if (head == "nep5" || head == "nep5_zbl")
     m.version = 5;
   else if (starts_with(head, "nep"))
-    return unsup(head + " is a NEP variant outside this engine (only potential models nep3/4/5[_zbl]).");
+    return unsup(head + " is a NEP variant outside this engine (only potential models nep3/4/5[_zbl] and nep4[_zbl]_temperature).");
   else
     return head + " is an unsupported NEP model.";
-  m.zbl_enabled = head.size() > 4;
+  m.zbl_enabled = head.find("_zbl") != std::string::npos;
   m.num_types = std::atoi(tok[1].c_str());
   if (m.num_types < 1 || m.num_types > kMaxTypes || (int)tok.size() != 2 + m.num_types)
     return "The first line of nep.txt should have " + std::to_string(m.num_types) + " atom symbols.";
@@ -225,8 +229,9 @@ std::string load_nep_model(const std::string& path, NepModel& m, bool* unsupport
   const int nR1 = m.n_max_radial + 1, nA1 = m.n_max_angular + 1;
   const int kR1 = m.basis_size_radial + 1, kA1 = m.basis_size_angular + 1;
   m.dim = nR1 + nA1 * m.num_L;
+  const int dim_file = m.dim + (m.temperature_model ? 1 : 0); // annmb.dim of the reference (nep.cu:321-325)
 
-  const int per_type = (m.dim + 2) * m.num_neurons;
+  const int per_type = (dim_file + 2) * m.num_neurons;
   if (m.version == 3)
     m.num_para_ann = per_type + 1;
   else if (m.version == 4)
@@ -236,7 +241,7 @@ std::string load_nep_model(const std::string& path, NepModel& m, bool* unsupport
   m.num_c_radial = T * T * nR1 * kR1;
   m.num_para = m.num_para_ann + m.num_c_radial + T * T * nA1 * kA1;
 
-  m.params.resize((size_t)m.num_para + m.dim);
+  m.params.resize((size_t)m.num_para + dim_file);
   for (size_t k = 0; k < m.params.size(); ++k) {
     tok = next_tokens(in);
     if (tok.empty())
@@ -259,13 +264,18 @@ std::string load_nep_model(const std::string& path, NepModel& m, bool* unsupport
   m.b0.resize((size_t)T * nn);
   m.w1.resize((size_t)T * nn);
   m.b1t.assign(T, 0.0f);
+  m.w0_temp.assign(m.temperature_model ? (size_t)T * nn : 0, 0.0f);
   size_t off = 0;
   for (int t = 0; t < T; ++t) {
     if (t > 0 && m.version == 3)
       off = 0; // one ANN block shared by every type
-    for (int k = 0; k < nn * dim; ++k)
-      m.w0[(size_t)t * nn * dim + k] = (float)m.params[off + k];
-    off += (size_t)nn * dim;
+    for (int j = 0; j < nn; ++j) {
+      for (int d = 0; d < dim; ++d)
+        m.w0[((size_t)t * nn + j) * dim + d] = (float)m.params[off + (size_t)j * dim_file + d];
+      if (m.temperature_model)
+        m.w0_temp[(size_t)t * nn + j] = (float)m.params[off + (size_t)j * dim_file + dim];
+    }
+    off += (size_t)nn * dim_file;
     for (int k = 0; k < nn; ++k)
       m.b0[(size_t)t * nn + k] = (float)m.params[off + k];
     off += nn;
@@ -297,6 +307,8 @@ std::string load_nep_model(const std::string& path, NepModel& m, bool* unsupport
   m.q_scaler.resize(dim);
   for (int d = 0; d < dim; ++d)
     m.q_scaler[d] = (float)m.params[(size_t)m.num_para + d];
+  if (m.temperature_model)
+    m.q_scaler_temp = (float)m.params[(size_t)m.num_para + dim];
   m.rc_radial_f.resize(T);
   m.rc_angular_f.resize(T);
   for (int t = 0; t < T; ++t) {

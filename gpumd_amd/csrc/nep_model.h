@@ -19,6 +19,13 @@ struct NepModel {
   int kind = 0;    // 0: NEP, 1: Tersoff-1989 (BASELINE config 2)
   TersoffSet ters[3]; // type 0-0, type 1-1, mixed (tersoff1989.cu:115-140)
   int version = 0; // 3, 4, 5
+  // nep4[_zbl]_temperature (nep.cu:125-130, model_type 3): the ANN has one more input, the temperature handed to
+  // NEP::compute(temperature, ...).  `dim` below stays the DESCRIPTOR dimension (what the kernels see); the extra input's
+  // weights and scaler are kept aside and folded into the hidden-layer bias whenever the temperature changes
+  // (EngineT::set_temperature): tanh(sum_d w0[j][d] q[d] + w0[j][dim] * T * q_scaler[dim] - b0[j]).
+  bool temperature_model = false;
+  std::vector<float> w0_temp; // [T][neuron]: the last column of the file's w0
+  float q_scaler_temp = 0.0f; // the last entry of the file's q_scaler
   bool zbl_enabled = false, zbl_flexible = false;
   double zbl_rc_inner = 0, zbl_rc_outer = 0;
   bool zbl_typewise = false;            // zbl <rc_inner> <rc_outer> <factor> (nep.cu:183-186)

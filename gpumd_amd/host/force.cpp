@@ -23,6 +23,7 @@ NEP_MI::NEP_MI(const char* file_potential, int num_atoms)
   nepmi_info info;
   nepmi_model_info(model_, &info);
   rc = info.rc_radial;
+  nep_model_type = info.model_type;
   N1 = 0;
   N2 = num_atoms;
   if (info.version == 0) { // Tersoff-1989
@@ -138,6 +139,15 @@ nepmi_engine* Force::engine() const
   return p ? p->engine() : nullptr;
 }
 
+bool Force::has_temperature_model() const
+{
+  for (auto& p : potentials)
+    if (auto* q = dynamic_cast<NEP_MI*>(p.get()))
+      if (q->nep_model_type == 3)
+        return true;
+  return false;
+}
+
 void Force::compute(
   Box& box, GPU_Vector<double>& position, GPU_Vector<int>& type, GPU_Vector<double>& potential,
   GPU_Vector<double>& force, GPU_Vector<double>& virial)
@@ -149,6 +159,11 @@ void Force::compute(
   nepmi_engine* e = engine();
   die_on(nepmi_apply_pbc(e, box.cpu_h, pbc, n, position.data()), "gpu_apply_pbc");
   die_on(nepmi_zero_properties(e, n, potential.data(), force.data(), virial.data()), "initialize_properties");
+  // potentials[i]->compute(temperature, ...) for temperature-dependent NEP models (force.cu:516-562)
+  for (auto& p : potentials)
+    if (auto* q = dynamic_cast<NEP_MI*>(p.get()))
+      if (q->nep_model_type == 3)
+        die_on(nepmi_engine_set_temperature(q->engine(), temperature), "set_temperature");
   if (multiple_potentials_mode_ == "observe") { // the main potential only
     potentials[0]->compute(box, type, position, potential, force, virial);
   } else if (multiple_potentials_mode_ == "average") { // every compute adds; then one division

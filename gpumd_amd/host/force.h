@@ -34,6 +34,7 @@ public:
     GPU_Vector<double>& potential, GPU_Vector<double>& force, GPU_Vector<double>& virial) override;
   nepmi_engine* engine() { return engine_; }
   void write_neighbor_out() const; // neighbor.out, nep.cu:1014-1034
+  int nep_model_type = 0; // potential.cuh:33-34: 3 = temperature-dependent NEP (gets Force::temperature per call)
 
 private:
   nepmi_model* model_ = nullptr;
@@ -52,6 +53,11 @@ public:
     GPU_Vector<double>& force, GPU_Vector<double>& virial);
   std::vector<std::unique_ptr<Potential>> potentials;
   nepmi_engine* engine() const; // the main (first) potential's engine
+  // temperature-dependent NEP: Run::parse_run sets temperature = T1 and delta_T = (T2 - T1) / steps (run.cu:679-681); every
+  // compute of a run -- the initial one (run.cu:232-241) and one per step -- adds delta_T first (force.cu:803)
+  double temperature = 0.0, delta_T = 0.0;
+  bool has_temperature_model() const;
+  void advance_temperature() { temperature += delta_T; }
   // several `potential` lines (NEP only): "observe" = the first one drives the run, the others are only
   // evaluated by dump_observer; "average" = the run uses their mean (force.cu:514-565, force.cuh:81)
   void set_multiple_potentials_mode(const std::string& mode) { multiple_potentials_mode_ = mode; }

@@ -623,8 +623,10 @@ void Run::run_segment(int steps, double t_a, double t_b)
   const int N = atom.number_of_atoms;
   const int pbc[3] = {box.pbc_x, box.pbc_y, box.pbc_z};
   nepmi_engine* e = force.engine();
-  if (force.potentials.size() > 1 && force.multiple_potentials_mode() == "average") {
-    // the run follows the MEAN of several potentials (force.cu:533-562): every step goes through Force::compute
+  const bool ramped_temperature_model = force.has_temperature_model() && force.delta_T != 0.0;
+  if ((force.potentials.size() > 1 && force.multiple_potentials_mode() == "average") || ramped_temperature_model) {
+    // the run follows the MEAN of several potentials (force.cu:533-562), or a temperature-dependent NEP sees a new
+    // temperature every step (force.cu:803): every step goes through Force::compute
     if (ensemble == "nvt_nhc" && !nhc_state_) {
       hip_check(hipMalloc((void**)&nhc_state_, sizeof(double) * NEPMI_NHC_STATE_SIZE), "hipMalloc");
       die_on(nepmi_nhc_init(e, N, t_a, temperature_coupling, time_step, nhc_state_), "nhc_init");
@@ -638,6 +640,7 @@ void Run::run_segment(int steps, double t_a, double t_b)
       die_on(nepmi_vv_step1(e, N, time_step, atom.mass.data(), atom.force_per_atom.data(), atom.position_per_atom.data(),
                             atom.velocity_per_atom.data()),
              "vv_step1");
+      force.advance_temperature(); // temperature += delta_T (force.cu:803)
       force.compute(box, atom.position_per_atom, atom.type, atom.potential_per_atom, atom.force_per_atom, atom.virial_per_atom);
       die_on(nepmi_vv_step2(e, N, time_step, atom.mass.data(), atom.force_per_atom.data(), atom.velocity_per_atom.data()),
              "vv_step2");
@@ -703,7 +706,13 @@ void Run::perform_a_run()
     std::fclose(fid);
   }
   dump_observer_open(); // measure.initialize precedes the first force call (run.cu:215)
-  // initial force (run.cu:220-232)
+  // target temperature of a temperature-dependent NEP (Run::parse_run, run.cu:679-681)
+  // (integrate.temperature1/2 keep the values of the last ensemble that had them; an NVE-only input leaves them
+  // uninitialised in the reference -- here they start at 300 K)
+  force.temperature = temperature1;
+  force.delta_T = (temperature2 - temperature1) / number_of_steps;
+  // initial force (run.cu:220-241): the same Force::compute overload as in the loop, so it advances the temperature too
+  force.advance_temperature();
   force.compute(box, atom.position_per_atom, atom.type, atom.potential_per_atom, atom.force_per_atom, atom.virial_per_atom);
   hip_check(hipDeviceSynchronize(), "sync");
   const auto t0 = std::chrono::steady_clock::now();
@@ -900,6 +909,10 @@ void Run::perform_a_run_dist()
     std::fprintf(fid, "# columns T KE PE sxx syy szz syz sxz sxy ax ay az bx by bz cx cy cz\n");
     std::fclose(fid);
   }
+  // temperature-dependent NEP: Force::temperature = T1 advanced once by the initial force call (run.cu:679-681, :232-241);
+  // no effect on plain models
+  die_on(nepmi_engine_set_temperature(nepmi_dist_engine(dist_),
+                                      temperature1 + (temperature2 - temperature1) / number_of_steps), "set_temperature");
   die_on(nepmi_dist_compute(dist_), "dist compute"); // the initial force
   hip_check(hipDeviceSynchronize(), "sync");
   const auto t0 = std::chrono::steady_clock::now();

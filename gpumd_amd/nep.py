@@ -274,6 +274,11 @@ class NEP:
         matrix-core ANN kernel; 2: the matrix-core kernel wherever it applies (no fusion)"""
         self._ck(self.lib.nepmi_engine_set_mfma(self.handle, int(on)))
 
+    def set_temperature(self, temperature):
+        """The `temperature` argument of NEP::compute(temperature, ...) for nep4[_zbl]_temperature models (no effect on
+        plain models); stays in force for later compute / run calls."""
+        self._ck(self.lib.nepmi_engine_set_temperature(self.handle, float(temperature)))
+
     def set_angular_recompute(self, mode=-1):
         self._ck(self.lib.nepmi_engine_set_angular_recompute(self.handle, int(mode)))
 

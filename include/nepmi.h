@@ -65,6 +65,8 @@ typedef struct {
   int dim, num_neurons;
   int num_para; /* ANN + descriptor parameters, without q_scaler */
   int has_q_112, has_q_123, has_q_233, has_q_134; /* optional extra 4-body rows (nep.cu:275-310) */
+  int model_type; /* nep.cuh:48: 0 = potential, 3 = temperature-dependent (nep4[_zbl]_temperature); `dim` counts the
+                   * descriptor components, the reference's annmb.dim is dim + 1 for model_type 3 (nep.cu:321-325) */
 } nepmi_info;
 
 const char* nepmi_last_error(void);
@@ -361,6 +363,16 @@ int nepmi_engine_set_mfma(nepmi_engine* e, int on);
  * records, -1 (default) = rebuilt when the model has few angular neighbours (MN_angular <= 16).
  * Both give bit-identical results. */
 int nepmi_engine_set_angular_recompute(nepmi_engine* e, int mode);
+/* Temperature-dependent NEP (nep4[_zbl]_temperature): the `temperature` argument of
+ * NEP::compute(const float temperature, Box&, ...) (src/force/nep.cuh:126, nep.cu:1813-1856; Force::compute passes
+ * its own `temperature`, advanced by delta_T before every compute of a run, force.cu:803).  It stays in force for
+ * every later compute / nepmi_run_nve call of this engine; the default is 0 K.  The thermostatted run loops
+ * (nepmi_run_nvt_*, nepmi_dist_run) set it themselves like Run::parse_run + Force::compute do: step s of a run from
+ * t1 to t2 sees t1 + (s + 2) (t2 - t1) / nsteps (the initial force call of the run has already advanced it once).  The extra ANN input q[dim] = temperature * q_scaler[dim]
+ * (nep.cu:1483-1486) is folded into the hidden-layer bias, so the kernels are the ones of a plain model.  For a model
+ * of any other type the call is accepted and has no effect (Potential::compute(temperature, ...) falls back to the
+ * plain overload, potential.cuh:46-56). */
+int nepmi_engine_set_temperature(nepmi_engine* e, double temperature);
 
 #ifdef __cplusplus
 }

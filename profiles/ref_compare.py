@@ -73,6 +73,16 @@ def case_inputs(name, d):
         run = ("replicate %d %d %d\n" % (reps, reps, reps) if reps > 1 else "") + (
             "potential nep.txt\nvelocity 300\nensemble nve\ntime_step 1\ndump_thermo %d\nrun %d\n" % (steps // 10, steps))
         n = 250 * reps ** 3
+    elif name == "pbte_temperature":
+        # temperature-dependent NEP (nep4_temperature): a synthetic model (the PbTe file + one ANN input, made by
+        # tests/test_temperature_nep.py) under a Berendsen ramp 300 -> 900 K: the ANN sees a new temperature every step
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import pathlib
+        from test_temperature_nep import make_temperature_model
+        make_temperature_model(pathlib.Path(d), zbl=False, name="nep.txt")
+        shutil.copy(os.path.join(GOLD, "PbTe", "model.xyz"), os.path.join(d, "model.xyz"))
+        run = "replicate 4 4 4\npotential nep.txt\nvelocity 300\nensemble nvt_ber 300 900 100\ntime_step 1\ndump_thermo 20\nrun 200\n"
+        n = 250 * 64
     elif name == "si_tersoff":
         lat, spec, pos = diamond_cell(5.432, "Si")
         write_xyz(os.path.join(d, "model.xyz"), lat, spec, pos)

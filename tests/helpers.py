@@ -63,6 +63,8 @@ def oracle_lib():
         L.nepo_model_symbol.argtypes = [C.c_void_p, C.c_int]
         L.nepo_model_param.restype = C.c_double
         L.nepo_model_param.argtypes = [C.c_void_p, C.c_int]
+        L.nepo_model_is_temperature.argtypes = [C.c_void_p]
+        L.nepo_model_set_temperature.argtypes = [C.c_void_p, C.c_double]
         L.nepo_lists_build.restype = C.c_void_p
         L.nepo_lists_build.argtypes = [C.c_void_p, C.c_int, _ip, _dp, _ip, _dp, C.c_int]
         L.nepo_lists_path.argtypes = [C.c_void_p]
@@ -103,6 +105,10 @@ class Oracle:
         if getattr(self, "h", None):
             oracle_lib().nepo_model_free(self.h)
             self.h = None
+
+    def set_temperature(self, temperature):
+        """the temperature argument of NEP::compute(temperature, ...) (temperature-dependent models)"""
+        oracle_lib().nepo_model_set_temperature(self.h, float(temperature))
 
     def compute(self, typ, h, pos_soa, pbc=(1, 1, 1), precision=32, path=-1, stages=False):
         L = oracle_lib()

@@ -29,6 +29,9 @@ CASES = {
     "carbon_nhc": (2e-6, 2e-6, 1e-3),   # Nose-Hoover chain
     "carbon_bdp": (2e-6, 2e-6, 1e-3),   # Bussi-Donadio-Parrinello, both programs with the fixed DEBUG seed
     "unep": (2e-6, 2e-6, 1e-3),
+    # temperature-dependent NEP (synthetic nep4_temperature model) under a 300 -> 900 K Berendsen ramp: the reference's
+    # NEP::compute(temperature, ...) with Force::temperature advanced by delta_T every step
+    "pbte_temperature": (2e-6, 2e-6, 1e-3),
 }
 
 
