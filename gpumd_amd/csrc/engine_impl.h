@@ -9,6 +9,7 @@
 #include "nep_md.h"
 #include "nep_model.h"
 #include "nep_window.h"
+#include "nep_highl.h"
 #include "tersoff_bodies.h"
 
 #include <cmath>
@@ -844,6 +845,7 @@ private:
       b_.q = dalloc<float>((size_t)m.dim * N);
       b_.fp = dalloc<float>((size_t)m.dim * N);
       b_.sbuf = dalloc<float>((size_t)(m.n_max_angular + 1) * kNumHarm * N);
+      b_.shi = m.L_max > 4 ? dalloc<float>((size_t)(m.n_max_angular + 1) * kHighSums * N) : nullptr;
       b_.KRP = ((m.basis_size_radial + 1) + 3) / 4 * 4;
       b_.atab = dalloc<float>((size_t)N * m.num_types * b_.KRP);
       const AnnMfmaShape as = ann_mfma_shape(m.num_types, m.dim, m.num_neurons, b_.KRP);
@@ -1159,6 +1161,8 @@ private:
       be_.template launch_lds<kAngFusedBlock>(kSlotAngular, N_, AngularDescBody<S>{md_, b_, recompute_s(), 1});
     else
       be_.template launch_lds<kAngDescBlock>(kSlotAngular, N_, AngularDescBody<S>{md_, b_, recompute_s(), 0});
+    if (!S::fixed && model_.L_max > 4) // rows l = 5..l_max_3body on top of the 24-sum kernel (nep_highl.h)
+      be_.template launch<64>(kSlotAngular, N_, HighLDescBody{md_, b_});
   }
 
   // Descriptor + ANN in one kernel (AngularDescBody::fuse_ann): the one-lane descriptor form, few types (the
@@ -1183,6 +1187,8 @@ private:
       be_.template launch_lds_pairs<64>(kSlotAngForce, N_, AngularForceBody<S>{md_, b_, recompute_s()});
     else
       be_.template launch_lds<64>(kSlotAngForce, N_, AngularForceBody<S>{md_, b_, recompute_s()});
+    if (!S::fixed && model_.L_max > 4)
+      be_.template launch<64>(kSlotAngForce, N_, HighLForceBody{md_, b_});
   }
 
   // ---- shape dispatch ----

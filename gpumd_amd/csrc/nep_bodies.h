@@ -68,8 +68,8 @@ struct Shape {
   static constexpr int KRM = KR_ >= 0 ? KR_ : 19;
   static constexpr int NAM = NA_ >= 0 ? NA_ : 19;
   static constexpr int KAM = KA_ >= 0 ? KA_ : 19;
-  static constexpr int NLM = NL_ >= 0 ? NL_ : 10; // L = 1..4, 222, 1111 and the four extra 4-body rows
-  static constexpr int kRows = NR_ >= 0 ? 6 : 10;  // invariant rows a kernel of this shape can meet
+  static constexpr int NLM = NL_ >= 0 ? NL_ : 14; // L = 1..8, 222, 1111 and the four extra 4-body rows
+  static constexpr int kRows = NR_ >= 0 ? 6 : 14;  // invariant rows a kernel of this shape can meet
   static constexpr int DIMM = (NRM + 1) + (NAM + 1) * NLM;
 };
 using ShapeGeneric = Shape<-1, -1, -1, -1, -1, 0>;
@@ -114,6 +114,7 @@ struct Bufs {
   float* q;    // [dim][N]
   float* fp;   // [dim][N]
   float* sbuf; // [(NA+1)*24][N]
+  float* shi;  // [(NA+1)*56][N] sums of l = 5..8 (models with l_max_3body > 4 only, nep_highl.h), else nullptr
   float* atab; // [N][T*KRP]
   int KRP;
   float* ann_img; // [T][AnnMfmaShape::img_floats] MFMA-operand-order weight images, or null

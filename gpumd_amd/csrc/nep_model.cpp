@@ -211,8 +211,8 @@ std::string load_nep_model(const std::string& path, NepModel& m, bool* unsupport
   m.has_q_123 = tok.size() >= 6 && std::atoi(tok[5].c_str()) != 0;
   m.has_q_233 = tok.size() >= 7 && std::atoi(tok[6].c_str()) != 0;
   m.has_q_134 = tok.size() >= 8 && std::atoi(tok[7].c_str()) != 0;
-  if (m.L_max < 1 || m.L_max > 4) // nep_utilities.cuh carries L up to 8; this engine holds the 24 sums of L <= 4
-    return unsup("l_max_3body should be 1..4 in this engine.");
+  if (m.L_max < 1 || m.L_max > 8) // NUM_OF_ABC = 80 sums, nep_utilities.cuh:18
+    return "l_max_3body should be 1..8.";
   // a row built from sums the model does not have would be identically zero (and inconsistent with its force)
   if ((m.has_q_222 && m.L_max < 2) || (m.has_q_112 && m.L_max < 2) || ((m.has_q_123 || m.has_q_233) && m.L_max < 3) ||
       (m.has_q_134 && m.L_max < 4))

@@ -9,8 +9,8 @@
 #include <stdlib.h>
 #include <string.h>
 
-#define NEPO_LMAX 4
-#define NEPO_NABC 24 /* (L_max+1)^2 - 1 for L_max = 4 */
+#define NEPO_LMAX 8
+#define NEPO_NABC 80 /* (L_max+1)^2 - 1 for L_max = 8 (NUM_OF_ABC, nep_utilities.cuh:18) */
 #define NEPO_MAX_BASIS 20
 #define NEPO_MAX_TYPES 94
 
@@ -18,25 +18,24 @@
  * constants of the NEP model definition (C3B[lm] = N_lm^2 of the real harmonics, e.g.
  * 3/(4 pi), 3/(8 pi), 5/(16 pi), 15/(8 pi), 15/(32 pi), ...; C4B/C5B the Clebsch-Gordan
  * contractions for (222) and (1111)). */
+/* sums 0..23 (l <= 4) as they stand in the reference's table; 24..79 (l = 5..8) and Z for every l from their definition
+ * (addition theorem), generated in exact arithmetic by gpumd_amd/csrc/tools/gen_highl_tables.py; the generated l <= 4
+ * values agree with the 24 below to 1e-14 (NEPO_C3B_LOW_CHECK, tests/test_high_l.py) and the whole set is pinned
+ * against NEP_CPU by the tests */
+#include "nep_highl_tables.inc"
 static const double NEPO_C3B[NEPO_NABC] = {
   0.238732414637843, 0.119366207318922, 0.119366207318922, 0.099471839432435, 0.596831036594608,
   0.596831036594608, 0.149207759148652, 0.149207759148652, 0.139260575205408, 0.104445431404056,
   0.104445431404056, 1.044454314040563, 1.044454314040563, 0.174075719006761, 0.174075719006761,
   0.011190581936149, 0.223811638722978, 0.223811638722978, 0.111905819361489, 0.111905819361489,
-  1.566681471060845, 1.566681471060845, 0.195835183882606, 0.195835183882606};
+  1.566681471060845, 1.566681471060845, 0.195835183882606, 0.195835183882606,
+  NEPO_C3B_HIGH_LIST};
 static const double NEPO_C4B[5] = {
   -0.007499480826664, -0.134990654879954, 0.067495327439977, 0.404971964639861, -0.809943929279723};
 #include "nep_invariants_extra.inc"
 static const double NEPO_C5B[3] = {0.026596810706114, 0.053193621412227, 0.026596810706114};
 
-/* Z[L][n1][n2]: coefficient of z^n2 in the (unnormalised) associated Legendre factor that
- * multiplies Re/Im (x+iy)^n1 (nep_utilities.cuh:87-103). */
-static const double NEPO_Z[NEPO_LMAX + 1][NEPO_LMAX + 1][NEPO_LMAX + 1] = {
-  {{0}},
-  {{0, 1}, {1, 0}},
-  {{-1, 0, 3}, {0, 1, 0}, {1, 0, 0}},
-  {{0, -3, 0, 5}, {-1, 0, 5, 0}, {0, 1, 0, 0}, {1, 0, 0, 0}},
-  {{3, 0, -30, 0, 35}, {0, -3, 0, 7, 0}, {-1, 0, 7, 0, 0}, {0, 1, 0, 0, 0}, {1, 0, 0, 0, 0}}};
+/* NEPO_Z[L][n1][n2]: coefficient of z^n2 in the factor that multiplies Re/Im (x+iy)^n1 (nep_utilities.cuh:87-141): generated above */
 
 static const char* NEPO_ELEMENTS[NEPO_MAX_TYPES] = {
   "H",  "He", "Li", "Be", "B",  "C",  "N",  "O",  "F",  "Ne", "Na", "Mg", "Al", "Si", "P",  "S",

@@ -83,6 +83,16 @@ def case_inputs(name, d):
         shutil.copy(os.path.join(GOLD, "PbTe", "model.xyz"), os.path.join(d, "model.xyz"))
         run = "replicate 4 4 4\npotential nep.txt\nvelocity 300\nensemble nvt_ber 300 900 100\ntime_step 1\ndump_thermo 20\nrun 200\n"
         n = 250 * 64
+    elif name == "pbte_lmax8":
+        # l_max_3body = 8 with the 222 and 1111 rows (80 sums per radial channel): a synthetic model on the PbTe descriptor
+        # coefficients, made by tests/test_high_l.py
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import pathlib
+        from test_high_l import make_high_l
+        make_high_l(pathlib.Path(d), 8, (1, 1), name="nep.txt")
+        shutil.copy(os.path.join(GOLD, "PbTe", "model.xyz"), os.path.join(d, "model.xyz"))
+        run = "replicate 4 4 4\npotential nep.txt\nvelocity 300\nensemble nve\ntime_step 1\ndump_thermo 20\nrun 200\n"
+        n = 250 * 64
     elif name == "si_tersoff":
         lat, spec, pos = diamond_cell(5.432, "Si")
         write_xyz(os.path.join(d, "model.xyz"), lat, spec, pos)

@@ -32,6 +32,8 @@ CASES = {
     # temperature-dependent NEP (synthetic nep4_temperature model) under a 300 -> 900 K Berendsen ramp: the reference's
     # NEP::compute(temperature, ...) with Force::temperature advanced by delta_T every step
     "pbte_temperature": (2e-6, 2e-6, 1e-3),
+    # l_max_3body = 8 (synthetic model): the reference's 80-sum path
+    "pbte_lmax8": (5e-6, 5e-6, 2e-3),
 }
 
 
