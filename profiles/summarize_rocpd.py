@@ -48,5 +48,33 @@ def pmc(db, out):
             w.writerow([short(r[0]), r[1], r[2], "%.4f" % (r[3] / r[2]), "%.2f" % (r[4] / 1e3)])
 
 
+def timeline(db, out):
+    """Gaps on the device timeline: for every pair (kernel A ends, kernel B starts next on the queue) the mean idle time
+    between them, over dispatches longer than 20 us (the discarded speculative launches of a run loop return at once)."""
+    cur = sqlite3.connect(db).cursor()
+    rows = cur.execute("select name, start, end from kernels order by start").fetchall()
+    rows = [(short(n), s, e) for n, s, e in rows if e - s > 20000]
+    gaps = {}
+    busy = idle = 0
+    for (n0, s0, e0), (n1, s1, e1) in zip(rows, rows[1:]):
+        g = s1 - e0
+        if g > 2000000:  # a host-side pause (rebuild, set-up), not a launch gap
+            continue
+        k = (n0, n1)
+        a = gaps.setdefault(k, [0, 0.0, 0.0])
+        a[0] += 1
+        a[1] += g
+        a[2] += e1 - s1
+        busy += e1 - s1
+        idle += max(g, 0)
+    with open(out, "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel_before", "kernel_after", "count", "mean_gap_us", "mean_duration_after_us"])
+        for (n0, n1), (c, g, d) in sorted(gaps.items(), key=lambda kv: -kv[1][0]):
+            if c >= 5:
+                w.writerow([n0, n1, c, "%.2f" % (g / c / 1e3), "%.2f" % (d / c / 1e3)])
+        w.writerow(["TOTAL busy_us / idle_us / idle fraction", "", "", "%.1f" % (busy / 1e3), "%.1f / %.4f" % (idle / 1e3, idle / max(busy + idle, 1))])
+
+
 if __name__ == "__main__":
-    {"stats": stats, "pmc": pmc}[sys.argv[1]](sys.argv[2], sys.argv[3])
+    {"stats": stats, "pmc": pmc, "timeline": timeline}[sys.argv[1]](sys.argv[2], sys.argv[3])

@@ -24,6 +24,7 @@ CASES = {
     # case: (rtol T/K, rtol U, atol P [GPa])
     "si_tersoff": (1e-10, 1e-10, 1e-8),
     "pbte_16k": (1e-6, 1e-6, 1e-3),
+    "pbte_250": (2e-6, 2e-6, 2e-3),     # the small-box branch of both programs (nep_small_box.cuh / SmallBoxPairsBody)
     "carbon_nve": (2e-6, 2e-6, 1e-3),
     "carbon_nvt": (2e-6, 2e-6, 1e-3),   # Berendsen
     "carbon_nhc": (2e-6, 2e-6, 1e-3),   # Nose-Hoover chain
