@@ -368,8 +368,8 @@ int nepmi_engine_set_angular_recompute(nepmi_engine* e, int mode);
  * its own `temperature`, advanced by delta_T before every compute of a run, force.cu:803).  It stays in force for
  * every later compute / nepmi_run_nve call of this engine; the default is 0 K.  The thermostatted run loops
  * (nepmi_run_nvt_*, nepmi_dist_run) set it themselves like Run::parse_run + Force::compute do: step s of a run from
- * t1 to t2 sees t1 + (s + 2) (t2 - t1) / nsteps (the initial force call of the run has already advanced it once).  The extra ANN input q[dim] = temperature * q_scaler[dim]
- * (nep.cu:1483-1486) is folded into the hidden-layer bias, so the kernels are the ones of a plain model.  For a model
+ * t1 to t2 sees t1 + (s + 2) (t2 - t1) / nsteps (the initial force call of the run has already advanced it once).
+ * The extra ANN input q[dim] = temperature * q_scaler[dim] (nep.cu:1483-1486) is folded into the hidden-layer bias, so the kernels are the ones of a plain model.  For a model
  * of any other type the call is accepted and has no effect (Potential::compute(temperature, ...) falls back to the
  * plain overload, potential.cuh:46-56). */
 int nepmi_engine_set_temperature(nepmi_engine* e, double temperature);
