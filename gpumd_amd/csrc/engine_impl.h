@@ -873,6 +873,7 @@ private:
     b_.fo = dalloc<double>((size_t)kOutPlanes * N);
     b_.zbl = dalloc<float>(m.zbl_enabled ? (size_t)10 * N : 1);
     b_.lvl = dalloc<signed char>(N);
+    b_.angf = dalloc<signed char>(N);
     b_.tperm = dalloc<int>(N);
     b_.tpos = dalloc<int>(N);
     b_.tcount = dalloc<int>(((size_t)(N >> kTypeChunkShift) + 2) * m.num_types + 2);

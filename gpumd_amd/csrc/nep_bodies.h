@@ -123,6 +123,8 @@ struct Bufs {
   int* flags;  // [kNumFlags]
   const signed char* level; // caller order, or nullptr: 2 owned, 1 inner ghost, 0 outer ghost
   signed char* lvl;         // [N] the same in internal order (sampled at list rebuild)
+  signed char* angf;        // [N] 1 = this atom's partial angular forces f12 are needed: it is owned, or an inner-ring ghost with an
+                            // owned atom in its list A (decided at the rebuild; nobody reads the f12 of the other ghosts)
   int* tperm;               // [N] atoms ordered by (chunk of 1024, type): the ANN kernel's work order
   int* tpos;                // [N] inverse of tperm: q and fp are stored in work order, [dim][tpos]
   int* tcount;              // [(nchunks * T) + 1] histogram / offsets of that order
@@ -619,6 +621,7 @@ struct BuildListsBody {
     // periodic directions wrap (>= 5 bins guaranteed), non-periodic ones stop at the box edge
     const int lx = b.nbx > 1 ? 2 : 0, ly = b.nby > 1 ? 2 : 0, lz = b.nbz > 1 ? 2 : 0;
     int cnta = 0, cntb = 0;
+    bool near_owned = false; // an owned atom within rc_a + skin: only then can an owned atom ask for this atom's f12
     for (int kz = -lz; kz <= lz; ++kz) {
       int z2 = cz + kz;
       if (box.pbc[2]) { if (z2 < 0) z2 += b.nbz; else if (z2 >= b.nbz) z2 -= b.nbz; }
@@ -649,6 +652,7 @@ struct BuildListsBody {
                   b.code_ang[(int64_t)cnta * N + k] = code;
                 }
                 ++cnta;
+                near_owned = near_owned || b.lvl[j] >= 2;
               } else {
                 if (cntb < b.MN_skin) {
                   b.nl_skin[(int64_t)cntb * N + k] = j;
@@ -670,6 +674,7 @@ struct BuildListsBody {
     }
     b.nn_ang[k] = cnta;
     b.nn_skin[k] = cntb;
+    b.angf[k] = (b.lvl[k] >= 2 || (b.lvl[k] == 1 && near_owned)) ? 1 : 0;
   }
 };
 
@@ -902,6 +907,7 @@ struct SmallBoxPairsBody {
     b.tperm[k] = (int)k;
     b.tpos[k] = (int)k;
     b.lvl[k] = 2;
+    b.angf[k] = 1;
     int cnta = 0, cntb = 0;
     for (int64_t j = 0; j < N; ++j) {
       const int t2 = type[j];
@@ -1763,7 +1769,7 @@ struct AngularForceBody {
   {
     constexpr int NLOC = (S::NAM + PARTS) / PARTS;
     const int64_t N = b.N;
-    if (b.lvl[k] < 1)
+    if (b.lvl[k] < 1 || !b.angf[k]) // outer ghosts; inner-ring ghosts whose f12 no owned atom will read
       return;
     const int64_t gk = b.tpos[k]; // q / fp column of this atom (work order)
     const int NR = S::fixed ? S::NR : m.NR;

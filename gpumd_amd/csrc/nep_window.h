@@ -226,6 +226,7 @@ struct RadialWinBody {
       q[n] = 0.0f;
 
     const int na = b.nn_ang[k], nbn = b.nn_skin[k];
+    const bool owned = b.lvl[k] >= 2;
     int cnt = 0, cnt1 = 0, ca = 0; // cnt: entries at the front of ccode, cnt1: at its back (type-1 neighbours)
     F4* __restrict__ acomp = b.acomp + k;
     unsigned short* __restrict__ amap = b.amap + k;
@@ -290,7 +291,7 @@ struct RadialWinBody {
           pos = cnt;
           ++cnt;
         }
-        if (cnt + cnt1 <= b.MN_rad)
+        if (owned && cnt + cnt1 <= b.MN_rad) // the compact list is read by the force assembly: owned atoms only
           ccode[(int64_t)pos * N] = (unsigned short)slot;
       }
       c.inside = inside;
