@@ -907,7 +907,10 @@ struct ForceWinBody {
   WinStage st;
   ModelD m;
   const int* frozen;
-  static constexpr int kMinWavesPerEu = L == 1 ? NEPMI_FW_WAVES : 1; // 4: <= 128 VGPRs, four 256-thread workgroups per CU
+  // 4: <= 128 VGPRs, four 256-thread workgroups per CU.  Shapes with register-resident table rows of 9 or more
+  // coefficients (carbon: 11) spill 60-90 bytes per lane there; three wavefronts (<= 168 VGPRs) keep them in registers
+  // (carbon 1 M atoms: 1.09 -> 0.97 ms)
+  static constexpr int kMinWavesPerEu = L != 1 ? 1 : ((S::TS > 0 && S::KR >= 8) ? 3 : NEPMI_FW_WAVES);
   static constexpr int kLanes = L;
 
   NEPMI_HD int lds_bytes() const { return st.lay.bytes(); }

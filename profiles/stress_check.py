@@ -39,7 +39,8 @@ def report(name, fn):
 
 def nvt(kind):
     def run():
-        h, typ, x, mass, _ = bench.build_pbte((10, 10, 10))
+        from gpumd_amd import structures as S
+        h, typ, x, mass, _ = S.pbte_block((10, 10, 10))
         eng, t, pe, f, w, n = setup(H.golden("PbTe", "nep.txt"), h, typ, x, mass, 300.0)
         fn = getattr(eng, "run_nvt_" + kind)
         th = fn(h, t[0], t[3], dt, 1500, 300.0, 300.0, 100.0, t[1], t[2], pe, f, w, thermo_every=500)
