@@ -347,6 +347,38 @@ int nepmi_run_nvt_bdp(
   });
 }
 
+int nepmi_lan_seed(nepmi_engine* e, int seed)
+{
+  if (!e)
+    return fail(NEPMI_ERR_ARG, "null engine");
+  e->e->lan_seed(seed);
+  return NEPMI_OK;
+}
+
+int nepmi_lan_half_step(nepmi_engine* e, int64_t n, double temperature, double t_coup, const double* mass, double* vel)
+{
+  if (!e || !mass || !vel)
+    return fail(NEPMI_ERR_ARG, "bad argument");
+  if (t_coup < 1.0)
+    return fail(NEPMI_ERR_ARG, "Temperature coupling should >= 1.");
+  return guarded([&] { e->e->lan_half_step(n, temperature, t_coup, mass, vel); });
+}
+
+int nepmi_run_nvt_lan(
+  nepmi_engine* e, const double h[9], const int pbc[3], int64_t n, const int* type, const double* mass,
+  double dt, int64_t nsteps, double t1, double t2, double t_coup, double* pos, double* vel, double* pe,
+  double* force, double* virial, int64_t thermo_every, double* thermo_host)
+{
+  if (!e)
+    return fail(NEPMI_ERR_ARG, "null engine");
+  if (t_coup < 1.0)
+    return fail(NEPMI_ERR_ARG, "Temperature coupling should >= 1.");
+  return guarded([&] {
+    e->e->run_md(e->e->kLan, h, pbc, n, type, mass, dt, nsteps, t1, t2, t_coup, pos, vel, pe, force, virial, thermo_every,
+                 thermo_host);
+  });
+}
+
 int nepmi_neighbors_export(nepmi_engine* e, int which, int* nn, int* nl, int64_t ld)
 {
   if (!e || which < 0 || which > 2 || !nn || !nl)

@@ -8,6 +8,7 @@
 // path other than the 32-byte flag read-back per force call (the reference's 4-byte skin-check
 // D2H, neighbor.cu:752, extended with overflow flags).
 #include <hip/hip_runtime.h>
+#include <hiprand/hiprand_kernel.h> // XORWOW states of the Langevin thermostat (device API only)
 
 #include <cstring>
 #include <stdexcept>
@@ -485,6 +486,71 @@ __global__ void __launch_bounds__(kScanBlock) nepmi_scan_add(int* data, int64_t 
       data[base + k] += add;
 }
 
+// ---- Langevin thermostat (Ensemble_LAN, src/integrate/ensemble_lan.cu:30-41, :96-127; kernels of
+//      src/integrate/langevin_utilities.cuh:24-124).  One XORWOW state per atom, hiprand_init(seed, n, 0, ...) like the
+//      reference (its gpurand_* are hiprand_* in the HIP build), v <- c1 v + c2 sqrt(1/m) xi with three
+//      hiprand_normal_double draws per atom, then the centre-of-mass velocity is removed.  The four sums (m vx, m vy,
+//      m vz, m) are formed by four 1024-thread blocks in the same order as gpu_find_momentum, so the corrected
+//      velocities equal the reference's bit for bit (tests/test_langevin.py pins them on its kernels). ----
+
+__global__ void nepmi_lan_init(hiprandState* state, const int64_t N, const int seed)
+{
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n < N)
+    hiprand_init(seed, n, 0, &state[n]);
+}
+
+__global__ void nepmi_lan_kick(
+  hiprandState* g_state, const int64_t N, const double c1, const double c2, const double* __restrict__ g_mass, double* g_v)
+{
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n < N) {
+    hiprandState state = g_state[n];
+    const double c2m = c2 * sqrt(1.0 / g_mass[n]);
+    g_v[n] = c1 * g_v[n] + c2m * hiprand_normal_double(&state);
+    g_v[N + n] = c1 * g_v[N + n] + c2m * hiprand_normal_double(&state);
+    g_v[2 * N + n] = c1 * g_v[2 * N + n] + c2m * hiprand_normal_double(&state);
+    g_state[n] = state;
+  }
+}
+
+// block b < 3: sum_n m v_b, block 3: sum_n m; thread t takes atoms t, t + 1024, ... then a binary tree over the threads
+__global__ void __launch_bounds__(1024) nepmi_momentum_sum(
+  const int64_t N, const double* __restrict__ g_mass, const double* __restrict__ g_v, double* __restrict__ sums4)
+{
+  __shared__ double s_sum[1024];
+  const int tid = threadIdx.x, bid = blockIdx.x;
+  double acc = 0.0;
+  if (bid < 3) { // the product and the sum contract to one fma, as in the reference's build of gpu_find_momentum
+    const double* __restrict__ v = g_v + (int64_t)bid * N;
+    for (int64_t n = tid; n < N; n += 1024)
+      acc += g_mass[n] * v[n];
+  } else {
+    for (int64_t n = tid; n < N; n += 1024)
+      acc += g_mass[n];
+  }
+  s_sum[tid] = acc;
+  __syncthreads();
+  for (int offset = 512; offset > 0; offset >>= 1) {
+    if (tid < offset)
+      s_sum[tid] += s_sum[tid + offset];
+    __syncthreads();
+  }
+  if (tid == 0)
+    sums4[bid] = s_sum[0];
+}
+
+__global__ void nepmi_momentum_fix(const int64_t N, const double* __restrict__ sums4, double* g_v)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) {
+    const double inverse_of_total_mass = 1.0 / sums4[3];
+    g_v[i] -= sums4[0] * inverse_of_total_mass;
+    g_v[N + i] -= sums4[1] * inverse_of_total_mass;
+    g_v[2 * N + i] -= sums4[2] * inverse_of_total_mass;
+  }
+}
+
 // ---- Ensemble::find_thermo (ensemble.cu:434-673): 8 sums in one pass over the atoms ----
 constexpr int kThermoBlock = 256;
 constexpr int kThermoMaxBlocks = 1024;
@@ -942,6 +1008,22 @@ struct HipBackend {
                        thermo8, raw);
     NEPMI_HIP_CHECK(hipGetLastError());
     (void)slot;
+  }
+
+  // Langevin thermostat (kernels above): per-atom generator states, one half-step
+  size_t lan_state_bytes() const { return sizeof(hiprandState); }
+  void lan_init(void* states, int64_t n, int seed)
+  {
+    hipLaunchKernelGGL(nepmi_lan_init, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, stream, (hiprandState*)states, n, seed);
+    NEPMI_HIP_CHECK(hipGetLastError());
+  }
+  void lan_half(void* states, int64_t n, double c1, double c2, const double* mass, double* vel, double* sums4)
+  {
+    const unsigned grid = (unsigned)((n + 127) / 128);
+    hipLaunchKernelGGL(nepmi_lan_kick, dim3(grid), dim3(128), 0, stream, (hiprandState*)states, n, c1, c2, mass, vel);
+    hipLaunchKernelGGL(nepmi_momentum_sum, dim3(4), dim3(1024), 0, stream, n, mass, vel, sums4);
+    hipLaunchKernelGGL(nepmi_momentum_fix, dim3(grid), dim3(128), 0, stream, n, sums4, vel);
+    NEPMI_HIP_CHECK(hipGetLastError());
   }
 };
 

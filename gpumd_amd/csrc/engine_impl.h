@@ -344,6 +344,31 @@ public:
     be_.template launch<256>(kSlotMisc, n, ScaleVelocityBody{n, state + 3 * kNhcLinks, vel});
   }
 
+  // ---- Langevin thermostat (Ensemble_LAN, ensemble_lan.cu): one generator state per atom, in the CALLER's atom order
+  //      (the reference initialises state n with hiprand_init(seed, n, 0)); seed = rand() there (ensemble_lan.cu:39) ----
+  void lan_seed(int seed)
+  {
+    lan_seed_ = seed;
+    lan_fresh_ = true;
+  }
+  // integrate_nvt_lan_half (ensemble_lan.cu:96-127): v <- c1 v + c2 sqrt(1/m) xi, then the centre-of-mass velocity is removed
+  void lan_half_step(int64_t n, double temperature, double t_coup, const double* mass, double* vel)
+  {
+    if (n < 1 || n > cap_)
+      throw EngineError{-4, "number of atoms exceeds the engine's capacity"};
+    if (!lan_states_) {
+      lan_states_ = dalloc<char>(be_.lan_state_bytes() * (size_t)cap_);
+      lan_sums_ = dalloc<double>(4);
+    }
+    if (lan_fresh_) {
+      be_.lan_init(lan_states_, n, lan_seed_);
+      lan_fresh_ = false;
+    }
+    const double c1 = std::exp(-0.5 / t_coup);
+    const double c2 = std::sqrt((1.0 - c1 * c1) * kBoltzmann * temperature);
+    be_.lan_half(lan_states_, n, c1, c2, mass, vel, lan_sums_);
+  }
+
   // ---- Bussi-Donadio-Parrinello stochastic velocity rescaling (Ensemble_BDP, ensemble_bdp.cu:71-104;
   //      resamplekin & co., svr_utilities.cuh:28-122, after Bussi's reference code).  Like the
   //      reference the noise is drawn on the host from std::mt19937 through
@@ -452,7 +477,7 @@ public:
   // at it only every kPollEvery steps (and at thermo records), rebuilds the lists and resumes from the frozen
   // step.  The caller's arrays are read at entry and written at exit.
   // ---------------------------------------------------------------------------------------------
-  enum Ensemble { kNve = 0, kBer = 1, kNhc = 2, kBdp = 3 };
+  enum Ensemble { kNve = 0, kBer = 1, kNhc = 2, kBdp = 3, kLan = 4 };
   static constexpr int kPollEvery = 4; // steps between two snapshots of the device flags
   static constexpr int kPollDepth = 2; // snapshots in flight: the host runs 8-12 steps ahead of the device
 
@@ -465,7 +490,9 @@ public:
     box_from_h9(h9, pbc, box);
     if (n < 1 || n > cap_)
       throw EngineError{-4, "number of atoms exceeds the engine's capacity"};
-    if (is_small_box(box) && model_.kind == 0) {
+    if ((is_small_box(box) && model_.kind == 0) || ens == kLan) {
+      // (Langevin: the generator states follow the caller's atom order, like the reference's; the stepwise loop
+      // works on the caller's arrays)
       run_md_small_box(ens, h9, pbc, n, type, mass, dt, nsteps, t1, t2, tcoup, pos, vel, pe, force, virial, thermo_every,
                        thermo_host);
       return;
@@ -647,6 +674,8 @@ public:
       if (ens == kNhc) {
         find_thermo(n, box.volume, mass, pe, vel, virial, thermo_dev_);
         nhc_half_step(n, target, dt, thermo_dev_, nhc_dev_, vel);
+      } else if (ens == kLan) { // Ensemble_LAN::compute1, ensemble_lan.cu:206-218
+        lan_half_step(n, target, tcoup, mass, vel);
       }
       velocity_verlet(true, n, dt, mass, force, pos, vel, &box);
       zero_properties(n, pe, force, virial);
@@ -655,7 +684,9 @@ public:
       potential_compute(h9, pbc, n, type, pos, pe, force, virial);
       velocity_verlet(false, n, dt, mass, force, pos, vel, nullptr);
       const bool record = thermo_every > 0 && (step + 1) % thermo_every == 0;
-      if (ens != kNve || record)
+      if (ens == kLan) // Ensemble_LAN::compute2 (:241-262): second half-step of the thermostat, then find_thermo
+        lan_half_step(n, target, tcoup, mass, vel);
+      if ((ens != kNve && ens != kLan) || record)
         find_thermo(n, box.volume, mass, pe, vel, virial, thermo_dev_);
       if (ens == kBer)
         berendsen(n, target, 1.0 / tcoup, thermo_dev_, vel);
@@ -1396,6 +1427,10 @@ private:
   int tile_mode_ = -1;           // -1 auto, 0 none, 1 radial window only, 2 radial + force windows
   bool records_valid_ = false; // rstash holds the pair records of the last evaluated positions
   int recompute_mode_ = -1;
+  char* lan_states_ = nullptr; // Langevin generator states (backend-defined size per atom)
+  double* lan_sums_ = nullptr;
+  int lan_seed_ = 12345678;
+  bool lan_fresh_ = true;
   double temperature_ = 0.0;  // set_temperature (temperature-dependent models)
   std::vector<float> b0_eff_; // hidden-layer bias with the temperature input folded in
   int ann_mode_ = 1;

@@ -418,6 +418,8 @@ struct GlibcRand {
 };
 static GlibcRand g_rand; // the process-wide stream of rand(), default seed 1 like the C library's
 
+int host_rand() { return g_rand.next(); } // the next draw of the process-wide stream (what rand() returns in the reference)
+
 int host_rand_for_tests(unsigned seed, bool reseed)
 {
   if (reseed)

@@ -100,6 +100,7 @@ bool read_xyz(
 void replicate(const int n[3], Box& box, Atom& atom, std::vector<Group>& groups);
 // Velocity::initialize (velocity.cu:312-347): glibc rand() stream, momentum corrections, rescale
 void initialize_velocity(double temperature, bool use_seed, int seed, Atom& atom);
+int host_rand(); // rand() of the restated glibc stream (seeds of the Langevin generators, ensemble_lan.cu:39)
 int host_rand_for_tests(unsigned seed, bool reseed); // the restated glibc rand() stream (gpumd-mi --rand-check)
 // Velocity::correct_velocity (velocity.cu:210-271): zero the linear and angular momentum of the listed atoms
 // (all atoms when contents == nullptr); host arrays, SoA with stride N

@@ -171,7 +171,7 @@ void Run::parse_one_keyword(const std::vector<std::string>& p)
       input_error("ensemble should have at least 1 parameter.");
     if (p[1] == "nve") {
       std::printf("Use NVE ensemble for this run.\n");
-    } else if (p[1] == "nvt_ber" || p[1] == "nvt_nhc" || p[1] == "nvt_bdp") { // Integrate::parse_ensemble, integrate.cu:424-432, 569-600
+    } else if (p[1] == "nvt_ber" || p[1] == "nvt_nhc" || p[1] == "nvt_bdp" || p[1] == "nvt_lan") { // Integrate::parse_ensemble, integrate.cu:424-437, 569-600
       if (p.size() != 5)
         input_error("ensemble " + p[1] + " should have 3 parameters.");
       temperature1 = std::atof(p[2].c_str());
@@ -183,9 +183,10 @@ void Run::parse_one_keyword(const std::vector<std::string>& p)
         input_error("Temperature coupling should >= 1.");
       std::printf("Use NVT ensemble for this run.\n    choose the %s method.\n    initial temperature is %g K.\n"
                   "    final temperature is %g K.\n    tau_T is %g time_step.\n",
-                  p[1] == "nvt_ber" ? "Berendsen" : p[1] == "nvt_nhc" ? "Nose-Hoover chain" : "Bussi-Donadio-Parrinello", temperature1, temperature2, temperature_coupling);
+                  p[1] == "nvt_ber" ? "Berendsen" : p[1] == "nvt_nhc" ? "Nose-Hoover chain" : p[1] == "nvt_lan" ? "Langevin" : "Bussi-Donadio-Parrinello",
+                  temperature1, temperature2, temperature_coupling);
     } else {
-      input_error("ensemble " + p[1] + " is not available in gpumd-mi yet (nve, nvt_ber, nvt_nhc, nvt_bdp; DESIGN.md section 8).");
+      input_error("ensemble " + p[1] + " is not available in gpumd-mi yet (nve, nvt_ber, nvt_nhc, nvt_bdp, nvt_lan; DESIGN.md section 8).");
     }
     ensemble = p[1];
   } else if (k == "time_step") {
@@ -636,6 +637,8 @@ void Run::run_segment(int steps, double t_a, double t_b)
       if (ensemble == "nvt_nhc") { // integrate_nvt_nhc_1, ensemble_nhc.cu:166-197
         find_thermo();
         die_on(nepmi_nhc_half_step(e, N, target, time_step, thermo.data(), nhc_state_, atom.velocity_per_atom.data()), "nhc");
+      } else if (ensemble == "nvt_lan") { // Ensemble_LAN::compute1
+        die_on(nepmi_lan_half_step(e, N, target, temperature_coupling, atom.mass.data(), atom.velocity_per_atom.data()), "lan");
       }
       die_on(nepmi_vv_step1(e, N, time_step, atom.mass.data(), atom.force_per_atom.data(), atom.position_per_atom.data(),
                             atom.velocity_per_atom.data()),
@@ -644,6 +647,8 @@ void Run::run_segment(int steps, double t_a, double t_b)
       force.compute(box, atom.position_per_atom, atom.type, atom.potential_per_atom, atom.force_per_atom, atom.virial_per_atom);
       die_on(nepmi_vv_step2(e, N, time_step, atom.mass.data(), atom.force_per_atom.data(), atom.velocity_per_atom.data()),
              "vv_step2");
+      if (ensemble == "nvt_lan") // Ensemble_LAN::compute2: the thermostat's second half-step precedes find_thermo
+        die_on(nepmi_lan_half_step(e, N, target, temperature_coupling, atom.mass.data(), atom.velocity_per_atom.data()), "lan");
       if (ensemble != "nve" || s + 1 == steps)
         find_thermo();
       if (ensemble == "nvt_ber")
@@ -666,6 +671,9 @@ void Run::run_segment(int steps, double t_a, double t_b)
                            temperature_coupling, x, v, pe, f, w, steps, th);
   else if (ensemble == "nvt_nhc")
     st = nepmi_run_nvt_nhc(e, box.cpu_h, pbc, N, atom.type.data(), atom.mass.data(), time_step, steps, t_a, t_b,
+                           temperature_coupling, x, v, pe, f, w, steps, th);
+  else if (ensemble == "nvt_lan")
+    st = nepmi_run_nvt_lan(e, box.cpu_h, pbc, N, atom.type.data(), atom.mass.data(), time_step, steps, t_a, t_b,
                            temperature_coupling, x, v, pe, f, w, steps, th);
   else
     st = nepmi_run_nvt_bdp(e, box.cpu_h, pbc, N, atom.type.data(), atom.mass.data(), time_step, steps, t_a, t_b,
@@ -720,6 +728,11 @@ void Run::perform_a_run()
   if (nhc_state_) {
     (void)hipFree(nhc_state_);
     nhc_state_ = nullptr;
+  }
+  if (ensemble == "nvt_lan") { // Ensemble_LAN::Ensemble_LAN (ensemble_lan.cu:39): the generator states are seeded with rand()
+    const int seed = host_rand();
+    die_on(nepmi_lan_seed(e, seed), "lan_seed");
+    std::printf("    Langevin generator seed = %d.\n", seed);
   }
   if (ensemble == "nvt_bdp") { // Ensemble_BDP::initialize_rng (ensemble_bdp.cu:32-39): seeded from the clock
     // GPUMD_MI_DEBUG=1 is the run-time counterpart of the reference's -DDEBUG build: the fixed seed 12345678
@@ -901,6 +914,8 @@ void Run::perform_a_run_dist()
       input_error("unwrapped positions are not tracked in multi-GPU runs.");
   const int N = atom.number_of_atoms;
   const bool root = par_.rank == 0;
+  if (ensemble == "nvt_lan")
+    input_error("ensemble nvt_lan is not available in multi-GPU runs (nve, nvt_ber, nvt_nhc, nvt_bdp).");
   const int ens = ensemble == "nve" ? 0 : ensemble == "nvt_ber" ? 1 : ensemble == "nvt_nhc" ? 2 : 3;
   if (root && dump_thermo_interval > 0) {
     FILE* fid = std::fopen("thermo.out", "a");

@@ -218,6 +218,22 @@ int nepmi_run_nvt_bdp(
   const double* mass, double dt, int64_t nsteps, double t1, double t2, double t_coup, double* pos,
   double* vel, double* pe, double* force, double* virial, int64_t thermo_every, double* thermo_host);
 
+/* ---- Langevin thermostat: Ensemble_LAN (src/integrate/ensemble_lan.cu:30-41, :96-127, :206-262; kernels of
+ *      src/integrate/langevin_utilities.cuh), `ensemble nvt_lan T1 T2 T_coup`.  One XORWOW generator state per atom
+ *      (hiprand_init(seed, n, 0), n = the caller's atom index, as in the reference, which takes seed = rand()):
+ *      nepmi_lan_seed sets the seed and makes the next half-step initialise the states (default 12345678).
+ *      nepmi_lan_half_step = integrate_nvt_lan_half: v <- c1 v + c2 sqrt(1/m) xi with c1 = exp(-1/(2 T_coup)),
+ *      c2 = sqrt((1 - c1^2) k_B T), three normal draws per atom, then the centre-of-mass velocity is removed (the four
+ *      sums in gpu_find_momentum's order: with the same seed the velocities equal the reference kernels' bit for bit).
+ *      A step of the ensemble: lan_half_step, vv_step1, force, vv_step2, lan_half_step, find_thermo.
+ *      nepmi_run_nvt_lan is that loop on the caller's arrays (the states follow the caller's atom order). ---- */
+int nepmi_lan_seed(nepmi_engine* e, int seed);
+int nepmi_lan_half_step(nepmi_engine* e, int64_t n, double temperature, double t_coup, const double* mass, double* vel);
+int nepmi_run_nvt_lan(
+  nepmi_engine* e, const double h[9], const int pbc[3], int64_t n, const int* type,
+  const double* mass, double dt, int64_t nsteps, double t1, double t2, double t_coup, double* pos,
+  double* vel, double* pe, double* force, double* virial, int64_t thermo_every, double* thermo_host);
+
 /* ---- multi-GPU: spatial domain decomposition, one process per GPU ----
  *      Replaces NEP_MULTIGPU (src/force/nep_multigpu.cuh:42-50 ranges, nep_multigpu.cu:1416-1803 compute) and
  *      Force::parse_potential's choice of it for `potential <file> [x|y|z]` (src/force/force.cu:122-160).  Every

@@ -9,6 +9,8 @@
 // refuses to run without a gfx950 device.
 #include <cstdlib>
 #include <cstring>
+#include <new>
+#include <random>
 #include <vector>
 
 #include "../../gpumd_amd/csrc/nep_bodies.h"
@@ -125,6 +127,37 @@ struct HostLoopBackend {
       data[i] = run;
       run += v;
     }
+  }
+
+  // Langevin thermostat, host stand-in: the same update with a different normal generator (std::mt19937_64 per atom
+  // seeded from (seed, n)); the reference's XORWOW stream is pinned on the GPU tier only
+  size_t lan_state_bytes() const { return sizeof(std::mt19937_64); }
+  void lan_init(void* states, int64_t n, int seed)
+  {
+    std::mt19937_64* st = (std::mt19937_64*)states;
+    for (int64_t i = 0; i < n; ++i)
+      new (&st[i]) std::mt19937_64((uint64_t)seed * 1000003ull + (uint64_t)i);
+  }
+  void lan_half(void* states, int64_t n, double c1, double c2, const double* mass, double* vel, double* sums4)
+  {
+    std::mt19937_64* st = (std::mt19937_64*)states;
+    std::normal_distribution<double> nd(0.0, 1.0);
+    for (int64_t i = 0; i < n; ++i) {
+      const double c2m = c2 * std::sqrt(1.0 / mass[i]);
+      for (int d = 0; d < 3; ++d)
+        vel[d * n + i] = c1 * vel[d * n + i] + c2m * nd(st[i]);
+    }
+    double s[4] = {0, 0, 0, 0};
+    for (int64_t i = 0; i < n; ++i) {
+      for (int d = 0; d < 3; ++d)
+        s[d] += mass[i] * vel[d * n + i];
+      s[3] += mass[i];
+    }
+    for (int d = 0; d < 4; ++d)
+      sums4[d] = s[d];
+    for (int64_t i = 0; i < n; ++i)
+      for (int d = 0; d < 3; ++d)
+        vel[d * n + i] -= s[d] / s[3];
   }
 
   void thermo(

@@ -113,3 +113,15 @@ def test_correct_velocity_and_direction_token(tmp_path):
     bad = _workdir(str(tmp_path / "d"), "potential NEP q\nrun 1\n")
     res = subprocess.run([EXE], cwd=bad, capture_output=True, text=True)
     assert res.returncode != 0 and "partition direction" in res.stdout
+
+
+def test_nvt_lan_keyword_runs_and_thermostats(tmp_path):
+    """`ensemble nvt_lan` (the thermostat of the reference's own examples/gpumd_dynamic/run.in): parsed, the generator seed
+    drawn from the host's rand() stream like Ensemble_LAN does, a cold start is pulled towards the target."""
+    run_in = "potential NEP\nvelocity 50\nensemble nvt_lan 600 600 5\ntime_step 1\ndump_thermo 10\nrun 40\n"
+    wd = _workdir(str(tmp_path / "lan"), run_in)
+    out = _run(wd)
+    assert "choose the Langevin method." in out and "Langevin generator seed =" in out
+    th = _thermo(wd)
+    assert th.shape[0] == 4 and np.isfinite(th).all()
+    assert th[-1, 0] > 250.0, th[:, 0]  # from 50 K towards 600 K with tau = 5 steps
