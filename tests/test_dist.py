@@ -73,6 +73,7 @@ CASES = [
     # (world, model, reps, grid, ensemble, nsteps, temperature): hot enough for re-decompositions inside the run
     (2, "PbTe-reps", (4, 2, 2), (2, 1, 1), "nve", 20, 3000.0),
     (4, "PbTe-reps", (3, 3, 2), (2, 2, 1), "nve", 20, 3000.0),
+    (4, "PbTe-reps", (8, 2, 2), (4, 1, 1), "nve", 20, 3000.0),     # slabs: the grid of bench.py's weak scaling (N x 1 x 1)
     (2, "PbTe-reps", (4, 2, 2), (2, 1, 1), "nvt_ber", 16, 2000.0),
     (2, "PbTe-reps", (4, 2, 2), (2, 1, 1), "nvt_nhc", 16, 2000.0),
     (2, "PbTe-reps", (4, 2, 2), (2, 1, 1), "nvt_bdp", 16, 2000.0),
