@@ -96,6 +96,8 @@ SYMBOLS = {
     "nepmi_lan_half_step": (C.c_int, [VP, c_i64, C.c_double, C.c_double, VP, VP]),
     "nepmi_run_nvt_lan": (C.c_int, [VP, c_dp, c_ip, c_i64, VP, VP, C.c_double, c_i64, C.c_double, C.c_double,
                                     C.c_double, VP, VP, VP, VP, VP, c_i64, c_dp]),
+    "nepmi_run_nvt_bao": (C.c_int, [VP, c_dp, c_ip, c_i64, VP, VP, C.c_double, c_i64, C.c_double, C.c_double,
+                                    C.c_double, VP, VP, VP, VP, VP, c_i64, c_dp]),
     "nepmi_neighbors_export": (C.c_int, [VP, C.c_int, VP, VP, c_i64]),
     "nepmi_descriptors_export": (C.c_int, [VP, VP, VP]),
     "nepmi_engine_stats": (C.c_int, [VP, C.c_int, C.POINTER(NepmiStats)]),

@@ -379,6 +379,21 @@ int nepmi_run_nvt_lan(
   });
 }
 
+int nepmi_run_nvt_bao(
+  nepmi_engine* e, const double h[9], const int pbc[3], int64_t n, const int* type, const double* mass,
+  double dt, int64_t nsteps, double t1, double t2, double t_coup, double* pos, double* vel, double* pe,
+  double* force, double* virial, int64_t thermo_every, double* thermo_host)
+{
+  if (!e)
+    return fail(NEPMI_ERR_ARG, "null engine");
+  if (t_coup < 1.0)
+    return fail(NEPMI_ERR_ARG, "Temperature coupling should >= 1.");
+  return guarded([&] {
+    e->e->run_md(e->e->kBao, h, pbc, n, type, mass, dt, nsteps, t1, t2, t_coup, pos, vel, pe, force, virial, thermo_every,
+                 thermo_host);
+  });
+}
+
 int nepmi_neighbors_export(nepmi_engine* e, int which, int* nn, int* nl, int64_t ld)
 {
   if (!e || which < 0 || which > 2 || !nn || !nl)

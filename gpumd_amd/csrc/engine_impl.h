@@ -351,8 +351,7 @@ public:
     lan_seed_ = seed;
     lan_fresh_ = true;
   }
-  // integrate_nvt_lan_half (ensemble_lan.cu:96-127): v <- c1 v + c2 sqrt(1/m) xi, then the centre-of-mass velocity is removed
-  void lan_half_step(int64_t n, double temperature, double t_coup, const double* mass, double* vel)
+  void lan_prepare(int64_t n)
   {
     if (n < 1 || n > cap_)
       throw EngineError{-4, "number of atoms exceeds the engine's capacity"};
@@ -364,9 +363,28 @@ public:
       be_.lan_init(lan_states_, n, lan_seed_);
       lan_fresh_ = false;
     }
+  }
+  // integrate_nvt_lan_half (ensemble_lan.cu:96-127): v <- c1 v + c2 sqrt(1/m) xi, then the centre-of-mass velocity is removed
+  void lan_half_step(int64_t n, double temperature, double t_coup, const double* mass, double* vel)
+  {
+    lan_prepare(n);
     const double c1 = std::exp(-0.5 / t_coup);
     const double c2 = std::sqrt((1.0 - c1 * c1) * kBoltzmann * temperature);
     be_.lan_half(lan_states_, n, c1, c2, mass, vel, lan_sums_);
+  }
+  // the O step of the BAOAB integrator (Ensemble_BAO::integrate_nvt_lan, ensemble_bao.cu:30-41, :87-117): the same
+  // kernels with c1 = exp(-1 / T_coup) over a whole step
+  void bao_o_step(int64_t n, double temperature, double t_coup, const double* mass, double* vel)
+  {
+    const double keep = t_coup;
+    lan_prepare(n);
+    const double c1 = std::exp(-1.0 / keep);
+    const double c2 = std::sqrt((1.0 - c1 * c1) * kBoltzmann * temperature);
+    be_.lan_half(lan_states_, n, c1, c2, mass, vel, lan_sums_);
+  }
+  void half_drift(int64_t n, double dt, double* pos, const double* vel) // operator A
+  {
+    be_.template launch<256>(kSlotVV, n, HalfDriftBody{n, dt, pos, vel, unwrapped_});
   }
 
   // ---- Bussi-Donadio-Parrinello stochastic velocity rescaling (Ensemble_BDP, ensemble_bdp.cu:71-104;
@@ -477,7 +495,7 @@ public:
   // at it only every kPollEvery steps (and at thermo records), rebuilds the lists and resumes from the frozen
   // step.  The caller's arrays are read at entry and written at exit.
   // ---------------------------------------------------------------------------------------------
-  enum Ensemble { kNve = 0, kBer = 1, kNhc = 2, kBdp = 3, kLan = 4 };
+  enum Ensemble { kNve = 0, kBer = 1, kNhc = 2, kBdp = 3, kLan = 4, kBao = 5 };
   static constexpr int kPollEvery = 4; // steps between two snapshots of the device flags
   static constexpr int kPollDepth = 2; // snapshots in flight: the host runs 8-12 steps ahead of the device
 
@@ -490,7 +508,7 @@ public:
     box_from_h9(h9, pbc, box);
     if (n < 1 || n > cap_)
       throw EngineError{-4, "number of atoms exceeds the engine's capacity"};
-    if ((is_small_box(box) && model_.kind == 0) || ens == kLan) {
+    if ((is_small_box(box) && model_.kind == 0) || ens == kLan || ens == kBao) {
       // (Langevin: the generator states follow the caller's atom order, like the reference's; the stepwise loop
       // works on the caller's arrays)
       run_md_small_box(ens, h9, pbc, n, type, mass, dt, nsteps, t1, t2, tcoup, pos, vel, pe, force, virial, thermo_every,
@@ -677,7 +695,17 @@ public:
       } else if (ens == kLan) { // Ensemble_LAN::compute1, ensemble_lan.cu:206-218
         lan_half_step(n, target, tcoup, mass, vel);
       }
-      velocity_verlet(true, n, dt, mass, force, pos, vel, &box);
+      if (ens == kBao) {
+        // Ensemble_BAO::compute1 (ensemble_bao.cu:419-446): B A O A; the noise amplitude keeps the temperature the
+        // ensemble was constructed with (its c2 is set in the constructor, :36, and never updated: T1 of the run)
+        velocity_verlet(false, n, dt, mass, force, pos, vel, nullptr);
+        half_drift(n, dt, pos, vel);
+        bao_o_step(n, t1, tcoup, mass, vel);
+        half_drift(n, dt, pos, vel);
+        apply_pbc(h9, pbc, n, pos); // Force::compute wraps (force.cu:787-795)
+      } else {
+        velocity_verlet(true, n, dt, mass, force, pos, vel, &box);
+      }
       zero_properties(n, pe, force, virial);
       if (model_.temperature_model && ens != kNve) // as in run_md
         set_temperature(t1 + (t2 - t1) * ((double)(step + 2) / (double)nsteps));
@@ -686,7 +714,7 @@ public:
       const bool record = thermo_every > 0 && (step + 1) % thermo_every == 0;
       if (ens == kLan) // Ensemble_LAN::compute2 (:241-262): second half-step of the thermostat, then find_thermo
         lan_half_step(n, target, tcoup, mass, vel);
-      if ((ens != kNve && ens != kLan) || record)
+      if ((ens != kNve && ens != kLan && ens != kBao) || record)
         find_thermo(n, box.volume, mass, pe, vel, virial, thermo_dev_);
       if (ens == kBer)
         berendsen(n, target, 1.0 / tcoup, thermo_dev_, vel);

@@ -251,6 +251,27 @@ struct VelocityVerletBody {
   }
 };
 
+// gpu_operator_A of the BAOAB Langevin integrator (ensemble_bao.cu:224-250): half a drift
+struct HalfDriftBody {
+  int64_t N;
+  double dt;
+  double* pos;
+  const double* vel;
+  double* unwrapped; // as in VelocityVerletBody
+  NEPMI_HD void operator()(int64_t i) const
+  {
+    const double half = dt * 0.5;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const double old = pos[d * N + i];
+      const double r = old + vel[d * N + i] * half;
+      if (unwrapped)
+        unwrapped[d * N + i] += r - old;
+      pos[d * N + i] = r;
+    }
+  }
+};
+
 // Step n's second half-kick, step n+1's first half-kick + drift + wrap, and initialize_properties
 // for step n+1 in ONE pass over the atoms (run_nve between thermo records): the three kernels it
 // replaces read the same force and touch the same arrays.  The two half-kicks stay two separate

@@ -171,7 +171,7 @@ void Run::parse_one_keyword(const std::vector<std::string>& p)
       input_error("ensemble should have at least 1 parameter.");
     if (p[1] == "nve") {
       std::printf("Use NVE ensemble for this run.\n");
-    } else if (p[1] == "nvt_ber" || p[1] == "nvt_nhc" || p[1] == "nvt_bdp" || p[1] == "nvt_lan") { // Integrate::parse_ensemble, integrate.cu:424-437, 569-600
+    } else if (p[1] == "nvt_ber" || p[1] == "nvt_nhc" || p[1] == "nvt_bdp" || p[1] == "nvt_lan" || p[1] == "nvt_bao") { // Integrate::parse_ensemble, integrate.cu:424-437, 569-600
       if (p.size() != 5)
         input_error("ensemble " + p[1] + " should have 3 parameters.");
       temperature1 = std::atof(p[2].c_str());
@@ -183,10 +183,10 @@ void Run::parse_one_keyword(const std::vector<std::string>& p)
         input_error("Temperature coupling should >= 1.");
       std::printf("Use NVT ensemble for this run.\n    choose the %s method.\n    initial temperature is %g K.\n"
                   "    final temperature is %g K.\n    tau_T is %g time_step.\n",
-                  p[1] == "nvt_ber" ? "Berendsen" : p[1] == "nvt_nhc" ? "Nose-Hoover chain" : p[1] == "nvt_lan" ? "Langevin" : "Bussi-Donadio-Parrinello",
+                  p[1] == "nvt_ber" ? "Berendsen" : p[1] == "nvt_nhc" ? "Nose-Hoover chain" : p[1] == "nvt_lan" ? "Langevin" : p[1] == "nvt_bao" ? "BAOAB Langevin" : "Bussi-Donadio-Parrinello",
                   temperature1, temperature2, temperature_coupling);
     } else {
-      input_error("ensemble " + p[1] + " is not available in gpumd-mi yet (nve, nvt_ber, nvt_nhc, nvt_bdp, nvt_lan; DESIGN.md section 8).");
+      input_error("ensemble " + p[1] + " is not available in gpumd-mi yet (nve, nvt_ber, nvt_nhc, nvt_bdp, nvt_lan, nvt_bao; DESIGN.md section 8).");
     }
     ensemble = p[1];
   } else if (k == "time_step") {
@@ -625,6 +625,9 @@ void Run::run_segment(int steps, double t_a, double t_b)
   const int pbc[3] = {box.pbc_x, box.pbc_y, box.pbc_z};
   nepmi_engine* e = force.engine();
   const bool ramped_temperature_model = force.has_temperature_model() && force.delta_T != 0.0;
+  if (ensemble == "nvt_bao" &&
+      ((force.potentials.size() > 1 && force.multiple_potentials_mode() == "average") || ramped_temperature_model))
+    input_error("ensemble nvt_bao is not available with averaged potentials or a ramped temperature-dependent NEP.");
   if ((force.potentials.size() > 1 && force.multiple_potentials_mode() == "average") || ramped_temperature_model) {
     // the run follows the MEAN of several potentials (force.cu:533-562), or a temperature-dependent NEP sees a new
     // temperature every step (force.cu:803): every step goes through Force::compute
@@ -675,6 +678,9 @@ void Run::run_segment(int steps, double t_a, double t_b)
   else if (ensemble == "nvt_lan")
     st = nepmi_run_nvt_lan(e, box.cpu_h, pbc, N, atom.type.data(), atom.mass.data(), time_step, steps, t_a, t_b,
                            temperature_coupling, x, v, pe, f, w, steps, th);
+  else if (ensemble == "nvt_bao") // the noise amplitude stays that of T1 (ensemble_bao.cu:36), whatever the segment
+    st = nepmi_run_nvt_bao(e, box.cpu_h, pbc, N, atom.type.data(), atom.mass.data(), time_step, steps, temperature1,
+                           temperature2, temperature_coupling, x, v, pe, f, w, steps, th);
   else
     st = nepmi_run_nvt_bdp(e, box.cpu_h, pbc, N, atom.type.data(), atom.mass.data(), time_step, steps, t_a, t_b,
                            temperature_coupling, x, v, pe, f, w, steps, th);
@@ -729,7 +735,7 @@ void Run::perform_a_run()
     (void)hipFree(nhc_state_);
     nhc_state_ = nullptr;
   }
-  if (ensemble == "nvt_lan") { // Ensemble_LAN::Ensemble_LAN (ensemble_lan.cu:39): the generator states are seeded with rand()
+  if (ensemble == "nvt_lan" || ensemble == "nvt_bao") { // Ensemble_LAN / Ensemble_BAO constructors (ensemble_lan.cu:39, ensemble_bao.cu:39): seeded with rand()
     const int seed = host_rand();
     die_on(nepmi_lan_seed(e, seed), "lan_seed");
     std::printf("    Langevin generator seed = %d.\n", seed);
@@ -914,8 +920,8 @@ void Run::perform_a_run_dist()
       input_error("unwrapped positions are not tracked in multi-GPU runs.");
   const int N = atom.number_of_atoms;
   const bool root = par_.rank == 0;
-  if (ensemble == "nvt_lan")
-    input_error("ensemble nvt_lan is not available in multi-GPU runs (nve, nvt_ber, nvt_nhc, nvt_bdp).");
+  if (ensemble == "nvt_lan" || ensemble == "nvt_bao")
+    input_error("ensemble " + ensemble + " is not available in multi-GPU runs (nve, nvt_ber, nvt_nhc, nvt_bdp).");
   const int ens = ensemble == "nve" ? 0 : ensemble == "nvt_ber" ? 1 : ensemble == "nvt_nhc" ? 2 : 3;
   if (root && dump_thermo_interval > 0) {
     FILE* fid = std::fopen("thermo.out", "a");

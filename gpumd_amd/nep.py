@@ -265,6 +265,19 @@ class NEP:
             self._ptr(force), self._ptr(virial), int(thermo_every), th.ctypes.data_as(_capi.c_dp)))
         return th[:nrec]
 
+    def run_nvt_bao(self, box, type, mass, dt, nsteps, t1, t2, t_coup, position, velocity, potential, force,
+                    virial, thermo_every=0):
+        """`ensemble nvt_bao T1 T2 T_coup` (Ensemble_BAO, BAOAB Langevin) -> thermo array like run_nve."""
+        _, hp = _h9(box)
+        _, pp = _pbc3(self.pbc)
+        nrec = (nsteps // thermo_every) if thermo_every > 0 else 0
+        th = np.zeros((max(nrec, 1), 8))
+        self._ck(self.lib.nepmi_run_nvt_bao(
+            self.handle, hp, pp, self.n, self._ptr(type), self._ptr(mass), float(dt), int(nsteps), float(t1),
+            float(t2), float(t_coup), self._ptr(position), self._ptr(velocity), self._ptr(potential),
+            self._ptr(force), self._ptr(virial), int(thermo_every), th.ctypes.data_as(_capi.c_dp)))
+        return th[:nrec]
+
     # -- diagnostics ---------------------------------------------------------------------------
     def neighbors(self, which, nn, nl, ld):
         return self._ck(self.lib.nepmi_neighbors_export(self.handle, int(which), self._ptr(nn), self._ptr(nl), int(ld)))

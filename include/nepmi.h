@@ -234,6 +234,16 @@ int nepmi_run_nvt_lan(
   const double* mass, double dt, int64_t nsteps, double t1, double t2, double t_coup, double* pos,
   double* vel, double* pe, double* force, double* virial, int64_t thermo_every, double* thermo_host);
 
+/* ---- BAOAB Langevin integrator: Ensemble_BAO (src/integrate/ensemble_bao.cu:30-41, :87-117, :224-250, :340-373,
+ *      :419-514), `ensemble nvt_bao T1 T2 T_coup`.  A step: B (half kick), A (half drift), O (the Langevin kernels of
+ *      nvt_lan over a whole step, c1 = exp(-1 / T_coup)), A, force, B, find_thermo; the generators are those of
+ *      nepmi_lan_seed.  As in the reference the noise amplitude is fixed when the ensemble is set up (c2 from T1,
+ *      ensemble_bao.cu:36): t2 is accepted and has no effect. ---- */
+int nepmi_run_nvt_bao(
+  nepmi_engine* e, const double h[9], const int pbc[3], int64_t n, const int* type,
+  const double* mass, double dt, int64_t nsteps, double t1, double t2, double t_coup, double* pos,
+  double* vel, double* pe, double* force, double* virial, int64_t thermo_every, double* thermo_host);
+
 /* ---- multi-GPU: spatial domain decomposition, one process per GPU ----
  *      Replaces NEP_MULTIGPU (src/force/nep_multigpu.cuh:42-50 ranges, nep_multigpu.cu:1416-1803 compute) and
  *      Force::parse_potential's choice of it for `potential <file> [x|y|z]` (src/force/force.cu:122-160).  Every

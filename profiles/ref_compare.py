@@ -93,6 +93,14 @@ def case_inputs(name, d):
         shutil.copy(os.path.join(GOLD, "PbTe", "model.xyz"), os.path.join(d, "model.xyz"))
         run = "replicate 4 4 4\npotential nep.txt\nvelocity 300\nensemble nve\ntime_step 1\ndump_thermo 20\nrun 200\n"
         n = 250 * 64
+    elif name in ("pbte_lan", "pbte_bao"):
+        # the stochastic thermostats (seeded from rand(): not reproducible in the reference's HIP build, compared statistically):
+        # the reference's examples/gpumd_dynamic set-up on 16,000 atoms
+        shutil.copy(os.path.join(GOLD, "PbTe", "model.xyz"), os.path.join(d, "model.xyz"))
+        shutil.copy(os.path.join(GOLD, "PbTe", "nep.txt"), os.path.join(d, "nep.txt"))
+        ens = "nvt_lan" if name == "pbte_lan" else "nvt_bao"
+        run = "replicate 4 4 4\npotential nep.txt\nvelocity 300\nensemble %s 300 300 100\ntime_step 1\ndump_thermo 200\nrun 2000\n" % ens
+        n = 250 * 64
     elif name == "si_tersoff":
         lat, spec, pos = diamond_cell(5.432, "Si")
         write_xyz(os.path.join(d, "model.xyz"), lat, spec, pos)

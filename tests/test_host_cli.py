@@ -99,7 +99,7 @@ def test_group_labels_need_a_grouping_method(tmp_path):
 
 
 @pytest.mark.parametrize("bad,msg", [("potential NEP\nfoo 1\nrun 1\n", "invalid keyword"),
-                                     ("potential NEP\nensemble nvt_bao 300 300 100\nrun 1\n", "not available"),
+                                     ("potential NEP\nensemble nvt_qtb 300 300 100\nrun 1\n", "not available"),
                                      ("potential NEP\nensemble nvt_nhc 300 300 0.5\nrun 1\n", "coupling should >= 1"),
                                      ("velocity 300\nrun 1\n", "no 'potential'")])
 def test_input_errors_exit_like_the_reference(tmp_path, bad, msg):

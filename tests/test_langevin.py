@@ -71,6 +71,43 @@ def _relaxes_to_target(drv):
     assert np.abs((v * mass[None, :]).sum(axis=1)).max() < 1e-8 * np.abs(v * mass[None, :]).sum()
 
 
+def _bao_relaxes(drv):
+    """`ensemble nvt_bao` (Ensemble_BAO: B A O A, force, B): thermostats to the target and conserves nothing it should
+    not; with T_coup -> infinity (no noise, c1 = 1) it is velocity Verlet, i.e. equal to the NVE run step for step."""
+    h, typ, x = H.pbte_supercell((3, 3, 3), seed=4)
+    n = len(typ)
+    mass = np.where(typ == 0, H.MASS["Te"], H.MASS["Pb"]).astype(np.float64)
+    vel = H.maxwell_velocities(mass, 100.0, seed=9)
+    eng = drv.engine(drv.model(H.golden("PbTe", "nep.txt")), n)
+
+    def fresh():
+        d = [drv.dev(a) for a in (typ, mass, x.copy(), vel.copy())]
+        out = [drv.zeros(n), drv.zeros(3 * n), drv.zeros(9 * n)]
+        eng.force_compute(h, d[0], d[2], *out, n=n)
+        return d, out
+    (d_t, d_m, d_x, d_v), (pe, f, w) = fresh()
+    eng.lan_seed(11)
+    th = eng.run_nvt_bao(h, d_t, d_m, 1.0 / H.TIME_UNIT, 120, 300.0, 300.0, 10.0, d_x, d_v, pe, f, w, thermo_every=20)
+    assert np.isfinite(th).all() and 270.0 < th[-1, 0] < 360.0, th[:, 0]
+    # the deterministic limit: B A A B with c1 = exp(-1e-300) = 1, c2 = 0 is velocity Verlet
+    (d_t, d_m, d_x, d_v), (pe, f, w) = fresh()
+    th_bao = eng.run_nvt_bao(h, d_t, d_m, 1.0 / H.TIME_UNIT, 10, 300.0, 300.0, 1e300, d_x, d_v, pe, f, w, thermo_every=5)
+    x_bao = drv.host(d_x)
+    (d_t, d_m, d_x, d_v), (pe, f, w) = fresh()
+    th_nve = eng.run_nve(h, d_t, d_m, 1.0 / H.TIME_UNIT, 10, d_x, d_v, pe, f, w, thermo_every=5)
+    np.testing.assert_allclose(th_bao[:, :3], th_nve[:, :3], rtol=2e-6)
+    assert np.abs(x_bao - drv.host(d_x)).max() < 1e-6
+
+
+def test_nvt_bao_on_emulator():
+    _bao_relaxes(H.EmuDriver())
+
+
+@pytest.mark.gpu
+def test_nvt_bao_on_gpu():
+    _bao_relaxes(H.GpuDriver())
+
+
 def test_nvt_lan_relaxes_to_the_target_on_emulator():
     _relaxes_to_target(H.EmuDriver())
 
