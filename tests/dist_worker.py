@@ -17,8 +17,15 @@ from gpumd_amd.dist import DistMD, Transport  # noqa: E402
 
 def main():
     out_dir, spec = sys.argv[1], json.loads(sys.argv[2])
-    on_gpu = spec["device"] == "gpu"
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    run_rank(out_dir, spec, rank, world,
+             lambda drv: Transport.tcp(drv.lib, "127.0.0.1", int(os.environ["MASTER_PORT"]), rank, world))
+
+
+def run_rank(out_dir, spec, rank, world, make_transport, stream=None):
+    """One rank of a decomposed run; make_transport(driver) -> gpumd_amd.dist.Transport (TCP between processes, or the
+    in-process device transport of tests/inproc between threads)."""
+    on_gpu = spec["device"] == "gpu"
     drv = H.GpuDriver() if on_gpu else H.EmuDriver()
     nep_rel, build, _ = P.MODELS[spec["model"]] if spec["model"] in P.MODELS else (None, None, None)
     if spec["model"] == "PbTe-reps":
@@ -42,8 +49,8 @@ def main():
     vel = H.maxwell_velocities(mass, spec["temp"], seed=5)
     mine = np.arange(n) % world == rank  # arbitrary initial distribution; setup() migrates
     ids = np.arange(n, dtype=np.int64)[mine]
-    tr = Transport.tcp(drv.lib, "127.0.0.1", int(os.environ["MASTER_PORT"]), rank, world)
-    md = DistMD(model, tr, h, (1, 1, 1), spec["grid"])
+    tr = make_transport(drv)
+    md = DistMD(model, tr, h, (1, 1, 1), spec["grid"], stream=stream)
     md.setup(drv.dev(typ[mine]), drv.dev(mass[mine]), drv.dev(np.ascontiguousarray(x.reshape(3, n)[:, mine]).reshape(-1)),
              drv.dev(np.ascontiguousarray(vel.reshape(3, n)[:, mine]).reshape(-1)), drv.dev(ids))
     if "overlap" in spec:

@@ -1,0 +1,106 @@
+"""The code path an 8-GPU node runs, on a 1-GPU box: the domain-decomposed driver with a DEVICE transport
+(device_buffers = 1: ghost positions never leave the GPU, the skin vote is all-reduced on the device, steps are enqueued
+speculatively behind the device flag) and MORE THAN ONE rank.  nepmi_transport_rccl cannot do that here (RCCL refuses two
+ranks on one device) and the TCP transport of tests/test_dist.py is a host transport, so the ranks run as threads of one
+process over tests/inproc/inproc_transport.hip (events + device-to-device copies on the ranks' own streams, the same
+stream-ordered contract as the RCCL transport).  Compared with the single-domain run like tests/test_dist.py."""
+import ctypes as C
+import os
+import tempfile
+import threading
+
+import numpy as np
+import pytest
+
+import helpers as H
+
+LIB = {"gpu": os.path.join(H.ROOT, "tests", "inproc", "libinproc_transport.so"),
+       "cpu": os.path.join(H.ROOT, "tests", "inproc", "libinproc_transport_host.so")}
+HANG_SECONDS = 120  # a rank that has not finished by then is out of step with the others
+
+
+def _run_threads(world, spec):
+    import dist_worker
+    from gpumd_amd import _capi
+    from gpumd_amd.dist import Transport
+    on_gpu = spec["device"] == "gpu"
+    if on_gpu:
+        import torch
+    lib = C.CDLL(LIB[spec["device"]])
+    lib.inproc_group_create.restype = C.c_void_p
+    lib.inproc_group_create.argtypes = [C.c_int]
+    lib.inproc_group_destroy.argtypes = [C.c_void_p]
+    lib.inproc_transport.argtypes = [C.c_void_p, C.c_int, C.POINTER(_capi.NepmiTransport)]
+    group = lib.inproc_group_create(world)
+    assert group
+    out = tempfile.mkdtemp(prefix="nepmi_inproc_")
+    errors = []
+
+    def body(rank):
+        try:
+            def make(drv):
+                t = _capi.NepmiTransport()
+                assert lib.inproc_transport(group, rank, C.byref(t)) == 0
+                return Transport(drv.lib, t)
+            stream = None
+            if on_gpu:
+                stream = torch.cuda.Stream()
+                torch.cuda.synchronize()
+            dist_worker.run_rank(out, spec, rank, world, make, stream=stream)
+        except BaseException as e:  # noqa: BLE001 -- reported by the main thread
+            errors.append((rank, repr(e)))
+
+    threads = [threading.Thread(target=body, args=(r,), daemon=True) for r in range(world)]
+    for t in threads:
+        t.start()
+    import time
+    t_end = time.time() + HANG_SECONDS
+    for t in threads:
+        t.join(timeout=max(1.0, t_end - time.time()))
+    if any(t.is_alive() for t in threads):
+        # daemon threads: the interpreter can still exit; do not wait for a stuck rank (GPU box time is budgeted)
+        os.write(2, b"test_dist_inproc: a rank hangs (exchange / all-reduce sequence out of step)\n")
+        os._exit(3)
+    assert not errors, errors
+    lib.inproc_group_destroy(group)
+    return [np.load(os.path.join(out, "rank%d.npz" % r)) for r in range(world)]
+
+
+CASES = [
+    (2, "PbTe-reps", (4, 2, 2), (2, 1, 1), "nve", 20, 3000.0),      # re-decompositions under speculation
+    (4, "PbTe-reps", (8, 2, 2), (4, 1, 1), "nve", 20, 3000.0),      # the slab grid of bench.py's weak scaling
+    (4, "PbTe-reps", (4, 4, 2), (2, 2, 1), "nvt_ber", 16, 2000.0),
+    (2, "PbTe-reps", (4, 2, 2), (2, 1, 1), "nvt_nhc", 16, 2000.0),
+    (2, "C-2022", (12, 6, 6), (2, 1, 1), "nvt_ber", 10, 3000.0),
+]
+
+
+def _check(device, world, model, reps, grid, ensemble, nsteps, temp):
+    if not os.path.exists(LIB[device]):
+        pytest.skip("tests/inproc transports not built")
+    import test_dist as T
+    spec = T._spec(device, model, reps, grid, ensemble, nsteps, temp)
+    n = T._natoms(model, reps)
+    multi = _run_threads(world, spec)
+    single = T._run_ranks(1, dict(spec, grid=[1, 1, 1]))
+    xs, vs, fs, f0s = T._merge(single, n)
+    xm, vm, fm, f0m = T._merge(multi, n)
+    assert np.abs(f0m - f0s).max() < 3e-5 + 1e-5 * np.abs(f0s).max()
+    assert np.abs(vm - vs).max() < 2e-6
+    assert np.abs(fm - fs).max() < 30 * 3e-5 + 1e-4 * np.abs(fs).max()
+    for r in multi:
+        np.testing.assert_allclose(r["th1"], multi[0]["th1"], rtol=0, atol=0)
+        np.testing.assert_allclose(r["th1"][:2], single[0]["th1"][:2], rtol=1e-6)
+    if model == "PbTe-reps" and ensemble == "nve":
+        assert max(int(r["ndec"]) for r in multi) >= 2
+
+
+@pytest.mark.parametrize("world,model,reps,grid,ensemble,nsteps,temp", CASES[:4])
+def test_device_transport_with_several_ranks_on_emulator(world, model, reps, grid, ensemble, nsteps, temp):
+    _check("cpu", world, model, reps, grid, ensemble, nsteps, temp)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,model,reps,grid,ensemble,nsteps,temp", CASES)
+def test_device_transport_with_several_ranks_on_gpu(world, model, reps, grid, ensemble, nsteps, temp):
+    _check("gpu", world, model, reps, grid, ensemble, nsteps, temp)
