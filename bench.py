@@ -336,8 +336,8 @@ def run_decomposed(args, world, rank, dev, model, label, h_block, typ, x, mass, 
     lib = gpumd_amd.load_library()
     # Weak scaling stacks the ranks' blocks along the first lattice vector (N x 1 x 1 slabs, the reference's own
     # one-directional partition, force.cu:122-160): every rank has two neighbours and ghosts across two faces only -- a
-    # 1,024,000-atom PbTe block gets +17 % atoms that need descriptors instead of +61 % in a 2 x 2 x 2 arrangement of the
-    # same blocks.  Strong scaling cuts ONE system: there the most cubic grid has the least surface.
+    # 1,024,000-atom PbTe block gets +12 % local atoms (+6 % that need descriptors) instead of +36 % (+17 %) in a 2 x 2 x 2
+    # arrangement of the same blocks.  Strong scaling cuts ONE system: there the most cubic grid has the least surface.
     grid = (world, 1, 1) if args.scaling == "weak" else choose_grid(world)
     Hb = np.asarray(h_block).reshape(3, 3)
     n = len(typ)
