@@ -51,7 +51,7 @@ class NepmiTransport(C.Structure):
 
 class NepmiDistInfo(C.Structure):
     _fields_ = [("n_owned", c_i64), ("n_local", c_i64), ("n_total", c_i64), ("num_decompositions", c_i64),
-                ("num_steps", c_i64), ("num_overlapped", c_i64)]
+                ("num_steps", c_i64), ("num_overlapped", c_i64), ("decompose_ms", C.c_double)]
 
 
 # every symbol include/nepmi.h declares: name -> (restype, argtypes)

@@ -104,6 +104,7 @@ int nepmi_dist_get_info(nepmi_dist* d, nepmi_dist_info* out)
   out->num_decompositions = d->d->num_decompositions;
   out->num_steps = d->d->num_steps;
   out->num_overlapped = d->d->num_overlapped;
+  out->decompose_ms = d->d->decompose_ms;
   return NEPMI_OK;
 }
 

@@ -21,6 +21,7 @@
 // step), or a host transport (TCP sockets; a caller's own callbacks) whose payloads are staged through pinned
 // memory -- the same driver code, used by the CPU test tier and by ranks that share one GPU.
 #pragma once
+#include <chrono>
 #include "../../include/nepmi.h"
 #include "dist_bodies.h"
 #include "engine_impl.h"
@@ -351,6 +352,7 @@ public:
   void bdp_seed(uint64_t seed) { seed_ = seed; if (eng_) eng_->bdp_seed(seed); }
   void set_overlap(bool on) { overlap_ = on; }
   int64_t num_overlapped = 0; // steps whose interior radial pass ran before / while the ghosts travelled
+  double decompose_ms = 0.0;  // wall time of all (re-)decompositions (migration, ghost stages, list rebuild), synchronised
 
 private:
   struct State { // owned + ghost atoms in local order, stride = n (DEVICE)
@@ -563,6 +565,14 @@ private:
 
   // ---- migration + ghost construction + list rebuild ----
   void decompose()
+  {
+    const auto t_begin = std::chrono::steady_clock::now();
+    decompose_body();
+    be_.sync();
+    decompose_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+  }
+
+  void decompose_body()
   {
     const int me = tr_.rank, P = tr_.nranks;
     if (resident_) {

@@ -312,6 +312,7 @@ typedef struct {
   int64_t n_owned, n_local, n_total; /* atoms owned by this rank, owned + ghosts, in the whole system */
   int64_t num_decompositions, num_steps;
   int64_t num_overlapped; /* steps whose interior radial pass was enqueued before the ghost exchange completed */
+  double decompose_ms;    /* wall time spent in the (re-)decompositions so far: migration, ghost stages, list rebuild */
 } nepmi_dist_info;
 int nepmi_dist_get_info(nepmi_dist* d, nepmi_dist_info* out);
 /* The owned atoms of this rank (n_owned entries per plane, global coordinates) into the caller's DEVICE arrays;

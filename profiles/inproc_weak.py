@@ -86,7 +86,7 @@ def main():
                 barrier.wait()
                 times[rank] = time.perf_counter() - t0
                 i = md.info()
-                infos[rank] = (int(i.n_owned), int(i.n_local), int(i.num_decompositions))
+                infos[rank] = (int(i.n_owned), int(i.n_local), int(i.num_decompositions), float(i.decompose_ms))
                 md.close()
                 tr.close()
             except BaseException as e:  # noqa: BLE001
@@ -114,7 +114,9 @@ def main():
            "ms_per_step_one_domain_same_atoms": t_single / args.steps * 1e3,
            "decomposition_overhead": t_multi / t_single,
            "predicted_weak_scaling_efficiency_excl_xgmi": t_single / t_multi,
-           "atoms_total": n_total, "decompositions": [i[2] for i in info_multi]}
+           "atoms_total": n_total, "decompositions": [i[2] for i in info_multi],
+           "decompose_ms_total_incl_setup": [round(i[3], 2) for i in info_multi],
+           "one_domain_decompositions": info_single[0][2], "one_domain_decompose_ms_total": round(info_single[0][3], 2)}
     print(json.dumps(out))
 
 
