@@ -22,6 +22,8 @@
 // memory -- the same driver code, used by the CPU test tier and by ranks that share one GPU.
 #pragma once
 #include <chrono>
+#include <map>
+#include <unordered_map>
 #include "../../include/nepmi.h"
 #include "dist_bodies.h"
 #include "engine_impl.h"
@@ -104,6 +106,8 @@ public:
       free_stage(st);
     for (void* p : scratch_)
       be_.free(p);
+    for (auto& kv : pool_size_)
+      be_.free(kv.first);
   }
 
   // ---- setup: the atoms this rank starts with (DEVICE arrays, any position: they are migrated to their owners) ----
@@ -398,6 +402,32 @@ private:
     s.id = (int64_t*)be_.alloc(sizeof(int64_t) * cap);
     s.lvl = (signed char*)be_.alloc(cap);
   }
+  // Transient device buffers of the (re-)decomposition -- migration payloads, per-stage index lists and send/receive
+  // buffers, the 8-byte bounce words of the count exchange -- come from a small pool: hipMalloc / hipFree cost 0.1-1 ms
+  // each (hipFree synchronises the device) and a re-decomposition asked for about thirty of them.  A freed block is
+  // handed out again when it is large enough and not more than twice the request; everything returns to HIP in ~DistT.
+  void* palloc(size_t bytes)
+  {
+    bytes = bytes ? bytes : 1;
+    auto it = pool_free_.lower_bound(bytes);
+    if (it != pool_free_.end() && it->first <= 2 * bytes + 4096) {
+      void* p = it->second;
+      pool_free_.erase(it);
+      return p;
+    }
+    const size_t cap = bytes + bytes / 4 + 256; // headroom: the next decomposition asks for slightly different sizes
+    void* p = be_.alloc(cap);
+    pool_size_[p] = cap;
+    return p;
+  }
+  void pfree(void* p)
+  {
+    if (p)
+      pool_free_.emplace(pool_size_.at(p), p);
+  }
+  std::multimap<size_t, void*> pool_free_;
+  std::unordered_map<void*, size_t> pool_size_;
+
   void free_state(State& s)
   {
     for (void* p : {(void*)s.x, (void*)s.v, (void*)s.m, (void*)s.t, (void*)s.id, (void*)s.lvl})
@@ -408,8 +438,7 @@ private:
   void free_stage(Stage& st)
   {
     for (void* p : {(void*)st.send_idx, (void*)st.send_int, (void*)st.recv_int, (void*)st.sendbuf, (void*)st.recvbuf})
-      if (p)
-        be_.free(p);
+      pfree(p);
     st = Stage();
   }
   int* iscratch(int which, int64_t count) // grow-only int scratch arrays
@@ -440,12 +469,12 @@ private:
       return;
     if (tr_.device_buffers) { // a host buffer through a device transport: bounce through device memory
       const size_t bytes = (size_t)count * (dtype == kDtI32 ? 4 : 8);
-      void* d = be_.alloc(bytes);
+      void* d = palloc(bytes);
       be_.h2d(d, buf, bytes);
       if (tr_.allreduce(tr_.ctx, d, count, dtype, op, be_.stream_handle()) != 0)
         throw EngineError{-5, "transport all-reduce failed"};
       be_.d2h(buf, d, bytes);
-      be_.free(d);
+      pfree(d);
     } else if (tr_.allreduce(tr_.ctx, buf, count, dtype, op, nullptr) != 0) {
       throw EngineError{-5, "transport all-reduce failed"};
     }
@@ -625,7 +654,7 @@ private:
       if (r != me && c > 0) {
         int* di = iscratch(7, c + 1);
         be_.h2d(di, by_dest[r].data(), sizeof(int) * c);
-        double* buf = (double*)be_.alloc(sizeof(double) * 9 * c);
+        double* buf = (double*)palloc(sizeof(double) * 9 * c);
         be_.template launch<256>(kSlotMisc, c, PackStateBody{geom_, n_old, c, di, cur_.x, cur_.v, cur_.m, cur_.t, cur_.id, buf});
         be_.sync();
         sbuf.push_back(buf);
@@ -633,7 +662,7 @@ private:
       }
       const int64_t a = mat[(size_t)r * P + me];
       if (r != me && a > 0) {
-        double* buf = (double*)be_.alloc(sizeof(double) * 9 * a);
+        double* buf = (double*)palloc(sizeof(double) * 9 * a);
         rbuf.push_back(buf);
         rcount.push_back(a);
         recvs.push_back(TransportMsg{buf, (int64_t)sizeof(double) * 9 * a, r});
@@ -664,8 +693,8 @@ private:
       off += rcount[k];
     }
     be_.sync();
-    for (double* p : sbuf) be_.free(p);
-    for (double* p : rbuf) be_.free(p);
+    for (double* p : sbuf) pfree(p);
+    for (double* p : rbuf) pfree(p);
     // 5. ghost stages over the decomposed directions
     for (auto& st : stages_)
       free_stage(st);
@@ -705,11 +734,11 @@ private:
       if (n_loc + crt > N.cap)
         throw EngineError{-6, "domain decomposition: more ghost atoms than the density-based capacity of the local system "
                               "(strongly non-uniform density across the sub-boxes)"};
-      st.send_idx = (int*)be_.alloc(sizeof(int) * (cst + 1));
-      st.send_int = (int*)be_.alloc(sizeof(int) * (cst + 1));
-      st.recv_int = (int*)be_.alloc(sizeof(int) * (crt + 1));
-      st.sendbuf = (double*)be_.alloc(sizeof(double) * 4 * (cst + 1));
-      st.recvbuf = (double*)be_.alloc(sizeof(double) * 4 * (crt + 1));
+      st.send_idx = (int*)palloc(sizeof(int) * (cst + 1));
+      st.send_int = (int*)palloc(sizeof(int) * (cst + 1));
+      st.recv_int = (int*)palloc(sizeof(int) * (crt + 1));
+      st.sendbuf = (double*)palloc(sizeof(double) * 4 * (cst + 1));
+      st.recvbuf = (double*)palloc(sizeof(double) * 4 * (crt + 1));
       if (cs[0]) copy_dev(st.send_idx, gidx[0], sizeof(int) * cs[0]);
       if (cs[1]) copy_dev(st.send_idx + cs[0], gidx[1], sizeof(int) * cs[1]);
       TransportMsg s[2], r[2];
@@ -788,8 +817,7 @@ private:
   int64_t compact(int* flag, int64_t n, int* scan, int* idx_out, int* scr)
   {
     copy_dev(scan, flag, sizeof(int) * n);
-    int zero = 0;
-    be_.h2d(scan + n, &zero, sizeof(int));
+    be_.memset(scan + n, 0, sizeof(int)); // (stream-ordered: no host round trip for a zero)
     be_.exclusive_scan(scan, n + 1, scr);
     be_.template launch<256>(kSlotMisc, n, CompactBody{flag, scan, idx_out});
     int total = 0;
@@ -805,14 +833,14 @@ private:
       return;
     }
     // counts travel through the host-side path of the transport (8 bytes each)
-    int64_t* d = (int64_t*)be_.alloc(sizeof(int64_t) * 4);
+    int64_t* d = (int64_t*)palloc(sizeof(int64_t) * 4);
     be_.h2d(d, cs, sizeof(int64_t) * 2);
     TransportMsg s[2] = {{d, 8, st.peer_send[0]}, {d + 1, 8, st.peer_send[1]}};
     TransportMsg r[2] = {{d + 2, 8, st.peer_recv[0]}, {d + 3, 8, st.peer_recv[1]}};
     exchange(2, s, 2, r);
     be_.sync();
     be_.d2h(cr, d + 2, sizeof(int64_t) * 2);
-    be_.free(d);
+    pfree(d);
   }
 
   // [3][S] staging arrays -> [3][n] arrays of the current state
