@@ -184,13 +184,32 @@ struct RadialWinBody {
   const int* frozen;  // fused run loops: a non-zero value means "a list rebuild is pending": do nothing
   static constexpr int kMinWavesPerEu = NEPMI_RW_WAVES;
 
-  NEPMI_HD int lds_bytes() const { return st.lay.bytes(); }
+  // Shapes without register-resident per-type sums (many types: UNEP-v1 has 16) contract the radial coefficients
+  // c[t1][t2][n][k] per pair, with (t1, t2) different from lane to lane: 45 loads per pair that hit up to 64 different
+  // cache lines each.  The whole table (T^2 (n_r+1)(k_r+1) floats, 46 KB for UNEP-v1) is therefore staged in LDS behind
+  // the window when two workgroups per CU still fit (<= 80 KB together); the loads become LDS reads.
+  NEPMI_HD int ctab_floats() const { return S::TS > 0 ? 0 : m.T * m.T * (m.NR + 1) * (m.KR + 1); }
+  NEPMI_HD int ctab_offset() const { return (st.lay.bytes() + 15) / 16 * 16; }
+#ifndef NEPMI_RW_CTAB
+#define NEPMI_RW_CTAB 1 // A/B switch (profiles/ab_variants.sh)
+#endif
+  NEPMI_HD bool ctab_on() const { return NEPMI_RW_CTAB && S::TS == 0 && ctab_offset() + 4 * ctab_floats() <= 80 * 1024; }
+  NEPMI_HD int lds_bytes() const { return ctab_on() ? ctab_offset() + 4 * ctab_floats() : st.lay.bytes(); }
   NEPMI_HD int64_t map_brick(int64_t w) const { return first < 0 ? w : (int64_t)st.b.brick_order[first + w]; }
   NEPMI_HD bool skip() const { return frozen && *frozen != 0; }
   template <class LC>
   NEPMI_HD void stage_cells(int64_t brick, LC lds, int tid, int nth) const { st.stage_cells(brick, lds, tid, nth); }
   template <class LC>
-  NEPMI_HD void stage_copy(int64_t brick, LC lds, int tid, int nth) const { st.stage_copy(brick, lds, tid, nth); }
+  NEPMI_HD void stage_copy(int64_t brick, LC lds, int tid, int nth) const
+  {
+    st.stage_copy(brick, lds, tid, nth);
+    if (ctab_on()) {
+      NEPMI_LDS(float)* ct = (NEPMI_LDS(float)*)(lds + ctab_offset());
+      const int nf = ctab_floats();
+      for (int i = tid; i < nf; i += nth)
+        ct[i] = m.c_rad[i];
+    }
+  }
   NEPMI_HD void brick_range(int64_t brick, int64_t& a0, int64_t& a1) const { st.brick_range(brick, a0, a1); }
 
   template <class LC>
@@ -205,6 +224,8 @@ struct RadialWinBody {
     }
     NEPMI_LDS(const int)* woff = (NEPMI_LDS(const int)*)(lds + st.lay.off_woff());
     NEPMI_LDS(const WinRec)* wrec = (NEPMI_LDS(const WinRec)*)(lds + st.lay.off_rec());
+    const bool ctab = ctab_on();
+    NEPMI_LDS(const float)* ctab_lds = (NEPMI_LDS(const float)*)(lds + ctab_offset());
     const int NR = S::fixed ? S::NR : m.NR;
     const int KR = S::fixed ? S::KR : m.KR;
     const PosQ p1 = b.posq[k];
@@ -334,12 +355,23 @@ struct RadialWinBody {
         basis_fn<S::KRM>(rcinv, dc, fc, fn);
       else
         basis_fn_rt(KR, rcinv, dc, fc, fn);
-      const float* cc = m.c_rad + (size_t)(t1 * m.T + c.t2) * (NR + 1) * (KR + 1);
-      for (int n = 0; n <= NR; ++n) {
-        float gsum = 0.0f;
-        for (int kk = 0; kk <= KR; ++kk)
-          gsum += fn[kk] * cc[n * (KR + 1) + kk];
-        q[n] += gsum;
+      const int coff = (t1 * m.T + c.t2) * (NR + 1) * (KR + 1);
+      if (ctab) {
+        NEPMI_LDS(const float)* cc = ctab_lds + coff;
+        for (int n = 0; n <= NR; ++n) {
+          float gsum = 0.0f;
+          for (int kk = 0; kk <= KR; ++kk)
+            gsum += fn[kk] * cc[n * (KR + 1) + kk];
+          q[n] += gsum;
+        }
+      } else {
+        const float* cc = m.c_rad + coff;
+        for (int n = 0; n <= NR; ++n) {
+          float gsum = 0.0f;
+          for (int kk = 0; kk <= KR; ++kk)
+            gsum += fn[kk] * cc[n * (KR + 1) + kk];
+          q[n] += gsum;
+        }
       }
     };
     // accumulation of two candidates side by side (f2: packed FP32), branch-free: entries outside the cutoff run

@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--reps", type=int, nargs=3, default=[16, 16, 16])
+    ap.add_argument("--only", default="both", choices=["both", "ranks", "one"], help="profiling: run only one of the two legs")
     args = ap.parse_args()
     import torch
     import gpumd_amd
@@ -106,6 +107,14 @@ def main():
             os._exit(3)
         return max(times), infos
 
+    if args.only == "ranks":
+        t_multi, info_multi = run(R, 1)
+        print(json.dumps({"ms_per_step": t_multi / args.steps * 1e3, "info": info_multi}))
+        return
+    if args.only == "one":
+        t_single, info_single = run(1, R)
+        print(json.dumps({"ms_per_step": t_single / args.steps * 1e3, "info": info_single}))
+        return
     t_multi, info_multi = run(R, 1)
     t_single, info_single = run(1, R)
     n_total = sum(i[0] for i in info_multi)
