@@ -1790,7 +1790,7 @@ struct AngularForceBody {
   {
     constexpr int NLOC = (S::NAM + PARTS) / PARTS;
     const int64_t N = b.N;
-    if (b.lvl[k] < 1 || !b.angf[k]) // outer ghosts; inner-ring ghosts whose f12 no owned atom will read
+    if (b.lvl[k] < 1 || (b.level && !b.angf[k])) // outer ghosts; inner-ring ghosts whose f12 no owned atom will read
       return;
     const int64_t gk = b.tpos[k]; // q / fp column of this atom (work order)
     const int NR = S::fixed ? S::NR : m.NR;

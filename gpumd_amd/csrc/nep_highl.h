@@ -206,7 +206,7 @@ struct HighLForceBody {
   NEPMI_HD void operator()(int64_t k) const
   {
     const int64_t N = b.N;
-    if (b.lvl[k] < 1 || !b.angf[k])
+    if (b.lvl[k] < 1 || (b.level && !b.angf[k]))
       return;
     const int64_t gk = b.tpos[k];
     const int NA = m.NA, KA = m.KA, Lmax = m.Lmax;
