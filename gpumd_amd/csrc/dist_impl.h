@@ -287,6 +287,9 @@ public:
       ++step;
     }
     num_steps += nsteps;
+    // the last step's kernels may have raised a capacity bit after its vote: reduce the words once more, so that the
+    // final check throws on every rank or on none
+    device_allreduce(e.bufs().flags + kFlagMoved, 2, kDtI32, kOpMax);
     be_.sync();
     e.check_flags_now();
   }
@@ -530,8 +533,12 @@ private:
   // and non-speculative ensembles), 0 otherwise (device transports: the kernels look at the reduced word themselves)
   int vote(bool spec, B& on)
   {
+    // [moved, overflow] are adjacent: the capacity bits travel with the vote, so that every rank sees a capacity error at
+    // the same synchronisation point and they all report it (a rank that threw alone would leave the others waiting in
+    // their next collective)
+    static_assert(kFlagOverflow == kFlagMoved + 1, "the vote reduces two adjacent flag words");
     int* word = eng_->bufs().flags + kFlagMoved;
-    device_allreduce_on(on, word, 1, kDtI32, kOpMax);
+    device_allreduce_on(on, word, 2, kDtI32, kOpMax);
     if (spec)
       return 0;
     int w = 0;
@@ -793,7 +800,21 @@ private:
     }
     Engine& e = *eng_;
     e.invalidate();
-    e.prepare_lists(h_loc_, pbc_loc_, n_loc, C.t, C.x, C.lvl);
+    {
+      // a list-capacity error of ONE rank's rebuild must end the run on every rank
+      int64_t failed = 0;
+      std::string what;
+      try {
+        e.prepare_lists(h_loc_, pbc_loc_, n_loc, C.t, C.x, C.lvl);
+      } catch (const EngineError& ex) {
+        failed = 1;
+        what = ex.msg;
+      }
+      int64_t any = failed;
+      host_allreduce(&any, 1, kDtI64, kOpMax);
+      if (any)
+        throw EngineError{-6, failed ? what : std::string("another rank exceeded a neighbour list capacity at the rebuild")};
+    }
     e.resident_alloc();
     e.resident_import(C.v, C.m, nullptr, nullptr, nullptr);
     int* inv = iscratch(10, n_loc + 1);

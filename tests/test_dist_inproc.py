@@ -19,7 +19,7 @@ LIB = {"gpu": os.path.join(H.ROOT, "tests", "inproc", "libinproc_transport.so"),
 HANG_SECONDS = 120  # a rank that has not finished by then is out of step with the others
 
 
-def _run_threads(world, spec):
+def _run_threads(world, spec, expect_errors=False):
     import dist_worker
     from gpumd_amd import _capi
     from gpumd_amd.dist import Transport
@@ -61,6 +61,8 @@ def _run_threads(world, spec):
         # daemon threads: the interpreter can still exit; do not wait for a stuck rank (GPU box time is budgeted)
         os.write(2, b"test_dist_inproc: a rank hangs (exchange / all-reduce sequence out of step)\n")
         os._exit(3)
+    if expect_errors:
+        return errors
     assert not errors, errors
     lib.inproc_group_destroy(group)
     return [np.load(os.path.join(out, "rank%d.npz" % r)) for r in range(world)]
@@ -104,3 +106,16 @@ def test_device_transport_with_several_ranks_on_emulator(world, model, reps, gri
 @pytest.mark.parametrize("world,model,reps,grid,ensemble,nsteps,temp", CASES)
 def test_device_transport_with_several_ranks_on_gpu(world, model, reps, grid, ensemble, nsteps, temp):
     _check("gpu", world, model, reps, grid, ensemble, nsteps, temp)
+
+
+def test_a_capacity_error_of_one_rank_ends_the_run_on_every_rank():
+    """40 steps at 3000 K melt the PbTe block until one rank exceeds the angular list capacity of the model file (MN): the
+    capacity bits travel with the skin vote, so both ranks report the error at the same point instead of one of them
+    waiting for ever in its next collective."""
+    import test_dist as T
+    if not os.path.exists(LIB["cpu"]):
+        pytest.skip("tests/inproc transports not built")
+    spec = T._spec("cpu", "PbTe-reps", (4, 2, 2), (2, 1, 1), "nve", 40, 3000.0)
+    errors = _run_threads(2, spec, expect_errors=True)
+    assert sorted(r for r, _ in errors) == [0, 1], errors
+    assert all("capacity" in msg for _, msg in errors), errors
