@@ -28,6 +28,9 @@ def main():
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--reps", type=int, nargs=3, default=[16, 16, 16])
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling: ONE block of --reps cells shared by the ranks (most cubic grid) against the same block as "
+                         "one domain -- the work the decomposition adds when a fixed system is cut into R sub-boxes")
     ap.add_argument("--only", default="both", choices=["both", "ranks", "one"], help="profiling: run only one of the two legs")
     args = ap.parse_args()
     import torch
@@ -107,6 +110,58 @@ def main():
             os._exit(3)
         return max(times), infos
 
+    def run_strong(world):
+        from gpumd_amd.dist import choose_grid
+        group = tlib.inproc_group_create(world)
+        barrier = threading.Barrier(world)
+        times, infos, errs = [0.0] * world, [None] * world, []
+        Hb, typ, x, mass, vel = block(0)
+        n = len(typ)
+        grid = choose_grid(world)
+
+        def body(rank):
+            try:
+                mine = np.arange(n) % world == rank
+                t = _capi.NepmiTransport()
+                assert tlib.inproc_transport(group, rank, C.byref(t)) == 0
+                tr = Transport(lib, t)
+                stream = torch.cuda.Stream()
+                md = DistMD(model, tr, Hb.reshape(9), (1, 1, 1), grid, stream=stream)
+                md.setup(torch.from_numpy(np.ascontiguousarray(typ[mine])).to(dev),
+                         torch.from_numpy(np.ascontiguousarray(mass[mine])).to(dev),
+                         torch.from_numpy(np.ascontiguousarray(x.reshape(3, n)[:, mine]).reshape(-1)).to(dev),
+                         torch.from_numpy(np.ascontiguousarray(vel.reshape(3, n)[:, mine]).reshape(-1)).to(dev))
+                torch.cuda.synchronize()
+                md.compute()
+                md.run("nve", dt, args.warmup)
+                torch.cuda.synchronize()
+                barrier.wait()
+                t0 = time.perf_counter()
+                md.run("nve", dt, args.steps)
+                torch.cuda.synchronize()
+                barrier.wait()
+                times[rank] = time.perf_counter() - t0
+                i = md.info()
+                infos[rank] = (int(i.n_owned), int(i.n_local), int(i.num_decompositions), float(i.decompose_ms))
+                md.close()
+                tr.close()
+            except BaseException as e:  # noqa: BLE001
+                errs.append((rank, repr(e)))
+                try:
+                    barrier.abort()
+                except Exception:
+                    pass
+
+        ths = [threading.Thread(target=body, args=(r,), daemon=True) for r in range(world)]
+        [t.start() for t in ths]
+        t_end = time.time() + 240
+        for t in ths:
+            t.join(timeout=max(1.0, t_end - time.time()))
+        if any(t.is_alive() for t in ths) or errs:
+            sys.stderr.write("inproc_weak: %s\n" % (errs or "a rank hangs"))
+            os._exit(3)
+        return max(times), infos
+
     if args.only == "ranks":
         t_multi, info_multi = run(R, 1)
         print(json.dumps({"ms_per_step": t_multi / args.steps * 1e3, "info": info_multi}))
@@ -114,6 +169,15 @@ def main():
     if args.only == "one":
         t_single, info_single = run(1, R)
         print(json.dumps({"ms_per_step": t_single / args.steps * 1e3, "info": info_single}))
+        return
+    if args.strong:
+        t_multi, info_multi = run_strong(R)
+        t_single, info_single = run_strong(1)
+        print(json.dumps({"mode": "strong", "ranks": R, "atoms_total": sum(i[0] for i in info_multi),
+                          "owned_per_rank": [i[0] for i in info_multi], "local_per_rank": [i[1] for i in info_multi],
+                          "ms_per_step_ranks_sharing_one_gpu": t_multi / args.steps * 1e3,
+                          "ms_per_step_one_domain": t_single / args.steps * 1e3, "work_inflation": t_multi / t_single,
+                          "decompositions": [i[2] for i in info_multi]}))
         return
     t_multi, info_multi = run(R, 1)
     t_single, info_single = run(1, R)
