@@ -916,6 +916,7 @@ private:
       b_.nn_t0 = dalloc<int>(N);
       b_.prec = dalloc<WinRec>(N);
       b_.aidx = dalloc<unsigned short>((size_t)b_.MN_acomp * N);
+      b_.amask = dalloc<unsigned>(4 * (size_t)N);
     } else { // Tersoff-1989: Tersoff1989::Tersoff1989 allocations (tersoff1989.cu:141-149)
       tb_.rec = dalloc<D4>((size_t)b_.MN_ang * N);
       tb_.bb = dalloc<double>((size_t)b_.MN_ang * N);
@@ -1196,6 +1197,7 @@ private:
     be_.d2h(flags, b_.flags, sizeof(flags));
     check_overflow(flags);
     num_boundary_bricks_ = flags[kFlagNumBoundary];
+    max_ang_rebuild_ = flags[kFlagMaxAng];
     // LDS-window radial pass: unique window cells (>= 8 cells per periodic direction), 7-bit rank
     // in cell, window fits the LDS budget
     tile_ok_ = use_tiles_ && model_.kind == 0 && flags[kFlagMaxCell] <= 127 && flags[kFlagMaxWindow] <= kWinMaxAtoms &&
@@ -1366,6 +1368,11 @@ private:
   template <class S>
   void force_kernels_shape(int phase, const int* frozen)
   {
+#ifndef NEPMI_AMASK
+#define NEPMI_AMASK 1 // A/B switch (profiles/ab_variants.sh): 0 = amap entries instead of the membership mask
+#endif
+    // membership mask instead of amap: the one-lane window kernels, list A within the mask's 128 bits (counted at the rebuild)
+    b_.use_amask = (NEPMI_AMASK && tile_ok_ && win_lanes() == 1 && max_ang_rebuild_ <= 128) ? 1 : 0;
     const WinStage ws{box_, b_, win_};
     if (phase == kPhaseRecords) { // diagnostics: materialise the pair records of the current positions
       be_.template launch<64>(kSlotMisc, N_, RadialDescBody<S>{box_, md_, b_, 1});
@@ -1452,6 +1459,7 @@ private:
   double* ui_alloc_ = nullptr;
   double* factor_dev_ = nullptr;
   bool tile_ok_ = false, use_tiles_ = true;
+  int max_ang_rebuild_ = 1 << 30; // longest list A of the last rebuild
   int tile_mode_ = -1;           // -1 auto, 0 none, 1 radial window only, 2 radial + force windows
   bool records_valid_ = false; // rstash holds the pair records of the last evaluated positions
   int recompute_mode_ = -1;

@@ -31,6 +31,10 @@ struct alignas(16) F4 {
 // Fixed-point position record of the LDS-window kernels (nep_window.h): x, y, z in grid units of WinGeom::unit,
 // relative to the corner of the atom's cell of the rebuild-time grid (global array Bufs::prec) or, once staged,
 // relative to the centre of a brick's window (LDS); w = internal index | type << kIdxBits.
+struct alignas(16) U4 { // four membership words of Bufs::amask
+  unsigned x, y, z, w;
+};
+
 struct alignas(16) WinRec {
   int x, y, z;
   int w;
@@ -140,6 +144,10 @@ struct Bufs {
   unsigned short* ccode; // [MN_rad][N]; two-type shapes: neighbours of type 0 from row 0 up, of type 1 from row MN_rad-1 down
   int* nn_t0;            // [N] entries at the front of ccode (all of them unless the shape has two types)
   unsigned short* aidx;  // [MN_acomp][N] reverse slot (rev_ang) of every compact angular slot's pair
+  unsigned* amask;       // [N][4] membership bits of list A this step (bit i: entry i is an angular neighbour and has a compact
+                         // slot = the number of set bits below it): what amap holds, in 16 bytes per atom that stay in L2,
+                         // written by the one-lane window radial pass instead of one amap store per list-A entry
+  int use_amask;         // 1: amask is valid this step (window kernels, one lane per atom, list A <= 128 entries)
   // integrator state in internal order while a fused run loop owns the step (positions live in posq)
   double* vi; // [3][N]
   double* mi; // [N]

@@ -248,6 +248,7 @@ struct RadialWinBody {
 
     const int na = b.nn_ang[k], nbn = b.nn_skin[k];
     const bool owned = b.lvl[k] >= 2;
+    unsigned am_cur = 0u; // membership bits of the current 32 entries of list A (Bufs::amask)
     int cnt = 0, cnt1 = 0, ca = 0; // cnt: entries at the front of ccode, cnt1: at its back (type-1 neighbours)
     F4* __restrict__ acomp = b.acomp + k;
     unsigned short* __restrict__ amap = b.amap + k;
@@ -261,7 +262,8 @@ struct RadialWinBody {
       int t2;
       bool inside;
     };
-    auto decide = [&](const int slot, const WinRec r, const int idx, const bool live, auto in_list_a) -> Cand {
+    auto decide = [&](const int slot, const WinRec r, const int idx, const bool live, auto in_list_a)
+                    __attribute__((always_inline)) -> Cand {
       constexpr bool LIST_A = decltype(in_list_a)::value;
       Cand c;
       c.fx = (float)(r.x - ox);
@@ -296,10 +298,12 @@ struct RadialWinBody {
             acomp[(int64_t)ca * N] = e;
             aidx[(int64_t)ca * N] = b.rev_ang[(int64_t)idx * N + k]; // reverse slot of this pair in j's list A
             cs = (unsigned short)ca;
+            am_cur |= 1u << (idx & 31); // membership bit (Bufs::amask); the walk stores the word every 32 entries
           }
           ++ca;
         }
-        amap[(int64_t)idx * N] = cs;
+        if (!b.use_amask)
+          amap[(int64_t)idx * N] = cs;
       }
       if (inside) {
         // two-type shapes: the compact list is partitioned by the neighbour's type (front / back), so that the force
@@ -321,7 +325,7 @@ struct RadialWinBody {
 
     // accumulation of one candidate, one-wide: shapes without register-resident per-type sums (many types,
     // run-time shape) contract the coefficients per pair
-    auto accumulate1 = [&](const Cand& c) {
+    auto accumulate1 = [&](const Cand& c) __attribute__((always_inline)) {
       if (S::TS > 0) { // one-wide form of accumulate2 (kept for A/B measurements)
         const float rc = m.uniform_rc ? m.rc_r_max : (rc1 + m.rc_r[c.t2]) * 0.5f;
         float d, dinv;
@@ -382,7 +386,7 @@ struct RadialWinBody {
 #pragma unroll
       for (int kk = 0; kk <= S::KRM; ++kk)
         Ssum2[t][kk] = bc2(0.0f);
-    auto accumulate2 = [&](const Cand& c0, const Cand& c1) {
+    auto accumulate2 = [&](const Cand& c0, const Cand& c1) __attribute__((always_inline)) {
       float rc0, rc1v, ri0, ri1;
       if (m.uniform_rc) {
         rc0 = rc1v = m.rc_r_max;
@@ -416,7 +420,7 @@ struct RadialWinBody {
     // decided and accumulated; the window records of a chunk (slot offset, then the record: two dependent LDS reads)
     // are issued together, ahead of the branchy bookkeeping -- one LDS latency per chunk instead of two per candidate.
     // NEPMI_RW_PIPE = 1 additionally reads chunk c + 1's records before chunk c is processed (16 more registers).
-    auto walk = [&](const unsigned short* __restrict__ codes, const int nn, auto in_list_a) {
+    auto walk = [&](const unsigned short* __restrict__ codes, const int nn, auto in_list_a) __attribute__((always_inline)) {
       auto load_codes = [&](int s0, unsigned* cc) {
 #pragma unroll
         for (int u = 0; u < kWinG; ++u) {
@@ -439,6 +443,10 @@ struct RadialWinBody {
       load_recs(c1, sl0, r0);
       load_codes(kWinG, c1);
       for (int s0 = 0; s0 < nn; s0 += kWinG) {
+        if (decltype(in_list_a)::value && b.use_amask && (s0 & 31) == 0 && s0 > 0) { // a word of the mask is complete
+          b.amask[4 * k + (s0 >> 5) - 1] = am_cur;
+          am_cur = 0u;
+        }
         load_codes(s0 + 2 * kWinG, c2);
         if (NEPMI_RW_PIPE)
           load_recs(c1, sl1, r1);
@@ -466,6 +474,12 @@ struct RadialWinBody {
       }
     };
     walk(b.code_ang + k, na, std::true_type{});
+    if (b.use_amask) { // the last (partial) word and zeros behind it; na <= 128 is what use_amask guarantees
+      const int wlast = na > 0 ? (na - 1) >> 5 : 0;
+      for (int w = 0; w < 4; ++w)
+        if (w >= wlast)
+          b.amask[4 * k + w] = w == wlast ? am_cur : 0u;
+    }
     walk(b.code_skin + k, nbn, std::false_type{});
     if (S::TS > 0 && NEPMI_RW_PACK) {
 #pragma unroll
@@ -482,7 +496,6 @@ struct RadialWinBody {
     b.nn_rad[k] = cnt + cnt1;
     b.nn_t0[k] = cnt;
     b.nn_angstep[k] = ca;
-
     if (S::TS > 0) {
       // q[n] = sum_t2 sum_k c[t1][t2][n][k] S[t2][k]; type loop is wave-uniform => scalar loads
       for (int tu = 0; tu < m.T; ++tu) {
@@ -823,10 +836,28 @@ NEPMI_HD void win_force_angular(const Bufs& b, int64_t k, int part, float* F, fl
       fa[u] = f12o[(int64_t)aa * N];
       rs[u] = arev[(int64_t)aa * N];
     }
+    if (b.use_amask) {
+      // the partner's compact slot = rank of the reverse entry among the set bits of the partner's membership mask
+      U4 mj[C];
 #pragma unroll
-    for (int u = 0; u < C; ++u) {
-      const int j = (int)((unsigned)e[u].w & (unsigned)kIdxMask);
-      ap[u] = rs[u] != (int)kNoSlot ? b.amap[(int64_t)rs[u] * N + j] : kNoSlot;
+      for (int u = 0; u < C; ++u)
+        mj[u] = reinterpret_cast<const U4*>(b.amask)[(int)((unsigned)e[u].w & (unsigned)kIdxMask)];
+#pragma unroll
+      for (int u = 0; u < C; ++u) {
+        const int w = rs[u] >> 5;
+        const unsigned bit = 1u << (rs[u] & 31);
+        const unsigned word = w == 0 ? mj[u].x : (w == 1 ? mj[u].y : (w == 2 ? mj[u].z : mj[u].w));
+        const int base = (w > 0 ? __builtin_popcount(mj[u].x) : 0) + (w > 1 ? __builtin_popcount(mj[u].y) : 0) +
+                         (w > 2 ? __builtin_popcount(mj[u].z) : 0);
+        const bool member = rs[u] != (int)kNoSlot && (word & bit) != 0u;
+        ap[u] = member ? (unsigned short)(base + __builtin_popcount(word & (bit - 1u))) : kNoSlot;
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < C; ++u) {
+        const int j = (int)((unsigned)e[u].w & (unsigned)kIdxMask);
+        ap[u] = rs[u] != (int)kNoSlot ? b.amap[(int64_t)rs[u] * N + j] : kNoSlot;
+      }
     }
 #pragma unroll
     for (int u = 0; u < C; ++u) {
