@@ -57,6 +57,8 @@ int nepmi_dist_compute(nepmi_dist* d)
 {
   if (!d)
     return fail(NEPMI_ERR_ARG, "null handle");
+  if (!d->d->engine())
+    return fail(NEPMI_ERR_ARG, "nepmi_dist_setup has not been called");
   return guarded([&] { d->d->compute(); });
 }
 
@@ -64,8 +66,12 @@ int nepmi_dist_run(
   nepmi_dist* d, int ensemble, double dt, int64_t nsteps, double t1, double t2, double t_coup, int64_t thermo_every,
   double* thermo_host)
 {
-  if (!d || ensemble < 0 || ensemble > 3)
+  if (!d || ensemble < 0 || ensemble > 3 || nsteps < 0)
     return fail(NEPMI_ERR_ARG, "bad argument");
+  if (!d->d->engine())
+    return fail(NEPMI_ERR_ARG, "nepmi_dist_setup has not been called");
+  if (thermo_every > 0 && !thermo_host)
+    return fail(NEPMI_ERR_ARG, "thermo_every > 0 needs a thermo_host buffer");
   if (ensemble != 0 && t_coup < 1.0)
     return fail(NEPMI_ERR_ARG, "Temperature coupling should >= 1.");
   return guarded([&] { d->d->run(ensemble, dt, nsteps, t1, t2, t_coup, thermo_every, thermo_host); });
@@ -75,6 +81,8 @@ int nepmi_dist_thermo(nepmi_dist* d, double thermo8_host[8])
 {
   if (!d || !thermo8_host)
     return fail(NEPMI_ERR_ARG, "null argument");
+  if (!d->d->engine())
+    return fail(NEPMI_ERR_ARG, "nepmi_dist_setup has not been called");
   return guarded([&] { d->d->thermo(thermo8_host); });
 }
 
@@ -112,6 +120,8 @@ int nepmi_dist_gather_owned(nepmi_dist* d, int64_t* ids, double* pos, double* ve
 {
   if (!d)
     return fail(NEPMI_ERR_ARG, "null handle");
+  if (!d->d->engine())
+    return fail(NEPMI_ERR_ARG, "nepmi_dist_setup has not been called");
   return guarded([&] { d->d->gather_owned(ids, pos, vel, force, pe, virial); });
 }
 
@@ -119,6 +129,8 @@ int nepmi_dist_gather_global(nepmi_dist* d, int root, double* pos, double* vel, 
 {
   if (!d)
     return fail(NEPMI_ERR_ARG, "null handle");
+  if (!d->d->engine())
+    return fail(NEPMI_ERR_ARG, "nepmi_dist_setup has not been called");
   return guarded([&] { d->d->gather_global(root, pos, vel, force, pe, virial); });
 }
 

@@ -172,7 +172,7 @@ public:
   {
     if (!have_force_)
       compute();
-    Engine& e = *eng_;
+    Engine* e = eng_.get(); // re-fetched after every decompose(): a grown local system replaces the engine
     if (ens == Engine::kNhc && nhc_fresh_) { // a fresh chain per `run` (integrate.cu:85-92), kept across the calls of one
       be_.template launch<64>(kSlotMisc, 1, NhcInitBody{n_total_, t1, tcoup, dt, nhc_dev_});
       nhc_fresh_ = false;
@@ -183,12 +183,12 @@ public:
     auto nhc_half = [&](double target) {
       thermo_global();
       be_.template launch<64>(kSlotMisc, 1, NhcChainBody{n_total_, target, 0.5 * dt, thermo_dev_, nhc_dev_, frozen()});
-      be_.template launch<256>(kSlotVV, e.num_atoms(), ResidentScaleBody{e.bufs(), nhc_dev_ + 3 * kNhcLinks, 1.0});
+      be_.template launch<256>(kSlotVV, e->num_atoms(), ResidentScaleBody{e->bufs(), nhc_dev_ + 3 * kNhcLinks, 1.0});
     };
     // temperature-dependent NEP: as in EngineT::run_md (every rank sets the same value)
-    const bool temp_ramp = e.temperature_model() && ens != Engine::kNve && t1 != t2;
-    if (e.temperature_model() && ens != Engine::kNve && e.temperature() != t1)
-      e.set_temperature(t1);
+    const bool temp_ramp = e->temperature_model() && ens != Engine::kNve && t1 != t2;
+    if (e->temperature_model() && ens != Engine::kNve && e->temperature() != t1)
+      e->set_temperature(t1);
     std::vector<int> pending;
     int ring_next = 0;
     int64_t step = 0;
@@ -196,12 +196,12 @@ public:
     while (step < nsteps) {
       const double target = target_of(step);
       if (temp_ramp)
-        e.set_temperature(t1 + (t2 - t1) * ((double)(step + 2) / (double)nsteps));
+        e->set_temperature(t1 + (t2 - t1) * ((double)(step + 2) / (double)nsteps));
       if (!resume_after_vv1) {
         if (ens == Engine::kNhc)
           nhc_half(target);
-        be_.template launch<256>(kSlotVV, e.num_atoms(),
-                                 ResidentStepBody{e.box(), e.bufs(), dt, kick2_pending ? 1 : 0, 1, tag_of(step)});
+        be_.template launch<256>(kSlotVV, e->num_atoms(),
+                                 ResidentStepBody{e->box(), e->bufs(), dt, kick2_pending ? 1 : 0, 1, tag_of(step)});
       }
       resume_after_vv1 = false;
       kick2_pending = false;
@@ -209,12 +209,12 @@ public:
       // communication stream; meanwhile the radial pass of the interior bricks -- those whose window holds no ghost --
       // runs on the compute stream.  Host transports block: the interior pass simply runs first, which proves its
       // independence of this step's ghosts (tests/test_dist.py compares both orders bit for bit).
-      const bool split = overlap_ && e.tiles_active() && tr_.nranks > 1;
+      const bool split = overlap_ && e->tiles_active() && tr_.nranks > 1;
       B& comm = (split && tr_.device_buffers) ? comm_backend() : be_;
       if (&comm != &be_)
         be_.fork_to(comm);
       if (split) {
-        e.force_kernels(Engine::kPhaseInterior);
+        e->force_kernels(Engine::kPhaseInterior);
         ++num_overlapped;
       }
       int trip = vote(spec, comm);
@@ -223,20 +223,20 @@ public:
       if (&comm != &be_)
         be_.join_from(comm);
       if (!trip) {
-        e.force_kernels(split ? Engine::kPhaseBoundary : Engine::kPhaseAll, frozen());
+        e->force_kernels(split ? Engine::kPhaseBoundary : Engine::kPhaseAll, frozen());
         const bool record = thermo_every > 0 && (step + 1) % thermo_every == 0;
         const bool last = step + 1 == nsteps;
         bool need_sync = record || last;
         if (ens == Engine::kNve && !record && !last) {
           kick2_pending = true;
         } else {
-          be_.template launch<256>(kSlotVV, e.num_atoms(), ResidentStepBody{e.box(), e.bufs(), dt, 1, 0, 0});
+          be_.template launch<256>(kSlotVV, e->num_atoms(), ResidentStepBody{e->box(), e->bufs(), dt, 1, 0, 0});
           if (ens == Engine::kBer) {
             thermo_global();
             if (1.0 / tcoup > 1.0e-5) {
               be_.template launch<64>(kSlotMisc, 1,
-                                      BerendsenFactorBody{e.bufs().flags, target, 1.0 / tcoup, thermo_dev_, factor_dev_});
-              be_.template launch<256>(kSlotVV, e.num_atoms(), ResidentScaleBody{e.bufs(), factor_dev_, 1.0});
+                                      BerendsenFactorBody{e->bufs().flags, target, 1.0 / tcoup, thermo_dev_, factor_dev_});
+              be_.template launch<256>(kSlotVV, e->num_atoms(), ResidentScaleBody{e->bufs(), factor_dev_, 1.0});
             }
           } else if (ens == Engine::kNhc) {
             nhc_half(target);
@@ -254,14 +254,14 @@ public:
             if (ens == Engine::kBdp) {
               double T = 0.0;
               be_.d2h(&T, thermo_dev_, sizeof(double));
-              be_.template launch<256>(kSlotVV, e.num_atoms(),
-                                       ResidentScaleBody{e.bufs(), nullptr, e.bdp_factor(n_total_, T, target, tcoup)});
+              be_.template launch<256>(kSlotVV, e->num_atoms(),
+                                       ResidentScaleBody{e->bufs(), nullptr, e->bdp_factor(n_total_, T, target, tcoup)});
             }
             if (record && thermo_host)
               be_.d2h(thermo_host + 8 * ((step + 1) / thermo_every - 1), thermo_dev_, 8 * sizeof(double));
           }
         } else if (spec && (step + 1) % Engine::kPollEvery == 0) {
-          be_.poll_record(ring_next, e.bufs().flags);
+          be_.poll_record(ring_next, e->bufs().flags);
           pending.push_back(ring_next);
           ring_next = (ring_next + 1) % 8;
           if ((int)pending.size() > Engine::kPollDepth) {
@@ -277,9 +277,10 @@ public:
         // frozen right after the first half-step of step `trip - 1` on every rank: re-decompose and resume there
         be_.sync();
         pending.clear();
-        e.num_discarded += step - ((int64_t)trip - 1) + 1;
+        e->num_discarded += step - ((int64_t)trip - 1) + 1;
         step = (int64_t)trip - 1;
         decompose();
+        e = eng_.get();
         resume_after_vv1 = true;
         kick2_pending = false;
         continue;
@@ -289,9 +290,9 @@ public:
     num_steps += nsteps;
     // the last step's kernels may have raised a capacity bit after its vote: reduce the words once more, so that the
     // final check throws on every rank or on none
-    device_allreduce(e.bufs().flags + kFlagMoved, 2, kDtI32, kOpMax);
+    device_allreduce(e->bufs().flags + kFlagMoved, 2, kDtI32, kOpMax);
     be_.sync();
-    e.check_flags_now();
+    e->check_flags_now();
   }
 
   // T, U and the six stress components of the whole system -> thermo8 (HOST)
@@ -794,9 +795,12 @@ private:
     // 7. engine: lists on the local system, internal index lists of the halo, integrator state
     if (!eng_ || n_loc > eng_cap_) {
       eng_cap_ = n_loc + n_loc / 7 + 1024;
-      eng_.reset(new Engine(model_, eng_cap_, be_));
-      eng_->set_external_skin(true); // the global vote is the skin policy
-      eng_->bdp_seed(seed_);
+      std::unique_ptr<Engine> grown(new Engine(model_, eng_cap_, be_));
+      grown->set_external_skin(true); // the global vote is the skin policy
+      grown->bdp_seed(seed_);
+      if (eng_) // a grown local system: the switches, the temperature, the noise sequence and the counters move over
+        grown->adopt_from(*eng_);
+      eng_ = std::move(grown);
     }
     Engine& e = *eng_;
     e.invalidate();

@@ -898,6 +898,12 @@ struct HipBackend {
       timer_stop(timing->slot[slot]);
   }
   void set_mfma(bool on) { mfma_on = on; }
+  void adopt_options(const HipBackend& o) // a replacement engine keeps the switches of the one it replaces
+  {
+    timing_on = o.timing_on;
+    timing_mode = o.timing_mode;
+    mfma_on = o.mfma_on;
+  }
 
   template <class Body>
   void launch_win(int slot, int64_t nbricks, const Body& body)
@@ -1054,9 +1060,50 @@ static NepmiBackend nepmi_make_backend(void* stream)
 #include "dist_capi_impl.h"
 
 // ---- RCCL transport (device buffers over xGMI): nepmi_transport_rccl ---------------------------------------
-#include <rccl/rccl.h>
+// librccl.so is opened on first use, so that a single-GPU host without RCCL can still load libnepmi.so.
+#include <dlfcn.h>
+#include <rccl/rccl.h> // types and prototypes only: every call goes through the table below
 
 namespace {
+
+struct RcclApi {
+  decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+  decltype(&ncclCommInitRank) CommInitRank = nullptr;
+  decltype(&ncclCommDestroy) CommDestroy = nullptr;
+  decltype(&ncclGroupStart) GroupStart = nullptr;
+  decltype(&ncclGroupEnd) GroupEnd = nullptr;
+  decltype(&ncclSend) Send = nullptr;
+  decltype(&ncclRecv) Recv = nullptr;
+  decltype(&ncclAllReduce) AllReduce = nullptr;
+  bool ok = false;
+};
+
+const RcclApi& rccl_api()
+{
+  static const RcclApi api = [] {
+    RcclApi a;
+    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h)
+      h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h)
+      h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!h)
+      return a;
+#define NEPMI_RCCL_SYM(name) a.name = reinterpret_cast<decltype(a.name)>(dlsym(h, "nccl" #name))
+    NEPMI_RCCL_SYM(GetUniqueId);
+    NEPMI_RCCL_SYM(CommInitRank);
+    NEPMI_RCCL_SYM(CommDestroy);
+    NEPMI_RCCL_SYM(GroupStart);
+    NEPMI_RCCL_SYM(GroupEnd);
+    NEPMI_RCCL_SYM(Send);
+    NEPMI_RCCL_SYM(Recv);
+    NEPMI_RCCL_SYM(AllReduce);
+#undef NEPMI_RCCL_SYM
+    a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.GroupStart && a.GroupEnd && a.Send && a.Recv && a.AllReduce;
+    return a;
+  }();
+  return api;
+}
 
 struct RcclCtx {
   ncclComm_t comm;
@@ -1065,12 +1112,13 @@ struct RcclCtx {
 int rccl_exchange(void* vctx, int ns, const nepmi_msg* sends, int nr, const nepmi_msg* recvs, void* stream)
 {
   RcclCtx* c = (RcclCtx*)vctx;
-  bool ok = ncclGroupStart() == ncclSuccess;
+  const RcclApi& R = rccl_api();
+  bool ok = R.GroupStart() == ncclSuccess;
   for (int k = 0; k < ns && ok; ++k)
-    ok = ncclSend(sends[k].buf, (size_t)sends[k].bytes, ncclChar, sends[k].peer, c->comm, (hipStream_t)stream) == ncclSuccess;
+    ok = R.Send(sends[k].buf, (size_t)sends[k].bytes, ncclChar, sends[k].peer, c->comm, (hipStream_t)stream) == ncclSuccess;
   for (int k = 0; k < nr && ok; ++k)
-    ok = ncclRecv(recvs[k].buf, (size_t)recvs[k].bytes, ncclChar, recvs[k].peer, c->comm, (hipStream_t)stream) == ncclSuccess;
-  ok = (ncclGroupEnd() == ncclSuccess) && ok;
+    ok = R.Recv(recvs[k].buf, (size_t)recvs[k].bytes, ncclChar, recvs[k].peer, c->comm, (hipStream_t)stream) == ncclSuccess;
+  ok = (R.GroupEnd() == ncclSuccess) && ok;
   return ok ? 0 : -1;
 }
 
@@ -1079,14 +1127,14 @@ int rccl_allreduce(void* vctx, void* buf, int64_t count, int dtype, int op, void
   RcclCtx* c = (RcclCtx*)vctx;
   const ncclDataType_t dt = dtype == 0 ? ncclFloat64 : (dtype == 1 ? ncclInt32 : ncclInt64);
   const ncclRedOp_t ro = op == 0 ? ncclSum : ncclMax;
-  return ncclAllReduce(buf, buf, (size_t)count, dt, ro, c->comm, (hipStream_t)stream) == ncclSuccess ? 0 : -1;
+  return rccl_api().AllReduce(buf, buf, (size_t)count, dt, ro, c->comm, (hipStream_t)stream) == ncclSuccess ? 0 : -1;
 }
 
 void rccl_destroy(void* vctx)
 {
   RcclCtx* c = (RcclCtx*)vctx;
   if (c) {
-    ncclCommDestroy(c->comm);
+    rccl_api().CommDestroy(c->comm);
     delete c;
   }
 }
@@ -1096,8 +1144,10 @@ void rccl_destroy(void* vctx)
 extern "C" int nepmi_transport_rccl_id(char id[NEPMI_RCCL_ID_BYTES])
 {
   static_assert(sizeof(ncclUniqueId) <= NEPMI_RCCL_ID_BYTES, "ncclUniqueId does not fit the id buffer");
+  if (!rccl_api().ok)
+    return fail(NEPMI_ERR_HIP, "librccl.so could not be opened: the RCCL transport is not available on this host");
   ncclUniqueId u;
-  if (ncclGetUniqueId(&u) != ncclSuccess)
+  if (rccl_api().GetUniqueId(&u) != ncclSuccess)
     return fail(NEPMI_ERR_HIP, "ncclGetUniqueId failed");
   std::memset(id, 0, NEPMI_RCCL_ID_BYTES);
   std::memcpy(id, &u, sizeof u);
@@ -1108,10 +1158,12 @@ extern "C" int nepmi_transport_rccl(const char id[NEPMI_RCCL_ID_BYTES], int rank
 {
   if (!id || !out || rank < 0 || rank >= nranks)
     return fail(NEPMI_ERR_ARG, "bad argument");
+  if (!rccl_api().ok)
+    return fail(NEPMI_ERR_HIP, "librccl.so could not be opened: the RCCL transport is not available on this host");
   ncclUniqueId u;
   std::memcpy(&u, id, sizeof u);
   RcclCtx* c = new RcclCtx();
-  if (ncclCommInitRank(&c->comm, nranks, u, rank) != ncclSuccess) {
+  if (rccl_api().CommInitRank(&c->comm, nranks, u, rank) != ncclSuccess) {
     delete c;
     return fail(NEPMI_ERR_HIP, "ncclCommInitRank failed (one process per GPU: two ranks cannot share a device)");
   }

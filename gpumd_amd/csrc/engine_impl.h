@@ -1357,6 +1357,34 @@ public:
   {
     return recompute_mode_ < 0 ? (model_.MN_angular <= 16 ? 1 : 0) : (recompute_mode_ ? 1 : 0);
   }
+  // A decomposed run replaces its engine when the local system outgrows it (DistT::decompose): everything that is not
+  // derived from the atom count moves over -- option switches, the temperature of a temperature-dependent model, the BDP
+  // generator (the noise sequence continues), the thermostat chain flag and the counters.
+  void adopt_from(const EngineT& o)
+  {
+    use_tiles_ = o.use_tiles_;
+    tile_mode_ = o.tile_mode_;
+    recompute_mode_ = o.recompute_mode_;
+    win_lanes_ = o.win_lanes_;
+    external_skin_ = o.external_skin_;
+    unwrapped_ = o.unwrapped_;
+    nhc_fresh_ = o.nhc_fresh_;
+    bdp_rng_ = o.bdp_rng_;
+    bdp_iset_ = o.bdp_iset_;
+    bdp_gset_ = o.bdp_gset_;
+    lan_seed_ = o.lan_seed_;
+    num_compute = o.num_compute;
+    num_rebuild = o.num_rebuild;
+    num_discarded = o.num_discarded;
+    be_.adopt_options(o.be_);
+    if (ann_mode_ != o.ann_mode_)
+      set_use_mfma(o.ann_mode_);
+    if (force_generic_ != o.force_generic_)
+      set_force_generic(o.force_generic_);
+    if (o.temperature_ != temperature_)
+      set_temperature(o.temperature_);
+    have_list_ = false;
+  }
   void set_force_generic(bool on)
   {
     force_generic_ = on;

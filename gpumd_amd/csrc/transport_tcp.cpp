@@ -8,6 +8,7 @@
 // order + broadcast, which gives every rank bit-identical sums.
 #include <arpa/inet.h>
 #include <netinet/in.h>
+#include <netdb.h>
 #include <netinet/tcp.h>
 #include <poll.h>
 #include <sys/socket.h>
@@ -60,6 +61,41 @@ bool recv_all(int fd, void* buf, size_t n)
   return true;
 }
 
+// dotted quad or host name (MASTER_ADDR=localhost is common under torchrun / mpirun) -> IPv4 address; false if unknown
+bool resolve_ipv4(const char* addr, in_addr* out)
+{
+  if (!addr) {
+    out->s_addr = htonl(INADDR_LOOPBACK);
+    return true;
+  }
+  if (inet_pton(AF_INET, addr, out) == 1)
+    return true;
+  addrinfo hints;
+  std::memset(&hints, 0, sizeof hints);
+  hints.ai_family = AF_INET;
+  hints.ai_socktype = SOCK_STREAM;
+  addrinfo* res = nullptr;
+  if (getaddrinfo(addr, nullptr, &hints, &res) != 0 || !res)
+    return false;
+  *out = ((sockaddr_in*)res->ai_addr)->sin_addr;
+  freeaddrinfo(res);
+  return true;
+}
+
+// accept with a deadline: a rank that never starts must not hang the others for ever
+int accept_within(int lsock, int timeout_ms)
+{
+  pollfd pf{lsock, POLLIN, 0};
+  for (;;) {
+    const int r = ::poll(&pf, 1, timeout_ms);
+    if (r < 0 && errno == EINTR)
+      continue;
+    if (r <= 0)
+      return -1;
+    return ::accept(lsock, nullptr, nullptr);
+  }
+}
+
 int listen_on(const char* addr, int port, int* port_out)
 {
   const int s = ::socket(AF_INET, SOCK_STREAM, 0);
@@ -71,7 +107,10 @@ int listen_on(const char* addr, int port, int* port_out)
   std::memset(&a, 0, sizeof a);
   a.sin_family = AF_INET;
   a.sin_port = htons((uint16_t)port);
-  a.sin_addr.s_addr = addr ? inet_addr(addr) : htonl(INADDR_LOOPBACK);
+  if (!resolve_ipv4(addr, &a.sin_addr)) {
+    ::close(s);
+    return -1;
+  }
   if (::bind(s, (sockaddr*)&a, sizeof a) != 0 || ::listen(s, 128) != 0) {
     ::close(s);
     return -1;
@@ -84,6 +123,9 @@ int listen_on(const char* addr, int port, int* port_out)
 
 int connect_to(const char* addr, int port)
 {
+  in_addr ip;
+  if (!resolve_ipv4(addr, &ip))
+    return -1;
   for (int attempt = 0; attempt < 600; ++attempt) { // the peer may not be listening yet: retry for ~60 s
     const int s = ::socket(AF_INET, SOCK_STREAM, 0);
     if (s < 0)
@@ -92,7 +134,7 @@ int connect_to(const char* addr, int port)
     std::memset(&a, 0, sizeof a);
     a.sin_family = AF_INET;
     a.sin_port = htons((uint16_t)port);
-    a.sin_addr.s_addr = inet_addr(addr);
+    a.sin_addr = ip;
     if (::connect(s, (sockaddr*)&a, sizeof a) == 0) {
       int one = 1;
       ::setsockopt(s, IPPROTO_TCP, TCP_NODELAY, &one, sizeof one);
@@ -156,7 +198,11 @@ int tcp_exchange(void* vctx, int ns, const nepmi_msg* sends, int nr, const nepmi
     }
     if (pf.empty())
       return 0;
-    if (::poll(pf.data(), (nfds_t)pf.size(), 60000) <= 0)
+    int pr;
+    do
+      pr = ::poll(pf.data(), (nfds_t)pf.size(), 60000);
+    while (pr < 0 && errno == EINTR);
+    if (pr <= 0)
       return -1;
     for (size_t k = 0; k < pf.size(); ++k) {
       Op& o = ops[which[k]];
@@ -266,7 +312,7 @@ extern "C" int nepmi_transport_tcp(const char* master_addr, int port, int rank, 
   if (rank == 0) {
     // accept the nranks - 1 others; each first says who it is and where it listens
     for (int k = 1; k < nranks && ok; ++k) {
-      const int s = ::accept(lsock, nullptr, nullptr);
+      const int s = accept_within(lsock, 120000);
       int hello[2] = {0, 0};
       ok = s >= 0 && recv_all(s, hello, sizeof hello) && hello[0] > 0 && hello[0] < nranks && c->fd[hello[0]] < 0;
       if (ok) {
@@ -291,7 +337,7 @@ extern "C" int nepmi_transport_tcp(const char* master_addr, int port, int rank, 
       c->fd[r] = t;
     }
     for (int k = rank + 1; k < nranks && ok; ++k) {
-      const int t = ::accept(lsock, nullptr, nullptr);
+      const int t = accept_within(lsock, 120000);
       int who = -1;
       ok = t >= 0 && recv_all(t, &who, sizeof who) && who > rank && who < nranks && c->fd[who] < 0;
       if (ok) {

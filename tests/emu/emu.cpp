@@ -63,6 +63,7 @@ struct HostLoopBackend {
     launch<64>(slot, n, AnnBody<S>{m, b});
   }
   void set_mfma(bool) {}
+  void adopt_options(const HostLoopBackend&) {}
   void probe_start() {}
   double probe_stop_ms() { return 0.0; } // no clock on the CPU tier: the engine keeps its default variant
   void ann_prepare(const ModelD&, const Bufs&) {}

@@ -109,7 +109,24 @@ def test_decomposed_run_matches_single_domain(world, model, reps, grid, ensemble
     (2, "UNEP-v1", (10, 5, 5), (2, 1, 1), "nve", 8, 3000.0),
 ])
 def test_decomposed_run_on_gpu_kernels(world, model, reps, grid, ensemble, nsteps, temp):
-    _check(world, _spec("gpu", model, reps, grid, ensemble, nsteps, temp), _natoms(model, reps))
+    n = _natoms(model, reps)
+    multi, _ = _check(world, _spec("gpu", model, reps, grid, ensemble, nsteps, temp), n)
+    # ... and against the ORACLE, not only against the single-domain run of the same library: the forces of the initial
+    # configuration, and the forces the decomposed run ends with (after its re-decompositions, migrations and ghost
+    # levels) at the positions it ends with
+    xm, vm, fm, f0m = _merge(multi, n)
+    if model == "PbTe-reps":
+        nep, (h, typ, x) = H.golden("PbTe", "nep.txt"), H.pbte_supercell(tuple(reps), rattle=0.02, seed=31)
+    elif model == "C-2022":
+        nep, (h, typ, x) = H.golden("C", "nep.txt"), H.diamond(tuple(reps), 3.57, rattle=0.02, seed=32)
+    else:
+        nep, (h, typ, x) = H.golden("UNEP", "nep.txt"), H.fcc_alloy(tuple(reps), 3.9, 16, rattle=0.02, seed=33)
+    orc = H.Oracle(nep)
+    _, f64, _ = orc.compute(typ, h, x, precision=64, path=0)
+    assert np.all(np.abs(f0m.reshape(-1) - f64) <= 1e-4 * np.abs(f64) + 3e-5), np.abs(f0m.reshape(-1) - f64).max()
+    x1 = H.oracle_apply_pbc(h, np.ascontiguousarray(xm).reshape(-1))
+    _, f64e, _ = orc.compute(typ, h, x1, precision=64, path=0)
+    assert np.all(np.abs(fm.reshape(-1) - f64e) <= 1e-4 * np.abs(f64e) + 3e-5), np.abs(fm.reshape(-1) - f64e).max()
 
 
 def test_decomposed_nve_matches_the_fused_single_gpu_loop():
