@@ -26,6 +26,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 REF = os.path.join(ROOT, "oracle", "_ref", "gpumd_ref")
 MI = os.path.join(ROOT, "gpumd_amd", "bin", "gpumd-mi")
+# the drop-in, executed: the reference's own host with its NEP factory line patched to the INTEGRATION.md adaptor, linked
+# against libnepmi.so (oracle/ref_gpumd.mk: _ref/gpumd_ref_mi)
+REF_MI = os.path.join(ROOT, "oracle", "_ref", "gpumd_ref_mi")
 GOLD = os.path.join(ROOT, "tests", "golden")
 
 
@@ -209,6 +212,8 @@ def main():
     ap.add_argument("--cases", nargs="+", default=["pbte_1m", "si_tersoff", "carbon_nvt", "unep", "pbte_16k"])
     ap.add_argument("--timeout", type=float, default=240.0)
     ap.add_argument("--fine", type=int, default=0, help="thermo every step, run this many steps (MD-level parity)")
+    ap.add_argument("--dropin", action="store_true",
+                    help="also run oracle/_ref/gpumd_ref_mi (the reference host on libnepmi.so) on every case")
     args = ap.parse_args()
     global FINE
     FINE = args.fine
@@ -220,7 +225,10 @@ def main():
         base = os.path.join(args.out, name)
         res = {}
         ths = {}
-        for tag, exe in (("ref", REF), ("mi", MI)):
+        binaries = [("ref", REF), ("mi", MI)]
+        if args.dropin and os.path.exists(REF_MI) and name != "si_tersoff":
+            binaries.append(("ref_mi", REF_MI))
+        for tag, exe in binaries:
             d = os.path.join(base, tag)
             n = case_inputs(name, d)
             res[tag], ths[tag] = run_binary(exe, d, args.timeout)
@@ -232,8 +240,12 @@ def main():
         res["thermo"] = compare_thermo(ths["ref"], ths["mi"])
         if res["ref"]["speed"] and res["mi"]["speed"]:
             res["speedup_mi_over_ref"] = res["mi"]["speed"] / res["ref"]["speed"]
+        if "ref_mi" in res:
+            res["thermo_dropin_vs_ref"] = compare_thermo(ths["ref"], ths["ref_mi"])
+            if res["ref"]["speed"] and res["ref_mi"]["speed"]:
+                res["speedup_dropin_over_ref"] = res["ref_mi"]["speed"] / res["ref"]["speed"]
         summary[name] = res
-        print(name, json.dumps({k: v for k, v in res.items() if k != "thermo"}), flush=True)
+        print(name, json.dumps({k: v for k, v in res.items() if not k.startswith("thermo")}), flush=True)
         if res["thermo"].get("comparable"):
             print("   thermo first row:", json.dumps(res["thermo"]["first_row"]))
             print("   thermo last row: ", json.dumps(res["thermo"]["last_row"]), flush=True)

@@ -62,3 +62,40 @@ def test_thermo_rows_match_reference_gpumd(case, tmp_path):
     np.testing.assert_allclose(b[:, 2], a[:, 2], rtol=ru)            # potential energy
     np.testing.assert_allclose(b[:, 3:9], a[:, 3:9], rtol=0, atol=ap)  # stress components, GPa
     np.testing.assert_allclose(b[:, 9:], a[:, 9:], rtol=1e-12)       # box
+
+
+# ---- the drop-in, executed: the REFERENCE's own host -- its run.in parser, Integrate / Ensemble_*, Force, Measure,
+# dump_thermo -- with the NEP line of its potential factory (src/force/force.cu:145) constructing the INTEGRATION.md adaptor
+# `class NEP_MI : public Potential` over libnepmi.so (oracle/ref_gpumd.mk: _ref/gpumd_ref_mi).  Its thermo.out rows against
+# the unpatched reference (same tolerances as above) and against gpumd-mi.
+DROPIN_CASES = ["pbte_16k", "pbte_250", "carbon_nvt", "carbon_nhc", "unep", "pbte_temperature"]
+
+
+@pytest.mark.parametrize("case", DROPIN_CASES)
+def test_reference_host_runs_on_libnepmi(case, tmp_path):
+    import ref_compare as R
+    if not os.path.exists(R.REF) or not os.path.exists(R.REF_MI):
+        pytest.skip("oracle/_ref/gpumd_ref[_mi] not built (needs /root/reference at build time)")
+    R.FINE = 20
+    try:
+        th, out = {}, {}
+        for tag, exe in (("ref", R.REF), ("ref_mi", R.REF_MI), ("mi", R.MI)):
+            d = str(tmp_path / tag)
+            R.case_inputs(case, d)
+            res, th[tag] = R.run_binary(exe, d, 300.0)
+            out[tag] = open(os.path.join(d, "stdout.txt")).read()
+            assert res["rc"] == 0, out[tag][-2000:]
+            assert res["speed"] is not None  # the reference's "Speed of this run" line
+    finally:
+        R.FINE = 0
+    # it is our engine that ran inside the reference's process: the adaptor's constructor says so in the reference's log
+    assert "through libnepmi (NEP_MI)" in out["ref_mi"] and "NEP_MI" not in out["ref"]
+    a, b, c = th["ref"], th["ref_mi"], th["mi"]
+    assert a is not None and b is not None and a.shape == b.shape and a.shape[0] == 20
+    rt, ru, ap = CASES[case]
+    for other in (a, c):  # vs the unpatched reference, and vs our own host on the same library
+        np.testing.assert_allclose(b[:, 0], other[:, 0], rtol=rt)
+        np.testing.assert_allclose(b[:, 1], other[:, 1], rtol=rt)
+        np.testing.assert_allclose(b[:, 2], other[:, 2], rtol=ru)
+        np.testing.assert_allclose(b[:, 3:9], other[:, 3:9], rtol=0, atol=ap)
+        np.testing.assert_allclose(b[:, 9:], other[:, 9:], rtol=1e-12)
