@@ -10,6 +10,10 @@
 #include <string.h>
 
 #define NEPO_LMAX 8
+/* The per-atom sweeps are shared among the host's cores (OpenMP) from this size on: a team of hundreds of threads costs more
+ * than the work of a small cell (the parity cases of a few thousand atoms run thousands of sweeps).  The results do not
+ * depend on the thread count: every atom's arithmetic is that of the serial sweep. */
+#define NEPO_OMP_MIN_ATOMS 30000
 #define NEPO_NABC 80 /* (L_max+1)^2 - 1 for L_max = 8 (NUM_OF_ABC, nep_utilities.cuh:18) */
 #define NEPO_MAX_BASIS 20
 #define NEPO_MAX_TYPES 94
