@@ -353,6 +353,30 @@ nepmi_win_kernel(const Body body, const int64_t nbricks)
     body.compute(brick, k, lds);
 }
 
+// The window kernels on the static window layout (Bufs::wtab, RadialWin2Body / ForceWinBody::stage): the records are copied
+// straight to their slots -- no cell-count scan, one barrier.
+template <class Body>
+__global__ void __launch_bounds__(kWinThreads) __attribute__((amdgpu_waves_per_eu(Body::kMinWavesPerEu)))
+nepmi_win2_kernel(const Body body, const int64_t nbricks)
+{
+  extern __shared__ __attribute__((aligned(16))) char nepmi_win_lds[];
+  NEPMI_LDS(char)* lds = (NEPMI_LDS(char)*)nepmi_win_lds;
+  if (body.skip())
+    return;
+  const unsigned per_xcd = gridDim.x >> 3;
+  const int64_t wg = (int64_t)(blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+  if (wg >= nbricks)
+    return;
+  const int64_t brick = body.map_brick(wg);
+  const int tid = (int)threadIdx.x;
+  body.stage(brick, lds, tid, kWinThreads);
+  __syncthreads();
+  int64_t a0, a1;
+  body.brick_range(brick, a0, a1);
+  for (int64_t k = a0 + tid; k < a1; k += kWinThreads)
+    body.compute(brick, k, lds);
+}
+
 // The same with Body::kLanes = 2 or 4 adjacent lanes per atom (256 kLanes threads): systems with too few bricks to
 // fill the chip, where a window kernel's run time is the latency of one workgroup (RadialWinSplitBody).
 template <class Body>
@@ -920,6 +944,26 @@ struct HipBackend {
     if (t)
       timer_start(timing->slot[slot]);
     hipLaunchKernelGGL((nepmi_win_kernel<Body>), dim3((unsigned)grid), dim3(kWinThreads), lds_bytes, stream, body, nbricks);
+    NEPMI_HIP_CHECK(hipGetLastError());
+    if (t)
+      timer_stop(timing->slot[slot]);
+  }
+
+  template <class Body>
+  void launch_win2(int slot, int64_t nbricks, const Body& body)
+  {
+    if (nbricks <= 0)
+      return;
+    const int64_t grid = (nbricks + 7) / 8 * 8;
+    const size_t lds_bytes = ((size_t)body.lds_bytes() + 15) / 16 * 16;
+    if (lds_bytes > 64 * 1024)
+      NEPMI_HIP_CHECK(hipFuncSetAttribute(
+        reinterpret_cast<const void*>(&nepmi_win2_kernel<Body>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (int)lds_bytes));
+    const bool t = timed(slot);
+    if (t)
+      timer_start(timing->slot[slot]);
+    hipLaunchKernelGGL((nepmi_win2_kernel<Body>), dim3((unsigned)grid), dim3(kWinThreads), lds_bytes, stream, body, nbricks);
     NEPMI_HIP_CHECK(hipGetLastError());
     if (t)
       timer_stop(timing->slot[slot]);

@@ -19,6 +19,10 @@
 #include <random>
 #include <vector>
 
+#ifndef NEPMI_WIN2_DEFAULT
+#define NEPMI_WIN2_DEFAULT 1 // A/B switch (profiles/ab_variants.sh): 0 = the scanned window layout unless asked for
+#endif
+
 namespace nepmi {
 
 enum KernelSlot {
@@ -917,6 +921,10 @@ private:
       b_.prec = dalloc<WinRec>(N);
       b_.aidx = dalloc<unsigned short>((size_t)b_.MN_acomp * N);
       b_.amask = dalloc<unsigned>(4 * (size_t)N);
+      // static window layout (Bufs::wtab comes with the cell arrays): list words of four LDS slots
+      b_.MN_wchunks = (b_.MN_ang + 3) / 4 + 2 * ((b_.MN_skin + 3) / 4) + 4;
+      b_.wcode = dalloc<unsigned short>((size_t)b_.MN_wchunks * 4 * N);
+      b_.wseg = dalloc<int>(N);
     } else { // Tersoff-1989: Tersoff1989::Tersoff1989 allocations (tersoff1989.cu:141-149)
       tb_.rec = dalloc<D4>((size_t)b_.MN_ang * N);
       tb_.bb = dalloc<double>((size_t)b_.MN_ang * N);
@@ -1091,6 +1099,7 @@ private:
       b_.cell_ghost = dalloc<int>(ncell);
       b_.brick_flag = dalloc<int>(ncell / 64 + 2);
       b_.brick_order = dalloc<int>(ncell / 64 + 1);
+      b_.wtab = model_.kind == 0 ? dalloc<int>((size_t)(ncell / 64 + 1) * 1024) : nullptr;
       scan_scratch_ = dalloc<int>(ncell / 1024 + 1024);
       ncell_cap_ = ncell;
     }
@@ -1206,6 +1215,14 @@ private:
       if (box_.pbc[d] && nb[d] < 8)
         tile_ok_ = false;
     win_.wmax = (flags[kFlagMaxWindow] + 63) / 64 * 64;
+    // static window layout of the one-lane window kernels: Verlet entries as LDS slots, four to a word
+    win2_ok_ = tile_ok_ && use_win2_ && b_.wtab != nullptr && win_.wmax < 65535;
+    if (win2_ok_) {
+      b_.wsent = win_.wmax;
+      be_.template launch<128>(kSlotMisc, N_, PackCodesBody{b_, shape_ts() == 2 ? 2 : 1});
+      be_.d2h(flags, b_.flags, sizeof(flags));
+      check_overflow(flags);
+    }
     have_list_ = true;
     ++num_rebuild;
   }
@@ -1307,7 +1324,7 @@ public:
     return num_bricks_ <= 256 ? 4 : (num_bricks_ <= 400 ? 2 : 1);
   }
   void set_win_lanes(int lanes) { win_lanes_ = (lanes == 1 || lanes == 2 || lanes == 4) ? lanes : 0; }
-  int tile_mode_in_use() const { return tile_ok_ ? 2 : 0; }
+  int tile_mode_in_use() const { return tile_ok_ ? ((win2_ok_ && win_lanes() == 1) ? 3 : 2) : 0; }
   bool tiles_active() const { return tile_ok_; }
   // 0: per-atom ANN kernel; 1 (default): descriptor + ANN fused where the shape allows it, else the matrix-core
   // kernel; 2: the matrix-core kernel wherever it applies (no fusion)
@@ -1366,6 +1383,7 @@ public:
     tile_mode_ = o.tile_mode_;
     recompute_mode_ = o.recompute_mode_;
     win_lanes_ = o.win_lanes_;
+    use_win2_ = o.use_win2_;
     external_skin_ = o.external_skin_;
     unwrapped_ = o.unwrapped_;
     nhc_fresh_ = o.nhc_fresh_;
@@ -1389,6 +1407,15 @@ public:
   {
     force_generic_ = on;
     select_shape();
+    have_list_ = false; // the packed list words follow the shape (two type-pure streams for two-type shapes)
+  }
+  // types with register-resident sums of the selected shape (Shape::TS)
+  int shape_ts() const { return (shape_ == 1 || shape_ == 2) ? 2 : (shape_ == 3 ? 1 : 0); }
+  // 1 (default): the one-lane window kernels run on the static window layout (RadialWin2Body); 0: the scanned layout
+  void set_win2(bool on)
+  {
+    use_win2_ = on;
+    have_list_ = false;
   }
   int shape_id() const { return shape_; }
 
@@ -1408,8 +1435,14 @@ private:
       return;
     }
     const int lanes = win_lanes();
+    const bool win2 = win2_ok_ && lanes == 1;
+    WinLayout lay2 = win_;
+    lay2.compact = 1;
+    const WinStage ws2{box_, b_, lay2};
     auto radial = [&](int64_t nb, int first) {
-      if (lanes == 4)
+      if (win2)
+        be_.launch_win2(kSlotRadial, nb, RadialWin2Body<S>{ws2, md_, first, frozen});
+      else if (lanes == 4)
         be_.launch_win_split(kSlotRadial, nb, RadialWinSplitBody<S, 4>{ws, md_, first, frozen});
       else if (lanes == 2)
         be_.launch_win_split(kSlotRadial, nb, RadialWinSplitBody<S, 2>{ws, md_, first, frozen});
@@ -1437,6 +1470,8 @@ private:
     launch_angular_force<S>();
     if (!tile_ok_)
       be_.template launch<64>(kSlotForce, N_, ForceAssembleBody<S>{md_, b_});
+    else if (win2)
+      be_.launch_win2(kSlotForce, num_bricks_, ForceWinBody<S>{ws2, md_, frozen});
     else if (lanes == 4)
       be_.launch_win_split(kSlotForce, num_bricks_, ForceWinBody<S, 4>{ws, md_, frozen});
     else if (lanes == 2)
@@ -1483,7 +1518,8 @@ private:
   ModelD md_;
   Bufs b_;
   BoxD box_;
-  WinLayout win_{0};
+  WinLayout win_{0, 0};
+  bool win2_ok_ = false, use_win2_ = NEPMI_WIN2_DEFAULT != 0; // static window layout (Bufs::wtab / wcode) in use / allowed
   double* ui_alloc_ = nullptr;
   double* factor_dev_ = nullptr;
   bool tile_ok_ = false, use_tiles_ = true;

@@ -156,6 +156,19 @@ struct Bufs {
   WinRec* prec; // [N]
   int* kcell;   // [N] cell index (brick-major numbering) at the last rebuild
   WinGeom wg;
+  // Static window layout (one-lane window kernels): which atom sits at which LDS slot of a brick's window is fixed between two
+  // list rebuilds (cells keep their members), so it is tabulated once per rebuild instead of being scanned by every launch:
+  //   wtab[(brick * 512 + wc) * 2 + {0, 1}] = first atom of window cell wc, LDS slot of its first atom | atoms << 16
+  // and the Verlet entries are kept as LDS slots, four to an 8-byte word:
+  //   wcode[(chunk * N + k) * 4 + u]: list A (its own order), then list B -- for two-type shapes first the neighbours of
+  //   type 0 and of type 1 as word pairs (row 2p: four of type 0, row 2p + 1: four of type 1) -- every segment padded to
+  //   whole words with the sentinel slot `wsent` (a record far outside every cutoff); wseg[k] = words of A | words (word
+  //   pairs) of B << 8
+  int* wtab;
+  unsigned short* wcode;
+  int* wseg;
+  int wsent;      // sentinel slot = WinLayout::wmax (one record beyond the fullest window)
+  int MN_wchunks; // rows of wcode
 };
 
 // planes of Bufs::fo
@@ -811,6 +824,11 @@ struct TileStatsBody {
     const int bx = (int)(brick % b.gbx), by = (int)((brick / b.gbx) % b.gby), bz = (int)(brick / ((int64_t)b.gbx * b.gby));
     const int nbr = b.cell_count[brick * 64 + 64] - b.cell_count[brick * 64];
     int win = 0, mxc = 0, ghost = 0;
+    if (b.wtab) // window cells beyond an open face of the box hold nothing
+      for (int wc = 0; wc < 512; ++wc) {
+        b.wtab[((int64_t)brick * 512 + wc) * 2] = 0;
+        b.wtab[((int64_t)brick * 512 + wc) * 2 + 1] = 0;
+      }
     for (int wz = 0; wz < 8; ++wz)
       for (int wy = 0; wy < 8; ++wy)
         for (int wx = 0; wx < 8; ++wx) {
@@ -823,6 +841,11 @@ struct TileStatsBody {
             continue;
           const int c = cell_index(b, cx, cy, cz);
           const int cnt = b.cell_count[c + 1] - b.cell_count[c];
+          if (b.wtab) {
+            int* t = b.wtab + ((int64_t)brick * 512 + ((wz << 6) | (wy << 3) | wx)) * 2;
+            t[0] = b.cell_count[c];
+            t[1] = (win & 0xFFFF) | (cnt << 16);
+          }
           win += cnt;
           mxc = cnt > mxc ? cnt : mxc;
           ghost |= b.cell_ghost[c];
@@ -859,6 +882,76 @@ struct BrickOrderBody {
       b.brick_order[brick - before] = (int)brick;
     if (brick == 0)
       b.flags[kFlagNumBoundary] = nbound;
+  }
+};
+
+// Verlet entries as static LDS slots, packed four to a word (Bufs::wcode): one work-item per atom, at the rebuild, after
+// TileStatsBody has tabulated the windows.  parts = 2: list B split by the neighbour's type (two-type shapes).
+struct PackCodesBody {
+  Bufs b;
+  int parts;
+  NEPMI_HD void operator()(int64_t k) const
+  {
+    const int64_t N = b.N;
+    const int64_t brick = b.kcell[k] >> 6;
+    const int* tab = b.wtab + brick * 1024;
+    unsigned short* out = b.wcode + k * 4;
+    const int64_t row = N * 4; // halfwords per row of words
+    int word = 0, fill = 0;
+    unsigned short cur[4];
+    auto put = [&](unsigned short slot) {
+      cur[fill++] = slot;
+      if (fill == 4) {
+        if (word < b.MN_wchunks)
+          for (int u = 0; u < 4; ++u)
+            out[(int64_t)word * row + u] = cur[u];
+        ++word;
+        fill = 0;
+      }
+    };
+    auto flush = [&]() { // pad the segment to a whole word
+      while (fill != 0)
+        put((unsigned short)b.wsent);
+    };
+    auto slot_of = [&](unsigned code) { return (unsigned short)((tab[(code >> 7) * 2 + 1] & 0xFFFF) + (code & 127u)); };
+    const int na = b.nn_ang[k], nb = b.nn_skin[k];
+    for (int s = 0; s < na; ++s)
+      put(slot_of(b.code_ang[(int64_t)s * N + k]));
+    flush();
+    const int wa = word;
+    int wb = 0;
+    if (parts == 2) {
+      // two type-pure streams, word by word side by side: row wa + 2p = four neighbours of type 0, row wa + 2p + 1 = four of
+      // type 1; the shorter stream is padded with sentinel words
+      int s0 = 0, s1 = 0; // cursors over list B: next entry of type 0 / of type 1
+      auto next_of = [&](int& s, int want) -> int {
+        while (s < nb && (b.posq[b.nl_skin[(int64_t)s * N + k]].type != 0) != (want != 0))
+          ++s;
+        return s < nb ? s++ : -1;
+      };
+      for (;;) {
+        int e0[4], e1[4];
+        for (int u = 0; u < 4; ++u)
+          e0[u] = next_of(s0, 0);
+        for (int u = 0; u < 4; ++u)
+          e1[u] = next_of(s1, 1);
+        if (e0[0] < 0 && e1[0] < 0)
+          break;
+        for (int u = 0; u < 4; ++u)
+          put(e0[u] >= 0 ? slot_of(b.code_skin[(int64_t)e0[u] * N + k]) : (unsigned short)b.wsent);
+        for (int u = 0; u < 4; ++u)
+          put(e1[u] >= 0 ? slot_of(b.code_skin[(int64_t)e1[u] * N + k]) : (unsigned short)b.wsent);
+        ++wb;
+      }
+    } else {
+      for (int s = 0; s < nb; ++s)
+        put(slot_of(b.code_skin[(int64_t)s * N + k]));
+      flush();
+      wb = word - wa;
+    }
+    if (word > b.MN_wchunks || wa > 255 || wb > 255)
+      NEPMI_ATOMIC_OR(&b.flags[kFlagOverflow], 1);
+    b.wseg[k] = wa | (wb << 8);
   }
 };
 

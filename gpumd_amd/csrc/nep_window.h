@@ -37,12 +37,14 @@ constexpr int kWinMaxAtoms = 5000; // window capacity (LDS budget); larger windo
 #endif
 
 // LDS layout (bytes): int woff[513] | int wstart[512] | WinRec rec[wmax]
+// compact = 1 (static window layout, Bufs::wtab): WinRec rec[wmax + 1] only -- rec[wmax] is the sentinel record
 struct WinLayout {
   int wmax;
+  int compact;
   NEPMI_HD int off_woff() const { return 0; }
   NEPMI_HD int off_wstart() const { return 2064; } // 513 ints, padded to 16 B
-  NEPMI_HD int off_rec() const { return 2064 + 2048; }
-  NEPMI_HD int bytes() const { return off_rec() + 16 * wmax; }
+  NEPMI_HD int off_rec() const { return compact ? 0 : 2064 + 2048; }
+  NEPMI_HD int bytes() const { return off_rec() + 16 * (wmax + (compact ? 1 : 0)); }
 };
 
 // Staging, shared by the two passes (identical window contents and slot order in both): the records of the window
@@ -136,6 +138,49 @@ struct WinStage {
             rec[w0 + a + u] = r[u];
         }
       }
+    }
+  }
+
+  // Static layout: the window cells' first atoms and LDS offsets come from the table of the last rebuild (Bufs::wtab), so
+  // staging is one pass without a scan: thread t copies window cells t, t + nth, ...; rec[wmax] = the sentinel record the
+  // padded list words point at (0.875 R away along every axis: beyond every cutoff, within the 32-bit difference).
+  template <class LC>
+  NEPMI_HD void stage_direct(int64_t brick, LC lds, int tid, int nth) const
+  {
+    NEPMI_LDS(WinRec)* rec = (NEPMI_LDS(WinRec)*)(lds + lay.off_rec());
+    const int* tab = b.wtab + brick * 1024;
+    int bx, by, bz;
+    brick_coords(brick, bx, by, bz);
+    for (int wc = tid; wc < kWinCells; wc += nth) {
+      const int j0 = tab[2 * wc], pk = tab[2 * wc + 1];
+      const int w0 = pk & 0xFFFF;
+      int cnt = pk >> 16;
+      if (w0 + cnt > lay.wmax)
+        cnt = lay.wmax > w0 ? lay.wmax - w0 : 0;
+      if (cnt == 0)
+        continue;
+      int qx, qy, qz;
+      cell_offset(bx, by, bz, wc & 7, (wc >> 3) & 7, wc >> 6, qx, qy, qz);
+      for (int a = 0; a < cnt; a += 4) {
+        WinRec r[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          r[u] = b.prec[j0 + (a + u < cnt ? a + u : cnt - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          r[u].x += qx;
+          r[u].y += qy;
+          r[u].z += qz;
+          if (a + u < cnt)
+            rec[w0 + a + u] = r[u];
+        }
+      }
+    }
+    if (tid == 0) {
+      WinRec sr;
+      sr.x = sr.y = sr.z = 0x38000000;
+      sr.w = 0;
+      rec[lay.wmax] = sr;
     }
   }
 
@@ -497,6 +542,459 @@ struct RadialWinBody {
     b.nn_t0[k] = cnt;
     b.nn_angstep[k] = ca;
     if (S::TS > 0) {
+      // q[n] = sum_t2 sum_k c[t1][t2][n][k] S[t2][k]; type loop is wave-uniform => scalar loads
+      for (int tu = 0; tu < m.T; ++tu) {
+        if (!NEPMI_WAVE_ANY(t1 == tu))
+          continue;
+        float qq[S::NRM + 1];
+#pragma unroll
+        for (int n = 0; n <= S::NRM; ++n)
+          qq[n] = 0.0f;
+#pragma unroll
+        for (int t2 = 0; t2 < TSM; ++t2) {
+          cfloat_ptr c = as_const(m.c_rad) + (size_t)(tu * m.T + t2) * (S::NRM + 1) * (S::KRM + 1);
+#pragma unroll
+          for (int n = 0; n <= S::NRM; ++n)
+#pragma unroll
+            for (int kk = 0; kk <= S::KRM; ++kk)
+              qq[n] = fmaf(c[n * (S::KRM + 1) + kk], Ssum[t2][kk], qq[n]);
+        }
+        if (t1 == tu) {
+#pragma unroll
+          for (int n = 0; n <= S::NRM; ++n)
+            q[n] = qq[n];
+        }
+      }
+    }
+    const int64_t gk = b.tpos[k];
+    for (int n = 0; n <= NR; ++n)
+      b.q[(int64_t)n * N + gk] = q[n] * m.qscale[n];
+  }
+};
+
+// ---------------------------------------------------------------------------------------------------------------------
+// RadialWin2Body: the one-lane radial pass on the STATIC window layout (Bufs::wtab / wcode / wseg, written once per list
+// rebuild).  Same results as RadialWinBody -- the same lists bit for bit, the same sums up to their order -- with less
+// work per candidate:
+//   * a Verlet entry is the LDS slot itself (no cell-offset look-up: one ds_read_b128 per candidate, no scan and one
+//     barrier instead of three in the staging, 4 KB less LDS per workgroup);
+//   * four entries arrive as one 8-byte word (a quarter of the list-load instructions);
+//   * list B of a two-type model is stored as two type-pure streams, walked side by side: the two halves of a packed
+//     FP32 value carry one neighbour of type 0 and one of type 1, so the basis sums of both types are ONE packed
+//     accumulator row (7 v_pk_fma per two candidates instead of 14, no per-type weights), and the compact radial list
+//     grows at its front and at its back without a select;
+//   * segments are padded with a sentinel slot whose record lies beyond every cutoff: no "live" predicate in list B;
+//   * the exact retake of a decision inside the band of a cutoff is one test per word, not one per candidate.
+// ---------------------------------------------------------------------------------------------------------------------
+#ifndef NEPMI_RW2_WAVES
+#define NEPMI_RW2_WAVES 1
+#endif
+#ifndef NEPMI_RW2_HALF
+#define NEPMI_RW2_HALF 1 // 1: a word pair is processed as two halves of 2 + 2 candidates (fewer live registers), 0: 4 + 4 at once
+#endif
+struct alignas(8) U2w { // four 16-bit LDS slots
+  unsigned lo, hi;
+};
+
+template <class S>
+struct RadialWin2Body {
+  WinStage st;
+  ModelD m;
+  int first;         // workgroup w runs brick_order[first + w] (first < 0: brick w)
+  const int* frozen;
+  static constexpr int kMinWavesPerEu = NEPMI_RW2_WAVES;
+
+  NEPMI_HD int ctab_floats() const { return S::TS > 0 ? 0 : m.T * m.T * (m.NR + 1) * (m.KR + 1); }
+  NEPMI_HD int ctab_offset() const { return (st.lay.bytes() + 15) / 16 * 16; }
+  NEPMI_HD bool ctab_on() const { return NEPMI_RW_CTAB && S::TS == 0 && ctab_offset() + 4 * ctab_floats() <= 80 * 1024; }
+  NEPMI_HD int lds_bytes() const { return ctab_on() ? ctab_offset() + 4 * ctab_floats() : st.lay.bytes(); }
+  NEPMI_HD int64_t map_brick(int64_t w) const { return first < 0 ? w : (int64_t)st.b.brick_order[first + w]; }
+  NEPMI_HD bool skip() const { return frozen && *frozen != 0; }
+  template <class LC>
+  NEPMI_HD void stage(int64_t brick, LC lds, int tid, int nth) const
+  {
+    st.stage_direct(brick, lds, tid, nth);
+    if (ctab_on()) {
+      NEPMI_LDS(float)* ct = (NEPMI_LDS(float)*)(lds + ctab_offset());
+      const int nf = ctab_floats();
+      for (int i = tid; i < nf; i += nth)
+        ct[i] = m.c_rad[i];
+    }
+  }
+  NEPMI_HD void brick_range(int64_t brick, int64_t& a0, int64_t& a1) const { st.brick_range(brick, a0, a1); }
+
+  template <class LC>
+  NEPMI_HD void compute(int64_t brick, int64_t k, LC lds) const
+  {
+    const Bufs& b = st.b;
+    const int64_t N = b.N;
+    if (b.lvl[k] < 1) { // outer ghost: lends its position only
+      b.nn_rad[k] = 0;
+      b.nn_angstep[k] = 0;
+      return;
+    }
+    NEPMI_LDS(const WinRec)* wrec = (NEPMI_LDS(const WinRec)*)(lds + st.lay.off_rec());
+    const bool ctab = ctab_on();
+    NEPMI_LDS(const float)* ctab_lds = (NEPMI_LDS(const float)*)(lds + ctab_offset());
+    const int NR = S::fixed ? S::NR : m.NR;
+    const int KR = S::fixed ? S::KR : m.KR;
+    const PosQ p1 = b.posq[k];
+    const int t1 = p1.type;
+    int ox, oy, oz;
+    st.place_own(k, ox, oy, oz);
+    const float rc1 = m.rc_r[t1], rca1 = m.rc_a[t1];
+    const float unit = st.b.wg.unit, unit2 = st.b.wg.unit2, band = st.b.wg.band;
+    constexpr int TSM = S::TS > 0 ? S::TS : 1;
+    constexpr bool ZIP = S::TS == 2; // list B as two type-pure streams side by side
+    float q[S::NRM + 1];
+#pragma unroll
+    for (int n = 0; n <= S::NRM; ++n)
+      q[n] = 0.0f;
+
+    const int na = b.nn_ang[k];
+    const bool owned = b.lvl[k] >= 2;
+    const int seg = b.wseg[k];
+    const int wa = seg & 255, wb = (seg >> 8) & 255; // words of list A; words (ZIP: word pairs) of list B
+    unsigned am[4] = {0u, 0u, 0u, 0u}; // membership bits of list A (Bufs::amask)
+    int cnt = 0, cnt1 = 0, ca = 0;     // cnt: entries at the front of ccode, cnt1: at its back (type-1 neighbours)
+    F4* __restrict__ acomp = b.acomp + k;
+    unsigned short* __restrict__ amap = b.amap + k;
+    unsigned short* __restrict__ aidx = b.aidx + k;
+    unsigned short* __restrict__ ccode = b.ccode + k;
+    const U2w* __restrict__ words = reinterpret_cast<const U2w*>(b.wcode) + k;
+
+    struct Cand {
+      float fx, fy, fz, d2;
+      int rw, slot;
+      bool inside, ang;
+    };
+    // geometry and list decisions from the fixed-point record; *nearband: the decision has to be retaken exactly
+    auto judge = [&](int slot, bool list_a, bool& nearband) __attribute__((always_inline)) -> Cand {
+      Cand c;
+      const WinRec r = wrec[slot];
+      c.slot = slot;
+      c.rw = r.w;
+      c.fx = (float)(r.x - ox);
+      c.fy = (float)(r.y - oy);
+      c.fz = (float)(r.z - oz);
+      c.d2 = dot3f(c.fx, c.fx, c.fy, c.fy, c.fz, c.fz) * unit2;
+      const int t2 = (int)((unsigned)r.w >> kIdxBits);
+      const float rc = m.uniform_rc ? m.rc_r_max : (rc1 + m.rc_r[t2]) * 0.5f;
+      const float er = c.d2 - rc * rc;
+      c.inside = er < 0.0f;
+      float near = fabsf(er);
+      c.ang = false;
+      if (list_a) {
+        const float rca = m.uniform_rc ? m.rc_a_max : (rca1 + m.rc_a[t2]) * 0.5f;
+        const float ea = c.d2 - rca * rca;
+        c.ang = ea < 0.0f;
+        near = fminf(near, fabsf(ea));
+      }
+      nearband = nearband || near < band;
+      return c;
+    };
+    // the reference's arithmetic decides (pair_geometry: FP64 difference, float minimum image); rare
+    auto retake = [&](Cand& c, bool list_a) __attribute__((always_inline)) {
+      const int t2 = (int)((unsigned)c.rw >> kIdxBits);
+      const float rc = m.uniform_rc ? m.rc_r_max : (rc1 + m.rc_r[t2]) * 0.5f;
+      const float rca = m.uniform_rc ? m.rc_a_max : (rca1 + m.rc_a[t2]) * 0.5f;
+      const float er = c.d2 - rc * rc, ea = c.d2 - rca * rca;
+      const float near = list_a ? fminf(fabsf(er), fabsf(ea)) : fabsf(er);
+      if (near < band && c.slot != b.wsent) {
+        float ex, ey, ez;
+        const float d2e = pair_geometry(st.box, p1, b.posq[(unsigned)c.rw & (unsigned)kIdxMask], ex, ey, ez);
+        c.inside = d2e < rc * rc;
+        c.ang = list_a && d2e < rca * rca;
+      }
+    };
+    auto push_front = [&](const Cand& c) __attribute__((always_inline)) {
+      if (c.inside) {
+        if (owned && cnt + cnt1 < b.MN_rad)
+          ccode[(int64_t)cnt * N] = (unsigned short)c.slot;
+        ++cnt;
+      }
+    };
+    auto push_back = [&](const Cand& c) __attribute__((always_inline)) {
+      if (c.inside) {
+        if (owned && cnt + cnt1 < b.MN_rad)
+          ccode[(int64_t)(b.MN_rad - 1 - cnt1) * N] = (unsigned short)c.slot;
+        ++cnt1;
+      }
+    };
+    auto rc_of = [&](int rw, float& rc, float& ri) __attribute__((always_inline)) {
+      if (m.uniform_rc) {
+        rc = m.rc_r_max;
+        ri = m.rcinv_r;
+      } else {
+        rc = (rc1 + m.rc_r[(unsigned)rw >> kIdxBits]) * 0.5f;
+        ri = fast_rcp(rc);
+      }
+    };
+    // packed basis functions of two candidates, already weighted by "inside" (the envelope is evaluated at min(d, rc))
+    auto basis2 = [&](const Cand& c0, const Cand& c1, f2* fn) __attribute__((always_inline)) {
+      float rc0, rc1v, ri0, ri1;
+      rc_of(c0.rw, rc0, ri0);
+      rc_of(c1.rw, rc1v, ri1);
+      float d0, d1, i0, i1;
+      dist_and_inv(c0.d2, d0, i0);
+      dist_and_inv(c1.d2, d1, i1);
+      const f2 dc = mk2(d0 < rc0 ? d0 : rc0, d1 < rc1v ? d1 : rc1v);
+      const f2 rcinv = mk2(ri0, ri1);
+      f2 fc;
+      cutoff_fc_v(rcinv, dc, fc);
+      fc = fc * mk2(c0.inside ? 1.0f : 0.0f, c1.inside ? 1.0f : 0.0f);
+      basis_fn_v<S::KRM>(rcinv, dc, fc, fn);
+    };
+    // one-wide accumulation with the coefficients contracted per pair (many types / run-time shape)
+    auto accumulate1 = [&](const Cand& c) __attribute__((always_inline)) {
+      if (!c.inside)
+        return;
+      const int t2 = (int)((unsigned)c.rw >> kIdxBits);
+      const float rc = m.uniform_rc ? m.rc_r_max : (rc1 + m.rc_r[t2]) * 0.5f;
+      float d, dinv;
+      dist_and_inv(c.d2, d, dinv);
+      const float rcinv = fast_rcp(rc);
+      const float dc = d < rc ? d : rc;
+      float fc;
+      cutoff_fc(rcinv, dc, fc);
+      float fn[S::KRM + 1];
+      if (S::fixed)
+        basis_fn<S::KRM>(rcinv, dc, fc, fn);
+      else
+        basis_fn_rt(KR, rcinv, dc, fc, fn);
+      const int coff = (t1 * m.T + t2) * (NR + 1) * (KR + 1);
+      if (ctab) {
+        NEPMI_LDS(const float)* cc = ctab_lds + coff;
+        for (int n = 0; n <= NR; ++n) {
+          float gsum = 0.0f;
+          for (int kk = 0; kk <= KR; ++kk)
+            gsum += fn[kk] * cc[n * (KR + 1) + kk];
+          q[n] += gsum;
+        }
+      } else {
+        const float* cc = m.c_rad + coff;
+        for (int n = 0; n <= NR; ++n) {
+          float gsum = 0.0f;
+          for (int kk = 0; kk <= KR; ++kk)
+            gsum += fn[kk] * cc[n * (KR + 1) + kk];
+          q[n] += gsum;
+        }
+      }
+    };
+
+    // The packed sums: ZIP: SS[k] = {sum over type-0 neighbours, sum over type-1 neighbours}; one type: the two halves
+    // are added at the end.  List A of a two-type model (mixed types, word order = list order) uses its own two rows.
+    f2 SS[S::KRM + 1];
+#pragma unroll
+    for (int kk = 0; kk <= S::KRM; ++kk)
+      SS[kk] = bc2(0.0f);
+
+    auto load_word = [&](int w, int wend) __attribute__((always_inline)) -> U2w {
+      U2w v = {0u, 0u};
+      if (wend > 0)
+        v = words[(int64_t)(w < wend ? w : wend - 1) * N];
+      return v;
+    };
+
+    // ---- list A: angular membership + radial sums; words 0 .. wa-1 ----
+    {
+      f2 SA[TSM][S::KRM + 1];
+#pragma unroll
+      for (int t = 0; t < TSM; ++t)
+#pragma unroll
+        for (int kk = 0; kk <= S::KRM; ++kk)
+          SA[t][kk] = bc2(0.0f);
+      U2w w1 = load_word(0, wa), w2 = load_word(1, wa);
+      for (int w = 0; w < wa; ++w) {
+        const U2w cur = w1;
+        w1 = w2;
+        w2 = load_word(w + 2, wa);
+        bool nearband = false;
+        Cand c[4];
+        c[0] = judge((int)(cur.lo & 0xFFFFu), true, nearband);
+        c[1] = judge((int)(cur.lo >> 16), true, nearband);
+        c[2] = judge((int)(cur.hi & 0xFFFFu), true, nearband);
+        c[3] = judge((int)(cur.hi >> 16), true, nearband);
+        if (nearband) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            retake(c[u], true);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int idx = 4 * w + u;
+          const bool live = idx < na; // (a sentinel is never inside a cutoff; `live` guards the amap rows)
+          unsigned short cs = kNoSlot;
+          if (c[u].ang) {
+            if (ca < b.MN_acomp) {
+              F4 e;
+              e.x = c[u].fx * unit;
+              e.y = c[u].fy * unit;
+              e.z = c[u].fz * unit;
+              e.w = c[u].rw;
+              acomp[(int64_t)ca * N] = e;
+              aidx[(int64_t)ca * N] = b.rev_ang[(int64_t)idx * N + k]; // reverse slot of this pair in j's list A
+              cs = (unsigned short)ca;
+              const unsigned bit = 1u << (idx & 31);
+              const int aw = idx >> 5;
+              am[0] |= aw == 0 ? bit : 0u;
+              am[1] |= aw == 1 ? bit : 0u;
+              am[2] |= aw == 2 ? bit : 0u;
+              am[3] |= aw == 3 ? bit : 0u;
+            }
+            ++ca;
+          }
+          if (!b.use_amask && live)
+            amap[(int64_t)idx * N] = cs;
+          if (S::TS == 2 && ((unsigned)c[u].rw >> kIdxBits) == 1u)
+            push_back(c[u]);
+          else
+            push_front(c[u]);
+        }
+        if (S::TS > 0) {
+#pragma unroll
+          for (int u = 0; u < 4; u += 2) {
+            f2 fn[S::KRM + 1];
+            basis2(c[u], c[u + 1], fn);
+            if (TSM == 1) {
+#pragma unroll
+              for (int kk = 0; kk <= S::KRM; ++kk)
+                SA[0][kk] = SA[0][kk] + fn[kk];
+            } else {
+#pragma unroll
+              for (int t = 0; t < TSM; ++t) {
+                const f2 wt = mk2((int)((unsigned)c[u].rw >> kIdxBits) == t ? 1.0f : 0.0f,
+                                  (int)((unsigned)c[u + 1].rw >> kIdxBits) == t ? 1.0f : 0.0f);
+#pragma unroll
+                for (int kk = 0; kk <= S::KRM; ++kk)
+                  SA[t][kk] = vfma(wt, fn[kk], SA[t][kk]);
+              }
+            }
+          }
+        } else {
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            accumulate1(c[u]);
+        }
+      }
+      if (S::TS > 0) {
+#pragma unroll
+        for (int kk = 0; kk <= S::KRM; ++kk)
+          SS[kk] = ZIP ? mk2(SA[0][kk].x + SA[0][kk].y, SA[TSM - 1][kk].x + SA[TSM - 1][kk].y) : SA[0][kk];
+      }
+    }
+    if (b.use_amask) {
+      U4 mv;
+      mv.x = am[0];
+      mv.y = am[1];
+      mv.z = am[2];
+      mv.w = am[3];
+      reinterpret_cast<U4*>(b.amask)[k] = mv;
+    }
+
+    // ---- list B: radial only ----
+    if (ZIP) {
+      // word pair p: row wa + 2p holds four neighbours of type 0, row wa + 2p + 1 four of type 1
+      const int rows = 2 * wb;
+      U2w a1 = load_word(wa, wa + rows), b1 = load_word(wa + 1, wa + rows);
+      U2w a2 = load_word(wa + 2, wa + rows), b2 = load_word(wa + 3, wa + rows);
+      for (int p = 0; p < wb; ++p) {
+        const U2w ca0 = a1, cb0 = b1;
+        a1 = a2;
+        b1 = b2;
+        a2 = load_word(wa + 2 * p + 4, wa + rows);
+        b2 = load_word(wa + 2 * p + 5, wa + rows);
+        constexpr int HN = NEPMI_RW2_HALF ? 2 : 4;
+#pragma unroll
+        for (int hh = 0; hh < 4 / HN; ++hh) {
+          const unsigned xa = HN == 4 ? ca0.lo : (hh == 0 ? ca0.lo : ca0.hi), xb = HN == 4 ? ca0.hi : 0u;
+          const unsigned ya = HN == 4 ? cb0.lo : (hh == 0 ? cb0.lo : cb0.hi), yb = HN == 4 ? cb0.hi : 0u;
+          bool nearband = false;
+          Cand x[HN], y[HN];
+          x[0] = judge((int)(xa & 0xFFFFu), false, nearband);
+          x[1] = judge((int)(xa >> 16), false, nearband);
+          y[0] = judge((int)(ya & 0xFFFFu), false, nearband);
+          y[1] = judge((int)(ya >> 16), false, nearband);
+          if (HN == 4) {
+            x[HN - 2] = judge((int)(xb & 0xFFFFu), false, nearband);
+            x[HN - 1] = judge((int)(xb >> 16), false, nearband);
+            y[HN - 2] = judge((int)(yb & 0xFFFFu), false, nearband);
+            y[HN - 1] = judge((int)(yb >> 16), false, nearband);
+          }
+          if (nearband) {
+#pragma unroll
+            for (int u = 0; u < HN; ++u) {
+              retake(x[u], false);
+              retake(y[u], false);
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < HN; ++u) {
+            push_front(x[u]);
+            push_back(y[u]);
+            f2 fn[S::KRM + 1];
+            basis2(x[u], y[u], fn);
+#pragma unroll
+            for (int kk = 0; kk <= S::KRM; ++kk)
+              SS[kk] = SS[kk] + fn[kk];
+          }
+        }
+      }
+    } else {
+      U2w w1 = load_word(wa, wa + wb), w2 = load_word(wa + 1, wa + wb);
+      for (int w = 0; w < wb; ++w) {
+        const U2w cur = w1;
+        w1 = w2;
+        w2 = load_word(wa + w + 2, wa + wb);
+        bool nearband = false;
+        Cand c[4];
+        c[0] = judge((int)(cur.lo & 0xFFFFu), false, nearband);
+        c[1] = judge((int)(cur.lo >> 16), false, nearband);
+        c[2] = judge((int)(cur.hi & 0xFFFFu), false, nearband);
+        c[3] = judge((int)(cur.hi >> 16), false, nearband);
+        if (nearband) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            retake(c[u], false);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          push_front(c[u]);
+        if (S::TS > 0) {
+#pragma unroll
+          for (int u = 0; u < 4; u += 2) {
+            f2 fn[S::KRM + 1];
+            basis2(c[u], c[u + 1], fn);
+#pragma unroll
+            for (int kk = 0; kk <= S::KRM; ++kk)
+              SS[kk] = SS[kk] + fn[kk];
+          }
+        } else {
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            accumulate1(c[u]);
+        }
+      }
+    }
+
+    if (ca > b.MN_acomp || cnt + cnt1 > b.MN_rad) {
+      NEPMI_ATOMIC_OR(&b.flags[kFlagOverflow], 4);
+      ca = ca > b.MN_acomp ? b.MN_acomp : ca;
+    }
+    b.nn_rad[k] = cnt + cnt1;
+    b.nn_t0[k] = cnt;
+    b.nn_angstep[k] = ca;
+    if (S::TS > 0) {
+      float Ssum[TSM][S::KRM + 1];
+#pragma unroll
+      for (int kk = 0; kk <= S::KRM; ++kk) {
+        if (ZIP) {
+          Ssum[0][kk] = SS[kk].x;
+          Ssum[TSM - 1][kk] = SS[kk].y;
+        } else {
+          Ssum[0][kk] = SS[kk].x + SS[kk].y;
+        }
+      }
       // q[n] = sum_t2 sum_k c[t1][t2][n][k] S[t2][k]; type loop is wave-uniform => scalar loads
       for (int tu = 0; tu < m.T; ++tu) {
         if (!NEPMI_WAVE_ANY(t1 == tu))
@@ -985,6 +1483,8 @@ struct ForceWinBody {
   NEPMI_HD void stage_cells(int64_t brick, LC lds, int tid, int nth) const { st.stage_cells(brick, lds, tid, nth); }
   template <class LC>
   NEPMI_HD void stage_copy(int64_t brick, LC lds, int tid, int nth) const { st.stage_copy(brick, lds, tid, nth); }
+  template <class LC>
+  NEPMI_HD void stage(int64_t brick, LC lds, int tid, int nth) const { st.stage_direct(brick, lds, tid, nth); } // static layout
   NEPMI_HD void brick_range(int64_t brick, int64_t& a0, int64_t& a1) const { st.brick_range(brick, a0, a1); }
 
   template <class LC>

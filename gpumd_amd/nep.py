@@ -304,6 +304,10 @@ class NEP:
         """lanes per atom of the LDS-window kernels: 0 = by the number of bricks, or 1 / 2 / 4"""
         self._ck(self.lib.nepmi_engine_set_win_lanes(self.handle, int(lanes)))
 
+    def set_win_static(self, on=True):
+        """static window layout of the one-lane window kernels (default on); False = the scanned layout"""
+        self._ck(self.lib.nepmi_engine_set_win_static(self.handle, int(bool(on))))
+
     def set_mfma(self, on=True):
         """False / 0: per-atom ANN kernel; True / 1 (default): descriptor + ANN fused where the shape allows it, else the
         matrix-core ANN kernel; 2: the matrix-core kernel wherever it applies (no fusion)"""

@@ -354,7 +354,8 @@ typedef struct {
                             6 velocity-Verlet, 7 list rebuild (whole) */
   double ms_kernel_sum[8]; /* same slots: sum over all launches since timing was (re)enabled */
   int64_t launches[8];     /* ... and their number (slot 7: rebuilds)                       */
-  int radial_tiles;        /* LDS-window kernels in the last force call: 0 no (gather kernels), 2 yes */
+  int radial_tiles;        /* LDS-window kernels in the last force call: 0 no (gather kernels), 2 yes, 3 yes on the static
+                            * window layout (one lane per atom: Verlet entries kept as LDS slots, see below) */
   int64_t discarded_steps; /* steps of the fused run loops that were enqueued speculatively and then re-run after a list
                               rebuild: their launches returned at once; launches[] counts them, so a mean kernel time is
                               ms_kernel_sum[k] / (launches[k] - discarded_steps) for the per-step kernels (slots 1..5) */
@@ -378,6 +379,11 @@ int nepmi_engine_set_tiles(nepmi_engine* e, int on);
 /* Lanes per atom of the LDS-window kernels: 0 (default) = by the number of bricks (4 up to 256 bricks, 2 up to 400,
  * else 1: small systems are bound by the latency of one workgroup); 1, 2, 4 pin it. */
 int nepmi_engine_set_win_lanes(nepmi_engine* e, int lanes);
+/* Static window layout of the one-lane window kernels (default on): between two list rebuilds the LDS slot of every window
+ * atom is fixed, so the rebuild tabulates the windows and stores the Verlet entries as LDS slots, four to an 8-byte word
+ * (two-type models: list B as two type-pure streams); on = 0 keeps the per-launch scan of the window cells and the
+ * (window cell, rank) codes.  Same lists bit for bit, sums differ by their order only.  Forces a list rebuild. */
+int nepmi_engine_set_win_static(nepmi_engine* e, int on);
 /* How the per-atom ANN runs.  on = 1 (default): inside the angular-descriptor kernel where the shape allows it (one
  * lane per atom, at most 4 types: the descriptor never leaves the registers), else the matrix-core
  * (v_mfma_f32_32x32x2_f32) ANN kernel; on = 2: the matrix-core kernel wherever it applies; on = 0: the per-atom ANN

@@ -101,6 +101,24 @@ struct HostLoopBackend {
     }
   }
 
+  // the same on the static window layout (Bufs::wtab): one staging pass, then the atoms of the brick
+  template <class Body>
+  void launch_win2(int, int64_t nbricks, const Body& body)
+  {
+    if (body.skip())
+      return;
+    std::vector<double> raw((size_t)body.lds_bytes() / 8 + 8);
+    char* lds = reinterpret_cast<char*>(raw.data());
+    for (int64_t wg = 0; wg < nbricks; ++wg) {
+      const int64_t brick = body.map_brick(wg);
+      body.stage(brick, lds, 0, 1);
+      int64_t a0, a1;
+      body.brick_range(brick, a0, a1);
+      for (int64_t k = a0; k < a1; ++k)
+        body.compute(brick, k, lds);
+    }
+  }
+
   // bodies with a workgroup-staged table: the "LDS" is an ordinary host buffer here
   template <int BLOCK, class Body>
   void launch_lds(int, int64_t n, const Body& body)

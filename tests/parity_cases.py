@@ -36,7 +36,7 @@ MODELS = {
 }
 
 
-def check_force_parity(drv, name, generic=False, check_lists=True, tiles=True, mfma=True, lanes=None):
+def check_force_parity(drv, name, generic=False, check_lists=True, tiles=True, mfma=True, lanes=None, win_static=None):
     nep_rel, build, _ = MODELS[name]
     nep = H.golden(*nep_rel.split("/"))
     h, typ, x = build()
@@ -55,9 +55,13 @@ def check_force_parity(drv, name, generic=False, check_lists=True, tiles=True, m
         eng.set_mfma(False)
     if lanes is not None:
         eng.set_win_lanes(lanes)
+    if win_static is not None:
+        eng.set_win_static(win_static)
     xw, pe, f, v = H.engine_force(drv, eng, h, typ, x)
     if not tiles:
         assert eng.stats().radial_tiles == 0
+    if win_static is not None and tiles is True and lanes == 1:  # (0: the box is too small for windows at all)
+        assert eng.stats().radial_tiles in (0, 3 if win_static else 2)
 
     assert np.array_equal(xw, H.oracle_apply_pbc(h, x)), "wrapped positions must be bit-exact"
     np.testing.assert_allclose(pe.sum(), pe64.sum(), rtol=1e-5, atol=1e-8)

@@ -28,6 +28,14 @@ def test_force_parity_without_lds_window(drv, name):
     P.check_force_parity(drv, name, tiles=False)
 
 
+@pytest.mark.parametrize("static", [True, False])
+@pytest.mark.parametrize("name", ["PbTe-A", "PbTe-B", "C-2022", "UNEP-v1", "BaZrO3", "PbTe-3x3x3"])
+def test_force_parity_window_layouts(drv, name, static):
+    """One lane per atom on the static window layout (Verlet entries kept as LDS slots, four to a word; two-type models
+    walk list B as two type-pure streams) and on the scanned layout: the same lists bit for bit."""
+    P.check_force_parity(drv, name, lanes=1, win_static=static)
+
+
 @pytest.mark.parametrize("name", ["PbTe-A", "C-2022"])
 def test_force_parity_with_pair_records(drv, name):
     """Tile mode 1: LDS-window radial pass that writes pair records + the record-reading force assembly."""
