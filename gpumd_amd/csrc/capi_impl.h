@@ -447,6 +447,17 @@ int nepmi_engine_stats(nepmi_engine* e, int with_lists, nepmi_stats* out)
   });
 }
 
+int nepmi_engine_describe(nepmi_engine* e, char* buf, int len)
+{
+  if (!e || !buf || len < 1)
+    return fail(NEPMI_ERR_ARG, "bad argument");
+  const std::string s = e->e->describe();
+  const int n = (int)s.size() < len - 1 ? (int)s.size() : len - 1;
+  std::memcpy(buf, s.data(), (size_t)n);
+  buf[n] = 0;
+  return n;
+}
+
 int nepmi_engine_set_timing(nepmi_engine* e, int on)
 {
   if (!e)

@@ -377,6 +377,33 @@ nepmi_win2_kernel(const Body body, const int64_t nbricks)
     body.compute(brick, k, lds);
 }
 
+// Static layout with Body::kLanes lanes per atom and a second staging phase (ForceWinBody<..., ROWS>: the table rows of the
+// window atoms behind the records): 256 kLanes threads, one workgroup per CU when the rows fill the LDS.
+template <class Body>
+__global__ void __launch_bounds__(kWinThreads * Body::kLanes) nepmi_win2_kernel_split(const Body body, const int64_t nbricks)
+{
+  constexpr int NT = kWinThreads * Body::kLanes;
+  extern __shared__ __attribute__((aligned(16))) char nepmi_win_lds[];
+  NEPMI_LDS(char)* lds = (NEPMI_LDS(char)*)nepmi_win_lds;
+  if (body.skip())
+    return;
+  const unsigned per_xcd = gridDim.x >> 3;
+  const int64_t wg = (int64_t)(blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+  if (wg >= nbricks)
+    return;
+  const int64_t brick = body.map_brick(wg);
+  const int tid = (int)threadIdx.x;
+  body.stage(brick, lds, tid, NT);
+  __syncthreads();
+  body.stage_rows(brick, lds, tid, NT);
+  __syncthreads();
+  int64_t a0, a1;
+  body.brick_range(brick, a0, a1);
+  const int sub = tid % Body::kLanes;
+  for (int64_t k = a0 + tid / Body::kLanes; k < a1; k += kWinThreads)
+    body.compute(brick, k, lds, sub);
+}
+
 // The same with Body::kLanes = 2 or 4 adjacent lanes per atom (256 kLanes threads): systems with too few bricks to
 // fill the chip, where a window kernel's run time is the latency of one workgroup (RadialWinSplitBody).
 template <class Body>
@@ -968,6 +995,28 @@ struct HipBackend {
     if (t)
       timer_stop(timing->slot[slot]);
   }
+
+  template <class Body>
+  void launch_win2_split(int slot, int64_t nbricks, const Body& body)
+  {
+    if (nbricks <= 0)
+      return;
+    const int64_t grid = (nbricks + 7) / 8 * 8;
+    const size_t lds_bytes = ((size_t)body.lds_bytes() + 15) / 16 * 16;
+    if (lds_bytes > 64 * 1024)
+      NEPMI_HIP_CHECK(hipFuncSetAttribute(
+        reinterpret_cast<const void*>(&nepmi_win2_kernel_split<Body>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        (int)lds_bytes));
+    const bool t = timed(slot);
+    if (t)
+      timer_start(timing->slot[slot]);
+    hipLaunchKernelGGL((nepmi_win2_kernel_split<Body>), dim3((unsigned)grid), dim3(kWinThreads * Body::kLanes), lds_bytes,
+                       stream, body, nbricks);
+    NEPMI_HIP_CHECK(hipGetLastError());
+    if (t)
+      timer_stop(timing->slot[slot]);
+  }
+  static constexpr size_t kMaxLdsBytes = 160 * 1024; // per workgroup (one per CU)
 
   static constexpr bool kSplitLanes = true; // window kernels with several lanes per atom exist on this backend
   template <class Body>

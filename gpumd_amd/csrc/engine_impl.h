@@ -925,6 +925,8 @@ private:
       b_.MN_wchunks = (b_.MN_ang + 3) / 4 + 2 * ((b_.MN_skin + 3) / 4) + 4;
       b_.wcode = dalloc<unsigned short>((size_t)b_.MN_wchunks * 4 * N);
       b_.wseg = dalloc<int>(N);
+      b_.MN_cw = (b_.MN_rad + 3) / 4 + 1;
+      b_.cword = dalloc<unsigned short>((size_t)2 * b_.MN_cw * 4 * N);
     } else { // Tersoff-1989: Tersoff1989::Tersoff1989 allocations (tersoff1989.cu:141-149)
       tb_.rec = dalloc<D4>((size_t)b_.MN_ang * N);
       tb_.bb = dalloc<double>((size_t)b_.MN_ang * N);
@@ -1262,8 +1264,14 @@ private:
   template <class S>
   void launch_angular_force()
   {
+    // The coefficient table c_ang is staged in LDS once per workgroup: T^2 (n_a+1)(k_a+1) floats -- 46 KB for the 16-type
+    // UNEP-v1.  With 64-thread workgroups that is three WAVEFRONTS per CU (r3a: 2.06 ms at 1 M atoms); large tables take
+    // 512-thread workgroups so that the table is shared by eight wavefronts.
+    const bool big_table = (size_t)cang_floats(md_) * sizeof(float) > 16 * 1024;
     if (S::fixed && S::NA + 1 >= 7)
       be_.template launch_lds_pairs<64>(kSlotAngForce, N_, AngularForceBody<S>{md_, b_, recompute_s()});
+    else if (big_table)
+      be_.template launch_lds<512>(kSlotAngForce, N_, AngularForceBody<S>{md_, b_, recompute_s()});
     else
       be_.template launch_lds<64>(kSlotAngForce, N_, AngularForceBody<S>{md_, b_, recompute_s()});
     if (!S::fixed && model_.L_max > 4)
@@ -1436,6 +1444,7 @@ private:
     }
     const int lanes = win_lanes();
     const bool win2 = win2_ok_ && lanes == 1;
+    last_rows_form_ = false;
     WinLayout lay2 = win_;
     lay2.compact = 1;
     const WinStage ws2{box_, b_, lay2};
@@ -1470,8 +1479,10 @@ private:
     launch_angular_force<S>();
     if (!tile_ok_)
       be_.template launch<64>(kSlotForce, N_, ForceAssembleBody<S>{md_, b_});
+    else if (win2 && rows_form<S>(ws2, frozen))
+      ; // (launched by rows_form)
     else if (win2)
-      be_.launch_win2(kSlotForce, num_bricks_, ForceWinBody<S>{ws2, md_, frozen});
+      be_.launch_win2(kSlotForce, num_bricks_, ForceWinBody<S, 1, NEPMI_CW != 0>{ws2, md_, frozen});
     else if (lanes == 4)
       be_.launch_win_split(kSlotForce, num_bricks_, ForceWinBody<S, 4>{ws, md_, frozen});
     else if (lanes == 2)
@@ -1481,7 +1492,56 @@ private:
     be_.end_region(kRegionForce);
   }
 
+  // Force assembly with the neighbours' table rows in LDS (ForceWinBody<..., ROWS>): shapes with register-resident sums whose
+  // records + rows fit the LDS of a CU; a counted rule.  The emulator's host loop runs the same body with one lane per atom.
+#ifndef NEPMI_FW_ROWS
+#define NEPMI_FW_ROWS 0 // A/B switch (profiles/ab_variants.sh); r3d: PbTe 1 M 0.517 (gather) vs 0.52 (rows, 4 lanes) vs 0.515 (2 lanes), carbon 0.79 vs 1.10 vs 0.95 ms: off
+#endif
+  template <class S>
+  bool rows_form(const WinStage& ws2, const int* frozen)
+  {
+    if (!(S::TS > 0) || !NEPMI_FW_ROWS || NEPMI_CW || !use_rows_)
+      return false;
+#ifndef NEPMI_FW_ROWS_LANES
+#define NEPMI_FW_ROWS_LANES 4
+#endif
+    constexpr int LR = B::kSplitLanes ? NEPMI_FW_ROWS_LANES : 1;
+    const ForceWinBody<S, LR, false, true> body{ws2, md_, frozen};
+    if ((size_t)body.lds_bytes() > B::kMaxLdsBytes)
+      return false;
+    be_.launch_win2_split(kSlotForce, num_bricks_, body);
+    last_rows_form_ = true;
+    return true;
+  }
+
 public:
+  void set_rows(bool on) { use_rows_ = on; }
+  // the kernel forms of the last force evaluation (the counted rules above, in words)
+  std::string describe() const
+  {
+    static const char* shapes[] = {"generic", "PbTe-A(6,6,6,6,5;2)", "PbTe-B(4,8,4,8,5;2)", "C-2022(10,10,8,8,6;1)", "UNEP(4,8,4,8,6;T)",
+                                   "BaZrO3(8,8,6,8,5;T)"};
+    std::string s;
+    if (model_.kind == 1)
+      return "potential=tersoff1989 kernels=bond_order+force(fp64)";
+    s += std::string("shape=") + shapes[shape_ >= 0 && shape_ <= 5 ? shape_ : 0];
+    if (last_small_)
+      return s + " path=small_box(all image pairs)";
+    const int lanes = win_lanes();
+    const bool win2 = win2_ok_ && lanes == 1;
+    s += tile_ok_ ? (win2 ? " window=lds_static" : " window=lds_scanned") : " window=none(gather kernels)";
+    s += " lanes_per_atom=" + std::to_string(tile_ok_ ? lanes : 1);
+    if (fuse_ann_active())
+      s += " ann=fused_with_angular_descriptor(packed_fp32,no_mfma)";
+    else if (ann_mode_ != 0 && b_.ann_img)
+      s += " ann=mfma_f32_32x32x2";
+    else
+      s += " ann=per_atom";
+    s += (shape_ != 0 && model_.n_max_angular + 1 >= 7) ? " angular_force=lane_pairs" : " angular_force=one_lane";
+    s += recompute_s() ? " angular_sums=recomputed" : " angular_sums=stored";
+    s += last_rows_form_ ? " force_assembly=table_rows_in_lds" : " force_assembly=table_rows_gathered";
+    return s;
+  }
   // frozen != nullptr: a speculatively enqueued step of a fused run loop -- every kernel of the force path looks at
   // that device word first and returns when a list rebuild is pending
   void force_kernels(int phase, const int* frozen = nullptr)
@@ -1519,7 +1579,9 @@ private:
   Bufs b_;
   BoxD box_;
   WinLayout win_{0, 0};
-  bool win2_ok_ = false, use_win2_ = NEPMI_WIN2_DEFAULT != 0; // static window layout (Bufs::wtab / wcode) in use / allowed
+  bool win2_ok_ = false, use_win2_ = NEPMI_WIN2_DEFAULT != 0;
+  bool use_rows_ = true; // force assembly with the table rows in LDS where they fit
+  bool last_rows_form_ = false; // static window layout (Bufs::wtab / wcode) in use / allowed
   double* ui_alloc_ = nullptr;
   double* factor_dev_ = nullptr;
   bool tile_ok_ = false, use_tiles_ = true;

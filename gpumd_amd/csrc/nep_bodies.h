@@ -169,6 +169,10 @@ struct Bufs {
   int* wseg;
   int wsent;      // sentinel slot = WinLayout::wmax (one record beyond the fullest window)
   int MN_wchunks; // rows of wcode
+  // per step, static layout: the compact radial list as words of four LDS slots -- rows [0, MN_cw): neighbours of type 0 (or
+  // all), rows [MN_cw, 2 MN_cw): neighbours of type 1 (two-type shapes); nn_t0 / nn_rad count entries as before
+  unsigned short* cword;
+  int MN_cw;
 };
 
 // planes of Bufs::fo
@@ -824,11 +828,6 @@ struct TileStatsBody {
     const int bx = (int)(brick % b.gbx), by = (int)((brick / b.gbx) % b.gby), bz = (int)(brick / ((int64_t)b.gbx * b.gby));
     const int nbr = b.cell_count[brick * 64 + 64] - b.cell_count[brick * 64];
     int win = 0, mxc = 0, ghost = 0;
-    if (b.wtab) // window cells beyond an open face of the box hold nothing
-      for (int wc = 0; wc < 512; ++wc) {
-        b.wtab[((int64_t)brick * 512 + wc) * 2] = 0;
-        b.wtab[((int64_t)brick * 512 + wc) * 2 + 1] = 0;
-      }
     for (int wz = 0; wz < 8; ++wz)
       for (int wy = 0; wy < 8; ++wy)
         for (int wx = 0; wx < 8; ++wx) {
@@ -837,8 +836,14 @@ struct TileStatsBody {
           if (box.pbc[0]) cx = ((cx % b.nbx) + b.nbx) % b.nbx; else ok = ok && cx >= 0 && cx < b.nbx;
           if (box.pbc[1]) cy = ((cy % b.nby) + b.nby) % b.nby; else ok = ok && cy >= 0 && cy < b.nby;
           if (box.pbc[2]) cz = ((cz % b.nbz) + b.nbz) % b.nbz; else ok = ok && cz >= 0 && cz < b.nbz;
-          if (!ok)
+          if (!ok) { // a window cell beyond an open face of the box holds nothing (the running offset stays valid)
+            if (b.wtab) {
+              int* t = b.wtab + ((int64_t)brick * 512 + ((wz << 6) | (wy << 3) | wx)) * 2;
+              t[0] = 0;
+              t[1] = win & 0xFFFF;
+            }
             continue;
+          }
           const int c = cell_index(b, cx, cy, cz);
           const int cnt = b.cell_count[c + 1] - b.cell_count[c];
           if (b.wtab) {

@@ -589,6 +589,10 @@ struct RadialWinBody {
 #ifndef NEPMI_RW2_WAVES
 #define NEPMI_RW2_WAVES 1
 #endif
+#ifndef NEPMI_CW
+#define NEPMI_CW 0 // 1: the compact radial list of the static layout is written / read as words of four slots (Bufs::cword);
+                   // measured (r3c, PbTe 1 M atoms): radial pass 0.364 -> 0.359 ms, force assembly 0.523 -> 0.539 ms: off
+#endif
 #ifndef NEPMI_RW2_HALF
 #define NEPMI_RW2_HALF 1 // 1: a word pair is processed as two halves of 2 + 2 candidates (fewer live registers), 0: 4 + 4 at once
 #endif
@@ -707,18 +711,71 @@ struct RadialWin2Body {
         c.ang = list_a && d2e < rca * rca;
       }
     };
+    // The compact radial list.  NEPMI_CW: words of four slots, staged in two registers per stream and stored as 8 bytes when
+    // full -- a quarter of the store instructions (the window kernels are bound by the number of vector-memory
+    // instructions); the front stream (neighbours of type 0, or all) fills rows 0, 1, ... of
+    // Bufs::cword, the back stream (type 1) rows MN_cw, MN_cw + 1, ...; the last word of a stream is padded with the
+    // sentinel slot, which the force assembly evaluates to zero.
+    U2w* __restrict__ cword = reinterpret_cast<U2w*>(b.cword) + k;
+    unsigned long long accf = 0ull, accb = 0ull;
     auto push_front = [&](const Cand& c) __attribute__((always_inline)) {
       if (c.inside) {
-        if (owned && cnt + cnt1 < b.MN_rad)
+        if (NEPMI_CW) {
+          const int f = cnt & 3;
+          accf |= (unsigned long long)(unsigned)c.slot << (16 * f);
+          if (f == 3) {
+            if (owned && (cnt >> 2) < b.MN_cw) {
+              U2w v;
+              v.lo = (unsigned)accf;
+              v.hi = (unsigned)(accf >> 32);
+              cword[(int64_t)(cnt >> 2) * N] = v;
+            }
+            accf = 0ull;
+          }
+        } else if (owned && cnt + cnt1 < b.MN_rad) {
           ccode[(int64_t)cnt * N] = (unsigned short)c.slot;
+        }
         ++cnt;
       }
     };
     auto push_back = [&](const Cand& c) __attribute__((always_inline)) {
       if (c.inside) {
-        if (owned && cnt + cnt1 < b.MN_rad)
+        if (NEPMI_CW) {
+          const int f = cnt1 & 3;
+          accb |= (unsigned long long)(unsigned)c.slot << (16 * f);
+          if (f == 3) {
+            if (owned && (cnt1 >> 2) < b.MN_cw) {
+              U2w v;
+              v.lo = (unsigned)accb;
+              v.hi = (unsigned)(accb >> 32);
+              cword[(int64_t)(b.MN_cw + (cnt1 >> 2)) * N] = v;
+            }
+            accb = 0ull;
+          }
+        } else if (owned && cnt + cnt1 < b.MN_rad) {
           ccode[(int64_t)(b.MN_rad - 1 - cnt1) * N] = (unsigned short)c.slot;
+        }
         ++cnt1;
+      }
+    };
+    // the last, partial word of a stream: the free places take the sentinel slot
+    auto flush_words = [&]() __attribute__((always_inline)) {
+      if (!NEPMI_CW || !owned)
+        return;
+      const unsigned long long sent = 0x0001000100010001ull * (unsigned long long)(unsigned)b.wsent;
+      if ((cnt & 3) != 0 && (cnt >> 2) < b.MN_cw) {
+        const unsigned long long a = accf | (sent << (16 * (cnt & 3)));
+        U2w v;
+        v.lo = (unsigned)a;
+        v.hi = (unsigned)(a >> 32);
+        cword[(int64_t)(cnt >> 2) * N] = v;
+      }
+      if ((cnt1 & 3) != 0 && (cnt1 >> 2) < b.MN_cw) {
+        const unsigned long long a = accb | (sent << (16 * (cnt1 & 3)));
+        U2w v;
+        v.lo = (unsigned)a;
+        v.hi = (unsigned)(a >> 32);
+        cword[(int64_t)(b.MN_cw + (cnt1 >> 2)) * N] = v;
       }
     };
     auto rc_of = [&](int rw, float& rc, float& ri) __attribute__((always_inline)) {
@@ -977,6 +1034,7 @@ struct RadialWin2Body {
       }
     }
 
+    flush_words();
     if (ca > b.MN_acomp || cnt + cnt1 > b.MN_rad) {
       NEPMI_ATOMIC_OR(&b.flags[kFlagOverflow], 4);
       ca = ca > b.MN_acomp ? b.MN_acomp : ca;
@@ -1460,21 +1518,124 @@ NEPMI_HD void win_force_segment(
   }
 }
 
+// The same over a stream of compact-list WORDS (Bufs::cword: four LDS slots per 8 bytes, the last word padded with the
+// sentinel slot, whose record lies beyond the cutoff: the clamped envelope and its derivative vanish there, so a padded
+// place adds exactly zero and the loop needs no "live" weights).  One lane per atom; `nwords` words at rows row0, row0 + 1, ...
+template <class S, class LC, class Rows>
+NEPMI_HD void win_force_words(
+  const ModelD& m, const U2w* __restrict__ cword, int64_t N, LC wrec, const Rows& rows, const float* Aown, int nwords, int row0,
+  int ox, int oy, int oz, float rc1, float unit2, f2* Fr2, f2* W2)
+{
+  auto load_word = [&](int w) -> U2w {
+    U2w v = {0u, 0u};
+    if (nwords > 0)
+      v = cword[(int64_t)(row0 + (w < nwords ? w : nwords - 1)) * N];
+    return v;
+  };
+  U2w w1 = load_word(0);
+  for (int w = 0; w < nwords; ++w) {
+    const U2w cur = w1;
+    w1 = load_word(w + 1); // in flight while this word (two packed evaluations of two pairs) is processed
+#pragma unroll 1
+    for (int hh = 0; hh < 2; ++hh) {
+      const unsigned pr = hh == 0 ? cur.lo : cur.hi;
+      const unsigned cur0 = pr & 0xFFFFu, cur1 = pr >> 16;
+      const WinRec r0 = wrec[cur0], r1 = wrec[cur1];
+      f2 Aj[S::KRM + 1];
+      rows(cur0, cur1, r0, r1, Aj);
+      const f2 fx = mk2((float)(r0.x - ox), (float)(r1.x - ox));
+      const f2 fy = mk2((float)(r0.y - oy), (float)(r1.y - oy));
+      const f2 fz = mk2((float)(r0.z - oz), (float)(r1.z - oz));
+      const f2 d2 = vfma(fz, fz, vfma(fy, fy, fx * fx)) * unit2;
+      float d0, d1, i0, i1;
+      dist_and_inv(d2.x, d0, i0);
+      dist_and_inv(d2.y, d1, i1);
+      float rc0, rc1v, ri0, ri1;
+      if (m.uniform_rc) {
+        rc0 = rc1v = m.rc_r_max;
+        ri0 = ri1 = m.rcinv_r;
+      } else {
+        rc0 = (rc1 + m.rc_r[(unsigned)r0.w >> kIdxBits]) * 0.5f;
+        rc1v = (rc1 + m.rc_r[(unsigned)r1.w >> kIdxBits]) * 0.5f;
+        ri0 = fast_rcp(rc0);
+        ri1 = fast_rcp(rc1v);
+      }
+      const f2 dc = mk2(d0 < rc0 ? d0 : rc0, d1 < rc1v ? d1 : rc1v);
+      const f2 rcinv = mk2(ri0, ri1);
+      f2 fc, fcp;
+      cutoff_fc_fcp_v(rcinv, dc, fc, fcp);
+      f2 fnp[S::KRM + 1];
+      basis_fnp_v<S::KRM>(rcinv, dc, fc, fcp, fnp);
+      f2 s12 = bc2(0.0f), s21 = bc2(0.0f);
+#pragma unroll
+      for (int kk = 0; kk <= S::KRM; ++kk) {
+        s12 = vfma(fnp[kk], bc2(Aown[kk]), s12);
+        s21 = vfma(fnp[kk], Aj[kk], s21);
+      }
+      const f2 wgt = mk2(i0, i1);
+      const f2 fs = (s12 + s21) * wgt; // f12 - f21 = fs * r12
+      const f2 bb = s21 * wgt;         // f21 = -bb * r12
+      Fr2[0] = vfma(fs, fx, Fr2[0]);
+      Fr2[1] = vfma(fs, fy, Fr2[1]);
+      Fr2[2] = vfma(fs, fz, Fr2[2]);
+      const f2 bx = bb * fx, by = bb * fy, bz = bb * fz;
+      W2[0] = vfma(-fx, bx, W2[0]);
+      W2[1] = vfma(-fy, by, W2[1]);
+      W2[2] = vfma(-fz, bz, W2[2]);
+      W2[3] = vfma(-fx, by, W2[3]);
+      W2[4] = vfma(-fx, bz, W2[4]);
+      W2[5] = vfma(-fy, bz, W2[5]);
+    }
+  }
+}
+
 // L = 1: one lane per atom.  L = 2, 4 (small systems, see RadialWinSplitBody): L adjacent lanes share the atom, lane
 // `sub` takes every L-th chunk of two entries of the compact radial list and every L-th group of angular records; the
 // sums are linear in the pairs and are added across the lanes at the end, lane 0 writes.
-template <class S, int L = 1>
+// ROWS (static layout, shapes with register-resident sums): the radial-table rows of every window atom are staged in LDS
+// behind the records (T KRP floats per atom) and the pair loop reads the neighbour's row with ds_read instead of gathering it
+// from L2.  The gathers are what binds the plain form: a per-lane random 16-byte global load costs the CU ~46-115 cycles per
+// wavefront instruction against ~13-16 for a random ds_read_b128 (profiles/r3b_gather_rate.txt), and the texture-address unit
+// is busy for 75 % of the kernel (profiles/r3b_pmc_ta1.csv).  records + rows fill the LDS of a CU (PbTe: 80 B x ~1,700 window
+// atoms), so the workgroup is 1024 threads, L = 4 lanes per atom, one workgroup per CU (the same 16 wavefronts).
+template <class S, int L = 1, bool CW = false, bool ROWS = false> // CW: the compact list arrives as words (Bufs::cword, L = 1)
 struct ForceWinBody {
   WinStage st;
   ModelD m;
   const int* frozen;
+  NEPMI_HD int rows_offset() const { return (st.lay.bytes() + 15) / 16 * 16; }
+#ifndef NEPMI_FW_ROWPAD
+#define NEPMI_FW_ROWPAD 4 // floats of padding per LDS row: a 64-byte stride puts every row on one of four bank groups
+#endif
+  NEPMI_HD int row_stride() const { return m.T * st.b.KRP + ((m.T * st.b.KRP) % 16 == 0 ? NEPMI_FW_ROWPAD : 0); }
+  NEPMI_HD int rows_bytes() const { return ROWS ? 4 * row_stride() * (st.lay.wmax + 1) : 0; }
+  // second staging phase (after a barrier: the records are in place): the table row of the atom at every window slot
+  template <class LC>
+  NEPMI_HD void stage_rows(int64_t brick, LC lds, int tid, int nth) const
+  {
+    if (!ROWS)
+      return;
+    NEPMI_LDS(const WinRec)* wrec = (NEPMI_LDS(const WinRec)*)(lds + st.lay.off_rec());
+    NEPMI_LDS(F4)* rows = (NEPMI_LDS(F4)*)(lds + rows_offset());
+    const int q4 = m.T * st.b.KRP / 4; // 16-byte groups per row (KRP is a multiple of 4)
+    const int last = st.b.wtab[(brick * 512 + 511) * 2 + 1]; // atoms in this window = offset + count of the last window cell
+    int total = (last & 0xFFFF) + (last >> 16);
+    total = total < st.lay.wmax ? total : st.lay.wmax;
+    const F4* src = reinterpret_cast<const F4*>(st.b.atab);
+    const int s4 = row_stride() / 4;
+    for (int i = tid; i < total * q4; i += nth) {
+      const int slot = i / q4, g = i - slot * q4;
+      const int j = (int)((unsigned)wrec[slot].w & (unsigned)kIdxMask);
+      rows[slot * s4 + g] = src[(size_t)j * q4 + g];
+    }
+  }
   // 4: <= 128 VGPRs, four 256-thread workgroups per CU.  Shapes with register-resident table rows of 9 or more
   // coefficients (carbon: 11) spill 60-90 bytes per lane there; three wavefronts (<= 168 VGPRs) keep them in registers
   // (carbon 1 M atoms: 1.09 -> 0.97 ms)
   static constexpr int kMinWavesPerEu = L != 1 ? 1 : ((S::TS > 0 && S::KR >= 8) ? 3 : NEPMI_FW_WAVES);
   static constexpr int kLanes = L;
 
-  NEPMI_HD int lds_bytes() const { return st.lay.bytes(); }
+  NEPMI_HD int lds_bytes() const { return ROWS ? rows_offset() + rows_bytes() : st.lay.bytes(); }
   template <class LC>
   NEPMI_HD void stage_lists(int64_t, LC, int, int) const {}
   NEPMI_HD int64_t map_brick(int64_t w) const { return w; }
@@ -1522,12 +1683,22 @@ struct ForceWinBody {
       // type-pure segments of the compact list (front: neighbours of type 0, back: of type 1), packed arithmetic
       f2 Fr2[3] = {bc2(0.0f), bc2(0.0f), bc2(0.0f)};
       f2 W2[6] = {bc2(0.0f), bc2(0.0f), bc2(0.0f), bc2(0.0f), bc2(0.0f), bc2(0.0f)};
-      auto rows = [&](unsigned, unsigned, const WinRec& r0, const WinRec& r1, f2* Aj) {
-        const float* row0 = atab + (size_t)((unsigned)r0.w & (unsigned)kIdxMask) * arow + t1 * KRP;
-        const float* row1 = atab + (size_t)((unsigned)r1.w & (unsigned)kIdxMask) * arow + t1 * KRP;
+      NEPMI_LDS(const float)* lrows = (NEPMI_LDS(const float)*)(lds + rows_offset()) + t1 * KRP;
+      const int lstride = row_stride();
+      auto rows = [&](unsigned c0, unsigned c1, const WinRec& r0, const WinRec& r1, f2* Aj) {
+        if (ROWS) { // the neighbours' rows from the LDS copy, by window slot
+          NEPMI_LDS(const float)* row0 = lrows + c0 * lstride;
+          NEPMI_LDS(const float)* row1 = lrows + c1 * lstride;
 #pragma unroll
-        for (int kk = 0; kk <= S::KRM; ++kk)
-          Aj[kk] = mk2(row0[kk], row1[kk]);
+          for (int kk = 0; kk <= S::KRM; ++kk)
+            Aj[kk] = mk2(row0[kk], row1[kk]);
+        } else {
+          const float* row0 = atab + (size_t)((unsigned)r0.w & (unsigned)kIdxMask) * arow + t1 * KRP;
+          const float* row1 = atab + (size_t)((unsigned)r1.w & (unsigned)kIdxMask) * arow + t1 * KRP;
+#pragma unroll
+          for (int kk = 0; kk <= S::KRM; ++kk)
+            Aj[kk] = mk2(row0[kk], row1[kk]);
+        }
       };
       const int n0 = b.nn_t0[k] < nrad ? b.nn_t0[k] : nrad;
 #pragma unroll
@@ -1536,8 +1707,16 @@ struct ForceWinBody {
 #pragma unroll
         for (int kk = 0; kk <= S::KRM; ++kk)
           Aown[kk] = atab[(size_t)k * arow + t * KRP + kk];
-        win_force_segment<S>(m, ccode, N, wrec, rows, Aown, t == 0 ? n0 : nrad - n0, t == 0 ? 0 : b.MN_rad - 1,
-                             t == 0 ? 1 : -1, sub, L, ox, oy, oz, rc1, unit2, Fr2, W2);
+        if (CW) {
+          const int ne = t == 0 ? n0 : nrad - n0;
+          int nw = (ne + 3) >> 2;
+          nw = nw < b.MN_cw ? nw : b.MN_cw;
+          win_force_words<S>(m, reinterpret_cast<const U2w*>(b.cword) + k, N, wrec, rows, Aown, nw, t == 0 ? 0 : b.MN_cw, ox, oy,
+                             oz, rc1, unit2, Fr2, W2);
+        } else {
+          win_force_segment<S>(m, ccode, N, wrec, rows, Aown, t == 0 ? n0 : nrad - n0, t == 0 ? 0 : b.MN_rad - 1,
+                               t == 0 ? 1 : -1, sub, L, ox, oy, oz, rc1, unit2, Fr2, W2);
+        }
       }
 #pragma unroll
       for (int d = 0; d < 3; ++d)
@@ -1548,16 +1727,7 @@ struct ForceWinBody {
     } else {
       // one-wide form: the neighbour-type row of the own table is gathered per pair (many types / run-time shape)
       constexpr int G = 2;
-      unsigned cur[G], nxt[G];
-#pragma unroll
-      for (int u = 0; u < G; ++u)
-        cur[u] = nrad > 0 ? ccode[(int64_t)(G * sub + u < nrad ? G * sub + u : nrad - 1) * N] : 0u;
-      for (int s0 = G * sub; s0 < nrad; s0 += G * L) {
-#pragma unroll
-        for (int u = 0; u < G; ++u) {
-          const int idx = s0 + G * L + u;
-          nxt[u] = ccode[(int64_t)(idx < nrad ? idx : nrad - 1) * N];
-        }
+      auto chunk = [&](const unsigned* cur, const int s0) __attribute__((always_inline)) {
         WinRec rr[G];
         float Aj[G][S::KRM + 1];
 #pragma unroll
@@ -1615,9 +1785,45 @@ struct ForceWinBody {
           W[4] = fmaf(-fx, bz, W[4]);
           W[5] = fmaf(-fy, bz, W[5]);
         }
+      };
+      if (CW) {
+        // the compact list as words of four slots (Bufs::cword); a sentinel place past the end carries weight zero
+        const U2w* __restrict__ cw = reinterpret_cast<const U2w*>(b.cword) + k;
+        int nw = (nrad + 3) >> 2;
+        nw = nw < b.MN_cw ? nw : b.MN_cw;
+        auto load_word = [&](int w) -> U2w {
+          U2w v = {0u, 0u};
+          if (nw > 0)
+            v = cw[(int64_t)(w < nw ? w : nw - 1) * N];
+          return v;
+        };
+        U2w w1 = load_word(0);
+        for (int w = 0; w < nw; ++w) {
+          const U2w cu = w1;
+          w1 = load_word(w + 1);
+#pragma unroll 1
+          for (int hh = 0; hh < 2; ++hh) {
+            const unsigned pr = hh == 0 ? cu.lo : cu.hi;
+            const unsigned c2[G] = {pr & 0xFFFFu, pr >> 16};
+            chunk(c2, 4 * w + 2 * hh);
+          }
+        }
+      } else {
+        unsigned cur[G], nxt[G];
 #pragma unroll
         for (int u = 0; u < G; ++u)
-          cur[u] = nxt[u];
+          cur[u] = nrad > 0 ? ccode[(int64_t)(G * sub + u < nrad ? G * sub + u : nrad - 1) * N] : 0u;
+        for (int s0 = G * sub; s0 < nrad; s0 += G * L) {
+#pragma unroll
+          for (int u = 0; u < G; ++u) {
+            const int idx = s0 + G * L + u;
+            nxt[u] = ccode[(int64_t)(idx < nrad ? idx : nrad - 1) * N];
+          }
+          chunk(cur, s0);
+#pragma unroll
+          for (int u = 0; u < G; ++u)
+            cur[u] = nxt[u];
+        }
       }
     }
 

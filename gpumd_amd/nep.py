@@ -304,6 +304,15 @@ class NEP:
         """lanes per atom of the LDS-window kernels: 0 = by the number of bricks, or 1 / 2 / 4"""
         self._ck(self.lib.nepmi_engine_set_win_lanes(self.handle, int(lanes)))
 
+    def describe(self):
+        """the kernel forms the last force evaluation ran (counted rules of the engine, as text)"""
+        import ctypes as C
+        buf = C.create_string_buffer(512)
+        n = self.lib.nepmi_engine_describe(self.handle, buf, 512)
+        if n < 0:
+            self._ck(n)
+        return buf.value.decode()
+
     def set_win_static(self, on=True):
         """static window layout of the one-lane window kernels (default on); False = the scanned layout"""
         self._ck(self.lib.nepmi_engine_set_win_static(self.handle, int(bool(on))))

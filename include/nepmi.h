@@ -362,6 +362,10 @@ typedef struct {
 } nepmi_stats;
 /* Synchronises the stream.  with_lists != 0 also recounts the per-step list lengths. */
 int nepmi_engine_stats(nepmi_engine* e, int with_lists, nepmi_stats* out);
+/* Which kernel forms the LAST force evaluation ran, as a short text (e.g. "shape=PbTe-A window=static lanes=1 radial=win2
+ * ann=fused_fp32 angular_force=lane_pairs force=lds_rows"): the counted rules of the engine made visible (bench.py prints it
+ * as config.kernel_forms).  Returns the length written (without the terminator) or a negative status. */
+int nepmi_engine_describe(nepmi_engine* e, char* buf, int len);
 /* HIP-event timing on the engine's stream.  on = 1: every kernel and region (two event records per launch: the
  * kernels no longer run back to back, about 5 % slower steps); on = 2: the force-assembly kernel only (what bench.py
  * keeps inside its timed region for the roofline figure); 0: off. */

@@ -119,6 +119,26 @@ struct HostLoopBackend {
     }
   }
 
+  // ... with the second staging phase of the bodies that keep the neighbours' table rows in "LDS"; the host loop runs one lane
+  template <class Body>
+  void launch_win2_split(int, int64_t nbricks, const Body& body)
+  {
+    if (body.skip())
+      return;
+    std::vector<double> raw((size_t)body.lds_bytes() / 8 + 8);
+    char* lds = reinterpret_cast<char*>(raw.data());
+    for (int64_t wg = 0; wg < nbricks; ++wg) {
+      const int64_t brick = body.map_brick(wg);
+      body.stage(brick, lds, 0, 1);
+      body.stage_rows(brick, lds, 0, 1);
+      int64_t a0, a1;
+      body.brick_range(brick, a0, a1);
+      for (int64_t k = a0; k < a1; ++k)
+        body.compute(brick, k, lds, 0);
+    }
+  }
+  static constexpr size_t kMaxLdsBytes = 160 * 1024;
+
   // bodies with a workgroup-staged table: the "LDS" is an ordinary host buffer here
   template <int BLOCK, class Body>
   void launch_lds(int, int64_t n, const Body& body)
