@@ -590,8 +590,11 @@ struct RadialWinBody {
 #define NEPMI_RW2_WAVES 1
 #endif
 #ifndef NEPMI_CW
-#define NEPMI_CW 0 // 1: the compact radial list of the static layout is written / read as words of four slots (Bufs::cword);
-                   // measured (r3c, PbTe 1 M atoms): radial pass 0.364 -> 0.359 ms, force assembly 0.523 -> 0.539 ms: off
+#define NEPMI_CW 0 // 1: the compact radial list of the static layout is written / read as words of four slots (Bufs::cword) and
+                   // the force assembly walks them software-pipelined (win_force_words).  Measured on PbTe 1 M atoms
+                   // (profiles/r3cd_ab_window_variants.txt, r3e): radial pass 0.364 -> 0.359 ms; force assembly 0.517 (2-byte list,
+                   // no pipeline) vs 0.508 (words, pipelined, 3 waves) vs 1.02 (4 waves: the two stages spill); carbon 0.79 ->
+                   // 0.98.  Off.
 #endif
 #ifndef NEPMI_RW2_HALF
 #define NEPMI_RW2_HALF 1 // 1: a word pair is processed as two halves of 2 + 2 candidates (fewer live registers), 0: 4 + 4 at once
@@ -1521,71 +1524,97 @@ NEPMI_HD void win_force_segment(
 // The same over a stream of compact-list WORDS (Bufs::cword: four LDS slots per 8 bytes, the last word padded with the
 // sentinel slot, whose record lies beyond the cutoff: the clamped envelope and its derivative vanish there, so a padded
 // place adds exactly zero and the loop needs no "live" weights).  One lane per atom; `nwords` words at rows row0, row0 + 1, ...
+//
+// Software-pipelined: a wavefront's pair loop is a chain  list word -> window record (LDS) -> neighbour's table row (a gather
+// that misses L1) -> arithmetic, and with four wavefronts per SIMD nothing hides a global round trip per evaluation (r3c/r3d:
+// the loop took the same time with the rows gathered from L2, read from LDS, or the list packed -- it was waiting for whichever
+// global load came last).  Here the list words are requested NEPMI_FW_AHEAD words (two evaluations each) ahead and the records
+// + rows of evaluation e + 1 are requested before evaluation e is computed.
+#ifndef NEPMI_FW_AHEAD
+#define NEPMI_FW_AHEAD 3
+#endif
 template <class S, class LC, class Rows>
 NEPMI_HD void win_force_words(
   const ModelD& m, const U2w* __restrict__ cword, int64_t N, LC wrec, const Rows& rows, const float* Aown, int nwords, int row0,
   int ox, int oy, int oz, float rc1, float unit2, f2* Fr2, f2* W2)
 {
-  auto load_word = [&](int w) -> U2w {
-    U2w v = {0u, 0u};
-    if (nwords > 0)
-      v = cword[(int64_t)(row0 + (w < nwords ? w : nwords - 1)) * N];
-    return v;
+  if (nwords <= 0)
+    return;
+  auto load_word = [&](int w) -> U2w { return cword[(int64_t)(row0 + (w < nwords ? w : nwords - 1)) * N]; };
+  struct Stage { // operands of one packed evaluation of two pairs: the two slots and the neighbours' table rows (the window
+    unsigned pr; // records are read again from LDS when the evaluation starts: cheaper than eight registers per stage)
+    f2 Aj[S::KRM + 1];
   };
-  U2w w1 = load_word(0);
-  for (int w = 0; w < nwords; ++w) {
-    const U2w cur = w1;
-    w1 = load_word(w + 1); // in flight while this word (two packed evaluations of two pairs) is processed
-#pragma unroll 1
-    for (int hh = 0; hh < 2; ++hh) {
-      const unsigned pr = hh == 0 ? cur.lo : cur.hi;
-      const unsigned cur0 = pr & 0xFFFFu, cur1 = pr >> 16;
-      const WinRec r0 = wrec[cur0], r1 = wrec[cur1];
-      f2 Aj[S::KRM + 1];
-      rows(cur0, cur1, r0, r1, Aj);
-      const f2 fx = mk2((float)(r0.x - ox), (float)(r1.x - ox));
-      const f2 fy = mk2((float)(r0.y - oy), (float)(r1.y - oy));
-      const f2 fz = mk2((float)(r0.z - oz), (float)(r1.z - oz));
-      const f2 d2 = vfma(fz, fz, vfma(fy, fy, fx * fx)) * unit2;
-      float d0, d1, i0, i1;
-      dist_and_inv(d2.x, d0, i0);
-      dist_and_inv(d2.y, d1, i1);
-      float rc0, rc1v, ri0, ri1;
-      if (m.uniform_rc) {
-        rc0 = rc1v = m.rc_r_max;
-        ri0 = ri1 = m.rcinv_r;
-      } else {
-        rc0 = (rc1 + m.rc_r[(unsigned)r0.w >> kIdxBits]) * 0.5f;
-        rc1v = (rc1 + m.rc_r[(unsigned)r1.w >> kIdxBits]) * 0.5f;
-        ri0 = fast_rcp(rc0);
-        ri1 = fast_rcp(rc1v);
-      }
-      const f2 dc = mk2(d0 < rc0 ? d0 : rc0, d1 < rc1v ? d1 : rc1v);
-      const f2 rcinv = mk2(ri0, ri1);
-      f2 fc, fcp;
-      cutoff_fc_fcp_v(rcinv, dc, fc, fcp);
-      f2 fnp[S::KRM + 1];
-      basis_fnp_v<S::KRM>(rcinv, dc, fc, fcp, fnp);
-      f2 s12 = bc2(0.0f), s21 = bc2(0.0f);
-#pragma unroll
-      for (int kk = 0; kk <= S::KRM; ++kk) {
-        s12 = vfma(fnp[kk], bc2(Aown[kk]), s12);
-        s21 = vfma(fnp[kk], Aj[kk], s21);
-      }
-      const f2 wgt = mk2(i0, i1);
-      const f2 fs = (s12 + s21) * wgt; // f12 - f21 = fs * r12
-      const f2 bb = s21 * wgt;         // f21 = -bb * r12
-      Fr2[0] = vfma(fs, fx, Fr2[0]);
-      Fr2[1] = vfma(fs, fy, Fr2[1]);
-      Fr2[2] = vfma(fs, fz, Fr2[2]);
-      const f2 bx = bb * fx, by = bb * fy, bz = bb * fz;
-      W2[0] = vfma(-fx, bx, W2[0]);
-      W2[1] = vfma(-fy, by, W2[1]);
-      W2[2] = vfma(-fz, bz, W2[2]);
-      W2[3] = vfma(-fx, by, W2[3]);
-      W2[4] = vfma(-fx, bz, W2[4]);
-      W2[5] = vfma(-fy, bz, W2[5]);
+  auto fetch = [&](unsigned pr, Stage& st) __attribute__((always_inline)) {
+    const unsigned c0 = pr & 0xFFFFu, c1 = pr >> 16;
+    st.pr = pr;
+    const WinRec r0 = wrec[c0], r1 = wrec[c1];
+    rows(c0, c1, r0, r1, st.Aj);
+  };
+  auto evaluate = [&](const Stage& st) __attribute__((always_inline)) {
+    const WinRec r0 = wrec[st.pr & 0xFFFFu], r1 = wrec[st.pr >> 16];
+    const f2 fx = mk2((float)(r0.x - ox), (float)(r1.x - ox));
+    const f2 fy = mk2((float)(r0.y - oy), (float)(r1.y - oy));
+    const f2 fz = mk2((float)(r0.z - oz), (float)(r1.z - oz));
+    const f2 d2 = vfma(fz, fz, vfma(fy, fy, fx * fx)) * unit2;
+    float d0, d1, i0, i1;
+    dist_and_inv(d2.x, d0, i0);
+    dist_and_inv(d2.y, d1, i1);
+    float rc0, rc1v, ri0, ri1;
+    if (m.uniform_rc) {
+      rc0 = rc1v = m.rc_r_max;
+      ri0 = ri1 = m.rcinv_r;
+    } else {
+      rc0 = (rc1 + m.rc_r[(unsigned)r0.w >> kIdxBits]) * 0.5f;
+      rc1v = (rc1 + m.rc_r[(unsigned)r1.w >> kIdxBits]) * 0.5f;
+      ri0 = fast_rcp(rc0);
+      ri1 = fast_rcp(rc1v);
     }
+    const f2 dc = mk2(d0 < rc0 ? d0 : rc0, d1 < rc1v ? d1 : rc1v);
+    const f2 rcinv = mk2(ri0, ri1);
+    f2 fc, fcp;
+    cutoff_fc_fcp_v(rcinv, dc, fc, fcp);
+    f2 fnp[S::KRM + 1];
+    basis_fnp_v<S::KRM>(rcinv, dc, fc, fcp, fnp);
+    f2 s12 = bc2(0.0f), s21 = bc2(0.0f);
+#pragma unroll
+    for (int kk = 0; kk <= S::KRM; ++kk) {
+      s12 = vfma(fnp[kk], bc2(Aown[kk]), s12);
+      s21 = vfma(fnp[kk], st.Aj[kk], s21);
+    }
+    const f2 wgt = mk2(i0, i1);
+    const f2 fs = (s12 + s21) * wgt; // f12 - f21 = fs * r12
+    const f2 bb = s21 * wgt;         // f21 = -bb * r12
+    Fr2[0] = vfma(fs, fx, Fr2[0]);
+    Fr2[1] = vfma(fs, fy, Fr2[1]);
+    Fr2[2] = vfma(fs, fz, Fr2[2]);
+    const f2 bx = bb * fx, by = bb * fy, bz = bb * fz;
+    W2[0] = vfma(-fx, bx, W2[0]);
+    W2[1] = vfma(-fy, by, W2[1]);
+    W2[2] = vfma(-fz, bz, W2[2]);
+    W2[3] = vfma(-fx, by, W2[3]);
+    W2[4] = vfma(-fx, bz, W2[4]);
+    W2[5] = vfma(-fy, bz, W2[5]);
+  };
+  constexpr int AH = NEPMI_FW_AHEAD;
+  U2w q[AH]; // words w + 1 .. w + AH (clamped to the last word: a repeated word is fetched, never evaluated)
+  U2w cur = load_word(0);
+#pragma unroll
+  for (int a = 0; a < AH; ++a)
+    q[a] = load_word(1 + a);
+  Stage A, Bs;
+  fetch(cur.lo, A);
+  for (int w = 0; w < nwords; ++w) {
+    fetch(cur.hi, Bs); // second evaluation of this word: in flight while the first is computed
+    evaluate(A);
+    const U2w nxt = q[0];
+#pragma unroll
+    for (int a = 0; a + 1 < AH; ++a)
+      q[a] = q[a + 1];
+    q[AH - 1] = load_word(w + 1 + AH);
+    fetch(nxt.lo, A); // first evaluation of the next word (of the same word again past the end: unused)
+    evaluate(Bs);
+    cur = nxt;
   }
 }
 
@@ -1668,9 +1697,11 @@ struct ForceWinBody {
     const float* __restrict__ atab = b.atab;
 
     // ---- angular part: f12 - f21 of this step's angular pairs (compact records) ----
+    // (CW: after the radial loop, whose software pipeline needs the registers of these twelve sums)
     float F[3] = {0, 0, 0};
     float Wa[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}; // xx yy zz xy xz yz yx zx zy
-    win_force_angular<L>(b, k, sub, F, Wa);
+    if (!CW)
+      win_force_angular<L>(b, k, sub, F, Wa);
 
     // ---- radial part over the compact list: every entry is a pair inside the cutoff ----
     constexpr int TSM = S::TS > 0 ? S::TS : 1;
@@ -1827,6 +1858,8 @@ struct ForceWinBody {
       }
     }
 
+    if (CW)
+      win_force_angular<L>(b, k, sub, F, Wa);
     if (L > 1) {
 #pragma unroll
       for (int msk = 1; msk < L; msk <<= 1) {
