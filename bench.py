@@ -324,6 +324,49 @@ def kernel_report(st, info, n_atoms_per_launch, st_all=None, tersoff=False):
     return kern, roofline, b_step
 
 
+def measure_extra(workload, reps, steps, warmup, dev):
+    """One more measurement AFTER the clock of the bench line has stopped (config.extra_measurements): its own engine, the
+    same protocol (inputs resident, warm-up, K steps between synchronisations, HIP events on the dominant kernel inside
+    the timed region, an instrumented pass after it).  -> dict with value / ms_per_step / roofline."""
+    import torch
+    import gpumd_amd
+    from gpumd_amd import structures as H
+    label, nep_txt, h, typ, x, mass, vel = build_workload(workload, reps, 42)
+    n = len(typ)
+    model = gpumd_amd.Model(nep_txt)
+    eng = gpumd_amd.NEP(model, n)
+    dt = 1.0 / H.TIME_UNIT
+    t_type, t_mass = torch.from_numpy(typ).to(dev), torch.from_numpy(mass).to(dev)
+    t_x, t_v = torch.from_numpy(x).to(dev), torch.from_numpy(vel).to(dev)
+    t_pe, t_f, t_w = (torch.zeros(k * n, dtype=torch.float64, device=dev) for k in (1, 3, 9))
+    eng.force_compute(h, t_type, t_x, t_pe, t_f, t_w)
+    if warmup > 0:
+        eng.run_nve(h, t_type, t_mass, dt, warmup, t_x, t_v, t_pe, t_f, t_w)
+    eng.set_timing(2)
+    reb0 = eng.stats().num_rebuild
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eng.run_nve(h, t_type, t_mass, dt, steps, t_x, t_v, t_pe, t_f, t_w, thermo_every=steps)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    st = eng.stats(with_lists=True)
+    eng.set_timing(1)
+    extra = max(10, min(steps, 40))
+    eng.run_nve(h, t_type, t_mass, dt, extra, t_x, t_v, t_pe, t_f, t_w, thermo_every=extra)
+    st_all = eng.stats(with_lists=False)
+    eng.set_timing(0)
+    tersoff = workload == "si_tersoff"
+    kern, roofline, b_step = kernel_report(st, model.info, n, st_all, tersoff=tersoff)
+    if tersoff and roofline:
+        roofline["kernel"] = {"radial_descriptor": "tersoff_bond_order", "force_assemble": "tersoff_force"}[roofline["kernel"]]
+    return {"workload": label, "metric": METRIC[workload], "value": n * steps / elapsed, "unit": "atom-steps/s",
+            "steps": steps, "warmup": warmup, "ms_per_step": elapsed / steps * 1e3, "dtype": "f64" if tersoff else "f32",
+            "rebuilds_in_timed_region": int(st.num_rebuild - reb0), "kernel_forms": eng.describe(),
+            "roofline": roofline, "step_algorithmic_bytes_per_atom": b_step,
+            "step_hbm_frac": b_step * (n * steps / elapsed) / (HBM_PEAK_GBS * 1e9),
+            "kernels_avg_ms": {k: round(v["avg_ms"], 5) for k, v in kern.items()}}
+
+
 def run_decomposed(args, world, rank, dev, model, label, h_block, typ, x, mass, vel):
     """N > 1 (or --decomposed on one GPU): the C++ domain-decomposed driver of libnepmi (nepmi_dist_*), one rank per
     GPU, ghost positions over RCCL/xGMI.  Python only builds the synthetic block and passes pointers."""
@@ -439,6 +482,8 @@ def main():
     ap.add_argument("--workload", default="pbte", choices=["pbte", "pbte_ortho", "carbon", "unep", "si_tersoff"],
                     help="pbte = BASELINE config 3 (the bench line); the others are extra single-GPU measurements")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip extra_measurements (config 2 and the rebuild-inclusive PbTe segment, timed after the bench line's clock)")
     ap.add_argument("--decomposed", action="store_true",
                     help="run the N > 1 code path (the C++ domain-decomposed driver) even on one GPU, to measure its overhead")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
@@ -560,7 +605,14 @@ def main():
             "config": {"workload": label,
                        "atoms_total": total_atoms, "rebuilds_in_timed_region": int(st.num_rebuild - reb0),
                        "mean_nn_radial": st.mean_nn_radial, "mean_nn_angular": st.mean_nn_angular,
-                       "lds_window_mode": int(st.radial_tiles), "parallelism": "1 GPU"},
+                       "lds_window_mode": int(st.radial_tiles), "parallelism": "1 GPU",
+                       "kernel_forms": eng.describe(),
+                       "ann_form": ("per-atom descriptor + ANN fused in one kernel, packed FP32 on the vector units (no MFMA in this "
+                                    "workload's step)" if "ann=fused" in eng.describe() else
+                                    ("matrix-core ANN kernel (v_mfma_f32_32x32x2_f32)" if "ann=mfma" in eng.describe() else "per-atom ANN kernel")),
+                       "thermo_every": args.steps,
+                       "thermo_note": "thermo reduced once, at the last step of the timed region (the reference's Ensemble reduces it "
+                                      "every step, ensemble_nve.cu:59-95: a legitimate saving of the fused loop, stated here)"},
             "roofline": roofline,
             "step_algorithmic_bytes_per_atom": b_step,
             "step_hbm_frac": b_step * (n * args.steps / elapsed) / (HBM_PEAK_GBS * 1e9),
@@ -579,6 +631,36 @@ def main():
                                 "note": "frac_own prices the operations this engine executes (counted from its kernels for "
                                         "this model shape; ~1.31 Verlet candidates per radial neighbour); the survey figure is "
                                         "the reference algorithm's count and only says how much of it was avoided"}
+        if world == 1 and not args.no_extras and not args.no_cpu_baseline and args.workload == "pbte":
+            # After the clock: (a) the same engine for further 100-step segments until one of them contains a list rebuild
+            # (at 300 K one rebuild per ~100 steps): the rebuild-inclusive rate; (b) BASELINE config 2 (Si 13,824 atoms,
+            # Tersoff-1989, FP64) on its own engine.  Each carries its own roofline object.
+            extras = {}
+            try:
+                seg = None
+                for _ in range(4):
+                    r0 = eng.stats().num_rebuild
+                    eng.set_timing(2)
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    eng.run_nve(h, t_type, t_mass, dt, 100, t_x, t_v, t_pe, t_f, t_w, thermo_every=100)
+                    torch.cuda.synchronize()
+                    el = time.perf_counter() - t1
+                    st2 = eng.stats(with_lists=True)
+                    eng.set_timing(0)
+                    kern2, roof2, _ = kernel_report(st2, model.info, n, None)
+                    seg = {"workload": label, "steps": 100, "ms_per_step": el / 100 * 1e3, "value": n * 100 / el,
+                           "unit": "atom-steps/s", "rebuilds_in_timed_region": int(st2.num_rebuild - r0), "roofline": roof2}
+                    if seg["rebuilds_in_timed_region"] >= 1:
+                        break
+                extras["pbte_100_steps_with_rebuild"] = seg
+            except Exception as e:  # never lose the bench line to an extra
+                extras["pbte_100_steps_with_rebuild"] = {"error": str(e)}
+            try:
+                extras["config2_si_tersoff"] = measure_extra("si_tersoff", (16, 16, 16), 2000, 200, dev)
+            except Exception as e:
+                extras["config2_si_tersoff"] = {"error": str(e)}
+            out["extra_measurements"] = extras
         if world == 1 and not args.no_cpu_baseline and args.workload == "pbte":
             with _stdout_to_stderr():
                 out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)

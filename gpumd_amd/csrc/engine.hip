@@ -936,6 +936,10 @@ struct HipBackend {
         case 3: launch_ann_mfma<3, 24>(a.DT, lds_bytes, grid, m, b, nchunks); break;
         default: launch_ann_mfma<4, 24>(a.DT, lds_bytes, grid, m, b, nchunks); break;
       }
+    } else if (a.KS <= 34 && a.MT == 4) {
+      // C_2022_NEP4 (dim 65: 33 k-pairs, 100 neurons): the operand buffer of 40 k-pairs pushed the kernel ten registers past
+      // the 256 of two wavefronts per SIMD (r3a: scratch 44 bytes per lane)
+      launch_ann_mfma<4, 34>(a.DT, lds_bytes, grid, m, b, nchunks);
     } else {
       switch (a.MT) {
         case 1: launch_ann_mfma<1, 40>(a.DT, lds_bytes, grid, m, b, nchunks); break;

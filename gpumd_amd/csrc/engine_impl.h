@@ -925,6 +925,8 @@ private:
       b_.MN_wchunks = (b_.MN_ang + 3) / 4 + 2 * ((b_.MN_skin + 3) / 4) + 4;
       b_.wcode = dalloc<unsigned short>((size_t)b_.MN_wchunks * 4 * N);
       b_.wseg = dalloc<int>(N);
+      b_.FPR = (m.n_max_radial + 1 + 3) / 4 * 4;
+      b_.fpr = m.num_types > 4 ? dalloc<float>((size_t)N * b_.FPR) : nullptr; // many-type models: see ForceWinBody<..., FPJ>
       b_.MN_cw = (b_.MN_rad + 3) / 4 + 1;
       b_.cword = dalloc<unsigned short>((size_t)2 * b_.MN_cw * 4 * N);
     } else { // Tersoff-1989: Tersoff1989::Tersoff1989 allocations (tersoff1989.cu:141-149)
@@ -933,6 +935,7 @@ private:
       tb_.bp = dalloc<double>((size_t)b_.MN_ang * N);
       tb_.f12 = dalloc<D4>((size_t)b_.MN_ang * N);
       tb_.pe_d = dalloc<double>(N);
+      tb_.mask = dalloc<unsigned long long>(N);
       for (int k = 0; k < 3; ++k) {
         const TersoffSet& s = m.ters[k];
         tp_.p[k] = TersoffSetD{s.a, s.b, s.lambda, s.mu, s.beta, s.n, s.c, s.d, s.h, s.r1, s.r2, s.c2, s.d2,
@@ -1445,6 +1448,7 @@ private:
     const int lanes = win_lanes();
     const bool win2 = win2_ok_ && lanes == 1;
     last_rows_form_ = false;
+    last_fpj_form_ = false;
     WinLayout lay2 = win_;
     lay2.compact = 1;
     const WinStage ws2{box_, b_, lay2};
@@ -1470,6 +1474,7 @@ private:
       radial(num_bricks_, -1);
     else
       be_.template launch<64>(kSlotRadial, N_, RadialDescBody<S>{box_, md_, b_, 1});
+    b_.skip_atab = (win2 && fpj_wanted<S>(ws2)) ? 1 : 0; // the FPJ force assembly needs no radial table from the ANN kernel
     if (fuse_ann_active()) {
       launch_angular_desc<S>(true);
     } else {
@@ -1481,6 +1486,8 @@ private:
       be_.template launch<64>(kSlotForce, N_, ForceAssembleBody<S>{md_, b_});
     else if (win2 && rows_form<S>(ws2, frozen))
       ; // (launched by rows_form)
+    else if (win2 && fpj_form<S>(ws2, frozen))
+      ; // (launched by fpj_form)
     else if (win2)
       be_.launch_win2(kSlotForce, num_bricks_, ForceWinBody<S, 1, NEPMI_CW != 0>{ws2, md_, frozen});
     else if (lanes == 4)
@@ -1514,6 +1521,31 @@ private:
     return true;
   }
 
+  // Force assembly of many-type models with the neighbour's half contracted from its radial Fp row (ForceWinBody<..., FPJ>):
+  // one-wide shapes, more than four types (the per-atom ANN kernel writes Bufs::fpr), window + coefficient table within 80 KB
+  // (two workgroups per CU).  A counted rule.
+#ifndef NEPMI_FW_FPJ
+#define NEPMI_FW_FPJ 1 // A/B switch (profiles/ab_variants.sh)
+#endif
+  template <class S>
+  bool fpj_wanted(const WinStage& ws2) const
+  {
+    if (S::TS > 0 || !NEPMI_FW_FPJ || NEPMI_CW || !b_.fpr || fuse_ann_active() || (ann_mode_ != 0 && b_.ann_img != nullptr))
+      return false; // (fpr is written by the per-atom ANN kernel only)
+    const ForceWinBody<S, 1, false, false, true> body{ws2, md_, nullptr};
+    return body.lds_bytes() <= 80 * 1024;
+  }
+  template <class S>
+  bool fpj_form(const WinStage& ws2, const int* frozen)
+  {
+    if (!fpj_wanted<S>(ws2))
+      return false;
+    const ForceWinBody<S, 1, false, false, true> body{ws2, md_, frozen};
+    be_.launch_win2(kSlotForce, num_bricks_, body);
+    last_fpj_form_ = true;
+    return true;
+  }
+
 public:
   void set_rows(bool on) { use_rows_ = on; }
   // the kernel forms of the last force evaluation (the counted rules above, in words)
@@ -1539,7 +1571,8 @@ public:
       s += " ann=per_atom";
     s += (shape_ != 0 && model_.n_max_angular + 1 >= 7) ? " angular_force=lane_pairs" : " angular_force=one_lane";
     s += recompute_s() ? " angular_sums=recomputed" : " angular_sums=stored";
-    s += last_rows_form_ ? " force_assembly=table_rows_in_lds" : " force_assembly=table_rows_gathered";
+    s += last_rows_form_ ? " force_assembly=table_rows_in_lds"
+                         : (last_fpj_form_ ? " force_assembly=neighbour_half_from_fp_rows" : " force_assembly=table_rows_gathered");
     return s;
   }
   // frozen != nullptr: a speculatively enqueued step of a fused run loop -- every kernel of the force path looks at
@@ -1556,7 +1589,7 @@ private:
   {
     if (model_.kind == 1) { // Tersoff1989::compute, tersoff1989.cu:508-586
       be_.begin_region(kRegionForce);
-      be_.template launch<64>(kSlotRadial, N_, TersoffPartialBody{box_, tp_, b_, tb_});
+      be_.template launch_lds<kTersoffBlock>(kSlotRadial, N_, TersoffPartialBody{box_, tp_, b_, tb_}); // members of the local list in LDS
       be_.template launch<64>(kSlotForce, N_, TersoffAssembleBody{b_, tb_});
       be_.end_region(kRegionForce);
       return;
@@ -1581,7 +1614,7 @@ private:
   WinLayout win_{0, 0};
   bool win2_ok_ = false, use_win2_ = NEPMI_WIN2_DEFAULT != 0;
   bool use_rows_ = true; // force assembly with the table rows in LDS where they fit
-  bool last_rows_form_ = false; // static window layout (Bufs::wtab / wcode) in use / allowed
+  bool last_rows_form_ = false, last_fpj_form_ = false; // static window layout (Bufs::wtab / wcode) in use / allowed
   double* ui_alloc_ = nullptr;
   double* factor_dev_ = nullptr;
   bool tile_ok_ = false, use_tiles_ = true;

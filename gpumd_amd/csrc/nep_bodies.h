@@ -173,6 +173,12 @@ struct Bufs {
   // all), rows [MN_cw, 2 MN_cw): neighbours of type 1 (two-type shapes); nn_t0 / nn_rad count entries as before
   unsigned short* cword;
   int MN_cw;
+  // radial part of Fp per atom, contiguous ([N][FPR], FPR = n_r + 1 rounded up to a multiple of 4): what the force assembly of
+  // many-type models gathers from the neighbour (ForceWinBody<..., FPJ>); written by the per-atom ANN kernel; else nullptr
+  float* fpr;
+  int FPR;
+  int skip_atab; // 1: this step's force assembly contracts both halves of a pair from Fp rows (FPJ form): the ANN kernel need not
+                 // form the radial table (T k_r' floats per atom)
 };
 
 // planes of Bufs::fo
@@ -1832,7 +1838,7 @@ struct AnnBody {
       }
       // radial force table for atoms of this type
       const int KRP = b.KRP;
-      for (int t2 = 0; t2 < m.T; ++t2) {
+      for (int t2 = 0; t2 < (b.skip_atab ? 0 : m.T); ++t2) {
         cfloat_ptr c = as_const(m.c_rad) + (size_t)(tu * m.T + t2) * (NR + 1) * (KR + 1);
 #pragma unroll
         for (int kk = 0; kk <= S::KRM; ++kk) {
@@ -1856,6 +1862,14 @@ struct AnnBody {
       if (!S::fixed && d >= dim)
         break;
       b.fp[(int64_t)d * N + g] = Fp[d];
+    }
+    if (b.fpr) { // the radial rows again, atom-major (gathered by the neighbours' force assembly)
+#pragma unroll
+      for (int n = 0; n <= S::NRM; ++n) {
+        if (!S::fixed && n > NR)
+          break;
+        b.fpr[(size_t)k * b.FPR + n] = Fp[n];
+      }
     }
   }
 };

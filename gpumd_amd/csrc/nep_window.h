@@ -47,6 +47,59 @@ struct WinLayout {
   NEPMI_HD int bytes() const { return off_rec() + 16 * (wmax + (compact ? 1 : 0)); }
 };
 
+// Radial coefficient table of many-type shapes in LDS (static layout): one block of (n_r+1)(k_r+1) floats per ordered type
+// pair, padded to a multiple of four so that a lane reads its pair's block with 16-byte ds_reads (12 instead of 45 for UNEP-v1)
+struct alignas(16) F4f {
+  float x, y, z, w;
+};
+NEPMI_HD int ctab_block(int NR, int KR) { return ((NR + 1) * (KR + 1) + 3) / 4 * 4; }
+template <class LC>
+NEPMI_HD void ctab_stage_padded(const ModelD& m, LC dst_bytes, int tid, int nth)
+{
+  NEPMI_LDS(float)* ct = (NEPMI_LDS(float)*)dst_bytes;
+  const int raw = (m.NR + 1) * (m.KR + 1), blk = ctab_block(m.NR, m.KR), npair = m.T * m.T;
+  for (int i = tid; i < npair * blk; i += nth) {
+    const int pr = i / blk, e = i - pr * blk;
+    ct[i] = e < raw ? m.c_rad[pr * raw + e] : 0.0f;
+  }
+}
+// g[n] = sum_k c[n][k] f[k] from one padded block
+// VEC: the block is read with 16-byte ds_reads into registers first; else element by element as it is used (measured on UNEP-v1,
+// r3g: the radial pass, which runs this once per candidate next to its bookkeeping, takes 2.15 ms with the wide reads against
+// 1.13 ms without; the force assembly, which runs it twice per pair, keeps them)
+template <class S, bool VEC, class LP>
+NEPMI_HD void ctab_contract(LP blk_ptr, int NR, int KR, const float* f, float* g)
+{
+  if (S::fixed && VEC) {
+    constexpr int RAW = (S::NRM + 1) * (S::KRM + 1), BLK = (RAW + 3) / 4 * 4;
+    float v[BLK];
+    NEPMI_LDS(const F4f)* p4 = (NEPMI_LDS(const F4f)*)blk_ptr;
+#pragma unroll
+    for (int i = 0; i < BLK / 4; ++i) {
+      const F4f t = p4[i];
+      v[4 * i] = t.x;
+      v[4 * i + 1] = t.y;
+      v[4 * i + 2] = t.z;
+      v[4 * i + 3] = t.w;
+    }
+#pragma unroll
+    for (int n = 0; n <= S::NRM; ++n) {
+      float gs = 0.0f;
+#pragma unroll
+      for (int kk = 0; kk <= S::KRM; ++kk)
+        gs = fmaf(v[n * (S::KRM + 1) + kk], f[kk], gs);
+      g[n] = gs;
+    }
+  } else {
+    for (int n = 0; n <= NR; ++n) {
+      float gs = 0.0f;
+      for (int kk = 0; kk <= KR; ++kk)
+        gs = fmaf(blk_ptr[n * (KR + 1) + kk], f[kk], gs);
+      g[n] = gs;
+    }
+  }
+}
+
 // Staging, shared by the two passes (identical window contents and slot order in both): the records of the window
 // cells' atoms are copied from Bufs::prec (fixed point, relative to the corner of the atom's own cell) with the
 // integer offset of that cell from the window centre added -- no FP64, no search.
@@ -611,7 +664,7 @@ struct RadialWin2Body {
   const int* frozen;
   static constexpr int kMinWavesPerEu = NEPMI_RW2_WAVES;
 
-  NEPMI_HD int ctab_floats() const { return S::TS > 0 ? 0 : m.T * m.T * (m.NR + 1) * (m.KR + 1); }
+  NEPMI_HD int ctab_floats() const { return S::TS > 0 ? 0 : m.T * m.T * ctab_block(m.NR, m.KR); }
   NEPMI_HD int ctab_offset() const { return (st.lay.bytes() + 15) / 16 * 16; }
   NEPMI_HD bool ctab_on() const { return NEPMI_RW_CTAB && S::TS == 0 && ctab_offset() + 4 * ctab_floats() <= 80 * 1024; }
   NEPMI_HD int lds_bytes() const { return ctab_on() ? ctab_offset() + 4 * ctab_floats() : st.lay.bytes(); }
@@ -621,12 +674,8 @@ struct RadialWin2Body {
   NEPMI_HD void stage(int64_t brick, LC lds, int tid, int nth) const
   {
     st.stage_direct(brick, lds, tid, nth);
-    if (ctab_on()) {
-      NEPMI_LDS(float)* ct = (NEPMI_LDS(float)*)(lds + ctab_offset());
-      const int nf = ctab_floats();
-      for (int i = tid; i < nf; i += nth)
-        ct[i] = m.c_rad[i];
-    }
+    if (ctab_on())
+      ctab_stage_padded(m, lds + ctab_offset(), tid, nth);
   }
   NEPMI_HD void brick_range(int64_t brick, int64_t& a0, int64_t& a1) const { st.brick_range(brick, a0, a1); }
 
@@ -822,17 +871,17 @@ struct RadialWin2Body {
         basis_fn<S::KRM>(rcinv, dc, fc, fn);
       else
         basis_fn_rt(KR, rcinv, dc, fc, fn);
-      const int coff = (t1 * m.T + t2) * (NR + 1) * (KR + 1);
       if (ctab) {
-        NEPMI_LDS(const float)* cc = ctab_lds + coff;
-        for (int n = 0; n <= NR; ++n) {
-          float gsum = 0.0f;
-          for (int kk = 0; kk <= KR; ++kk)
-            gsum += fn[kk] * cc[n * (KR + 1) + kk];
-          q[n] += gsum;
+        float g[S::NRM + 1];
+        ctab_contract<S, false>(ctab_lds + (t1 * m.T + t2) * ctab_block(NR, KR), NR, KR, fn, g);
+#pragma unroll
+        for (int n = 0; n <= S::NRM; ++n) {
+          if (!S::fixed && n > NR)
+            break;
+          q[n] += g[n];
         }
       } else {
-        const float* cc = m.c_rad + coff;
+        const float* cc = m.c_rad + (t1 * m.T + t2) * (NR + 1) * (KR + 1);
         for (int n = 0; n <= NR; ++n) {
           float gsum = 0.0f;
           for (int kk = 0; kk <= KR; ++kk)
@@ -1627,7 +1676,13 @@ NEPMI_HD void win_force_words(
 // wavefront instruction against ~13-16 for a random ds_read_b128 (profiles/r3b_gather_rate.txt), and the texture-address unit
 // is busy for 75 % of the kernel (profiles/r3b_pmc_ta1.csv).  records + rows fill the LDS of a CU (PbTe: 80 B x ~1,700 window
 // atoms), so the workgroup is 1024 threads, L = 4 lanes per atom, one workgroup per CU (the same 16 wavefronts).
-template <class S, int L = 1, bool CW = false, bool ROWS = false> // CW: the compact list arrives as words (Bufs::cword, L = 1)
+// FPJ (static layout, many-type shapes in the one-wide form): the neighbour's half of a pair force is contracted on the fly,
+//   s21 = sum_n Fp_j[n] sum_k c[t_j][t_i][n][k] f'_k(r),
+// from the neighbour's radial Fp row (Bufs::fpr: (n_r+1 -> multiple of 4) floats per atom, 32 MB for a million atoms: the
+// gathers stay in L2 / Infinity Cache) and the coefficient table staged in LDS behind the window -- instead of gathering row
+// t_i of the neighbour's radial table (T k_r' floats per atom: 768 B for the 16-type UNEP-v1, 0.8 GB per million atoms, every
+// row read only ~4 times per step: each gather a line from HBM; r3a: 2.54 ms of a 7.2 ms step).
+template <class S, int L = 1, bool CW = false, bool ROWS = false, bool FPJ = false> // CW: compact list as words (Bufs::cword, L = 1)
 struct ForceWinBody {
   WinStage st;
   ModelD m;
@@ -1661,10 +1716,12 @@ struct ForceWinBody {
   // 4: <= 128 VGPRs, four 256-thread workgroups per CU.  Shapes with register-resident table rows of 9 or more
   // coefficients (carbon: 11) spill 60-90 bytes per lane there; three wavefronts (<= 168 VGPRs) keep them in registers
   // (carbon 1 M atoms: 1.09 -> 0.97 ms)
-  static constexpr int kMinWavesPerEu = L != 1 ? 1 : ((S::TS > 0 && S::KR >= 8) ? 3 : NEPMI_FW_WAVES);
+  // (FPJ: window + coefficient table leave room for two workgroups per CU = two wavefronts per SIMD anyway)
+  static constexpr int kMinWavesPerEu = L != 1 ? 1 : (FPJ ? 2 : ((S::TS > 0 && S::KR >= 8) ? 3 : NEPMI_FW_WAVES));
   static constexpr int kLanes = L;
 
-  NEPMI_HD int lds_bytes() const { return ROWS ? rows_offset() + rows_bytes() : st.lay.bytes(); }
+  NEPMI_HD int ctab_floats() const { return FPJ ? m.T * m.T * ctab_block(m.NR, m.KR) : 0; }
+  NEPMI_HD int lds_bytes() const { return ROWS ? rows_offset() + rows_bytes() : (FPJ ? rows_offset() + 4 * ctab_floats() : st.lay.bytes()); }
   template <class LC>
   NEPMI_HD void stage_lists(int64_t, LC, int, int) const {}
   NEPMI_HD int64_t map_brick(int64_t w) const { return w; }
@@ -1674,7 +1731,12 @@ struct ForceWinBody {
   template <class LC>
   NEPMI_HD void stage_copy(int64_t brick, LC lds, int tid, int nth) const { st.stage_copy(brick, lds, tid, nth); }
   template <class LC>
-  NEPMI_HD void stage(int64_t brick, LC lds, int tid, int nth) const { st.stage_direct(brick, lds, tid, nth); } // static layout
+  NEPMI_HD void stage(int64_t brick, LC lds, int tid, int nth) const // static layout
+  {
+    st.stage_direct(brick, lds, tid, nth);
+    if (FPJ)
+      ctab_stage_padded(m, lds + rows_offset(), tid, nth);
+  }
   NEPMI_HD void brick_range(int64_t brick, int64_t& a0, int64_t& a1) const { st.brick_range(brick, a0, a1); }
 
   template <class LC>
@@ -1758,19 +1820,36 @@ struct ForceWinBody {
     } else {
       // one-wide form: the neighbour-type row of the own table is gathered per pair (many types / run-time shape)
       constexpr int G = 2;
+      const int NRr = S::fixed ? S::NR : m.NR;
+      NEPMI_LDS(const float)* ctl = (NEPMI_LDS(const float)*)(lds + rows_offset());
+      const int cblk = ctab_block(NRr, KR);
+      float Fpi[S::NRM + 1]; // FPJ: the own radial Fp row (the own half of a pair is contracted on the fly as well)
+#pragma unroll
+      for (int n = 0; n <= S::NRM; ++n)
+        Fpi[n] = (FPJ && (S::fixed || n <= NRr)) ? b.fpr[(size_t)k * b.FPR + n] : 0.0f;
       auto chunk = [&](const unsigned* cur, const int s0) __attribute__((always_inline)) {
         WinRec rr[G];
-        float Aj[G][S::KRM + 1];
+        float Aj[G][FPJ ? S::NRM + 1 : S::KRM + 1]; // FPJ: the neighbour's radial Fp row, else row t1 of its radial table
 #pragma unroll
         for (int u = 0; u < G; ++u) {
           rr[u] = wrec[cur[u]];
           const int j = (int)((unsigned)rr[u].w & (unsigned)kIdxMask);
-          const float* row = atab + (size_t)j * arow + t1 * KRP;
+          if (FPJ) {
+            const float* row = b.fpr + (size_t)j * b.FPR;
 #pragma unroll
-          for (int kk = 0; kk <= S::KRM; ++kk) {
-            if (!S::fixed && kk > KR)
-              break;
-            Aj[u][kk] = row[kk];
+            for (int n = 0; n <= S::NRM; ++n) {
+              if (!S::fixed && n > NRr)
+                break;
+              Aj[u][n] = row[n];
+            }
+          } else {
+            const float* row = atab + (size_t)j * arow + t1 * KRP;
+#pragma unroll
+            for (int kk = 0; kk <= S::KRM; ++kk) {
+              if (!S::fixed && kk > KR)
+                break;
+              Aj[u][kk] = row[kk];
+            }
           }
         }
 #pragma unroll
@@ -1793,14 +1872,33 @@ struct ForceWinBody {
           else
             basis_fn_fnp_rt(KR, rcinv, dc, fc, fcp, fn, fnp);
           float s12 = 0.0f, s21 = 0.0f;
-          const float* Ai = atab + (size_t)k * arow + t2 * KRP;
-          for (int kk = 0; kk <= KR; ++kk)
-            s12 = fmaf(fnp[kk], Ai[kk], s12);
+          if (FPJ) {
+            // s12 = sum_n Fp_i[n] sum_k c[t1][t2][n][k] f'_k,  s21 = sum_n Fp_j[n] sum_k c[t2][t1][n][k] f'_k
+            float g12[S::NRM + 1], g21[S::NRM + 1];
+#ifndef NEPMI_CT_VEC_FORCE
+#define NEPMI_CT_VEC_FORCE 1
+#endif
+            ctab_contract<S, NEPMI_CT_VEC_FORCE != 0>(ctl + (t1 * m.T + t2) * cblk, NRr, KR, fnp, g12);
+            ctab_contract<S, NEPMI_CT_VEC_FORCE != 0>(ctl + (t2 * m.T + t1) * cblk, NRr, KR, fnp, g21);
 #pragma unroll
-          for (int kk = 0; kk <= S::KRM; ++kk) {
-            if (!S::fixed && kk > KR)
-              break;
-            s21 = fmaf(fnp[kk], Aj[u][kk], s21);
+            for (int n = 0; n <= S::NRM; ++n) {
+              if (!S::fixed && n > NRr)
+                break;
+              s12 = fmaf(Fpi[n], g12[n], s12);
+              s21 = fmaf(Aj[u][n], g21[n], s21);
+            }
+          } else {
+            const float* Ai = atab + (size_t)k * arow + t2 * KRP;
+            for (int kk = 0; kk <= KR; ++kk)
+              s12 = fmaf(fnp[kk], Ai[kk], s12);
+          }
+          if (!FPJ) {
+#pragma unroll
+            for (int kk = 0; kk <= S::KRM; ++kk) {
+              if (!S::fixed && kk > KR)
+                break;
+              s21 = fmaf(fnp[kk], Aj[u][kk], s21);
+            }
           }
           const float wgt = live ? dinv : 0.0f;
           const float fs = (s12 + s21) * wgt;

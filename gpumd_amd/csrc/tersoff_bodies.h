@@ -75,13 +75,185 @@ struct TersoffBufs {
   double* bp;   // [MN_ang][N] its derivative
   D4* f12;      // [MN_ang][N] partial forces
   double* pe_d; // [N]
+  unsigned long long* mask; // [N] membership bits of the Verlet slots (lists of at most 64 entries), written by the partial kernel
 };
+
+// Members of the local list per lane kept in LDS by the fast path of TersoffPartialBody: x, y, z, type, b, b' as doubles,
+// element e of member m of lane l at [(m * 6 + e) * 64 + l] (consecutive lanes, consecutive doubles: conflict-free)
+constexpr int kTersoffLocalMax = 8;
+constexpr int kTersoffBlock = 64;
+constexpr int kTersoffLdsDoubles = kTersoffLocalMax * 6 * kTersoffBlock;
 
 struct TersoffPartialBody {
   BoxD box;
   TersoffParamsD tp;
   Bufs b;
   TersoffBufs tb;
+  static constexpr int kMinWavesPerEu = 1;
+  NEPMI_HD int lds_floats() const { return 2 * kTersoffLdsDoubles; }
+  template <class LP>
+  NEPMI_HD void lds_stage(LP, int, int) const {}
+
+  // Fast path (13,824 silicon atoms are 54 atoms per CU: the kernel's run time is the latency of ONE wavefront, and the
+  // plain form below walks its bonded neighbours through global memory: record written, read back 2 (n - 1) times, bond order
+  // written and read back -- some forty dependent round trips per atom).  With at most kTersoffLocalMax members of the local
+  // list (silicon: 4) the members' geometry and bond orders live in LDS: the loops below are the same arithmetic in the
+  // same order -- bit-identical results -- with LDS latencies instead of HBM ones.
+  template <class LP>
+  NEPMI_HD void run(int64_t k, LP lds_f) const
+  {
+    const int64_t N = b.N;
+    if (b.lvl[k] < 1)
+      return;
+    const PosQ p1 = b.posq[k];
+    const int t1 = p1.type;
+    const TersoffSetD& s1 = tp.p[t1];
+    const int nn = b.nn_ang[k];
+    // pass A: membership of every Verlet entry (float geometry), records of the members only in full
+    int cnt = 0;
+    unsigned long long inr = 0ull;
+    // (eight entries per round: the index loads of a round, then its position gathers, are in flight together -- this loop
+    // of ~20 dependent load pairs was most of the kernel's 36 us at 54 atoms per CU)
+    constexpr int RB = 8;
+    for (int s0 = 0; s0 < nn && s0 < 64; s0 += RB) {
+      int jj[RB];
+#pragma unroll
+      for (int u = 0; u < RB; ++u)
+        jj[u] = b.nl_ang[(int64_t)(s0 + u < nn ? s0 + u : nn - 1) * N + k];
+      PosQ pp[RB];
+#pragma unroll
+      for (int u = 0; u < RB; ++u)
+        pp[u] = b.posq[jj[u]];
+#pragma unroll
+      for (int u = 0; u < RB; ++u) {
+        float xf, yf, zf;
+        const float d2f = pair_geometry(box, p1, pp[u], xf, yf, zf);
+        if (s0 + u < nn && s0 + u < 64 && d2f < tp.rc_sq) {
+          inr |= 1ull << (s0 + u);
+          ++cnt;
+        }
+      }
+    }
+    if (nn > 64 || cnt > kTersoffLocalMax) { // long lists: the plain form
+      (*this)(k);
+      return;
+    }
+    tb.mask[k] = inr;
+    double* L = const_cast<double*>(reinterpret_cast<const double*>(&lds_f[0])) + (int)(k % kTersoffBlock);
+    auto at = [&](int m, int e) -> double& { return L[(m * 6 + e) * kTersoffBlock]; };
+    {
+      // the members' records (FP64 difference + FP64 minimum image): all their positions are requested before the first is used
+      int ms[kTersoffLocalMax];
+      PosQ mp[kTersoffLocalMax];
+      unsigned long long rest = inr;
+#pragma unroll
+      for (int m = 0; m < kTersoffLocalMax; ++m) {
+        ms[m] = rest ? (int)__builtin_ctzll(rest) : 0;
+        rest &= rest - 1ull;
+      }
+#pragma unroll
+      for (int m = 0; m < kTersoffLocalMax; ++m)
+        if (m < cnt)
+          mp[m] = b.posq[b.nl_ang[(int64_t)ms[m] * N + k]];
+#pragma unroll
+      for (int m = 0; m < kTersoffLocalMax; ++m) {
+        if (m < cnt) {
+          D4 r;
+          r.x = mp[m].x - p1.x;
+          r.y = mp[m].y - p1.y;
+          r.z = mp[m].z - p1.z;
+          mic_d(box, r.x, r.y, r.z);
+          r.w = 1 | ((long long)mp[m].type << 8);
+          at(m, 0) = r.x;
+          at(m, 1) = r.y;
+          at(m, 2) = r.z;
+          at(m, 3) = (double)mp[m].type;
+          tb.rec[(int64_t)ms[m] * N + k] = r;
+        }
+      }
+      // (non-members: the force kernel and the list export read the membership bits, not their records)
+    }
+    b.nn_rad[k] = cnt;
+    b.nn_angstep[k] = cnt;
+    // step 1: bond order
+    for (int i1 = 0; i1 < cnt; ++i1) {
+      const double x12 = at(i1, 0), y12 = at(i1, 1), z12 = at(i1, 2);
+      const double d12 = sqrt(x12 * x12 + y12 * y12 + z12 * z12);
+      double zeta = 0.0;
+      for (int i2 = 0; i2 < cnt; ++i2) {
+        if (i2 == i1)
+          continue;
+        const double x13 = at(i2, 0), y13 = at(i2, 1), z13 = at(i2, 2);
+        const int t3 = (int)at(i2, 3);
+        const double d13 = sqrt(x13 * x13 + y13 * y13 + z13 * z13);
+        const double c123 = (x12 * x13 + y12 * y13 + z12 * z13) / (d12 * d13);
+        double fc13, fcp13;
+        ters_fc(ters_pair(tp, t1, t3), d13, fc13, fcp13);
+        const double tmp = s1.d2 + (c123 - s1.h) * (c123 - s1.h);
+        zeta += fc13 * (s1.one_plus_c2overd2 - s1.c2 / tmp);
+      }
+      const double bzn = pow(s1.beta * zeta, s1.n);
+      const double b12 = pow(1.0 + bzn, s1.minus_half_over_n);
+      if (zeta < 1.0e-16) { // avoid division by 0
+        at(i1, 4) = 1.0;
+        at(i1, 5) = 0.0;
+      } else {
+        at(i1, 4) = b12;
+        at(i1, 5) = -b12 * bzn * 0.5 / ((1.0 + bzn) * zeta);
+      }
+    }
+    // step 2: partial forces and energy; member m sits at Verlet slot = position of the m-th set bit
+    double u = 0.0;
+    unsigned long long rest = inr;
+    for (int i1 = 0; i1 < cnt; ++i1) {
+      const int slot = (int)__builtin_ctzll(rest);
+      rest &= rest - 1ull;
+      const double x12 = at(i1, 0), y12 = at(i1, 1), z12 = at(i1, 2);
+      const int t2 = (int)at(i1, 3);
+      const TersoffSetD& p12 = ters_pair(tp, t1, t2);
+      const double d12 = sqrt(x12 * x12 + y12 * y12 + z12 * z12);
+      const double d12inv = 1.0 / d12;
+      double fc12, fcp12;
+      ters_fc(p12, d12, fc12, fcp12);
+      const double fa12 = p12.b * exp(-p12.mu * d12), fap12 = -p12.mu * fa12;
+      const double fr12 = p12.a * exp(-p12.lambda * d12), frp12 = -p12.lambda * fr12;
+      const double b12 = at(i1, 4), bp12 = at(i1, 5);
+      const double factor3 = (fcp12 * (fr12 - b12 * fa12) + fc12 * (frp12 - b12 * fap12)) * d12inv;
+      double fx = x12 * factor3 * 0.5, fy = y12 * factor3 * 0.5, fz = z12 * factor3 * 0.5;
+      u += fc12 * (fr12 - b12 * fa12) * 0.5;
+      for (int i2 = 0; i2 < cnt; ++i2) {
+        if (i2 == i1)
+          continue;
+        const double x13 = at(i2, 0), y13 = at(i2, 1), z13 = at(i2, 2);
+        const int t3 = (int)at(i2, 3);
+        const TersoffSetD& p13 = ters_pair(tp, t1, t3);
+        const double d13 = sqrt(x13 * x13 + y13 * y13 + z13 * z13);
+        double fc13, fcp13;
+        ters_fc(p13, d13, fc13, fcp13);
+        const double fa13 = p13.b * exp(-p13.mu * d13);
+        const double bp13 = at(i2, 5);
+        const double od = 1.0 / (d12 * d13);
+        const double c123 = (x12 * x13 + y12 * y13 + z12 * z13) * od;
+        const double c_over = c123 * d12inv * d12inv;
+        const double tmp = s1.d2 + (c123 - s1.h) * (c123 - s1.h);
+        const double g123 = s1.one_plus_c2overd2 - s1.c2 / tmp;
+        const double gp123 = 2.0 * s1.c2 * (c123 - s1.h) / (tmp * tmp);
+        const double ta = (-bp12 * fc12 * fa12 * fc13 - bp13 * fc13 * fa13 * fc12) * gp123;
+        const double tbb = -bp13 * fc13 * fa13 * fcp12 * g123 * d12inv;
+        fx += (x12 * tbb + ta * (x13 * od - x12 * c_over)) * 0.5;
+        fy += (y12 * tbb + ta * (y13 * od - y12 * c_over)) * 0.5;
+        fz += (z12 * tbb + ta * (z13 * od - z12 * c_over)) * 0.5;
+      }
+      D4 out;
+      out.x = fx;
+      out.y = fy;
+      out.z = fz;
+      out.w = 0;
+      tb.f12[(int64_t)slot * N + k] = out;
+    }
+    tb.pe_d[k] = u;
+  }
+
   NEPMI_HD void operator()(int64_t k) const
   {
     const int64_t N = b.N;
@@ -123,6 +295,7 @@ struct TersoffPartialBody {
     };
     b.nn_rad[k] = cnt;
     b.nn_angstep[k] = cnt;
+    tb.mask[k] = inr; // (meaningful for lists of at most 64 entries: the readers check nn)
     // step 1: bond order
     for (int i1 = next_slot(0); i1 < nn; i1 = next_slot(i1 + 1)) {
       const D4 r12 = tb.rec[(int64_t)i1 * N + k];
@@ -219,7 +392,52 @@ struct TersoffAssembleBody {
       return;
     double F[3] = {0, 0, 0}, W[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     const int nn = b.nn_ang[k];
-    for (int s = 0; s < nn; ++s) {
+    if (nn <= 64) {
+      // the members straight from the membership bits, four at a time with their loads in flight together, in slot order
+      // (the same order of additions as the scan below)
+      unsigned long long rest = tb.mask[k];
+      while (rest) {
+        constexpr int MB = 4;
+        int sl[MB];
+        bool on[MB];
+#pragma unroll
+        for (int u = 0; u < MB; ++u) {
+          on[u] = rest != 0ull;
+          sl[u] = on[u] ? (int)__builtin_ctzll(rest) : 0;
+          rest &= rest - 1ull;
+        }
+        D4 r[MB], fa[MB], fb[MB];
+        int jj[MB], rs[MB];
+#pragma unroll
+        for (int u = 0; u < MB; ++u) {
+          r[u] = tb.rec[(int64_t)sl[u] * N + k];
+          jj[u] = b.nl_ang[(int64_t)sl[u] * N + k];
+          rs[u] = b.rev_ang[(int64_t)sl[u] * N + k];
+          fa[u] = tb.f12[(int64_t)sl[u] * N + k];
+        }
+#pragma unroll
+        for (int u = 0; u < MB; ++u)
+          fb[u] = tb.f12[(int64_t)rs[u] * N + jj[u]];
+#pragma unroll
+        for (int u = 0; u < MB; ++u) {
+          if (!on[u])
+            continue;
+          F[0] += fa[u].x - fb[u].x;
+          F[1] += fa[u].y - fb[u].y;
+          F[2] += fa[u].z - fb[u].z;
+          W[0] += r[u].x * fb[u].x;
+          W[1] += r[u].y * fb[u].y;
+          W[2] += r[u].z * fb[u].z;
+          W[3] += r[u].x * fb[u].y;
+          W[4] += r[u].x * fb[u].z;
+          W[5] += r[u].y * fb[u].z;
+          W[6] += r[u].y * fb[u].x;
+          W[7] += r[u].z * fb[u].x;
+          W[8] += r[u].z * fb[u].y;
+        }
+      }
+    }
+    for (int s = 0; s < (nn <= 64 ? 0 : nn); ++s) {
       const D4 r = tb.rec[(int64_t)s * N + k];
       if (!(r.w & 1))
         continue;
@@ -263,8 +481,10 @@ struct TersoffExportBody {
     const int64_t N = b.N;
     const int64_t i = b.perm[k];
     int cnt = 0;
+    const bool by_mask = b.nn_ang[k] <= 64;
+    const unsigned long long mk = tb.mask[k];
     for (int s = 0; s < b.nn_ang[k]; ++s) {
-      if (!(tb.rec[(int64_t)s * N + k].w & 1))
+      if (by_mask ? !((mk >> s) & 1ull) : !(tb.rec[(int64_t)s * N + k].w & 1))
         continue;
       const int jc = b.perm[b.nl_ang[(int64_t)s * N + k]];
       if (cnt < ld) {

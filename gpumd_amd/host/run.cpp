@@ -10,6 +10,20 @@
 
 namespace gmi {
 
+// is_valid_real (src/utilities/read_file.cu): the whole token must be one floating-point number
+static bool is_valid_real(const std::string& tok, double* result)
+{
+  if (tok.empty())
+    return false;
+  char* end = nullptr;
+  errno = 0;
+  const double v = std::strtod(tok.c_str(), &end);
+  if (errno != 0 || end == tok.c_str() || *end != 0)
+    return false;
+  *result = v;
+  return true;
+}
+
 // is_valid_int (src/utilities/read_file.cu:26-41): the whole token must be one integer (any strtol base)
 static bool is_valid_int(const std::string& tok, int* result)
 {
@@ -326,6 +340,30 @@ void Run::parse_one_keyword(const std::vector<std::string>& p)
                   "%d steps.\n", o.interval_thermo, o.interval_exyz);
     o.active = true;
     observer = o;
+  } else if (k == "active") { // Active::parse, active.cu:117-169
+    std::printf("Active learning.\n");
+    if (p.size() != 6)
+      input_error("active should have 5 parameters.");
+    ActiveLearning a;
+    if (!is_valid_int(p[1], &a.interval))
+      input_error("check interval should be an integer.");
+    if (a.interval <= 0)
+      input_error("check interval should > 0.");
+    std::printf("    check uncertainty every %d steps.\n", a.interval);
+    if (!is_valid_int(p[2], &a.has_velocity))
+      input_error("has_velocity should be an integer.");
+    std::printf(a.has_velocity ? "    with velocity data.\n" : "    without velocity data.\n");
+    if (!is_valid_int(p[3], &a.has_force))
+      input_error("has_force should be an integer.");
+    std::printf(a.has_force ? "    with force data.\n" : "    without force data.\n");
+    if (!is_valid_int(p[4], &a.has_uncertainty))
+      input_error("has_uncertainty should be an integer.");
+    std::printf(a.has_uncertainty ? "    with per-atom uncertainty data.\n" : "    without per-atom uncertainty data.\n");
+    if (!is_valid_real(p[5], &a.threshold))
+      input_error("threshold should be a real number.\n");
+    std::printf("    will check if uncertainties exceed %f every %d iterations.\n", a.threshold, a.interval);
+    a.active = true;
+    active_ = a;
   } else if (k == "run") {
     if (p.size() != 2)
       input_error("run should have 1 parameter.");
@@ -341,6 +379,7 @@ void Run::parse_one_keyword(const std::vector<std::string>& p)
     dump_restart_interval = 0;
     dump_xyzs.clear();
     observer.active = false;
+    active_.active = false;
   } else {
     input_error("'" + k + "' is invalid keyword (or outside the path gpumd-mi covers).");
   }
@@ -562,6 +601,107 @@ void Run::dump_observer_write(int step, int file_index)
   }
 }
 
+// Active::preprocess (active.cu:171-199): always "observe" -- the run follows the first potential, the others are only
+// evaluated at the check steps
+void Run::active_open()
+{
+  if (!active_.active)
+    return;
+  force.set_multiple_potentials_mode("observe");
+  active_.exyz_file = std::fopen("active.xyz", "a");
+  active_.out_file = std::fopen("active.out", "a");
+  if (!active_.exyz_file || !active_.out_file)
+    input_error("Cannot open the active learning files.");
+}
+
+// Active::process (active.cu:201-289): every potential on the current coordinates, the main one last; per atom and
+// Cartesian direction the mean and the mean square of the M forces (each term divided by M before it is added, as the
+// reference's compute_mean does), uncertainty_i = sqrt(sum_d (<f_d^2> - <f_d>^2)), sigma_f = max_i; time and sigma_f go to
+// active.out, the structure to active.xyz when sigma_f exceeds the threshold (write_exyz / output_line2, active.cu:305-445)
+void Run::active_process(int step)
+{
+  if (!active_.active || (step + 1) % active_.interval != 0)
+    return;
+  const int N = atom.number_of_atoms;
+  const int M = (int)force.potentials.size();
+  std::vector<double> mean(3 * (size_t)N, 0.0), mean_sq(3 * (size_t)N, 0.0), f(3 * (size_t)N), unc((size_t)N);
+  for (int k = M - 1; k >= 0; --k) {
+    if (nepmi_zero_properties(force.engine(), N, atom.potential_per_atom.data(), atom.force_per_atom.data(),
+                              atom.virial_per_atom.data()) != NEPMI_OK)
+      input_error(nepmi_last_error());
+    force.potentials[k]->compute(box, atom.type, atom.position_per_atom, atom.potential_per_atom, atom.force_per_atom,
+                                 atom.virial_per_atom);
+    atom.force_per_atom.copy_to_host(f.data());
+    for (size_t i = 0; i < 3 * (size_t)N; ++i) {
+      mean[i] += f[i] / M;
+      mean_sq[i] += f[i] * f[i] / M;
+    }
+  }
+  double uncertainty = -1.0;
+  for (int n = 0; n < N; ++n) {
+    double var = 0.0;
+    for (int d = 0; d < 3; ++d) {
+      const size_t i = (size_t)d * N + n;
+      var += mean_sq[i] - mean[i] * mean[i];
+    }
+    unc[n] = std::sqrt(var);
+    if (uncertainty < unc[n])
+      uncertainty = unc[n];
+  }
+  std::fprintf(active_.out_file, "%20.10e%20.10e\n", global_time * TIME_UNIT_CONVERSION, uncertainty);
+  std::fflush(active_.out_file);
+  if (!(uncertainty > active_.threshold))
+    return;
+  // the arrays hold the main potential's values again (it was evaluated last)
+  find_thermo();
+  double t[8];
+  thermo.copy_to_host(t, 8);
+  const double* h = box.cpu_h;
+  FILE* fid = active_.exyz_file;
+  std::vector<double> pos(3 * (size_t)N), vel, vir(9 * (size_t)N);
+  atom.position_per_atom.copy_to_host(pos.data());
+  atom.virial_per_atom.copy_to_host(vir.data());
+  if (active_.has_velocity) { vel.resize(3 * (size_t)N); atom.velocity_per_atom.copy_to_host(vel.data()); }
+  double tv[6] = {0, 0, 0, 0, 0, 0};
+  for (int c = 0; c < 6; ++c)
+    for (int n = 0; n < N; ++n)
+      tv[c] += vir[(size_t)c * N + n];
+  std::fprintf(fid, "%d\n", N);
+  std::fprintf(fid, "Time=%.8f", global_time * TIME_UNIT_CONVERSION);
+  std::fprintf(fid, " pbc=\"%c %c %c\"", box.pbc_x ? 'T' : 'F', box.pbc_y ? 'T' : 'F', box.pbc_z ? 'T' : 'F');
+  std::fprintf(fid, " uncertainty=%.8f", uncertainty);
+  std::fprintf(fid, " Lattice=\"%.8f %.8f %.8f %.8f %.8f %.8f %.8f %.8f %.8f\"", h[0], h[3], h[6], h[1], h[4], h[7], h[2], h[5],
+               h[8]);
+  std::fprintf(fid, " energy=%.8f", t[1]);
+  std::fprintf(fid, " virial=\"%.8f %.8f %.8f %.8f %.8f %.8f %.8f %.8f %.8f\"", tv[0], tv[3], tv[4], tv[3], tv[1], tv[5], tv[4],
+               tv[5], tv[2]);
+  std::fprintf(fid, " stress=\"%.8f %.8f %.8f %.8f %.8f %.8f %.8f %.8f %.8f\"", t[2], t[5], t[6], t[5], t[3], t[7], t[6], t[7],
+               t[4]);
+  std::fprintf(fid, " Properties=species:S:1:pos:R:3");
+  if (active_.has_velocity) std::fprintf(fid, ":vel:R:3");
+  if (active_.has_force) std::fprintf(fid, ":forces:R:3");
+  if (active_.has_uncertainty) std::fprintf(fid, ":uncertainty:R:1");
+  std::fprintf(fid, "\n");
+  for (int n = 0; n < N; ++n) {
+    std::fprintf(fid, "%s", atom.cpu_atom_symbol[n].c_str());
+    for (int c = 0; c < 3; ++c) std::fprintf(fid, " %.8f", pos[n + (size_t)N * c]);
+    if (active_.has_velocity)
+      for (int c = 0; c < 3; ++c) std::fprintf(fid, " %.8f", vel[n + (size_t)N * c] * (1.0 / TIME_UNIT_CONVERSION));
+    if (active_.has_force)
+      for (int c = 0; c < 3; ++c) std::fprintf(fid, " %.8f", f[n + (size_t)N * c]); // (the main potential's: evaluated last)
+    if (active_.has_uncertainty) std::fprintf(fid, " %.8f", unc[n]);
+    std::fprintf(fid, "\n");
+  }
+  std::fflush(fid);
+}
+
+void Run::active_close()
+{
+  if (active_.exyz_file) std::fclose(active_.exyz_file);
+  if (active_.out_file) std::fclose(active_.out_file);
+  active_.exyz_file = active_.out_file = nullptr;
+}
+
 void Run::dump_observer_close()
 {
   for (FILE* f : observer.exyz_files) std::fclose(f);
@@ -720,6 +860,7 @@ void Run::perform_a_run()
     std::fclose(fid);
   }
   dump_observer_open(); // measure.initialize precedes the first force call (run.cu:215)
+  active_open();
   // target temperature of a temperature-dependent NEP (Run::parse_run, run.cu:679-681)
   // (integrate.temperature1/2 keep the values of the last ensemble that had them; an NVE-only input leaves them
   // uninitialised in the reference -- here they start at 300 K)
@@ -765,6 +906,8 @@ void Run::perform_a_run()
       upto(observer.interval_thermo);
       upto(observer.interval_exyz);
     }
+    if (active_.active)
+      upto(active_.interval);
     if (number_of_steps >= 10)
       upto(number_of_steps / 10); // progress lines
     if (correct_interval_ > 0) { // the correction precedes the steps 0, k, 2k, ...: a segment ends right before them
@@ -788,11 +931,13 @@ void Run::perform_a_run()
       dump_xyz(d, step);
     dump_restart(step);
     dump_observer_process(step);
+    active_process(step);
     if (number_of_steps >= 10 && (step + 1) % (number_of_steps / 10) == 0)
       std::printf("    %d steps completed.\n", step + 1);
   }
   hip_check(hipDeviceSynchronize(), "sync");
   dump_observer_close();
+  active_close();
   const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   std::printf("Time used for this run = %g second.\n", sec);
   std::printf("Speed of this run = %g atom*step/second.\n", (double)N * number_of_steps / sec); // run.cu:325-326
@@ -913,6 +1058,8 @@ void Run::perform_a_run_dist()
     dist_setup_atoms();
   if (observer.active)
     input_error("dump_observer is not available in multi-GPU runs.");
+  if (active_.active)
+    input_error("active is not available in multi-GPU runs.");
   if (correct_interval_ > 0)
     input_error("correct_velocity is not available in multi-GPU runs.");
   for (const auto& d : dump_xyzs)

@@ -26,6 +26,16 @@ struct DumpObserver {
   std::vector<FILE*> exyz_files, thermo_files; // observer<i>.xyz / observer<i>.out (no index when there is one)
 };
 
+// Active (src/measure/active.cuh): `active <interval> <has_velocity> <has_force> <has_uncertainty> <threshold>` -- committee
+// uncertainty over the `potential` lines of run.in, the run itself follows the first one
+struct ActiveLearning {
+  bool active = false;
+  int interval = 1, has_velocity = 0, has_force = 0, has_uncertainty = 0;
+  double threshold = 0.0;
+  FILE* exyz_file = nullptr; // active.xyz
+  FILE* out_file = nullptr;  // active.out
+};
+
 // One process per GPU (torchrun / mpirun style launch: RANK, WORLD_SIZE, LOCAL_RANK, MASTER_ADDR, MASTER_PORT or
 // OMPI_COMM_WORLD_*): the run is domain-decomposed by libnepmi's nepmi_dist_* driver (RCCL over xGMI when every
 // rank has its own GPU, TCP sockets otherwise); rank 0 writes the output files.
@@ -59,6 +69,9 @@ private:
   void dump_observer_process(int step);
   void dump_observer_write(int step, int file_index);
   void dump_observer_close();
+  void active_open();
+  void active_process(int step);
+  void active_close();
 
   bool check_only_;
   Parallel par_;
@@ -86,6 +99,7 @@ private:
   int dump_restart_interval = 0;
   std::vector<DumpXyz> dump_xyzs;
   DumpObserver observer;
+  ActiveLearning active_;
   GPU_Vector<double> thermo; // 8 doubles
   std::vector<std::string> elements;
   std::string potential_file;

@@ -1,0 +1,19 @@
+# round 3, seventh GPU call: UNEP with both pair halves from Fp rows + padded LDS blocks; Tersoff with the local list in LDS
+set -x
+cd /root/repo
+run() { # name, bench args
+  name=$1; shift
+  timeout 200 python bench.py --no-cpu-baseline "$@" > gpurun_out/r3g_$name.json 2> gpurun_out/r3g_$name.err
+  python - gpurun_out/r3g_$name.json $name <<'PY'
+import json,sys
+try:
+    d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    print("%-16s ms/step %.5f value %.4g"%(sys.argv[2], d["ms_per_step"], d["value"]), {k[:12]:round(v["avg_ms"],4) for k,v in d["kernels"].items() if k!="list_rebuild"})
+except Exception as e:
+    print(sys.argv[2], "ERR", e)
+PY
+}
+(timeout 500 python -m pytest tests/test_gpu_parity.py tests/test_full_size_parity.py tests/test_ref_md_parity.py tests/test_tersoff.py tests/test_dist.py -m gpu -q -x -k "window_layouts or UNEP or unep or tersoff or Tersoff") > gpurun_out/r3g_pytest.log 2>&1; grep -E "passed|failed|Error" gpurun_out/r3g_pytest.log | tail -5
+run unep --workload unep --steps 20 --warmup 5
+run si --workload si_tersoff --steps 2000 --warmup 200
+run si884k --workload si_tersoff --reps 64 64 64 --steps 100 --warmup 10

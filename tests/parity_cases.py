@@ -26,6 +26,8 @@ MODELS = {
     "C-2022": ("C/nep.txt", lambda: H.diamond((6, 6, 7), 3.57), 1),
     "C-nep3": ("C/nep3.txt", lambda: H.diamond((6, 7, 6), 3.57, seed=10), 1),
     "UNEP-v1": ("UNEP/nep.txt", lambda: H.fcc_alloy((5, 5, 6), 3.9, 16), 16),
+    # large enough for the LDS-window kernels (13 cells per direction): many-type force assembly from the neighbours' Fp rows
+    "UNEP-v1-big": ("UNEP/nep.txt", lambda: H.fcc_alloy((12, 12, 12), 3.9, 16, seed=8), 16),
     "BaZrO3": ("BaZrO3/nep.txt", lambda: H.pbte_supercell((2, 2, 2), num_types=3, seed=4), 3),
     "water-model": ("water/nep.txt", lambda: H.pbte_supercell((2, 2, 2), num_types=2, seed=5), 2),
     # the other shipped potentials/nep models: 3-/4-/5-body silicon, long-range carbon (rc 7/4, 16 radial basis)
