@@ -465,6 +465,10 @@ def run_decomposed(args, world, rank, dev, model, label, h_block, typ, x, mass, 
             "step_hbm_frac": b_step * (total * args.steps / elapsed) / (HBM_PEAK_GBS * 1e9 * world),
             "kernels": kern, "thermo_last": [float(v) for v in th],
         }
+        free_b, total_b = torch.cuda.mem_get_info(dev)
+        out["device_memory"] = {"used_gb_rank0": (total_b - free_b) / 1e9, "total_gb": total_b / 1e9,
+                                "note": "hipMemGetInfo after the run on rank 0: engine + decomposition buffers + the PyTorch context"}
+        out["config"]["kernel_forms"] = md.engine_describe()
         print(json.dumps(out))
     md.close()
     tr.close()

@@ -47,17 +47,32 @@ struct WinLayout {
   NEPMI_HD int bytes() const { return off_rec() + 16 * (wmax + (compact ? 1 : 0)); }
 };
 
+#ifndef NEPMI_CT_VEC_FORCE
+#define NEPMI_CT_VEC_FORCE 0 // 1: the force assembly (FPJ form) reads its coefficient blocks with 16-byte ds_reads (block stride 52 floats for
+                             // UNEP-v1: 53 KB, which no longer leaves room for two workgroups per CU next to a 30 KB window); 0: element-wise, odd stride
+#endif
 // Radial coefficient table of many-type shapes in LDS (static layout): one block of (n_r+1)(k_r+1) floats per ordered type
 // pair, padded to a multiple of four so that a lane reads its pair's block with 16-byte ds_reads (12 instead of 45 for UNEP-v1)
 struct alignas(16) F4f {
   float x, y, z, w;
 };
-NEPMI_HD int ctab_block(int NR, int KR) { return ((NR + 1) * (KR + 1) + 3) / 4 * 4; }
+// Block stride in floats.  Lanes read the SAME element of DIFFERENT blocks at the same time, so the stride decides the bank
+// conflicts: element-wise reads want an odd stride (every block starts on another bank); 16-byte reads want a multiple of four
+// floats whose quarter is odd (16 lanes x 4 banks tile the 64 banks).  A stride of 48 floats -- the plain round-up of UNEP-v1's
+// 45 -- puts every block on one of four bank offsets: r3g measured the radial pass at 2.15 ms against 1.13 ms with stride 45.
+NEPMI_HD int ctab_block(int NR, int KR, bool vec)
+{
+  const int raw = (NR + 1) * (KR + 1);
+  if (!vec)
+    return raw | 1;
+  const int b4 = (raw + 3) / 4;
+  return 4 * (b4 | 1);
+}
 template <class LC>
-NEPMI_HD void ctab_stage_padded(const ModelD& m, LC dst_bytes, int tid, int nth)
+NEPMI_HD void ctab_stage_padded(const ModelD& m, LC dst_bytes, int tid, int nth, bool vec)
 {
   NEPMI_LDS(float)* ct = (NEPMI_LDS(float)*)dst_bytes;
-  const int raw = (m.NR + 1) * (m.KR + 1), blk = ctab_block(m.NR, m.KR), npair = m.T * m.T;
+  const int raw = (m.NR + 1) * (m.KR + 1), blk = ctab_block(m.NR, m.KR, vec), npair = m.T * m.T;
   for (int i = tid; i < npair * blk; i += nth) {
     const int pr = i / blk, e = i - pr * blk;
     ct[i] = e < raw ? m.c_rad[pr * raw + e] : 0.0f;
@@ -664,7 +679,7 @@ struct RadialWin2Body {
   const int* frozen;
   static constexpr int kMinWavesPerEu = NEPMI_RW2_WAVES;
 
-  NEPMI_HD int ctab_floats() const { return S::TS > 0 ? 0 : m.T * m.T * ctab_block(m.NR, m.KR); }
+  NEPMI_HD int ctab_floats() const { return S::TS > 0 ? 0 : m.T * m.T * ctab_block(m.NR, m.KR, false); }
   NEPMI_HD int ctab_offset() const { return (st.lay.bytes() + 15) / 16 * 16; }
   NEPMI_HD bool ctab_on() const { return NEPMI_RW_CTAB && S::TS == 0 && ctab_offset() + 4 * ctab_floats() <= 80 * 1024; }
   NEPMI_HD int lds_bytes() const { return ctab_on() ? ctab_offset() + 4 * ctab_floats() : st.lay.bytes(); }
@@ -675,7 +690,7 @@ struct RadialWin2Body {
   {
     st.stage_direct(brick, lds, tid, nth);
     if (ctab_on())
-      ctab_stage_padded(m, lds + ctab_offset(), tid, nth);
+      ctab_stage_padded(m, lds + ctab_offset(), tid, nth, false);
   }
   NEPMI_HD void brick_range(int64_t brick, int64_t& a0, int64_t& a1) const { st.brick_range(brick, a0, a1); }
 
@@ -873,7 +888,7 @@ struct RadialWin2Body {
         basis_fn_rt(KR, rcinv, dc, fc, fn);
       if (ctab) {
         float g[S::NRM + 1];
-        ctab_contract<S, false>(ctab_lds + (t1 * m.T + t2) * ctab_block(NR, KR), NR, KR, fn, g);
+        ctab_contract<S, false>(ctab_lds + (t1 * m.T + t2) * ctab_block(NR, KR, false), NR, KR, fn, g);
 #pragma unroll
         for (int n = 0; n <= S::NRM; ++n) {
           if (!S::fixed && n > NR)
@@ -1720,7 +1735,7 @@ struct ForceWinBody {
   static constexpr int kMinWavesPerEu = L != 1 ? 1 : (FPJ ? 2 : ((S::TS > 0 && S::KR >= 8) ? 3 : NEPMI_FW_WAVES));
   static constexpr int kLanes = L;
 
-  NEPMI_HD int ctab_floats() const { return FPJ ? m.T * m.T * ctab_block(m.NR, m.KR) : 0; }
+  NEPMI_HD int ctab_floats() const { return FPJ ? m.T * m.T * ctab_block(m.NR, m.KR, NEPMI_CT_VEC_FORCE != 0) : 0; }
   NEPMI_HD int lds_bytes() const { return ROWS ? rows_offset() + rows_bytes() : (FPJ ? rows_offset() + 4 * ctab_floats() : st.lay.bytes()); }
   template <class LC>
   NEPMI_HD void stage_lists(int64_t, LC, int, int) const {}
@@ -1735,7 +1750,7 @@ struct ForceWinBody {
   {
     st.stage_direct(brick, lds, tid, nth);
     if (FPJ)
-      ctab_stage_padded(m, lds + rows_offset(), tid, nth);
+      ctab_stage_padded(m, lds + rows_offset(), tid, nth, NEPMI_CT_VEC_FORCE != 0);
   }
   NEPMI_HD void brick_range(int64_t brick, int64_t& a0, int64_t& a1) const { st.brick_range(brick, a0, a1); }
 
@@ -1822,7 +1837,7 @@ struct ForceWinBody {
       constexpr int G = 2;
       const int NRr = S::fixed ? S::NR : m.NR;
       NEPMI_LDS(const float)* ctl = (NEPMI_LDS(const float)*)(lds + rows_offset());
-      const int cblk = ctab_block(NRr, KR);
+      const int cblk = ctab_block(NRr, KR, NEPMI_CT_VEC_FORCE != 0);
       float Fpi[S::NRM + 1]; // FPJ: the own radial Fp row (the own half of a pair is contracted on the fly as well)
 #pragma unroll
       for (int n = 0; n <= S::NRM; ++n)
@@ -1875,9 +1890,6 @@ struct ForceWinBody {
           if (FPJ) {
             // s12 = sum_n Fp_i[n] sum_k c[t1][t2][n][k] f'_k,  s21 = sum_n Fp_j[n] sum_k c[t2][t1][n][k] f'_k
             float g12[S::NRM + 1], g21[S::NRM + 1];
-#ifndef NEPMI_CT_VEC_FORCE
-#define NEPMI_CT_VEC_FORCE 1
-#endif
             ctab_contract<S, NEPMI_CT_VEC_FORCE != 0>(ctl + (t1 * m.T + t2) * cblk, NRr, KR, fnp, g12);
             ctab_contract<S, NEPMI_CT_VEC_FORCE != 0>(ctl + (t2 * m.T + t1) * cblk, NRr, KR, fnp, g21);
 #pragma unroll

@@ -78,11 +78,26 @@ struct TersoffBufs {
   unsigned long long* mask; // [N] membership bits of the Verlet slots (lists of at most 64 entries), written by the partial kernel
 };
 
-// Members of the local list per lane kept in LDS by the fast path of TersoffPartialBody: x, y, z, type, b, b' as doubles,
-// element e of member m of lane l at [(m * 6 + e) * 64 + l] (consecutive lanes, consecutive doubles: conflict-free)
+// Members of the local list of an atom kept in LDS by the fast path of TersoffPartialBody: x, y, z, type, b, b', u as doubles,
+// element e of member m of the a-th atom of the workgroup at [(m * 7 + e) * atoms_per_block + a]
 constexpr int kTersoffLocalMax = 8;
 constexpr int kTersoffBlock = 64;
-constexpr int kTersoffLdsDoubles = kTersoffLocalMax * 6 * kTersoffBlock;
+constexpr int kTersoffLanes = 4; // lanes per atom on the device (the emulator's host loop runs one)
+constexpr int kTersoffLdsDoubles = kTersoffLocalMax * 7 * kTersoffBlock;
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// lanes of one wavefront hand data to each other through LDS: order the writes before the reads
+#define NEPMI_WAVE_LDS_SYNC()                                  \
+  do {                                                         \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     \
+    __builtin_amdgcn_wave_barrier();                           \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");     \
+  } while (0)
+#else
+#define NEPMI_WAVE_LDS_SYNC() \
+  do {                        \
+  } while (0)
+#endif
 
 struct TersoffPartialBody {
   BoxD box;
@@ -93,14 +108,17 @@ struct TersoffPartialBody {
   NEPMI_HD int lds_floats() const { return 2 * kTersoffLdsDoubles; }
   template <class LP>
   NEPMI_HD void lds_stage(LP, int, int) const {}
-
-  // Fast path (13,824 silicon atoms are 54 atoms per CU: the kernel's run time is the latency of ONE wavefront, and the
-  // plain form below walks its bonded neighbours through global memory: record written, read back 2 (n - 1) times, bond order
-  // written and read back -- some forty dependent round trips per atom).  With at most kTersoffLocalMax members of the local
-  // list (silicon: 4) the members' geometry and bond orders live in LDS: the loops below are the same arithmetic in the
-  // same order -- bit-identical results -- with LDS latencies instead of HBM ones.
   template <class LP>
-  NEPMI_HD void run(int64_t k, LP lds_f) const
+  NEPMI_HD void run(int64_t k, LP lds_f) const { run_parts<1>(k, 0, lds_f); }
+
+  // Fast path.  13,824 silicon atoms are 54 atoms per CU: the kernel's run time is the latency of ONE wavefront, and the
+  // plain form below walks an atom's bonded neighbours through global memory (record written, read back 2 (n - 1) times, bond
+  // order written and read back: some forty dependent round trips per atom).  With at most kTersoffLocalMax members of the
+  // local list (silicon: 4) their geometry and bond orders live in LDS, P adjacent lanes share the atom -- lane `part` tests
+  // the Verlet entries part, part + P, ... and owns the bonds part, part + P, ... -- and every group of loads is requested
+  // before its first use.  Same arithmetic per bond, the energy summed in bond order by one lane: bit-identical results.
+  template <int P, class LP>
+  NEPMI_HD void run_parts(int64_t k, int part, LP lds_f) const
   {
     const int64_t N = b.N;
     if (b.lvl[k] < 1)
@@ -109,74 +127,102 @@ struct TersoffPartialBody {
     const int t1 = p1.type;
     const TersoffSetD& s1 = tp.p[t1];
     const int nn = b.nn_ang[k];
-    // pass A: membership of every Verlet entry (float geometry), records of the members only in full
-    int cnt = 0;
+    // pass A: membership of every Verlet entry (float geometry)
     unsigned long long inr = 0ull;
-    // (eight entries per round: the index loads of a round, then its position gathers, are in flight together -- this loop
-    // of ~20 dependent load pairs was most of the kernel's 36 us at 54 atoms per CU)
-    constexpr int RB = 8;
-    for (int s0 = 0; s0 < nn && s0 < 64; s0 += RB) {
+    constexpr int RB = 8 / P > 0 ? 8 / P : 1; // entries per lane and round: their index loads, then their gathers, together
+    for (int s0 = 0; s0 < nn && s0 < 64; s0 += RB * P) {
       int jj[RB];
 #pragma unroll
-      for (int u = 0; u < RB; ++u)
-        jj[u] = b.nl_ang[(int64_t)(s0 + u < nn ? s0 + u : nn - 1) * N + k];
+      for (int u = 0; u < RB; ++u) {
+        const int s = s0 + u * P + part;
+        jj[u] = b.nl_ang[(int64_t)(s < nn ? s : nn - 1) * N + k];
+      }
       PosQ pp[RB];
 #pragma unroll
       for (int u = 0; u < RB; ++u)
         pp[u] = b.posq[jj[u]];
 #pragma unroll
       for (int u = 0; u < RB; ++u) {
+        const int s = s0 + u * P + part;
         float xf, yf, zf;
         const float d2f = pair_geometry(box, p1, pp[u], xf, yf, zf);
-        if (s0 + u < nn && s0 + u < 64 && d2f < tp.rc_sq) {
-          inr |= 1ull << (s0 + u);
-          ++cnt;
-        }
+        if (s < nn && s < 64 && d2f < tp.rc_sq)
+          inr |= 1ull << s;
       }
     }
-    if (nn > 64 || cnt > kTersoffLocalMax) { // long lists: the plain form
-      (*this)(k);
+    if (P > 1) { // every lane of the atom gets all the bits
+      unsigned lo = (unsigned)inr, hi = (unsigned)(inr >> 32);
+#pragma unroll
+      for (int msk = 1; msk < P; msk <<= 1) {
+        lo |= (unsigned)NEPMI_SHFL_XOR((int)lo, msk);
+        hi |= (unsigned)NEPMI_SHFL_XOR((int)hi, msk);
+      }
+      inr = (unsigned long long)lo | ((unsigned long long)hi << 32);
+    }
+    const int cnt = __builtin_popcountll(inr);
+    if (nn > 64 || cnt > kTersoffLocalMax) { // long lists: the plain form, one lane
+      if (part == 0)
+        (*this)(k);
       return;
     }
-    tb.mask[k] = inr;
-    double* L = const_cast<double*>(reinterpret_cast<const double*>(&lds_f[0])) + (int)(k % kTersoffBlock);
-    auto at = [&](int m, int e) -> double& { return L[(m * 6 + e) * kTersoffBlock]; };
+    constexpr int APB = kTersoffBlock / P;
+    double* L = const_cast<double*>(reinterpret_cast<const double*>(&lds_f[0])) + (int)(k % APB);
+    auto at = [&](int m, int e) -> double& { return L[(m * 7 + e) * APB]; };
+    if (part == 0) {
+      tb.mask[k] = inr;
+      b.nn_rad[k] = cnt;
+      b.nn_angstep[k] = cnt;
+    }
+    // Verlet slot of member m = position of the m-th set bit
+    int ms[kTersoffLocalMax];
     {
-      // the members' records (FP64 difference + FP64 minimum image): all their positions are requested before the first is used
-      int ms[kTersoffLocalMax];
-      PosQ mp[kTersoffLocalMax];
       unsigned long long rest = inr;
 #pragma unroll
       for (int m = 0; m < kTersoffLocalMax; ++m) {
         ms[m] = rest ? (int)__builtin_ctzll(rest) : 0;
         rest &= rest - 1ull;
       }
+    }
+    // pass B: the members' records (FP64 difference + FP64 minimum image); lane `part` takes members part, part + P, ...
+    {
+      constexpr int MP = (kTersoffLocalMax + P - 1) / P;
+      PosQ mp[MP];
 #pragma unroll
-      for (int m = 0; m < kTersoffLocalMax; ++m)
+      for (int u = 0; u < MP; ++u) {
+        const int m = u * P + part;
+        int slot = 0;
+#pragma unroll
+        for (int q = 0; q < kTersoffLocalMax; ++q)
+          slot = q == m ? ms[q] : slot;
         if (m < cnt)
-          mp[m] = b.posq[b.nl_ang[(int64_t)ms[m] * N + k]];
+          mp[u] = b.posq[b.nl_ang[(int64_t)slot * N + k]];
+      }
 #pragma unroll
-      for (int m = 0; m < kTersoffLocalMax; ++m) {
+      for (int u = 0; u < MP; ++u) {
+        const int m = u * P + part;
         if (m < cnt) {
+          int slot = 0;
+#pragma unroll
+          for (int q = 0; q < kTersoffLocalMax; ++q)
+            slot = q == m ? ms[q] : slot;
           D4 r;
-          r.x = mp[m].x - p1.x;
-          r.y = mp[m].y - p1.y;
-          r.z = mp[m].z - p1.z;
+          r.x = mp[u].x - p1.x;
+          r.y = mp[u].y - p1.y;
+          r.z = mp[u].z - p1.z;
           mic_d(box, r.x, r.y, r.z);
-          r.w = 1 | ((long long)mp[m].type << 8);
+          r.w = 1 | ((long long)mp[u].type << 8);
           at(m, 0) = r.x;
           at(m, 1) = r.y;
           at(m, 2) = r.z;
-          at(m, 3) = (double)mp[m].type;
-          tb.rec[(int64_t)ms[m] * N + k] = r;
+          at(m, 3) = (double)mp[u].type;
+          tb.rec[(int64_t)slot * N + k] = r;
         }
       }
       // (non-members: the force kernel and the list export read the membership bits, not their records)
     }
-    b.nn_rad[k] = cnt;
-    b.nn_angstep[k] = cnt;
-    // step 1: bond order
-    for (int i1 = 0; i1 < cnt; ++i1) {
+    NEPMI_WAVE_LDS_SYNC();
+    // step 1: bond order of the bonds this lane owns
+    for (int i1 = part; i1 < cnt; i1 += P) {
       const double x12 = at(i1, 0), y12 = at(i1, 1), z12 = at(i1, 2);
       const double d12 = sqrt(x12 * x12 + y12 * y12 + z12 * z12);
       double zeta = 0.0;
@@ -202,12 +248,13 @@ struct TersoffPartialBody {
         at(i1, 5) = -b12 * bzn * 0.5 / ((1.0 + bzn) * zeta);
       }
     }
-    // step 2: partial forces and energy; member m sits at Verlet slot = position of the m-th set bit
-    double u = 0.0;
-    unsigned long long rest = inr;
-    for (int i1 = 0; i1 < cnt; ++i1) {
-      const int slot = (int)__builtin_ctzll(rest);
-      rest &= rest - 1ull;
+    NEPMI_WAVE_LDS_SYNC();
+    // step 2: partial forces and energy of the bonds this lane owns
+    for (int i1 = part; i1 < cnt; i1 += P) {
+      int slot = 0;
+#pragma unroll
+      for (int q = 0; q < kTersoffLocalMax; ++q)
+        slot = q == i1 ? ms[q] : slot;
       const double x12 = at(i1, 0), y12 = at(i1, 1), z12 = at(i1, 2);
       const int t2 = (int)at(i1, 3);
       const TersoffSetD& p12 = ters_pair(tp, t1, t2);
@@ -220,7 +267,7 @@ struct TersoffPartialBody {
       const double b12 = at(i1, 4), bp12 = at(i1, 5);
       const double factor3 = (fcp12 * (fr12 - b12 * fa12) + fc12 * (frp12 - b12 * fap12)) * d12inv;
       double fx = x12 * factor3 * 0.5, fy = y12 * factor3 * 0.5, fz = z12 * factor3 * 0.5;
-      u += fc12 * (fr12 - b12 * fa12) * 0.5;
+      at(i1, 6) = fc12 * (fr12 - b12 * fa12) * 0.5;
       for (int i2 = 0; i2 < cnt; ++i2) {
         if (i2 == i1)
           continue;
@@ -251,7 +298,13 @@ struct TersoffPartialBody {
       out.w = 0;
       tb.f12[(int64_t)slot * N + k] = out;
     }
-    tb.pe_d[k] = u;
+    NEPMI_WAVE_LDS_SYNC();
+    if (part == 0) { // the bonds' energies in bond order: the sum of the one-lane form, bit for bit
+      double u = 0.0;
+      for (int m = 0; m < cnt; ++m)
+        u += at(m, 6);
+      tb.pe_d[k] = u;
+    }
   }
 
   NEPMI_HD void operator()(int64_t k) const

@@ -138,3 +138,9 @@ class DistMD:
 
     def engine_set_timing(self, mode):
         self._ck(self.lib.nepmi_engine_set_timing(self.lib.nepmi_dist_engine(self.handle), int(mode)))
+
+    def engine_describe(self):
+        """the kernel forms the local engine's last force evaluation ran (nepmi_engine_describe)"""
+        buf = C.create_string_buffer(512)
+        n = self.lib.nepmi_engine_describe(self.lib.nepmi_dist_engine(self.handle), buf, 512)
+        return buf.value.decode() if n >= 0 else ""

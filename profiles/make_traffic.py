@@ -9,7 +9,8 @@ import csv
 import json
 import sys
 
-NAMES = [("CheckGatherBody", "gather_skin_check"), ("RadialWinBody", "radial_descriptor"), ("ForceWinBody", "force_assemble"),
+NAMES = [("CheckGatherBody", "gather_skin_check"), ("RadialWin2Body", "radial_descriptor"), ("RadialWinBody", "radial_descriptor"),
+         ("ForceWinBody", "force_assemble"),
          ("ResidentStepBody", "velocity_verlet"), ("RadialTileBody", "radial_descriptor"),
          ("RadialDescBody", "radial_descriptor"), ("AngularDescBody", "angular_descriptor"),
          ("nepmi_ann_mfma", "ann"), ("AnnBody", "ann"), ("AngularForceBody", "angular_partial_force"),
