@@ -309,6 +309,20 @@ nepmi_kernel_lds_pairs(const Body body, const int64_t n, const int* frozen)
     body.template run_parts<2>(i, (int)(threadIdx.x & 1u), (lds_cfloat_ptr)nepmi_lds_pairs);
 }
 
+// P adjacent lanes per atom (Body::run_parts<P>): TersoffPartialBody -- 54 atoms per CU need more than one wavefront per CU
+template <int BLOCK, int P, class Body>
+__global__ void __launch_bounds__(BLOCK) nepmi_kernel_lds_parts(const Body body, const int64_t n, const int* frozen)
+{
+  extern __shared__ __attribute__((aligned(16))) float nepmi_lds_parts[];
+  if (frozen && *frozen != 0)
+    return;
+  const unsigned per_xcd = gridDim.x >> 3;
+  const unsigned tile = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+  const int64_t i = ((int64_t)tile * BLOCK + threadIdx.x) / P;
+  if (i < n)
+    body.template run_parts<P>(i, (int)(threadIdx.x % P), (lds_cfloat_ptr)nepmi_lds_parts);
+}
+
 // ---- exclusive scan of int32, in place: 3 kernels (block scan, scan of block sums, add) ----
 template <int BLOCK>
 __device__ __forceinline__ int block_exclusive_scan(int v, int* total);
@@ -1059,6 +1073,23 @@ struct HipBackend {
     if (t)
       timer_start(timing->slot[slot]);
     hipLaunchKernelGGL((nepmi_kernel_lds<BLOCK, Body>), dim3((unsigned)grid), dim3(BLOCK), lds_bytes, stream, body, n, frozen);
+    NEPMI_HIP_CHECK(hipGetLastError());
+    if (t)
+      timer_stop(timing->slot[slot]);
+  }
+
+  template <int BLOCK, int P, class Body>
+  void launch_lds_parts(int slot, int64_t n, const Body& body)
+  {
+    if (n <= 0)
+      return;
+    const int64_t grid = ((P * n + BLOCK - 1) / BLOCK + 7) / 8 * 8;
+    const size_t lds_bytes = ((size_t)body.lds_floats() * sizeof(float) + 15) / 16 * 16;
+    const bool t = timed(slot);
+    if (t)
+      timer_start(timing->slot[slot]);
+    hipLaunchKernelGGL((nepmi_kernel_lds_parts<BLOCK, P, Body>), dim3((unsigned)grid), dim3(BLOCK), lds_bytes, stream, body, n,
+                       frozen);
     NEPMI_HIP_CHECK(hipGetLastError());
     if (t)
       timer_stop(timing->slot[slot]);

@@ -1589,7 +1589,12 @@ private:
   {
     if (model_.kind == 1) { // Tersoff1989::compute, tersoff1989.cu:508-586
       be_.begin_region(kRegionForce);
-      be_.template launch_lds<kTersoffBlock>(kSlotRadial, N_, TersoffPartialBody{box_, tp_, b_, tb_}); // members of the local list in LDS
+      // members of the local list in LDS; kTersoffLanes lanes per atom while the system leaves CUs short of wavefronts (a
+      // counted rule: 13,824 atoms 36 -> 16 us, 884,736 atoms 0.55 -> 0.63 ms with four lanes)
+      if (N_ < 200000)
+        be_.template launch_lds_parts<kTersoffBlock, kTersoffLanes>(kSlotRadial, N_, TersoffPartialBody{box_, tp_, b_, tb_});
+      else
+        be_.template launch_lds<kTersoffBlock>(kSlotRadial, N_, TersoffPartialBody{box_, tp_, b_, tb_});
       be_.template launch<64>(kSlotForce, N_, TersoffAssembleBody{b_, tb_});
       be_.end_region(kRegionForce);
       return;

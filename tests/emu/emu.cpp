@@ -151,6 +151,17 @@ struct HostLoopBackend {
       body.run(i, (const float*)lds.data());
   }
 
+  // P lanes per atom on the device; the host loop runs the one-lane form of the same body
+  template <int BLOCK, int P, class Body>
+  void launch_lds_parts(int, int64_t n, const Body& body)
+  {
+    if (is_frozen())
+      return;
+    std::vector<float> lds((size_t)body.lds_floats() + 1);
+    for (int64_t i = 0; i < n; ++i)
+      body.template run_parts<1>(i, 0, (const float*)lds.data());
+  }
+
   // the device runs these bodies with two lanes per atom; the host loop runs the one-lane form
   template <int BLOCK, class Body>
   void launch_lds_pairs(int slot, int64_t n, const Body& body)
