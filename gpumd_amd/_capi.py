@@ -121,6 +121,7 @@ SYMBOLS = {
     "nepmi_dist_run": (C.c_int, [VP, C.c_int, C.c_double, c_i64, C.c_double, C.c_double, C.c_double, c_i64, c_dp]),
     "nepmi_dist_thermo": (C.c_int, [VP, c_dp]),
     "nepmi_dist_bdp_seed": (C.c_int, [VP, C.c_uint64]),
+    "nepmi_dist_lan_seed": (C.c_int, [VP, C.c_int]),
     "nepmi_dist_set_overlap": (C.c_int, [VP, C.c_int]),
     "nepmi_dist_get_info": (C.c_int, [VP, C.POINTER(NepmiDistInfo)]),
     "nepmi_dist_gather_owned": (C.c_int, [VP, VP, VP, VP, VP, VP, VP]),

@@ -229,6 +229,13 @@ struct LevelBody {
   }
 };
 
+// owned[id[q]] = 1 for the owned atoms q of this rank (Langevin generator states are indexed by global id)
+struct MarkOwnedBody {
+  const int64_t* id;
+  signed char* owned;
+  NEPMI_HD void operator()(int64_t q) const { owned[id[q]] = 1; }
+};
+
 struct InversePermBody {
   const int* perm;
   int* inv;

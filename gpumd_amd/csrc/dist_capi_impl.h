@@ -66,7 +66,7 @@ int nepmi_dist_run(
   nepmi_dist* d, int ensemble, double dt, int64_t nsteps, double t1, double t2, double t_coup, int64_t thermo_every,
   double* thermo_host)
 {
-  if (!d || ensemble < 0 || ensemble > 3 || nsteps < 0)
+  if (!d || ensemble < 0 || ensemble > 4 || nsteps < 0) // 0..3 as nepmi_run_*; 4: nvt_lan (BAOAB has no decomposed form)
     return fail(NEPMI_ERR_ARG, "bad argument");
   if (!d->d->engine())
     return fail(NEPMI_ERR_ARG, "nepmi_dist_setup has not been called");
@@ -91,6 +91,14 @@ int nepmi_dist_bdp_seed(nepmi_dist* d, uint64_t seed)
   if (!d)
     return fail(NEPMI_ERR_ARG, "null handle");
   d->d->bdp_seed(seed);
+  return NEPMI_OK;
+}
+
+int nepmi_dist_lan_seed(nepmi_dist* d, int seed)
+{
+  if (!d)
+    return fail(NEPMI_ERR_ARG, "null handle");
+  d->d->lan_seed(seed);
   return NEPMI_OK;
 }
 

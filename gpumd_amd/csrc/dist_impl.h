@@ -185,6 +185,22 @@ public:
       be_.template launch<64>(kSlotMisc, 1, NhcChainBody{n_total_, target, 0.5 * dt, thermo_dev_, nhc_dev_, frozen()});
       be_.template launch<256>(kSlotVV, e->num_atoms(), ResidentScaleBody{e->bufs(), nhc_dev_ + 3 * kNhcLinks, 1.0});
     };
+    // Ensemble_LAN (ensemble_lan.cu:96-127, :206-262) on the decomposed system.  Every rank carries the generator states of
+    // ALL atoms, indexed by global id: it kicks the atoms it owns and advances the other states without using their draws, so
+    // an atom's noise is the single-domain run's whatever the decomposition and nothing migrates; the four momentum sums
+    // are all-reduced before the centre-of-mass velocity is removed.
+    if (ens == Engine::kLan)
+      lan_prepare();
+    auto lan_half = [&](double target) {
+      const double c1 = std::exp(-0.5 / tcoup);
+      const double c2 = std::sqrt((1.0 - c1 * c1) * kBoltzmann * target);
+      const Bufs& bb = e->bufs();
+      be_.lan_kick_resident(lan_states_, e->num_atoms(), c1, c2, bb.mi, bb.vi, bb.perm, bb.lvl, cur_.id, bb.flags);
+      be_.lan_advance_unowned(lan_states_, n_total_, lan_owned_, bb.flags);
+      be_.lan_momentum_resident(e->num_atoms(), bb.mi, bb.vi, nullptr, bb.lvl, lan_sums_, bb.flags);
+      device_allreduce(lan_sums_, 4, kDtF64, kOpSum);
+      be_.template launch<256>(kSlotVV, e->num_atoms(), ResidentMomentumFixBody{bb, lan_sums_});
+    };
     // temperature-dependent NEP: as in EngineT::run_md (every rank sets the same value)
     const bool temp_ramp = e->temperature_model() && ens != Engine::kNve && t1 != t2;
     if (e->temperature_model() && ens != Engine::kNve && e->temperature() != t1)
@@ -200,6 +216,8 @@ public:
       if (!resume_after_vv1) {
         if (ens == Engine::kNhc)
           nhc_half(target);
+        if (ens == Engine::kLan)
+          lan_half(target);
         be_.template launch<256>(kSlotVV, e->num_atoms(),
                                  ResidentStepBody{e->box(), e->bufs(), dt, kick2_pending ? 1 : 0, 1, tag_of(step)});
       }
@@ -243,6 +261,10 @@ public:
           } else if (ens == Engine::kBdp) {
             thermo_global();
             need_sync = true;
+          } else if (ens == Engine::kLan) {
+            lan_half(target);
+            if (record)
+              thermo_global();
           } else if (record) {
             thermo_global();
           }
@@ -281,6 +303,8 @@ public:
         step = (int64_t)trip - 1;
         decompose();
         e = eng_.get();
+        if (ens == Engine::kLan)
+          lan_mark_owned();
         resume_after_vv1 = true;
         kick2_pending = false;
         continue;
@@ -358,6 +382,38 @@ public:
   void reset_thermostat() { nhc_fresh_ = true; }
 
   void bdp_seed(uint64_t seed) { seed_ = seed; if (eng_) eng_->bdp_seed(seed); }
+  // Langevin thermostat: the seed of the per-atom generators (the same on every rank; state s = atom with global id s)
+  void lan_seed(int seed)
+  {
+    lan_seed_ = seed;
+    lan_fresh_ = true;
+  }
+  void lan_prepare()
+  {
+    if (!lan_states_ || lan_cap_ < n_total_) {
+      if (lan_states_) {
+        be_.free(lan_states_);
+        be_.free(lan_owned_);
+      }
+      lan_states_ = be_.alloc(be_.lan_state_bytes() * (size_t)n_total_);
+      lan_owned_ = (signed char*)be_.alloc((size_t)n_total_);
+      lan_cap_ = n_total_;
+      lan_fresh_ = true;
+    }
+    if (!lan_sums_)
+      lan_sums_ = (double*)be_.alloc(sizeof(double) * 4);
+    if (lan_fresh_) {
+      be_.lan_init(lan_states_, n_total_, lan_seed_);
+      lan_fresh_ = false;
+    }
+    lan_mark_owned();
+  }
+  void lan_mark_owned() // which global ids this rank owns now (after every (re-)decomposition)
+  {
+    be_.memset(lan_owned_, 0, (size_t)n_total_);
+    if (cur_.n_own > 0)
+      be_.template launch<256>(kSlotMisc, cur_.n_own, MarkOwnedBody{cur_.id, lan_owned_});
+  }
   void set_overlap(bool on) { overlap_ = on; }
   int64_t num_overlapped = 0; // steps whose interior radial pass ran before / while the ghosts travelled
   double decompose_ms = 0.0;  // wall time of all (re-)decompositions (migration, ghost stages, list rebuild), synchronised
@@ -902,6 +958,12 @@ private:
   B side_;               // the backend on the communication stream (device transports)
   bool side_ready_ = false;
   uint64_t seed_ = 12345678u;
+  void* lan_states_ = nullptr;       // generator states of ALL atoms, by global id
+  signed char* lan_owned_ = nullptr; // [n_total] 1: owned by this rank
+  double* lan_sums_ = nullptr;
+  int64_t lan_cap_ = 0;
+  int lan_seed_ = 12345678;
+  bool lan_fresh_ = true;
   int* flag_dev_ = nullptr;
   double *sums_dev_ = nullptr, *thermo_dev_ = nullptr, *nhc_dev_ = nullptr, *factor_dev_ = nullptr;
   std::vector<int*> iscr_;

@@ -616,6 +616,72 @@ __global__ void nepmi_momentum_fix(const int64_t N, const double* __restrict__ s
   }
 }
 
+// ---- the same thermostat inside the device-resident run loops (and the decomposed driver): velocities and masses in the
+//      engine's INTERNAL order (stride n), generator states where the reference keeps them -- state s belongs to the atom with
+//      caller index s (single domain: s = perm[k]) or global id s (decomposed: s = ids[perm[k]]; every rank carries the
+//      states of ALL atoms and advances the ones it does not own without using the draws, so an atom's noise does not
+//      depend on the decomposition and nothing has to migrate).  `flags`: the frozen word of the speculative loops. ----
+__global__ void nepmi_lan_kick_resident(
+  hiprandState* g_state, const int64_t n, const double c1, const double c2, const double* __restrict__ mi, double* vi,
+  const int* __restrict__ perm, const signed char* __restrict__ lvl, const int64_t* __restrict__ ids, const int* flags)
+{
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n || flags[nepmi::kFlagMoved] != 0 || lvl[k] < 2)
+    return;
+  const int64_t s = ids ? ids[perm[k]] : (int64_t)perm[k];
+  hiprandState state = g_state[s];
+  const double c2m = c2 * sqrt(1.0 / mi[k]);
+  vi[k] = c1 * vi[k] + c2m * hiprand_normal_double(&state);
+  vi[n + k] = c1 * vi[n + k] + c2m * hiprand_normal_double(&state);
+  vi[2 * n + k] = c1 * vi[2 * n + k] + c2m * hiprand_normal_double(&state);
+  g_state[s] = state;
+}
+
+__global__ void nepmi_lan_advance_unowned(hiprandState* g_state, const int64_t n_total, const signed char* __restrict__ owned,
+                                          const int* flags)
+{
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_total || flags[nepmi::kFlagMoved] != 0 || owned[s])
+    return;
+  hiprandState state = g_state[s];
+  (void)hiprand_normal_double(&state);
+  (void)hiprand_normal_double(&state);
+  (void)hiprand_normal_double(&state);
+  g_state[s] = state;
+}
+
+// invp != nullptr (single domain): the four sums in CALLER order exactly as nepmi_momentum_sum forms them (thread t takes
+// the atoms t, t + 1024, ... of the caller's numbering), so the corrected velocities stay bit-identical to the stepwise form;
+// invp == nullptr (decomposed): the owned atoms in internal order (a fixed order per rank; the ranks' sums are all-reduced)
+__global__ void __launch_bounds__(1024) nepmi_momentum_sum_resident(
+  const int64_t n, const double* __restrict__ mi, const double* __restrict__ vi, const int* __restrict__ invp,
+  const signed char* __restrict__ lvl, double* __restrict__ sums4, const int* flags)
+{
+  __shared__ double s_sum[1024];
+  if (flags[nepmi::kFlagMoved] != 0)
+    return;
+  const int tid = threadIdx.x, bid = blockIdx.x;
+  double acc = 0.0;
+  for (int64_t q = tid; q < n; q += 1024) {
+    const int64_t k = invp ? invp[q] : q;
+    if (!invp && lvl[k] < 2)
+      continue;
+    if (bid < 3)
+      acc += mi[k] * vi[(int64_t)bid * n + k];
+    else
+      acc += mi[k];
+  }
+  s_sum[tid] = acc;
+  __syncthreads();
+  for (int offset = 512; offset > 0; offset >>= 1) {
+    if (tid < offset)
+      s_sum[tid] += s_sum[tid + offset];
+    __syncthreads();
+  }
+  if (tid == 0)
+    sums4[bid] = s_sum[0];
+}
+
 // ---- Ensemble::find_thermo (ensemble.cu:434-673): 8 sums in one pass over the atoms ----
 constexpr int kThermoBlock = 256;
 constexpr int kThermoMaxBlocks = 1024;
@@ -1149,6 +1215,26 @@ struct HipBackend {
   void lan_init(void* states, int64_t n, int seed)
   {
     hipLaunchKernelGGL(nepmi_lan_init, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, stream, (hiprandState*)states, n, seed);
+    NEPMI_HIP_CHECK(hipGetLastError());
+  }
+  // resident forms (see the kernels above); the velocity correction itself is ResidentMomentumFixBody
+  void lan_kick_resident(void* states, int64_t n, double c1, double c2, const double* mi, double* vi, const int* perm,
+                         const signed char* lvl, const int64_t* ids, const int* flags)
+  {
+    hipLaunchKernelGGL(nepmi_lan_kick_resident, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, stream, (hiprandState*)states, n,
+                       c1, c2, mi, vi, perm, lvl, ids, flags);
+    NEPMI_HIP_CHECK(hipGetLastError());
+  }
+  void lan_advance_unowned(void* states, int64_t n_total, const signed char* owned, const int* flags)
+  {
+    hipLaunchKernelGGL(nepmi_lan_advance_unowned, dim3((unsigned)((n_total + 127) / 128)), dim3(128), 0, stream,
+                       (hiprandState*)states, n_total, owned, flags);
+    NEPMI_HIP_CHECK(hipGetLastError());
+  }
+  void lan_momentum_resident(int64_t n, const double* mi, const double* vi, const int* invp, const signed char* lvl,
+                             double* sums4, const int* flags)
+  {
+    hipLaunchKernelGGL(nepmi_momentum_sum_resident, dim3(4), dim3(1024), 0, stream, n, mi, vi, invp, lvl, sums4, flags);
     NEPMI_HIP_CHECK(hipGetLastError());
   }
   void lan_half(void* states, int64_t n, double c1, double c2, const double* mass, double* vel, double* sums4)

@@ -512,9 +512,8 @@ public:
     box_from_h9(h9, pbc, box);
     if (n < 1 || n > cap_)
       throw EngineError{-4, "number of atoms exceeds the engine's capacity"};
-    if ((is_small_box(box) && model_.kind == 0) || ens == kLan || ens == kBao) {
-      // (Langevin: the generator states follow the caller's atom order, like the reference's; the stepwise loop
-      // works on the caller's arrays)
+    if ((is_small_box(box) && model_.kind == 0) || ens == kBao) {
+      // (BAOAB: its half drifts with the O step in between have no fused form yet: the stepwise loop on the caller's arrays)
       run_md_small_box(ens, h9, pbc, n, type, mass, dt, nsteps, t1, t2, tcoup, pos, vel, pe, force, virial, thermo_every,
                        thermo_host);
       return;
@@ -534,6 +533,18 @@ public:
     }
     if (!factor_dev_)
       factor_dev_ = dalloc<double>(1);
+    if (ens == kLan)
+      lan_prepare(n);
+    // Ensemble_LAN (ensemble_lan.cu:96-127, :206-262): one thermostat half-step on the internal velocities.  The generator
+    // states stay in the caller's atom order (state perm[k] for internal atom k) and the momentum sums are formed in the
+    // caller's order through the inverse permutation: the same numbers as the stepwise nepmi_lan_half_step, bit for bit.
+    auto lan_half = [&](double target) {
+      const double c1 = std::exp(-0.5 / tcoup);
+      const double c2 = std::sqrt((1.0 - c1 * c1) * kBoltzmann * target);
+      be_.lan_kick_resident(lan_states_, N_, c1, c2, b_.mi, b_.vi, b_.perm, b_.lvl, nullptr, b_.flags);
+      be_.lan_momentum_resident(N_, b_.mi, b_.vi, b_.invp, b_.lvl, lan_sums_, b_.flags);
+      be_.template launch<256>(kSlotVV, N_, ResidentMomentumFixBody{b_, lan_sums_});
+    };
     const int* frozen = b_.flags + kFlagMoved;
     be_.memset(b_.flags + kFlagMoved, 0, sizeof(int));
     const int64_t compute0 = num_compute;
@@ -587,6 +598,8 @@ public:
       if (!resume_after_vv1) {
         if (ens == kNhc)
           nhc_half(target); // integrate_nvt_nhc_1: thermostat half-step before the first velocity-Verlet half
+        if (ens == kLan)
+          lan_half(target); // Ensemble_LAN::compute1
         be_.template launch<256>(kSlotVV, N_, ResidentStepBody{box_, b_, dt, kick2_pending ? 1 : 0, 1, tag_of(step)});
       }
       resume_after_vv1 = false;
@@ -612,6 +625,10 @@ public:
         } else if (ens == kBdp) {
           thermo_now();
           need_sync = true; // the noise is drawn on the host from the kinetic energy, as in the reference
+        } else if (ens == kLan) {
+          lan_half(target); // Ensemble_LAN::compute2: the second half-step of the thermostat precedes find_thermo
+          if (record)
+            thermo_now();
         } else if (record) {
           thermo_now();
         }
@@ -660,6 +677,7 @@ public:
     if (!b_.vi) {
       b_.vi = dalloc<double>(3 * cap_);
       b_.mi = dalloc<double>(cap_);
+      b_.invp = dalloc<int>(cap_);
     }
     if (unwrapped_ && !ui_alloc_)
       ui_alloc_ = dalloc<double>(3 * cap_);

@@ -152,6 +152,7 @@ struct Bufs {
   double* vi; // [3][N]
   double* mi; // [N]
   double* ui; // [3][N] unwrapped positions, or nullptr
+  int* invp;  // [N] caller index -> internal index (inverse of perm), written with the state import; or nullptr
   // fixed-point records of the current positions (written wherever posq is written) and the cell of every atom
   WinRec* prec; // [N]
   int* kcell;   // [N] cell index (brick-major numbering) at the last rebuild

@@ -14,7 +14,7 @@ import numpy as np
 
 from . import _capi
 
-ENSEMBLES = {"nve": 0, "nvt_ber": 1, "nvt_nhc": 2, "nvt_bdp": 3}
+ENSEMBLES = {"nve": 0, "nvt_ber": 1, "nvt_nhc": 2, "nvt_bdp": 3, "nvt_lan": 4}
 
 
 def choose_grid(world):
@@ -117,6 +117,10 @@ class DistMD:
 
     def bdp_seed(self, seed):
         self._ck(self.lib.nepmi_dist_bdp_seed(self.handle, int(seed)))
+
+    def lan_seed(self, seed):
+        """seed of the per-atom Langevin generators (ensemble nvt_lan); the same value on every rank"""
+        self._ck(self.lib.nepmi_dist_lan_seed(self.handle, int(seed)))
 
     def set_overlap(self, on=True):
         self._ck(self.lib.nepmi_dist_set_overlap(self.handle, 1 if on else 0))

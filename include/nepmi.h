@@ -297,13 +297,18 @@ int nepmi_dist_setup(
   const int64_t* ids);
 /* Force::compute on the decomposed system (the initial force of Run::perform_a_run). */
 int nepmi_dist_compute(nepmi_dist* d);
-/* The run loop for ensemble 0 = nve, 1 = nvt_ber, 2 = nvt_nhc, 3 = nvt_bdp (see nepmi_run_*); thermo_host (HOST,
+/* The run loop for ensemble 0 = nve, 1 = nvt_ber, 2 = nvt_nhc, 3 = nvt_bdp, 4 = nvt_lan (see nepmi_run_*); thermo_host (HOST,
  * 8 doubles per record, may be NULL) receives the GLOBAL T, U and stresses on every rank. */
 int nepmi_dist_run(
   nepmi_dist* d, int ensemble, double dt, int64_t nsteps, double t1, double t2, double t_coup,
   int64_t thermo_every, double* thermo_host);
 int nepmi_dist_thermo(nepmi_dist* d, double thermo8_host[8]);
 int nepmi_dist_bdp_seed(nepmi_dist* d, uint64_t seed);
+/* Langevin thermostat of a decomposed run (ensemble 4 of nepmi_dist_run = `ensemble nvt_lan`, Ensemble_LAN): the seed of the
+ * per-atom generators, the same value on every rank (the reference seeds them with rand(), ensemble_lan.cu:39).  State s belongs
+ * to the atom with global id s exactly as in the single-domain nepmi_run_nvt_lan, so the noise of an atom does not depend on the
+ * decomposition: every rank carries all states, kicks the atoms it owns and advances the others. */
+int nepmi_dist_lan_seed(nepmi_dist* d, int seed);
 /* on (default): the radial pass of the interior bricks (no ghost in their 8x8x8-cell window) is enqueued on the
  * compute stream while the skin vote and the ghost positions travel on a communication stream; off: the plain
  * exchange-then-compute order.  Both orders give bit-identical results. */

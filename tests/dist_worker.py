@@ -57,6 +57,7 @@ def run_rank(out_dir, spec, rank, world, make_transport, stream=None):
         md.set_overlap(spec["overlap"])
     if spec.get("seed") is not None:
         md.bdp_seed(spec["seed"])
+        md.lan_seed(spec["seed"])
     md.compute()
 
     def snapshot():

@@ -188,14 +188,67 @@ struct HostLoopBackend {
     for (int64_t i = 0; i < n; ++i)
       new (&st[i]) std::mt19937_64((uint64_t)seed * 1000003ull + (uint64_t)i);
   }
+  // resident forms of the thermostat (HipBackend::lan_kick_resident & co.): the same update on the internal-order arrays
+  void lan_kick_resident(void* states, int64_t n, double c1, double c2, const double* mi, double* vi, const int* perm,
+                         const signed char* lvl, const int64_t* ids, const int* flags)
+  {
+    if (flags[kFlagMoved] != 0)
+      return;
+    std::mt19937_64* st = (std::mt19937_64*)states;
+    std::normal_distribution<double> nd(0.0, 1.0);
+    for (int64_t k = 0; k < n; ++k) {
+      if (lvl[k] < 2)
+        continue;
+      const int64_t s = ids ? ids[perm[k]] : (int64_t)perm[k];
+      const double c2m = c2 * std::sqrt(1.0 / mi[k]);
+      for (int d = 0; d < 3; ++d) {
+        nd.reset(); // one fresh pair per draw: the stream of an atom does not depend on who draws it
+        vi[d * n + k] = c1 * vi[d * n + k] + c2m * nd(st[s]);
+      }
+    }
+  }
+  void lan_advance_unowned(void* states, int64_t n_total, const signed char* owned, const int* flags)
+  {
+    if (flags[kFlagMoved] != 0)
+      return;
+    std::mt19937_64* st = (std::mt19937_64*)states;
+    std::normal_distribution<double> nd(0.0, 1.0);
+    for (int64_t s = 0; s < n_total; ++s) {
+      if (owned[s])
+        continue;
+      for (int d = 0; d < 3; ++d) {
+        nd.reset();
+        (void)nd(st[s]);
+      }
+    }
+  }
+  void lan_momentum_resident(int64_t n, const double* mi, const double* vi, const int* invp, const signed char* lvl,
+                             double* sums4, const int* flags)
+  {
+    if (flags[kFlagMoved] != 0)
+      return;
+    double s[4] = {0, 0, 0, 0};
+    for (int64_t q = 0; q < n; ++q) {
+      const int64_t k = invp ? invp[q] : q;
+      if (!invp && lvl[k] < 2)
+        continue;
+      for (int d = 0; d < 3; ++d)
+        s[d] += mi[k] * vi[d * n + k];
+      s[3] += mi[k];
+    }
+    for (int d = 0; d < 4; ++d)
+      sums4[d] = s[d];
+  }
   void lan_half(void* states, int64_t n, double c1, double c2, const double* mass, double* vel, double* sums4)
   {
     std::mt19937_64* st = (std::mt19937_64*)states;
     std::normal_distribution<double> nd(0.0, 1.0);
     for (int64_t i = 0; i < n; ++i) {
       const double c2m = c2 * std::sqrt(1.0 / mass[i]);
-      for (int d = 0; d < 3; ++d)
+      for (int d = 0; d < 3; ++d) {
+        nd.reset(); // (as in the resident form: an atom's draws come from its own generator only)
         vel[d * n + i] = c1 * vel[d * n + i] + c2m * nd(st[i]);
+      }
     }
     double s[4] = {0, 0, 0, 0};
     for (int64_t i = 0; i < n; ++i) {
@@ -205,9 +258,10 @@ struct HostLoopBackend {
     }
     for (int d = 0; d < 4; ++d)
       sums4[d] = s[d];
+    const double inverse_of_total_mass = 1.0 / s[3]; // (as the reference's gpu_correct_momentum and the resident form)
     for (int64_t i = 0; i < n; ++i)
       for (int d = 0; d < 3; ++d)
-        vel[d * n + i] -= s[d] / s[3];
+        vel[d * n + i] -= s[d] * inverse_of_total_mass;
   }
 
   void thermo(

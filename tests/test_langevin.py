@@ -115,3 +115,51 @@ def test_nvt_lan_relaxes_to_the_target_on_emulator():
 @pytest.mark.gpu
 def test_nvt_lan_relaxes_to_the_target_on_gpu():
     _relaxes_to_target(H.GpuDriver())
+
+
+def _resident_loop_equals_stepwise(drv):
+    """nepmi_run_nvt_lan runs device-resident (state in the engine's internal order, steps enqueued speculatively, rebuilds
+    inside the run): the generator states stay in the caller's atom order and the momentum sums are formed in the caller's
+    order, so it must reproduce the stepwise sequence of the per-call entry points -- lan_half_step, vv_step1, Force::compute (wrap,
+    zero, force), vv_step2, lan_half_step -- BIT FOR BIT in the velocities and positions."""
+    h, typ, x = H.pbte_supercell((3, 3, 3), seed=4)
+    n = len(typ)
+    mass = np.where(typ == 0, H.MASS["Te"], H.MASS["Pb"]).astype(np.float64)
+    vel = H.maxwell_velocities(mass, 1500.0, seed=9)  # hot: list rebuilds inside the 40 steps
+    dt, nsteps, t_coup = 2.0 / H.TIME_UNIT, 40, 50.0
+    model = drv.model(H.golden("PbTe", "nep.txt"))
+
+    def start(eng):
+        d = [drv.dev(a) for a in (typ, mass, x.copy(), vel.copy())]
+        out = [drv.zeros(n), drv.zeros(3 * n), drv.zeros(9 * n)]
+        eng.force_compute(h, d[0], d[2], *out, n=n)
+        eng.lan_seed(2024)
+        return d, out
+    eng_a = drv.engine(model, n)
+    (d_t, d_m, d_x, d_v), (pe, f, w) = start(eng_a)
+    eng_a.run_nvt_lan(h, d_t, d_m, dt, nsteps, 600.0, 300.0, t_coup, d_x, d_v, pe, f, w)
+    assert eng_a.stats().num_rebuild >= 2
+    xa, va = drv.host(d_x), drv.host(d_v)
+    eng_b = drv.engine(model, n)
+    (d_t, d_m, d_x, d_v), (pe, f, w) = start(eng_b)
+    for s in range(nsteps):
+        target = 600.0 + (300.0 - 600.0) * (s / nsteps)
+        eng_b.lan_half_step(target, t_coup, d_m, d_v)
+        eng_b.vv_step1(dt, d_m, f, d_x, d_v)
+        eng_b.force_compute(h, d_t, d_x, pe, f, w, n=n)  # Force::compute: wrap, zero, compute
+        eng_b.vv_step2(dt, d_m, f, d_v)
+        eng_b.lan_half_step(target, t_coup, d_m, d_v)
+    xb, vb = drv.host(d_x), drv.host(d_v)
+    # the force kernels sum in the engine's internal order in both runs, so the forces -- and with them everything -- agree
+    # to the last bit as long as both runs rebuild their lists at the same steps (same skin policy on the same positions)
+    assert np.array_equal(va, vb), np.abs(va - vb).max()
+    assert np.array_equal(xa, xb), np.abs(xa - xb).max()
+
+
+def test_resident_nvt_lan_equals_the_stepwise_sequence_on_emulator():
+    _resident_loop_equals_stepwise(H.EmuDriver())
+
+
+@pytest.mark.gpu
+def test_resident_nvt_lan_equals_the_stepwise_sequence_on_gpu():
+    _resident_loop_equals_stepwise(H.GpuDriver())
