@@ -199,7 +199,7 @@ public:
       be_.lan_advance_unowned(lan_states_, n_total_, lan_owned_, bb.flags);
       be_.lan_momentum_resident(e->num_atoms(), bb.mi, bb.vi, nullptr, bb.lvl, lan_sums_, bb.flags);
       device_allreduce(lan_sums_, 4, kDtF64, kOpSum);
-      be_.template launch<256>(kSlotVV, e->num_atoms(), ResidentMomentumFixBody{bb, lan_sums_});
+      be_.lan_momentum_fix_resident(e->num_atoms(), lan_sums_, bb.vi, bb.lvl, bb.flags);
     };
     // temperature-dependent NEP: as in EngineT::run_md (every rank sets the same value)
     const bool temp_ramp = e->temperature_model() && ens != Engine::kNve && t1 != t2;

@@ -558,6 +558,23 @@ __global__ void __launch_bounds__(kScanBlock) nepmi_scan_add(int* data, int64_t 
 //      m vz, m) are formed by four 1024-thread blocks in the same order as gpu_find_momentum, so the corrected
 //      velocities equal the reference's bit for bit (tests/test_langevin.py pins them on its kernels). ----
 
+// The arithmetic of one kick / one momentum term / one correction as device functions shared by the stepwise kernels (pinned bit
+// for bit on the reference's own kernels, tests/test_langevin.py) and the resident ones: the same expressions reach the compiler,
+// so both forms take the same fused multiply-adds and round alike.
+__device__ __forceinline__ void nepmi_lan_kick3(hiprandState& state, const double c1, const double c2, const double mass, double& vx,
+                                                double& vy, double& vz)
+{
+  const double c2m = c2 * sqrt(1.0 / mass);
+  vx = c1 * vx + c2m * hiprand_normal_double(&state);
+  vy = c1 * vy + c2m * hiprand_normal_double(&state);
+  vz = c1 * vz + c2m * hiprand_normal_double(&state);
+}
+__device__ __forceinline__ double nepmi_momentum_term(const double acc, const double m, const double v) { return acc + m * v; }
+__device__ __forceinline__ double nepmi_momentum_fixed(const double v, const double sum, const double inverse_of_total_mass)
+{
+  return v - sum * inverse_of_total_mass;
+}
+
 __global__ void nepmi_lan_init(hiprandState* state, const int64_t N, const int seed)
 {
   const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -571,10 +588,11 @@ __global__ void nepmi_lan_kick(
   const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (n < N) {
     hiprandState state = g_state[n];
-    const double c2m = c2 * sqrt(1.0 / g_mass[n]);
-    g_v[n] = c1 * g_v[n] + c2m * hiprand_normal_double(&state);
-    g_v[N + n] = c1 * g_v[N + n] + c2m * hiprand_normal_double(&state);
-    g_v[2 * N + n] = c1 * g_v[2 * N + n] + c2m * hiprand_normal_double(&state);
+    double vx = g_v[n], vy = g_v[N + n], vz = g_v[2 * N + n];
+    nepmi_lan_kick3(state, c1, c2, g_mass[n], vx, vy, vz);
+    g_v[n] = vx;
+    g_v[N + n] = vy;
+    g_v[2 * N + n] = vz;
     g_state[n] = state;
   }
 }
@@ -589,7 +607,7 @@ __global__ void __launch_bounds__(1024) nepmi_momentum_sum(
   if (bid < 3) { // the product and the sum contract to one fma, as in the reference's build of gpu_find_momentum
     const double* __restrict__ v = g_v + (int64_t)bid * N;
     for (int64_t n = tid; n < N; n += 1024)
-      acc += g_mass[n] * v[n];
+      acc = nepmi_momentum_term(acc, g_mass[n], v[n]);
   } else {
     for (int64_t n = tid; n < N; n += 1024)
       acc += g_mass[n];
@@ -610,9 +628,9 @@ __global__ void nepmi_momentum_fix(const int64_t N, const double* __restrict__ s
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < N) {
     const double inverse_of_total_mass = 1.0 / sums4[3];
-    g_v[i] -= sums4[0] * inverse_of_total_mass;
-    g_v[N + i] -= sums4[1] * inverse_of_total_mass;
-    g_v[2 * N + i] -= sums4[2] * inverse_of_total_mass;
+    g_v[i] = nepmi_momentum_fixed(g_v[i], sums4[0], inverse_of_total_mass);
+    g_v[N + i] = nepmi_momentum_fixed(g_v[N + i], sums4[1], inverse_of_total_mass);
+    g_v[2 * N + i] = nepmi_momentum_fixed(g_v[2 * N + i], sums4[2], inverse_of_total_mass);
   }
 }
 
@@ -630,10 +648,11 @@ __global__ void nepmi_lan_kick_resident(
     return;
   const int64_t s = ids ? ids[perm[k]] : (int64_t)perm[k];
   hiprandState state = g_state[s];
-  const double c2m = c2 * sqrt(1.0 / mi[k]);
-  vi[k] = c1 * vi[k] + c2m * hiprand_normal_double(&state);
-  vi[n + k] = c1 * vi[n + k] + c2m * hiprand_normal_double(&state);
-  vi[2 * n + k] = c1 * vi[2 * n + k] + c2m * hiprand_normal_double(&state);
+  double vx = vi[k], vy = vi[n + k], vz = vi[2 * n + k];
+  nepmi_lan_kick3(state, c1, c2, mi[k], vx, vy, vz);
+  vi[k] = vx;
+  vi[n + k] = vy;
+  vi[2 * n + k] = vz;
   g_state[s] = state;
 }
 
@@ -667,7 +686,7 @@ __global__ void __launch_bounds__(1024) nepmi_momentum_sum_resident(
     if (!invp && lvl[k] < 2)
       continue;
     if (bid < 3)
-      acc += mi[k] * vi[(int64_t)bid * n + k];
+      acc = nepmi_momentum_term(acc, mi[k], vi[(int64_t)bid * n + k]);
     else
       acc += mi[k];
   }
@@ -680,6 +699,18 @@ __global__ void __launch_bounds__(1024) nepmi_momentum_sum_resident(
   }
   if (tid == 0)
     sums4[bid] = s_sum[0];
+}
+
+__global__ void nepmi_momentum_fix_resident(const int64_t n, const double* __restrict__ sums4, double* vi,
+                                            const signed char* __restrict__ lvl, const int* flags)
+{
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n || flags[nepmi::kFlagMoved] != 0 || lvl[k] < 2)
+    return;
+  const double inverse_of_total_mass = 1.0 / sums4[3];
+  vi[k] = nepmi_momentum_fixed(vi[k], sums4[0], inverse_of_total_mass);
+  vi[n + k] = nepmi_momentum_fixed(vi[n + k], sums4[1], inverse_of_total_mass);
+  vi[2 * n + k] = nepmi_momentum_fixed(vi[2 * n + k], sums4[2], inverse_of_total_mass);
 }
 
 // ---- Ensemble::find_thermo (ensemble.cu:434-673): 8 sums in one pass over the atoms ----
@@ -1235,6 +1266,11 @@ struct HipBackend {
                              double* sums4, const int* flags)
   {
     hipLaunchKernelGGL(nepmi_momentum_sum_resident, dim3(4), dim3(1024), 0, stream, n, mi, vi, invp, lvl, sums4, flags);
+    NEPMI_HIP_CHECK(hipGetLastError());
+  }
+  void lan_momentum_fix_resident(int64_t n, const double* sums4, double* vi, const signed char* lvl, const int* flags)
+  {
+    hipLaunchKernelGGL(nepmi_momentum_fix_resident, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, stream, n, sums4, vi, lvl, flags);
     NEPMI_HIP_CHECK(hipGetLastError());
   }
   void lan_half(void* states, int64_t n, double c1, double c2, const double* mass, double* vel, double* sums4)

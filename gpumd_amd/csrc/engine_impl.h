@@ -543,7 +543,7 @@ public:
       const double c2 = std::sqrt((1.0 - c1 * c1) * kBoltzmann * target);
       be_.lan_kick_resident(lan_states_, N_, c1, c2, b_.mi, b_.vi, b_.perm, b_.lvl, nullptr, b_.flags);
       be_.lan_momentum_resident(N_, b_.mi, b_.vi, b_.invp, b_.lvl, lan_sums_, b_.flags);
-      be_.template launch<256>(kSlotVV, N_, ResidentMomentumFixBody{b_, lan_sums_});
+      be_.lan_momentum_fix_resident(N_, lan_sums_, b_.vi, b_.lvl, b_.flags);
     };
     const int* frozen = b_.flags + kFlagMoved;
     be_.memset(b_.flags + kFlagMoved, 0, sizeof(int));

@@ -54,23 +54,6 @@ struct ImportStateBody {
   }
 };
 
-// centre-of-mass velocity removed from the owned atoms (gpu_correct_momentum of integrate_nvt_lan_half): sums4 = sum m vx,
-// sum m vy, sum m vz, sum m -- of the whole system (a decomposed run all-reduces them first)
-struct ResidentMomentumFixBody {
-  Bufs b;
-  const double* sums4;
-  NEPMI_HD void operator()(int64_t k) const
-  {
-    if (b.flags[kFlagMoved] != 0 || b.lvl[k] < 2)
-      return;
-    const int64_t N = b.N;
-    const double inverse_of_total_mass = 1.0 / sums4[3];
-    b.vi[k] -= sums4[0] * inverse_of_total_mass;
-    b.vi[N + k] -= sums4[1] * inverse_of_total_mass;
-    b.vi[2 * N + k] -= sums4[2] * inverse_of_total_mass;
-  }
-};
-
 struct ExportStateBody {
   Bufs b;
   double* pos;    // caller order; any of them may be nullptr

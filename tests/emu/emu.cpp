@@ -222,6 +222,16 @@ struct HostLoopBackend {
       }
     }
   }
+  void lan_momentum_fix_resident(int64_t n, const double* sums4, double* vi, const signed char* lvl, const int* flags)
+  {
+    if (flags[kFlagMoved] != 0)
+      return;
+    const double inverse_of_total_mass = 1.0 / sums4[3];
+    for (int64_t k = 0; k < n; ++k)
+      if (lvl[k] >= 2)
+        for (int d = 0; d < 3; ++d)
+          vi[d * n + k] -= sums4[d] * inverse_of_total_mass;
+  }
   void lan_momentum_resident(int64_t n, const double* mi, const double* vi, const int* invp, const signed char* lvl,
                              double* sums4, const int* flags)
   {
