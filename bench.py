@@ -559,6 +559,8 @@ def main():
         eng.set_angular_recompute(int(os.environ["NEPMI_BENCH_RECOMPUTE"]))
     if "NEPMI_BENCH_MFMA" in os.environ:
         eng.set_mfma(os.environ["NEPMI_BENCH_MFMA"] != "0")
+    if "NEPMI_BENCH_LANES" in os.environ:
+        eng.set_win_lanes(int(os.environ["NEPMI_BENCH_LANES"]))
     # initial force (Run::perform_a_run computes it before the loop), then warm-up steps
     eng.force_compute(h, t_type, t_x, t_pe, t_f, t_w)
     if args.warmup > 0:

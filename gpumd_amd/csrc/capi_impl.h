@@ -475,6 +475,14 @@ int nepmi_engine_set_win_lanes(nepmi_engine* e, int lanes)
   return NEPMI_OK;
 }
 
+int nepmi_engine_set_stepwise_loops(nepmi_engine* e, int on)
+{
+  if (!e)
+    return fail(NEPMI_ERR_ARG, "null engine");
+  e->e->set_stepwise_loops(on != 0);
+  return NEPMI_OK;
+}
+
 int nepmi_engine_set_win_static(nepmi_engine* e, int on)
 {
   if (!e)

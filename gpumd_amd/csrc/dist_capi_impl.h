@@ -66,7 +66,7 @@ int nepmi_dist_run(
   nepmi_dist* d, int ensemble, double dt, int64_t nsteps, double t1, double t2, double t_coup, int64_t thermo_every,
   double* thermo_host)
 {
-  if (!d || ensemble < 0 || ensemble > 4 || nsteps < 0) // 0..3 as nepmi_run_*; 4: nvt_lan (BAOAB has no decomposed form)
+  if (!d || ensemble < 0 || ensemble > 5 || nsteps < 0) // 0..3 as nepmi_run_*; 4: nvt_lan, 5: nvt_bao
     return fail(NEPMI_ERR_ARG, "bad argument");
   if (!d->d->engine())
     return fail(NEPMI_ERR_ARG, "nepmi_dist_setup has not been called");

@@ -189,10 +189,10 @@ public:
     // ALL atoms, indexed by global id: it kicks the atoms it owns and advances the other states without using their draws, so
     // an atom's noise is the single-domain run's whatever the decomposition and nothing migrates; the four momentum sums
     // are all-reduced before the centre-of-mass velocity is removed.
-    if (ens == Engine::kLan)
+    if (ens == Engine::kLan || ens == Engine::kBao)
       lan_prepare();
-    auto lan_half = [&](double target) {
-      const double c1 = std::exp(-0.5 / tcoup);
+    auto lan_half = [&](double target, bool whole_step = false) { // whole_step: the O of BAOAB
+      const double c1 = std::exp((whole_step ? -1.0 : -0.5) / tcoup);
       const double c2 = std::sqrt((1.0 - c1 * c1) * kBoltzmann * target);
       const Bufs& bb = e->bufs();
       be_.lan_kick_resident(lan_states_, e->num_atoms(), c1, c2, bb.mi, bb.vi, bb.perm, bb.lvl, cur_.id, bb.flags);
@@ -218,8 +218,14 @@ public:
           nhc_half(target);
         if (ens == Engine::kLan)
           lan_half(target);
-        be_.template launch<256>(kSlotVV, e->num_atoms(),
-                                 ResidentStepBody{e->box(), e->bufs(), dt, kick2_pending ? 1 : 0, 1, tag_of(step)});
+        if (ens == Engine::kBao) { // B A O A (Ensemble_BAO::compute1); noise amplitude of T1
+          be_.template launch<256>(kSlotVV, e->num_atoms(), ResidentBaoBody{e->box(), e->bufs(), dt, 1, 0, tag_of(step)});
+          lan_half(t1, true);
+          be_.template launch<256>(kSlotVV, e->num_atoms(), ResidentBaoBody{e->box(), e->bufs(), dt, 2, 0, tag_of(step)});
+        } else {
+          be_.template launch<256>(kSlotVV, e->num_atoms(),
+                                   ResidentStepBody{e->box(), e->bufs(), dt, kick2_pending ? 1 : 0, 1, tag_of(step)});
+        }
       }
       resume_after_vv1 = false;
       kick2_pending = false;
@@ -303,7 +309,7 @@ public:
         step = (int64_t)trip - 1;
         decompose();
         e = eng_.get();
-        if (ens == Engine::kLan)
+        if (ens == Engine::kLan || ens == Engine::kBao)
           lan_mark_owned();
         resume_after_vv1 = true;
         kick2_pending = false;

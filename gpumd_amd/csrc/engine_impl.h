@@ -512,8 +512,9 @@ public:
     box_from_h9(h9, pbc, box);
     if (n < 1 || n > cap_)
       throw EngineError{-4, "number of atoms exceeds the engine's capacity"};
-    if ((is_small_box(box) && model_.kind == 0) || ens == kBao) {
-      // (BAOAB: its half drifts with the O step in between have no fused form yet: the stepwise loop on the caller's arrays)
+    if ((is_small_box(box) && model_.kind == 0) || (stepwise_loops_ && (ens == kLan || ens == kBao))) {
+      // (set_stepwise_loops: the Langevin ensembles as the plain sequence of the per-call entry points on the caller's
+      // arrays -- what the resident forms are checked against, bit for bit)
       run_md_small_box(ens, h9, pbc, n, type, mass, dt, nsteps, t1, t2, tcoup, pos, vel, pe, force, virial, thermo_every,
                        thermo_host);
       return;
@@ -533,13 +534,13 @@ public:
     }
     if (!factor_dev_)
       factor_dev_ = dalloc<double>(1);
-    if (ens == kLan)
+    if (ens == kLan || ens == kBao)
       lan_prepare(n);
     // Ensemble_LAN (ensemble_lan.cu:96-127, :206-262): one thermostat half-step on the internal velocities.  The generator
     // states stay in the caller's atom order (state perm[k] for internal atom k) and the momentum sums are formed in the
     // caller's order through the inverse permutation: the same numbers as the stepwise nepmi_lan_half_step, bit for bit.
-    auto lan_half = [&](double target) {
-      const double c1 = std::exp(-0.5 / tcoup);
+    auto lan_half = [&](double target, bool whole_step = false) { // whole_step: the O of BAOAB, c1 = exp(-1 / T_coup)
+      const double c1 = std::exp((whole_step ? -1.0 : -0.5) / tcoup);
       const double c2 = std::sqrt((1.0 - c1 * c1) * kBoltzmann * target);
       be_.lan_kick_resident(lan_states_, N_, c1, c2, b_.mi, b_.vi, b_.perm, b_.lvl, nullptr, b_.flags);
       be_.lan_momentum_resident(N_, b_.mi, b_.vi, b_.invp, b_.lvl, lan_sums_, b_.flags);
@@ -600,7 +601,15 @@ public:
           nhc_half(target); // integrate_nvt_nhc_1: thermostat half-step before the first velocity-Verlet half
         if (ens == kLan)
           lan_half(target); // Ensemble_LAN::compute1
-        be_.template launch<256>(kSlotVV, N_, ResidentStepBody{box_, b_, dt, kick2_pending ? 1 : 0, 1, tag_of(step)});
+        if (ens == kBao) {
+          // Ensemble_BAO::compute1 (ensemble_bao.cu:419-446): B A O A; the noise amplitude keeps the temperature the
+          // ensemble was set up with (T1: its c2 is fixed in the constructor, :36)
+          be_.template launch<256>(kSlotVV, N_, ResidentBaoBody{box_, b_, dt, 1, 0, tag_of(step)});
+          lan_half(t1, true);
+          be_.template launch<256>(kSlotVV, N_, ResidentBaoBody{box_, b_, dt, 2, 0, tag_of(step)});
+        } else {
+          be_.template launch<256>(kSlotVV, N_, ResidentStepBody{box_, b_, dt, kick2_pending ? 1 : 0, 1, tag_of(step)});
+        }
       }
       resume_after_vv1 = false;
       kick2_pending = false;
@@ -1566,6 +1575,7 @@ private:
 
 public:
   void set_rows(bool on) { use_rows_ = on; }
+  void set_stepwise_loops(bool on) { stepwise_loops_ = on; }
   // the kernel forms of the last force evaluation (the counted rules above, in words)
   std::string describe() const
   {
@@ -1637,7 +1647,8 @@ private:
   WinLayout win_{0, 0};
   bool win2_ok_ = false, use_win2_ = NEPMI_WIN2_DEFAULT != 0;
   bool use_rows_ = true; // force assembly with the table rows in LDS where they fit
-  bool last_rows_form_ = false, last_fpj_form_ = false; // static window layout (Bufs::wtab / wcode) in use / allowed
+  bool last_rows_form_ = false, last_fpj_form_ = false;
+  bool stepwise_loops_ = false; // test hook: nvt_lan / nvt_bao as the stepwise sequence // static window layout (Bufs::wtab / wcode) in use / allowed
   double* ui_alloc_ = nullptr;
   double* factor_dev_ = nullptr;
   bool tile_ok_ = false, use_tiles_ = true;
@@ -1654,7 +1665,11 @@ private:
   int ann_mode_ = 1;
   int win_lanes_ = 0;
   bool external_skin_ = false;
-  static constexpr int kBrickFill = 253; // of the 256 atom slots of a window-kernel pass (atoms drift between rebuilds;
+#ifndef NEPMI_BRICK_FILL
+#define NEPMI_BRICK_FILL 256 // A/B switch (profiles/ab_variants.sh); r3l: 253 -> 256 lets PbTe 1 M atoms take the 64^3 grid (4,096 full bricks
+                             // instead of 4,913 of which 817 partly filled): force assembly 0.524 -> 0.490 ms, step 1.650 -> 1.596; 264 and 280 pick the same grid
+#endif
+  static constexpr int kBrickFill = NEPMI_BRICK_FILL; // of the 256 atom slots of a window-kernel pass (atoms drift between rebuilds;
                                          // a brick that does overflow just takes a second pass)
   double grid_edge_ = 0.0, grid_h_[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}; // cell edge chosen for this box and atom count
   int64_t grid_n_ = -1;

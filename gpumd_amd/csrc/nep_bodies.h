@@ -283,6 +283,9 @@ struct VelocityVerletBody {
   }
 };
 
+// one coordinate of gpu_operator_A (shared by the stepwise and the resident form: the same expression, the same rounding)
+NEPMI_HD double half_drift_1(const double old, const double v, const double half) { return old + v * half; }
+
 // gpu_operator_A of the BAOAB Langevin integrator (ensemble_bao.cu:224-250): half a drift
 struct HalfDriftBody {
   int64_t N;
@@ -296,7 +299,7 @@ struct HalfDriftBody {
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
       const double old = pos[d * N + i];
-      const double r = old + vel[d * N + i] * half;
+      const double r = half_drift_1(old, vel[d * N + i], half);
       if (unwrapped)
         unwrapped[d * N + i] += r - old;
       pos[d * N + i] = r;

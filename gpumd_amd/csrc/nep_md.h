@@ -187,6 +187,76 @@ struct ResidentStepBody {
   }
 };
 
+// BAOAB (Ensemble_BAO::compute1, ensemble_bao.cu:419-446) on the internal-order state: phase 1 = B (half kick; with do_kick2 the
+// closing B of the previous step first) + A (half drift), then the O step (Langevin kernels), phase 2 = A (half drift) + what
+// Force::compute does to the positions (wrap), the skin check and the lattice-jump / fixed-point bookkeeping of posq.
+struct ResidentBaoBody {
+  BoxD box;
+  Bufs b;
+  double dt;
+  int phase, do_kick2;
+  int step_tag; // phase 2: written to flags[kFlagMoved] when the skin check fires
+  NEPMI_HD void operator()(int64_t k) const
+  {
+#pragma clang fp contract(off)
+    const int mv = b.flags[kFlagMoved];
+    if (mv != 0 && !(phase == 2 && mv == step_tag))
+      return; // a rebuild is pending: frozen
+    if (b.lvl[k] < 2)
+      return;
+    const int64_t N = b.N;
+    const double half = dt * 0.5;
+    PosQ p = b.posq[k];
+    double r[3] = {p.x, p.y, p.z};
+    double v[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+      v[d] = b.vi[d * N + k];
+    if (phase == 1) {
+      const double minv = 1.0 / b.mi[k];
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        const double a = b.fo[(kOutF + d) * N + k] * minv;
+        const double kick = a * half;
+        if (do_kick2)
+          v[d] = v[d] + kick;
+        v[d] = v[d] + kick;
+        b.vi[d * N + k] = v[d];
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const double old = r[d];
+      r[d] = half_drift_1(old, v[d], half);
+      if (b.ui)
+        b.ui[d * N + k] += r[d] - old;
+    }
+    if (phase == 1) {
+      p.x = r[0];
+      p.y = r[1];
+      p.z = r[2];
+      b.posq[k] = p;
+      return;
+    }
+    wrap_position(box, r[0], r[1], r[2]);
+    float dx = (float)(r[0] - b.x0s[k]);
+    float dy = (float)(r[1] - b.x0s[N + k]);
+    float dz = (float)(r[2] - b.x0s[2 * N + k]);
+    int n0, n1, n2;
+    mic_f_img(box, dx, dy, dz, n0, n1, n2);
+    const float d2 = (dx * dx + dy * dy) + dz * dz;
+    if (!((double)d2 <= 0.25))
+      NEPMI_ATOMIC_MAX(&b.flags[kFlagMoved], step_tag);
+    p.x = r[0];
+    p.y = r[1];
+    p.z = r[2];
+    p.pad = pack_img(n0, n1, n2);
+    b.posq[k] = p;
+    if (b.prec)
+      b.prec[k] = make_prec(box, b, k, p);
+  }
+};
+
 // v *= factor for the owned atoms (internal order); factor read from device memory (Berendsen / NHC) or a constant
 struct ResidentScaleBody {
   Bufs b;

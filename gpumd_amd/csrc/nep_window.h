@@ -920,91 +920,79 @@ struct RadialWin2Body {
       return v;
     };
 
-    // ---- list A: angular membership + radial sums; words 0 .. wa-1 ----
+    // ---- list A: angular membership + radial sums; words 0 .. wa-1 (two candidates at a time: register budget) ----
     {
-      f2 SA[TSM][S::KRM + 1];
-#pragma unroll
-      for (int t = 0; t < TSM; ++t)
-#pragma unroll
-        for (int kk = 0; kk <= S::KRM; ++kk)
-          SA[t][kk] = bc2(0.0f);
       U2w w1 = load_word(0, wa), w2 = load_word(1, wa);
       for (int w = 0; w < wa; ++w) {
         const U2w cur = w1;
         w1 = w2;
         w2 = load_word(w + 2, wa);
-        bool nearband = false;
-        Cand c[4];
-        c[0] = judge((int)(cur.lo & 0xFFFFu), true, nearband);
-        c[1] = judge((int)(cur.lo >> 16), true, nearband);
-        c[2] = judge((int)(cur.hi & 0xFFFFu), true, nearband);
-        c[3] = judge((int)(cur.hi >> 16), true, nearband);
-        if (nearband) {
 #pragma unroll
-          for (int u = 0; u < 4; ++u)
-            retake(c[u], true);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int idx = 4 * w + u;
-          const bool live = idx < na; // (a sentinel is never inside a cutoff; `live` guards the amap rows)
-          unsigned short cs = kNoSlot;
-          if (c[u].ang) {
-            if (ca < b.MN_acomp) {
-              F4 e;
-              e.x = c[u].fx * unit;
-              e.y = c[u].fy * unit;
-              e.z = c[u].fz * unit;
-              e.w = c[u].rw;
-              acomp[(int64_t)ca * N] = e;
-              aidx[(int64_t)ca * N] = b.rev_ang[(int64_t)idx * N + k]; // reverse slot of this pair in j's list A
-              cs = (unsigned short)ca;
-              const unsigned bit = 1u << (idx & 31);
-              const int aw = idx >> 5;
-              am[0] |= aw == 0 ? bit : 0u;
-              am[1] |= aw == 1 ? bit : 0u;
-              am[2] |= aw == 2 ? bit : 0u;
-              am[3] |= aw == 3 ? bit : 0u;
-            }
-            ++ca;
+        for (int hh = 0; hh < 2; ++hh) {
+          const unsigned pr = hh == 0 ? cur.lo : cur.hi;
+          bool nearband = false;
+          Cand c[2];
+          c[0] = judge((int)(pr & 0xFFFFu), true, nearband);
+          c[1] = judge((int)(pr >> 16), true, nearband);
+          if (nearband) {
+            retake(c[0], true);
+            retake(c[1], true);
           }
-          if (!b.use_amask && live)
-            amap[(int64_t)idx * N] = cs;
-          if (S::TS == 2 && ((unsigned)c[u].rw >> kIdxBits) == 1u)
-            push_back(c[u]);
-          else
-            push_front(c[u]);
-        }
-        if (S::TS > 0) {
 #pragma unroll
-          for (int u = 0; u < 4; u += 2) {
+          for (int u = 0; u < 2; ++u) {
+            const int idx = 4 * w + 2 * hh + u;
+            const bool live = idx < na; // (a sentinel is never inside a cutoff; `live` guards the amap rows)
+            unsigned short cs = kNoSlot;
+            if (c[u].ang) {
+              if (ca < b.MN_acomp) {
+                F4 e;
+                e.x = c[u].fx * unit;
+                e.y = c[u].fy * unit;
+                e.z = c[u].fz * unit;
+                e.w = c[u].rw;
+                acomp[(int64_t)ca * N] = e;
+                aidx[(int64_t)ca * N] = b.rev_ang[(int64_t)idx * N + k]; // reverse slot of this pair in j's list A
+                cs = (unsigned short)ca;
+                const unsigned bit = 1u << (idx & 31);
+                const int aw = idx >> 5;
+                am[0] |= aw == 0 ? bit : 0u;
+                am[1] |= aw == 1 ? bit : 0u;
+                am[2] |= aw == 2 ? bit : 0u;
+                am[3] |= aw == 3 ? bit : 0u;
+              }
+              ++ca;
+            }
+            if (!b.use_amask && live)
+              amap[(int64_t)idx * N] = cs;
+            if (S::TS == 2 && ((unsigned)c[u].rw >> kIdxBits) == 1u)
+              push_back(c[u]);
+            else
+              push_front(c[u]);
+          }
+          if (S::TS > 0 && !ZIP) { // one type: the two candidates side by side
             f2 fn[S::KRM + 1];
-            basis2(c[u], c[u + 1], fn);
-            if (TSM == 1) {
+            basis2(c[0], c[1], fn);
+#pragma unroll
+            for (int kk = 0; kk <= S::KRM; ++kk)
+              SS[kk] = SS[kk] + fn[kk];
+          } else if (ZIP) {
+            // two types, mixed order: each candidate in both halves, the half of its type carries the weight (list A is a
+            // quarter of the candidates; separate per-type rows would cost 28 registers over the whole kernel)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              f2 fn[S::KRM + 1];
+              basis2(c[u], c[u], fn);
+              const bool one = ((unsigned)c[u].rw >> kIdxBits) == 1u;
+              const f2 wt = mk2(one ? 0.0f : 1.0f, one ? 1.0f : 0.0f);
 #pragma unroll
               for (int kk = 0; kk <= S::KRM; ++kk)
-                SA[0][kk] = SA[0][kk] + fn[kk];
-            } else {
-#pragma unroll
-              for (int t = 0; t < TSM; ++t) {
-                const f2 wt = mk2((int)((unsigned)c[u].rw >> kIdxBits) == t ? 1.0f : 0.0f,
-                                  (int)((unsigned)c[u + 1].rw >> kIdxBits) == t ? 1.0f : 0.0f);
-#pragma unroll
-                for (int kk = 0; kk <= S::KRM; ++kk)
-                  SA[t][kk] = vfma(wt, fn[kk], SA[t][kk]);
-              }
+                SS[kk] = vfma(wt, fn[kk], SS[kk]);
             }
+          } else {
+            accumulate1(c[0]);
+            accumulate1(c[1]);
           }
-        } else {
-#pragma unroll
-          for (int u = 0; u < 4; ++u)
-            accumulate1(c[u]);
         }
-      }
-      if (S::TS > 0) {
-#pragma unroll
-        for (int kk = 0; kk <= S::KRM; ++kk)
-          SS[kk] = ZIP ? mk2(SA[0][kk].x + SA[0][kk].y, SA[TSM - 1][kk].x + SA[TSM - 1][kk].y) : SA[0][kk];
       }
     }
     if (b.use_amask) {
@@ -1777,7 +1765,10 @@ struct ForceWinBody {
     // (CW: after the radial loop, whose software pipeline needs the registers of these twelve sums)
     float F[3] = {0, 0, 0};
     float Wa[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}; // xx yy zz xy xz yz yx zx zy
-    if (!CW)
+#ifndef NEPMI_FW_ANG_LAST
+#define NEPMI_FW_ANG_LAST 1 // 1: the angular part runs after the radial loop (its twelve sums are not live across the loop)
+#endif
+    if (!CW && !NEPMI_FW_ANG_LAST)
       win_force_angular<L>(b, k, sub, F, Wa);
 
     // ---- radial part over the compact list: every entry is a pair inside the cutoff ----
@@ -1968,7 +1959,7 @@ struct ForceWinBody {
       }
     }
 
-    if (CW)
+    if (CW || NEPMI_FW_ANG_LAST)
       win_force_angular<L>(b, k, sub, F, Wa);
     if (L > 1) {
 #pragma unroll

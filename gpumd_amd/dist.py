@@ -14,7 +14,7 @@ import numpy as np
 
 from . import _capi
 
-ENSEMBLES = {"nve": 0, "nvt_ber": 1, "nvt_nhc": 2, "nvt_bdp": 3, "nvt_lan": 4}
+ENSEMBLES = {"nve": 0, "nvt_ber": 1, "nvt_nhc": 2, "nvt_bdp": 3, "nvt_lan": 4, "nvt_bao": 5}
 
 
 def choose_grid(world):

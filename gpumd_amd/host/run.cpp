@@ -1067,9 +1067,8 @@ void Run::perform_a_run_dist()
       input_error("unwrapped positions are not tracked in multi-GPU runs.");
   const int N = atom.number_of_atoms;
   const bool root = par_.rank == 0;
-  if (ensemble == "nvt_bao")
-    input_error("ensemble nvt_bao is not available in multi-GPU runs (nve, nvt_ber, nvt_nhc, nvt_bdp, nvt_lan).");
-  const int ens = ensemble == "nve" ? 0 : ensemble == "nvt_ber" ? 1 : ensemble == "nvt_nhc" ? 2 : ensemble == "nvt_bdp" ? 3 : 4;
+  const int ens = ensemble == "nve" ? 0 : ensemble == "nvt_ber" ? 1 : ensemble == "nvt_nhc" ? 2 : ensemble == "nvt_bdp" ? 3
+                  : ensemble == "nvt_lan" ? 4 : 5;
   if (root && dump_thermo_interval > 0) {
     FILE* fid = std::fopen("thermo.out", "a");
     std::fprintf(fid, "# dump_thermo %d\n# format_version 1\n# num_atoms %d\n# dt_output %.10e fs\n", dump_thermo_interval, N,
@@ -1094,8 +1093,8 @@ void Run::perform_a_run_dist()
     die_on(nepmi_dist_bdp_seed(dist_, (uint64_t)seed), "bdp_seed");
     std::printf("    BDP noise seed = %llu.\n", (unsigned long long)((std::mt19937::result_type)seed));
   }
-  if (ens == 4) {
-    // Ensemble_LAN's constructor seeds the per-atom generators with rand() (ensemble_lan.cu:39): rank 0 draws, every rank uses it
+  if (ens == 4 || ens == 5) {
+    // Ensemble_LAN's / Ensemble_BAO's constructor seeds the per-atom generators with rand() (ensemble_lan.cu:39): rank 0 draws, every rank uses it
     int64_t seed = root ? (int64_t)host_rand() : 0;
     boot_.allreduce(boot_.ctx, &seed, 1, 2, 0, nullptr);
     die_on(nepmi_dist_lan_seed(dist_, (int)seed), "lan_seed");

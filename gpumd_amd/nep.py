@@ -313,6 +313,10 @@ class NEP:
             self._ck(n)
         return buf.value.decode()
 
+    def set_stepwise_loops(self, on=True):
+        """test hook: run_nvt_lan / run_nvt_bao as the stepwise sequence on the caller's arrays"""
+        self._ck(self.lib.nepmi_engine_set_stepwise_loops(self.handle, int(bool(on))))
+
     def set_win_static(self, on=True):
         """static window layout of the one-lane window kernels (default on); False = the scanned layout"""
         self._ck(self.lib.nepmi_engine_set_win_static(self.handle, int(bool(on))))

@@ -226,7 +226,8 @@ int nepmi_run_nvt_bdp(
  *      c2 = sqrt((1 - c1^2) k_B T), three normal draws per atom, then the centre-of-mass velocity is removed (the four
  *      sums in gpu_find_momentum's order: with the same seed the velocities equal the reference kernels' bit for bit).
  *      A step of the ensemble: lan_half_step, vv_step1, force, vv_step2, lan_half_step, find_thermo.
- *      nepmi_run_nvt_lan is that loop on the caller's arrays (the states follow the caller's atom order). ---- */
+ *      nepmi_run_nvt_lan is that loop, device-resident (the states stay in the caller's atom order; bit-identical to the
+ *      sequence above). ---- */
 int nepmi_lan_seed(nepmi_engine* e, int seed);
 int nepmi_lan_half_step(nepmi_engine* e, int64_t n, double temperature, double t_coup, const double* mass, double* vel);
 int nepmi_run_nvt_lan(
@@ -297,14 +298,14 @@ int nepmi_dist_setup(
   const int64_t* ids);
 /* Force::compute on the decomposed system (the initial force of Run::perform_a_run). */
 int nepmi_dist_compute(nepmi_dist* d);
-/* The run loop for ensemble 0 = nve, 1 = nvt_ber, 2 = nvt_nhc, 3 = nvt_bdp, 4 = nvt_lan (see nepmi_run_*); thermo_host (HOST,
+/* The run loop for ensemble 0 = nve, 1 = nvt_ber, 2 = nvt_nhc, 3 = nvt_bdp, 4 = nvt_lan, 5 = nvt_bao (see nepmi_run_*); thermo_host (HOST,
  * 8 doubles per record, may be NULL) receives the GLOBAL T, U and stresses on every rank. */
 int nepmi_dist_run(
   nepmi_dist* d, int ensemble, double dt, int64_t nsteps, double t1, double t2, double t_coup,
   int64_t thermo_every, double* thermo_host);
 int nepmi_dist_thermo(nepmi_dist* d, double thermo8_host[8]);
 int nepmi_dist_bdp_seed(nepmi_dist* d, uint64_t seed);
-/* Langevin thermostat of a decomposed run (ensemble 4 of nepmi_dist_run = `ensemble nvt_lan`, Ensemble_LAN): the seed of the
+/* Langevin thermostats of a decomposed run (ensembles 4 and 5 of nepmi_dist_run = `ensemble nvt_lan` / `nvt_bao`): the seed of the
  * per-atom generators, the same value on every rank (the reference seeds them with rand(), ensemble_lan.cu:39).  State s belongs
  * to the atom with global id s exactly as in the single-domain nepmi_run_nvt_lan, so the noise of an atom does not depend on the
  * decomposition: every rank carries all states, kicks the atoms it owns and advances the others. */
@@ -393,6 +394,9 @@ int nepmi_engine_set_win_lanes(nepmi_engine* e, int lanes);
  * (two-type models: list B as two type-pure streams); on = 0 keeps the per-launch scan of the window cells and the
  * (window cell, rank) codes.  Same lists bit for bit, sums differ by their order only.  Forces a list rebuild. */
 int nepmi_engine_set_win_static(nepmi_engine* e, int on);
+/* Test hook: on = 1 makes nepmi_run_nvt_lan / nepmi_run_nvt_bao run as the plain sequence of the per-call steps on the caller's
+ * arrays (what they were before they became device-resident loops); the resident forms reproduce it bit for bit. */
+int nepmi_engine_set_stepwise_loops(nepmi_engine* e, int on);
 /* How the per-atom ANN runs.  on = 1 (default): inside the angular-descriptor kernel where the shape allows it (one
  * lane per atom, at most 4 types: the descriptor never leaves the registers), else the matrix-core
  * (v_mfma_f32_32x32x2_f32) ANN kernel; on = 2: the matrix-core kernel wherever it applies; on = 0: the per-atom ANN

@@ -79,6 +79,7 @@ CASES = [
     (2, "PbTe-reps", (4, 2, 2), (2, 1, 1), "nvt_bdp", 16, 2000.0),
     (2, "PbTe-reps", (4, 2, 2), (2, 1, 1), "nvt_lan", 16, 2000.0),  # Langevin: an atom's noise does not depend on the decomposition
     (4, "PbTe-reps", (3, 3, 2), (2, 2, 1), "nvt_lan", 12, 2000.0),
+    (2, "PbTe-reps", (4, 2, 2), (2, 1, 1), "nvt_bao", 16, 2000.0),  # BAOAB
     (2, "C-2022", (12, 6, 6), (2, 1, 1), "nve", 10, 3000.0),       # config 5's model through the ghost levels
     (2, "C-2022", (12, 6, 6), (2, 1, 1), "nvt_ber", 10, 3000.0),   # config 5: NVT on the decomposed path
     (2, "UNEP-v1", (10, 5, 5), (2, 1, 1), "nve", 8, 3000.0),       # config 4's model (16 types, ZBL)

@@ -75,7 +75,8 @@ def test_single_rank_run_against_the_oracle(tmp_path):
     assert np.abs(rs["pos"] - fr[1]["pos"]).max() < 1e-4  # restart (full precision) vs the single-precision dump
 
 
-@pytest.mark.parametrize("ens", ["nve", "nvt_ber 1500 1000 20", "nvt_nhc 1500 1000 20", "nvt_lan 1500 1000 20"])
+@pytest.mark.parametrize("ens", ["nve", "nvt_ber 1500 1000 20", "nvt_nhc 1500 1000 20", "nvt_lan 1500 1000 20",
+                                 "nvt_bao 1500 1500 20"])
 def test_two_ranks_write_the_same_files_as_one(tmp_path, ens):
     """One process per GPU: thermo.out, dump_xyz (every atom gathered to rank 0 in file order) and restart.xyz of a
     2-rank run equal the single-rank run's to FP32 summation noise."""

@@ -163,3 +163,36 @@ def test_resident_nvt_lan_equals_the_stepwise_sequence_on_emulator():
 @pytest.mark.gpu
 def test_resident_nvt_lan_equals_the_stepwise_sequence_on_gpu():
     _resident_loop_equals_stepwise(H.GpuDriver())
+
+
+def _resident_bao_equals_stepwise(drv):
+    """nepmi_run_nvt_bao device-resident (B A O A on the internal-order state, speculative enqueue, rebuilds inside) against the
+    stepwise sequence of the same engine (nepmi_engine_set_stepwise_loops): bit for bit."""
+    h, typ, x = H.pbte_supercell((3, 3, 3), seed=4)
+    n = len(typ)
+    mass = np.where(typ == 0, H.MASS["Te"], H.MASS["Pb"]).astype(np.float64)
+    vel = H.maxwell_velocities(mass, 1500.0, seed=9)
+    model = drv.model(H.golden("PbTe", "nep.txt"))
+    out = []
+    for stepwise in (False, True):
+        eng = drv.engine(model, n)
+        eng.set_stepwise_loops(stepwise)
+        d_t, d_m, d_x, d_v = [drv.dev(a) for a in (typ, mass, x.copy(), vel.copy())]
+        pe, f, w = drv.zeros(n), drv.zeros(3 * n), drv.zeros(9 * n)
+        eng.force_compute(h, d_t, d_x, pe, f, w, n=n)
+        eng.lan_seed(77)
+        th = eng.run_nvt_bao(h, d_t, d_m, 2.0 / H.TIME_UNIT, 40, 600.0, 600.0, 50.0, d_x, d_v, pe, f, w, thermo_every=10)
+        out.append((drv.host(d_x), drv.host(d_v), th, eng.stats().num_rebuild))
+    assert out[0][3] >= 2 and out[0][3] == out[1][3]
+    assert np.array_equal(out[0][1], out[1][1]), np.abs(out[0][1] - out[1][1]).max()
+    assert np.array_equal(out[0][0], out[1][0]), np.abs(out[0][0] - out[1][0]).max()
+    np.testing.assert_allclose(out[0][2], out[1][2], rtol=1e-12)
+
+
+def test_resident_nvt_bao_equals_the_stepwise_sequence_on_emulator():
+    _resident_bao_equals_stepwise(H.EmuDriver())
+
+
+@pytest.mark.gpu
+def test_resident_nvt_bao_equals_the_stepwise_sequence_on_gpu():
+    _resident_bao_equals_stepwise(H.GpuDriver())
