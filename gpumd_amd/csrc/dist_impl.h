@@ -22,6 +22,8 @@
 // memory -- the same driver code, used by the CPU test tier and by ranks that share one GPU.
 #pragma once
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <unordered_map>
 #include "../../include/nepmi.h"
@@ -671,8 +673,22 @@ private:
     decompose_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
   }
 
+  // NEPMI_DIST_TRACE=1: wall time of the phases of every (re-)decomposition on stderr (synchronised: a diagnostic, not the product path)
   void decompose_body()
   {
+    const bool trace = std::getenv("NEPMI_DIST_TRACE") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    std::string tline;
+    auto mark = [&](const char* what) {
+      if (!trace)
+        return;
+      be_.sync();
+      const auto now = std::chrono::steady_clock::now();
+      char buf[64];
+      std::snprintf(buf, sizeof buf, " %s %.2f", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+      tline += buf;
+      t_last = now;
+    };
     const int me = tr_.rank, P = tr_.nranks;
     if (resident_) {
       // owned state back to local order (positions in local coordinates, velocities)
@@ -704,6 +720,7 @@ private:
       h_dest.resize((size_t)n_own);
       be_.d2h(h_dest.data(), dest, sizeof(int) * n_own);
     }
+    mark("owners");
     // 2. who sends how many to whom (all ranks learn the whole matrix)
     std::vector<int64_t> mat((size_t)P * P, 0);
     std::vector<std::vector<int>> by_dest(P);
@@ -739,6 +756,7 @@ private:
       }
     }
     exchange((int)sends.size(), sends.data(), (int)recvs.size(), recvs.data());
+    mark("migrate");
     // 4. new owned set: stayers in their order, then the arrivals by source rank
     const int64_t n_own_new = n_stay + n_arrive;
     // capacity of the local system: the ghost shell's share of the padded sub-box at uniform density, with 30 % headroom
@@ -765,6 +783,7 @@ private:
     be_.sync();
     for (double* p : sbuf) pfree(p);
     for (double* p : rbuf) pfree(p);
+    mark("gather");
     // 5. ghost stages over the decomposed directions
     for (auto& st : stages_)
       free_stage(st);
@@ -845,6 +864,7 @@ private:
       be_.sync();
       stages_.push_back(st);
     }
+    mark("ghosts");
     // 6. repack to stride n_loc, levels
     State& C = cur_;
     if (C.cap < n_loc + 1)
@@ -854,6 +874,7 @@ private:
     C.n_own = n_own_new;
     if (n_loc > 0)
       be_.template launch<256>(kSlotMisc, n_loc, LevelBody{geom_, n_loc, n_own_new, C.x, C.lvl});
+    mark("repack");
     // 7. engine: lists on the local system, internal index lists of the halo, integrator state
     if (!eng_ || n_loc > eng_cap_) {
       eng_cap_ = n_loc + n_loc / 7 + 1024;
@@ -881,6 +902,7 @@ private:
       if (any)
         throw EngineError{-6, failed ? what : std::string("another rank exceeded a neighbour list capacity at the rebuild")};
     }
+    mark("lists");
     e.resident_alloc();
     e.resident_import(C.v, C.m, nullptr, nullptr, nullptr);
     int* inv = iscratch(10, n_loc + 1);
@@ -896,6 +918,9 @@ private:
                                  MapIndexBody{inv, nullptr, st.off_recv[1], st.recv_int + st.cnt_recv[0]});
     }
     be_.sync();
+    mark("maps");
+    if (trace)
+      std::fprintf(stderr, "[nepmi dist rank %d] decomposition %lld (ms):%s\n", me, (long long)num_decompositions, tline.c_str());
     resident_ = true;
     ++num_decompositions;
   }
