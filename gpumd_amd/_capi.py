@@ -51,7 +51,8 @@ class NepmiTransport(C.Structure):
 
 class NepmiDistInfo(C.Structure):
     _fields_ = [("n_owned", c_i64), ("n_local", c_i64), ("n_total", c_i64), ("num_decompositions", c_i64),
-                ("num_steps", c_i64), ("num_overlapped", c_i64), ("decompose_ms", C.c_double)]
+                ("num_steps", c_i64), ("num_overlapped", c_i64), ("decompose_ms", C.c_double),
+                ("reverse_ghosts", c_i64)]
 
 
 # every symbol include/nepmi.h declares: name -> (restype, argtypes)
@@ -124,6 +125,7 @@ SYMBOLS = {
     "nepmi_dist_bdp_seed": (C.c_int, [VP, C.c_uint64]),
     "nepmi_dist_lan_seed": (C.c_int, [VP, C.c_int]),
     "nepmi_dist_set_overlap": (C.c_int, [VP, C.c_int]),
+    "nepmi_dist_set_ghost_mode": (C.c_int, [VP, C.c_int]),
     "nepmi_dist_get_info": (C.c_int, [VP, C.POINTER(NepmiDistInfo)]),
     "nepmi_dist_gather_owned": (C.c_int, [VP, VP, VP, VP, VP, VP, VP]),
     "nepmi_dist_gather_global": (C.c_int, [VP, C.c_int, VP, VP, VP, VP, VP]),

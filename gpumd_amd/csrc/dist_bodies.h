@@ -209,10 +209,15 @@ struct LevelBody {
   int64_t n, n_own;
   const double* x;
   signed char* level;
+  int all_inner; // reverse-mode ghosts: the shell IS the inner ring
   NEPMI_HD void operator()(int64_t i) const
   {
     if (i < n_own) {
       level[i] = 2;
+      return;
+    }
+    if (all_inner) {
+      level[i] = 1;
       return;
     }
     double s[3];
@@ -271,6 +276,51 @@ struct HaloPackBody {
       out1[cnt1 + r] = p.y + shift1[1];
       out1[2 * cnt1 + r] = p.z + shift1[2];
     }
+  }
+};
+// Reverse-mode ghosts: planes [first, first + planes) of Bufs::fo (forces: kOutF, 3; virials: kOutW, 9) of the ghosts one
+// stage received -> [planes][cnt] per message, back to the ranks the ghosts came from ...
+struct GhostForcePackBody {
+  Bufs b;
+  const int* idx; // internal indices of the received ghosts, cnt0 + cnt1 entries
+  int64_t cnt0, cnt1;
+  int first, planes;
+  double* out0;
+  double* out1;
+  NEPMI_HD void operator()(int64_t q) const
+  {
+    if (b.flags[kFlagMoved] != 0)
+      return;
+    const int64_t N = b.N;
+    const int k = idx[q];
+    const bool lower = q < cnt0;
+    const int64_t r = lower ? q : q - cnt0, cnt = lower ? cnt0 : cnt1;
+    double* out = lower ? out0 : out1;
+    for (int p = 0; p < planes; ++p)
+      out[p * cnt + r] = b.fo[(int64_t)(first + p) * N + k];
+  }
+};
+// ... where they are added to the atoms that were sent (owned atoms, or ghosts of an earlier stage that travel on in the next
+// reverse stage).  The two messages of a stage in one launch when no atom sits in both send lists (a sub-box at least two
+// shells wide: DistT::reverse_exchange), else one launch per message.
+struct GhostForceAddBody {
+  Bufs b;
+  const int* idx; // internal indices of the atoms sent: cnt0 of message 0, then cnt1 of message 1
+  int64_t cnt0, cnt1;
+  int first, planes;
+  const double* in0;
+  const double* in1;
+  NEPMI_HD void operator()(int64_t q) const
+  {
+    if (b.flags[kFlagMoved] != 0)
+      return;
+    const int64_t N = b.N;
+    const int k = idx[q];
+    const bool lower = q < cnt0;
+    const int64_t r = lower ? q : q - cnt0, cnt = lower ? cnt0 : cnt1;
+    const double* in = lower ? in0 : in1;
+    for (int p = 0; p < planes; ++p)
+      b.fo[(int64_t)(first + p) * N + k] += in[p * cnt + r];
   }
 };
 // received ghost positions -> posq (internal order), with the lattice-jump bookkeeping and the fixed-point record of

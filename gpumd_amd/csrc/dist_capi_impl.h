@@ -110,6 +110,13 @@ int nepmi_dist_set_overlap(nepmi_dist* d, int on)
   return NEPMI_OK;
 }
 
+int nepmi_dist_set_ghost_mode(nepmi_dist* d, int mode)
+{
+  if (!d)
+    return fail(NEPMI_ERR_ARG, "null handle");
+  return guarded([&] { d->d->set_ghost_mode(mode); });
+}
+
 int nepmi_dist_get_info(nepmi_dist* d, nepmi_dist_info* out)
 {
   if (!d || !out)
@@ -121,6 +128,7 @@ int nepmi_dist_get_info(nepmi_dist* d, nepmi_dist_info* out)
   out->num_steps = d->d->num_steps;
   out->num_overlapped = d->d->num_overlapped;
   out->decompose_ms = d->d->decompose_ms;
+  out->reverse_ghosts = d->d->reverse_ghosts() ? 1 : 0;
   return NEPMI_OK;
 }
 

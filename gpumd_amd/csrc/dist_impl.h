@@ -61,36 +61,22 @@ public:
       hg_[k] = h9[k];
     }
     volume_ = gb.volume;
-    const double rc = model.rc_radial_max;
     const int r = tr.rank;
     g.coords[0] = r % grid[0];
     g.coords[1] = (r / grid[0]) % grid[1];
     g.coords[2] = r / (grid[0] * grid[1]);
-    double ext[3] = {1, 1, 1}, org[3] = {0, 0, 0};
     for (int d = 0; d < 3; ++d) {
       g.grid[d] = grid[d];
       g.pbc[d] = pbc[d] ? 1 : 0;
       g.decomposed[d] = grid[d] > 1;
       g.lo[d] = (double)g.coords[d] / grid[d];
       g.hi[d] = (double)(g.coords[d] + 1) / grid[d];
-      g.wfrac[d] = (2.0 * rc + 2.0 * kSkin) / gb.thickness[d];
-      g.ifrac[d] = (rc + kSkin) / gb.thickness[d];
-      if (g.decomposed[d]) {
-        if (g.wfrac[d] > 1.0 / grid[d])
-          throw EngineError{-3, "domain thinner than the ghost shell 2 (rc + skin) in a decomposed direction"};
-        ext[d] = (g.hi[d] - g.lo[d]) + 2.0 * g.wfrac[d];
-        org[d] = g.lo[d] - g.wfrac[d];
-      }
+      thick_[d] = gb.thickness[d];
       pbc_loc_[d] = g.decomposed[d] ? 0 : g.pbc[d];
     }
-    // local box handed to the engine: the ghost-padded sub-box, open in the decomposed directions
-    for (int c = 0; c < 3; ++c) {
-      g.origin[c] = 0.0;
-      for (int d = 0; d < 3; ++d) {
-        h_loc_[3 * c + d] = g.H[3 * c + d] * ext[d];
-        g.origin[c] += g.H[3 * c + d] * org[d];
-      }
-    }
+    if (const char* env = std::getenv("NEPMI_DIST_GHOSTS")) // experiments: "forward" / "reverse" instead of the counted rule
+      ghost_mode_ = env[0] == 'r' ? 1 : (env[0] == 'f' ? 0 : -1);
+    configure_shell();
     flag_dev_ = (int*)be_.alloc(sizeof(int) * 4);
     sums_dev_ = (double*)be_.alloc(sizeof(double) * 8);
     thermo_dev_ = (double*)be_.alloc(sizeof(double) * 8);
@@ -154,6 +140,26 @@ public:
     decompose();
   }
 
+  // Ghost shell and what the ghosts are for.
+  //   forward (0): shell 2 (rc + skin), the reference's ranges (nep_multigpu.cuh:42-50): the inner ring's descriptors are
+  //     recomputed, forces only on owned atoms, one exchange per step (positions);
+  //   reverse (1): shell rc + skin, descriptors / ANN / partial forces for owned atoms only; the force assembly runs on the
+  //     ghosts as well and yields there the pair halves -f21 that this rank's owned atoms contribute (a ghost's own rows are
+  //     zero), which travel back to the owners: a second exchange per step (3 doubles per ghost), no redundant descriptor
+  //     work -- the strong-scaling form (SURVEY.md:541-546);
+  //   -1: the counted rule -- reverse when the forward shell would leave less than 70 % of the local atoms owned (uniform
+  //     density: the volume ratio of the sub-box and its padded box), or when the sub-box is too thin for the forward shell.
+  void set_ghost_mode(int mode)
+  {
+    if (cur_.cap != 0)
+      throw EngineError{-4, "nepmi_dist_set_ghost_mode: call it before nepmi_dist_setup"};
+    if (mode < -1 || mode > 1)
+      throw EngineError{-4, "ghost mode: -1 (counted rule), 0 (forward), 1 (reverse)"};
+    ghost_mode_ = mode;
+    configure_shell();
+  }
+  bool reverse_ghosts() const { return reverse_; }
+
   int64_t num_owned() const { return cur_.n_own; }
   int64_t num_local() const { return cur_.n; }
   int64_t num_total() const { return n_total_; }
@@ -165,6 +171,7 @@ public:
   {
     halo_exchange();
     eng_->force_kernels(Engine::kPhaseAll);
+    force_reverse();
     ++eng_->num_compute;
     have_force_ = true;
   }
@@ -250,6 +257,7 @@ public:
         be_.join_from(comm);
       if (!trip) {
         e->force_kernels(split ? Engine::kPhaseBoundary : Engine::kPhaseAll, frozen());
+        force_reverse();
         const bool record = thermo_every > 0 && (step + 1) % thermo_every == 0;
         const bool last = step + 1 == nsteps;
         bool need_sync = record || last;
@@ -338,6 +346,8 @@ public:
   void gather_owned(int64_t* ids, double* pos, double* vel, double* force, double* pe, double* virial)
   {
     Engine& e = *eng_;
+    if (virial)
+      fold_virial();
     be_.template launch<256>(kSlotMisc, e.num_atoms(),
                              GatherOwnedBody{e.bufs(), geom_, cur_.n_own, cur_.id, ids, pos, vel, force, pe, virial});
     be_.sync();
@@ -348,6 +358,7 @@ public:
   void gather_global(int root, double* pos, double* vel, double* force, double* pe, double* virial)
   {
     Engine& e = *eng_;
+    fold_virial(); // collective: every rank, whether or not the root asked for the virials
     const int P = tr_.nranks, me = tr_.rank;
     const int64_t no = cur_.n_own;
     std::vector<int64_t> cnt((size_t)P, 0);
@@ -625,7 +636,7 @@ private:
     Engine& e = *eng_;
     const Bufs& b = e.bufs();
     be_.thermo(kSlotThermo, e.num_atoms(), volume_, b.mi, b.fo, b.vi, b.fo + (int64_t)kOutW * e.num_atoms(), sums_dev_,
-               e.thermo_scratch(), b.lvl, 1, 0);
+               e.thermo_scratch(), b.lvl, 1, 0, (reverse_ && !virial_folded_) ? 1 : 2);
     device_allreduce(sums_dev_, 8, kDtF64, kOpSum);
     be_.template launch<64>(kSlotMisc, 1, ThermoNormBody{sums_dev_, (double)n_total_, volume_, thermo_dev_});
   }
@@ -661,6 +672,92 @@ private:
       if (r0 + r1 > 0)
         on.template launch<256>(kSlotMisc, r0 + r1,
                                 HaloUnpackBody{e.box(), e.bufs(), st.recv_int, r0, r1, st.recvbuf, st.recvbuf + 3 * r0});
+    }
+  }
+
+  // ---- reverse mode: per-step reverse communication of what the force assembly left on the ghosts ----
+  // The stages in reverse order; in each, the planes of the ghosts received from a peer go back to it and are added to the
+  // atoms it had sent (owned atoms, or ghosts of an earlier stage, which the next reverse stage carries on).
+  void reverse_exchange(int first, int planes)
+  {
+    Engine& e = *eng_;
+    for (size_t si = stages_.size(); si-- > 0;) {
+      Stage& st = stages_[si];
+      const int64_t c0 = st.cnt_send[0], c1 = st.cnt_send[1], r0 = st.cnt_recv[0], r1 = st.cnt_recv[1];
+      if (r0 + r1 > 0)
+        be_.template launch<256>(kSlotMisc, r0 + r1, GhostForcePackBody{e.bufs(), st.recv_int, r0, r1, first, planes, st.recvbuf,
+                                                                         st.recvbuf + (int64_t)planes * r0});
+      TransportMsg s[2], r[2];
+      int ns = 0, nr = 0;
+      const int64_t pb = (int64_t)sizeof(double) * planes;
+      if (r0) s[ns++] = TransportMsg{st.recvbuf, pb * r0, st.peer_recv[0]};
+      if (r1) s[ns++] = TransportMsg{st.recvbuf + (int64_t)planes * r0, pb * r1, st.peer_recv[1]};
+      if (c0) r[nr++] = TransportMsg{st.sendbuf, pb * c0, st.peer_send[0]};
+      if (c1) r[nr++] = TransportMsg{st.sendbuf + (int64_t)planes * c0, pb * c1, st.peer_send[1]};
+      exchange(ns, s, nr, r);
+      const double* in1 = st.sendbuf + (int64_t)planes * c0;
+      if (geom_.wfrac[st.d] * 2.0 <= 1.0 / geom_.grid[st.d]) { // the lower and the upper shell of the sub-box do not meet
+        if (c0 + c1 > 0)
+          be_.template launch<256>(kSlotMisc, c0 + c1, GhostForceAddBody{e.bufs(), st.send_int, c0, c1, first, planes, st.sendbuf, in1});
+      } else {
+        if (c0)
+          be_.template launch<256>(kSlotMisc, c0, GhostForceAddBody{e.bufs(), st.send_int, c0, 0, first, planes, st.sendbuf, in1});
+        if (c1)
+          be_.template launch<256>(kSlotMisc, c1, GhostForceAddBody{e.bufs(), st.send_int + c0, c1, 0, first, planes, in1, in1});
+      }
+    }
+  }
+  void force_reverse()
+  {
+    virial_folded_ = false;
+    if (reverse_)
+      reverse_exchange(kOutF, 3);
+  }
+  // per-atom virials for output: the halves computed on other ranks' ghosts come home once per force evaluation (the run
+  // loop only needs the global sum, which thermo_global takes over owned atoms AND ghosts until then)
+  void fold_virial()
+  {
+    if (!reverse_ || virial_folded_ || !have_force_)
+      return;
+    reverse_exchange(kOutW, 9);
+    virial_folded_ = true;
+  }
+
+  // shell width, local box and origin for the chosen ghost mode (constructor; set_ghost_mode before setup)
+  void configure_shell()
+  {
+    DomainGeom& g = geom_;
+    const double rc = model_.rc_radial_max;
+    double owned_frac = 1.0;
+    bool forward_fits = true;
+    for (int d = 0; d < 3; ++d)
+      if (g.decomposed[d]) {
+        const double w = (2.0 * rc + 2.0 * kSkin) / thick_[d];
+        owned_frac *= (1.0 / g.grid[d]) / (1.0 / g.grid[d] + 2.0 * w);
+        forward_fits = forward_fits && w <= 1.0 / g.grid[d];
+      }
+    reverse_ = ghost_mode_ == 1 || (ghost_mode_ < 0 && model_.kind == 0 && (owned_frac < 0.7 || !forward_fits));
+    if (reverse_ && model_.kind != 0)
+      throw EngineError{-4, "reverse-mode ghosts: NEP models only"};
+    double ext[3] = {1, 1, 1}, org[3] = {0, 0, 0};
+    for (int d = 0; d < 3; ++d) {
+      g.ifrac[d] = (rc + kSkin) / thick_[d];
+      g.wfrac[d] = reverse_ ? g.ifrac[d] : 2.0 * g.ifrac[d];
+      if (g.decomposed[d]) {
+        if (g.wfrac[d] > 1.0 / g.grid[d])
+          throw EngineError{-3, reverse_ ? "domain thinner than the ghost shell rc + skin in a decomposed direction"
+                                         : "domain thinner than the ghost shell 2 (rc + skin) in a decomposed direction"};
+        ext[d] = (g.hi[d] - g.lo[d]) + 2.0 * g.wfrac[d];
+        org[d] = g.lo[d] - g.wfrac[d];
+      }
+    }
+    // local box handed to the engine: the ghost-padded sub-box, open in the decomposed directions
+    for (int c = 0; c < 3; ++c) {
+      g.origin[c] = 0.0;
+      for (int d = 0; d < 3; ++d) {
+        h_loc_[3 * c + d] = g.H[3 * c + d] * ext[d];
+        g.origin[c] += g.H[3 * c + d] * org[d];
+      }
     }
   }
 
@@ -826,8 +923,9 @@ private:
       st.send_idx = (int*)palloc(sizeof(int) * (cst + 1));
       st.send_int = (int*)palloc(sizeof(int) * (cst + 1));
       st.recv_int = (int*)palloc(sizeof(int) * (crt + 1));
-      st.sendbuf = (double*)palloc(sizeof(double) * 4 * (cst + 1));
-      st.recvbuf = (double*)palloc(sizeof(double) * 4 * (crt + 1));
+      const int bw = reverse_ ? 9 : 4; // doubles per atom: [x y z type] of the ghost stages; reverse mode: up to nine virial planes
+      st.sendbuf = (double*)palloc(sizeof(double) * bw * (cst + 1));
+      st.recvbuf = (double*)palloc(sizeof(double) * bw * (crt + 1));
       if (cs[0]) copy_dev(st.send_idx, gidx[0], sizeof(int) * cs[0]);
       if (cs[1]) copy_dev(st.send_idx + cs[0], gidx[1], sizeof(int) * cs[1]);
       TransportMsg s[2], r[2];
@@ -873,13 +971,14 @@ private:
     C.n = n_loc;
     C.n_own = n_own_new;
     if (n_loc > 0)
-      be_.template launch<256>(kSlotMisc, n_loc, LevelBody{geom_, n_loc, n_own_new, C.x, C.lvl});
+      be_.template launch<256>(kSlotMisc, n_loc, LevelBody{geom_, n_loc, n_own_new, C.x, C.lvl, reverse_ ? 1 : 0});
     mark("repack");
     // 7. engine: lists on the local system, internal index lists of the halo, integrator state
     if (!eng_ || n_loc > eng_cap_) {
       eng_cap_ = n_loc + n_loc / 7 + 1024;
       std::unique_ptr<Engine> grown(new Engine(model_, eng_cap_, be_));
       grown->set_external_skin(true); // the global vote is the skin policy
+      grown->set_reverse_ghosts(reverse_);
       grown->bdp_seed(seed_);
       if (eng_) // a grown local system: the switches, the temperature, the noise sequence and the counters move over
         grown->adopt_from(*eng_);
@@ -986,6 +1085,9 @@ private:
   bool resident_ = false, have_force_ = false;
   bool nhc_fresh_ = true;
   bool overlap_ = true;  // interior bricks' radial pass while the ghost positions travel
+  int ghost_mode_ = -1;  // set_ghost_mode
+  bool reverse_ = false, virial_folded_ = false;
+  double thick_[3] = {0, 0, 0};
   B side_;               // the backend on the communication stream (device transports)
   bool side_ready_ = false;
   uint64_t seed_ = 12345678u;

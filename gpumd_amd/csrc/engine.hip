@@ -189,7 +189,7 @@ nepmi_ann_mfma(const ModelD m, const Bufs b, const int64_t nchunks, const int* f
     {
       const int gl = tile + lane;
       k_cur = b.tperm[gl < end ? gl : lo];
-      act_cur = (gl < end && b.lvl[k_cur] >= 1) ? 1 : 0;
+      act_cur = (gl < end && b.lvl[k_cur] >= b.lvl_desc) ? 1 : 0;
     }
     // q and fp are stored in work order: column g of the [dim][N] arrays is work item g
     int gc = min(tile + col, end - 1);
@@ -208,7 +208,7 @@ nepmi_ann_mfma(const ModelD m, const Bufs b, const int64_t nchunks, const int* f
         const int gl = tile + 64 * kAnnStride + lane;
         const bool more = tile + 64 * kAnnStride < end;
         k_nxt = b.tperm[(more && gl < end) ? gl : lo];
-        act_nxt = (more && gl < end && b.lvl[k_nxt] >= 1) ? 1 : 0;
+        act_nxt = (more && gl < end && b.lvl[k_nxt] >= b.lvl_desc) ? 1 : 0;
       }
       const int actc = __shfl(act_cur, nt * 32 + col);
       nepmi_f32x16 acc[MT];
@@ -727,12 +727,16 @@ __device__ __forceinline__ double wave_sum(double v)
 
 __global__ void __launch_bounds__(kThermoBlock) nepmi_thermo_partial(
   int64_t n, const double* __restrict__ mass, const double* __restrict__ pe, const double* __restrict__ vel,
-  const double* __restrict__ virial, const signed char* __restrict__ lvl, double* __restrict__ partial)
+  const double* __restrict__ virial, const signed char* __restrict__ lvl, double* __restrict__ partial, int virial_lvl)
 {
   double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   for (int64_t i = (int64_t)blockIdx.x * kThermoBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kThermoBlock) {
-    if (lvl && lvl[i] < 2)
-      continue; // domain decomposition: ghosts carry no state
+    if (lvl && lvl[i] < 2) { // domain decomposition: ghosts carry no state ...
+      if (lvl[i] >= virial_lvl) // ... but, with reverse-mode ghosts, the virial of the pair halves computed on them
+        for (int q = 0; q < 6; ++q)
+          s[2 + q] += virial[(int64_t)q * n + i];
+      continue;
+    }
     const double m = mass[i];
     const double vx = vel[i], vy = vel[n + i], vz = vel[2 * n + i];
     s[0] += (vx * vx + vy * vy + vz * vz) * m;
@@ -1228,13 +1232,13 @@ struct HipBackend {
   void thermo(
     int slot, int64_t n, double volume, const double* mass, const double* pe, const double* vel,
     const double* virial, double* thermo8, double* scratch, const signed char* lvl = nullptr, int raw = 0,
-    int64_t n_norm = 0)
+    int64_t n_norm = 0, int virial_lvl = 2)
   {
     int64_t nb = (n + kThermoBlock - 1) / kThermoBlock;
     if (nb > kThermoMaxBlocks)
       nb = kThermoMaxBlocks;
     hipLaunchKernelGGL(
-      nepmi_thermo_partial, dim3((unsigned)nb), dim3(kThermoBlock), 0, stream, n, mass, pe, vel, virial, lvl, scratch);
+      nepmi_thermo_partial, dim3((unsigned)nb), dim3(kThermoBlock), 0, stream, n, mass, pe, vel, virial, lvl, scratch, virial_lvl);
     hipLaunchKernelGGL(nepmi_thermo_final, dim3(1), dim3(64), 0, stream, (int)nb, n_norm > 0 ? n_norm : n, volume, scratch,
                        thermo8, raw);
     NEPMI_HIP_CHECK(hipGetLastError());

@@ -1255,6 +1255,14 @@ private:
       be_.d2h(flags, b_.flags, sizeof(flags));
       check_overflow(flags);
     }
+    if (reverse_ghosts_ && b_.level) {
+      // the rows a ghost would have written in forward mode are read by its neighbours' (and its own) force assembly: zero
+      // = no contribution; owned atoms rewrite theirs every step
+      be_.memset(b_.atab, 0, sizeof(float) * (size_t)cap_ * model_.num_types * b_.KRP);
+      be_.memset(b_.f12, 0, sizeof(F4) * (size_t)b_.MN_acomp * cap_);
+      if (b_.fpr)
+        be_.memset(b_.fpr, 0, sizeof(float) * (size_t)cap_ * b_.FPR);
+    }
     have_list_ = true;
     ++num_rebuild;
   }
@@ -1376,6 +1384,19 @@ public:
   // invalidate()): no per-step flag read-back, the force path is enqueued without a host round trip.
   // List-capacity overflow is then reported at the next rebuild or stats() call.
   void set_external_skin(bool on) { external_skin_ = on; }
+  // Reverse-mode ghosts of a decomposed run (Bufs::lvl_desc / lvl_force): descriptors, ANN and partial forces for owned atoms
+  // only; the force assembly also runs on the ghosts, whose own rows stay zero, and leaves on each the halves its owned
+  // neighbours contribute -- DistT sends them to the owners.  NEP models only.
+  void set_reverse_ghosts(bool on)
+  {
+    if (on && model_.kind != 0)
+      throw EngineError{-4, "reverse-mode ghosts: NEP models only"};
+    reverse_ghosts_ = on;
+    b_.lvl_desc = on ? 2 : 1;
+    b_.lvl_force = on ? 1 : 2;
+    invalidate();
+  }
+  bool reverse_ghosts() const { return reverse_ghosts_; }
   void reset_thermostat() { nhc_fresh_ = true; }
   // caller-owned [3N] array that every first-half-step drift is also added to (atom.unwrapped_position)
   void set_unwrapped(double* u) { unwrapped_ = u; }
@@ -1423,6 +1444,8 @@ public:
     win_lanes_ = o.win_lanes_;
     use_win2_ = o.use_win2_;
     external_skin_ = o.external_skin_;
+    if (reverse_ghosts_ != o.reverse_ghosts_)
+      set_reverse_ghosts(o.reverse_ghosts_);
     unwrapped_ = o.unwrapped_;
     nhc_fresh_ = o.nhc_fresh_;
     bdp_rng_ = o.bdp_rng_;
@@ -1674,6 +1697,7 @@ private:
   double grid_edge_ = 0.0, grid_h_[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}; // cell edge chosen for this box and atom count
   int64_t grid_n_ = -1;
   double* unwrapped_ = nullptr;
+  bool reverse_ghosts_ = false;  // see set_reverse_ghosts
   bool split_pending_ = false;   // compute_levels_begin ran, compute_levels_end has not yet
   int64_t num_boundary_bricks_ = 0;
   int64_t num_bricks_ = 0;

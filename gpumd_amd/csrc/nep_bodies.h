@@ -127,6 +127,12 @@ struct Bufs {
   int* flags;  // [kNumFlags]
   const signed char* level; // caller order, or nullptr: 2 owned, 1 inner ghost, 0 outer ghost
   signed char* lvl;         // [N] the same in internal order (sampled at list rebuild)
+  // Which levels do what.  Default (forward-only ghosts, shell 2 (rc + skin)): descriptors, ANN and partial angular forces for
+  // level >= 1, compact radial list and force assembly for level 2.  Reverse mode (shell rc + skin, every ghost level 1): the
+  // former for owned atoms only, the latter for ghosts too -- a ghost's table rows, Fp rows and f12 rows stay zero (cleared at
+  // the rebuild), so its force assembly yields exactly the halves -f21 its OWNED neighbours contribute, which the decomposed
+  // driver adds to the owner's force (dist_impl.h: reverse exchange).
+  signed char lvl_desc = 1, lvl_force = 2;
   signed char* angf;        // [N] 1 = this atom's partial angular forces f12 are needed: it is owned, or an inner-ring ghost with an
                             // owned atom in its list A (decided at the rebuild; nobody reads the f12 of the other ghosts)
   int* tperm;               // [N] atoms ordered by (chunk of 1024, type): the ANN kernel's work order
@@ -730,7 +736,7 @@ struct BuildListsBody {
     }
     b.nn_ang[k] = cnta;
     b.nn_skin[k] = cntb;
-    b.angf[k] = (b.lvl[k] >= 2 || (b.lvl[k] == 1 && near_owned)) ? 1 : 0;
+    b.angf[k] = (b.lvl[k] >= 2 || (b.lvl[k] >= b.lvl_desc && near_owned)) ? 1 : 0;
   }
 };
 
@@ -1663,7 +1669,7 @@ struct AngularDescBody {
   {
     constexpr int NLOC = (S::NAM + PARTS) / PARTS;
     const int64_t N = b.N;
-    if (b.lvl[k] < 1)
+    if (b.lvl[k] < b.lvl_desc)
       return;
     const int64_t gk = b.tpos[k]; // q / fp column of this atom (work order)
     const int NR = S::fixed ? S::NR : m.NR;
@@ -1782,7 +1788,7 @@ struct AnnBody {
   {
     const int64_t N = b.N;
     const int64_t k = b.tperm[g]; // type-grouped work order
-    if (b.lvl[k] < 1)
+    if (b.lvl[k] < b.lvl_desc)
       return;
     const int NR = S::fixed ? S::NR : m.NR;
     const int KR = S::fixed ? S::KR : m.KR;
@@ -1914,7 +1920,7 @@ struct AngularForceBody {
   {
     constexpr int NLOC = (S::NAM + PARTS) / PARTS;
     const int64_t N = b.N;
-    if (b.lvl[k] < 1 || (b.level && !b.angf[k])) // outer ghosts; inner-ring ghosts whose f12 no owned atom will read
+    if (b.lvl[k] < b.lvl_desc || (b.level && !b.angf[k])) // outer ghosts; inner-ring ghosts whose f12 no owned atom will read
       return;
     const int64_t gk = b.tpos[k]; // q / fp column of this atom (work order)
     const int NR = S::fixed ? S::NR : m.NR;
@@ -2173,7 +2179,7 @@ struct ForceAssembleBody {
   NEPMI_HD void run_parts(int64_t k, int part, const Src& src) const
   {
     const int64_t N = b.N;
-    if (b.lvl[k] < 2) // forces only for owned atoms
+    if (b.lvl[k] < b.lvl_force) // forces only for owned atoms (reverse mode: the neighbour halves on the ghosts too)
       return;
     const int KR = S::fixed ? S::KR : m.KR;
     const int t1 = b.posq[k].type;
@@ -2327,7 +2333,7 @@ struct ForceAssembleBody {
       if (part != 0)
         return;
     }
-    double E = (double)b.pe_i[k];
+    double E = b.lvl[k] >= 2 ? (double)b.pe_i[k] : 0.0;
     double Fd[3] = {(double)F[0], (double)F[1], (double)F[2]};
     double Wd[9];
     Wd[0] = (double)(W[0] + Wa[0]);
@@ -2339,7 +2345,7 @@ struct ForceAssembleBody {
     Wd[6] = (double)(W[3] + Wa[6]);
     Wd[7] = (double)(W[4] + Wa[7]);
     Wd[8] = (double)(W[5] + Wa[8]);
-    if (m.zbl_enabled) {
+    if (m.zbl_enabled && b.lvl[k] >= 2) { // (a reverse-mode ghost: its pair potential is its owner's business)
 #pragma unroll
       for (int d = 0; d < 3; ++d)
         Fd[d] += (double)b.zbl[(int64_t)d * N + k];

@@ -98,7 +98,7 @@ struct HighLDescBody {
   NEPMI_HD void operator()(int64_t k) const
   {
     const int64_t N = b.N;
-    if (b.lvl[k] < 1)
+    if (b.lvl[k] < b.lvl_desc)
       return;
     const int64_t gk = b.tpos[k];
     const int NR = m.NR, NA = m.NA, KA = m.KA, Lmax = m.Lmax;
@@ -206,7 +206,7 @@ struct HighLForceBody {
   NEPMI_HD void operator()(int64_t k) const
   {
     const int64_t N = b.N;
-    if (b.lvl[k] < 1 || (b.level && !b.angf[k]))
+    if (b.lvl[k] < b.lvl_desc || (b.level && !b.angf[k]))
       return;
     const int64_t gk = b.tpos[k];
     const int NA = m.NA, KA = m.KA, Lmax = m.Lmax;

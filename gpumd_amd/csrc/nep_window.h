@@ -360,7 +360,7 @@ struct RadialWinBody {
       q[n] = 0.0f;
 
     const int na = b.nn_ang[k], nbn = b.nn_skin[k];
-    const bool owned = b.lvl[k] >= 2;
+    const bool owned = b.lvl[k] >= b.lvl_force; // ("owned" = its force assembly runs and reads the compact list)
     unsigned am_cur = 0u; // membership bits of the current 32 entries of list A (Bufs::amask)
     int cnt = 0, cnt1 = 0, ca = 0; // cnt: entries at the front of ccode, cnt1: at its back (type-1 neighbours)
     F4* __restrict__ acomp = b.acomp + k;
@@ -723,7 +723,7 @@ struct RadialWin2Body {
       q[n] = 0.0f;
 
     const int na = b.nn_ang[k];
-    const bool owned = b.lvl[k] >= 2;
+    const bool owned = b.lvl[k] >= b.lvl_force; // ("owned" = its force assembly runs and reads the compact list)
     const int seg = b.wseg[k];
     const int wa = seg & 255, wb = (seg >> 8) & 255; // words of list A; words (ZIP: word pairs) of list B
     unsigned am[4] = {0u, 0u, 0u, 0u}; // membership bits of list A (Bufs::amask)
@@ -1747,7 +1747,7 @@ struct ForceWinBody {
   {
     const Bufs& b = st.b;
     const int64_t N = b.N;
-    if (b.lvl[k] < 2) // forces only for owned atoms
+    if (b.lvl[k] < b.lvl_force) // forces only for owned atoms (reverse mode: the neighbour halves on the ghosts too)
       return;
     NEPMI_LDS(const WinRec)* wrec = (NEPMI_LDS(const WinRec)*)(lds + st.lay.off_rec());
     const int KR = S::fixed ? S::KR : m.KR;
@@ -1980,7 +1980,7 @@ struct ForceWinBody {
         return;
     }
     // ---- outputs, internal order ----
-    double E = (double)b.pe_i[k];
+    double E = b.lvl[k] >= 2 ? (double)b.pe_i[k] : 0.0;
     double Fd[3], Wd[9];
 #pragma unroll
     for (int d = 0; d < 3; ++d)
@@ -1998,7 +1998,7 @@ struct ForceWinBody {
     Wd[6] = (double)(Wr[3] + Wa[6]);
     Wd[7] = (double)(Wr[4] + Wa[7]);
     Wd[8] = (double)(Wr[5] + Wa[8]);
-    if (m.zbl_enabled) {
+    if (m.zbl_enabled && b.lvl[k] >= 2) { // (a reverse-mode ghost: its pair potential is its owner's business)
 #pragma unroll
       for (int d = 0; d < 3; ++d)
         Fd[d] += (double)b.zbl[(int64_t)d * N + k];

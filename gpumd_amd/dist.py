@@ -63,7 +63,9 @@ class Transport:
 
 
 class DistMD:
-    def __init__(self, model, transport, h9, pbc, grid, stream=None):
+    def __init__(self, model, transport, h9, pbc, grid, stream=None, ghost_mode=None):
+        """ghost_mode: None / -1 the counted rule, 0 forward ghosts (shell 2 (rc + skin), one exchange per step),
+        1 reverse ghosts (shell rc + skin, forces of the ghosts travel back): nepmi_dist_set_ghost_mode"""
         self.lib = model.lib
         self.model = model
         self.transport = transport
@@ -76,6 +78,8 @@ class DistMD:
             p.ctypes.data_as(C.POINTER(C.c_int)), g.ctypes.data_as(C.POINTER(C.c_int)), sp)
         if not self.handle:
             raise _capi.NepmiError(-5, self.lib.nepmi_last_error().decode())
+        if ghost_mode is not None:
+            self._ck(self.lib.nepmi_dist_set_ghost_mode(self.handle, int(ghost_mode)))
 
     @staticmethod
     def _ptr(t):

@@ -1009,6 +1009,10 @@ void Run::setup_dist(const std::vector<std::string>& p)
     input_error(nepmi_last_error());
   std::printf("Use %d GPUs: process grid %d x %d x %d, ghost exchange over %s.\n", P, grid[0], grid[1], grid[2],
               par_.use_rccl ? "RCCL" : "TCP sockets");
+  nepmi_dist_info info;
+  nepmi_dist_get_info(dist_, &info);
+  std::printf(info.reverse_ghosts ? "    ghost shell rc + skin, the ghosts' partial forces return to their owners (two exchanges per step).\n"
+                                  : "    ghost shell 2 (rc + skin), descriptors of the inner ring recomputed (one exchange per step).\n");
 }
 
 // this rank's share of the atoms goes to the driver at the first run (the velocity keyword may follow potential)

@@ -314,11 +314,23 @@ int nepmi_dist_lan_seed(nepmi_dist* d, int seed);
  * compute stream while the skin vote and the ghost positions travel on a communication stream; off: the plain
  * exchange-then-compute order.  Both orders give bit-identical results. */
 int nepmi_dist_set_overlap(nepmi_dist* d, int on);
+/* What the ghost atoms are for; call between nepmi_dist_create and nepmi_dist_setup (the shell width shapes the local box).
+ *   0 forward: shell 2 (rc + skin), the reference's ranges (src/force/nep_multigpu.cuh:42-50) -- descriptors of the inner ring
+ *     rc + skin recomputed on every rank that sees them, forces for owned atoms only, ONE exchange per step (positions);
+ *   1 reverse: shell rc + skin, descriptors / network / partial forces for owned atoms only; the force assembly also runs on the
+ *     ghosts and leaves on each the pair halves this rank's owned atoms contribute, which travel back to the owner and are
+ *     added there: a SECOND exchange per step (3 doubles per ghost), no redundant descriptor work, 1.4 instead of 1.9 local
+ *     atoms per owned one for a 1 M-atom PbTe cell on 2 x 2 x 2 ranks -- the form for strong scaling.  NEP models only;
+ *  -1 (default) the counted rule: reverse when the forward shell would leave less than 70 % of the local atoms owned at
+ *     uniform density (volume of the sub-box / volume of its padded box), or when the sub-box is thinner than the forward
+ *     shell.  Per-atom virials of nepmi_dist_gather_* are completed by one extra reverse exchange when asked for. */
+int nepmi_dist_set_ghost_mode(nepmi_dist* d, int mode);
 typedef struct {
   int64_t n_owned, n_local, n_total; /* atoms owned by this rank, owned + ghosts, in the whole system */
   int64_t num_decompositions, num_steps;
   int64_t num_overlapped; /* steps whose interior radial pass was enqueued before the ghost exchange completed */
   double decompose_ms;    /* wall time spent in the (re-)decompositions so far: migration, ghost stages, list rebuild */
+  int64_t reverse_ghosts; /* 1: reverse-mode ghosts (nepmi_dist_set_ghost_mode), 0: forward */
 } nepmi_dist_info;
 int nepmi_dist_get_info(nepmi_dist* d, nepmi_dist_info* out);
 /* The owned atoms of this rank (n_owned entries per plane, global coordinates) into the caller's DEVICE arrays;

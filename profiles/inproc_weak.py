@@ -31,6 +31,9 @@ def main():
     ap.add_argument("--strong", action="store_true",
                     help="strong scaling: ONE block of --reps cells shared by the ranks (most cubic grid) against the same block as "
                          "one domain -- the work the decomposition adds when a fixed system is cut into R sub-boxes")
+    ap.add_argument("--ghosts", type=int, default=-1,
+                    help="nepmi_dist_set_ghost_mode: -1 the counted rule, 0 forward (shell 2 (rc + skin)), 1 reverse (shell rc + skin, "
+                         "the ghosts' partial forces return to the owners)")
     ap.add_argument("--only", default="both", choices=["both", "ranks", "one"], help="profiling: run only one of the two legs")
     args = ap.parse_args()
     import torch
@@ -75,7 +78,7 @@ def main():
                 assert tlib.inproc_transport(group, rank, C.byref(t)) == 0
                 tr = Transport(lib, t)
                 stream = torch.cuda.Stream()
-                md = DistMD(model, tr, Hg.reshape(9), (1, 1, 1), (world, 1, 1), stream=stream)
+                md = DistMD(model, tr, Hg.reshape(9), (1, 1, 1), (world, 1, 1), stream=stream, ghost_mode=args.ghosts)
                 md.setup(torch.from_numpy(np.ascontiguousarray(T)).to(dev), torch.from_numpy(np.ascontiguousarray(M)).to(dev),
                          torch.from_numpy(np.ascontiguousarray(X).reshape(-1)).to(dev),
                          torch.from_numpy(np.ascontiguousarray(V).reshape(-1)).to(dev))
@@ -90,7 +93,7 @@ def main():
                 barrier.wait()
                 times[rank] = time.perf_counter() - t0
                 i = md.info()
-                infos[rank] = (int(i.n_owned), int(i.n_local), int(i.num_decompositions), float(i.decompose_ms))
+                infos[rank] = (int(i.n_owned), int(i.n_local), int(i.num_decompositions), float(i.decompose_ms), int(i.reverse_ghosts))
                 md.close()
                 tr.close()
             except BaseException as e:  # noqa: BLE001
@@ -126,7 +129,7 @@ def main():
                 assert tlib.inproc_transport(group, rank, C.byref(t)) == 0
                 tr = Transport(lib, t)
                 stream = torch.cuda.Stream()
-                md = DistMD(model, tr, Hb.reshape(9), (1, 1, 1), grid, stream=stream)
+                md = DistMD(model, tr, Hb.reshape(9), (1, 1, 1), grid, stream=stream, ghost_mode=args.ghosts)
                 md.setup(torch.from_numpy(np.ascontiguousarray(typ[mine])).to(dev),
                          torch.from_numpy(np.ascontiguousarray(mass[mine])).to(dev),
                          torch.from_numpy(np.ascontiguousarray(x.reshape(3, n)[:, mine]).reshape(-1)).to(dev),
@@ -142,7 +145,7 @@ def main():
                 barrier.wait()
                 times[rank] = time.perf_counter() - t0
                 i = md.info()
-                infos[rank] = (int(i.n_owned), int(i.n_local), int(i.num_decompositions), float(i.decompose_ms))
+                infos[rank] = (int(i.n_owned), int(i.n_local), int(i.num_decompositions), float(i.decompose_ms), int(i.reverse_ghosts))
                 md.close()
                 tr.close()
             except BaseException as e:  # noqa: BLE001
@@ -162,6 +165,10 @@ def main():
             os._exit(3)
         return max(times), infos
 
+    if args.strong and args.only != "both":
+        t, info = run_strong(R if args.only == "ranks" else 1)
+        print(json.dumps({"mode": "strong", "ms_per_step": t / args.steps * 1e3, "info": info}))
+        return
     if args.only == "ranks":
         t_multi, info_multi = run(R, 1)
         print(json.dumps({"ms_per_step": t_multi / args.steps * 1e3, "info": info_multi}))
@@ -173,7 +180,7 @@ def main():
     if args.strong:
         t_multi, info_multi = run_strong(R)
         t_single, info_single = run_strong(1)
-        print(json.dumps({"mode": "strong", "ranks": R, "atoms_total": sum(i[0] for i in info_multi),
+        print(json.dumps({"mode": "strong", "ranks": R, "reverse_ghosts": info_multi[0][4], "atoms_total": sum(i[0] for i in info_multi),
                           "owned_per_rank": [i[0] for i in info_multi], "local_per_rank": [i[1] for i in info_multi],
                           "ms_per_step_ranks_sharing_one_gpu": t_multi / args.steps * 1e3,
                           "ms_per_step_one_domain": t_single / args.steps * 1e3, "work_inflation": t_multi / t_single,
@@ -182,7 +189,7 @@ def main():
     t_multi, info_multi = run(R, 1)
     t_single, info_single = run(1, R)
     n_total = sum(i[0] for i in info_multi)
-    out = {"ranks": R, "atoms_per_rank": info_multi[0][0], "local_atoms_per_rank": [i[1] for i in info_multi],
+    out = {"ranks": R, "reverse_ghosts": info_multi[0][4], "atoms_per_rank": info_multi[0][0], "local_atoms_per_rank": [i[1] for i in info_multi],
            "steps": args.steps, "ms_per_step_ranks_sharing_one_gpu": t_multi / args.steps * 1e3,
            "ms_per_step_one_domain_same_atoms": t_single / args.steps * 1e3,
            "decomposition_overhead": t_multi / t_single,

@@ -50,7 +50,7 @@ def run_rank(out_dir, spec, rank, world, make_transport, stream=None):
     mine = np.arange(n) % world == rank  # arbitrary initial distribution; setup() migrates
     ids = np.arange(n, dtype=np.int64)[mine]
     tr = make_transport(drv)
-    md = DistMD(model, tr, h, (1, 1, 1), spec["grid"], stream=stream)
+    md = DistMD(model, tr, h, (1, 1, 1), spec["grid"], stream=stream, ghost_mode=spec.get("ghosts"))
     md.setup(drv.dev(typ[mine]), drv.dev(mass[mine]), drv.dev(np.ascontiguousarray(x.reshape(3, n)[:, mine]).reshape(-1)),
              drv.dev(np.ascontiguousarray(vel.reshape(3, n)[:, mine]).reshape(-1)), drv.dev(ids))
     if "overlap" in spec:
@@ -74,9 +74,15 @@ def run_rank(out_dir, spec, rank, world, make_transport, stream=None):
                 thermo_every=spec.get("thermo_every", 0))
     i1, x1, v1, f1 = snapshot()
     th1 = md.thermo()
+    # per-atom virials (reverse-mode ghosts: completed by one more reverse exchange), and the global sums afterwards
+    no = md.info().n_owned
+    d_w = drv.zeros(9 * no)
+    md.gather_owned(None, None, None, None, None, d_w)
+    w1 = drv.host(d_w).reshape(9, no)
+    th2 = md.thermo()
     info = md.info()
-    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), i0=i0, f0=f0, th0=th0, i1=i1, x1=x1, v1=v1, f1=f1, th1=th1, th=th,
-             n_loc=info.n_local, n_own=info.n_owned, ndec=info.num_decompositions, nover=info.num_overlapped)
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), i0=i0, f0=f0, th0=th0, i1=i1, x1=x1, v1=v1, f1=f1, th1=th1, th=th, w1=w1, th2=th2,
+             n_loc=info.n_local, n_own=info.n_owned, reverse=info.reverse_ghosts, ndec=info.num_decompositions, nover=info.num_overlapped)
     md.close()
     tr.close()
 

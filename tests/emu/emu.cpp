@@ -276,13 +276,18 @@ struct HostLoopBackend {
 
   void thermo(
     int, int64_t n, double volume, const double* mass, const double* pe, const double* vel,
-    const double* virial, double* th, double*, const signed char* lvl = nullptr, int raw = 0, int64_t n_norm = 0)
+    const double* virial, double* th, double*, const signed char* lvl = nullptr, int raw = 0, int64_t n_norm = 0,
+    int virial_lvl = 2)
   {
     double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const double *vx = vel, *vy = vel + n, *vz = vel + 2 * n;
     for (int64_t i = 0; i < n; ++i) {
-      if (lvl && lvl[i] < 2)
+      if (lvl && lvl[i] < 2) {
+        if (lvl[i] >= virial_lvl)
+          for (int q = 0; q < 6; ++q)
+            s[2 + q] += virial[(int64_t)q * n + i];
         continue;
+      }
       const double m = mass[i];
       s[0] += (vx[i] * vx[i] + vy[i] * vy[i] + vz[i] * vz[i]) * m;
       s[1] += pe[i];

@@ -86,9 +86,10 @@ CASES = [
 ]
 
 
-def _spec(device, model, reps, grid, ensemble, nsteps, temp):
+def _spec(device, model, reps, grid, ensemble, nsteps, temp, ghosts=None):
     return {"device": device, "model": model, "reps": list(reps), "grid": list(grid), "ensemble": ensemble, "nsteps": nsteps,
-            "temp": temp, "dt_fs": 2.0, "t1": temp, "t2": 0.5 * temp, "tcoup": 20.0, "thermo_every": 4, "seed": 777}
+            "temp": temp, "dt_fs": 2.0, "t1": temp, "t2": 0.5 * temp, "tcoup": 20.0, "thermo_every": 4, "seed": 777,
+            "ghosts": ghosts}
 
 
 def _natoms(model, reps):
@@ -101,6 +102,66 @@ def test_decomposed_run_matches_single_domain(world, model, reps, grid, ensemble
     multi, _ = _check(world, _spec("cpu", model, reps, grid, ensemble, nsteps, temp), _natoms(model, reps))
     if model == "PbTe-reps" and ensemble == "nve":
         assert max(int(r["ndec"]) for r in multi) >= 2  # atoms really moved past skin/2: migration + new ghosts
+
+
+REVERSE_CASES = [
+    # reverse-mode ghosts (nepmi_dist_set_ghost_mode 1): shell rc + skin, the ghosts' partial forces travel back to the owners
+    (2, "PbTe-reps", (4, 2, 2), (2, 1, 1), "nve", 20, 3000.0),
+    (4, "PbTe-reps", (3, 3, 2), (2, 2, 1), "nve", 20, 3000.0),      # two stages: edge ghosts are forwarded, and so are their forces
+    (8, "PbTe-reps", (3, 3, 3), (2, 2, 2), "nve", 12, 3000.0),      # three stages (the grid of a strong-scaling run on 8 GPUs)
+    (2, "PbTe-reps", (4, 2, 2), (2, 1, 1), "nvt_nhc", 16, 2000.0),
+    (2, "PbTe-reps", (4, 2, 2), (2, 1, 1), "nvt_lan", 16, 2000.0),
+    (2, "C-2022", (12, 6, 6), (2, 1, 1), "nve", 10, 3000.0),
+    (2, "UNEP-v1", (10, 5, 5), (2, 1, 1), "nve", 8, 3000.0),        # ZBL: a pair potential, never computed on a ghost
+]
+
+
+def _check_reverse(device, world, model, reps, grid, ensemble, nsteps, temp):
+    n = _natoms(model, reps)
+    multi, single = _check(world, _spec(device, model, reps, grid, ensemble, nsteps, temp, ghosts=1), n)
+    fwd = _run_ranks(world, _spec(device, model, reps, grid, "nve", 0, temp, ghosts=0))
+    for r, q in zip(multi, fwd):
+        assert int(r["reverse"]) == 1 and int(q["reverse"]) == 0
+        assert int(r["n_own"]) <= int(r["n_loc"]) < int(q["n_loc"])  # the thinner shell
+        # the six stress components: the virial halves left on the ghosts are part of the global sum
+        np.testing.assert_allclose(r["th1"][2:], single[0]["th1"][2:], rtol=2e-4, atol=2e-6)
+        np.testing.assert_allclose(r["th0"][2:], single[0]["th0"][2:], rtol=2e-4, atol=2e-6)
+        np.testing.assert_allclose(r["th2"], r["th1"], rtol=1e-9, atol=1e-12)  # the same sums once the virials are home
+    # per-atom virials in the order of the ids
+    def virials(ranks):
+        ids = np.concatenate([r["i1"] for r in ranks])
+        return np.concatenate([r["w1"] for r in ranks], axis=1)[:, np.argsort(ids)]
+    wm, ws = virials(multi), virials(single)
+    assert np.abs(wm - ws).max() < 1e-4 + 2e-5 * np.abs(ws).max(), np.abs(wm - ws).max()
+    return multi, single
+
+
+@pytest.mark.parametrize("world,model,reps,grid,ensemble,nsteps,temp", REVERSE_CASES)
+def test_reverse_ghosts_match_single_domain(world, model, reps, grid, ensemble, nsteps, temp):
+    _check_reverse("cpu", world, model, reps, grid, ensemble, nsteps, temp)
+
+
+def test_thin_subboxes_take_reverse_ghosts_by_the_counted_rule():
+    """Five slabs of 15.2 A: thinner than the forward shell 2 (rc + skin) = 18 A, so the rule (no mode set) picks reverse
+    ghosts; the lower and the upper shell of a slab overlap, i.e. an atom can be a ghost of both neighbours and its two
+    returned force parts are added one after the other."""
+    spec = _spec("cpu", "PbTe-reps", (4, 2, 2), (5, 1, 1), "nve", 16, 3000.0)
+    multi, _ = _check(5, spec, _natoms("PbTe-reps", (4, 2, 2)))
+    assert all(int(r["reverse"]) == 1 for r in multi)
+    with pytest.raises(AssertionError, match="thinner than the ghost shell 2"):
+        _run_ranks(5, dict(spec, ghosts=0, nsteps=0))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,model,reps,grid,ensemble,nsteps,temp", [
+    (2, "PbTe-reps", (4, 2, 2), (2, 1, 1), "nve", 20, 3000.0),
+    (4, "PbTe-reps", (4, 4, 2), (2, 2, 1), "nve", 20, 3000.0),
+    (8, "PbTe-reps", (4, 4, 4), (2, 2, 2), "nvt_nhc", 12, 3000.0),
+    (2, "C-2022", (12, 6, 6), (2, 1, 1), "nve", 10, 3000.0),
+    (2, "UNEP-v1", (10, 5, 5), (2, 1, 1), "nve", 8, 3000.0),
+])
+def test_reverse_ghosts_on_gpu_kernels(world, model, reps, grid, ensemble, nsteps, temp):
+    _check_reverse("gpu", world, model, reps, grid, ensemble, nsteps, temp)
 
 
 @pytest.mark.gpu
