@@ -8,7 +8,9 @@
 //     OWNS the atoms inside its sub-box and their integrator state for the whole run;
 //   * ghost shell 2 (rc + skin) with the reference's semantics (nep_multigpu.cuh:42-50, ranges N1..N5): positions
 //     only travel (forward communication), descriptors of the inner ring rc + skin are recomputed redundantly
-//     (level 1), forces are produced for owned atoms only (level 2), no reverse communication;
+//     (level 1), forces are produced for owned atoms only (level 2), no reverse communication -- or, when the sub-boxes are
+//     small against that shell (set_ghost_mode: a counted rule), shell rc + skin with descriptors for owned atoms only and a
+//     reverse exchange of the pair halves the force assembly leaves on the ghosts;
 //   * per step ONE ghost-position exchange, staged over the decomposed directions (2 messages per direction; edges
 //     and corners are forwarded: 6 messages instead of 26), and one all-reduce of the skin flag;  every ensemble of
 //     the fused run loops (NVE, Berendsen, Nose-Hoover chain, Bussi-Donadio-Parrinello) on top of one all-reduce
