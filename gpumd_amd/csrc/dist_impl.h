@@ -1086,7 +1086,7 @@ private:
   int64_t eng_cap_ = 0;
   bool resident_ = false, have_force_ = false;
   bool nhc_fresh_ = true;
-  bool overlap_ = true;  // interior bricks' radial pass while the ghost positions travel
+  bool overlap_ = false; // interior bricks' radial pass while the ghost positions travel (set_overlap; off: see nepmi.h)
   int ghost_mode_ = -1;  // set_ghost_mode
   bool reverse_ = false, virial_folded_ = false;
   double thick_[3] = {0, 0, 0};

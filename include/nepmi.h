@@ -310,9 +310,12 @@ int nepmi_dist_bdp_seed(nepmi_dist* d, uint64_t seed);
  * to the atom with global id s exactly as in the single-domain nepmi_run_nvt_lan, so the noise of an atom does not depend on the
  * decomposition: every rank carries all states, kicks the atoms it owns and advances the others. */
 int nepmi_dist_lan_seed(nepmi_dist* d, int seed);
-/* on (default): the radial pass of the interior bricks (no ghost in their 8x8x8-cell window) is enqueued on the
- * compute stream while the skin vote and the ghost positions travel on a communication stream; off: the plain
- * exchange-then-compute order.  Both orders give bit-identical results. */
+/* on: the radial pass of the interior bricks (no ghost in their 8x8x8-cell window) is enqueued on the compute stream while the
+ * skin vote and the ghost positions travel on a communication stream; off (default since round 3): the plain
+ * exchange-then-compute order.  Both orders give bit-identical results.  Two launches of the radial pass have two ramps and two
+ * tails of one brick's latency each (~50 us): measured in process, ranks sharing one GPU, the split costs 6 % of a 1 M-atom step
+ * per rank (profiles/r3u_*: 2 ranks weak +10.7 % off / +16.8 % on; 8 ranks strong 2.2 / 2.4) -- more than the exchange it hides
+ * is expected to take on xGMI; turn it on where the exchange is slow (host transports over a network). */
 int nepmi_dist_set_overlap(nepmi_dist* d, int on);
 /* What the ghost atoms are for; call between nepmi_dist_create and nepmi_dist_setup (the shell width shapes the local box).
  *   0 forward: shell 2 (rc + skin), the reference's ranges (src/force/nep_multigpu.cuh:42-50) -- descriptors of the inner ring

@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--ghosts", type=int, default=-1,
                     help="nepmi_dist_set_ghost_mode: -1 the counted rule, 0 forward (shell 2 (rc + skin)), 1 reverse (shell rc + skin, "
                          "the ghosts' partial forces return to the owners)")
+    ap.add_argument("--overlap", type=int, default=-1, help="nepmi_dist_set_overlap (interior bricks' radial pass before the ghosts arrive): 0 / 1, -1 = the library's default")
     ap.add_argument("--only", default="both", choices=["both", "ranks", "one"], help="profiling: run only one of the two legs")
     args = ap.parse_args()
     import torch
@@ -83,6 +84,8 @@ def main():
                          torch.from_numpy(np.ascontiguousarray(X).reshape(-1)).to(dev),
                          torch.from_numpy(np.ascontiguousarray(V).reshape(-1)).to(dev))
                 torch.cuda.synchronize()
+                if args.overlap >= 0:
+                    md.set_overlap(bool(args.overlap))
                 md.compute()
                 md.run("nve", dt, args.warmup)
                 torch.cuda.synchronize()
@@ -135,6 +138,8 @@ def main():
                          torch.from_numpy(np.ascontiguousarray(x.reshape(3, n)[:, mine]).reshape(-1)).to(dev),
                          torch.from_numpy(np.ascontiguousarray(vel.reshape(3, n)[:, mine]).reshape(-1)).to(dev))
                 torch.cuda.synchronize()
+                if args.overlap >= 0:
+                    md.set_overlap(bool(args.overlap))
                 md.compute()
                 md.run("nve", dt, args.warmup)
                 torch.cuda.synchronize()
