@@ -411,7 +411,9 @@ def run_decomposed(args, world, rank, dev, model, label, h_block, typ, x, mass, 
         tr = Transport.tcp(lib, os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29400")) + 1,
                            rank, world)
         transport = "TCP sockets (host staging)" if world > 1 else "single rank"
-    md = DistMD(model, tr, Hg.reshape(9), (1, 1, 1), grid)
+    md = DistMD(model, tr, Hg.reshape(9), (1, 1, 1), grid, ghost_mode=args.ghosts)
+    if args.overlap >= 0:
+        md.set_overlap(bool(args.overlap))
     md.setup(torch.from_numpy(np.ascontiguousarray(T)).to(dev), torch.from_numpy(np.ascontiguousarray(M)).to(dev),
              torch.from_numpy(np.ascontiguousarray(X).reshape(-1)).to(dev),
              torch.from_numpy(np.ascontiguousarray(V).reshape(-1)).to(dev))
@@ -457,7 +459,11 @@ def run_decomposed(args, world, rank, dev, model, label, h_block, typ, x, mass, 
             "data": "synthetic",
             "config": {"workload": label + (" (per GPU)" if args.scaling == "weak" else " (whole system, strong scaling)"),
                        "ensemble": ens, "atoms_total": total,
-                       "parallelism": "spatial decomposition %dx%dx%d, ghost shell 2(rc+skin), %s" % (grid + (transport,)),
+                       "parallelism": "spatial decomposition %dx%dx%d, %s, %s" % (grid + (
+                           "ghost shell rc+skin, partial forces returned to the owners (two exchanges per step)"
+                           if info.reverse_ghosts else "ghost shell 2(rc+skin), inner ring recomputed (one exchange per step)",
+                           transport)),
+                       "ghost_mode": "reverse" if info.reverse_ghosts else "forward",
                        "local_atoms_max": int(n_loc.item()), "decompositions_in_timed_region": int(info.num_decompositions - dec0),
                        "steps_with_overlapped_exchange": int(info.num_overlapped),
                        "mean_nn_radial": st.mean_nn_radial, "mean_nn_angular": st.mean_nn_angular},
@@ -493,7 +499,11 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N > 1: weak = every GPU gets its own block of --reps cells (default); strong = the --reps system is "
                          "shared by all GPUs (SURVEY.md 8e: >= 6x at 8 GPUs on the 1 M-atom config)")
-    ap.add_argument("--ensemble", default="nve", choices=["nve", "nvt_ber", "nvt_nhc", "nvt_bdp"],
+    ap.add_argument("--ghosts", type=int, default=-1, choices=[-1, 0, 1],
+                    help="decomposed runs, nepmi_dist_set_ghost_mode: -1 the counted rule (default), 0 forward, 1 reverse ghosts")
+    ap.add_argument("--overlap", type=int, default=-1, choices=[-1, 0, 1],
+                    help="decomposed runs, nepmi_dist_set_overlap: interior bricks' radial pass while the ghosts travel (-1: library default)")
+    ap.add_argument("--ensemble", default="nve", choices=["nve", "nvt_ber", "nvt_nhc", "nvt_bdp", "nvt_lan", "nvt_bao"],
                     help="decomposed runs: the ensemble (config 5 is NVT); the single-GPU bench line is NVE")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--cpu-worker", type=float, default=None, help=argparse.SUPPRESS)

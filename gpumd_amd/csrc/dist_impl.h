@@ -255,10 +255,15 @@ public:
       int trip = vote(spec, comm);
       if (!trip)
         halo_exchange_on(comm);
+      // the boundary bricks' radial pass right behind the unpack on the communication stream: it runs beside the tail of the
+      // interior launch instead of after it (two launches in a row cost two ramps and two tails of one brick's latency)
+      const bool side_radial = split && &comm != &be_ && !trip;
+      if (side_radial)
+        e->force_kernels_on(comm, Engine::kPhaseBoundaryRadial, frozen());
       if (&comm != &be_)
         be_.join_from(comm);
       if (!trip) {
-        e->force_kernels(split ? Engine::kPhaseBoundary : Engine::kPhaseAll, frozen());
+        e->force_kernels(split ? (side_radial ? Engine::kPhaseAfterRadial : Engine::kPhaseBoundary) : Engine::kPhaseAll, frozen());
         force_reverse();
         const bool record = thermo_every > 0 && (step + 1) % thermo_every == 0;
         const bool last = step + 1 == nsteps;

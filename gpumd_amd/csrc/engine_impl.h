@@ -129,7 +129,11 @@ public:
   const Bufs& bufs() const { return b_; }
   int64_t num_atoms() const { return N_; }
   int64_t num_compute = 0, num_rebuild = 0, num_discarded = 0;
-  enum Phase { kPhaseAll = 0, kPhaseInterior = 1, kPhaseBoundary = 2, kPhaseRecords = 3 };
+  // kPhaseBoundaryRadial / kPhaseAfterRadial: kPhaseBoundary in two parts, so that the boundary bricks' radial pass can be
+  // enqueued on the communication stream right behind the ghost unpack (force_kernels_on) and run beside the tail of the
+  // interior launch instead of after it
+  enum Phase { kPhaseAll = 0, kPhaseInterior = 1, kPhaseBoundary = 2, kPhaseRecords = 3, kPhaseBoundaryRadial = 4,
+               kPhaseAfterRadial = 5 };
 
   // Potential::compute (adds to pe/force/virial; positions already wrapped)
   void potential_compute(
@@ -1502,24 +1506,31 @@ private:
     WinLayout lay2 = win_;
     lay2.compact = 1;
     const WinStage ws2{box_, b_, lay2};
+    B& rbe = radial_side_ ? *radial_side_ : be_; // (force_kernels_on: the boundary bricks on the communication stream)
     auto radial = [&](int64_t nb, int first) {
       if (win2)
-        be_.launch_win2(kSlotRadial, nb, RadialWin2Body<S>{ws2, md_, first, frozen});
+        rbe.launch_win2(kSlotRadial, nb, RadialWin2Body<S>{ws2, md_, first, frozen});
       else if (lanes == 4)
-        be_.launch_win_split(kSlotRadial, nb, RadialWinSplitBody<S, 4>{ws, md_, first, frozen});
+        rbe.launch_win_split(kSlotRadial, nb, RadialWinSplitBody<S, 4>{ws, md_, first, frozen});
       else if (lanes == 2)
-        be_.launch_win_split(kSlotRadial, nb, RadialWinSplitBody<S, 2>{ws, md_, first, frozen});
+        rbe.launch_win_split(kSlotRadial, nb, RadialWinSplitBody<S, 2>{ws, md_, first, frozen});
       else
-        be_.launch_win(kSlotRadial, nb, RadialWinBody<S>{ws, md_, first, frozen});
+        rbe.launch_win(kSlotRadial, nb, RadialWinBody<S>{ws, md_, first, frozen});
     };
     if (phase == kPhaseInterior) { // radial pass of the bricks whose window holds no ghost
       radial(num_bricks_ - num_boundary_bricks_, 0);
+      return;
+    }
+    if (phase == kPhaseBoundaryRadial) {
+      radial(num_boundary_bricks_, (int)(num_bricks_ - num_boundary_bricks_));
       return;
     }
     records_valid_ = !tile_ok_;
     be_.begin_region(kRegionForce);
     if (phase == kPhaseBoundary)
       radial(num_boundary_bricks_, (int)(num_bricks_ - num_boundary_bricks_));
+    else if (phase == kPhaseAfterRadial)
+      ; // (both parts of the radial pass are enqueued already)
     else if (tile_ok_)
       radial(num_bricks_, -1);
     else
@@ -1634,6 +1645,17 @@ public:
     force_kernels_dispatch(phase, frozen);
     be_.frozen = nullptr;
   }
+  // kPhaseBoundaryRadial on another stream of the same device (a backend from B::make_side_stream)
+  void force_kernels_on(B& side, int phase, const int* frozen)
+  {
+    if (phase != kPhaseBoundaryRadial || !tile_ok_)
+      throw EngineError{-4, "force_kernels_on: the boundary bricks' radial pass of the window kernels only"};
+    radial_side_ = &side;
+    side.frozen = frozen;
+    force_kernels_dispatch(phase, frozen);
+    side.frozen = nullptr;
+    radial_side_ = nullptr;
+  }
 
 private:
   void force_kernels_dispatch(int phase, const int* frozen)
@@ -1698,6 +1720,7 @@ private:
   int64_t grid_n_ = -1;
   double* unwrapped_ = nullptr;
   bool reverse_ghosts_ = false;  // see set_reverse_ghosts
+  B* radial_side_ = nullptr;     // force_kernels_on
   bool split_pending_ = false;   // compute_levels_begin ran, compute_levels_end has not yet
   int64_t num_boundary_bricks_ = 0;
   int64_t num_bricks_ = 0;

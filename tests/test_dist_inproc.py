@@ -77,11 +77,13 @@ CASES = [
 ]
 
 
-def _check(device, world, model, reps, grid, ensemble, nsteps, temp):
+def _check(device, world, model, reps, grid, ensemble, nsteps, temp, overlap=None, ghosts=None):
     if not os.path.exists(LIB[device]):
         pytest.skip("tests/inproc transports not built")
     import test_dist as T
-    spec = T._spec(device, model, reps, grid, ensemble, nsteps, temp)
+    spec = T._spec(device, model, reps, grid, ensemble, nsteps, temp, ghosts=ghosts)
+    if overlap is not None:
+        spec["overlap"] = overlap
     n = T._natoms(model, reps)
     multi = _run_threads(world, spec)
     single = T._run_ranks(1, dict(spec, grid=[1, 1, 1]))
@@ -93,8 +95,33 @@ def _check(device, world, model, reps, grid, ensemble, nsteps, temp):
     for r in multi:
         np.testing.assert_allclose(r["th1"], multi[0]["th1"], rtol=0, atol=0)
         np.testing.assert_allclose(r["th1"][:2], single[0]["th1"][:2], rtol=1e-6)
-    if model == "PbTe-reps" and ensemble == "nve":
+    if model == "PbTe-reps" and ensemble == "nve" and nsteps >= 20:
         assert max(int(r["ndec"]) for r in multi) >= 2
+    if overlap:
+        assert all(int(r["nover"]) > 0 for r in multi)
+    if ghosts is not None:
+        assert all(int(r["reverse"]) == ghosts for r in multi)
+
+
+# the interior / boundary split of the radial pass (nepmi_dist_set_overlap: boundary bricks on the communication stream behind
+# the ghost unpack) and reverse-mode ghosts (nepmi_dist_set_ghost_mode) over the device transport
+OPTION_CASES = [
+    (2, "PbTe-reps", (4, 2, 2), (2, 1, 1), "nve", 20, 3000.0, True, None),
+    (4, "PbTe-reps", (4, 4, 2), (2, 2, 1), "nvt_nhc", 16, 2000.0, True, 1),
+    (4, "PbTe-reps", (8, 2, 2), (4, 1, 1), "nve", 20, 3000.0, None, 1),
+    (8, "PbTe-reps", (4, 4, 4), (2, 2, 2), "nve", 12, 3000.0, True, 1),
+]
+
+
+@pytest.mark.parametrize("world,model,reps,grid,ensemble,nsteps,temp,overlap,ghosts", OPTION_CASES[:3])
+def test_device_transport_options_on_emulator(world, model, reps, grid, ensemble, nsteps, temp, overlap, ghosts):
+    _check("cpu", world, model, reps, grid, ensemble, nsteps, temp, overlap, ghosts)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,model,reps,grid,ensemble,nsteps,temp,overlap,ghosts", OPTION_CASES)
+def test_device_transport_options_on_gpu(world, model, reps, grid, ensemble, nsteps, temp, overlap, ghosts):
+    _check("gpu", world, model, reps, grid, ensemble, nsteps, temp, overlap, ghosts)
 
 
 @pytest.mark.parametrize("world,model,reps,grid,ensemble,nsteps,temp", CASES[:4])
