@@ -460,6 +460,49 @@ __global__ void __launch_bounds__(kWinThreads * Body::kLanes) nepmi_win_kernel_s
     body.compute(brick, k, lds, sub);
 }
 
+// Few bricks: Body::kLanes workgroups of 256 threads per brick instead of one workgroup of 256 kLanes threads.  Each stages the
+// window (the staging of nepmi_win_kernel) and takes 256 / kLanes atoms of the brick, kLanes lanes per atom: a 16,000-atom
+// system has 64 bricks -- 64 workgroups of 16 wavefronts leave three quarters of the CUs idle, 256 workgroups of 4 do not, and a
+// wavefront that has its SIMD to itself walks its list faster.
+template <class Body>
+__global__ void __launch_bounds__(kWinThreads) nepmi_win_kernel_parts(const Body body, const int64_t nbricks)
+{
+  constexpr int P = Body::kLanes;
+  extern __shared__ __attribute__((aligned(16))) char nepmi_win_lds[];
+  NEPMI_LDS(char)* lds = (NEPMI_LDS(char)*)nepmi_win_lds;
+  if (body.skip())
+    return;
+  const unsigned per_xcd = gridDim.x >> 3;
+  const int64_t wg = (int64_t)(blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3); // the parts of a brick sit on one XCD
+  const int64_t bw = wg / P;
+  const int part = (int)(wg - bw * P);
+  if (bw >= nbricks)
+    return;
+  const int64_t brick = body.map_brick(bw);
+  const int tid = (int)threadIdx.x;
+  body.stage_cells(brick, lds, tid, kWinThreads);
+  __syncthreads();
+  {
+    NEPMI_LDS(int)* woff = (NEPMI_LDS(int)*)lds;
+    const int v0 = woff[2 * tid], v1 = woff[2 * tid + 1];
+    int total;
+    const int ex = block_exclusive_scan<kWinThreads>(v0 + v1, &total);
+    woff[2 * tid] = ex;
+    woff[2 * tid + 1] = ex + v0;
+    if (tid == 0)
+      woff[kWinCells] = total;
+  }
+  __syncthreads();
+  body.stage_copy(brick, lds, tid, kWinThreads);
+  body.stage_lists(brick, lds, tid, kWinThreads);
+  __syncthreads();
+  int64_t a0, a1;
+  body.brick_range(brick, a0, a1);
+  const int sub = tid % P;
+  for (int64_t k = a0 + part * (kWinThreads / P) + tid / P; k < a1; k += kWinThreads)
+    body.compute(brick, k, lds, sub);
+}
+
 constexpr int kScanBlock = 256;
 constexpr int kScanItems = 8;
 constexpr int kScanTile = kScanBlock * kScanItems;
@@ -1152,12 +1195,26 @@ struct HipBackend {
     const bool t = timed(slot);
     if (t)
       timer_start(timing->slot[slot]);
-    hipLaunchKernelGGL((nepmi_win_kernel_split<Body>), dim3((unsigned)grid), dim3(kWinThreads * Body::kLanes), lds_bytes,
-                       stream, body, nbricks);
+    // kLanes workgroups of 256 threads per brick (nepmi_win_kernel_parts) while they fit two to a CU: a counted rule
+    // (profiles/r3x: PbTe 16,000 atoms 0.183 -> 0.155 ms/step, 31,250 atoms 0.166 -> 0.162, 54,000 atoms 0.178 -> 0.193)
+    if (win_parts && nbricks * Body::kLanes <= 512) {
+      const int64_t pgrid = (nbricks * Body::kLanes + 7) / 8 * 8;
+      if (lds_bytes > 64 * 1024)
+        NEPMI_HIP_CHECK(hipFuncSetAttribute(
+          reinterpret_cast<const void*>(&nepmi_win_kernel_parts<Body>), hipFuncAttributeMaxDynamicSharedMemorySize,
+          (int)lds_bytes));
+      hipLaunchKernelGGL((nepmi_win_kernel_parts<Body>), dim3((unsigned)pgrid), dim3(kWinThreads), lds_bytes, stream, body,
+                         nbricks);
+    } else {
+      hipLaunchKernelGGL((nepmi_win_kernel_split<Body>), dim3((unsigned)grid), dim3(kWinThreads * Body::kLanes), lds_bytes,
+                         stream, body, nbricks);
+    }
     NEPMI_HIP_CHECK(hipGetLastError());
     if (t)
       timer_stop(timing->slot[slot]);
   }
+  // A/B switch of launch_win_split (NEPMI_WIN_PARTS=0: one workgroup of 256 kLanes threads per brick)
+  bool win_parts = std::getenv("NEPMI_WIN_PARTS") == nullptr || std::getenv("NEPMI_WIN_PARTS")[0] != '0';
 
   template <int BLOCK, class Body>
   void launch_lds(int slot, int64_t n, const Body& body)
