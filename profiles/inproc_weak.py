@@ -31,6 +31,8 @@ def main():
     ap.add_argument("--strong", action="store_true",
                     help="strong scaling: ONE block of --reps cells shared by the ranks (most cubic grid) against the same block as "
                          "one domain -- the work the decomposition adds when a fixed system is cut into R sub-boxes")
+    ap.add_argument("--workload", default="pbte", choices=["pbte", "carbon", "unep"],
+                    help="pbte: --reps of the 250-atom cell; carbon / unep: --reps conventional cells of diamond (C_2022) / the fcc 16-metal alloy (UNEP-v1)")
     ap.add_argument("--ghosts", type=int, default=-1,
                     help="nepmi_dist_set_ghost_mode: -1 the counted rule, 0 forward (shell 2 (rc + skin)), 1 reverse (shell rc + skin, "
                          "the ghosts' partial forces return to the owners)")
@@ -48,13 +50,18 @@ def main():
     tlib.inproc_group_create.restype = C.c_void_p
     tlib.inproc_group_create.argtypes = [C.c_int]
     tlib.inproc_transport.argtypes = [C.c_void_p, C.c_int, C.POINTER(_capi.NepmiTransport)]
-    model = gpumd_amd.Model(S.golden("PbTe", "nep.txt"))
+    model = gpumd_amd.Model(S.golden({"pbte": "PbTe", "carbon": "C", "unep": "UNEP"}[args.workload], "nep.txt"))
     dt = 1.0 / S.TIME_UNIT
     R = args.ranks
     reps = tuple(args.reps)
 
     def block(rank):
-        h, typ, x, mass, vel = S.pbte_block(reps, seed=42 + rank)
+        if args.workload == "carbon":
+            h, typ, x, mass, vel = S.diamond_block(reps, seed=42 + rank)
+        elif args.workload == "unep":
+            h, typ, x, mass, vel = S.fcc_alloy_block(reps, seed=42 + rank)
+        else:
+            h, typ, x, mass, vel = S.pbte_block(reps, seed=42 + rank)
         return np.asarray(h).reshape(3, 3), typ, x, mass, vel
 
     def run(world, blocks_per_rank):
