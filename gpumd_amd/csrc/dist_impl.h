@@ -821,15 +821,18 @@ private:
       compact(leave, n_own, scan, lidx, sscr);
       h_leave.resize((size_t)n_leave);
       be_.d2h(h_leave.data(), lidx, sizeof(int) * n_leave);
-      h_dest.resize((size_t)n_own);
-      be_.d2h(h_dest.data(), dest, sizeof(int) * n_own);
+      // destinations of the leaving atoms only (the whole array is 4 bytes per owned atom through pageable memory)
+      int* dleave = iscratch(12, n_leave + 1);
+      be_.template launch<256>(kSlotMisc, n_leave, MapIndexBody{dest, lidx, 0, dleave});
+      h_dest.resize((size_t)n_leave);
+      be_.d2h(h_dest.data(), dleave, sizeof(int) * n_leave);
     }
     mark("owners");
     // 2. who sends how many to whom (all ranks learn the whole matrix)
     std::vector<int64_t> mat((size_t)P * P, 0);
     std::vector<std::vector<int>> by_dest(P);
     for (int64_t q = 0; q < n_leave; ++q)
-      by_dest[h_dest[h_leave[q]]].push_back(h_leave[q]);
+      by_dest[h_dest[q]].push_back(h_leave[q]);
     for (int r = 0; r < P; ++r)
       mat[(size_t)me * P + r] = (int64_t)by_dest[r].size();
     host_allreduce(mat.data(), (int64_t)P * P, kDtI64, kOpSum);
