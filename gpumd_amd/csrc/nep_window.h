@@ -49,7 +49,8 @@ struct WinLayout {
 
 #ifndef NEPMI_CT_VEC_FORCE
 #define NEPMI_CT_VEC_FORCE 0 // 1: the force assembly (FPJ form) reads its coefficient blocks with 16-byte ds_reads (block stride 52 floats for
-                             // UNEP-v1: 53 KB, which no longer leaves room for two workgroups per CU next to a 30 KB window); 0: element-wise, odd stride
+                             // UNEP-v1: 53 KB, which no longer leaves room for two workgroups per CU next to its 34.8 KB window -- the
+                             // counted rule then falls back to the gathered table rows, 1.54 -> 2.91 ms: profiles/r3z1_*); 0: element-wise, odd stride
 #endif
 // Radial coefficient table of many-type shapes in LDS (static layout): one block of (n_r+1)(k_r+1) floats per ordered type
 // pair, padded to a multiple of four so that a lane reads its pair's block with 16-byte ds_reads (12 instead of 45 for UNEP-v1)
