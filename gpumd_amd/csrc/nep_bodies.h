@@ -945,9 +945,31 @@ struct PackCodesBody {
       // two type-pure streams, word by word side by side: row wa + 2p = four neighbours of type 0, row wa + 2p + 1 = four of
       // type 1; the shorter stream is padded with sentinel words
       int s0 = 0, s1 = 0; // cursors over list B: next entry of type 0 / of type 1
+      // the types of the entries, looked up once (bit s: entry s is not of type 0); lists longer than the mask use the look-up
+      unsigned long long m0 = 0ull, m1 = 0ull, m2 = 0ull, m3 = 0ull; // (four scalars: no dynamically indexed register array)
+      const bool masked = nb <= 256;
+      if (masked)
+        for (int s = 0; s < nb; ++s) {
+          const unsigned long long bit = (b.posq[b.nl_skin[(int64_t)s * N + k]].type != 0 ? 1ull : 0ull) << (s & 63);
+          const int w = s >> 6;
+          m0 |= w == 0 ? bit : 0ull;
+          m1 |= w == 1 ? bit : 0ull;
+          m2 |= w == 2 ? bit : 0ull;
+          m3 |= w == 3 ? bit : 0ull;
+        }
+      auto other = [&](int s) -> bool {
+        const int w = s >> 6;
+        const unsigned long long m = w == 0 ? m0 : (w == 1 ? m1 : (w == 2 ? m2 : m3));
+        return ((m >> (s & 63)) & 1ull) != 0ull;
+      };
       auto next_of = [&](int& s, int want) -> int {
-        while (s < nb && (b.posq[b.nl_skin[(int64_t)s * N + k]].type != 0) != (want != 0))
-          ++s;
+        if (masked) {
+          while (s < nb && other(s) != (want != 0))
+            ++s;
+        } else {
+          while (s < nb && (b.posq[b.nl_skin[(int64_t)s * N + k]].type != 0) != (want != 0))
+            ++s;
+        }
         return s < nb ? s++ : -1;
       };
       for (;;) {
