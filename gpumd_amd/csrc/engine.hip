@@ -887,6 +887,13 @@ struct HipBackend {
   {
     void* p = nullptr;
     NEPMI_HIP_CHECK(hipMalloc(&p, bytes ? bytes : 1));
+    // NEPMI_POISON=<byte>: debugging aid -- fresh device memory is filled with that byte (e.g. 255: floats are NaN), so that a
+    // kernel which reads what nobody wrote fails every time instead of depending on what the block held before
+    static const int poison = std::getenv("NEPMI_POISON") ? std::atoi(std::getenv("NEPMI_POISON")) : -1;
+    if (poison >= 0 && bytes) {
+      NEPMI_HIP_CHECK(hipMemset(p, poison & 0xFF, bytes));
+      NEPMI_HIP_CHECK(hipDeviceSynchronize());
+    }
     return p;
   }
   void free(void* p) { (void)hipFree(p); }

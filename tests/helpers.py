@@ -373,11 +373,17 @@ class GpuDriver:
         return gpumd_amd.NEP(model, n, pbc=pbc)
 
     def dev(self, a):
-        return self.torch.from_numpy(np.ascontiguousarray(a)).to(self.devi)
+        t = self.torch.from_numpy(np.ascontiguousarray(a)).to(self.devi)
+        self.torch.cuda.current_stream().synchronize()
+        return t
 
     def zeros(self, n, dtype=np.float64):
         tdt = {np.float64: self.torch.float64, np.float32: self.torch.float32, np.int32: self.torch.int32}[dtype]
-        return self.torch.zeros(n, dtype=tdt, device=self.devi)
+        t = self.torch.zeros(n, dtype=tdt, device=self.devi)
+        # the fill runs on torch's current stream, the engines of the in-process multi-rank tests on streams of their own (not
+        # ordered against it): without this a gather into the fresh array could be overtaken by its own zero fill
+        self.torch.cuda.current_stream().synchronize()
+        return t
 
     def host(self, a):
         self.torch.cuda.synchronize()
