@@ -287,9 +287,10 @@ struct GhostForcePackBody {
   int first, planes;
   double* out0;
   double* out1;
+  const int* frozen; // the run loops' "rebuild pending" word (the force kernels of this step did not run), or nullptr
   NEPMI_HD void operator()(int64_t q) const
   {
-    if (b.flags[kFlagMoved] != 0)
+    if (frozen && *frozen != 0)
       return;
     const int64_t N = b.N;
     const int k = idx[q];
@@ -310,9 +311,10 @@ struct GhostForceAddBody {
   int first, planes;
   const double* in0;
   const double* in1;
+  const int* frozen;
   NEPMI_HD void operator()(int64_t q) const
   {
-    if (b.flags[kFlagMoved] != 0)
+    if (frozen && *frozen != 0)
       return;
     const int64_t N = b.N;
     const int k = idx[q];

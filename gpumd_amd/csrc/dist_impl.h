@@ -264,7 +264,7 @@ public:
         be_.join_from(comm);
       if (!trip) {
         e->force_kernels(split ? (side_radial ? Engine::kPhaseAfterRadial : Engine::kPhaseBoundary) : Engine::kPhaseAll, frozen());
-        force_reverse();
+        force_reverse(frozen());
         const bool record = thermo_every > 0 && (step + 1) % thermo_every == 0;
         const bool last = step + 1 == nsteps;
         bool need_sync = record || last;
@@ -685,7 +685,7 @@ private:
   // ---- reverse mode: per-step reverse communication of what the force assembly left on the ghosts ----
   // The stages in reverse order; in each, the planes of the ghosts received from a peer go back to it and are added to the
   // atoms it had sent (owned atoms, or ghosts of an earlier stage, which the next reverse stage carries on).
-  void reverse_exchange(int first, int planes)
+  void reverse_exchange(int first, int planes, const int* frz)
   {
     Engine& e = *eng_;
     for (size_t si = stages_.size(); si-- > 0;) {
@@ -693,7 +693,7 @@ private:
       const int64_t c0 = st.cnt_send[0], c1 = st.cnt_send[1], r0 = st.cnt_recv[0], r1 = st.cnt_recv[1];
       if (r0 + r1 > 0)
         be_.template launch<256>(kSlotMisc, r0 + r1, GhostForcePackBody{e.bufs(), st.recv_int, r0, r1, first, planes, st.recvbuf,
-                                                                         st.recvbuf + (int64_t)planes * r0});
+                                                                         st.recvbuf + (int64_t)planes * r0, frz});
       TransportMsg s[2], r[2];
       int ns = 0, nr = 0;
       const int64_t pb = (int64_t)sizeof(double) * planes;
@@ -705,20 +705,20 @@ private:
       const double* in1 = st.sendbuf + (int64_t)planes * c0;
       if (geom_.wfrac[st.d] * 2.0 <= 1.0 / geom_.grid[st.d]) { // the lower and the upper shell of the sub-box do not meet
         if (c0 + c1 > 0)
-          be_.template launch<256>(kSlotMisc, c0 + c1, GhostForceAddBody{e.bufs(), st.send_int, c0, c1, first, planes, st.sendbuf, in1});
+          be_.template launch<256>(kSlotMisc, c0 + c1, GhostForceAddBody{e.bufs(), st.send_int, c0, c1, first, planes, st.sendbuf, in1, frz});
       } else {
         if (c0)
-          be_.template launch<256>(kSlotMisc, c0, GhostForceAddBody{e.bufs(), st.send_int, c0, 0, first, planes, st.sendbuf, in1});
+          be_.template launch<256>(kSlotMisc, c0, GhostForceAddBody{e.bufs(), st.send_int, c0, 0, first, planes, st.sendbuf, in1, frz});
         if (c1)
-          be_.template launch<256>(kSlotMisc, c1, GhostForceAddBody{e.bufs(), st.send_int + c0, c1, 0, first, planes, in1, in1});
+          be_.template launch<256>(kSlotMisc, c1, GhostForceAddBody{e.bufs(), st.send_int + c0, c1, 0, first, planes, in1, in1, frz});
       }
     }
   }
-  void force_reverse()
+  void force_reverse(const int* frz = nullptr) // frz: as the force kernels of this step got it
   {
     virial_folded_ = false;
     if (reverse_)
-      reverse_exchange(kOutF, 3);
+      reverse_exchange(kOutF, 3, frz);
   }
   // per-atom virials for output: the halves computed on other ranks' ghosts come home once per force evaluation (the run
   // loop only needs the global sum, which thermo_global takes over owned atoms AND ghosts until then)
@@ -726,7 +726,7 @@ private:
   {
     if (!reverse_ || virial_folded_ || !have_force_)
       return;
-    reverse_exchange(kOutW, 9);
+    reverse_exchange(kOutW, 9, nullptr);
     virial_folded_ = true;
   }
 
