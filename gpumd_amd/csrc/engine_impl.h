@@ -1563,7 +1563,8 @@ private:
   // Force assembly with the neighbours' table rows in LDS (ForceWinBody<..., ROWS>): shapes with register-resident sums whose
   // records + rows fit the LDS of a CU; a counted rule.  The emulator's host loop runs the same body with one lane per atom.
 #ifndef NEPMI_FW_ROWS
-#define NEPMI_FW_ROWS 0 // A/B switch (profiles/ab_variants.sh); r3d: PbTe 1 M 0.517 (gather) vs 0.52 (rows, 4 lanes) vs 0.515 (2 lanes), carbon 0.79 vs 1.10 vs 0.95 ms: off
+#define NEPMI_FW_ROWS 0 // A/B switch (profiles/ab_variants.sh); r3d: carbon 0.79 (gather) vs 1.10 (rows, 4 lanes) vs 0.95 ms (2 lanes): off.  PbTe 1 M: records + rows
+                        // (64 B per window atom) exceed the 160 KB of a CU, the rule below keeps the gathered form
 #endif
   template <class S>
   bool rows_form(const WinStage& ws2, const int* frozen)
