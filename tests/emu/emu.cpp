@@ -20,7 +20,17 @@
 namespace nepmi {
 
 struct HostLoopBackend {
-  void* alloc(size_t bytes) { return std::calloc(1, bytes ? bytes : 1); }
+  // zero-filled by default; NEPMI_POISON=<byte> fills fresh blocks with that byte instead (as the HIP backend does on request), so
+  // that body logic which reads what nobody wrote shows up on the CPU tier as well
+  void* alloc(size_t bytes)
+  {
+    static const int poison = std::getenv("NEPMI_POISON") ? std::atoi(std::getenv("NEPMI_POISON")) : -1;
+    if (poison < 0)
+      return std::calloc(1, bytes ? bytes : 1);
+    void* p = std::malloc(bytes ? bytes : 1);
+    std::memset(p, poison & 0xFF, bytes ? bytes : 1);
+    return p;
+  }
   void free(void* p) { std::free(p); }
   void memset(void* p, int v, size_t bytes) { std::memset(p, v, bytes); }
   void h2d(void* dst, const void* src, size_t bytes) { std::memcpy(dst, src, bytes); }
