@@ -1228,7 +1228,7 @@ private:
       be_.template launch<256>(kSlotMisc, N_, TypeFillBody{b_, model_.num_types});
     }
     be_.template launch<128>(kSlotMisc, N_, BuildListsBody{box_, b_});
-    be_.template launch<128>(kSlotMisc, N_, ReverseSlotsBody{b_});
+    be_.template launch<128>(kSlotMisc, N_, ReverseSlotsBody{box_, b_});
     be_.memset(b_.flags + kFlagMaxWindow, 0, 3 * sizeof(int));
     num_bricks_ = (int64_t)b_.gbx * b_.gby * b_.gbz;
     if (b_.level)
