@@ -50,7 +50,7 @@ def run_rank(out_dir, spec, rank, world, make_transport, stream=None):
     mine = np.arange(n) % world == rank  # arbitrary initial distribution; setup() migrates
     ids = np.arange(n, dtype=np.int64)[mine]
     tr = make_transport(drv)
-    md = DistMD(model, tr, h, (1, 1, 1), spec["grid"], stream=stream, ghost_mode=spec.get("ghosts"))
+    md = DistMD(model, tr, h, tuple(spec.get("pbc", (1, 1, 1))), spec["grid"], stream=stream, ghost_mode=spec.get("ghosts"))
     md.setup(drv.dev(typ[mine]), drv.dev(mass[mine]), drv.dev(np.ascontiguousarray(x.reshape(3, n)[:, mine]).reshape(-1)),
              drv.dev(np.ascontiguousarray(vel.reshape(3, n)[:, mine]).reshape(-1)), drv.dev(ids))
     if "overlap" in spec:

@@ -141,6 +141,15 @@ def test_reverse_ghosts_match_single_domain(world, model, reps, grid, ensemble, 
     _check_reverse("cpu", world, model, reps, grid, ensemble, nsteps, temp)
 
 
+@pytest.mark.parametrize("ghosts", [0, 1])
+def test_open_boundary_in_the_decomposed_direction(ghosts):
+    """A slab geometry: no periodic images along the decomposed direction, so the end ranks have one neighbour only (no
+    message across the open faces, forward or reverse)."""
+    spec = dict(_spec("cpu", "PbTe-reps", (6, 2, 2), (3, 1, 1), "nve", 16, 2000.0, ghosts=ghosts), pbc=[0, 1, 1])
+    multi, _ = _check(3, spec, _natoms("PbTe-reps", (6, 2, 2)))
+    assert all(int(r["reverse"]) == ghosts for r in multi)
+
+
 def test_thin_subboxes_take_reverse_ghosts_by_the_counted_rule():
     """Five slabs of 15.2 A: thinner than the forward shell 2 (rc + skin) = 18 A, so the rule (no mode set) picks reverse
     ghosts; the lower and the upper shell of a slab overlap, i.e. an atom can be a ghost of both neighbours and its two
