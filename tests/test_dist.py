@@ -111,6 +111,8 @@ REVERSE_CASES = [
     (8, "PbTe-reps", (3, 3, 3), (2, 2, 2), "nve", 12, 3000.0),      # three stages (the grid of a strong-scaling run on 8 GPUs)
     (2, "PbTe-reps", (4, 2, 2), (2, 1, 1), "nvt_nhc", 16, 2000.0),
     (2, "PbTe-reps", (4, 2, 2), (2, 1, 1), "nvt_lan", 16, 2000.0),
+    (2, "PbTe-reps", (4, 2, 2), (2, 1, 1), "nvt_bao", 16, 2000.0),
+    (2, "PbTe-reps", (4, 2, 2), (2, 1, 1), "nvt_bdp", 16, 2000.0),
     (2, "C-2022", (12, 6, 6), (2, 1, 1), "nve", 10, 3000.0),
     (2, "UNEP-v1", (10, 5, 5), (2, 1, 1), "nve", 8, 3000.0),        # ZBL: a pair potential, never computed on a ghost
 ]
