@@ -85,6 +85,9 @@ def test_two_ranks_write_the_same_files_as_one(tmp_path, ens):
     _run(a, 1)
     out = _run(b, 2)
     assert "Use 2 GPUs: process grid 2 x 1 x 1" in out
+    # 38 A slabs: the counted rule takes the reverse ghosts (shell rc + skin, forces returned to the owners), so the pressure
+    # columns below also check the virial halves that stay on the ghosts
+    assert "partial forces return to their owners" in out
     ta, tb = _thermo(a), _thermo(b)
     np.testing.assert_allclose(tb[:, :3], ta[:, :3], rtol=2e-6)
     np.testing.assert_allclose(tb[:, 3:9], ta[:, 3:9], rtol=1e-3, atol=1e-4)
