@@ -117,12 +117,12 @@ def test_nvt_lan_relaxes_to_the_target_on_gpu():
     _relaxes_to_target(H.GpuDriver())
 
 
-def _resident_loop_equals_stepwise(drv):
+def _resident_loop_equals_stepwise(drv, reps=(3, 3, 3)):
     """nepmi_run_nvt_lan runs device-resident (state in the engine's internal order, steps enqueued speculatively, rebuilds
     inside the run): the generator states stay in the caller's atom order and the momentum sums are formed in the caller's
     order, so it must reproduce the stepwise sequence of the per-call entry points -- lan_half_step, vv_step1, Force::compute (wrap,
     zero, force), vv_step2, lan_half_step -- BIT FOR BIT in the velocities and positions."""
-    h, typ, x = H.pbte_supercell((3, 3, 3), seed=4)
+    h, typ, x = H.pbte_supercell(reps, seed=4)
     n = len(typ)
     mass = np.where(typ == 0, H.MASS["Te"], H.MASS["Pb"]).astype(np.float64)
     vel = H.maxwell_velocities(mass, 1500.0, seed=9)  # hot: list rebuilds inside the 40 steps
@@ -157,7 +157,7 @@ def _resident_loop_equals_stepwise(drv):
 
 
 def test_resident_nvt_lan_equals_the_stepwise_sequence_on_emulator():
-    _resident_loop_equals_stepwise(H.EmuDriver())
+    _resident_loop_equals_stepwise(H.EmuDriver(), reps=(2, 2, 2))
 
 
 @pytest.mark.gpu
@@ -165,10 +165,10 @@ def test_resident_nvt_lan_equals_the_stepwise_sequence_on_gpu():
     _resident_loop_equals_stepwise(H.GpuDriver())
 
 
-def _resident_bao_equals_stepwise(drv):
+def _resident_bao_equals_stepwise(drv, reps=(3, 3, 3)):
     """nepmi_run_nvt_bao device-resident (B A O A on the internal-order state, speculative enqueue, rebuilds inside) against the
     stepwise sequence of the same engine (nepmi_engine_set_stepwise_loops): bit for bit."""
-    h, typ, x = H.pbte_supercell((3, 3, 3), seed=4)
+    h, typ, x = H.pbte_supercell(reps, seed=4)
     n = len(typ)
     mass = np.where(typ == 0, H.MASS["Te"], H.MASS["Pb"]).astype(np.float64)
     vel = H.maxwell_velocities(mass, 1500.0, seed=9)
@@ -190,7 +190,7 @@ def _resident_bao_equals_stepwise(drv):
 
 
 def test_resident_nvt_bao_equals_the_stepwise_sequence_on_emulator():
-    _resident_bao_equals_stepwise(H.EmuDriver())
+    _resident_bao_equals_stepwise(H.EmuDriver(), reps=(2, 2, 2))
 
 
 @pytest.mark.gpu
