@@ -337,7 +337,9 @@ typedef struct {
 } nepmi_dist_info;
 int nepmi_dist_get_info(nepmi_dist* d, nepmi_dist_info* out);
 /* The owned atoms of this rank (n_owned entries per plane, global coordinates) into the caller's DEVICE arrays;
- * any pointer may be NULL. */
+ * any pointer may be NULL.  With reverse-mode ghosts (nepmi_dist_set_ghost_mode) a non-NULL `virial` makes the call
+ * collective -- every rank has to ask for the virials in the same call, the halves computed on other ranks' ghosts come
+ * home through one more reverse exchange. */
 int nepmi_dist_gather_owned(
   nepmi_dist* d, int64_t* ids, double* pos, double* vel, double* force, double* pe, double* virial);
 /* Every atom of the system on rank `root`, ordered by global id (which must be 0 .. n_total-1, the default): DEVICE
