@@ -367,9 +367,15 @@ def measure_extra(workload, reps, steps, warmup, dev):
             "kernels_avg_ms": {k: round(v["avg_ms"], 5) for k, v in kern.items()}}
 
 
-def run_decomposed(args, world, rank, dev, model, label, h_block, typ, x, mass, vel):
+def run_decomposed(args, world, rank, dev, model, label, h_block, typ, x, mass, vel, scaling=None, leg=0, steps=None,
+                   warmup=None):
     """N > 1 (or --decomposed on one GPU): the C++ domain-decomposed driver of libnepmi (nepmi_dist_*), one rank per
-    GPU, ghost positions over RCCL/xGMI.  Python only builds the synthetic block and passes pointers."""
+    GPU, ghost positions over RCCL/xGMI.  Python only builds the synthetic block and passes pointers.
+    -> the bench line as a dict on rank 0 (None elsewhere).  `leg` numbers the runs of one process (own TCP port each)."""
+    global STAGE
+    scaling = scaling or args.scaling
+    steps = args.steps if steps is None else steps
+    warmup = args.warmup if warmup is None else warmup
     import torch
     import torch.distributed as dist
     import gpumd_amd
@@ -381,10 +387,11 @@ def run_decomposed(args, world, rank, dev, model, label, h_block, typ, x, mass, 
     # one-directional partition, force.cu:122-160): every rank has two neighbours and ghosts across two faces only -- a
     # 1,024,000-atom PbTe block gets +12 % local atoms (+6 % that need descriptors) instead of +36 % (+17 %) in a 2 x 2 x 2
     # arrangement of the same blocks.  Strong scaling cuts ONE system: there the most cubic grid has the least surface.
-    grid = (world, 1, 1) if args.scaling == "weak" else choose_grid(world)
+    grid = (world, 1, 1) if scaling == "weak" else choose_grid(world)
     Hb = np.asarray(h_block).reshape(3, 3)
     n = len(typ)
-    if args.scaling == "strong":
+    STAGE = "decomposed[%s]: transport" % scaling
+    if scaling == "strong":
         # the SAME global system on every N: rank r contributes a slice of it (setup migrates the atoms to their owners)
         Hg = Hb
         mine = np.arange(n) % world == rank
@@ -408,9 +415,12 @@ def run_decomposed(args, world, rank, dev, model, label, h_block, typ, x, mass, 
         transport = "RCCL send/recv of ghost positions over xGMI, skin vote all-reduced on the device"
     else:
         # functional check on a box with fewer GPUs than ranks (or one rank): host sockets, never a performance run
-        tr = Transport.tcp(lib, os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29400")) + 1,
-                           rank, world)
+        tr = Transport.tcp(lib, os.environ.get("MASTER_ADDR", "127.0.0.1"),
+                           int(os.environ.get("MASTER_PORT", "29400")) + 1 + leg, rank, world)
         transport = "TCP sockets (host staging)" if world > 1 else "single rank"
+    STAGE = "decomposed[%s]: setup (first decomposition, ghost exchange, list build)" % scaling
+    if os.environ.get("NEPMI_BENCH_FAIL_STAGE") == "setup" and rank == world - 1:
+        raise RuntimeError("injected failure (NEPMI_BENCH_FAIL_STAGE: tests/test_bench_launch.py)")
     md = DistMD(model, tr, Hg.reshape(9), (1, 1, 1), grid, ghost_mode=args.ghosts)
     if args.overlap >= 0:
         md.set_overlap(bool(args.overlap))
@@ -420,44 +430,55 @@ def run_decomposed(args, world, rank, dev, model, label, h_block, typ, x, mass, 
     dt = 1.0 / H.TIME_UNIT
     ens = args.ensemble
     t_args = (300.0, 300.0, 100.0)
+    STAGE = "decomposed[%s]: initial force (first ghost exchange of a step)" % scaling
     md.compute()
-    if args.warmup > 0:
-        md.run(ens, dt, args.warmup, *t_args)
+    STAGE = "decomposed[%s]: warm-up steps" % scaling
+    if warmup > 0:
+        md.run(ens, dt, warmup, *t_args)
     md.engine_set_timing(2)  # the dominant kernel only inside the timed region (see the single-GPU path)
     dec0 = md.info().num_decompositions
+    STAGE = "decomposed[%s]: timed region" % scaling
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    md.run(ens, dt, args.steps, *t_args)
+    md.run(ens, dt, steps, *t_args)
+    torch.cuda.synchronize()
+    own = time.perf_counter() - t0  # this rank's own time, before it waits for the others
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    STAGE = "decomposed[%s]: instrumented pass" % scaling
     st = md.engine_stats(with_lists=True)
     th = md.thermo()
     md.engine_set_timing(1)
-    md.run(ens, dt, max(10, min(args.steps, 40)), *t_args)  # instrumented pass for the per-kernel table, outside the clock
+    md.run(ens, dt, max(10, min(steps, 40)), *t_args)  # instrumented pass for the per-kernel table, outside the clock
     st_all = md.engine_stats(with_lists=False)
     md.engine_set_timing(0)
     info = md.info()
     t_el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     n_loc = torch.tensor([float(info.n_local)], dtype=torch.float64, device=dev)
+    t_own = torch.zeros(world, dtype=torch.float64, device=dev)
+    t_own[rank] = own
     if world > 1:
         dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
         dist.all_reduce(n_loc, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t_own, op=dist.ReduceOp.SUM)
     elapsed = float(t_el.item())
+    out = None
     if rank == 0:
         kern, roofline, b_step = kernel_report(st, model.info, info.n_local, st_all)
         total = info.n_total
+        per_rank_ms = [float(v) / steps * 1e3 for v in t_own.cpu().numpy()]
         out = {
             "metric": METRIC[args.workload] + (", " + ens if ens != "nve" else ""),
-            "value": total * args.steps / elapsed, "unit": "atom-steps/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": args.scaling, "vs_baseline": None, "dtype": "f32",
+            "value": total * steps / elapsed, "unit": "atom-steps/s", "n_gpus": world, "steps": steps,
+            "warmup": warmup, "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True,
+            "scaling": scaling, "vs_baseline": None, "dtype": "f32",
             "dtype_note": "FP32 kernel arithmetic like the reference NEP path; FP64 positions, velocities and accumulated per-atom outputs",
             "data": "synthetic",
-            "config": {"workload": label + (" (per GPU)" if args.scaling == "weak" else " (whole system, strong scaling)"),
+            "config": {"workload": label + (" (per GPU)" if scaling == "weak" else " (whole system, strong scaling)"),
                        "ensemble": ens, "atoms_total": total,
                        "parallelism": "spatial decomposition %dx%dx%d, %s, %s" % (grid + (
                            "ghost shell rc+skin, partial forces returned to the owners (two exchanges per step)"
@@ -465,22 +486,83 @@ def run_decomposed(args, world, rank, dev, model, label, h_block, typ, x, mass, 
                            transport)),
                        "ghost_mode": "reverse" if info.reverse_ghosts else "forward",
                        "local_atoms_max": int(n_loc.item()), "decompositions_in_timed_region": int(info.num_decompositions - dec0),
+                       "per_rank_ms_per_step": {"min": min(per_rank_ms), "max": max(per_rank_ms),
+                                                "all": [round(v, 4) for v in per_rank_ms],
+                                                "note": "each rank's own wall time of the timed region before the closing barrier"},
                        "steps_with_overlapped_exchange": int(info.num_overlapped),
                        "mean_nn_radial": st.mean_nn_radial, "mean_nn_angular": st.mean_nn_angular},
             "roofline": roofline, "step_algorithmic_bytes_per_atom": b_step,
-            "step_hbm_frac": b_step * (total * args.steps / elapsed) / (HBM_PEAK_GBS * 1e9 * world),
+            "step_hbm_frac": b_step * (total * steps / elapsed) / (HBM_PEAK_GBS * 1e9 * world),
             "kernels": kern, "thermo_last": [float(v) for v in th],
         }
         free_b, total_b = torch.cuda.mem_get_info(dev)
         out["device_memory"] = {"used_gb_rank0": (total_b - free_b) / 1e9, "total_gb": total_b / 1e9,
                                 "note": "hipMemGetInfo after the run on rank 0: engine + decomposition buffers + the PyTorch context"}
         out["config"]["kernel_forms"] = md.engine_describe()
-        print(json.dumps(out))
+    STAGE = "decomposed[%s]: teardown" % scaling
     md.close()
     tr.close()
     if world > 1:
         dist.barrier()
-        dist.destroy_process_group()
+    return out
+
+
+STAGE = "start"  # what the process was doing when it failed (the "error" line names it)
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: re-run this command under torch.distributed.run, one rank per GPU
+    (the reference starts its multi-GPU path from one process, src/force/force.cu:122-160; here one process drives one
+    GPU, so the plain command spawns them).  On a box with fewer GPUs than ranks the ranks share the devices over the
+    TCP transport: a functional run of the same protocol, labelled as such in the line."""
+    import socket
+    import subprocess
+    import torch
+    env = dict(os.environ)
+    ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if ndev == 0:
+        print(json.dumps({"error": "no GPU visible", "stage": "self-launch", "n_gpus": args.gpus}))
+        raise SystemExit(2)
+    if ndev < args.gpus and "NEPMI_DIST_BACKEND" not in env:
+        env["NEPMI_DIST_BACKEND"] = "tcp"
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus,
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # the children's stdout is filtered down to ONE JSON line: rank 0's bench line, or -- when the launch failed -- one
+    # {"error": ...} line that names the stage of the first rank that reported one (failed ranks print theirs on either stream)
+    pr = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    import threading
+    errs, lines = [], []
+
+    def pump(src, sink, keep):
+        for ln in src:
+            if ln.startswith("{") and ('"error"' in ln or '"metric"' in ln):
+                keep.append(ln.strip())
+            else:
+                sink.write(ln)
+                sink.flush()
+    th = [threading.Thread(target=pump, args=(pr.stdout, sys.stderr, lines)),
+          threading.Thread(target=pump, args=(pr.stderr, sys.stderr, errs))]
+    for t in th:
+        t.start()
+    rc = pr.wait()
+    for t in th:
+        t.join()
+    good = [ln for ln in lines if '"error"' not in ln[:20] and '"value"' in ln]
+    if good:
+        print(good[0])
+    else:
+        bad = [ln for ln in lines + errs if ln.startswith('{"error"')]
+        if bad:
+            print(bad[0])
+        else:
+            print(json.dumps({"error": "the %d-rank launch exited with code %d before any rank reported" % (args.gpus, rc),
+                              "stage": "torch.distributed.run", "n_gpus": args.gpus}))
+        rc = rc or 3
+    raise SystemExit(rc)
 
 
 def main():
@@ -493,7 +575,8 @@ def main():
                     help="pbte = BASELINE config 3 (the bench line); the others are extra single-GPU measurements")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
-                    help="skip extra_measurements (config 2 and the rebuild-inclusive PbTe segment, timed after the bench line's clock)")
+                    help="skip extra_measurements (config 2, the rebuild-inclusive PbTe segment, the config 4/5 model families; "
+                         "N > 1: the strong-scaling leg), all timed after the bench line's clock")
     ap.add_argument("--decomposed", action="store_true",
                     help="run the N > 1 code path (the C++ domain-decomposed driver) even on one GPU, to measure its overhead")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
@@ -502,7 +585,8 @@ def main():
     ap.add_argument("--ghosts", type=int, default=-1, choices=[-1, 0, 1],
                     help="decomposed runs, nepmi_dist_set_ghost_mode: -1 the counted rule (default), 0 forward, 1 reverse ghosts")
     ap.add_argument("--overlap", type=int, default=-1, choices=[-1, 0, 1],
-                    help="decomposed runs, nepmi_dist_set_overlap: interior bricks' radial pass while the ghosts travel (-1: library default)")
+                    help="decomposed runs, nepmi_dist_set_overlap: exchange on the side stream while interior bricks run "
+                         "(-1: library default; 0 / 1 for an A/B in one command)")
     ap.add_argument("--ensemble", default="nve", choices=["nve", "nvt_ber", "nvt_nhc", "nvt_bdp", "nvt_lan", "nvt_bao"],
                     help="decomposed runs: the ensemble (config 5 is NVT); the single-GPU bench line is NVE")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -511,7 +595,24 @@ def main():
     if args.cpu_worker is not None:  # one instance of the all-cores CPU aggregate, no GPU involved
         cpu_worker(args.cpu_worker)
         return
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
+    rank = int(os.environ.get("RANK", "0"))
+    try:
+        bench(args)
+    except SystemExit:
+        raise
+    except BaseException as e:  # a failed rank says where it failed instead of dying silently (rank 0's is the bench line)
+        line = json.dumps({"error": "%s: %s" % (type(e).__name__, e), "stage": STAGE, "rank": rank, "n_gpus": args.gpus,
+                           "metric": METRIC.get(args.workload, args.workload)})
+        (sys.stdout if rank == 0 else sys.stderr).write(line + "\n")
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(3)  # do not wait in a collective's destructor for ranks that are gone
 
+
+def bench(args):
+    global STAGE
     import torch
     import torch.distributed as dist
     import gpumd_amd
@@ -521,24 +622,26 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU path for the product")
-    # NEPMI_DIST_BACKEND=gloo: functional check of the N > 1 path on a box with fewer GPUs than
+    # NEPMI_DIST_BACKEND=tcp|gloo: functional check of the N > 1 path on a box with fewer GPUs than
     # ranks (ranks share devices, messages staged through host memory); never a performance run.
     backend = os.environ.get("NEPMI_DIST_BACKEND", "nccl")
     local_dev = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
     if world > 1:
+        STAGE = "torch.distributed init (%s)" % backend
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             # a wedged exchange should fail fast (watchdog), not hold the node for the default 10 min
             dist.init_process_group("nccl", device_id=dev, timeout=datetime.timedelta(seconds=300))
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=300))
 
     # ---- workload: every rank generates its own block of `reps` cells (weak scaling) ----
+    STAGE = "workload"
     reps = tuple(args.reps)
     label, nep_txt, h, typ, x, mass, vel = build_workload(args.workload, reps, 42 + (rank if args.scaling == "weak" else 0))
     n = len(typ)
@@ -546,7 +649,28 @@ def main():
     model = gpumd_amd.Model(nep_txt)
     dt = 1.0 / H.TIME_UNIT
     if world > 1 or args.decomposed:
-        run_decomposed(args, world, rank, dev, model, label, h, typ, x, mass, vel)
+        out = run_decomposed(args, world, rank, dev, model, label, h, typ, x, mass, vel)
+        if world > 1 and backend != "nccl" and out is not None:
+            out["functional_only"] = ("ranks share %d GPU(s) over the TCP transport (host staging): the protocol of the N-GPU run, "
+                                      "not its performance" % torch.cuda.device_count())
+        if world > 1 and args.scaling == "weak" and not args.no_extras:
+            # after the clock: the SAME 1,024,000-atom system as the N = 1 line cut over the N GPUs (strong scaling)
+            try:
+                label_s, _, h_s, typ_s, x_s, mass_s, vel_s = build_workload(args.workload, reps, 42)
+                strong = run_decomposed(args, world, rank, dev, model, label_s, h_s, typ_s, x_s, mass_s, vel_s,
+                                        scaling="strong", leg=1, steps=min(args.steps, 100), warmup=min(args.warmup, 10))
+                if out is not None and strong is not None:
+                    out.setdefault("extra_measurements", {})["strong"] = {
+                        k: strong[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "scaling", "config", "roofline",
+                                               "step_hbm_frac")}
+            except Exception as e:  # never lose the bench line to an extra
+                if out is not None:
+                    out.setdefault("extra_measurements", {})["strong"] = {"error": "%s: %s" % (type(e).__name__, e), "stage": STAGE}
+        if out is not None:
+            print(json.dumps(out))
+            sys.stdout.flush()
+        if world > 1:
+            dist.destroy_process_group()
         return
     eng = gpumd_amd.NEP(model, n)
     t_type = torch.from_numpy(typ).to(dev)
