@@ -475,6 +475,16 @@ int nepmi_engine_set_win_lanes(nepmi_engine* e, int lanes)
   return NEPMI_OK;
 }
 
+int nepmi_engine_set_force_form(nepmi_engine* e, int mode)
+{
+  if (!e)
+    return fail(NEPMI_ERR_ARG, "null engine");
+  if (mode < -1 || mode > 1)
+    return fail(NEPMI_ERR_ARG, "force form: -1 (by caller), 0 (gather), 1 (scatter)");
+  e->e->set_force_form(mode);
+  return NEPMI_OK;
+}
+
 int nepmi_engine_set_stepwise_loops(nepmi_engine* e, int on)
 {
   if (!e)

@@ -353,8 +353,13 @@ public:
   void gather_owned(int64_t* ids, double* pos, double* vel, double* force, double* pe, double* virial)
   {
     Engine& e = *eng_;
-    if (virial)
-      fold_virial();
+    // Per-atom virials leave the engine: the reference's attribution (a virial-only pass of the gather form after scatter-form
+    // steps) and, with reverse ghosts, the halves computed on other ranks' ghosts.  Both on EVERY call, whether or not this
+    // rank asked for the virials: the fold is a collective, and a caller that passes NULL on some ranks must not leave the
+    // others waiting in it (as gather_global does).
+    e.exact_virials();
+    fold_virial();
+    (void)virial;
     be_.template launch<256>(kSlotMisc, e.num_atoms(),
                              GatherOwnedBody{e.bufs(), geom_, cur_.n_own, cur_.id, ids, pos, vel, force, pe, virial});
     be_.sync();
@@ -365,6 +370,7 @@ public:
   void gather_global(int root, double* pos, double* vel, double* force, double* pe, double* virial)
   {
     Engine& e = *eng_;
+    e.exact_virials();
     fold_virial(); // collective: every rank, whether or not the root asked for the virials
     const int P = tr_.nranks, me = tr_.rank;
     const int64_t no = cur_.n_own;
@@ -988,6 +994,8 @@ private:
       eng_cap_ = n_loc + n_loc / 7 + 1024;
       std::unique_ptr<Engine> grown(new Engine(model_, eng_cap_, be_));
       grown->set_external_skin(true); // the global vote is the skin policy
+      grown->set_loop_context(true);  // every force evaluation here feeds the integrator and the global sums: the force
+                                      // assembly may take its scatter form (per-atom virials: exact_virials at the gathers)
       grown->set_reverse_ghosts(reverse_);
       grown->bdp_seed(seed_);
       if (eng_) // a grown local system: the switches, the temperature, the noise sequence and the counters move over

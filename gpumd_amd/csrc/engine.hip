@@ -15,6 +15,7 @@
 #include <string>
 
 #include "engine_impl.h"
+#include "nep_scatter.h" // device-only force assembly (LDS scatter of the own pair halves)
 
 namespace nepmi {
 
@@ -1186,6 +1187,52 @@ struct HipBackend {
       timer_stop(timing->slot[slot]);
   }
   static constexpr size_t kMaxLdsBytes = 160 * 1024; // per workgroup (one per CU)
+
+  // Force assembly in the scatter form (nep_scatter.h): one workgroup per brick scatters the own pair halves into its LDS
+  // window accumulator and writes it to its row of hacc; ForceFoldBody then adds every atom's entries.  One timing bracket
+  // around both launches: together they are the force assembly.
+  static constexpr bool kHasScatter = true;
+  template <class S>
+  void launch_force_scatter(int slot, int64_t nbricks, int64_t natoms, const WinStage& ws2, const ModelD& md, int* halo,
+                            const unsigned* fmap, int fold_rows, const int* frz)
+  {
+    if constexpr (S::TS > 0) {
+      if (nbricks <= 0)
+        return;
+      const ForceScatterBody<S> body{ws2, md, frz, reinterpret_cast<I4*>(halo)};
+      const ScatterLayout lay{ws2.lay.wmax};
+      const int64_t grid = (nbricks + 7) / 8 * 8;
+      const size_t lds_bytes = ((size_t)lay.bytes() + 15) / 16 * 16;
+      if (lds_bytes > 64 * 1024)
+        NEPMI_HIP_CHECK(hipFuncSetAttribute(
+          reinterpret_cast<const void*>(&nepmi_force_scatter_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize,
+          (int)lds_bytes));
+      const bool t = timed(slot);
+      if (t)
+        timer_start(timing->slot[slot]);
+      hipLaunchKernelGGL((nepmi_force_scatter_kernel<S>), dim3((unsigned)grid), dim3(kWinThreads), lds_bytes, stream, body, nbricks);
+      NEPMI_HIP_CHECK(hipGetLastError());
+      const ForceFoldBody fold{ws2.b, md, ws2.lay.wmax, fold_rows, fmap, reinterpret_cast<const I4*>(halo)};
+      const int64_t fgrid = ((natoms + 255) / 256 + 7) / 8 * 8;
+      hipLaunchKernelGGL((nepmi_kernel<256, ForceFoldBody>), dim3((unsigned)fgrid), dim3(256), 0, stream, fold, natoms, frz);
+      NEPMI_HIP_CHECK(hipGetLastError());
+      if (t)
+        timer_stop(timing->slot[slot]);
+    }
+  }
+  // the windows that hold each atom (FoldMapBody), once per list rebuild; returns the largest number of windows met
+  int build_fold_map(int64_t natoms, const BoxD& box, const Bufs& b, int wmax, int rows, unsigned* fmap)
+  {
+    int* word = b.flags + kFlagFoldRows;
+    NEPMI_HIP_CHECK(hipMemsetAsync(word, 0, sizeof(int), stream));
+    const FoldMapBody body{box, b, wmax, rows, fmap, word};
+    const int64_t grid = ((natoms + 255) / 256 + 7) / 8 * 8;
+    hipLaunchKernelGGL((nepmi_kernel<256, FoldMapBody>), dim3((unsigned)grid), dim3(256), 0, stream, body, natoms, nullptr);
+    NEPMI_HIP_CHECK(hipGetLastError());
+    int most = 0;
+    d2h(&most, word, sizeof(int));
+    return most;
+  }
 
   static constexpr bool kSplitLanes = true; // window kernels with several lanes per atom exist on this backend
   template <class Body>

@@ -516,6 +516,12 @@ public:
     box_from_h9(h9, pbc, box);
     if (n < 1 || n > cap_)
       throw EngineError{-4, "number of atoms exceeds the engine's capacity"};
+    struct LoopCtx { // the steps of this loop need forces, energies and the total virial only
+      EngineT& e;
+      bool was;
+      explicit LoopCtx(EngineT& e_) : e(e_), was(e_.loop_ctx_) { e.loop_ctx_ = true; }
+      ~LoopCtx() { e.loop_ctx_ = was; }
+    } loop_ctx(*this);
     if ((is_small_box(box) && model_.kind == 0) || (stepwise_loops_ && (ens == kLan || ens == kBao))) {
       // (set_stepwise_loops: the Langevin ensembles as the plain sequence of the per-call entry points on the caller's
       // arrays -- what the resident forms are checked against, bit for bit)
@@ -678,6 +684,8 @@ public:
       ++step;
     }
     num_compute = compute0 + nsteps;
+    if (virial)
+      exact_virials(); // per-atom virials leave the engine
     resident_export(pos, vel, pe, force, virial);
     be_.sync();
     be_.d2h(flags, b_.flags, sizeof(flags));
@@ -960,6 +968,9 @@ private:
       b_.fpr = m.num_types > 4 ? dalloc<float>((size_t)N * b_.FPR) : nullptr; // many-type models: see ForceWinBody<..., FPJ>
       b_.MN_cw = (b_.MN_rad + 3) / 4 + 1;
       b_.cword = dalloc<unsigned short>((size_t)2 * b_.MN_cw * 4 * N);
+      // scatter-form force assembly (nep_scatter.h; device backends only)
+      b_.aslot = B::kHasScatter ? dalloc<unsigned short>((size_t)b_.MN_acomp * N) : nullptr;
+      b_.compact_all = b_.aslot ? 1 : 0;
     } else { // Tersoff-1989: Tersoff1989::Tersoff1989 allocations (tersoff1989.cu:141-149)
       tb_.rec = dalloc<D4>((size_t)b_.MN_ang * N);
       tb_.bb = dalloc<double>((size_t)b_.MN_ang * N);
@@ -990,6 +1001,12 @@ private:
 
   void check_overflow(const int* flags)
   {
+    if (flags[kFlagRange] && !scatter_disabled_) {
+      // nep_scatter.h: a pair half beyond the guard band of the fixed-point accumulators (the sums are still exact: the band
+      // sits a factor eight below their range).  The gather form has no such limit: it takes over for the rest of the run.
+      scatter_disabled_ = true;
+      be_.memset(b_.flags + kFlagRange, 0, sizeof(int));
+    }
     if (flags[kFlagOverflow] & 8)
       throw EngineError{-4, "non-finite atom coordinates (the simulation has blown up, or the position array is not initialised)"};
     if (flags[kFlagOverflow]) {
@@ -1259,6 +1276,26 @@ private:
       be_.d2h(flags, b_.flags, sizeof(flags));
       check_overflow(flags);
     }
+    if (win2_ok_ && b_.aslot) {
+      // scatter-form force assembly: one halo row per brick (the window sums its workgroup leaves for ForceFoldBody, 16 bytes
+      // per window slot) and, per atom, the table of the windows that hold it (nep_scatter.h: FoldMapBody)
+      const size_t need = (size_t)num_bricks_ * (size_t)win_.wmax * 4;
+      if (need > halo_cap_) {
+        halo_ = dalloc<int>(need + need / 8);
+        halo_cap_ = need + need / 8;
+      }
+      if (!fmap_)
+        fmap_ = dalloc<unsigned>((size_t)fold_rows_ * cap_);
+      fold_ok_ = num_bricks_ < ((int64_t)1 << 19) && win_.wmax < (1 << 13);
+      if (fold_ok_) {
+        int most = be_.build_fold_map(N_, box_, b_, win_.wmax, fold_rows_, fmap_);
+        if (most > fold_rows_) { // (partly filled bricks next to a periodic face: a cell can lie in up to 27 windows)
+          fold_rows_ = most;
+          fmap_ = dalloc<unsigned>((size_t)fold_rows_ * cap_);
+          most = be_.build_fold_map(N_, box_, b_, win_.wmax, fold_rows_, fmap_);
+        }
+      }
+    }
     if (reverse_ghosts_ && b_.level) {
       // the rows a ghost would have written in forward mode are read by its neighbours' (and its own) force assembly: zero
       // = no contribution; owned atoms rewrite theirs every step
@@ -1448,6 +1485,9 @@ public:
     win_lanes_ = o.win_lanes_;
     use_win2_ = o.use_win2_;
     external_skin_ = o.external_skin_;
+    force_form_ = o.force_form_;
+    loop_ctx_ = o.loop_ctx_;
+    scatter_disabled_ = o.scatter_disabled_;
     if (reverse_ghosts_ != o.reverse_ghosts_)
       set_reverse_ghosts(o.reverse_ghosts_);
     unwrapped_ = o.unwrapped_;
@@ -1543,8 +1583,28 @@ private:
       be_.template launch_ann<S>(kSlotAnn, N_, md_, b_, true);
     }
     launch_angular_force<S>();
+    last_scatter_form_ = false;
+    if (win2 && scatter_form<S>(ws2, frozen)) {
+      virial_local_ = true; // the virial planes hold the own-half form: exact_virials() before they leave the engine
+      if (force_form_ == 1 && !loop_ctx_) // a per-call evaluation in the forced scatter form returns per-atom virials
+        gather_assembly<S>(ws, ws2, lanes, win2, frozen, 1);
+    } else {
+      virial_local_ = false;
+      gather_assembly<S>(ws, ws2, lanes, win2, frozen, 0);
+    }
+    be_.end_region(kRegionForce);
+  }
+
+  // The gather form of the force assembly (ForceWinBody / ForceAssembleBody); wonly: only the nine virial planes are written
+  template <class S>
+  void gather_assembly(const WinStage& ws, const WinStage& ws2, int lanes, bool win2, const int* frozen, int wonly)
+  {
+    if (wonly)
+      virial_local_ = false;
     if (!tile_ok_)
       be_.template launch<64>(kSlotForce, N_, ForceAssembleBody<S>{md_, b_});
+    else if (wonly && win2)
+      be_.launch_win2(kSlotMisc, num_bricks_, ForceWinBody<S, 1, NEPMI_CW != 0>{ws2, md_, frozen, 1});
     else if (win2 && rows_form<S>(ws2, frozen))
       ; // (launched by rows_form)
     else if (win2 && fpj_form<S>(ws2, frozen))
@@ -1557,7 +1617,66 @@ private:
       be_.launch_win_split(kSlotForce, num_bricks_, ForceWinBody<S, 2>{ws, md_, frozen});
     else
       be_.launch_win(kSlotForce, num_bricks_, ForceWinBody<S>{ws, md_, frozen});
-    be_.end_region(kRegionForce);
+  }
+
+  // Force assembly as an LDS-local scatter of the own pair halves (nep_scatter.h): the static window layout with one lane per
+  // atom, shapes with register-resident per-type rows, a device backend; in the run loops (or wherever set_force_form(1)
+  // asks for it) and until a pair half has left the fixed-point guard band (flags[kFlagRange]).  A counted rule.
+  template <class S>
+  bool scatter_wanted() const
+  {
+    if (!B::kHasScatter || !(S::TS > 0) || !b_.aslot || !halo_ || !fmap_ || !fold_ok_ || scatter_disabled_ || force_form_ == 0)
+      return false;
+    if (force_form_ < 0 && !loop_ctx_)
+      return false;
+    return 24 * (size_t)win_.wmax <= B::kMaxLdsBytes;
+  }
+  template <class S>
+  bool scatter_form(const WinStage& ws2, const int* frozen)
+  {
+    if (!scatter_wanted<S>())
+      return false;
+    be_.template launch_force_scatter<S>(kSlotForce, num_bricks_, N_, ws2, md_, halo_, fmap_, fold_rows_, frozen);
+    last_scatter_form_ = true;
+    return true;
+  }
+
+public:
+  // -1 (default): the run loops take the scatter form where it applies, the per-call entry points the gather form (their
+  // per-atom virials are the reference's); 0: gather everywhere; 1: scatter everywhere it applies (per-call evaluations
+  // then add one virial-only pass of the gather form)
+  void set_force_form(int mode) { force_form_ = mode < 0 ? -1 : (mode > 1 ? 1 : mode); }
+  // the callers whose steps need forces, energies and the TOTAL virial only (run loops; the decomposed driver)
+  void set_loop_context(bool on) { loop_ctx_ = on; }
+  bool loop_context() const { return loop_ctx_; }
+  // Per-atom virials in the reference's attribution (W_i = sum_j r_ij (x) f21): after a scatter-form step the virial planes
+  // hold the own-half form, whose sum is the same; one virial-only pass of the gather form on the step's data replaces them.
+  void exact_virials()
+  {
+    if (!virial_local_ || model_.kind != 0 || last_small_)
+      return;
+    be_.frozen = nullptr;
+    switch (shape_) {
+      case 1: exact_virials_shape<S_PbTeA>(); break;
+      case 2: exact_virials_shape<S_PbTeB>(); break;
+      case 3: exact_virials_shape<S_C2022>(); break;
+      case 4: exact_virials_shape<S_UNEP>(); break;
+      case 5: exact_virials_shape<S_BZO>(); break;
+      default: exact_virials_shape<ShapeGeneric>(); break;
+    }
+  }
+  bool virial_local() const { return virial_local_; }
+
+private:
+  template <class S>
+  void exact_virials_shape()
+  {
+    const WinStage ws{box_, b_, win_};
+    WinLayout lay2 = win_;
+    lay2.compact = 1;
+    const WinStage ws2{box_, b_, lay2};
+    const int lanes = win_lanes();
+    gather_assembly<S>(ws, ws2, lanes, win2_ok_ && lanes == 1, nullptr, 1);
   }
 
   // Force assembly with the neighbours' table rows in LDS (ForceWinBody<..., ROWS>): shapes with register-resident sums whose
@@ -1634,7 +1753,8 @@ public:
       s += " ann=per_atom";
     s += (shape_ != 0 && model_.n_max_angular + 1 >= 7) ? " angular_force=lane_pairs" : " angular_force=one_lane";
     s += recompute_s() ? " angular_sums=recomputed" : " angular_sums=stored";
-    s += last_rows_form_ ? " force_assembly=table_rows_in_lds"
+    s += last_scatter_form_ ? " force_assembly=lds_scatter_of_own_halves(fixed_point)+fold" :
+         last_rows_form_ ? " force_assembly=table_rows_in_lds"
                          : (last_fpj_form_ ? " force_assembly=neighbour_half_from_fp_rows" : " force_assembly=table_rows_gathered");
     return s;
   }
@@ -1693,7 +1813,16 @@ private:
   WinLayout win_{0, 0};
   bool win2_ok_ = false, use_win2_ = NEPMI_WIN2_DEFAULT != 0;
   bool use_rows_ = true; // force assembly with the table rows in LDS where they fit
-  bool last_rows_form_ = false, last_fpj_form_ = false;
+  bool last_rows_form_ = false, last_fpj_form_ = false, last_scatter_form_ = false;
+  int force_form_ = -1;          // set_force_form
+  bool loop_ctx_ = false;        // set_loop_context
+  bool virial_local_ = false;    // the virial planes of the last force evaluation hold the own-half form (exact_virials)
+  bool scatter_disabled_ = false; // a pair half left the fixed-point guard band of the scatter form: gather form from then on
+  int* halo_ = nullptr;          // [bricks][wmax][4] window sums of the scatter form (fixed point)
+  size_t halo_cap_ = 0;
+  unsigned* fmap_ = nullptr;     // [fold_rows_][cap_] the windows that hold each atom (brick << 13 | slot)
+  int fold_rows_ = 8;
+  bool fold_ok_ = false;
   bool stepwise_loops_ = false; // test hook: nvt_lan / nvt_bao as the stepwise sequence // static window layout (Bufs::wtab / wcode) in use / allowed
   double* ui_alloc_ = nullptr;
   double* factor_dev_ = nullptr;

@@ -82,6 +82,8 @@ enum FlagSlot {
   kFlagMoved = 0, kFlagOverflow = 1, kFlagMaxSkin = 2, kFlagMaxAng = 3,
   kFlagMaxWindow = 4, kFlagMaxBrick = 5, kFlagMaxCell = 6, kFlagNumBoundary = 7,
   kFlagOutlier = 8, // an atom sits more than half a cell outside the box along an open direction
+  kFlagRange = 9,   // the scatter-form force assembly met a pair half beyond its fixed-point guard band (nep_scatter.h)
+  kFlagFoldRows = 10, // scratch word of FoldMapBody: the most windows an atom lies in
   kNumFlags = 12
 };
 
@@ -186,6 +188,11 @@ struct Bufs {
   int FPR;
   int skip_atab; // 1: this step's force assembly contracts both halves of a pair from Fp rows (FPJ form): the ANN kernel need not
                  // form the radial table (T k_r' floats per atom)
+  // scatter-form force assembly (nep_scatter.h, device only): LDS window slot of the partner of every compact angular slot,
+  // written by the static-layout radial pass next to aidx; nullptr on backends without that form
+  unsigned short* aslot; // [MN_acomp][N]
+  int compact_all;       // 1: every atom with level >= 1 writes its compact radial list (the scatter form walks the lists of the
+                         // atoms that have descriptors, the gather form those of the atoms that receive forces)
 };
 
 // planes of Bufs::fo

@@ -724,7 +724,7 @@ struct RadialWin2Body {
       q[n] = 0.0f;
 
     const int na = b.nn_ang[k];
-    const bool owned = b.lvl[k] >= b.lvl_force; // ("owned" = its force assembly runs and reads the compact list)
+    const bool owned = b.lvl[k] >= (b.compact_all ? 1 : b.lvl_force); // ("owned" = its force assembly runs and reads the compact list)
     const int seg = b.wseg[k];
     const int wa = seg & 255, wb = (seg >> 8) & 255; // words of list A; words (ZIP: word pairs) of list B
     unsigned am[4] = {0u, 0u, 0u, 0u}; // membership bits of list A (Bufs::amask)
@@ -953,6 +953,8 @@ struct RadialWin2Body {
                 e.w = c[u].rw;
                 acomp[(int64_t)ca * N] = e;
                 aidx[(int64_t)ca * N] = b.rev_ang[(int64_t)idx * N + k]; // reverse slot of this pair in j's list A
+                if (b.aslot)
+                  b.aslot[(int64_t)ca * N + k] = (unsigned short)c[u].slot; // the partner's place in this brick's window
                 cs = (unsigned short)ca;
                 const unsigned bit = 1u << (idx & 31);
                 const int aw = idx >> 5;
@@ -1691,6 +1693,8 @@ struct ForceWinBody {
   WinStage st;
   ModelD m;
   const int* frozen;
+  int wonly = 0; // 1: only the nine virial planes are written (the per-atom virials of the reference's attribution after a
+                 // step whose forces came from the scatter form, nep_scatter.h)
   NEPMI_HD int rows_offset() const { return (st.lay.bytes() + 15) / 16 * 16; }
 #ifndef NEPMI_FW_ROWPAD
 #define NEPMI_FW_ROWPAD 4 // floats of padding per LDS row: a 64-byte stride puts every row on one of four bank groups
@@ -2012,10 +2016,12 @@ struct ForceWinBody {
       E += (double)b.zbl[(int64_t)9 * N + k];
     }
     double* __restrict__ fo = b.fo + k;
-    fo[0] = E;
+    if (!wonly) {
+      fo[0] = E;
 #pragma unroll
-    for (int d = 0; d < 3; ++d)
-      fo[(int64_t)(kOutF + d) * N] = Fd[d];
+      for (int d = 0; d < 3; ++d)
+        fo[(int64_t)(kOutF + d) * N] = Fd[d];
+    }
 #pragma unroll
     for (int d = 0; d < 9; ++d)
       fo[(int64_t)(kOutW + d) * N] = Wd[d];

@@ -304,6 +304,11 @@ class NEP:
         """lanes per atom of the LDS-window kernels: 0 = by the number of bricks, or 1 / 2 / 4"""
         self._ck(self.lib.nepmi_engine_set_win_lanes(self.handle, int(lanes)))
 
+    def set_force_form(self, mode=-1):
+        """force assembly: -1 run loops scatter / per-call gather (default), 0 gather everywhere, 1 scatter wherever it applies
+        (nepmi_engine_set_force_form)"""
+        self._ck(self.lib.nepmi_engine_set_force_form(self.handle, int(mode)))
+
     def describe(self):
         """the kernel forms the last force evaluation ran (counted rules of the engine, as text)"""
         import ctypes as C

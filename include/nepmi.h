@@ -406,6 +406,19 @@ int nepmi_engine_set_tiles(nepmi_engine* e, int on);
 /* Lanes per atom of the LDS-window kernels: 0 (default) = by the number of bricks (4 up to 256 bricks, 2 up to 400,
  * else 1: small systems are bound by the latency of one workgroup); 1, 2, 4 pin it. */
 int nepmi_engine_set_win_lanes(nepmi_engine* e, int lanes);
+/* Form of the force assembly (find_force_radial + gpu_find_force_many_body: nep.cu:661-772, potential.cu:170-297).
+ *   gather  : every lane evaluates both halves of its pairs, f12 - f21, the partner's half from rows gathered from the
+ *             partner -- per-atom virials in the reference's attribution (W_i = sum_j r_ij (x) f21);
+ *   scatter : every lane evaluates its own half only and adds the reaction to the partner's slot of a fixed-point accumulator
+ *             over the brick's LDS window (the reference's small-box formulation, nep_small_box.cuh:473-478, made local and
+ *             deterministic); forces, energies and the TOTAL virial are the same to f32 rounding, the per-atom virial planes
+ *             hold the own-half form until a virial-only pass of the gather form replaces them -- the engine runs that pass
+ *             itself whenever per-atom virials leave it.  Static window layout, one lane per atom, one or two types.
+ * mode -1 (default): the fused run loops (nepmi_run_*, nepmi_dist_*) take the scatter form where it applies, the per-call
+ * entry points (nepmi_potential_compute, nepmi_force_compute) the gather form; 0: gather everywhere; 1: scatter wherever it
+ * applies (per-call evaluations then add the virial-only pass).  A pair half beyond 64 eV/A returns the engine to the gather
+ * form for the rest of its life (the fixed-point sums wrap at +-512 eV/A net per window). */
+int nepmi_engine_set_force_form(nepmi_engine* e, int mode);
 /* Static window layout of the one-lane window kernels (default on): between two list rebuilds the LDS slot of every window
  * atom is fixed, so the rebuild tabulates the windows and stores the Verlet entries as LDS slots, four to an 8-byte word
  * (two-type models: list B as two type-pure streams); on = 0 keeps the per-launch scan of the window cells and the

@@ -148,6 +148,14 @@ struct HostLoopBackend {
     }
   }
   static constexpr size_t kMaxLdsBytes = 160 * 1024;
+  // the scatter form of the force assembly (gpumd_amd/csrc/nep_scatter.h) is device code only: never selected here
+  static constexpr bool kHasScatter = false;
+  template <class S>
+  void launch_force_scatter(int, int64_t, int64_t, const WinStage&, const ModelD&, int*, const unsigned*, int, const int*)
+  {
+    std::abort();
+  }
+  int build_fold_map(int64_t, const BoxD&, const Bufs&, int, int, unsigned*) { return 0; }
 
   // bodies with a workgroup-staged table: the "LDS" is an ordinary host buffer here
   template <int BLOCK, class Body>

@@ -80,6 +80,43 @@ def test_force_parity_window_layouts(drv, name, static):
         assert ("neighbour_half_from_fp_rows" in eng.describe()) == bool(static)
 
 
+@pytest.mark.parametrize("name", ["PbTe-A", "PbTe-B", "PbTe-3x3x3", "PbTe-ortho-big", "C-2022", "C-nep3", "C-2024", "Si-5body"])
+def test_force_parity_scatter_form(drv, name):
+    """The force assembly as an LDS-local scatter of the own pair halves into fixed-point window accumulators + the fold
+    (gpumd_amd/csrc/nep_scatter.h; the form the run loops take), forced for a per-call evaluation -- which then adds the
+    virial-only pass of the gather form, so every check of the parity case applies unchanged: energies, every force against
+    the FP64 and the FP32 oracle, per-atom virials in the reference's attribution, descriptors, the three lists."""
+    eng = P.check_force_parity(drv, name, lanes=1, win_static=True, force_form=1)
+    if eng.stats().radial_tiles == 3:  # (smaller boxes have no window kernels at all: the gather kernels ran)
+        assert "lds_scatter_of_own_halves" in eng.describe(), eng.describe()
+
+
+def test_scatter_form_properties(drv):
+    """Scatter form vs gather form of one engine on the same positions: forces equal to fixed-point + f32 rounding, the TOTAL
+    virial of the own-half form equals the gather form's, total force exactly zero in fixed point (+g and -g are the same
+    integer), a second call bit-identical (integer sums do not depend on the order the lanes arrive in)."""
+    nep = H.golden("PbTe", "nep.txt")
+    h, typ, x = H.pbte_supercell((3, 3, 3), rattle=0.05, seed=11)
+    n = len(typ)
+    model = drv.model(nep)
+    out = {}
+    for form in (0, 1):
+        eng = drv.engine(model, n)
+        eng.set_win_lanes(1)
+        eng.set_force_form(form)
+        _, pe, f, v = H.engine_force(drv, eng, h, typ, x)
+        _, pe2, f2, v2 = H.engine_force(drv, eng, h, typ, x)
+        assert np.array_equal(f, f2) and np.array_equal(pe, pe2) and np.array_equal(v, v2)
+        out[form] = (pe, f, v, eng.describe())
+    assert "lds_scatter_of_own_halves" in out[1][3] and "lds_scatter" not in out[0][3]
+    assert np.array_equal(out[0][0], out[1][0])  # energies: the same kernels
+    assert np.abs(out[0][1] - out[1][1]).max() < 4e-6, np.abs(out[0][1] - out[1][1]).max()
+    np.testing.assert_allclose(out[1][2], out[0][2], rtol=0, atol=1e-12)  # per-atom virials: the same virial-only gather pass
+    # total force: every pair half enters twice with opposite sign as the same integer of 2^-22 eV/A
+    fsum = out[1][1].reshape(3, n).sum(axis=1)
+    assert np.abs(fsum).max() < 1e-9, fsum
+
+
 @pytest.mark.parametrize("name", ["PbTe-A", "C-2022"])
 def test_force_parity_with_pair_records(drv, name):
     """Tile mode 1: LDS-window radial pass that writes pair records + the record-reading force assembly."""
