@@ -235,10 +235,19 @@ struct LevelBody {
 };
 
 // owned[id[q]] = 1 for the owned atoms q of this rank (Langevin generator states are indexed by global id)
-struct MarkOwnedBody {
-  const int64_t* id;
-  signed char* owned;
-  NEPMI_HD void operator()(int64_t q) const { owned[id[q]] = 1; }
+// Langevin generator states travel with their atoms: records of `words` 8-byte words each.
+//   out[q] = in[idx[q]] (idx == nullptr: in[q]); one work-item per record
+struct GatherRecordsBody {
+  const unsigned long long* in;
+  const int* idx;
+  int words;
+  unsigned long long* out;
+  NEPMI_HD void operator()(int64_t q) const
+  {
+    const int64_t i = idx ? (int64_t)idx[q] : q;
+    for (int w = 0; w < words; ++w)
+      out[q * words + w] = in[i * words + w];
+  }
 };
 
 struct InversePermBody {
@@ -252,6 +261,233 @@ struct MapIndexBody { // out[q] = inv[base + in[q]] (in == nullptr: identity)
   int64_t base;
   int* out;
   NEPMI_HD void operator()(int64_t q) const { out[q] = inv[base + (in ? in[q] : (int)q)]; }
+};
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Direct halo: every rank exchanges with its (up to 26) neighbours of the process grid in ONE grouped exchange -- faces,
+// edges and corners as separate messages, no forwarding through intermediate ranks (every peer of a 2x2x2
+// grid on an 8-GPU node is a direct xGMI link).  Peer p has the grid offset off[p] in {-1, 0, +1}^3 (0 along directions
+// that are not decomposed); an owned atom goes to p when it lies in the shell next to every face off[p] points through.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int kMaxPeers = 26;
+struct PeerTable {
+  int n;
+  int off[kMaxPeers][3];
+  double shift[kMaxPeers][3]; // added to a position sent to peer p: the receiver's local coordinates
+};
+
+// decomposition: bit p of mask[i] = owned atom i goes to peer p; any[i] = mask != 0
+struct PeerMaskBody {
+  DomainGeom g;
+  PeerTable pt;
+  int64_t n; // stride of x
+  const double* x;
+  unsigned* mask;
+  int* any;
+  NEPMI_HD void operator()(int64_t i) const
+  {
+    double s[3];
+    frac_of(g, x[i] + g.origin[0], x[n + i] + g.origin[1], x[2 * n + i] + g.origin[2], s);
+    bool lo[3], hi[3];
+    for (int d = 0; d < 3; ++d) {
+      lo[d] = s[d] < g.lo[d] + g.wfrac[d];
+      hi[d] = s[d] >= g.hi[d] - g.wfrac[d];
+    }
+    unsigned m = 0u;
+    for (int p = 0; p < pt.n; ++p) {
+      bool ok = true;
+      for (int d = 0; d < 3; ++d)
+        ok = ok && (pt.off[p][d] == 0 || (pt.off[p][d] < 0 ? lo[d] : hi[d]));
+      m |= ok ? (1u << p) : 0u;
+    }
+    mask[i] = m;
+    any[i] = m != 0u ? 1 : 0;
+  }
+};
+// flag[p (m + 1) + j] = shell atom j (= owned atom L[j]) goes to peer p; the slot j = m of every block and the last word stay 0:
+// ONE exclusive scan of the whole array then numbers the send entries peer-major (entry = scan value) and its value at the
+// start of block p is the offset of peer p's message
+struct PeerFlagBody {
+  const unsigned* mask;
+  const int* L;
+  int64_t m;
+  int npeers;
+  int* flag;
+  NEPMI_HD void operator()(int64_t q) const
+  {
+    const int64_t p = q / (m + 1), j = q - p * (m + 1);
+    flag[q] = (p < npeers && j < m && ((mask[L[j]] >> p) & 1u)) ? 1 : 0;
+  }
+};
+struct PeerFillBody { // send_idx / send_peer of every entry; `scan` = the exclusive scan of PeerFlagBody's array
+  const unsigned* mask;
+  const int* L;
+  int64_t m;
+  int npeers;
+  const int* scan;
+  int* send_idx;
+  unsigned char* send_peer;
+  NEPMI_HD void operator()(int64_t q) const
+  {
+    const int64_t p = q / (m + 1), j = q - p * (m + 1);
+    if (j < m && ((mask[L[j]] >> p) & 1u)) {
+      send_idx[scan[q]] = L[j];
+      send_peer[scan[q]] = (unsigned char)p;
+    }
+  }
+};
+struct PeerOffsetsBody { // out[p] = first entry of peer p, out[npeers] = number of entries
+  const int* scan;
+  int64_t m;
+  int npeers;
+  int* out;
+  NEPMI_HD void operator()(int64_t p) const { out[p] = scan[p * (m + 1)]; }
+};
+// reverse path: the entries of every shell atom in ascending peer order (what GhostAddPeersBody adds, in that order)
+struct PeerCountBody { // cnt[j] = number of peers of shell atom j (cnt[m] = 0)
+  const unsigned* mask;
+  const int* L;
+  int64_t m;
+  int* cnt;
+  NEPMI_HD void operator()(int64_t j) const
+  {
+    unsigned v = j < m ? mask[L[j]] : 0u;
+    int c = 0;
+    for (; v; v &= v - 1u)
+      ++c;
+    cnt[j] = c;
+  }
+};
+struct PeerCsrBody {
+  const unsigned* mask;
+  const int* L;
+  int64_t m;
+  int npeers;
+  const int* scan;  // entry numbers (PeerFlagBody's array, scanned)
+  const int* start; // exclusive scan of PeerCountBody's counts
+  int* entry;
+  NEPMI_HD void operator()(int64_t j) const
+  {
+    const unsigned v = mask[L[j]];
+    int pos = start[j];
+    for (int p = 0; p < npeers; ++p)
+      if ((v >> p) & 1u)
+        entry[pos++] = scan[(int64_t)p * (m + 1) + j];
+  }
+};
+// decomposition-time payload: [x y z type] of every send entry, entry-major (a peer's message is a contiguous range)
+struct PackGhostPeersBody {
+  int64_t n, cnt; // stride of x, number of entries
+  const int* idx;
+  const unsigned char* peer;
+  const double* x;
+  const int* type;
+  PeerTable pt;
+  double* out; // [cnt][4]
+  NEPMI_HD void operator()(int64_t q) const
+  {
+    const int64_t i = idx[q];
+    const int p = peer[q];
+    for (int d = 0; d < 3; ++d)
+      out[4 * q + d] = x[d * n + i] + pt.shift[p][d];
+    out[4 * q + 3] = (double)type[i];
+  }
+};
+struct UnpackGhostPeersBody {
+  int64_t n, off, cnt;
+  const double* in; // [cnt][4]
+  double* x;
+  int* type;
+  NEPMI_HD void operator()(int64_t q) const
+  {
+    for (int d = 0; d < 3; ++d)
+      x[d * n + off + q] = in[4 * q + d];
+    type[off + q] = (int)in[4 * q + 3];
+  }
+};
+// per step, forward: positions of the send entries (internal indices) + their peer's shift -> [cnt][3]
+struct HaloPackPeersBody {
+  Bufs b;
+  const int* idx;
+  const unsigned char* peer;
+  PeerTable pt;
+  double* out;
+  NEPMI_HD void operator()(int64_t q) const
+  {
+    const PosQ p = b.posq[idx[q]];
+    const int r = peer[q];
+    out[3 * q] = p.x + pt.shift[r][0];
+    out[3 * q + 1] = p.y + pt.shift[r][1];
+    out[3 * q + 2] = p.z + pt.shift[r][2];
+  }
+};
+// received ghost positions [cnt][3] -> posq (internal order), with the lattice-jump bookkeeping and the fixed-point record
+// of CheckGatherBody
+struct HaloUnpackPeersBody {
+  BoxD box;
+  Bufs b;
+  const int* idx; // internal indices of the ghosts
+  const double* in;
+  NEPMI_HD void operator()(int64_t q) const
+  {
+    const int64_t N = b.N;
+    const int k = idx[q];
+    const double x = in[3 * q], y = in[3 * q + 1], z = in[3 * q + 2];
+    float dx = (float)(x - b.x0s[k]);
+    float dy = (float)(y - b.x0s[N + k]);
+    float dz = (float)(z - b.x0s[2 * N + k]);
+    int n0, n1, n2;
+    mic_f_img(box, dx, dy, dz, n0, n1, n2);
+    PosQ p = b.posq[k];
+    p.x = x;
+    p.y = y;
+    p.z = z;
+    p.pad = pack_img(n0, n1, n2);
+    b.posq[k] = p;
+    if (b.prec)
+      b.prec[k] = make_prec(box, b, k, p);
+  }
+};
+// per step, reverse (reverse-mode ghosts): planes [first, first + planes) of Bufs::fo of every ghost -> [cnt][planes], back to
+// the rank that owns it ...
+struct GhostPackPeersBody {
+  Bufs b;
+  const int* idx; // internal indices of the ghosts
+  int first, planes;
+  double* out;
+  const int* frozen; // the run loops' "rebuild pending" word (the force kernels of this step did not run), or nullptr
+  NEPMI_HD void operator()(int64_t q) const
+  {
+    if (frozen && *frozen != 0)
+      return;
+    const int64_t N = b.N;
+    const int k = idx[q];
+    for (int p = 0; p < planes; ++p)
+      out[(int64_t)planes * q + p] = b.fo[(int64_t)(first + p) * N + k];
+  }
+};
+// ... where one work-item per shell atom adds what its images collected, in ascending peer order (a fixed order: the sum does
+// not depend on which message arrived first)
+struct GhostAddPeersBody {
+  Bufs b;
+  const int* src_int;   // internal index of shell atom j
+  const int* src_start; // its entries: src_entry[src_start[j] .. src_start[j + 1])
+  const int* src_entry;
+  int first, planes;
+  const double* in; // [entries][planes]
+  const int* frozen;
+  NEPMI_HD void operator()(int64_t j) const
+  {
+    if (frozen && *frozen != 0)
+      return;
+    const int64_t N = b.N;
+    const int k = src_int[j];
+    for (int t = src_start[j]; t < src_start[j + 1]; ++t) {
+      const int64_t e = src_entry[t];
+      for (int p = 0; p < planes; ++p)
+        b.fo[(int64_t)(first + p) * N + k] += in[(int64_t)planes * e + p];
+    }
+  }
 };
 
 // Per-step halo of one stage: positions of the listed atoms (internal indices) + the message's shift -> send buffer

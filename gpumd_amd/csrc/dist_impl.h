@@ -11,9 +11,11 @@
 //     (level 1), forces are produced for owned atoms only (level 2), no reverse communication -- or, when the sub-boxes are
 //     small against that shell (set_ghost_mode: a counted rule), shell rc + skin with descriptors for owned atoms only and a
 //     reverse exchange of the pair halves the force assembly leaves on the ghosts;
-//   * per step ONE ghost-position exchange, staged over the decomposed directions (2 messages per direction; edges
-//     and corners are forwarded: 6 messages instead of 26), and one all-reduce of the skin flag;  every ensemble of
-//     the fused run loops (NVE, Berendsen, Nose-Hoover chain, Bussi-Donadio-Parrinello) on top of one all-reduce
+//   * per step ONE grouped ghost-position exchange with the (up to 26) neighbours of the process grid -- faces, edges
+//     and corners as separate direct messages, nothing forwarded: one pack launch, one transport call, one unpack
+//     launch (on an 8-GPU node every peer of a 2x2x2 grid is a direct xGMI link) -- and one all-reduce of the skin
+//     flag; in reverse mode one more grouped exchange of the ghosts' partial forces;  every ensemble of the fused run
+//     loops (NVE, Berendsen, Nose-Hoover chain, Bussi-Donadio-Parrinello, Langevin, BAOAB) on top of one all-reduce
 //     of the eight thermodynamic sums;
 //   * migration + ghost-list rebuild only when some atom of some rank has moved more than skin/2 since the last
 //     decomposition (the criterion of Neighbor::find_neighbor_global, neighbor.cu:741-800, made global).
@@ -92,8 +94,7 @@ public:
       be_.free(p);
     free_state(cur_);
     free_state(nxt_);
-    for (auto& st : stages_)
-      free_stage(st);
+    free_plan();
     for (void* p : scratch_)
       be_.free(p);
     for (auto& kv : pool_size_)
@@ -139,6 +140,7 @@ public:
     }
     resident_ = false;
     have_force_ = false;
+    lan_fresh_ = true; // new atoms: their generator states are created from (seed, global id) when a Langevin run starts
     decompose();
   }
 
@@ -196,18 +198,18 @@ public:
       be_.template launch<64>(kSlotMisc, 1, NhcChainBody{n_total_, target, 0.5 * dt, thermo_dev_, nhc_dev_, frozen()});
       be_.template launch<256>(kSlotVV, e->num_atoms(), ResidentScaleBody{e->bufs(), nhc_dev_ + 3 * kNhcLinks, 1.0});
     };
-    // Ensemble_LAN (ensemble_lan.cu:96-127, :206-262) on the decomposed system.  Every rank carries the generator states of
-    // ALL atoms, indexed by global id: it kicks the atoms it owns and advances the other states without using their draws, so
-    // an atom's noise is the single-domain run's whatever the decomposition and nothing migrates; the four momentum sums
-    // are all-reduced before the centre-of-mass velocity is removed.
+    // Ensemble_LAN (ensemble_lan.cu:96-127, :206-262) on the decomposed system.  The generator state of an atom is per-atom
+    // state like its velocity (ensemble_lan.cu:96-127): it is created from (seed, GLOBAL id), lives on the rank that owns the
+    // atom (State::rng, local order) and migrates with it at a re-decomposition, so it only ever advances on its owner -- an
+    // atom's noise is the single-domain run's whatever the decomposition, and a rank holds and touches the states of its own
+    // atoms only.  The four momentum sums are all-reduced before the centre-of-mass velocity is removed.
     if (ens == Engine::kLan || ens == Engine::kBao)
       lan_prepare();
     auto lan_half = [&](double target, bool whole_step = false) { // whole_step: the O of BAOAB
       const double c1 = std::exp((whole_step ? -1.0 : -0.5) / tcoup);
       const double c2 = std::sqrt((1.0 - c1 * c1) * kBoltzmann * target);
       const Bufs& bb = e->bufs();
-      be_.lan_kick_resident(lan_states_, e->num_atoms(), c1, c2, bb.mi, bb.vi, bb.perm, bb.lvl, cur_.id, bb.flags);
-      be_.lan_advance_unowned(lan_states_, n_total_, lan_owned_, bb.flags);
+      be_.lan_kick_resident(cur_.rng, e->num_atoms(), c1, c2, bb.mi, bb.vi, bb.perm, bb.lvl, nullptr, bb.flags);
       be_.lan_momentum_resident(e->num_atoms(), bb.mi, bb.vi, nullptr, bb.lvl, lan_sums_, bb.flags);
       device_allreduce(lan_sums_, 4, kDtF64, kOpSum);
       be_.lan_momentum_fix_resident(e->num_atoms(), lan_sums_, bb.vi, bb.lvl, bb.flags);
@@ -244,12 +246,19 @@ public:
       // communication stream; meanwhile the radial pass of the interior bricks -- those whose window holds no ghost --
       // runs on the compute stream.  Host transports block: the interior pass simply runs first, which proves its
       // independence of this step's ghosts (tests/test_dist.py compares both orders bit for bit).
+      const bool record = thermo_every > 0 && (step + 1) % thermo_every == 0;
+      const bool last = step + 1 == nsteps;
+      // per-atom energies and virials are read at thermo records and at the exit only (EngineT::set_step_outputs)
+      auto force_phase = [&](int phase, const int* frz) {
+        e->set_step_outputs(record || last);
+        e->force_kernels(phase, frz);
+      };
       const bool split = overlap_ && e->tiles_active() && tr_.nranks > 1;
       B& comm = (split && tr_.device_buffers) ? comm_backend() : be_;
       if (&comm != &be_)
         be_.fork_to(comm);
       if (split) {
-        e->force_kernels(Engine::kPhaseInterior);
+        force_phase(Engine::kPhaseInterior, nullptr);
         ++num_overlapped;
       }
       int trip = vote(spec, comm);
@@ -263,10 +272,8 @@ public:
       if (&comm != &be_)
         be_.join_from(comm);
       if (!trip) {
-        e->force_kernels(split ? (side_radial ? Engine::kPhaseAfterRadial : Engine::kPhaseBoundary) : Engine::kPhaseAll, frozen());
+        force_phase(split ? (side_radial ? Engine::kPhaseAfterRadial : Engine::kPhaseBoundary) : Engine::kPhaseAll, frozen());
         force_reverse(frozen());
-        const bool record = thermo_every > 0 && (step + 1) % thermo_every == 0;
-        const bool last = step + 1 == nsteps;
         bool need_sync = record || last;
         if (ens == Engine::kNve && !record && !last) {
           kick2_pending = true;
@@ -326,8 +333,6 @@ public:
         step = (int64_t)trip - 1;
         decompose();
         e = eng_.get();
-        if (ens == Engine::kLan || ens == Engine::kBao)
-          lan_mark_owned();
         resume_after_vv1 = true;
         kick2_pending = false;
         continue;
@@ -422,29 +427,20 @@ public:
   }
   void lan_prepare()
   {
-    if (!lan_states_ || lan_cap_ < n_total_) {
-      if (lan_states_) {
-        be_.free(lan_states_);
-        be_.free(lan_owned_);
-      }
-      lan_states_ = be_.alloc(be_.lan_state_bytes() * (size_t)n_total_);
-      lan_owned_ = (signed char*)be_.alloc((size_t)n_total_);
-      lan_cap_ = n_total_;
+    const size_t sb = be_.lan_state_bytes();
+    if (!lan_on_ || !cur_.rng) {
+      lan_on_ = true; // from now on the states are part of the per-atom state (alloc_state, decompose)
+      if (!cur_.rng)
+        cur_.rng = (char*)be_.alloc(sb * (size_t)cur_.cap);
       lan_fresh_ = true;
     }
     if (!lan_sums_)
       lan_sums_ = (double*)be_.alloc(sizeof(double) * 4);
-    if (lan_fresh_) {
-      be_.lan_init(lan_states_, n_total_, lan_seed_);
+    if (lan_fresh_) { // state of the atom with global id g = the single-domain run's state g (hiprand_init(seed, g, 0))
+      if (cur_.n_own > 0)
+        be_.lan_init_ids(cur_.rng, cur_.n_own, cur_.id, lan_seed_);
       lan_fresh_ = false;
     }
-    lan_mark_owned();
-  }
-  void lan_mark_owned() // which global ids this rank owns now (after every (re-)decomposition)
-  {
-    be_.memset(lan_owned_, 0, (size_t)n_total_);
-    if (cur_.n_own > 0)
-      be_.template launch<256>(kSlotMisc, cur_.n_own, MarkOwnedBody{cur_.id, lan_owned_});
   }
   void set_overlap(bool on) { overlap_ = on; }
   int64_t num_overlapped = 0; // steps whose interior radial pass ran before / while the ghosts travelled
@@ -457,18 +453,27 @@ private:
     int* t = nullptr;
     int64_t* id = nullptr;
     signed char* lvl = nullptr;
+    char* rng = nullptr; // Langevin generator states of the owned atoms, local order (allocated once a Langevin ensemble runs)
   };
-  struct Stage {
-    int d = 0;
-    int peer_send[2] = {0, 0}, peer_recv[2] = {0, 0}; // [0]: to lower / from upper, [1]: to upper / from lower
-    int64_t cnt_send[2] = {0, 0}, cnt_recv[2] = {0, 0};
-    int64_t off_recv[2] = {0, 0};
-    double shift[2][3] = {{0, 0, 0}, {0, 0, 0}};
-    int* send_idx = nullptr;     // local indices, cnt_send[0] + cnt_send[1]
-    int* send_int = nullptr;     // the same, internal indices of the engine
-    int* recv_int = nullptr;     // internal indices of the received ghosts
-    double* sendbuf = nullptr;   // device [3][cnt0] | [3][cnt1]
-    double* recvbuf = nullptr;
+  // The halo of the current decomposition: who gets which owned atoms, where the ghosts sit (dist_bodies.h: direct halo).
+  struct Peer {
+    int rank = 0;
+    int64_t cnt_send = 0, cnt_recv = 0, send_off = 0, recv_off = 0; // entries; messages are contiguous ranges of the buffers
+  };
+  struct Plan {
+    PeerTable pt;
+    std::vector<Peer> peers; // ascending offset order (z slowest); sends are posted in this order, receives in the reverse
+                             // one -- the peer of entry i sends what we receive from it with the opposite offset, whose
+                             // index runs the other way, so the messages between a pair of ranks match in order
+    int64_t n_send = 0, n_recv = 0, n_src = 0;
+    int* send_idx = nullptr;            // [n_send] local indices (owned atoms), peer-major
+    int* send_int = nullptr;            // [n_send] the same as internal indices of the engine
+    unsigned char* send_peer = nullptr; // [n_send] peer of every entry
+    int* recv_int = nullptr;            // [n_recv] internal indices of the ghosts (peer-major, ascending peers)
+    double* sendbuf = nullptr;          // [n_send][bw]
+    double* recvbuf = nullptr;          // [n_recv][bw]
+    int *src_int = nullptr, *src_start = nullptr, *src_entry = nullptr; // reverse path: the entries of every shell atom
+    int* src_idx = nullptr;             // [n_src] local indices of the shell atoms
   };
 
   const int* frozen() const { return eng_->bufs().flags + kFlagMoved; }
@@ -493,6 +498,7 @@ private:
     s.t = (int*)be_.alloc(sizeof(int) * cap);
     s.id = (int64_t*)be_.alloc(sizeof(int64_t) * cap);
     s.lvl = (signed char*)be_.alloc(cap);
+    s.rng = lan_on_ ? (char*)be_.alloc(be_.lan_state_bytes() * (size_t)cap) : nullptr;
   }
   // Transient device buffers of the (re-)decomposition -- migration payloads, per-stage index lists and send/receive
   // buffers, the 8-byte bounce words of the count exchange -- come from a small pool: hipMalloc / hipFree cost 0.1-1 ms
@@ -522,16 +528,18 @@ private:
 
   void free_state(State& s)
   {
-    for (void* p : {(void*)s.x, (void*)s.v, (void*)s.m, (void*)s.t, (void*)s.id, (void*)s.lvl})
+    for (void* p : {(void*)s.x, (void*)s.v, (void*)s.m, (void*)s.t, (void*)s.id, (void*)s.lvl, (void*)s.rng})
       if (p)
         be_.free(p);
     s = State();
   }
-  void free_stage(Stage& st)
+  void free_plan()
   {
-    for (void* p : {(void*)st.send_idx, (void*)st.send_int, (void*)st.recv_int, (void*)st.sendbuf, (void*)st.recvbuf})
+    Plan& h = plan_;
+    for (void* p : {(void*)h.send_idx, (void*)h.send_int, (void*)h.send_peer, (void*)h.recv_int, (void*)h.sendbuf, (void*)h.recvbuf,
+                    (void*)h.src_int, (void*)h.src_start, (void*)h.src_entry, (void*)h.src_idx})
       pfree(p);
-    st = Stage();
+    h = Plan();
   }
   int* iscratch(int which, int64_t count) // grow-only int scratch arrays
   {
@@ -654,71 +662,61 @@ private:
     be_.template launch<64>(kSlotMisc, 1, ThermoNormBody{sums_dev_, (double)n_total_, volume_, thermo_dev_});
   }
 
-  // ---- per-step forward communication of the ghost positions ----
+  // ---- per-step forward communication of the ghost positions: one pack launch, one grouped exchange, one unpack launch ----
   void halo_exchange() { halo_exchange_on(be_); }
   void halo_exchange_on(B& on)
   {
     Engine& e = *eng_;
-    for (Stage& st : stages_) {
-      const int64_t c0 = st.cnt_send[0], c1 = st.cnt_send[1], r0 = st.cnt_recv[0], r1 = st.cnt_recv[1];
-      if (c0 + c1 > 0) {
-        HaloPackBody pk;
-        pk.b = e.bufs();
-        pk.idx = st.send_int;
-        pk.cnt0 = c0;
-        pk.cnt1 = c1;
-        for (int k = 0; k < 3; ++k) {
-          pk.shift0[k] = st.shift[0][k];
-          pk.shift1[k] = st.shift[1][k];
-        }
-        pk.out0 = st.sendbuf;
-        pk.out1 = st.sendbuf + 3 * c0;
-        on.template launch<256>(kSlotMisc, c0 + c1, pk);
-      }
-      TransportMsg s[2], r[2];
-      int ns = 0, nr = 0;
-      if (c0) s[ns++] = TransportMsg{st.sendbuf, (int64_t)sizeof(double) * 3 * c0, st.peer_send[0]};
-      if (c1) s[ns++] = TransportMsg{st.sendbuf + 3 * c0, (int64_t)sizeof(double) * 3 * c1, st.peer_send[1]};
-      if (r0) r[nr++] = TransportMsg{st.recvbuf, (int64_t)sizeof(double) * 3 * r0, st.peer_recv[0]};
-      if (r1) r[nr++] = TransportMsg{st.recvbuf + 3 * r0, (int64_t)sizeof(double) * 3 * r1, st.peer_recv[1]};
-      exchange_on(on, ns, s, nr, r);
-      if (r0 + r1 > 0)
-        on.template launch<256>(kSlotMisc, r0 + r1,
-                                HaloUnpackBody{e.box(), e.bufs(), st.recv_int, r0, r1, st.recvbuf, st.recvbuf + 3 * r0});
+    Plan& h = plan_;
+    if (h.peers.empty())
+      return;
+    if (h.n_send > 0)
+      on.template launch<256>(kSlotMisc, h.n_send, HaloPackPeersBody{e.bufs(), h.send_int, h.send_peer, h.pt, h.sendbuf});
+    peer_exchange(on, 3, false);
+    if (h.n_recv > 0)
+      on.template launch<256>(kSlotMisc, h.n_recv, HaloUnpackPeersBody{e.box(), e.bufs(), h.recv_int, h.recvbuf});
+  }
+  // the grouped exchange of the plan: forward = send entries out, ghosts in; backward = the ghosts' planes out, the entries'
+  // in.  `w` doubles per entry.  Sends in ascending peer order, receives in descending order (see Plan::peers).
+  void peer_exchange(B& on, int w, bool backward)
+  {
+    Plan& h = plan_;
+    TransportMsg sm[kMaxPeers], rm[kMaxPeers];
+    int ns = 0, nr = 0;
+    const int P = (int)h.peers.size();
+    const int64_t wb = (int64_t)sizeof(double) * w;
+    for (int i = 0; i < P; ++i) {
+      const Peer& p = h.peers[i];
+      const int64_t c = backward ? p.cnt_recv : p.cnt_send;
+      double* buf = backward ? h.recvbuf + (int64_t)w * p.recv_off : h.sendbuf + (int64_t)w * p.send_off;
+      if (c)
+        sm[ns++] = TransportMsg{buf, wb * c, p.rank};
     }
+    for (int i = P - 1; i >= 0; --i) {
+      const Peer& p = h.peers[i];
+      const int64_t c = backward ? p.cnt_send : p.cnt_recv;
+      double* buf = backward ? h.sendbuf + (int64_t)w * p.send_off : h.recvbuf + (int64_t)w * p.recv_off;
+      if (c)
+        rm[nr++] = TransportMsg{buf, wb * c, p.rank};
+    }
+    exchange_on(on, ns, sm, nr, rm);
   }
 
   // ---- reverse mode: per-step reverse communication of what the force assembly left on the ghosts ----
-  // The stages in reverse order; in each, the planes of the ghosts received from a peer go back to it and are added to the
-  // atoms it had sent (owned atoms, or ghosts of an earlier stage, which the next reverse stage carries on).
+  // The planes of every ghost go back to the rank that owns the atom (one grouped exchange); there one work-item per shell
+  // atom adds what its images collected, in ascending peer order.
   void reverse_exchange(int first, int planes, const int* frz)
   {
     Engine& e = *eng_;
-    for (size_t si = stages_.size(); si-- > 0;) {
-      Stage& st = stages_[si];
-      const int64_t c0 = st.cnt_send[0], c1 = st.cnt_send[1], r0 = st.cnt_recv[0], r1 = st.cnt_recv[1];
-      if (r0 + r1 > 0)
-        be_.template launch<256>(kSlotMisc, r0 + r1, GhostForcePackBody{e.bufs(), st.recv_int, r0, r1, first, planes, st.recvbuf,
-                                                                         st.recvbuf + (int64_t)planes * r0, frz});
-      TransportMsg s[2], r[2];
-      int ns = 0, nr = 0;
-      const int64_t pb = (int64_t)sizeof(double) * planes;
-      if (r0) s[ns++] = TransportMsg{st.recvbuf, pb * r0, st.peer_recv[0]};
-      if (r1) s[ns++] = TransportMsg{st.recvbuf + (int64_t)planes * r0, pb * r1, st.peer_recv[1]};
-      if (c0) r[nr++] = TransportMsg{st.sendbuf, pb * c0, st.peer_send[0]};
-      if (c1) r[nr++] = TransportMsg{st.sendbuf + (int64_t)planes * c0, pb * c1, st.peer_send[1]};
-      exchange(ns, s, nr, r);
-      const double* in1 = st.sendbuf + (int64_t)planes * c0;
-      if (geom_.wfrac[st.d] * 2.0 <= 1.0 / geom_.grid[st.d]) { // the lower and the upper shell of the sub-box do not meet
-        if (c0 + c1 > 0)
-          be_.template launch<256>(kSlotMisc, c0 + c1, GhostForceAddBody{e.bufs(), st.send_int, c0, c1, first, planes, st.sendbuf, in1, frz});
-      } else {
-        if (c0)
-          be_.template launch<256>(kSlotMisc, c0, GhostForceAddBody{e.bufs(), st.send_int, c0, 0, first, planes, st.sendbuf, in1, frz});
-        if (c1)
-          be_.template launch<256>(kSlotMisc, c1, GhostForceAddBody{e.bufs(), st.send_int + c0, c1, 0, first, planes, in1, in1, frz});
-      }
-    }
+    Plan& h = plan_;
+    if (h.peers.empty())
+      return;
+    if (h.n_recv > 0)
+      be_.template launch<256>(kSlotMisc, h.n_recv, GhostPackPeersBody{e.bufs(), h.recv_int, first, planes, h.recvbuf, frz});
+    peer_exchange(be_, planes, true);
+    if (h.n_src > 0)
+      be_.template launch<256>(kSlotMisc, h.n_src,
+                               GhostAddPeersBody{e.bufs(), h.src_int, h.src_start, h.src_entry, first, planes, h.sendbuf, frz});
   }
   void force_reverse(const int* frz = nullptr) // frz: as the force kernels of this step got it
   {
@@ -869,6 +867,32 @@ private:
       }
     }
     exchange((int)sends.size(), sends.data(), (int)recvs.size(), recvs.data());
+    // the Langevin generator states of the migrating atoms: a second message per (source, destination) in the same order
+    const size_t sb = lan_on_ ? be_.lan_state_bytes() : 0;
+    const int rw = (int)(sb / 8);
+    std::vector<char*> rs_buf, rr_buf;
+    if (lan_on_) {
+      std::vector<TransportMsg> rsends, rrecvs;
+      for (int r = 0; r < P; ++r) {
+        const int64_t c = (int64_t)by_dest[r].size();
+        if (r != me && c > 0) {
+          int* di = iscratch(7, c + 1);
+          be_.h2d(di, by_dest[r].data(), sizeof(int) * c);
+          char* buf = (char*)palloc(sb * (size_t)c);
+          be_.template launch<256>(kSlotMisc, c, GatherRecordsBody{(const unsigned long long*)cur_.rng, di, rw, (unsigned long long*)buf});
+          be_.sync();
+          rs_buf.push_back(buf);
+          rsends.push_back(TransportMsg{buf, (int64_t)(sb * (size_t)c), r});
+        }
+        const int64_t a = mat[(size_t)r * P + me];
+        if (r != me && a > 0) {
+          char* buf = (char*)palloc(sb * (size_t)a);
+          rr_buf.push_back(buf);
+          rrecvs.push_back(TransportMsg{buf, (int64_t)(sb * (size_t)a), r});
+        }
+      }
+      exchange((int)rsends.size(), rsends.data(), (int)rrecvs.size(), rrecvs.data());
+    }
     mark("migrate");
     // 4. new owned set: stayers in their order, then the arrivals by source rank
     const int64_t n_own_new = n_stay + n_arrive;
@@ -881,6 +905,8 @@ private:
     State& N = nxt_;
     if (N.cap < cap_need)
       alloc_state(N, cap_need);
+    if (lan_on_ && !N.rng) // (allocated before the first Langevin run)
+      N.rng = (char*)be_.alloc(be_.lan_state_bytes() * (size_t)N.cap);
     // the gather uses stride n_new, which is only known after the ghost stages: build owned arrays with a
     // provisional stride = N.cap and repack at the end
     const int64_t S = N.cap;
@@ -893,90 +919,150 @@ private:
       be_.template launch<256>(kSlotMisc, rcount[k], UnpackStateBody{geom_, S, off, rcount[k], rbuf[k], N.x, N.v, N.m, N.t, N.id});
       off += rcount[k];
     }
+    if (lan_on_) { // stayers in their order, then the arrivals by source rank: the order of the other per-atom arrays
+      if (n_stay > 0)
+        be_.template launch<256>(kSlotMisc, n_stay,
+                                 GatherRecordsBody{(const unsigned long long*)cur_.rng, sidx, rw, (unsigned long long*)N.rng});
+      int64_t o2 = n_stay;
+      for (size_t k = 0; k < rr_buf.size(); ++k) {
+        copy_dev(N.rng + sb * (size_t)o2, rr_buf[k], sb * (size_t)rcount[k]);
+        o2 += rcount[k];
+      }
+    }
     be_.sync();
     for (double* p : sbuf) pfree(p);
     for (double* p : rbuf) pfree(p);
+    for (char* p : rs_buf) pfree(p);
+    for (char* p : rr_buf) pfree(p);
     mark("gather");
-    // 5. ghost stages over the decomposed directions
-    for (auto& st : stages_)
-      free_stage(st);
-    stages_.clear();
+    // 5. ghosts: the owned atoms in the shell next to a face go to the neighbour through it -- faces, edges and corners of the
+    //    process grid as separate direct messages (dist_bodies.h: direct halo)
+    free_plan();
+    Plan& h = plan_;
+    {
+      const DomainGeom& g = geom_;
+      h.pt.n = 0;
+      for (int oz = -1; oz <= 1; ++oz)
+        for (int oy = -1; oy <= 1; ++oy)
+          for (int ox = -1; ox <= 1; ++ox) {
+            const int o[3] = {ox, oy, oz};
+            if (ox == 0 && oy == 0 && oz == 0)
+              continue;
+            bool ok = true;
+            int c[3];
+            for (int d = 0; d < 3; ++d) {
+              c[d] = g.coords[d] + o[d];
+              if (o[d] != 0 && !g.decomposed[d])
+                ok = false;
+              if (c[d] < 0 || c[d] >= g.grid[d]) {
+                if (!g.pbc[d])
+                  ok = false;
+                c[d] = (c[d] + g.grid[d]) % g.grid[d];
+              }
+            }
+            if (!ok)
+              continue;
+            const int i = h.pt.n++;
+            Peer pe;
+            pe.rank = c[0] + g.grid[0] * (c[1] + g.grid[1] * c[2]);
+            h.peers.push_back(pe);
+            for (int d = 0; d < 3; ++d)
+              h.pt.off[i][d] = o[d];
+            // receiver-local coordinates: + (sender origin - receiver origin); across a periodic face the lattice-vector
+            // image and the jump of the origin cancel, so the shift is the same for edge ranks
+            for (int cc = 0; cc < 3; ++cc) {
+              h.pt.shift[i][cc] = 0.0;
+              for (int d = 0; d < 3; ++d)
+                h.pt.shift[i][cc] -= g.H[3 * cc + d] * (double)o[d] / g.grid[d];
+            }
+          }
+    }
+    const int NP = (int)h.peers.size();
     int64_t n_loc = n_own_new;
-    for (int d = 0; d < 3; ++d) {
-      if (!geom_.decomposed[d])
-        continue;
-      Stage st;
-      st.d = d;
-      int* gflag = iscratch(1, n_loc + 1);
-      int* gscan = iscratch(2, n_loc + 2);
-      int* gidx[2] = {iscratch(8, n_loc + 1), iscratch(9, n_loc + 1)};
-      int* gscr = iscratch(4, n_loc / 512 + 2048);
-      for (int dir = 0; dir < 2; ++dir) { // 0: to the lower neighbour, 1: to the upper one
-        const bool edge = dir == 0 ? geom_.coords[d] == 0 : geom_.coords[d] == geom_.grid[d] - 1;
-        st.peer_send[dir] = neighbor(d, dir == 0 ? -1 : +1);
-        st.peer_recv[dir] = neighbor(d, dir == 0 ? +1 : -1); // message 0 arrives from the upper neighbour (its "to lower")
-        st.cnt_send[dir] = 0;
-        if (!(edge && !geom_.pbc[d]) && n_loc > 0) {
-          be_.template launch<256>(kSlotMisc, n_loc, GhostFlagBody{geom_, S, d, dir, N.x, gflag});
-          st.cnt_send[dir] = compact(gflag, n_loc, gscan, gidx[dir], gscr);
-        }
-        // receiver-local coordinates: + periodic image (edge ranks) + (sender origin - receiver origin)
-        // the receiver's origin sits one sub-box below (dir 0) / above (dir 1) this rank's; across the periodic face
-        // the lattice-vector image and the jump of the origin cancel, so the shift is the same for edge ranks
-        const double dorg = (dir == 0 ? 1.0 : -1.0) / geom_.grid[d];
-        for (int c = 0; c < 3; ++c)
-          st.shift[dir][c] = geom_.H[3 * c + d] * dorg;
+    if (NP > 0) {
+      // shell atoms L (stable compaction of the owned atoms with a non-empty peer mask), then ONE scan numbers all entries
+      unsigned* mask = (unsigned*)iscratch(13, n_own_new + 1);
+      int* any = iscratch(1, n_own_new + 1);
+      int* gscan = iscratch(2, n_own_new + 2);
+      int* L = iscratch(8, n_own_new + 1);
+      int* gscr = iscratch(4, (int64_t)(NP + 1) * (n_own_new + 1) / 512 + 2048);
+      int64_t m = 0;
+      if (n_own_new > 0) {
+        be_.template launch<256>(kSlotMisc, n_own_new, PeerMaskBody{geom_, h.pt, S, N.x, mask, any});
+        m = compact(any, n_own_new, gscan, L, gscr);
       }
-      // counts, then payloads (position in the receiver's local coordinates + type)
-      int64_t cs[2] = {st.cnt_send[0], st.cnt_send[1]}, cr[2] = {0, 0};
-      exchange_counts(st, cs, cr);
-      st.cnt_recv[0] = cr[0];
-      st.cnt_recv[1] = cr[1];
-      const int64_t cst = cs[0] + cs[1], crt = cr[0] + cr[1];
-      if (n_loc + crt > N.cap)
+      const int64_t nflag = (int64_t)NP * (m + 1) + 1;
+      int* pscan = iscratch(14, nflag + 1);
+      be_.template launch<256>(kSlotMisc, nflag, PeerFlagBody{mask, L, m, NP, pscan});
+      int* pflag = nullptr; // (the fill reads the mask again: the flags are not kept)
+      (void)pflag;
+      be_.exclusive_scan(pscan, nflag, gscr);
+      int* offs = iscratch(15, NP + 2);
+      be_.template launch<64>(kSlotMisc, NP + 1, PeerOffsetsBody{pscan, m, NP, offs});
+      std::vector<int> hoff((size_t)NP + 1, 0);
+      be_.sync();
+      be_.d2h(hoff.data(), offs, sizeof(int) * (NP + 1));
+      h.n_send = hoff[NP];
+      for (int i = 0; i < NP; ++i) {
+        h.peers[i].send_off = hoff[i];
+        h.peers[i].cnt_send = hoff[i + 1] - hoff[i];
+      }
+      h.send_idx = (int*)palloc(sizeof(int) * (h.n_send + 1));
+      h.send_int = (int*)palloc(sizeof(int) * (h.n_send + 1));
+      h.send_peer = (unsigned char*)palloc((size_t)h.n_send + 8);
+      if (h.n_send > 0)
+        be_.template launch<256>(kSlotMisc, nflag - 1, PeerFillBody{mask, L, m, NP, pscan, h.send_idx, h.send_peer});
+      // the reverse path's table: every shell atom's entries in ascending peer order
+      h.n_src = m;
+      h.src_idx = (int*)palloc(sizeof(int) * (m + 1));
+      h.src_int = (int*)palloc(sizeof(int) * (m + 1));
+      h.src_start = (int*)palloc(sizeof(int) * (m + 2));
+      h.src_entry = (int*)palloc(sizeof(int) * (h.n_send + 1));
+      if (m > 0) {
+        copy_dev(h.src_idx, L, sizeof(int) * m);
+        be_.template launch<256>(kSlotMisc, m + 1, PeerCountBody{mask, L, m, h.src_start});
+        be_.exclusive_scan(h.src_start, m + 1, gscr);
+        be_.template launch<256>(kSlotMisc, m, PeerCsrBody{mask, L, m, NP, pscan, h.src_start, h.src_entry});
+      }
+      // counts: one 8-byte message per peer (sends ascending, receives descending: Plan::peers)
+      {
+        std::vector<int64_t> cs((size_t)NP), cr((size_t)NP, 0);
+        for (int i = 0; i < NP; ++i)
+          cs[i] = h.peers[i].cnt_send;
+        int64_t* d = (int64_t*)palloc(sizeof(int64_t) * 2 * NP);
+        be_.h2d(d, cs.data(), sizeof(int64_t) * NP);
+        TransportMsg sm[kMaxPeers], rm[kMaxPeers];
+        for (int i = 0; i < NP; ++i)
+          sm[i] = TransportMsg{d + i, 8, h.peers[i].rank};
+        for (int i = 0; i < NP; ++i)
+          rm[i] = TransportMsg{d + NP + (NP - 1 - i), 8, h.peers[NP - 1 - i].rank};
+        exchange(NP, sm, NP, rm);
+        be_.sync();
+        be_.d2h(cr.data(), d + NP, sizeof(int64_t) * NP);
+        pfree(d);
+        h.n_recv = 0;
+        for (int i = 0; i < NP; ++i) {
+          h.peers[i].cnt_recv = cr[i];
+          h.peers[i].recv_off = h.n_recv;
+          h.n_recv += cr[i];
+        }
+      }
+      if (n_loc + h.n_recv > N.cap)
         throw EngineError{-6, "domain decomposition: more ghost atoms than the density-based capacity of the local system "
                               "(strongly non-uniform density across the sub-boxes)"};
-      st.send_idx = (int*)palloc(sizeof(int) * (cst + 1));
-      st.send_int = (int*)palloc(sizeof(int) * (cst + 1));
-      st.recv_int = (int*)palloc(sizeof(int) * (crt + 1));
-      const int bw = reverse_ ? 9 : 4; // doubles per atom: [x y z type] of the ghost stages; reverse mode: up to nine virial planes
-      st.sendbuf = (double*)palloc(sizeof(double) * bw * (cst + 1));
-      st.recvbuf = (double*)palloc(sizeof(double) * bw * (crt + 1));
-      if (cs[0]) copy_dev(st.send_idx, gidx[0], sizeof(int) * cs[0]);
-      if (cs[1]) copy_dev(st.send_idx + cs[0], gidx[1], sizeof(int) * cs[1]);
-      TransportMsg s[2], r[2];
-      int ns = 0, nr = 0;
-      for (int dir = 0; dir < 2; ++dir) {
-        const int64_t c = cs[dir];
-        if (c == 0)
-          continue;
-        double* out = st.sendbuf + (dir == 0 ? 0 : 4 * cs[0]);
-        PackGhostBody pg;
-        pg.n = S;
-        pg.cnt = c;
-        pg.idx = st.send_idx + (dir == 0 ? 0 : cs[0]);
-        pg.x = N.x;
-        pg.type = N.t;
-        for (int k = 0; k < 3; ++k)
-          pg.shift[k] = st.shift[dir][k];
-        pg.out = out;
-        be_.template launch<256>(kSlotMisc, c, pg);
-        s[ns++] = TransportMsg{out, (int64_t)sizeof(double) * 4 * c, st.peer_send[dir]};
-      }
-      for (int dir = 0; dir < 2; ++dir)
-        if (cr[dir])
-          r[nr++] = TransportMsg{st.recvbuf + (dir == 0 ? 0 : 4 * cr[0]), (int64_t)sizeof(double) * 4 * cr[dir], st.peer_recv[dir]};
+      const int bw = reverse_ ? 9 : 4; // doubles per entry: [x y z type] here; reverse mode: up to nine virial planes
+      h.sendbuf = (double*)palloc(sizeof(double) * bw * (h.n_send + 1));
+      h.recvbuf = (double*)palloc(sizeof(double) * bw * (h.n_recv + 1));
+      h.recv_int = (int*)palloc(sizeof(int) * (h.n_recv + 1));
+      if (h.n_send > 0)
+        be_.template launch<256>(kSlotMisc, h.n_send,
+                                 PackGhostPeersBody{S, h.n_send, h.send_idx, h.send_peer, N.x, N.t, h.pt, h.sendbuf});
       be_.sync();
-      exchange(ns, s, nr, r);
-      for (int dir = 0; dir < 2; ++dir) {
-        st.off_recv[dir] = n_loc;
-        if (cr[dir])
-          be_.template launch<256>(kSlotMisc, cr[dir],
-                                   UnpackGhostBody{S, n_loc, cr[dir], st.recvbuf + (dir == 0 ? 0 : 4 * cr[0]), N.x, N.t});
-        n_loc += cr[dir];
-      }
+      peer_exchange(be_, 4, false);
+      if (h.n_recv > 0)
+        be_.template launch<256>(kSlotMisc, h.n_recv, UnpackGhostPeersBody{S, n_loc, h.n_recv, h.recvbuf, N.x, N.t});
+      n_loc += h.n_recv;
       be_.sync();
-      stages_.push_back(st);
     }
     mark("ghosts");
     // 6. repack to stride n_loc, levels
@@ -1024,16 +1110,12 @@ private:
     e.resident_import(C.v, C.m, nullptr, nullptr, nullptr);
     int* inv = iscratch(10, n_loc + 1);
     be_.template launch<256>(kSlotMisc, n_loc, InversePermBody{e.bufs().perm, inv});
-    for (Stage& st : stages_) {
-      const int64_t cst = st.cnt_send[0] + st.cnt_send[1];
-      if (cst)
-        be_.template launch<256>(kSlotMisc, cst, MapIndexBody{inv, st.send_idx, 0, st.send_int});
-      if (st.cnt_recv[0])
-        be_.template launch<256>(kSlotMisc, st.cnt_recv[0], MapIndexBody{inv, nullptr, st.off_recv[0], st.recv_int});
-      if (st.cnt_recv[1])
-        be_.template launch<256>(kSlotMisc, st.cnt_recv[1],
-                                 MapIndexBody{inv, nullptr, st.off_recv[1], st.recv_int + st.cnt_recv[0]});
-    }
+    if (h.n_send > 0)
+      be_.template launch<256>(kSlotMisc, h.n_send, MapIndexBody{inv, h.send_idx, 0, h.send_int});
+    if (h.n_recv > 0)
+      be_.template launch<256>(kSlotMisc, h.n_recv, MapIndexBody{inv, nullptr, n_own_new, h.recv_int});
+    if (h.n_src > 0)
+      be_.template launch<256>(kSlotMisc, h.n_src, MapIndexBody{inv, h.src_idx, 0, h.src_int});
     be_.sync();
     mark("maps");
     if (trace)
@@ -1055,23 +1137,6 @@ private:
     return total;
   }
 
-  void exchange_counts(const Stage& st, const int64_t cs[2], int64_t cr[2])
-  {
-    if (tr_.nranks == 1) {
-      cr[0] = cr[1] = 0;
-      return;
-    }
-    // counts travel through the host-side path of the transport (8 bytes each)
-    int64_t* d = (int64_t*)palloc(sizeof(int64_t) * 4);
-    be_.h2d(d, cs, sizeof(int64_t) * 2);
-    TransportMsg s[2] = {{d, 8, st.peer_send[0]}, {d + 1, 8, st.peer_send[1]}};
-    TransportMsg r[2] = {{d + 2, 8, st.peer_recv[0]}, {d + 3, 8, st.peer_recv[1]}};
-    exchange(2, s, 2, r);
-    be_.sync();
-    be_.d2h(cr, d + 2, sizeof(int64_t) * 2);
-    pfree(d);
-  }
-
   // [3][S] staging arrays -> [3][n] arrays of the current state
   void repack(const State& from, int64_t S, State& to, int64_t n, int64_t n_own)
   {
@@ -1084,6 +1149,8 @@ private:
     if (n_own) {
       copy_dev(to.m, from.m, sizeof(double) * n_own);
       copy_dev(to.id, from.id, sizeof(int64_t) * n_own);
+      if (lan_on_)
+        copy_dev(to.rng, from.rng, be_.lan_state_bytes() * (size_t)n_own);
     }
     if (n)
       copy_dev(to.t, from.t, sizeof(int) * n);
@@ -1097,7 +1164,7 @@ private:
   int pbc_loc_[3];
   int64_t n_total_ = 0;
   State cur_, nxt_;
-  std::vector<Stage> stages_;
+  Plan plan_;
   std::unique_ptr<Engine> eng_;
   int64_t eng_cap_ = 0;
   bool resident_ = false, have_force_ = false;
@@ -1109,10 +1176,8 @@ private:
   B side_;               // the backend on the communication stream (device transports)
   bool side_ready_ = false;
   uint64_t seed_ = 12345678u;
-  void* lan_states_ = nullptr;       // generator states of ALL atoms, by global id
-  signed char* lan_owned_ = nullptr; // [n_total] 1: owned by this rank
+  bool lan_on_ = false;              // a Langevin ensemble has run: State::rng is part of the per-atom state
   double* lan_sums_ = nullptr;
-  int64_t lan_cap_ = 0;
   int lan_seed_ = 12345678;
   bool lan_fresh_ = true;
   int* flag_dev_ = nullptr;

@@ -680,9 +680,8 @@ __global__ void nepmi_momentum_fix(const int64_t N, const double* __restrict__ s
 
 // ---- the same thermostat inside the device-resident run loops (and the decomposed driver): velocities and masses in the
 //      engine's INTERNAL order (stride n), generator states where the reference keeps them -- state s belongs to the atom with
-//      caller index s (single domain: s = perm[k]) or global id s (decomposed: s = ids[perm[k]]; every rank carries the
-//      states of ALL atoms and advances the ones it does not own without using the draws, so an atom's noise does not
-//      depend on the decomposition and nothing has to migrate).  `flags`: the frozen word of the speculative loops. ----
+//      caller index s = perm[k] (single domain: the caller's atom; decomposed: the rank's local atom, whose state was created
+//      from its global id and migrates with it).  `flags`: the frozen word of the speculative loops. ----
 __global__ void nepmi_lan_kick_resident(
   hiprandState* g_state, const int64_t n, const double c1, const double c2, const double* __restrict__ mi, double* vi,
   const int* __restrict__ perm, const signed char* __restrict__ lvl, const int64_t* __restrict__ ids, const int* flags)
@@ -700,17 +699,13 @@ __global__ void nepmi_lan_kick_resident(
   g_state[s] = state;
 }
 
-__global__ void nepmi_lan_advance_unowned(hiprandState* g_state, const int64_t n_total, const signed char* __restrict__ owned,
-                                          const int* flags)
+// decomposed runs: state q of a rank belongs to its owned atom q (local order) and is the single-domain run's state of that
+// atom's GLOBAL id (subsequence id of the XORWOW generator); it migrates with the atom (dist_impl.h)
+__global__ void nepmi_lan_init_ids(hiprandState* state, const int64_t n, const int64_t* __restrict__ ids, const int seed)
 {
-  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= n_total || flags[nepmi::kFlagMoved] != 0 || owned[s])
-    return;
-  hiprandState state = g_state[s];
-  (void)hiprand_normal_double(&state);
-  (void)hiprand_normal_double(&state);
-  (void)hiprand_normal_double(&state);
-  g_state[s] = state;
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < n)
+    hiprand_init(seed, ids[q], 0, &state[q]);
 }
 
 // invp != nullptr (single domain): the four sums in CALLER order exactly as nepmi_momentum_sum forms them (thread t takes
@@ -1194,7 +1189,7 @@ struct HipBackend {
   static constexpr bool kHasScatter = true;
   template <class S>
   void launch_force_scatter(int slot, int64_t nbricks, int64_t natoms, const WinStage& ws2, const ModelD& md, int* halo,
-                            const unsigned* fmap, int fold_rows, const int* frz)
+                            const unsigned* fmap, int fold_rows, bool outputs, const int* frz)
   {
     if constexpr (S::TS > 0) {
       if (nbricks <= 0)
@@ -1203,14 +1198,22 @@ struct HipBackend {
       const ScatterLayout lay{ws2.lay.wmax};
       const int64_t grid = (nbricks + 7) / 8 * 8;
       const size_t lds_bytes = ((size_t)lay.bytes() + 15) / 16 * 16;
-      if (lds_bytes > 64 * 1024)
-        NEPMI_HIP_CHECK(hipFuncSetAttribute(
-          reinterpret_cast<const void*>(&nepmi_force_scatter_kernel<S>), hipFuncAttributeMaxDynamicSharedMemorySize,
-          (int)lds_bytes));
       const bool t = timed(slot);
       if (t)
         timer_start(timing->slot[slot]);
-      hipLaunchKernelGGL((nepmi_force_scatter_kernel<S>), dim3((unsigned)grid), dim3(kWinThreads), lds_bytes, stream, body, nbricks);
+      if (outputs) {
+        if (lds_bytes > 64 * 1024)
+          NEPMI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&nepmi_force_scatter_kernel<S, true>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        hipLaunchKernelGGL((nepmi_force_scatter_kernel<S, true>), dim3((unsigned)grid), dim3(kWinThreads), lds_bytes, stream, body,
+                           nbricks);
+      } else {
+        if (lds_bytes > 64 * 1024)
+          NEPMI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&nepmi_force_scatter_kernel<S, false>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        hipLaunchKernelGGL((nepmi_force_scatter_kernel<S, false>), dim3((unsigned)grid), dim3(kWinThreads), lds_bytes, stream, body,
+                           nbricks);
+      }
       NEPMI_HIP_CHECK(hipGetLastError());
       const ForceFoldBody fold{ws2.b, md, ws2.lay.wmax, fold_rows, fmap, reinterpret_cast<const I4*>(halo)};
       const int64_t fgrid = ((natoms + 255) / 256 + 7) / 8 * 8;
@@ -1371,10 +1374,10 @@ struct HipBackend {
                        c1, c2, mi, vi, perm, lvl, ids, flags);
     NEPMI_HIP_CHECK(hipGetLastError());
   }
-  void lan_advance_unowned(void* states, int64_t n_total, const signed char* owned, const int* flags)
+  void lan_init_ids(void* states, int64_t n, const int64_t* ids, int seed)
   {
-    hipLaunchKernelGGL(nepmi_lan_advance_unowned, dim3((unsigned)((n_total + 127) / 128)), dim3(128), 0, stream,
-                       (hiprandState*)states, n_total, owned, flags);
+    hipLaunchKernelGGL(nepmi_lan_init_ids, dim3((unsigned)((n + 127) / 128)), dim3(128), 0, stream, (hiprandState*)states, n, ids,
+                       seed);
     NEPMI_HIP_CHECK(hipGetLastError());
   }
   void lan_momentum_resident(int64_t n, const double* mi, const double* vi, const int* invp, const signed char* lvl,

@@ -625,9 +625,10 @@ public:
       kick2_pending = false;
       if (temp_ramp)
         set_temperature(t1 + (t2 - t1) * ((double)(step + 2) / (double)nsteps));
-      force_kernels(kPhaseAll, frozen);
       const bool record = thermo_every > 0 && (step + 1) % thermo_every == 0;
       const bool last = step + 1 == nsteps;
+      step_outputs_ = record || last; // per-atom energies and virials: read at thermo records and at the exit only
+      force_kernels(kPhaseAll, frozen);
       bool need_sync = record || last;
       if (ens == kNve && !record && !last) {
         kick2_pending = true; // fused into the next step's pass over the atoms
@@ -1584,6 +1585,7 @@ private:
     }
     launch_angular_force<S>();
     last_scatter_form_ = false;
+    outputs_stale_ = false;
     if (win2 && scatter_form<S>(ws2, frozen)) {
       virial_local_ = true; // the virial planes hold the own-half form: exact_virials() before they leave the engine
       if (force_form_ == 1 && !loop_ctx_) // a per-call evaluation in the forced scatter form returns per-atom virials
@@ -1636,7 +1638,9 @@ private:
   {
     if (!scatter_wanted<S>())
       return false;
-    be_.template launch_force_scatter<S>(kSlotForce, num_bricks_, N_, ws2, md_, halo_, fmap_, fold_rows_, frozen);
+    be_.template launch_force_scatter<S>(kSlotForce, num_bricks_, N_, ws2, md_, halo_, fmap_, fold_rows_, step_outputs_, frozen);
+    if (!step_outputs_)
+      outputs_stale_ = true;
     last_scatter_form_ = true;
     return true;
   }
@@ -1648,6 +1652,10 @@ public:
   void set_force_form(int mode) { force_form_ = mode < 0 ? -1 : (mode > 1 ? 1 : mode); }
   // the callers whose steps need forces, energies and the TOTAL virial only (run loops; the decomposed driver)
   void set_loop_context(bool on) { loop_ctx_ = on; }
+  // Run loops: does the NEXT force evaluation have to leave per-atom energies and virials (a thermo record, a thermostat that
+  // reads the sums, the last step)?  The scatter form skips their arithmetic and their 80 bytes of stores per atom otherwise.
+  // Reset to true after every evaluation: a caller has to ask for the saving step by step.
+  void set_step_outputs(bool on) { step_outputs_ = on; }
   bool loop_context() const { return loop_ctx_; }
   // Per-atom virials in the reference's attribution (W_i = sum_j r_ij (x) f21): after a scatter-form step the virial planes
   // hold the own-half form, whose sum is the same; one virial-only pass of the gather form on the step's data replaces them.
@@ -1765,6 +1773,7 @@ public:
     be_.frozen = frozen;
     force_kernels_dispatch(phase, frozen);
     be_.frozen = nullptr;
+    step_outputs_ = true; // (set_step_outputs: asked for evaluation by evaluation)
   }
   // kPhaseBoundaryRadial on another stream of the same device (a backend from B::make_side_stream)
   void force_kernels_on(B& side, int phase, const int* frozen)
@@ -1817,6 +1826,8 @@ private:
   int force_form_ = -1;          // set_force_form
   bool loop_ctx_ = false;        // set_loop_context
   bool virial_local_ = false;    // the virial planes of the last force evaluation hold the own-half form (exact_virials)
+  bool step_outputs_ = true;     // set_step_outputs
+  bool outputs_stale_ = false;   // the last force evaluation left the energy / virial planes as they were
   bool scatter_disabled_ = false; // a pair half left the fixed-point guard band of the scatter form: gather form from then on
   int* halo_ = nullptr;          // [bricks][wmax][4] window sums of the scatter form (fixed point)
   size_t halo_cap_ = 0;

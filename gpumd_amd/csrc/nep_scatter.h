@@ -17,8 +17,8 @@
 // the entries of the (normally eight) windows its cell lies in -- tabulated per atom at the list rebuild (FoldMapBody), a fixed
 // order, no atomics anywhere outside the LDS.
 //
-// LDS per workgroup: positions as {x, y} (8 B) + z (4 B) planes -- the index | type word of the 16-byte records of the other
-// window kernels is not needed here (type-pure list segments; nothing is gathered by index) -- + three accumulator planes:
+// LDS per workgroup: positions as 12-byte rows {x, y, z} -- the index | type word of the 16-byte records of the other window
+// kernels is not needed here (type-pure list segments; nothing is gathered by index) -- + accumulators as 12-byte rows:
 // 24 B per window atom, 49 KB for the 2,048-slot windows of PbTe 1 M atoms: three workgroups per CU.
 //
 // Range: a pair half beyond +-64 eV/A (|s12| or a partial angular force component) sets flags[kFlagRange]; the engine then
@@ -31,6 +31,11 @@
 // (find_thermo) and the engine re-runs the gather form for the virial planes when per-atom virials leave the engine.
 #pragma once
 #include "nep_window.h"
+
+#ifndef NEPMI_FS_ABL
+#define NEPMI_FS_ABL 0 // ablation builds (profiles/ab_variants.sh; timings only, results are wrong): 1 no LDS atomics in the pair loop,
+                       // 2 no pair loop, 3 no staging of the positions, 4 no angular part, 5 no halo rows written
+#endif
 
 namespace nepmi {
 
@@ -47,10 +52,14 @@ struct alignas(16) I4 {
   int x, y, z, w;
 };
 
+struct I3 { // position of a window atom, fixed point, relative to the window centre
+  int x, y, z;
+};
 struct ScatterLayout {
   int wmax; // a multiple of 64; slot wmax = the sentinel of the other window kernels (never addressed here)
-  __device__ __host__ int off_xy() const { return 0; }
-  __device__ __host__ int off_z() const { return 8 * wmax; }
+  // positions and accumulators as 12-byte rows [slot]{x, y, z}: one address (12 slot) serves the three words of either
+  // (immediate offsets 0, 4, 8); 3 is coprime with the number of banks, so random slots spread over all of them
+  __device__ __host__ int off_pos() const { return 0; }
   __device__ __host__ int off_acc() const { return 12 * wmax; }
   __device__ __host__ int bytes() const { return 24 * wmax; }
 };
@@ -67,10 +76,30 @@ __device__ __forceinline__ void lds_add(NEPMI_LDS(int)* p, int v)
 {
   __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-__device__ __forceinline__ int to_fixed(float v) { return (int)__builtin_rintf(v); }
+__device__ __forceinline__ void lds_sub(NEPMI_LDS(int)* p, int v) // ds_sub_u32: the reaction needs no negation
+{
+  __hip_atomic_fetch_sub(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// float -> fixed point, round to nearest (ties towards +inf: floor(v + 0.5)) in one instruction; the value is added to one
+// atom and subtracted from the other as the SAME integer, so the rounding never unbalances a pair
+__device__ __forceinline__ unsigned row12(unsigned slot) // byte offset of a 12-byte row: two full-rate shift-adds (a 32-bit
+{                                                         // v_mul_lo_u32 runs at a quarter of the rate)
+  unsigned r;
+  asm("v_lshl_add_u32 %0, %1, 1, %1" : "=v"(r) : "v"(slot));
+  return r << 2;
+}
+__device__ __forceinline__ int to_fixed(float v)
+{
+  int r;
+  asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(v));
+  return r;
+}
 
-// one lane = one atom of the brick
-template <class S>
+// one lane = one atom of the brick.  OUT: the step's energies and (own-half) virials are wanted -- a thermo record, the last
+// step of a run loop, a per-call evaluation; the other steps of a run loop need forces only (the reference computes and
+// stores all thirteen per-atom outputs every step, potential.cu:170-297; find_thermo reads them at the dump_thermo interval
+// only): no virial arithmetic, no pair-vector loads in the angular part, no 80 bytes of stores per atom.
+template <class S, bool OUT>
 __device__ __forceinline__ void force_scatter_atom(const ForceScatterBody<S>& B, const int64_t brick, const int64_t k,
                                                    NEPMI_LDS(char)* lds, const ScatterLayout lay)
 {
@@ -81,7 +110,7 @@ __device__ __forceinline__ void force_scatter_atom(const ForceScatterBody<S>& B,
   const int lv = b.lvl[k];
   double* __restrict__ fo = b.fo + k;
   if (lv < b.lvl_desc) {
-    if (lv >= b.lvl_force) { // a reverse-mode ghost: it only collects what its owned neighbours scatter; no own terms
+    if (OUT && lv >= b.lvl_force) { // a reverse-mode ghost: it only collects what its owned neighbours scatter; no own terms
       fo[0] = 0.0;
 #pragma unroll
       for (int d = 0; d < 9; ++d)
@@ -89,10 +118,8 @@ __device__ __forceinline__ void force_scatter_atom(const ForceScatterBody<S>& B,
     }
     return;
   }
-  NEPMI_LDS(const I2)* wxy = (NEPMI_LDS(const I2)*)(lds + lay.off_xy());
-  NEPMI_LDS(const int)* wz = (NEPMI_LDS(const int)*)(lds + lay.off_z());
-  NEPMI_LDS(int)* acc = (NEPMI_LDS(int)*)(lds + lay.off_acc());
-  const int W = lay.wmax;
+  NEPMI_LDS(const char)* wpos = (NEPMI_LDS(const char)*)(lds + lay.off_pos());
+  NEPMI_LDS(char)* wacc = (NEPMI_LDS(char)*)(lds + lay.off_acc());
   // own record in the window frame and own LDS slot (the brick's cells are the 4x4x4 in the middle of the window)
   const int l = b.kcell[k] & 63;
   const int wc_own = ((l & 3) + 2) + 8 * (((l >> 2) & 3) + 2) + 64 * ((l >> 4) + 2);
@@ -106,152 +133,224 @@ __device__ __forceinline__ void force_scatter_atom(const ForceScatterBody<S>& B,
   const int* tab = b.wtab + (brick * 512 + wc_own) * 2;
   const int own_slot = (tab[1] & 0xFFFF) + (int)(k - tab[0]);
   const float rc1 = m.rc_r[t1];
-  const float unit = b.wg.unit, unit2 = b.wg.unit2;
+  const float unit = b.wg.unit;
   const float qs = unit * kScatterScale; // grid-unit force coefficient -> fixed-point force
   const int KRP = b.KRP;
   const float* __restrict__ atab = b.atab + (size_t)k * (m.T * KRP);
   constexpr int TSM = S::TS;
+  constexpr int K = S::KRM;
 
   int Fi[3] = {0, 0, 0};  // own half, fixed point (the same integers the partners receive with the other sign)
   float big = 0.0f;       // largest |pair-half coefficient| (eV/A) met
   const int nrad = b.nn_rad[k] < b.MN_rad ? b.nn_rad[k] : b.MN_rad;
-  const unsigned short* __restrict__ ccode = b.ccode + k;
-  f2 W2[6] = {bc2(0.0f), bc2(0.0f), bc2(0.0f), bc2(0.0f), bc2(0.0f), bc2(0.0f)}; // -sum r (x) g, grid units^2, xx yy zz xy xz yz
+  // -sum r (x) g in units of (grid unit)^2 * qs (the fixed-point scale rides along; taken out at the end): xx yy zz xy xz yz
+  f2 W2[6] = {bc2(0.0f), bc2(0.0f), bc2(0.0f), bc2(0.0f), bc2(0.0f), bc2(0.0f)};
 
+  // operands of the first chunk of the angular part, requested now: their latency passes behind the radial loop
+  constexpr int kAngChunk = 4;
+  const bool ang_on = NEPMI_FS_ABL != 4 && (!b.level || b.angf[k]); // (an inner-ring ghost nobody asked for partial forces has none)
+  const int nang = ang_on ? b.nn_angstep[k] : 0;
+  const F4* __restrict__ acomp = b.acomp + k;
+  const F4* __restrict__ f12o = b.f12 + k;
+  const unsigned short* __restrict__ aslot = b.aslot + k;
+  F4 fa_first[kAngChunk];
+  int sl_first[kAngChunk];
+#pragma unroll
+  for (int u = 0; u < kAngChunk; ++u) {
+    fa_first[u] = F4{0.0f, 0.0f, 0.0f, 0};
+    sl_first[u] = 0;
+    if (u < nang) {
+      fa_first[u] = f12o[(int64_t)u * N];
+      sl_first[u] = aslot[(int64_t)u * N];
+    }
+  }
   // type-pure segments of the compact list (front: neighbours of type 0, back: of type 1): the own row of the segment's
   // type stays in registers, the pair cutoff is a constant of the segment
   const int n0 = b.nn_t0[k] < nrad ? b.nn_t0[k] : nrad;
 #pragma unroll
   for (int t = 0; t < TSM; ++t) {
-    float Aown[S::KRM + 1];
+    // Own half of a pair: s12 = sum_k A_k f_k'(r) with f_k' = (k U_{k-1}(x)) dx/dr fc/2 + (T_k(x) + 1) fc'/2
+    // (find_fn_and_fnp, nep_utilities.cuh:590-623), contracted as  fc'/2 (SA + sum_k A_k T_k) + (dx/dr fc/2) sum_k (k A_k) U_{k-1}:
+    // the Chebyshev recurrences feed two running sums instead of seven separate basis derivatives.
+    float A[K + 1], Bk[K + 1], SA = 0.0f;
 #pragma unroll
-    for (int kk = 0; kk <= S::KRM; ++kk)
-      Aown[kk] = atab[t * KRP + kk];
+    for (int kk = 0; kk <= K; ++kk) {
+      A[kk] = atab[t * KRP + kk];
+      Bk[kk] = (float)kk * A[kk];
+      SA += A[kk];
+    }
     const int count = t == 0 ? n0 : nrad - n0;
-    const int row0 = t == 0 ? 0 : b.MN_rad - 1, step = t == 0 ? 1 : -1;
     const float rcp = m.uniform_rc ? m.rc_r_max : (rc1 + m.rc_r[t]) * 0.5f;
     const float rip = m.uniform_rc ? m.rcinv_r : fast_rcp(rcp);
-    auto load2 = [&](int s0, unsigned& c0, unsigned& c1) __attribute__((always_inline)) {
-      const int i0 = s0 < count ? s0 : count - 1, i1 = s0 + 1 < count ? s0 + 1 : count - 1;
-      c0 = ccode[(int64_t)(row0 + i0 * step) * N];
-      c1 = ccode[(int64_t)(row0 + i1 * step) * N];
-    };
-    // list entries two chunks ahead of the arithmetic (2-byte coalesced loads: the only global latency of this loop)
-    unsigned a0 = 0, a1 = 0, n0c = 0, n1c = 0, m0 = 0, m1 = 0;
-    if (count > 0) {
-      load2(0, a0, a1);
-      load2(2, n0c, n1c);
-    }
-    for (int s0 = 0; s0 < count; s0 += 2) {
-      if (s0 + 4 < count)
-        load2(s0 + 4, m0, m1);
+    const f2 rcinv = bc2(rip);
+    // the segment's entries: row r of ccode at r N; the front segment walks rows 0, 1, ..., the back one MN_rad-1, MN_rad-2, ...
+    const int64_t stride = t == 0 ? N : -N;
+    const unsigned short* __restrict__ q = b.ccode + k + (t == 0 ? (int64_t)0 : (int64_t)(b.MN_rad - 1) * N);
+    // two pairs side by side (packed FP32); w1 = 0: the second place repeats the first (odd end of the segment) and adds nothing
+    auto two_pairs = [&](const unsigned a0, const unsigned a1, const float w1) __attribute__((always_inline)) {
       // two pairs side by side (packed FP32)
-      const bool live1 = s0 + 1 < count;
-      const I2 p0 = wxy[a0], p1 = wxy[a1];
-      const int z0 = wz[a0], z1 = wz[a1];
+      const unsigned o0 = row12(a0), o1 = row12(a1);
+      const I3 p0 = *(NEPMI_LDS(const I3)*)(wpos + o0), p1 = *(NEPMI_LDS(const I3)*)(wpos + o1);
       const f2 fx = mk2((float)(p0.x - ox), (float)(p1.x - ox));
       const f2 fy = mk2((float)(p0.y - oy), (float)(p1.y - oy));
-      const f2 fz = mk2((float)(z0 - oz), (float)(z1 - oz));
-      const f2 d2 = vfma(fz, fz, vfma(fy, fy, fx * fx)) * unit2;
+      const f2 fz = mk2((float)(p0.z - oz), (float)(p1.z - oz));
+      const f2 d2 = vfma(fz, fz, vfma(fy, fy, fx * fx)) * b.wg.unit2;
       float d0, d1, i0, i1;
       dist_and_inv(d2.x, d0, i0);
       dist_and_inv(d2.y, d1, i1);
       const f2 dc = mk2(d0 < rcp ? d0 : rcp, d1 < rcp ? d1 : rcp); // (a pair the exact test admitted can sit a rounding above rc)
-      const f2 rcinv = bc2(rip);
       f2 fc, fcp;
       cutoff_fc_fcp_v(rcinv, dc, fc, fcp);
-      f2 fnp[S::KRM + 1];
-      basis_fnp_v<S::KRM>(rcinv, dc, fc, fcp, fnp);
-      f2 s12 = bc2(0.0f);
+      const f2 dr = dc * rcinv - 1.0f;
+      const f2 x = vfma(dr * 2.0f, dr, bc2(-1.0f));
+      const f2 x2 = x * 2.0f;
+      f2 tm2 = bc2(1.0f), tm1 = x;
+      f2 u0 = bc2(1.0f), u1 = x2; // U_0, U_1
+      f2 ST = vfma(x, bc2(A[1]), bc2(SA + A[0])); // SA + A_0 T_0 + A_1 T_1
+      f2 SU = bc2(Bk[1]);                          // B_1 U_0
 #pragma unroll
-      for (int kk = 0; kk <= S::KRM; ++kk)
-        s12 = vfma(fnp[kk], bc2(Aown[kk]), s12);
-      big = fmaxf(big, fmaxf(fabsf(s12.x), live1 ? fabsf(s12.y) : 0.0f));
-      const f2 g = s12 * mk2(i0, live1 ? i1 : 0.0f); // own half of the pair force = g * r12 (r12 in grid units here)
+      for (int kk = 2; kk <= K; ++kk) {
+        const f2 tk = vfma(x2, tm1, -tm2);
+        tm2 = tm1;
+        tm1 = tk;
+        ST = vfma(tk, bc2(A[kk]), ST);
+        SU = vfma(u1, bc2(Bk[kk]), SU); // k A_k U_{k-1}
+        if (kk < K) {
+          const f2 u2 = vfma(x2, u1, -u0);
+          u0 = u1;
+          u1 = u2;
+        }
+      }
+      const f2 s12 = vfma(dr * rcinv * 2.0f * fc, SU, fcp * 0.5f * ST); // (dx/dr fc / 2 = 2 dr fc / rc)
+      big = fmaxf(big, fmaxf(fabsf(s12.x), fabsf(s12.y)));
+      // own half of the pair force = g r12; here already in fixed-point units per grid unit of r12
+      const f2 g = s12 * mk2(i0 * qs, i1 * (qs * w1));
       const f2 gx = g * fx, gy = g * fy, gz = g * fz;
-      W2[0] = vfma(-fx, gx, W2[0]);
-      W2[1] = vfma(-fy, gy, W2[1]);
-      W2[2] = vfma(-fz, gz, W2[2]);
-      W2[3] = vfma(-fx, gy, W2[3]);
-      W2[4] = vfma(-fx, gz, W2[4]);
-      W2[5] = vfma(-fy, gz, W2[5]);
-      const int ax = to_fixed(gx.x * qs), ay = to_fixed(gy.x * qs), az = to_fixed(gz.x * qs);
-      const int bx = to_fixed(gx.y * qs), by = to_fixed(gy.y * qs), bz = to_fixed(gz.y * qs);
+      if (OUT) {
+        W2[0] = vfma(-fx, gx, W2[0]);
+        W2[1] = vfma(-fy, gy, W2[1]);
+        W2[2] = vfma(-fz, gz, W2[2]);
+        W2[3] = vfma(-fx, gy, W2[3]);
+        W2[4] = vfma(-fx, gz, W2[4]);
+        W2[5] = vfma(-fy, gz, W2[5]);
+      }
+      const int ax = to_fixed(gx.x), ay = to_fixed(gy.x), az = to_fixed(gz.x);
+      const int bx = to_fixed(gx.y), by = to_fixed(gy.y), bz = to_fixed(gz.y);
       Fi[0] += ax + bx;
       Fi[1] += ay + by;
       Fi[2] += az + bz;
-      lds_add(acc + a0, -ax);
-      lds_add(acc + W + a0, -ay);
-      lds_add(acc + 2 * W + a0, -az);
-      if (live1) {
-        lds_add(acc + a1, -bx);
-        lds_add(acc + W + a1, -by);
-        lds_add(acc + 2 * W + a1, -bz);
+      NEPMI_LDS(int)* r0 = (NEPMI_LDS(int)*)(wacc + o0);
+      NEPMI_LDS(int)* r1 = (NEPMI_LDS(int)*)(wacc + o1);
+      if (NEPMI_FS_ABL == 1)
+        return;
+      lds_sub(r0, ax);
+      lds_sub(r0 + 1, ay);
+      lds_sub(r0 + 2, az);
+      lds_sub(r1, bx); // (the repeated entry of an odd end subtracts zero)
+      lds_sub(r1 + 1, by);
+      lds_sub(r1 + 2, bz);
+    };
+    // The list entries (2-byte coalesced loads: the only global latency of this loop) are requested two chunks ahead of the
+    // arithmetic, whole pairs unconditionally; the entry of an odd end is requested before the loop.
+    auto load2 = [&](const unsigned short* at, unsigned& c0, unsigned& c1) __attribute__((always_inline)) {
+      c0 = at[0];
+      c1 = at[stride];
+    };
+    const int npairs = count >> 1;
+    unsigned a0 = 0, a1 = 0, n0c = 0, n1c = 0, tail = 0;
+    if (npairs > 0)
+      load2(q, a0, a1);
+    if (npairs > 1)
+      load2(q + 2 * stride, n0c, n1c);
+    if (count & 1)
+      tail = q[(int64_t)(count - 1) * stride];
+    q += 4 * stride;
+    // unrolled by two: the entries of chunk p + 2 are requested into the registers chunk p has just released -- no register
+    // rotation, so nothing waits for a load before two chunks of arithmetic have passed
+    for (int pr2 = 0; pr2 < (NEPMI_FS_ABL == 2 ? 0 : npairs); pr2 += 2) {
+      const unsigned x0 = a0, x1 = a1;
+      if (pr2 + 2 < npairs)
+        load2(q, a0, a1);
+      two_pairs(x0, x1, 1.0f);
+      if (pr2 + 1 < npairs) {
+        const unsigned y0 = n0c, y1 = n1c;
+        if (pr2 + 3 < npairs)
+          load2(q + 2 * stride, n0c, n1c);
+        two_pairs(y0, y1, 1.0f);
       }
-      a0 = n0c;
-      a1 = n1c;
-      n0c = m0;
-      n1c = m1;
+      q += 4 * stride;
     }
+    if (count & 1)
+      two_pairs(tail, tail, 0.0f);
   }
 
-  // ---- angular part: own partial forces f12 of this step's angular pairs (AngularForceBody wrote them) ----
+  // ---- angular part: own partial forces f12 of this step's angular pairs (AngularForceBody wrote them); the first chunk's
+  //      operands were requested before the radial loop ----
   float Wa[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}; // -sum r12 (x) f12: xx yy zz xy xz yz yx zx zy
-  if (!b.level || b.angf[k]) { // (an inner-ring ghost nobody asked for partial forces has none)
-    const int nang = b.nn_angstep[k];
-    const F4* __restrict__ acomp = b.acomp + k;
-    const F4* __restrict__ f12o = b.f12 + k;
-    const unsigned short* __restrict__ aslot = b.aslot + k;
-    constexpr int C = 4;
-    for (int a0 = 0; a0 < nang; a0 += C) {
-      F4 e[C], fa[C];
-      int sl[C];
+  if (ang_on) {
+    for (int c0 = 0; c0 < nang; c0 += kAngChunk) {
+      F4 e[kAngChunk], fa[kAngChunk];
+      int sl[kAngChunk];
 #pragma unroll
-      for (int u = 0; u < C; ++u) {
-        const int aa = a0 + u < nang ? a0 + u : a0;
-        e[u] = acomp[(int64_t)aa * N];
-        fa[u] = f12o[(int64_t)aa * N];
-        sl[u] = aslot[(int64_t)aa * N];
+      for (int u = 0; u < kAngChunk; ++u) {
+        if (c0 == 0) {
+          fa[u] = fa_first[u];
+          sl[u] = sl_first[u];
+        } else {
+          const int aa = c0 + u < nang ? c0 + u : c0;
+          fa[u] = f12o[(int64_t)aa * N];
+          sl[u] = aslot[(int64_t)aa * N];
+        }
+        if (OUT) {
+          const int aa = c0 + u < nang ? c0 + u : c0;
+          e[u] = acomp[(int64_t)aa * N];
+        }
       }
 #pragma unroll
-      for (int u = 0; u < C; ++u) {
-        if (a0 + u < nang) {
+      for (int u = 0; u < kAngChunk; ++u) {
+        if (c0 + u < nang) {
           big = fmaxf(big, fmaxf(fabsf(fa[u].x), fmaxf(fabsf(fa[u].y), fabsf(fa[u].z))));
           const int ax = to_fixed(fa[u].x * kScatterScale), ay = to_fixed(fa[u].y * kScatterScale),
                     az = to_fixed(fa[u].z * kScatterScale);
           Fi[0] += ax;
           Fi[1] += ay;
           Fi[2] += az;
-          lds_add(acc + sl[u], -ax);
-          lds_add(acc + W + sl[u], -ay);
-          lds_add(acc + 2 * W + sl[u], -az);
-          Wa[0] -= e[u].x * fa[u].x;
-          Wa[1] -= e[u].y * fa[u].y;
-          Wa[2] -= e[u].z * fa[u].z;
-          Wa[3] -= e[u].x * fa[u].y;
-          Wa[4] -= e[u].x * fa[u].z;
-          Wa[5] -= e[u].y * fa[u].z;
-          Wa[6] -= e[u].y * fa[u].x;
-          Wa[7] -= e[u].z * fa[u].x;
-          Wa[8] -= e[u].z * fa[u].y;
+          NEPMI_LDS(int)* rj = (NEPMI_LDS(int)*)(wacc + row12((unsigned)sl[u]));
+          lds_sub(rj, ax);
+          lds_sub(rj + 1, ay);
+          lds_sub(rj + 2, az);
+          if (OUT) {
+            Wa[0] -= e[u].x * fa[u].x;
+            Wa[1] -= e[u].y * fa[u].y;
+            Wa[2] -= e[u].z * fa[u].z;
+            Wa[3] -= e[u].x * fa[u].y;
+            Wa[4] -= e[u].x * fa[u].z;
+            Wa[5] -= e[u].y * fa[u].z;
+            Wa[6] -= e[u].y * fa[u].x;
+            Wa[7] -= e[u].z * fa[u].x;
+            Wa[8] -= e[u].z * fa[u].y;
+          }
         }
       }
     }
   }
-  lds_add(acc + own_slot, Fi[0]);
-  lds_add(acc + W + own_slot, Fi[1]);
-  lds_add(acc + 2 * W + own_slot, Fi[2]);
-  if (big >= kScatterFlagLimit)
+  {
+    NEPMI_LDS(int)* ro = (NEPMI_LDS(int)*)(wacc + row12((unsigned)own_slot));
+    lds_add(ro, Fi[0]);
+    lds_add(ro + 1, Fi[1]);
+    lds_add(ro + 2, Fi[2]);
+  }
+  if (NEPMI_FS_ABL == 0 && big >= kScatterFlagLimit)
     atomicOr(&b.flags[kFlagRange], 1);
 
   // ---- outputs of this kernel, internal order: energy and the local-form virial (the force comes from ForceFoldBody) ----
-  if (lv < b.lvl_force)
+  if (!OUT || lv < b.lvl_force)
     return; // (a forward-mode ring ghost: its halves are delivered, its own outputs are nobody's)
   double E = lv >= 2 ? (double)b.pe_i[k] : 0.0;
   float Wr[6];
 #pragma unroll
   for (int d = 0; d < 6; ++d)
-    Wr[d] = (W2[d].x + W2[d].y) * unit2;
+    Wr[d] = (W2[d].x + W2[d].y) * (unit * (1.0f / kScatterScale)); // (grid unit)^2 qs -> eV
   double Wd[9];
   Wd[0] = (double)(Wr[0] + Wa[0]);
   Wd[1] = (double)(Wr[1] + Wa[1]);
@@ -280,7 +379,7 @@ __device__ __forceinline__ void force_scatter_atom(const ForceScatterBody<S>& B,
 #ifndef NEPMI_FS_WAVES
 #define NEPMI_FS_WAVES 3
 #endif
-template <class S>
+template <class S, bool OUT>
 __global__ void __launch_bounds__(kWinThreads) __attribute__((amdgpu_waves_per_eu(NEPMI_FS_WAVES)))
 nepmi_force_scatter_kernel(const ForceScatterBody<S> body, const int64_t nbricks)
 {
@@ -298,12 +397,11 @@ nepmi_force_scatter_kernel(const ForceScatterBody<S> body, const int64_t nbricks
   {
     // staging: the window cells' fixed-point records from Bufs::prec with the cell's offset from the window centre added
     // (WinStage::stage_direct without the index | type word), accumulators cleared
-    NEPMI_LDS(I2)* wxy = (NEPMI_LDS(I2)*)(lds + lay.off_xy());
-    NEPMI_LDS(int)* wz = (NEPMI_LDS(int)*)(lds + lay.off_z());
+    NEPMI_LDS(I3)* wp = (NEPMI_LDS(I3)*)(lds + lay.off_pos());
     const int* tab = b.wtab + brick * 1024;
     int bx, by, bz;
     body.st.brick_coords(brick, bx, by, bz);
-    for (int wc = tid; wc < kWinCells; wc += kWinThreads) {
+    for (int wc = tid; wc < (NEPMI_FS_ABL == 3 ? 0 : kWinCells); wc += kWinThreads) {
       const int j0 = tab[2 * wc], pk = tab[2 * wc + 1];
       const int w0 = pk & 0xFFFF;
       int cnt = pk >> 16;
@@ -320,10 +418,8 @@ nepmi_force_scatter_kernel(const ForceScatterBody<S> body, const int64_t nbricks
           r[u] = b.prec[j0 + (a + u < cnt ? a + u : cnt - 1)];
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-          if (a + u < cnt) {
-            wxy[w0 + a + u] = I2{r[u].x + qx, r[u].y + qy};
-            wz[w0 + a + u] = r[u].z + qz;
-          }
+          if (a + u < cnt)
+            wp[w0 + a + u] = I3{r[u].x + qx, r[u].y + qy, r[u].z + qz};
       }
     }
     NEPMI_LDS(U4)* a4 = (NEPMI_LDS(U4)*)(lds + lay.off_acc());
@@ -336,15 +432,16 @@ nepmi_force_scatter_kernel(const ForceScatterBody<S> body, const int64_t nbricks
   int64_t a0, a1;
   body.st.brick_range(brick, a0, a1);
   for (int64_t k = a0 + tid; k < a1; k += kWinThreads)
-    force_scatter_atom<S>(body, brick, k, lds, lay);
+    force_scatter_atom<S, OUT>(body, brick, k, lds, lay);
   __syncthreads();
   {
     // the window sums, one 16-byte row per slot: what ForceFoldBody gathers
-    NEPMI_LDS(const int)* acc = (NEPMI_LDS(const int)*)(lds + lay.off_acc());
+    NEPMI_LDS(const I3)* acc = (NEPMI_LDS(const I3)*)(lds + lay.off_acc());
     I4* __restrict__ out = body.halo + (size_t)brick * lay.wmax;
-    const int W = lay.wmax;
-    for (int i = tid; i < W; i += kWinThreads)
-      out[i] = I4{acc[i], acc[W + i], acc[2 * W + i], 0};
+    for (int i = tid; i < (NEPMI_FS_ABL == 5 ? 0 : lay.wmax); i += kWinThreads) {
+      const I3 v = acc[i];
+      out[i] = I4{v.x, v.y, v.z, 0};
+    }
   }
 }
 

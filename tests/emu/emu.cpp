@@ -151,7 +151,7 @@ struct HostLoopBackend {
   // the scatter form of the force assembly (gpumd_amd/csrc/nep_scatter.h) is device code only: never selected here
   static constexpr bool kHasScatter = false;
   template <class S>
-  void launch_force_scatter(int, int64_t, int64_t, const WinStage&, const ModelD&, int*, const unsigned*, int, const int*)
+  void launch_force_scatter(int, int64_t, int64_t, const WinStage&, const ModelD&, int*, const unsigned*, int, bool, const int*)
   {
     std::abort();
   }
@@ -225,20 +225,11 @@ struct HostLoopBackend {
       }
     }
   }
-  void lan_advance_unowned(void* states, int64_t n_total, const signed char* owned, const int* flags)
+  void lan_init_ids(void* states, int64_t n, const int64_t* ids, int seed) // state q = the generator of global id ids[q]
   {
-    if (flags[kFlagMoved] != 0)
-      return;
     std::mt19937_64* st = (std::mt19937_64*)states;
-    std::normal_distribution<double> nd(0.0, 1.0);
-    for (int64_t s = 0; s < n_total; ++s) {
-      if (owned[s])
-        continue;
-      for (int d = 0; d < 3; ++d) {
-        nd.reset();
-        (void)nd(st[s]);
-      }
-    }
+    for (int64_t q = 0; q < n; ++q)
+      new (&st[q]) std::mt19937_64((uint64_t)seed * 1000003ull + (uint64_t)ids[q]);
   }
   void lan_momentum_fix_resident(int64_t n, const double* sums4, double* vi, const signed char* lvl, const int* flags)
   {

@@ -80,6 +80,10 @@ CASES = [
     (2, "PbTe-reps", (4, 2, 2), (2, 1, 1), "nvt_lan", 16, 2000.0),  # Langevin: an atom's noise does not depend on the decomposition
     (4, "PbTe-reps", (3, 3, 2), (2, 2, 1), "nvt_lan", 12, 2000.0),
     (2, "PbTe-reps", (4, 2, 2), (2, 1, 1), "nvt_bao", 16, 2000.0),  # BAOAB
+    # hot and long enough for a re-decomposition inside the Langevin loops: the generator states migrate with their atoms,
+    # the loop resumes after the first half-step (resume_after_vv1 skips B-A-O-A), the kernels of the frozen steps do nothing
+    (2, "PbTe-reps", (4, 2, 2), (2, 1, 1), "nvt_lan", 24, 3000.0),
+    (2, "PbTe-reps", (4, 2, 2), (2, 1, 1), "nvt_bao", 24, 3000.0),
     (2, "C-2022", (12, 6, 6), (2, 1, 1), "nve", 10, 3000.0),       # config 5's model through the ghost levels
     (2, "C-2022", (12, 6, 6), (2, 1, 1), "nvt_ber", 10, 3000.0),   # config 5: NVT on the decomposed path
     (2, "UNEP-v1", (10, 5, 5), (2, 1, 1), "nve", 8, 3000.0),       # config 4's model (16 types, ZBL)
@@ -100,7 +104,7 @@ def _natoms(model, reps):
 @pytest.mark.parametrize("world,model,reps,grid,ensemble,nsteps,temp", CASES)
 def test_decomposed_run_matches_single_domain(world, model, reps, grid, ensemble, nsteps, temp):
     multi, _ = _check(world, _spec("cpu", model, reps, grid, ensemble, nsteps, temp), _natoms(model, reps))
-    if model == "PbTe-reps" and ensemble == "nve":
+    if model == "PbTe-reps" and (ensemble == "nve" or (temp >= 3000.0 and nsteps >= 24)):
         assert max(int(r["ndec"]) for r in multi) >= 2  # atoms really moved past skin/2: migration + new ghosts
 
 
@@ -113,6 +117,8 @@ REVERSE_CASES = [
     (2, "PbTe-reps", (4, 2, 2), (2, 1, 1), "nvt_lan", 16, 2000.0),
     (2, "PbTe-reps", (4, 2, 2), (2, 1, 1), "nvt_bao", 16, 2000.0),
     (2, "PbTe-reps", (4, 2, 2), (2, 1, 1), "nvt_bdp", 16, 2000.0),
+    (2, "PbTe-reps", (4, 2, 2), (2, 1, 1), "nvt_lan", 24, 3000.0),  # with a re-decomposition: the generator states migrate
+    (2, "PbTe-reps", (4, 2, 2), (2, 1, 1), "nvt_bao", 24, 3000.0),
     (2, "C-2022", (12, 6, 6), (2, 1, 1), "nve", 10, 3000.0),
     (2, "UNEP-v1", (10, 5, 5), (2, 1, 1), "nve", 8, 3000.0),        # ZBL: a pair potential, never computed on a ghost
 ]
@@ -176,17 +182,23 @@ def test_reverse_ghosts_on_gpu_kernels(world, model, reps, grid, ensemble, nstep
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,model,reps,grid,ensemble,nsteps,temp", [
-    (2, "PbTe-reps", (4, 2, 2), (2, 1, 1), "nve", 20, 3000.0),
-    (4, "PbTe-reps", (4, 4, 2), (2, 2, 1), "nve", 20, 3000.0),
-    (2, "PbTe-reps", (4, 2, 2), (2, 1, 1), "nvt_nhc", 16, 2000.0),
-    (2, "PbTe-reps", (4, 2, 2), (2, 1, 1), "nvt_lan", 16, 2000.0),
-    (2, "C-2022", (12, 6, 6), (2, 1, 1), "nvt_ber", 10, 3000.0),
-    (2, "UNEP-v1", (10, 5, 5), (2, 1, 1), "nve", 8, 3000.0),
+@pytest.mark.parametrize("world,model,reps,grid,ensemble,nsteps,temp,ghosts", [
+    (2, "PbTe-reps", (4, 2, 2), (2, 1, 1), "nve", 20, 3000.0, 0),
+    (4, "PbTe-reps", (4, 4, 2), (2, 2, 1), "nve", 20, 3000.0, 0),
+    (2, "PbTe-reps", (4, 2, 2), (2, 1, 1), "nvt_nhc", 16, 2000.0, None),
+    (2, "PbTe-reps", (4, 2, 2), (2, 1, 1), "nvt_lan", 24, 3000.0, 0),  # with a re-decomposition: the generator states migrate
+    (2, "C-2022", (12, 6, 6), (2, 1, 1), "nvt_ber", 10, 3000.0, None),
+    (2, "UNEP-v1", (10, 5, 5), (2, 1, 1), "nve", 8, 3000.0, None),
+    # the reverse-ghost form against the ORACLE as well (one and three exchange stages)
+    (2, "PbTe-reps", (4, 2, 2), (2, 1, 1), "nve", 20, 3000.0, 1),
+    (8, "PbTe-reps", (4, 4, 4), (2, 2, 2), "nve", 12, 3000.0, 1),
+    (2, "C-2022", (12, 6, 6), (2, 1, 1), "nve", 10, 3000.0, 1),
 ])
-def test_decomposed_run_on_gpu_kernels(world, model, reps, grid, ensemble, nsteps, temp):
+def test_decomposed_run_on_gpu_kernels(world, model, reps, grid, ensemble, nsteps, temp, ghosts):
     n = _natoms(model, reps)
-    multi, _ = _check(world, _spec("gpu", model, reps, grid, ensemble, nsteps, temp), n)
+    multi, _ = _check(world, _spec("gpu", model, reps, grid, ensemble, nsteps, temp, ghosts=ghosts), n)
+    if ghosts is not None:
+        assert all(int(r["reverse"]) == ghosts for r in multi)  # the form that was asked for is the one that ran
     # ... and against the ORACLE, not only against the single-domain run of the same library: the forces of the initial
     # configuration, and the forces the decomposed run ends with (after its re-decompositions, migrations and ghost
     # levels) at the positions it ends with
