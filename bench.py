@@ -802,6 +802,13 @@ def bench(args):
                 extras["config2_si_tersoff"] = measure_extra("si_tersoff", (16, 16, 16), 2000, 200, dev)
             except Exception as e:
                 extras["config2_si_tersoff"] = {"error": str(e)}
+            # (c) the model families of configs 4 and 5 at one million atoms on this GPU (what every GPU of those 8-GPU
+            # configurations executes per million owned atoms), each on its own engine, same protocol
+            for key, wl, rp in (("config4_model_unep_1m", "unep", (16, 16, 16)), ("config5_model_carbon_1m", "carbon", (10, 10, 10))):
+                try:
+                    extras[key] = measure_extra(wl, rp, 40, 10, dev)
+                except Exception as e:
+                    extras[key] = {"error": str(e)}
             out["extra_measurements"] = extras
         if world == 1 and not args.no_cpu_baseline and args.workload == "pbte":
             with _stdout_to_stderr():

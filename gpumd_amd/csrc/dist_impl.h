@@ -458,13 +458,20 @@ private:
   // The halo of the current decomposition: who gets which owned atoms, where the ghosts sit (dist_bodies.h: direct halo).
   struct Peer {
     int rank = 0;
-    int64_t cnt_send = 0, cnt_recv = 0, send_off = 0, recv_off = 0; // entries; messages are contiguous ranges of the buffers
+    int64_t cnt_send = 0, cnt_recv = 0, send_off = 0, recv_off = 0; // entries; blocks of the buffers
+  };
+  struct Link { // everything that travels between this rank and ONE other rank is one message each way
+    int rank = 0;
+    int64_t send_off = 0, cnt_send = 0, recv_off = 0, cnt_recv = 0;
   };
   struct Plan {
     PeerTable pt;
-    std::vector<Peer> peers; // ascending offset order (z slowest); sends are posted in this order, receives in the reverse
-                             // one -- the peer of entry i sends what we receive from it with the opposite offset, whose
-                             // index runs the other way, so the messages between a pair of ranks match in order
+    // Peers ordered by (rank, grid offset ascending, z slowest): the send entries of all peers that are the same rank (a
+    // direction with two ranks and periodic images; any small grid) are contiguous and travel as ONE message.  What comes back
+    // from that rank is the concatenation of ITS blocks for us in ITS ascending offset order -- our offsets negated, i.e. our
+    // peers of that rank in DESCENDING order: the receive blocks of a rank are laid out that way (Peer::recv_off).
+    std::vector<Peer> peers;
+    std::vector<Link> links; // one per distinct peer rank, ascending
     int64_t n_send = 0, n_recv = 0, n_src = 0;
     int* send_idx = nullptr;            // [n_send] local indices (owned atoms), peer-major
     int* send_int = nullptr;            // [n_send] the same as internal indices of the engine
@@ -677,27 +684,21 @@ private:
       on.template launch<256>(kSlotMisc, h.n_recv, HaloUnpackPeersBody{e.box(), e.bufs(), h.recv_int, h.recvbuf});
   }
   // the grouped exchange of the plan: forward = send entries out, ghosts in; backward = the ghosts' planes out, the entries'
-  // in.  `w` doubles per entry.  Sends in ascending peer order, receives in descending order (see Plan::peers).
+  // in.  `w` doubles per entry.  One message per distinct peer rank each way (Plan::links).
   void peer_exchange(B& on, int w, bool backward)
   {
     Plan& h = plan_;
     TransportMsg sm[kMaxPeers], rm[kMaxPeers];
     int ns = 0, nr = 0;
-    const int P = (int)h.peers.size();
     const int64_t wb = (int64_t)sizeof(double) * w;
-    for (int i = 0; i < P; ++i) {
-      const Peer& p = h.peers[i];
-      const int64_t c = backward ? p.cnt_recv : p.cnt_send;
-      double* buf = backward ? h.recvbuf + (int64_t)w * p.recv_off : h.sendbuf + (int64_t)w * p.send_off;
-      if (c)
-        sm[ns++] = TransportMsg{buf, wb * c, p.rank};
-    }
-    for (int i = P - 1; i >= 0; --i) {
-      const Peer& p = h.peers[i];
-      const int64_t c = backward ? p.cnt_send : p.cnt_recv;
-      double* buf = backward ? h.sendbuf + (int64_t)w * p.send_off : h.recvbuf + (int64_t)w * p.recv_off;
-      if (c)
-        rm[nr++] = TransportMsg{buf, wb * c, p.rank};
+    for (const Link& k : h.links) {
+      const int64_t cs = backward ? k.cnt_recv : k.cnt_send, cr = backward ? k.cnt_send : k.cnt_recv;
+      double* sb = backward ? h.recvbuf + (int64_t)w * k.recv_off : h.sendbuf + (int64_t)w * k.send_off;
+      double* rb = backward ? h.sendbuf + (int64_t)w * k.send_off : h.recvbuf + (int64_t)w * k.recv_off;
+      if (cs)
+        sm[ns++] = TransportMsg{sb, wb * cs, k.rank};
+      if (cr)
+        rm[nr++] = TransportMsg{rb, wb * cr, k.rank};
     }
     exchange_on(on, ns, sm, nr, rm);
   }
@@ -942,6 +943,10 @@ private:
     {
       const DomainGeom& g = geom_;
       h.pt.n = 0;
+      struct Cand {
+        int rank, o[3];
+      };
+      std::vector<Cand> cands;
       for (int oz = -1; oz <= 1; ++oz)
         for (int oy = -1; oy <= 1; ++oy)
           for (int ox = -1; ox <= 1; ++ox) {
@@ -962,20 +967,29 @@ private:
             }
             if (!ok)
               continue;
-            const int i = h.pt.n++;
-            Peer pe;
-            pe.rank = c[0] + g.grid[0] * (c[1] + g.grid[1] * c[2]);
-            h.peers.push_back(pe);
+            Cand cd;
+            cd.rank = c[0] + g.grid[0] * (c[1] + g.grid[1] * c[2]);
             for (int d = 0; d < 3; ++d)
-              h.pt.off[i][d] = o[d];
-            // receiver-local coordinates: + (sender origin - receiver origin); across a periodic face the lattice-vector
-            // image and the jump of the origin cancel, so the shift is the same for edge ranks
-            for (int cc = 0; cc < 3; ++cc) {
-              h.pt.shift[i][cc] = 0.0;
-              for (int d = 0; d < 3; ++d)
-                h.pt.shift[i][cc] -= g.H[3 * cc + d] * (double)o[d] / g.grid[d];
-            }
+              cd.o[d] = o[d];
+            cands.push_back(cd);
           }
+      // by rank, the enumeration order (ascending offsets) within a rank
+      std::stable_sort(cands.begin(), cands.end(), [](const Cand& a, const Cand& b2) { return a.rank < b2.rank; });
+      for (const Cand& cd : cands) {
+        const int i = h.pt.n++;
+        Peer pe;
+        pe.rank = cd.rank;
+        h.peers.push_back(pe);
+        for (int d = 0; d < 3; ++d)
+          h.pt.off[i][d] = cd.o[d];
+        // receiver-local coordinates: + (sender origin - receiver origin); across a periodic face the lattice-vector
+        // image and the jump of the origin cancel, so the shift is the same for edge ranks
+        for (int cc = 0; cc < 3; ++cc) {
+          h.pt.shift[i][cc] = 0.0;
+          for (int d = 0; d < 3; ++d)
+            h.pt.shift[i][cc] -= g.H[3 * cc + d] * (double)cd.o[d] / g.grid[d];
+        }
+      }
     }
     const int NP = (int)h.peers.size();
     int64_t n_loc = n_own_new;
@@ -1024,7 +1038,8 @@ private:
         be_.exclusive_scan(h.src_start, m + 1, gscr);
         be_.template launch<256>(kSlotMisc, m, PeerCsrBody{mask, L, m, NP, pscan, h.src_start, h.src_entry});
       }
-      // counts: one 8-byte message per peer (sends ascending, receives descending: Plan::peers)
+      // counts: one 8-byte message per peer; between a pair of ranks the sender's ascending offsets are the receiver's
+      // descending ones (Plan::peers), so the receives of a rank are posted in descending order of our peer index
       {
         std::vector<int64_t> cs((size_t)NP), cr((size_t)NP, 0);
         for (int i = 0; i < NP; ++i)
@@ -1032,19 +1047,45 @@ private:
         int64_t* d = (int64_t*)palloc(sizeof(int64_t) * 2 * NP);
         be_.h2d(d, cs.data(), sizeof(int64_t) * NP);
         TransportMsg sm[kMaxPeers], rm[kMaxPeers];
+        std::vector<int> rorder; // our peers in the order their blocks arrive: rank ascending, offsets descending within a rank
+        for (int i = 0; i < NP;) {
+          int j = i;
+          while (j < NP && h.peers[j].rank == h.peers[i].rank)
+            ++j;
+          for (int q = j - 1; q >= i; --q)
+            rorder.push_back(q);
+          i = j;
+        }
         for (int i = 0; i < NP; ++i)
           sm[i] = TransportMsg{d + i, 8, h.peers[i].rank};
         for (int i = 0; i < NP; ++i)
-          rm[i] = TransportMsg{d + NP + (NP - 1 - i), 8, h.peers[NP - 1 - i].rank};
+          rm[i] = TransportMsg{d + NP + rorder[i], 8, h.peers[rorder[i]].rank};
         exchange(NP, sm, NP, rm);
         be_.sync();
         be_.d2h(cr.data(), d + NP, sizeof(int64_t) * NP);
         pfree(d);
         h.n_recv = 0;
-        for (int i = 0; i < NP; ++i) {
-          h.peers[i].cnt_recv = cr[i];
-          h.peers[i].recv_off = h.n_recv;
-          h.n_recv += cr[i];
+        for (int i = 0; i < NP; ++i) { // receive blocks in arrival order
+          Peer& pe = h.peers[rorder[i]];
+          pe.cnt_recv = cr[rorder[i]];
+          pe.recv_off = h.n_recv;
+          h.n_recv += pe.cnt_recv;
+        }
+        h.links.clear();
+        for (int i = 0; i < NP;) {
+          int j = i;
+          Link k;
+          k.rank = h.peers[i].rank;
+          k.send_off = h.peers[i].send_off;
+          k.recv_off = h.peers[i].recv_off;
+          while (j < NP && h.peers[j].rank == k.rank) {
+            k.cnt_send += h.peers[j].cnt_send;
+            k.cnt_recv += h.peers[j].cnt_recv;
+            k.recv_off = h.peers[j].recv_off < k.recv_off ? h.peers[j].recv_off : k.recv_off;
+            ++j;
+          }
+          h.links.push_back(k);
+          i = j;
         }
       }
       if (n_loc + h.n_recv > N.cap)

@@ -1221,6 +1221,41 @@ struct HipBackend {
       NEPMI_HIP_CHECK(hipGetLastError());
       if (t)
         timer_stop(timing->slot[slot]);
+    } else {
+      // many types / run-time shapes: nepmi_force_scatter_mt_kernel, four lanes per atom, one workgroup per CU
+      if (nbricks <= 0)
+        return;
+#ifndef NEPMI_FS_MT_LANES
+#define NEPMI_FS_MT_LANES 4
+#endif
+      constexpr int L = NEPMI_FS_MT_LANES;
+      const ForceScatterBody<S> body{ws2, md, frz, reinterpret_cast<I4*>(halo)};
+      const ScatterLayoutMT lay{ws2.lay.wmax, md.T * md.T * ctab_block(md.NR, md.KR, NEPMI_FS_MT_VEC != 0)};
+      const int64_t grid = (nbricks + 7) / 8 * 8;
+      const size_t lds_bytes = ((size_t)lay.bytes() + 15) / 16 * 16;
+      const bool t = timed(slot);
+      if (t)
+        timer_start(timing->slot[slot]);
+      if (outputs) {
+        if (lds_bytes > 64 * 1024)
+          NEPMI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&nepmi_force_scatter_mt_kernel<S, true, L>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        hipLaunchKernelGGL((nepmi_force_scatter_mt_kernel<S, true, L>), dim3((unsigned)grid), dim3(kWinThreads * L), lds_bytes, stream,
+                           body, nbricks);
+      } else {
+        if (lds_bytes > 64 * 1024)
+          NEPMI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&nepmi_force_scatter_mt_kernel<S, false, L>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        hipLaunchKernelGGL((nepmi_force_scatter_mt_kernel<S, false, L>), dim3((unsigned)grid), dim3(kWinThreads * L), lds_bytes, stream,
+                           body, nbricks);
+      }
+      NEPMI_HIP_CHECK(hipGetLastError());
+      const ForceFoldBody fold{ws2.b, md, ws2.lay.wmax, fold_rows, fmap, reinterpret_cast<const I4*>(halo)};
+      const int64_t fgrid = ((natoms + 255) / 256 + 7) / 8 * 8;
+      hipLaunchKernelGGL((nepmi_kernel<256, ForceFoldBody>), dim3((unsigned)fgrid), dim3(256), 0, stream, fold, natoms, frz);
+      NEPMI_HIP_CHECK(hipGetLastError());
+      if (t)
+        timer_stop(timing->slot[slot]);
     }
   }
   // the windows that hold each atom (FoldMapBody), once per list rebuild; returns the largest number of windows met

@@ -1605,6 +1605,8 @@ private:
       virial_local_ = false;
     if (!tile_ok_)
       be_.template launch<64>(kSlotForce, N_, ForceAssembleBody<S>{md_, b_});
+    else if (wonly && win2 && fpj_wanted<S>(ws2))
+      be_.launch_win2(kSlotMisc, num_bricks_, ForceWinBody<S, 1, false, false, true>{ws2, md_, frozen, 1});
     else if (wonly && win2)
       be_.launch_win2(kSlotMisc, num_bricks_, ForceWinBody<S, 1, NEPMI_CW != 0>{ws2, md_, frozen, 1});
     else if (win2 && rows_form<S>(ws2, frozen))
@@ -1625,18 +1627,23 @@ private:
   // atom, shapes with register-resident per-type rows, a device backend; in the run loops (or wherever set_force_form(1)
   // asks for it) and until a pair half has left the fixed-point guard band (flags[kFlagRange]).  A counted rule.
   template <class S>
-  bool scatter_wanted() const
+  bool scatter_wanted(const WinStage& ws2) const
   {
-    if (!B::kHasScatter || !(S::TS > 0) || !b_.aslot || !halo_ || !fmap_ || !fold_ok_ || scatter_disabled_ || force_form_ == 0)
+    if (!B::kHasScatter || !b_.aslot || !halo_ || !fmap_ || !fold_ok_ || scatter_disabled_ || force_form_ == 0)
       return false;
     if (force_form_ < 0 && !loop_ctx_)
       return false;
-    return 24 * (size_t)win_.wmax <= B::kMaxLdsBytes;
+    if (S::TS > 0)
+      return 24 * (size_t)win_.wmax <= B::kMaxLdsBytes;
+    // many types / run-time shapes: the own half from the atom's radial Fp row and the coefficient table in LDS -- where the
+    // FPJ gather form applies (it supplies the virial-only pass; neither needs the per-atom radial table from the ANN kernel)
+    return fpj_wanted<S>(ws2) &&
+           25 * (size_t)win_.wmax + 4 * (size_t)model_.num_types * model_.num_types * ctab_block(md_.NR, md_.KR, true) <= B::kMaxLdsBytes;
   }
   template <class S>
   bool scatter_form(const WinStage& ws2, const int* frozen)
   {
-    if (!scatter_wanted<S>())
+    if (!scatter_wanted<S>(ws2))
       return false;
     be_.template launch_force_scatter<S>(kSlotForce, num_bricks_, N_, ws2, md_, halo_, fmap_, fold_rows_, step_outputs_, frozen);
     if (!step_outputs_)

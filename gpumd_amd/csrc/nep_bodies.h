@@ -1960,7 +1960,10 @@ struct AngularForceBody {
   // one-lane form: the per-atom table G and the P/Q sums sit a few registers above 256; held to two wavefronts per SIMD
   static constexpr int kMinWavesPerEu = (S::fixed && S::NA + 1 < 7) ? NEPMI_AF_WAVES : 1;
   // lane-pair form: half the table per lane; two wavefronts per SIMD is what it exists for
-  static constexpr int kMinWavesPerEuPairs = S::fixed ? 2 : 1;
+#ifndef NEPMI_AF_WAVES_PAIRS
+#define NEPMI_AF_WAVES_PAIRS 2 // A/B switch (profiles/ab_variants.sh): 1 = the whole register file for one wavefront per SIMD
+#endif
+  static constexpr int kMinWavesPerEuPairs = S::fixed ? NEPMI_AF_WAVES_PAIRS : 1;
   NEPMI_HD int lds_floats() const { return cang_floats(m); }
   NEPMI_HD void lds_stage(float* dst, int tid, int nth) const { cang_stage(m, dst, tid, nth); }
 

@@ -32,6 +32,9 @@
 #pragma once
 #include "nep_window.h"
 
+#ifndef NEPMI_FS_MT_VEC
+#define NEPMI_FS_MT_VEC 1 // many-type form: coefficient blocks padded to 4 (odd) floats and read with 16-byte ds_reads (r4j: UNEP-v1 1 M atoms, force assembly 1.02 -> 0.78 ms); 0 = element-wise, odd stride
+#endif
 #ifndef NEPMI_FS_ABL
 #define NEPMI_FS_ABL 0 // ablation builds (profiles/ab_variants.sh; timings only, results are wrong): 1 no LDS atomics in the pair loop,
                        // 2 no pair loop, 3 no staging of the positions, 4 no angular part, 5 no halo rows written
@@ -439,6 +442,297 @@ nepmi_force_scatter_kernel(const ForceScatterBody<S> body, const int64_t nbricks
     NEPMI_LDS(const I3)* acc = (NEPMI_LDS(const I3)*)(lds + lay.off_acc());
     I4* __restrict__ out = body.halo + (size_t)brick * lay.wmax;
     for (int i = tid; i < (NEPMI_FS_ABL == 5 ? 0 : lay.wmax); i += kWinThreads) {
+      const I3 v = acc[i];
+      out[i] = I4{v.x, v.y, v.z, 0};
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Many types (UNEP-v1: 16) and run-time shapes: the pair's coefficient block c[t_i][t_j] differs from lane to lane, so no
+// type-pure segments and no register-resident rows.  The own half is contracted per pair from the coefficient table in LDS,
+//   s12 = sum_n Fp_i[n] sum_k c[t_i][t_j][n][k] f_k'(r)
+// (Fp_i: the atom's own radial Fp row, Bufs::fpr, in registers) -- half of what the gather form's FPJ variant does per pair
+// (no c[t_j][t_i] block, no gather of the neighbour's Fp row).  The table (46 KB for UNEP-v1) + 24 B per window atom + a byte
+// of type fill most of a CU's LDS: ONE workgroup of 256 L threads per CU, L = 4 adjacent lanes per atom (lane `sub` takes
+// every L-th chunk of two pairs and every L-th angular pair; the scatter is atomic anyway, the own sums and the virial are
+// added across the lanes with shuffles): 16 wavefronts per CU.
+// ---------------------------------------------------------------------------------------------------------------------
+struct ScatterLayoutMT {
+  int wmax, ctab_floats;
+  __device__ __host__ int off_pos() const { return 0; }
+  __device__ __host__ int off_acc() const { return 12 * wmax; }
+  __device__ __host__ int off_type() const { return 24 * wmax; }
+  __device__ __host__ int off_ctab() const { return 25 * wmax; } // wmax is a multiple of 64
+  __device__ __host__ int bytes() const { return 25 * wmax + 4 * ctab_floats; }
+};
+
+template <class S, bool OUT, int L>
+__device__ __forceinline__ void force_scatter_atom_mt(const ForceScatterBody<S>& B, const int64_t brick, const int64_t k, const int sub,
+                                                      NEPMI_LDS(char)* lds, const ScatterLayoutMT lay)
+{
+  const Bufs& b = B.st.b;
+  const ModelD& m = B.m;
+  const int64_t N = b.N;
+  const int lv = b.lvl[k];
+  double* __restrict__ fo = b.fo + k;
+  if (lv < b.lvl_desc) {
+    if (OUT && sub == 0 && lv >= b.lvl_force) {
+      fo[0] = 0.0;
+#pragma unroll
+      for (int d = 0; d < 9; ++d)
+        fo[(int64_t)(kOutW + d) * N] = 0.0;
+    }
+    return;
+  }
+  NEPMI_LDS(const char)* wpos = (NEPMI_LDS(const char)*)(lds + lay.off_pos());
+  NEPMI_LDS(char)* wacc = (NEPMI_LDS(char)*)(lds + lay.off_acc());
+  NEPMI_LDS(const unsigned char)* wtyp = (NEPMI_LDS(const unsigned char)*)(lds + lay.off_type());
+  NEPMI_LDS(const float)* ctl = (NEPMI_LDS(const float)*)(lds + lay.off_ctab());
+  const int l = b.kcell[k] & 63;
+  const int wc_own = ((l & 3) + 2) + 8 * (((l >> 2) & 3) + 2) + 64 * ((l >> 4) + 2);
+  int ox, oy, oz;
+  B.st.cell_offset(0, 0, 0, (l & 3) + 2, ((l >> 2) & 3) + 2, (l >> 4) + 2, ox, oy, oz);
+  const WinRec pr = b.prec[k];
+  ox += pr.x;
+  oy += pr.y;
+  oz += pr.z;
+  const int t1 = (int)((unsigned)pr.w >> kIdxBits);
+  const int* tab = b.wtab + (brick * 512 + wc_own) * 2;
+  const int own_slot = (tab[1] & 0xFFFF) + (int)(k - tab[0]);
+  const float rc1 = m.rc_r[t1];
+  const float unit = b.wg.unit;
+  const float qs = unit * kScatterScale;
+  const int NR = S::fixed ? S::NR : m.NR;
+  const int KR = S::fixed ? S::KR : m.KR;
+  const int cblk = ctab_block(NR, KR, NEPMI_FS_MT_VEC != 0);
+  float Fpi[S::NRM + 1]; // the own radial Fp row
+#pragma unroll
+  for (int n = 0; n <= S::NRM; ++n)
+    Fpi[n] = (S::fixed || n <= NR) ? b.fpr[(size_t)k * b.FPR + n] : 0.0f;
+
+  int Fi[3] = {0, 0, 0};
+  float big = 0.0f;
+  const int nrad = b.nn_rad[k] < b.MN_rad ? b.nn_rad[k] : b.MN_rad;
+  float W[6] = {0, 0, 0, 0, 0, 0}; // -sum r (x) g in (grid unit)^2 qs: xx yy zz xy xz yz
+
+  // operands of this lane's first angular pair, requested now
+  const bool ang_on = NEPMI_FS_ABL != 4 && (!b.level || b.angf[k]);
+  const int nang = ang_on ? b.nn_angstep[k] : 0;
+  const F4* __restrict__ acomp = b.acomp + k;
+  const F4* __restrict__ f12o = b.f12 + k;
+  const unsigned short* __restrict__ aslot = b.aslot + k;
+
+  auto one_pair = [&](const unsigned a0) __attribute__((always_inline)) {
+    const unsigned o0 = row12(a0);
+    const I3 p0 = *(NEPMI_LDS(const I3)*)(wpos + o0);
+    const int t2 = wtyp[a0];
+    const float fx = (float)(p0.x - ox), fy = (float)(p0.y - oy), fz = (float)(p0.z - oz);
+    const float d2 = dot3f(fx, fx, fy, fy, fz, fz) * b.wg.unit2;
+    float d, dinv;
+    dist_and_inv(d2, d, dinv);
+    const float rc = m.uniform_rc ? m.rc_r_max : (rc1 + m.rc_r[t2]) * 0.5f;
+    const float rcinv = m.uniform_rc ? m.rcinv_r : fast_rcp(rc);
+    const float dc = d < rc ? d : rc;
+    float fc, fcp;
+    cutoff_fc_fcp(rcinv, dc, fc, fcp);
+    float fn[S::KRM + 1], fnp[S::KRM + 1];
+    if (S::fixed)
+      basis_fn_fnp<S::KRM>(rcinv, dc, fc, fcp, fn, fnp);
+    else
+      basis_fn_fnp_rt(KR, rcinv, dc, fc, fcp, fn, fnp);
+    float g12[S::NRM + 1];
+    if (NEPMI_FS_ABL == 6) { // (ablation: no table contraction)
+#pragma unroll
+      for (int n = 0; n <= S::NRM; ++n)
+        g12[n] = fnp[n % (S::KRM + 1)];
+    } else {
+      ctab_contract<S, NEPMI_FS_MT_VEC != 0>(ctl + (t1 * m.T + t2) * cblk, NR, KR, fnp, g12);
+    }
+    float s12 = 0.0f;
+#pragma unroll
+    for (int n = 0; n <= S::NRM; ++n) {
+      if (!S::fixed && n > NR)
+        break;
+      s12 = fmaf(Fpi[n], g12[n], s12);
+    }
+    big = fmaxf(big, fabsf(s12));
+    const float g = s12 * dinv * qs;
+    const float gx = g * fx, gy = g * fy, gz = g * fz;
+    if (OUT) {
+      W[0] = fmaf(-fx, gx, W[0]);
+      W[1] = fmaf(-fy, gy, W[1]);
+      W[2] = fmaf(-fz, gz, W[2]);
+      W[3] = fmaf(-fx, gy, W[3]);
+      W[4] = fmaf(-fx, gz, W[4]);
+      W[5] = fmaf(-fy, gz, W[5]);
+    }
+    const int ax = to_fixed(gx), ay = to_fixed(gy), az = to_fixed(gz);
+    Fi[0] += ax;
+    Fi[1] += ay;
+    Fi[2] += az;
+    NEPMI_LDS(int)* r0 = (NEPMI_LDS(int)*)(wacc + o0);
+    if (NEPMI_FS_ABL == 1)
+      return;
+    lds_sub(r0, ax);
+    lds_sub(r0 + 1, ay);
+    lds_sub(r0 + 2, az);
+  };
+  // this lane's entries: sub, sub + L, ...; the next one requested while the current one is evaluated
+  {
+    const unsigned short* __restrict__ q = b.ccode + k + (int64_t)sub * N;
+    const int64_t stride = (int64_t)L * N;
+    unsigned cur = 0, nxt = 0;
+    if (sub < nrad)
+      cur = q[0];
+    for (int s0 = sub; s0 < (NEPMI_FS_ABL == 2 ? 0 : nrad); s0 += L) {
+      q += stride;
+      if (s0 + L < nrad)
+        nxt = q[0];
+      one_pair(cur);
+      cur = nxt;
+    }
+  }
+  float Wa[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int a = sub; a < nang; a += L) {
+    const F4 fa = f12o[(int64_t)a * N];
+    const int sl = aslot[(int64_t)a * N];
+    big = fmaxf(big, fmaxf(fabsf(fa.x), fmaxf(fabsf(fa.y), fabsf(fa.z))));
+    const int ax = to_fixed(fa.x * kScatterScale), ay = to_fixed(fa.y * kScatterScale), az = to_fixed(fa.z * kScatterScale);
+    Fi[0] += ax;
+    Fi[1] += ay;
+    Fi[2] += az;
+    NEPMI_LDS(int)* rj = (NEPMI_LDS(int)*)(wacc + row12((unsigned)sl));
+    lds_sub(rj, ax);
+    lds_sub(rj + 1, ay);
+    lds_sub(rj + 2, az);
+    if (OUT) {
+      const F4 e = acomp[(int64_t)a * N];
+      Wa[0] -= e.x * fa.x;
+      Wa[1] -= e.y * fa.y;
+      Wa[2] -= e.z * fa.z;
+      Wa[3] -= e.x * fa.y;
+      Wa[4] -= e.x * fa.z;
+      Wa[5] -= e.y * fa.z;
+      Wa[6] -= e.y * fa.x;
+      Wa[7] -= e.z * fa.x;
+      Wa[8] -= e.z * fa.y;
+    }
+  }
+  {
+    NEPMI_LDS(int)* ro = (NEPMI_LDS(int)*)(wacc + row12((unsigned)own_slot)); // (every lane its part: integer adds commute)
+    lds_add(ro, Fi[0]);
+    lds_add(ro + 1, Fi[1]);
+    lds_add(ro + 2, Fi[2]);
+  }
+  if (NEPMI_FS_ABL == 0 && big >= kScatterFlagLimit)
+    atomicOr(&b.flags[kFlagRange], 1);
+  if (!OUT)
+    return;
+#pragma unroll
+  for (int msk = 1; msk < L; msk <<= 1) { // the L lanes of an atom are adjacent: a fixed tree
+#pragma unroll
+    for (int d = 0; d < 6; ++d)
+      W[d] += __shfl_xor(W[d], msk);
+#pragma unroll
+    for (int d = 0; d < 9; ++d)
+      Wa[d] += __shfl_xor(Wa[d], msk);
+  }
+  if (sub != 0 || lv < b.lvl_force)
+    return;
+  double E = lv >= 2 ? (double)b.pe_i[k] : 0.0;
+  float Wr[6];
+#pragma unroll
+  for (int d = 0; d < 6; ++d)
+    Wr[d] = W[d] * (unit * (1.0f / kScatterScale));
+  double Wd[9];
+  Wd[0] = (double)(Wr[0] + Wa[0]);
+  Wd[1] = (double)(Wr[1] + Wa[1]);
+  Wd[2] = (double)(Wr[2] + Wa[2]);
+  Wd[3] = (double)(Wr[3] + Wa[3]);
+  Wd[4] = (double)(Wr[4] + Wa[4]);
+  Wd[5] = (double)(Wr[5] + Wa[5]);
+  Wd[6] = (double)(Wr[3] + Wa[6]);
+  Wd[7] = (double)(Wr[4] + Wa[7]);
+  Wd[8] = (double)(Wr[5] + Wa[8]);
+  if (m.zbl_enabled && lv >= 2) {
+#pragma unroll
+    for (int d = 0; d < 6; ++d)
+      Wd[d] += (double)b.zbl[(int64_t)(3 + d) * N + k];
+    Wd[6] += (double)b.zbl[(int64_t)(3 + 3) * N + k];
+    Wd[7] += (double)b.zbl[(int64_t)(3 + 4) * N + k];
+    Wd[8] += (double)b.zbl[(int64_t)(3 + 5) * N + k];
+    E += (double)b.zbl[(int64_t)9 * N + k];
+  }
+  fo[0] = E;
+#pragma unroll
+  for (int d = 0; d < 9; ++d)
+    fo[(int64_t)(kOutW + d) * N] = Wd[d];
+}
+
+template <class S, bool OUT, int L>
+__global__ void __launch_bounds__(kWinThreads * L) nepmi_force_scatter_mt_kernel(const ForceScatterBody<S> body, const int64_t nbricks)
+{
+  constexpr int NT = kWinThreads * L;
+  extern __shared__ __attribute__((aligned(16))) char nepmi_win_lds[];
+  NEPMI_LDS(char)* lds = (NEPMI_LDS(char)*)nepmi_win_lds;
+  if (body.frozen && *body.frozen != 0)
+    return;
+  const unsigned per_xcd = gridDim.x >> 3;
+  const int64_t brick = (int64_t)(blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+  if (brick >= nbricks)
+    return;
+  const int tid = (int)threadIdx.x;
+  const Bufs& b = body.st.b;
+  const ModelD& m = body.m;
+  const ScatterLayoutMT lay{body.st.lay.wmax, m.T * m.T * ctab_block(m.NR, m.KR, NEPMI_FS_MT_VEC != 0)};
+  {
+    NEPMI_LDS(I3)* wp = (NEPMI_LDS(I3)*)(lds + lay.off_pos());
+    NEPMI_LDS(unsigned char)* wt = (NEPMI_LDS(unsigned char)*)(lds + lay.off_type());
+    const int* tab = b.wtab + brick * 1024;
+    int bx, by, bz;
+    body.st.brick_coords(brick, bx, by, bz);
+    for (int wc = tid; wc < kWinCells; wc += NT) {
+      const int j0 = tab[2 * wc], pk = tab[2 * wc + 1];
+      const int w0 = pk & 0xFFFF;
+      int cnt = pk >> 16;
+      if (w0 + cnt > lay.wmax)
+        cnt = lay.wmax > w0 ? lay.wmax - w0 : 0;
+      if (cnt == 0)
+        continue;
+      int qx, qy, qz;
+      body.st.cell_offset(bx, by, bz, wc & 7, (wc >> 3) & 7, wc >> 6, qx, qy, qz);
+      for (int a = 0; a < cnt; a += 4) {
+        WinRec r[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          r[u] = b.prec[j0 + (a + u < cnt ? a + u : cnt - 1)];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (a + u < cnt) {
+            wp[w0 + a + u] = I3{r[u].x + qx, r[u].y + qy, r[u].z + qz};
+            wt[w0 + a + u] = (unsigned char)((unsigned)r[u].w >> kIdxBits);
+          }
+      }
+    }
+    NEPMI_LDS(U4)* a4 = (NEPMI_LDS(U4)*)(lds + lay.off_acc());
+    const int n4 = 3 * lay.wmax / 4;
+    const U4 zero{0u, 0u, 0u, 0u};
+    for (int i = tid; i < n4; i += NT)
+      a4[i] = zero;
+    ctab_stage_padded(m, lds + lay.off_ctab(), tid, NT, NEPMI_FS_MT_VEC != 0);
+  }
+  __syncthreads();
+  int64_t a0, a1;
+  body.st.brick_range(brick, a0, a1);
+  const int sub = tid % L;
+  for (int64_t k = a0 + tid / L; k < a1; k += kWinThreads)
+    force_scatter_atom_mt<S, OUT, L>(body, brick, k, sub, lds, lay);
+  __syncthreads();
+  {
+    NEPMI_LDS(const I3)* acc = (NEPMI_LDS(const I3)*)(lds + lay.off_acc());
+    I4* __restrict__ out = body.halo + (size_t)brick * lay.wmax;
+    for (int i = tid; i < (NEPMI_FS_ABL == 5 ? 0 : lay.wmax); i += NT) {
       const I3 v = acc[i];
       out[i] = I4{v.x, v.y, v.z, 0};
     }
