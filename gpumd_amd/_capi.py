@@ -128,6 +128,8 @@ SYMBOLS = {
     "nepmi_dist_set_overlap": (C.c_int, [VP, C.c_int]),
     "nepmi_dist_set_ghost_mode": (C.c_int, [VP, C.c_int]),
     "nepmi_dist_get_info": (C.c_int, [VP, C.POINTER(NepmiDistInfo)]),
+    "nepmi_dist_info_bytes": (C.c_int, []),
+    "nepmi_dist_num_overlapped_reverse": (C.c_int64, [VP]),
     "nepmi_dist_gather_owned": (C.c_int, [VP, VP, VP, VP, VP, VP, VP]),
     "nepmi_dist_gather_global": (C.c_int, [VP, C.c_int, VP, VP, VP, VP, VP]),
     "nepmi_dist_reset_thermostat": (C.c_int, [VP]),

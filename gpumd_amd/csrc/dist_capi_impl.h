@@ -132,6 +132,10 @@ int nepmi_dist_get_info(nepmi_dist* d, nepmi_dist_info* out)
   return NEPMI_OK;
 }
 
+int nepmi_dist_info_bytes(void) { return (int)sizeof(nepmi_dist_info); }
+
+int64_t nepmi_dist_num_overlapped_reverse(nepmi_dist* d) { return d ? d->d->num_overlapped_reverse : 0; }
+
 int nepmi_dist_gather_owned(nepmi_dist* d, int64_t* ids, double* pos, double* vel, double* force, double* pe, double* virial)
 {
   if (!d)

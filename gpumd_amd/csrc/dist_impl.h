@@ -272,8 +272,28 @@ public:
       if (&comm != &be_)
         be_.join_from(comm);
       if (!trip) {
+        // Reverse-mode ghosts with the overlap on: the boundary bricks' force assembly and the ghosts' fold first, then the
+        // ghosts' partial forces travel on the communication stream while the interior bricks (and the owned atoms' fold) run
+        // on the compute stream; the returned parts are added after both (bit-identical to the plain order: the same integer
+        // sums, the same additions in the same order).  Host transports block: the exchange simply runs first.
+        const bool rsplit = overlap_ && reverse_ && tr_.nranks > 1;
+        if (rsplit)
+          e->set_assembly_part(1);
         force_phase(split ? (side_radial ? Engine::kPhaseAfterRadial : Engine::kPhaseBoundary) : Engine::kPhaseAll, frozen());
-        force_reverse(frozen());
+        if (rsplit && e->assembly_pending()) {
+          B& c2 = tr_.device_buffers ? comm_backend() : be_;
+          if (&c2 != &be_)
+            be_.fork_to(c2);
+          virial_folded_ = false;
+          reverse_send(c2, kOutF, 3, frozen());
+          e->force_assembly_rest(frozen());
+          if (&c2 != &be_)
+            be_.join_from(c2);
+          reverse_add(kOutF, 3, frozen());
+          ++num_overlapped_reverse;
+        } else {
+          force_reverse(frozen());
+        }
         bool need_sync = record || last;
         if (ens == Engine::kNve && !record && !last) {
           kick2_pending = true;
@@ -444,6 +464,7 @@ public:
   }
   void set_overlap(bool on) { overlap_ = on; }
   int64_t num_overlapped = 0; // steps whose interior radial pass ran before / while the ghosts travelled
+  int64_t num_overlapped_reverse = 0; // steps whose interior force assembly ran while the ghosts' partial forces travelled
   double decompose_ms = 0.0;  // wall time of all (re-)decompositions (migration, ghost stages, list rebuild), synchronised
 
 private:
@@ -596,6 +617,7 @@ private:
         throw EngineError{-5, "transport all-reduce failed"};
     } else {
       char tmp[64];
+      dtype &= 0xFF;
       const size_t bytes = (size_t)count * (dtype == kDtI32 ? 4 : 8);
       be_.d2h(tmp, dbuf, bytes); // synchronises the stream
       if (tr_.allreduce(tr_.ctx, tmp, count, dtype, op, nullptr) != 0)
@@ -642,7 +664,10 @@ private:
     // their next collective)
     static_assert(kFlagOverflow == kFlagMoved + 1, "the vote reduces two adjacent flag words");
     int* word = eng_->bufs().flags + kFlagMoved;
-    device_allreduce_on(on, word, 2, kDtI32, kOpMax);
+    // a transport that can (nepmi.h: NEPMI_DT_DEFER) posts the reduction inside the group of the ghost exchange that follows on
+    // the same stream: the word is first read by the kernels behind that exchange
+    const bool defer = spec && (tr_.device_buffers & 2) != 0;
+    device_allreduce_on(on, word, 2, kDtI32 | (defer ? NEPMI_DT_DEFER : 0), kOpMax);
     if (spec)
       return 0;
     int w = 0;
@@ -675,8 +700,6 @@ private:
   {
     Engine& e = *eng_;
     Plan& h = plan_;
-    if (h.peers.empty())
-      return;
     if (h.n_send > 0)
       on.template launch<256>(kSlotMisc, h.n_send, HaloPackPeersBody{e.bufs(), h.send_int, h.send_peer, h.pt, h.sendbuf});
     peer_exchange(on, 3, false);
@@ -708,16 +731,27 @@ private:
   // atom adds what its images collected, in ascending peer order.
   void reverse_exchange(int first, int planes, const int* frz)
   {
+    reverse_send(be_, first, planes, frz);
+    reverse_add(first, planes, frz);
+  }
+  void reverse_send(B& on, int first, int planes, const int* frz)
+  {
     Engine& e = *eng_;
     Plan& h = plan_;
     if (h.peers.empty())
       return;
     if (h.n_recv > 0)
-      be_.template launch<256>(kSlotMisc, h.n_recv, GhostPackPeersBody{e.bufs(), h.recv_int, first, planes, h.recvbuf, frz});
-    peer_exchange(be_, planes, true);
-    if (h.n_src > 0)
-      be_.template launch<256>(kSlotMisc, h.n_src,
-                               GhostAddPeersBody{e.bufs(), h.src_int, h.src_start, h.src_entry, first, planes, h.sendbuf, frz});
+      on.template launch<256>(kSlotMisc, h.n_recv, GhostPackPeersBody{e.bufs(), h.recv_int, first, planes, h.recvbuf, frz});
+    peer_exchange(on, planes, true);
+  }
+  void reverse_add(int first, int planes, const int* frz)
+  {
+    Engine& e = *eng_;
+    Plan& h = plan_;
+    if (h.peers.empty() || h.n_src == 0)
+      return;
+    be_.template launch<256>(kSlotMisc, h.n_src,
+                             GhostAddPeersBody{e.bufs(), h.src_int, h.src_start, h.src_entry, first, planes, h.sendbuf, frz});
   }
   void force_reverse(const int* frz = nullptr) // frz: as the force kernels of this step got it
   {

@@ -1187,76 +1187,64 @@ struct HipBackend {
   // window accumulator and writes it to its row of hacc; ForceFoldBody then adds every atom's entries.  One timing bracket
   // around both launches: together they are the force assembly.
   static constexpr bool kHasScatter = true;
+  // nb bricks from brick_order[first ...] (first < 0: all bricks in their own order); then the fold of the atoms with level in
+  // [fold_lo, fold_hi] (fold_lo > fold_hi: no fold)
   template <class S>
-  void launch_force_scatter(int slot, int64_t nbricks, int64_t natoms, const WinStage& ws2, const ModelD& md, int* halo,
-                            const unsigned* fmap, int fold_rows, bool outputs, const int* frz)
+  void launch_force_scatter(int slot, int64_t nb, int first, int64_t natoms, const WinStage& ws2, const ModelD& md, int* halo,
+                            const unsigned* fmap, int fold_rows, bool outputs, int fold_lo, int fold_hi, const int* frz)
   {
-    if constexpr (S::TS > 0) {
-      if (nbricks <= 0)
-        return;
-      const ForceScatterBody<S> body{ws2, md, frz, reinterpret_cast<I4*>(halo)};
-      const ScatterLayout lay{ws2.lay.wmax};
-      const int64_t grid = (nbricks + 7) / 8 * 8;
-      const size_t lds_bytes = ((size_t)lay.bytes() + 15) / 16 * 16;
-      const bool t = timed(slot);
-      if (t)
-        timer_start(timing->slot[slot]);
-      if (outputs) {
-        if (lds_bytes > 64 * 1024)
-          NEPMI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&nepmi_force_scatter_kernel<S, true>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        hipLaunchKernelGGL((nepmi_force_scatter_kernel<S, true>), dim3((unsigned)grid), dim3(kWinThreads), lds_bytes, stream, body,
-                           nbricks);
+    const ForceScatterBody<S> body{ws2, md, frz, reinterpret_cast<I4*>(halo), first};
+    const int64_t grid = (nb + 7) / 8 * 8;
+    const bool t = timed(slot);
+    if (t)
+      timer_start(timing->slot[slot]);
+    if (nb > 0) {
+      if constexpr (S::TS > 0) {
+        const ScatterLayout lay{ws2.lay.wmax};
+        const size_t lds_bytes = ((size_t)lay.bytes() + 15) / 16 * 16;
+        if (outputs) {
+          if (lds_bytes > 64 * 1024)
+            NEPMI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&nepmi_force_scatter_kernel<S, true>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+          hipLaunchKernelGGL((nepmi_force_scatter_kernel<S, true>), dim3((unsigned)grid), dim3(kWinThreads), lds_bytes, stream, body, nb);
+        } else {
+          if (lds_bytes > 64 * 1024)
+            NEPMI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&nepmi_force_scatter_kernel<S, false>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+          hipLaunchKernelGGL((nepmi_force_scatter_kernel<S, false>), dim3((unsigned)grid), dim3(kWinThreads), lds_bytes, stream, body, nb);
+        }
       } else {
-        if (lds_bytes > 64 * 1024)
-          NEPMI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&nepmi_force_scatter_kernel<S, false>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        hipLaunchKernelGGL((nepmi_force_scatter_kernel<S, false>), dim3((unsigned)grid), dim3(kWinThreads), lds_bytes, stream, body,
-                           nbricks);
-      }
-      NEPMI_HIP_CHECK(hipGetLastError());
-      const ForceFoldBody fold{ws2.b, md, ws2.lay.wmax, fold_rows, fmap, reinterpret_cast<const I4*>(halo)};
-      const int64_t fgrid = ((natoms + 255) / 256 + 7) / 8 * 8;
-      hipLaunchKernelGGL((nepmi_kernel<256, ForceFoldBody>), dim3((unsigned)fgrid), dim3(256), 0, stream, fold, natoms, frz);
-      NEPMI_HIP_CHECK(hipGetLastError());
-      if (t)
-        timer_stop(timing->slot[slot]);
-    } else {
-      // many types / run-time shapes: nepmi_force_scatter_mt_kernel, four lanes per atom, one workgroup per CU
-      if (nbricks <= 0)
-        return;
+        // many types / run-time shapes: nepmi_force_scatter_mt_kernel, four lanes per atom, one workgroup per CU
 #ifndef NEPMI_FS_MT_LANES
 #define NEPMI_FS_MT_LANES 4
 #endif
-      constexpr int L = NEPMI_FS_MT_LANES;
-      const ForceScatterBody<S> body{ws2, md, frz, reinterpret_cast<I4*>(halo)};
-      const ScatterLayoutMT lay{ws2.lay.wmax, md.T * md.T * ctab_block(md.NR, md.KR, NEPMI_FS_MT_VEC != 0)};
-      const int64_t grid = (nbricks + 7) / 8 * 8;
-      const size_t lds_bytes = ((size_t)lay.bytes() + 15) / 16 * 16;
-      const bool t = timed(slot);
-      if (t)
-        timer_start(timing->slot[slot]);
-      if (outputs) {
-        if (lds_bytes > 64 * 1024)
-          NEPMI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&nepmi_force_scatter_mt_kernel<S, true, L>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        hipLaunchKernelGGL((nepmi_force_scatter_mt_kernel<S, true, L>), dim3((unsigned)grid), dim3(kWinThreads * L), lds_bytes, stream,
-                           body, nbricks);
-      } else {
-        if (lds_bytes > 64 * 1024)
-          NEPMI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&nepmi_force_scatter_mt_kernel<S, false, L>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        hipLaunchKernelGGL((nepmi_force_scatter_mt_kernel<S, false, L>), dim3((unsigned)grid), dim3(kWinThreads * L), lds_bytes, stream,
-                           body, nbricks);
+        constexpr int L = NEPMI_FS_MT_LANES;
+        const ScatterLayoutMT lay{ws2.lay.wmax, md.T * md.T * ctab_block(md.NR, md.KR, NEPMI_FS_MT_VEC != 0)};
+        const size_t lds_bytes = ((size_t)lay.bytes() + 15) / 16 * 16;
+        if (outputs) {
+          if (lds_bytes > 64 * 1024)
+            NEPMI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&nepmi_force_scatter_mt_kernel<S, true, L>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+          hipLaunchKernelGGL((nepmi_force_scatter_mt_kernel<S, true, L>), dim3((unsigned)grid), dim3(kWinThreads * L), lds_bytes, stream,
+                             body, nb);
+        } else {
+          if (lds_bytes > 64 * 1024)
+            NEPMI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&nepmi_force_scatter_mt_kernel<S, false, L>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+          hipLaunchKernelGGL((nepmi_force_scatter_mt_kernel<S, false, L>), dim3((unsigned)grid), dim3(kWinThreads * L), lds_bytes, stream,
+                             body, nb);
+        }
       }
       NEPMI_HIP_CHECK(hipGetLastError());
-      const ForceFoldBody fold{ws2.b, md, ws2.lay.wmax, fold_rows, fmap, reinterpret_cast<const I4*>(halo)};
+    }
+    if (fold_lo <= fold_hi && natoms > 0) {
+      const ForceFoldBody fold{ws2.b, md, ws2.lay.wmax, fold_rows, fmap, reinterpret_cast<const I4*>(halo), fold_lo, fold_hi};
       const int64_t fgrid = ((natoms + 255) / 256 + 7) / 8 * 8;
       hipLaunchKernelGGL((nepmi_kernel<256, ForceFoldBody>), dim3((unsigned)fgrid), dim3(256), 0, stream, fold, natoms, frz);
       NEPMI_HIP_CHECK(hipGetLastError());
-      if (t)
-        timer_stop(timing->slot[slot]);
     }
+    if (t)
+      timer_stop(timing->slot[slot]);
   }
   // the windows that hold each atom (FoldMapBody), once per list rebuild; returns the largest number of windows met
   int build_fold_map(int64_t natoms, const BoxD& box, const Bufs& b, int wmax, int rows, unsigned* fmap)
@@ -1510,13 +1498,36 @@ const RcclApi& rccl_api()
 
 struct RcclCtx {
   ncclComm_t comm;
+  // NEPMI_RCCL_FUSE_VOTE=1: a reduction passed with NEPMI_DT_DEFER waits for the next exchange on its stream and is posted inside
+  // that call's ncclGroup (off by default: a collective and point-to-point operations in one group has only ever run here on a
+  // single rank)
+  bool fuse = false, pending = false;
+  void *p_buf = nullptr, *p_stream = nullptr;
+  int64_t p_count = 0;
+  int p_dtype = 0, p_op = 0;
 };
+
+ncclResult_t rccl_reduce_now(RcclCtx* c, void* buf, int64_t count, int dtype, int op, void* stream)
+{
+  const ncclDataType_t dt = dtype == 0 ? ncclFloat64 : (dtype == 1 ? ncclInt32 : ncclInt64);
+  const ncclRedOp_t ro = op == 0 ? ncclSum : ncclMax;
+  return rccl_api().AllReduce(buf, buf, (size_t)count, dt, ro, c->comm, (hipStream_t)stream);
+}
 
 int rccl_exchange(void* vctx, int ns, const nepmi_msg* sends, int nr, const nepmi_msg* recvs, void* stream)
 {
   RcclCtx* c = (RcclCtx*)vctx;
   const RcclApi& R = rccl_api();
-  bool ok = R.GroupStart() == ncclSuccess;
+  bool ok = true;
+  if (c->pending && c->p_stream != stream) { // a deferred reduction of another stream: on its own, first
+    ok = rccl_reduce_now(c, c->p_buf, c->p_count, c->p_dtype, c->p_op, c->p_stream) == ncclSuccess;
+    c->pending = false;
+  }
+  ok = (R.GroupStart() == ncclSuccess) && ok;
+  if (c->pending && ok) { // the skin vote rides in this group: one collective for the vote and the ghost positions
+    ok = rccl_reduce_now(c, c->p_buf, c->p_count, c->p_dtype, c->p_op, stream) == ncclSuccess;
+    c->pending = false;
+  }
   for (int k = 0; k < ns && ok; ++k)
     ok = R.Send(sends[k].buf, (size_t)sends[k].bytes, ncclChar, sends[k].peer, c->comm, (hipStream_t)stream) == ncclSuccess;
   for (int k = 0; k < nr && ok; ++k)
@@ -1528,9 +1539,21 @@ int rccl_exchange(void* vctx, int ns, const nepmi_msg* sends, int nr, const nepm
 int rccl_allreduce(void* vctx, void* buf, int64_t count, int dtype, int op, void* stream)
 {
   RcclCtx* c = (RcclCtx*)vctx;
-  const ncclDataType_t dt = dtype == 0 ? ncclFloat64 : (dtype == 1 ? ncclInt32 : ncclInt64);
-  const ncclRedOp_t ro = op == 0 ? ncclSum : ncclMax;
-  return rccl_api().AllReduce(buf, buf, (size_t)count, dt, ro, c->comm, (hipStream_t)stream) == ncclSuccess ? 0 : -1;
+  bool ok = true;
+  if (c->pending) { // reductions stay in order
+    ok = rccl_reduce_now(c, c->p_buf, c->p_count, c->p_dtype, c->p_op, c->p_stream) == ncclSuccess;
+    c->pending = false;
+  }
+  if ((dtype & NEPMI_DT_DEFER) && c->fuse) {
+    c->pending = true;
+    c->p_buf = buf;
+    c->p_count = count;
+    c->p_dtype = dtype & 0xFF;
+    c->p_op = op;
+    c->p_stream = stream;
+    return ok ? 0 : -1;
+  }
+  return (rccl_reduce_now(c, buf, count, dtype & 0xFF, op, stream) == ncclSuccess && ok) ? 0 : -1;
 }
 
 void rccl_destroy(void* vctx)
@@ -1573,7 +1596,11 @@ extern "C" int nepmi_transport_rccl(const char id[NEPMI_RCCL_ID_BYTES], int rank
   out->ctx = c;
   out->rank = rank;
   out->nranks = nranks;
-  out->device_buffers = 1;
+  {
+    const char* fv = std::getenv("NEPMI_RCCL_FUSE_VOTE");
+    ((RcclCtx*)out->ctx)->fuse = fv && fv[0] == '1';
+  }
+  out->device_buffers = ((RcclCtx*)out->ctx)->fuse ? 3 : 1;
   out->exchange = rccl_exchange;
   out->allreduce = rccl_allreduce;
   out->destroy = rccl_destroy;

@@ -1645,11 +1645,30 @@ private:
   {
     if (!scatter_wanted<S>(ws2))
       return false;
-    be_.template launch_force_scatter<S>(kSlotForce, num_bricks_, N_, ws2, md_, halo_, fmap_, fold_rows_, step_outputs_, frozen);
+    if (assembly_part_ == 1 && b_.level && num_boundary_bricks_ > 0 && num_boundary_bricks_ < num_bricks_) {
+      // a decomposed run with reverse-mode ghosts: the bricks whose window holds a ghost first, then the ghosts' fold -- their
+      // partial forces can travel while force_assembly_rest() runs the interior bricks and the owned atoms' fold
+      be_.template launch_force_scatter<S>(kSlotForce, num_boundary_bricks_, (int)(num_bricks_ - num_boundary_bricks_), N_, ws2, md_,
+                                           halo_, fmap_, fold_rows_, step_outputs_, 0, 1, frozen);
+      assembly_pending_ = true;
+      pending_outputs_ = step_outputs_;
+    } else {
+      be_.template launch_force_scatter<S>(kSlotForce, num_bricks_, -1, N_, ws2, md_, halo_, fmap_, fold_rows_, step_outputs_, 0, 2,
+                                           frozen);
+    }
     if (!step_outputs_)
       outputs_stale_ = true;
     last_scatter_form_ = true;
     return true;
+  }
+  template <class S>
+  void assembly_rest_shape(const int* frozen)
+  {
+    WinLayout lay2 = win_;
+    lay2.compact = 1;
+    const WinStage ws2{box_, b_, lay2};
+    be_.template launch_force_scatter<S>(kSlotForce, num_bricks_ - num_boundary_bricks_, 0, N_, ws2, md_, halo_, fmap_, fold_rows_,
+                                         pending_outputs_, 2, 2, frozen);
   }
 
 public:
@@ -1657,6 +1676,27 @@ public:
   // per-atom virials are the reference's); 0: gather everywhere; 1: scatter everywhere it applies (per-call evaluations
   // then add one virial-only pass of the gather form)
   void set_force_form(int mode) { force_form_ = mode < 0 ? -1 : (mode > 1 ? 1 : mode); }
+  // Decomposed runs with reverse-mode ghosts: 1 = the NEXT force evaluation stops after the boundary bricks' force assembly and
+  // the ghosts' fold (scatter form; else it runs whole as always); assembly_pending() then says that force_assembly_rest() has
+  // the interior bricks and the owned atoms' fold still to do.  Asked for evaluation by evaluation, like set_step_outputs.
+  void set_assembly_part(int part) { assembly_part_ = part; }
+  bool assembly_pending() const { return assembly_pending_; }
+  void force_assembly_rest(const int* frozen)
+  {
+    if (!assembly_pending_)
+      return;
+    assembly_pending_ = false;
+    be_.frozen = frozen;
+    switch (shape_) {
+      case 1: assembly_rest_shape<S_PbTeA>(frozen); break;
+      case 2: assembly_rest_shape<S_PbTeB>(frozen); break;
+      case 3: assembly_rest_shape<S_C2022>(frozen); break;
+      case 4: assembly_rest_shape<S_UNEP>(frozen); break;
+      case 5: assembly_rest_shape<S_BZO>(frozen); break;
+      default: assembly_rest_shape<ShapeGeneric>(frozen); break;
+    }
+    be_.frozen = nullptr;
+  }
   // the callers whose steps need forces, energies and the TOTAL virial only (run loops; the decomposed driver)
   void set_loop_context(bool on) { loop_ctx_ = on; }
   // Run loops: does the NEXT force evaluation have to leave per-atom energies and virials (a thermo record, a thermostat that
@@ -1781,6 +1821,7 @@ public:
     force_kernels_dispatch(phase, frozen);
     be_.frozen = nullptr;
     step_outputs_ = true; // (set_step_outputs: asked for evaluation by evaluation)
+    assembly_part_ = 0;
   }
   // kPhaseBoundaryRadial on another stream of the same device (a backend from B::make_side_stream)
   void force_kernels_on(B& side, int phase, const int* frozen)
@@ -1834,6 +1875,8 @@ private:
   bool loop_ctx_ = false;        // set_loop_context
   bool virial_local_ = false;    // the virial planes of the last force evaluation hold the own-half form (exact_virials)
   bool step_outputs_ = true;     // set_step_outputs
+  int assembly_part_ = 0;        // set_assembly_part
+  bool assembly_pending_ = false, pending_outputs_ = true;
   bool outputs_stale_ = false;   // the last force evaluation left the energy / virial planes as they were
   bool scatter_disabled_ = false; // a pair half left the fixed-point guard band of the scatter form: gather form from then on
   int* halo_ = nullptr;          // [bricks][wmax][4] window sums of the scatter form (fixed point)

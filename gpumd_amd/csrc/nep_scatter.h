@@ -72,7 +72,9 @@ struct ForceScatterBody {
   WinStage st; // lay.compact == 1 (static window layout)
   ModelD m;
   const int* frozen;
-  I4* halo; // [brick][wmax] {fx, fy, fz, 0} in fixed point
+  I4* halo;  // [brick][wmax] {fx, fy, fz, 0} in fixed point
+  int first; // workgroup w runs brick brick_order[first + w] (first < 0: brick w): the boundary bricks of a decomposed run first,
+             // so that the ghosts' partial forces can travel while the interior bricks run (DistT, reverse-mode ghosts)
 };
 
 __device__ __forceinline__ void lds_add(NEPMI_LDS(int)* p, int v)
@@ -391,9 +393,10 @@ nepmi_force_scatter_kernel(const ForceScatterBody<S> body, const int64_t nbricks
   if (body.frozen && *body.frozen != 0)
     return;
   const unsigned per_xcd = gridDim.x >> 3;
-  const int64_t brick = (int64_t)(blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
-  if (brick >= nbricks)
+  const int64_t wgi = (int64_t)(blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+  if (wgi >= nbricks)
     return;
+  const int64_t brick = body.first < 0 ? wgi : (int64_t)body.st.b.brick_order[body.first + wgi];
   const int tid = (int)threadIdx.x;
   const ScatterLayout lay{body.st.lay.wmax};
   const Bufs& b = body.st.b;
@@ -679,9 +682,10 @@ __global__ void __launch_bounds__(kWinThreads * L) nepmi_force_scatter_mt_kernel
   if (body.frozen && *body.frozen != 0)
     return;
   const unsigned per_xcd = gridDim.x >> 3;
-  const int64_t brick = (int64_t)(blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
-  if (brick >= nbricks)
+  const int64_t wgi = (int64_t)(blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+  if (wgi >= nbricks)
     return;
+  const int64_t brick = body.first < 0 ? wgi : (int64_t)body.st.b.brick_order[body.first + wgi];
   const int tid = (int)threadIdx.x;
   const Bufs& b = body.st.b;
   const ModelD& m = body.m;
@@ -814,10 +818,11 @@ struct ForceFoldBody {
   int wmax, rows;
   const unsigned* fmap;
   const I4* halo;
+  int lv_lo, lv_hi; // only atoms with level in [lv_lo, lv_hi] (the ghosts first when their forces travel during the interior bricks)
   __device__ void operator()(int64_t k) const
   {
     const int lv = b.lvl[k];
-    if (lv < b.lvl_force)
+    if (lv < b.lvl_force || lv < lv_lo || lv > lv_hi)
       return;
     const int64_t N = b.N;
     int s0 = 0, s1 = 0, s2 = 0; // (modular: the net of a window is what has to fit)

@@ -129,7 +129,12 @@ class DistMD:
     def set_overlap(self, on=True):
         self._ck(self.lib.nepmi_dist_set_overlap(self.handle, 1 if on else 0))
 
+    def num_overlapped_reverse(self):
+        """steps whose interior force assembly ran while the ghosts' partial forces travelled (reverse ghosts + overlap)"""
+        return int(self.lib.nepmi_dist_num_overlapped_reverse(self.handle))
+
     def info(self):
+        assert self.lib.nepmi_dist_info_bytes() == C.sizeof(_capi.NepmiDistInfo)
         out = _capi.NepmiDistInfo()
         self._ck(self.lib.nepmi_dist_get_info(self.handle, C.byref(out)))
         return out

@@ -270,11 +270,15 @@ typedef struct {
   /* all sends and receives of one call may progress concurrently (ncclGroupStart/End semantics); several messages
      to / from the same peer match in order */
   int (*exchange)(void* ctx, int nsend, const nepmi_msg* sends, int nrecv, const nepmi_msg* recvs, void* stream);
-  /* in place; dtype 0 = f64, 1 = i32, 2 = i64; op 0 = sum, 1 = max; every rank must end with identical bits */
+  /* in place; dtype 0 = f64, 1 = i32, 2 = i64; op 0 = sum, 1 = max; every rank must end with identical bits.
+     A transport that sets bit 1 of device_buffers (value 3) accepts dtype | NEPMI_DT_DEFER: the result is first read by work
+     enqueued AFTER the next exchange() call on the same stream, so the reduction may be posted inside that call's group --
+     the skin vote of a step then costs no collective of its own (nepmi_transport_rccl with NEPMI_RCCL_FUSE_VOTE=1). */
   int (*allreduce)(void* ctx, void* buf, int64_t count, int dtype, int op, void* stream);
   void (*destroy)(void* ctx);
 } nepmi_transport;
 
+#define NEPMI_DT_DEFER 0x100
 #define NEPMI_RCCL_ID_BYTES 128
 /* RCCL: rank 0 creates the id (ncclGetUniqueId) and hands it to the others by any means (a file, MPI, torch's
  * store); then every rank builds its communicator (ncclCommInitRank) on the current HIP device. */
@@ -315,7 +319,12 @@ int nepmi_dist_lan_seed(nepmi_dist* d, int seed);
  * exchange-then-compute order.  Both orders give bit-identical results.  Two launches of the radial pass have two ramps and two
  * tails of one brick's latency each (~50 us): measured in process, ranks sharing one GPU, the split costs 6 % of a 1 M-atom step
  * per rank (profiles/r3u_*: 2 ranks weak +10.7 % off / +16.8 % on; 8 ranks strong 2.2 / 2.4) -- more than the exchange it hides
- * is expected to take on xGMI; turn it on where the exchange is slow (host transports over a network). */
+ * is expected to take on xGMI; turn it on where the exchange is slow (host transports over a network).
+ * With reverse-mode ghosts the same switch also splits the force assembly (scatter form): the bricks whose window holds a ghost
+ * and the ghosts' fold first, then the ghosts' partial forces travel on the communication stream while the interior bricks and
+ * the owned atoms' fold run; bit-identical to the plain order.  Default off -- a rule, not a measurement of this hardware: the
+ * only multi-rank device runs so far share ONE GPU, where a second launch per kernel costs more than the exchange it hides;
+ * `bench.py --overlap 1` turns both splits on for an A/B on a node with one GPU per rank. */
 int nepmi_dist_set_overlap(nepmi_dist* d, int on);
 /* What the ghost atoms are for; call between nepmi_dist_create and nepmi_dist_setup (the shell width shapes the local box).
  *   0 forward: shell 2 (rc + skin), the reference's ranges (src/force/nep_multigpu.cuh:42-50) -- descriptors of the inner ring
@@ -336,6 +345,12 @@ typedef struct {
   int64_t reverse_ghosts; /* 1: reverse-mode ghosts (nepmi_dist_set_ghost_mode), 0: forward */
 } nepmi_dist_info;
 int nepmi_dist_get_info(nepmi_dist* d, nepmi_dist_info* out);
+/* sizeof(nepmi_dist_info) of the library: a caller compiled against an older header (a shorter struct) can tell before
+ * nepmi_dist_get_info writes past its buffer; counters added after round 3 have getters of their own instead of new fields. */
+int nepmi_dist_info_bytes(void);
+/* steps whose interior bricks' force assembly ran while the ghosts' partial forces travelled (reverse-mode ghosts with
+ * nepmi_dist_set_overlap(1)): the boundary bricks and the ghosts' fold first, the reverse exchange on the communication stream */
+int64_t nepmi_dist_num_overlapped_reverse(nepmi_dist* d);
 /* The owned atoms of this rank (n_owned entries per plane, global coordinates) into the caller's DEVICE arrays;
  * any pointer may be NULL.  With reverse-mode ghosts (nepmi_dist_set_ghost_mode) a non-NULL `virial` makes the call
  * collective -- every rank has to ask for the virials in the same call, the halves computed on other ranks' ghosts come

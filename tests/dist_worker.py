@@ -82,7 +82,8 @@ def run_rank(out_dir, spec, rank, world, make_transport, stream=None):
     th2 = md.thermo()
     info = md.info()
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), i0=i0, f0=f0, th0=th0, i1=i1, x1=x1, v1=v1, f1=f1, th1=th1, th=th, w1=w1, th2=th2,
-             n_loc=info.n_local, n_own=info.n_owned, reverse=info.reverse_ghosts, ndec=info.num_decompositions, nover=info.num_overlapped)
+             n_loc=info.n_local, n_own=info.n_owned, reverse=info.reverse_ghosts, ndec=info.num_decompositions, nover=info.num_overlapped,
+             nrev=md.num_overlapped_reverse())
     md.close()
     tr.close()
 

@@ -291,6 +291,25 @@ def test_rccl_transport_on_one_rank():
     torch.cuda.synchronize()
     assert d.tolist() == [1.5, -2.0] and i.tolist() == [3, 7, -1] and l.tolist() == [1 << 40]
 
+    # the skin vote posted inside the group of the next exchange (NEPMI_DT_DEFER; nepmi_transport_rccl with NEPMI_RCCL_FUSE_VOTE=1):
+    # a collective and point-to-point operations in one ncclGroup -- what one rank can show is that the call sequence completes
+    os.environ["NEPMI_RCCL_FUSE_VOTE"] = "1"
+    try:
+        tr2 = Transport.rccl(lib, 0, 1, lambda ident: ident)
+    finally:
+        del os.environ["NEPMI_RCCL_FUSE_VOTE"]
+    t2 = tr2.struct
+    assert t2.device_buffers == 3
+    i2 = torch.tensor([5, -3], dtype=torch.int32, device=dev)
+    b.zero_()
+    assert t2.allreduce(t2.ctx, i2.data_ptr(), 2, 1 | 0x100, 1, stream) == 0   # deferred
+    assert t2.exchange(t2.ctx, 2, sends, 2, recvs, stream) == 0                 # ... into this group
+    assert t2.allreduce(t2.ctx, i2.data_ptr(), 2, 1 | 0x100, 1, stream) == 0   # deferred again
+    assert t2.allreduce(t2.ctx, d.data_ptr(), 2, 0, 0, stream) == 0            # an ordinary one flushes it first
+    torch.cuda.synchronize()
+    assert torch.equal(a, b) and i2.tolist() == [5, -3] and d.tolist() == [1.5, -2.0]
+    tr2.close()
+
     # a run of the decomposed driver over this transport == the plain fused loop
     drv = H.GpuDriver()
     nep = H.golden("PbTe", "nep.txt")

@@ -99,6 +99,8 @@ def _check(device, world, model, reps, grid, ensemble, nsteps, temp, overlap=Non
         assert max(int(r["ndec"]) for r in multi) >= 2
     if overlap:
         assert all(int(r["nover"]) > 0 for r in multi)
+        # (these systems are too small for the one-lane window kernels, hence for the scatter form and its split force assembly:
+        # test_reverse_exchange_overlapped_with_the_interior_bricks_on_gpu below)
     if ghosts is not None:
         assert all(int(r["reverse"]) == ghosts for r in multi)
 
@@ -133,6 +135,26 @@ def test_device_transport_with_several_ranks_on_emulator(world, model, reps, gri
 @pytest.mark.parametrize("world,model,reps,grid,ensemble,nsteps,temp", CASES)
 def test_device_transport_with_several_ranks_on_gpu(world, model, reps, grid, ensemble, nsteps, temp):
     _check("gpu", world, model, reps, grid, ensemble, nsteps, temp)
+
+
+@pytest.mark.gpu
+def test_reverse_exchange_overlapped_with_the_interior_bricks_on_gpu():
+    """Reverse-mode ghosts + nepmi_dist_set_overlap(1) on a system large enough for the scatter form of the force assembly
+    (192,000 atoms on two ranks): the bricks whose window holds a ghost and the ghosts' fold first, the ghosts' partial forces
+    on the communication stream while the interior bricks run -- bit-identical to the plain order (the same integer window
+    sums, the returned parts added in the same order), and the split path is really taken."""
+    if not os.path.exists(LIB["gpu"]):
+        pytest.skip("tests/inproc transports not built")
+    import test_dist as T
+    spec = T._spec("gpu", "PbTe-reps", (12, 8, 8), (2, 1, 1), "nve", 12, 1500.0, ghosts=1)
+    a = _run_threads(2, dict(spec, overlap=True))
+    b = _run_threads(2, dict(spec, overlap=False))
+    assert all(int(r["nrev"]) >= 6 for r in a) and all(int(r["nrev"]) == 0 for r in b)
+    assert all(int(r["reverse"]) == 1 for r in a)
+    for ra, rb in zip(a, b):
+        assert np.array_equal(ra["i1"], rb["i1"])
+        assert np.array_equal(ra["x1"], rb["x1"]) and np.array_equal(ra["v1"], rb["v1"]) and np.array_equal(ra["f1"], rb["f1"])
+        np.testing.assert_allclose(ra["th1"], rb["th1"], rtol=0, atol=0)
 
 
 def test_a_capacity_error_of_one_rank_ends_the_run_on_every_rank():
