@@ -485,6 +485,14 @@ int nepmi_engine_set_force_form(nepmi_engine* e, int mode)
   return NEPMI_OK;
 }
 
+int nepmi_engine_set_radial_mask(nepmi_engine* e, int on)
+{
+  if (!e)
+    return fail(NEPMI_ERR_ARG, "null engine");
+  e->e->set_radial_mask(on != 0);
+  return NEPMI_OK;
+}
+
 int nepmi_engine_set_stepwise_loops(nepmi_engine* e, int on)
 {
   if (!e)

@@ -1191,7 +1191,7 @@ struct HipBackend {
   // [fold_lo, fold_hi] (fold_lo > fold_hi: no fold)
   template <class S>
   void launch_force_scatter(int slot, int64_t nb, int first, int64_t natoms, const WinStage& ws2, const ModelD& md, int* halo,
-                            const unsigned* fmap, int fold_rows, bool outputs, int fold_lo, int fold_hi, const int* frz)
+                            const unsigned* fmap, int fold_rows, bool outputs, bool mask, int fold_lo, int fold_hi, const int* frz)
   {
     const ForceScatterBody<S> body{ws2, md, frz, reinterpret_cast<I4*>(halo), first};
     const int64_t grid = (nb + 7) / 8 * 8;
@@ -1202,17 +1202,23 @@ struct HipBackend {
       if constexpr (S::TS > 0) {
         const ScatterLayout lay{ws2.lay.wmax};
         const size_t lds_bytes = ((size_t)lay.bytes() + 15) / 16 * 16;
-        if (outputs) {
-          if (lds_bytes > 64 * 1024)
-            NEPMI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&nepmi_force_scatter_kernel<S, true>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-          hipLaunchKernelGGL((nepmi_force_scatter_kernel<S, true>), dim3((unsigned)grid), dim3(kWinThreads), lds_bytes, stream, body, nb);
-        } else {
-          if (lds_bytes > 64 * 1024)
-            NEPMI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&nepmi_force_scatter_kernel<S, false>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-          hipLaunchKernelGGL((nepmi_force_scatter_kernel<S, false>), dim3((unsigned)grid), dim3(kWinThreads), lds_bytes, stream, body, nb);
-        }
+#define NEPMI_FS_LAUNCH(OUTV, MASKV)                                                                                             \
+  do {                                                                                                                           \
+    if (lds_bytes > 64 * 1024)                                                                                                   \
+      NEPMI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&nepmi_force_scatter_kernel<S, OUTV, MASKV>),           \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));                         \
+    hipLaunchKernelGGL((nepmi_force_scatter_kernel<S, OUTV, MASKV>), dim3((unsigned)grid), dim3(kWinThreads), lds_bytes, stream, \
+                       body, nb);                                                                                               \
+  } while (0)
+        if (outputs && mask)
+          NEPMI_FS_LAUNCH(true, true);
+        else if (outputs)
+          NEPMI_FS_LAUNCH(true, false);
+        else if (mask)
+          NEPMI_FS_LAUNCH(false, true);
+        else
+          NEPMI_FS_LAUNCH(false, false);
+#undef NEPMI_FS_LAUNCH
       } else {
         // many types / run-time shapes: nepmi_force_scatter_mt_kernel, four lanes per atom, one workgroup per CU
 #ifndef NEPMI_FS_MT_LANES

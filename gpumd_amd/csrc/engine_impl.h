@@ -133,7 +133,7 @@ public:
   // enqueued on the communication stream right behind the ghost unpack (force_kernels_on) and run beside the tail of the
   // interior launch instead of after it
   enum Phase { kPhaseAll = 0, kPhaseInterior = 1, kPhaseBoundary = 2, kPhaseRecords = 3, kPhaseBoundaryRadial = 4,
-               kPhaseAfterRadial = 5 };
+               kPhaseAfterRadial = 5, kPhaseRadialOnly = 6 };
 
   // Potential::compute (adds to pe/force/virial; positions already wrapped)
   void potential_compute(
@@ -972,6 +972,13 @@ private:
       // scatter-form force assembly (nep_scatter.h; device backends only)
       b_.aslot = B::kHasScatter ? dalloc<unsigned short>((size_t)b_.MN_acomp * N) : nullptr;
       b_.compact_all = b_.aslot ? 1 : 0;
+      // mask form of the per-step radial list (Bufs::rmaskA / rmaskB / tmaskA)
+      b_.MAW = (4 * ((b_.MN_ang + 3) / 4) + 31) / 32 + 1;
+      b_.MBW = (8 * ((b_.MN_skin + 3) / 4) + 31) / 32 + 1;
+      b_.rmaskA = B::kHasScatter ? dalloc<unsigned>((size_t)b_.MAW * N) : nullptr;
+      b_.rmaskB = B::kHasScatter ? dalloc<unsigned>((size_t)b_.MBW * N) : nullptr;
+      b_.tmaskA = B::kHasScatter ? dalloc<unsigned>((size_t)b_.MAW * N) : nullptr;
+      b_.use_rmask = 0;
     } else { // Tersoff-1989: Tersoff1989::Tersoff1989 allocations (tersoff1989.cu:141-149)
       tb_.rec = dalloc<D4>((size_t)b_.MN_ang * N);
       tb_.bb = dalloc<double>((size_t)b_.MN_ang * N);
@@ -1487,6 +1494,7 @@ public:
     use_win2_ = o.use_win2_;
     external_skin_ = o.external_skin_;
     force_form_ = o.force_form_;
+    use_rmask_ = o.use_rmask_;
     loop_ctx_ = o.loop_ctx_;
     scatter_disabled_ = o.scatter_disabled_;
     if (reverse_ghosts_ != o.reverse_ghosts_)
@@ -1526,6 +1534,9 @@ public:
   int shape_id() const { return shape_; }
 
 private:
+#ifndef NEPMI_RMASK
+#define NEPMI_RMASK 1 // A/B switch (profiles/ab_variants.sh): 0 = the compact list on every step
+#endif
   template <class S>
   void force_kernels_shape(int phase, const int* frozen)
   {
@@ -1544,6 +1555,18 @@ private:
     const bool win2 = win2_ok_ && lanes == 1;
     last_rows_form_ = false;
     last_fpj_form_ = false;
+    // Mask form of the per-step radial list: the run loops' scatter-form steps of shapes with type-pure streams.  Decided
+    // before the radial pass (which writes either the masks or the compact list); a per-call evaluation in the forced scatter
+    // form keeps the compact list (its virial-only pass of the gather form follows at once).
+    if (phase != kPhaseRadialOnly) {
+      WinLayout layq = win_;
+      layq.compact = 1;
+      const WinStage wsq{box_, b_, layq};
+      b_.use_rmask = (NEPMI_RMASK && use_rmask_ && S::TS > 0 && win2 && b_.rmaskB && loop_ctx_ && scatter_wanted<S>(wsq)) ? 1 : 0;
+      last_mask_form_ = b_.use_rmask != 0;
+    } else {
+      b_.use_rmask = 0; // (before the kernel bodies below copy Bufs)
+    }
     WinLayout lay2 = win_;
     lay2.compact = 1;
     const WinStage ws2{box_, b_, lay2};
@@ -1558,6 +1581,13 @@ private:
       else
         rbe.launch_win(kSlotRadial, nb, RadialWinBody<S>{ws, md_, first, frozen});
     };
+    if (phase == kPhaseRadialOnly) { // exact_virials: the compact list of the current positions (the masks were written instead)
+      b_.use_rmask = 0;
+      if (tile_ok_)
+        radial(num_bricks_, -1);
+      ccode_valid_ = true;
+      return;
+    }
     if (phase == kPhaseInterior) { // radial pass of the bricks whose window holds no ghost
       radial(num_bricks_ - num_boundary_bricks_, 0);
       return;
@@ -1576,6 +1606,7 @@ private:
       radial(num_bricks_, -1);
     else
       be_.template launch<64>(kSlotRadial, N_, RadialDescBody<S>{box_, md_, b_, 1});
+    ccode_valid_ = b_.use_rmask == 0;
     b_.skip_atab = (win2 && fpj_wanted<S>(ws2)) ? 1 : 0; // the FPJ force assembly needs no radial table from the ANN kernel
     if (fuse_ann_active()) {
       launch_angular_desc<S>(true);
@@ -1634,7 +1665,7 @@ private:
     if (force_form_ < 0 && !loop_ctx_)
       return false;
     if (S::TS > 0)
-      return 24 * (size_t)win_.wmax <= B::kMaxLdsBytes;
+      return 24 * (size_t)(win_.wmax + 4) <= B::kMaxLdsBytes;
     // many types / run-time shapes: the own half from the atom's radial Fp row and the coefficient table in LDS -- where the
     // FPJ gather form applies (it supplies the virial-only pass; neither needs the per-atom radial table from the ANN kernel)
     return fpj_wanted<S>(ws2) &&
@@ -1649,12 +1680,12 @@ private:
       // a decomposed run with reverse-mode ghosts: the bricks whose window holds a ghost first, then the ghosts' fold -- their
       // partial forces can travel while force_assembly_rest() runs the interior bricks and the owned atoms' fold
       be_.template launch_force_scatter<S>(kSlotForce, num_boundary_bricks_, (int)(num_bricks_ - num_boundary_bricks_), N_, ws2, md_,
-                                           halo_, fmap_, fold_rows_, step_outputs_, 0, 1, frozen);
+                                           halo_, fmap_, fold_rows_, step_outputs_, b_.use_rmask != 0, 0, 1, frozen);
       assembly_pending_ = true;
       pending_outputs_ = step_outputs_;
     } else {
-      be_.template launch_force_scatter<S>(kSlotForce, num_bricks_, -1, N_, ws2, md_, halo_, fmap_, fold_rows_, step_outputs_, 0, 2,
-                                           frozen);
+      be_.template launch_force_scatter<S>(kSlotForce, num_bricks_, -1, N_, ws2, md_, halo_, fmap_, fold_rows_, step_outputs_,
+                                           b_.use_rmask != 0, 0, 2, frozen);
     }
     if (!step_outputs_)
       outputs_stale_ = true;
@@ -1668,7 +1699,7 @@ private:
     lay2.compact = 1;
     const WinStage ws2{box_, b_, lay2};
     be_.template launch_force_scatter<S>(kSlotForce, num_bricks_ - num_boundary_bricks_, 0, N_, ws2, md_, halo_, fmap_, fold_rows_,
-                                         pending_outputs_, 2, 2, frozen);
+                                         pending_outputs_, b_.use_rmask != 0, 2, 2, frozen);
   }
 
 public:
@@ -1697,6 +1728,9 @@ public:
     }
     be_.frozen = nullptr;
   }
+  // 1 (default): scatter-form steps of the run loops keep the per-step radial list as inside bits over the packed Verlet words
+  // (Bufs::rmaskB) instead of compacting it; 0: the compact list on every step.  Identical results, bit for bit.
+  void set_radial_mask(bool on) { use_rmask_ = on; }
   // the callers whose steps need forces, energies and the TOTAL virial only (run loops; the decomposed driver)
   void set_loop_context(bool on) { loop_ctx_ = on; }
   // Run loops: does the NEXT force evaluation have to leave per-atom energies and virials (a thermo record, a thermostat that
@@ -1731,6 +1765,8 @@ private:
     lay2.compact = 1;
     const WinStage ws2{box_, b_, lay2};
     const int lanes = win_lanes();
+    if (!ccode_valid_) // the last radial pass wrote the masks: the compact list the gather form walks, on the same positions
+      force_kernels_shape<S>(kPhaseRadialOnly, nullptr);
     gather_assembly<S>(ws, ws2, lanes, win2_ok_ && lanes == 1, nullptr, 1);
   }
 
@@ -1808,6 +1844,7 @@ public:
       s += " ann=per_atom";
     s += (shape_ != 0 && model_.n_max_angular + 1 >= 7) ? " angular_force=lane_pairs" : " angular_force=one_lane";
     s += recompute_s() ? " angular_sums=recomputed" : " angular_sums=stored";
+    s += (last_scatter_form_ && last_mask_form_) ? " radial_list=inside_bits_over_the_verlet_words" : " radial_list=compacted";
     s += last_scatter_form_ ? " force_assembly=lds_scatter_of_own_halves(fixed_point)+fold" :
          last_rows_form_ ? " force_assembly=table_rows_in_lds"
                          : (last_fpj_form_ ? " force_assembly=neighbour_half_from_fp_rows" : " force_assembly=table_rows_gathered");
@@ -1874,6 +1911,9 @@ private:
   int force_form_ = -1;          // set_force_form
   bool loop_ctx_ = false;        // set_loop_context
   bool virial_local_ = false;    // the virial planes of the last force evaluation hold the own-half form (exact_virials)
+  bool use_rmask_ = true;        // set_radial_mask
+  bool last_mask_form_ = false;
+  bool ccode_valid_ = true;      // the compact radial list of the last force evaluation exists (else: the masks, Bufs::rmaskB)
   bool step_outputs_ = true;     // set_step_outputs
   int assembly_part_ = 0;        // set_assembly_part
   bool assembly_pending_ = false, pending_outputs_ = true;

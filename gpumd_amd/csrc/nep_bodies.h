@@ -191,6 +191,19 @@ struct Bufs {
   // scatter-form force assembly (nep_scatter.h, device only): LDS window slot of the partner of every compact angular slot,
   // written by the static-layout radial pass next to aidx; nullptr on backends without that form
   unsigned short* aslot; // [MN_acomp][N]
+  // Mask form of the per-step radial list (scatter-form steps of the run loops, shapes with type-pure streams): instead of
+  // compacting the pairs inside the cutoff into ccode -- one scattered 2-byte store per pair, a third of the radial pass's
+  // time (profiles/r4m_ab_radial_stores.txt) -- the radial pass sets one bit per candidate of the packed Verlet words
+  // (Bufs::wcode) and the force assembly walks those words with the bits as weights.
+  //   rmaskA[w >> 3][k] bit 4 (w & 7) + u : candidate u of list-A word w is inside the radial cutoff
+  //   rmaskB[...]                          : two-type shapes: word pair p, bit 8 (p & 3) + 4 t + u of word p >> 2 (t: type stream);
+  //                                          one type: word w of list B, bit 4 (w & 7) + u of word w >> 3
+  //   tmaskA (written at the rebuild)      : two-type shapes: bit s = entry s of list A is of type 1
+  unsigned* rmaskA;
+  unsigned* rmaskB;
+  unsigned* tmaskA;
+  int MAW, MBW;  // words per atom of rmaskA / tmaskA and of rmaskB
+  int use_rmask; // 1: this step's radial pass writes the masks instead of ccode
   int compact_all;       // 1: every atom with level >= 1 writes its compact radial list (the scatter form walks the lists of the
                          // atoms that have descriptors, the gather form those of the atoms that receive forces)
 };
@@ -978,6 +991,14 @@ struct PackCodesBody {
       put(slot_of(b.code_ang[(int64_t)s * N + k]));
     flush();
     const int wa = word;
+    if (b.tmaskA && parts == 2) { // the types of list A's entries (they do not change between rebuilds)
+      for (int w = 0; w < b.MAW; ++w) {
+        unsigned bits = 0u;
+        for (int s = 32 * w; s < na && s < 32 * w + 32; ++s)
+          bits |= (b.posq[b.nl_ang[(int64_t)s * N + k]].type != 0 ? 1u : 0u) << (s & 31);
+        b.tmaskA[(int64_t)w * N + k] = bits;
+      }
+    }
     int wb = 0;
     if (parts == 2) {
       // two type-pure streams, word by word side by side: row wa + 2p = four neighbours of type 0, row wa + 2p + 1 = four of

@@ -59,12 +59,13 @@ struct I3 { // position of a window atom, fixed point, relative to the window ce
   int x, y, z;
 };
 struct ScatterLayout {
-  int wmax; // a multiple of 64; slot wmax = the sentinel of the other window kernels (never addressed here)
+  int wmax; // a multiple of 64; row wmax = the sentinel slot the padded list words point at (far beyond every cutoff)
   // positions and accumulators as 12-byte rows [slot]{x, y, z}: one address (12 slot) serves the three words of either
   // (immediate offsets 0, 4, 8); 3 is coprime with the number of banks, so random slots spread over all of them
+  __device__ __host__ int rows() const { return wmax + 4; } // (a multiple of four rows: 16-byte aligned planes)
   __device__ __host__ int off_pos() const { return 0; }
-  __device__ __host__ int off_acc() const { return 12 * wmax; }
-  __device__ __host__ int bytes() const { return 24 * wmax; }
+  __device__ __host__ int off_acc() const { return 12 * rows(); }
+  __device__ __host__ int bytes() const { return 24 * rows(); }
 };
 
 template <class S>
@@ -104,7 +105,7 @@ __device__ __forceinline__ int to_fixed(float v)
 // step of a run loop, a per-call evaluation; the other steps of a run loop need forces only (the reference computes and
 // stores all thirteen per-atom outputs every step, potential.cu:170-297; find_thermo reads them at the dump_thermo interval
 // only): no virial arithmetic, no pair-vector loads in the angular part, no 80 bytes of stores per atom.
-template <class S, bool OUT>
+template <class S, bool OUT, bool MASK>
 __device__ __forceinline__ void force_scatter_atom(const ForceScatterBody<S>& B, const int64_t brick, const int64_t k,
                                                    NEPMI_LDS(char)* lds, const ScatterLayout lay)
 {
@@ -169,124 +170,224 @@ __device__ __forceinline__ void force_scatter_atom(const ForceScatterBody<S>& B,
       sl_first[u] = aslot[(int64_t)u * N];
     }
   }
-  // type-pure segments of the compact list (front: neighbours of type 0, back: of type 1): the own row of the segment's
-  // type stays in registers, the pair cutoff is a constant of the segment
-  const int n0 = b.nn_t0[k] < nrad ? b.nn_t0[k] : nrad;
+  // Own half of a pair: s12 = sum_k A_k f_k'(r) with f_k' = (k U_{k-1}(x)) dx/dr fc/2 + (T_k(x) + 1) fc'/2
+  // (find_fn_and_fnp, nep_utilities.cuh:590-623), contracted as  fc'/2 (SA + sum_k A_k T_k) + (dx/dr fc/2) sum_k (k A_k) U_{k-1}:
+  // the Chebyshev recurrences feed two running sums instead of seven separate basis derivatives.  The own rows of BOTH
+  // neighbour types stay in registers as f2 pairs (two pairs are evaluated side by side).
+  f2 A2[TSM][K + 1], B2[TSM][K + 1], SA2[TSM];
+  float rcp_t[TSM], rip_t[TSM];
 #pragma unroll
   for (int t = 0; t < TSM; ++t) {
-    // Own half of a pair: s12 = sum_k A_k f_k'(r) with f_k' = (k U_{k-1}(x)) dx/dr fc/2 + (T_k(x) + 1) fc'/2
-    // (find_fn_and_fnp, nep_utilities.cuh:590-623), contracted as  fc'/2 (SA + sum_k A_k T_k) + (dx/dr fc/2) sum_k (k A_k) U_{k-1}:
-    // the Chebyshev recurrences feed two running sums instead of seven separate basis derivatives.
-    float A[K + 1], Bk[K + 1], SA = 0.0f;
+    float sa = 0.0f;
 #pragma unroll
     for (int kk = 0; kk <= K; ++kk) {
-      A[kk] = atab[t * KRP + kk];
-      Bk[kk] = (float)kk * A[kk];
-      SA += A[kk];
+      const float a = atab[t * KRP + kk];
+      A2[t][kk] = bc2(a);
+      B2[t][kk] = bc2((float)kk * a);
+      sa += a;
     }
-    const int count = t == 0 ? n0 : nrad - n0;
-    const float rcp = m.uniform_rc ? m.rc_r_max : (rc1 + m.rc_r[t]) * 0.5f;
-    const float rip = m.uniform_rc ? m.rcinv_r : fast_rcp(rcp);
-    const f2 rcinv = bc2(rip);
-    // the segment's entries: row r of ccode at r N; the front segment walks rows 0, 1, ..., the back one MN_rad-1, MN_rad-2, ...
-    const int64_t stride = t == 0 ? N : -N;
-    const unsigned short* __restrict__ q = b.ccode + k + (t == 0 ? (int64_t)0 : (int64_t)(b.MN_rad - 1) * N);
-    // two pairs side by side (packed FP32); w1 = 0: the second place repeats the first (odd end of the segment) and adds nothing
-    auto two_pairs = [&](const unsigned a0, const unsigned a1, const float w1) __attribute__((always_inline)) {
-      // two pairs side by side (packed FP32)
-      const unsigned o0 = row12(a0), o1 = row12(a1);
-      const I3 p0 = *(NEPMI_LDS(const I3)*)(wpos + o0), p1 = *(NEPMI_LDS(const I3)*)(wpos + o1);
-      const f2 fx = mk2((float)(p0.x - ox), (float)(p1.x - ox));
-      const f2 fy = mk2((float)(p0.y - oy), (float)(p1.y - oy));
-      const f2 fz = mk2((float)(p0.z - oz), (float)(p1.z - oz));
-      const f2 d2 = vfma(fz, fz, vfma(fy, fy, fx * fx)) * b.wg.unit2;
-      float d0, d1, i0, i1;
-      dist_and_inv(d2.x, d0, i0);
-      dist_and_inv(d2.y, d1, i1);
-      const f2 dc = mk2(d0 < rcp ? d0 : rcp, d1 < rcp ? d1 : rcp); // (a pair the exact test admitted can sit a rounding above rc)
-      f2 fc, fcp;
-      cutoff_fc_fcp_v(rcinv, dc, fc, fcp);
-      const f2 dr = dc * rcinv - 1.0f;
-      const f2 x = vfma(dr * 2.0f, dr, bc2(-1.0f));
-      const f2 x2 = x * 2.0f;
-      f2 tm2 = bc2(1.0f), tm1 = x;
-      f2 u0 = bc2(1.0f), u1 = x2; // U_0, U_1
-      f2 ST = vfma(x, bc2(A[1]), bc2(SA + A[0])); // SA + A_0 T_0 + A_1 T_1
-      f2 SU = bc2(Bk[1]);                          // B_1 U_0
+    SA2[t] = bc2(sa);
+    rcp_t[t] = m.uniform_rc ? m.rc_r_max : (rc1 + m.rc_r[t]) * 0.5f;
+    rip_t[t] = m.uniform_rc ? m.rcinv_r : fast_rcp(rcp_t[t]);
+  }
+  // two pairs side by side (packed FP32): LDS slots a0 / a1, weights w0 / w1 (0: the place adds nothing), own rows Ax / Bx / SAx
+  // and pair cutoffs rc2 / ri2 per half
+  auto two_pairs = [&](const unsigned a0, const unsigned a1, const float w0, const float w1, const f2* Ax, const f2* Bx, const f2 SAx,
+                       const f2 rc2, const f2 ri2) __attribute__((always_inline)) {
+    const unsigned o0 = row12(a0), o1 = row12(a1);
+    const I3 p0 = *(NEPMI_LDS(const I3)*)(wpos + o0), p1 = *(NEPMI_LDS(const I3)*)(wpos + o1);
+    const f2 fx = mk2((float)(p0.x - ox), (float)(p1.x - ox));
+    const f2 fy = mk2((float)(p0.y - oy), (float)(p1.y - oy));
+    const f2 fz = mk2((float)(p0.z - oz), (float)(p1.z - oz));
+    const f2 d2 = vfma(fz, fz, vfma(fy, fy, fx * fx)) * b.wg.unit2;
+    float d0, d1, i0, i1;
+    dist_and_inv(d2.x, d0, i0);
+    dist_and_inv(d2.y, d1, i1);
+    const f2 dc = mk2(d0 < rc2.x ? d0 : rc2.x, d1 < rc2.y ? d1 : rc2.y); // (a pair the exact test admitted can sit a rounding above rc)
+    f2 fc, fcp;
+    cutoff_fc_fcp_v(ri2, dc, fc, fcp);
+    const f2 dr = dc * ri2 - 1.0f;
+    const f2 x = vfma(dr * 2.0f, dr, bc2(-1.0f));
+    const f2 x2 = x * 2.0f;
+    f2 tm2 = bc2(1.0f), tm1 = x;
+    f2 u0 = bc2(1.0f), u1 = x2; // U_0, U_1
+    f2 ST = vfma(x, Ax[1], SAx + Ax[0]); // SA + A_0 T_0 + A_1 T_1
+    f2 SU = Bx[1];                       // B_1 U_0
 #pragma unroll
-      for (int kk = 2; kk <= K; ++kk) {
-        const f2 tk = vfma(x2, tm1, -tm2);
-        tm2 = tm1;
-        tm1 = tk;
-        ST = vfma(tk, bc2(A[kk]), ST);
-        SU = vfma(u1, bc2(Bk[kk]), SU); // k A_k U_{k-1}
-        if (kk < K) {
-          const f2 u2 = vfma(x2, u1, -u0);
-          u0 = u1;
-          u1 = u2;
-        }
+    for (int kk = 2; kk <= K; ++kk) {
+      const f2 tk = vfma(x2, tm1, -tm2);
+      tm2 = tm1;
+      tm1 = tk;
+      ST = vfma(tk, Ax[kk], ST);
+      SU = vfma(u1, Bx[kk], SU); // k A_k U_{k-1}
+      if (kk < K) {
+        const f2 u2 = vfma(x2, u1, -u0);
+        u0 = u1;
+        u1 = u2;
       }
-      const f2 s12 = vfma(dr * rcinv * 2.0f * fc, SU, fcp * 0.5f * ST); // (dx/dr fc / 2 = 2 dr fc / rc)
-      big = fmaxf(big, fmaxf(fabsf(s12.x), fabsf(s12.y)));
-      // own half of the pair force = g r12; here already in fixed-point units per grid unit of r12
-      const f2 g = s12 * mk2(i0 * qs, i1 * (qs * w1));
-      const f2 gx = g * fx, gy = g * fy, gz = g * fz;
-      if (OUT) {
-        W2[0] = vfma(-fx, gx, W2[0]);
-        W2[1] = vfma(-fy, gy, W2[1]);
-        W2[2] = vfma(-fz, gz, W2[2]);
-        W2[3] = vfma(-fx, gy, W2[3]);
-        W2[4] = vfma(-fx, gz, W2[4]);
-        W2[5] = vfma(-fy, gz, W2[5]);
-      }
-      const int ax = to_fixed(gx.x), ay = to_fixed(gy.x), az = to_fixed(gz.x);
-      const int bx = to_fixed(gx.y), by = to_fixed(gy.y), bz = to_fixed(gz.y);
-      Fi[0] += ax + bx;
-      Fi[1] += ay + by;
-      Fi[2] += az + bz;
-      NEPMI_LDS(int)* r0 = (NEPMI_LDS(int)*)(wacc + o0);
-      NEPMI_LDS(int)* r1 = (NEPMI_LDS(int)*)(wacc + o1);
-      if (NEPMI_FS_ABL == 1)
-        return;
-      lds_sub(r0, ax);
-      lds_sub(r0 + 1, ay);
-      lds_sub(r0 + 2, az);
-      lds_sub(r1, bx); // (the repeated entry of an odd end subtracts zero)
-      lds_sub(r1 + 1, by);
-      lds_sub(r1 + 2, bz);
-    };
-    // The list entries (2-byte coalesced loads: the only global latency of this loop) are requested two chunks ahead of the
-    // arithmetic, whole pairs unconditionally; the entry of an odd end is requested before the loop.
-    auto load2 = [&](const unsigned short* at, unsigned& c0, unsigned& c1) __attribute__((always_inline)) {
-      c0 = at[0];
-      c1 = at[stride];
-    };
-    const int npairs = count >> 1;
-    unsigned a0 = 0, a1 = 0, n0c = 0, n1c = 0, tail = 0;
-    if (npairs > 0)
-      load2(q, a0, a1);
-    if (npairs > 1)
-      load2(q + 2 * stride, n0c, n1c);
-    if (count & 1)
-      tail = q[(int64_t)(count - 1) * stride];
-    q += 4 * stride;
-    // unrolled by two: the entries of chunk p + 2 are requested into the registers chunk p has just released -- no register
-    // rotation, so nothing waits for a load before two chunks of arithmetic have passed
-    for (int pr2 = 0; pr2 < (NEPMI_FS_ABL == 2 ? 0 : npairs); pr2 += 2) {
-      const unsigned x0 = a0, x1 = a1;
-      if (pr2 + 2 < npairs)
-        load2(q, a0, a1);
-      two_pairs(x0, x1, 1.0f);
-      if (pr2 + 1 < npairs) {
-        const unsigned y0 = n0c, y1 = n1c;
-        if (pr2 + 3 < npairs)
-          load2(q + 2 * stride, n0c, n1c);
-        two_pairs(y0, y1, 1.0f);
-      }
-      q += 4 * stride;
     }
-    if (count & 1)
-      two_pairs(tail, tail, 0.0f);
+    const f2 s12 = vfma(dr * ri2 * 2.0f * fc, SU, fcp * 0.5f * ST); // (dx/dr fc / 2 = 2 dr fc / rc)
+    big = fmaxf(big, fmaxf(fabsf(s12.x) * w0, fabsf(s12.y) * w1));
+    // own half of the pair force = g r12; here already in fixed-point units per grid unit of r12
+    const f2 g = s12 * mk2(i0 * (qs * w0), i1 * (qs * w1));
+    const f2 gx = g * fx, gy = g * fy, gz = g * fz;
+    if (OUT) {
+      W2[0] = vfma(-fx, gx, W2[0]);
+      W2[1] = vfma(-fy, gy, W2[1]);
+      W2[2] = vfma(-fz, gz, W2[2]);
+      W2[3] = vfma(-fx, gy, W2[3]);
+      W2[4] = vfma(-fx, gz, W2[4]);
+      W2[5] = vfma(-fy, gz, W2[5]);
+    }
+    const int ax = to_fixed(gx.x), ay = to_fixed(gy.x), az = to_fixed(gz.x);
+    const int bx = to_fixed(gx.y), by = to_fixed(gy.y), bz = to_fixed(gz.y);
+    Fi[0] += ax + bx;
+    Fi[1] += ay + by;
+    Fi[2] += az + bz;
+    NEPMI_LDS(int)* r0 = (NEPMI_LDS(int)*)(wacc + o0);
+    NEPMI_LDS(int)* r1 = (NEPMI_LDS(int)*)(wacc + o1);
+    if (NEPMI_FS_ABL == 1)
+      return;
+    lds_sub(r0, ax);
+    lds_sub(r0 + 1, ay);
+    lds_sub(r0 + 2, az);
+    lds_sub(r1, bx); // (a place of weight zero subtracts zero)
+    lds_sub(r1 + 1, by);
+    lds_sub(r1 + 2, bz);
+  };
+
+  if constexpr (!MASK) {
+    // type-pure segments of the compact list (Bufs::ccode; front: neighbours of type 0, back: of type 1)
+    const int n0 = b.nn_t0[k] < nrad ? b.nn_t0[k] : nrad;
+#pragma unroll
+    for (int t = 0; t < TSM; ++t) {
+      const int count = t == 0 ? n0 : nrad - n0;
+      const f2 rc2 = bc2(rcp_t[t]), ri2 = bc2(rip_t[t]);
+      // the segment's entries: row r of ccode at r N; the front segment walks rows 0, 1, ..., the back one MN_rad-1, MN_rad-2, ...
+      const int64_t stride = t == 0 ? N : -N;
+      const unsigned short* __restrict__ q = b.ccode + k + (t == 0 ? (int64_t)0 : (int64_t)(b.MN_rad - 1) * N);
+      // The list entries (2-byte coalesced loads: the only global latency of this loop) are requested two chunks ahead of the
+      // arithmetic, whole pairs unconditionally; the entry of an odd end is requested before the loop.
+      auto load2 = [&](const unsigned short* at, unsigned& c0, unsigned& c1) __attribute__((always_inline)) {
+        c0 = at[0];
+        c1 = at[stride];
+      };
+      const int npairs = count >> 1;
+      unsigned a0 = 0, a1 = 0, n0c = 0, n1c = 0, tail = 0;
+      if (npairs > 0)
+        load2(q, a0, a1);
+      if (npairs > 1)
+        load2(q + 2 * stride, n0c, n1c);
+      if (count & 1)
+        tail = q[(int64_t)(count - 1) * stride];
+      q += 4 * stride;
+      // unrolled by two: the entries of chunk p + 2 are requested into the registers chunk p has just released -- no register
+      // rotation, so nothing waits for a load before two chunks of arithmetic have passed
+      for (int pr2 = 0; pr2 < (NEPMI_FS_ABL == 2 ? 0 : npairs); pr2 += 2) {
+        const unsigned x0 = a0, x1 = a1;
+        if (pr2 + 2 < npairs)
+          load2(q, a0, a1);
+        two_pairs(x0, x1, 1.0f, 1.0f, A2[t], B2[t], SA2[t], rc2, ri2);
+        if (pr2 + 1 < npairs) {
+          const unsigned y0 = n0c, y1 = n1c;
+          if (pr2 + 3 < npairs)
+            load2(q + 2 * stride, n0c, n1c);
+          two_pairs(y0, y1, 1.0f, 1.0f, A2[t], B2[t], SA2[t], rc2, ri2);
+        }
+        q += 4 * stride;
+      }
+      if (count & 1)
+        two_pairs(tail, tail, 1.0f, 0.0f, A2[t], B2[t], SA2[t], rc2, ri2);
+    }
+  } else {
+    // Mask form: the packed Verlet words (Bufs::wcode: four LDS slots per 8 bytes, segments padded with the sentinel slot) with
+    // this step's inside bits as weights -- no compact list was written (Bufs::rmaskA / rmaskB).
+    const int seg = b.wseg[k];
+    const int wa = seg & 255, wb = (seg >> 8) & 255;
+    const U2w* __restrict__ words = reinterpret_cast<const U2w*>(b.wcode) + k;
+    auto wgt = [](unsigned bits, int i) __attribute__((always_inline)) -> float { return (float)((bits >> i) & 1u); };
+    // list A: mixed types (two-type shapes: the own row of every candidate's type is selected per half)
+    {
+      U2w cur = {0u, 0u}, nxt = {0u, 0u};
+      if (wa > 0)
+        cur = words[0];
+      unsigned mw = 0u, tw = 0u;
+      for (int w = 0; w < (NEPMI_FS_ABL == 2 ? 0 : wa); ++w) {
+        if (w + 1 < wa)
+          nxt = words[(int64_t)(w + 1) * N];
+        if ((w & 7) == 0) {
+          mw = b.rmaskA[(int64_t)(w >> 3) * N + k];
+          if (TSM == 2)
+            tw = b.tmaskA[(int64_t)(w >> 3) * N + k];
+        }
+        const unsigned bits = mw >> (4 * (w & 7)), tb = tw >> (4 * (w & 7));
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          const unsigned pr = hh == 0 ? cur.lo : cur.hi;
+          const int i0 = 2 * hh, i1 = 2 * hh + 1;
+          if (TSM == 2) {
+            const bool t0 = ((tb >> i0) & 1u) != 0u, t1 = ((tb >> i1) & 1u) != 0u;
+            f2 Am[K + 1], Bm[K + 1];
+#pragma unroll
+            for (int kk = 0; kk <= K; ++kk) {
+              Am[kk] = mk2(t0 ? A2[TSM - 1][kk].x : A2[0][kk].x, t1 ? A2[TSM - 1][kk].x : A2[0][kk].x);
+              Bm[kk] = mk2(t0 ? B2[TSM - 1][kk].x : B2[0][kk].x, t1 ? B2[TSM - 1][kk].x : B2[0][kk].x);
+            }
+            const f2 SAm = mk2(t0 ? SA2[TSM - 1].x : SA2[0].x, t1 ? SA2[TSM - 1].x : SA2[0].x);
+            const f2 rc2 = mk2(t0 ? rcp_t[TSM - 1] : rcp_t[0], t1 ? rcp_t[TSM - 1] : rcp_t[0]);
+            const f2 ri2 = mk2(t0 ? rip_t[TSM - 1] : rip_t[0], t1 ? rip_t[TSM - 1] : rip_t[0]);
+            two_pairs(pr & 0xFFFFu, pr >> 16, wgt(bits, i0), wgt(bits, i1), Am, Bm, SAm, rc2, ri2);
+          } else {
+            two_pairs(pr & 0xFFFFu, pr >> 16, wgt(bits, i0), wgt(bits, i1), A2[0], B2[0], SA2[0], bc2(rcp_t[0]), bc2(rip_t[0]));
+          }
+        }
+        cur = nxt;
+      }
+    }
+    // list B
+    if (TSM == 2) {
+      // word pair p: row wa + 2p holds four neighbours of type 0, row wa + 2p + 1 four of type 1
+      const U2w* __restrict__ wbp = words + (int64_t)wa * N;
+      U2w c0 = {0u, 0u}, c1 = {0u, 0u}, n0w = {0u, 0u}, n1w = {0u, 0u};
+      if (wb > 0) {
+        c0 = wbp[0];
+        c1 = wbp[N];
+      }
+      unsigned mw = 0u;
+      for (int p = 0; p < (NEPMI_FS_ABL == 2 ? 0 : wb); ++p) {
+        if (p + 1 < wb) {
+          n0w = wbp[(int64_t)(2 * p + 2) * N];
+          n1w = wbp[(int64_t)(2 * p + 3) * N];
+        }
+        if ((p & 3) == 0)
+          mw = b.rmaskB[(int64_t)(p >> 2) * N + k];
+        const unsigned bits = mw >> (8 * (p & 3));
+        two_pairs(c0.lo & 0xFFFFu, c0.lo >> 16, wgt(bits, 0), wgt(bits, 1), A2[0], B2[0], SA2[0], bc2(rcp_t[0]), bc2(rip_t[0]));
+        two_pairs(c0.hi & 0xFFFFu, c0.hi >> 16, wgt(bits, 2), wgt(bits, 3), A2[0], B2[0], SA2[0], bc2(rcp_t[0]), bc2(rip_t[0]));
+        two_pairs(c1.lo & 0xFFFFu, c1.lo >> 16, wgt(bits, 4), wgt(bits, 5), A2[TSM - 1], B2[TSM - 1], SA2[TSM - 1], bc2(rcp_t[TSM - 1]),
+                  bc2(rip_t[TSM - 1]));
+        two_pairs(c1.hi & 0xFFFFu, c1.hi >> 16, wgt(bits, 6), wgt(bits, 7), A2[TSM - 1], B2[TSM - 1], SA2[TSM - 1], bc2(rcp_t[TSM - 1]),
+                  bc2(rip_t[TSM - 1]));
+        c0 = n0w;
+        c1 = n1w;
+      }
+    } else {
+      const U2w* __restrict__ wbp = words + (int64_t)wa * N;
+      U2w cur = {0u, 0u}, nxt = {0u, 0u};
+      if (wb > 0)
+        cur = wbp[0];
+      unsigned mw = 0u;
+      for (int w = 0; w < (NEPMI_FS_ABL == 2 ? 0 : wb); ++w) {
+        if (w + 1 < wb)
+          nxt = wbp[(int64_t)(w + 1) * N];
+        if ((w & 7) == 0)
+          mw = b.rmaskB[(int64_t)(w >> 3) * N + k];
+        const unsigned bits = mw >> (4 * (w & 7));
+        two_pairs(cur.lo & 0xFFFFu, cur.lo >> 16, wgt(bits, 0), wgt(bits, 1), A2[0], B2[0], SA2[0], bc2(rcp_t[0]), bc2(rip_t[0]));
+        two_pairs(cur.hi & 0xFFFFu, cur.hi >> 16, wgt(bits, 2), wgt(bits, 3), A2[0], B2[0], SA2[0], bc2(rcp_t[0]), bc2(rip_t[0]));
+        cur = nxt;
+      }
+    }
   }
 
   // ---- angular part: own partial forces f12 of this step's angular pairs (AngularForceBody wrote them); the first chunk's
@@ -384,7 +485,7 @@ __device__ __forceinline__ void force_scatter_atom(const ForceScatterBody<S>& B,
 #ifndef NEPMI_FS_WAVES
 #define NEPMI_FS_WAVES 3
 #endif
-template <class S, bool OUT>
+template <class S, bool OUT, bool MASK>
 __global__ void __launch_bounds__(kWinThreads) __attribute__((amdgpu_waves_per_eu(NEPMI_FS_WAVES)))
 nepmi_force_scatter_kernel(const ForceScatterBody<S> body, const int64_t nbricks)
 {
@@ -429,7 +530,9 @@ nepmi_force_scatter_kernel(const ForceScatterBody<S> body, const int64_t nbricks
       }
     }
     NEPMI_LDS(U4)* a4 = (NEPMI_LDS(U4)*)(lds + lay.off_acc());
-    const int n4 = 3 * lay.wmax / 4;
+    const int n4 = 3 * lay.rows() / 4;
+    if (tid == 0)
+      wp[lay.wmax] = I3{0x38000000, 0x38000000, 0x38000000}; // the sentinel slot: 0.875 R away along every axis
     const U4 zero{0u, 0u, 0u, 0u};
     for (int i = tid; i < n4; i += kWinThreads)
       a4[i] = zero;
@@ -438,7 +541,7 @@ nepmi_force_scatter_kernel(const ForceScatterBody<S> body, const int64_t nbricks
   int64_t a0, a1;
   body.st.brick_range(brick, a0, a1);
   for (int64_t k = a0 + tid; k < a1; k += kWinThreads)
-    force_scatter_atom<S, OUT>(body, brick, k, lds, lay);
+    force_scatter_atom<S, OUT, MASK>(body, brick, k, lds, lay);
   __syncthreads();
   {
     // the window sums, one 16-byte row per slot: what ForceFoldBody gathers

@@ -665,6 +665,9 @@ struct RadialWinBody {
                    // no pipeline) vs 0.508 (words, pipelined, 3 waves) vs 1.02 (4 waves: the two stages spill); carbon 0.79 ->
                    // 0.98.  Off.
 #endif
+#ifndef NEPMI_RW2_ABL
+#define NEPMI_RW2_ABL 0 // ablation builds (timings only): 1 = no compact-list stores, 2 = no stores and no counters
+#endif
 #ifndef NEPMI_RW2_HALF
 #define NEPMI_RW2_HALF 1 // 1: a word pair is processed as two halves of 2 + 2 candidates (fewer live registers), 0: 4 + 4 at once
 #endif
@@ -786,7 +789,13 @@ struct RadialWin2Body {
     // sentinel slot, which the force assembly evaluates to zero.
     U2w* __restrict__ cword = reinterpret_cast<U2w*>(b.cword) + k;
     unsigned long long accf = 0ull, accb = 0ull;
-    auto push_front = [&](const Cand& c) __attribute__((always_inline)) {
+    unsigned mcur = 0u; // the mask word being filled (Bufs::rmaskA / rmaskB)
+    auto push_front = [&](const Cand& c, const int bit) __attribute__((always_inline)) {
+      if (b.use_rmask) {
+        mcur |= c.inside ? (1u << bit) : 0u;
+        cnt += c.inside ? 1 : 0;
+        return;
+      }
       if (c.inside) {
         if (NEPMI_CW) {
           const int f = cnt & 3;
@@ -800,13 +809,19 @@ struct RadialWin2Body {
             }
             accf = 0ull;
           }
-        } else if (owned && cnt + cnt1 < b.MN_rad) {
+        } else if (NEPMI_RW2_ABL == 0 && owned && cnt + cnt1 < b.MN_rad) {
           ccode[(int64_t)cnt * N] = (unsigned short)c.slot;
         }
-        ++cnt;
+        if (NEPMI_RW2_ABL < 2)
+          ++cnt;
       }
     };
-    auto push_back = [&](const Cand& c) __attribute__((always_inline)) {
+    auto push_back = [&](const Cand& c, const int bit) __attribute__((always_inline)) {
+      if (b.use_rmask) {
+        mcur |= c.inside ? (1u << bit) : 0u;
+        cnt1 += c.inside ? 1 : 0;
+        return;
+      }
       if (c.inside) {
         if (NEPMI_CW) {
           const int f = cnt1 & 3;
@@ -820,10 +835,11 @@ struct RadialWin2Body {
             }
             accb = 0ull;
           }
-        } else if (owned && cnt + cnt1 < b.MN_rad) {
+        } else if (NEPMI_RW2_ABL == 0 && owned && cnt + cnt1 < b.MN_rad) {
           ccode[(int64_t)(b.MN_rad - 1 - cnt1) * N] = (unsigned short)c.slot;
         }
-        ++cnt1;
+        if (NEPMI_RW2_ABL < 2)
+          ++cnt1;
       }
     };
     // the last, partial word of a stream: the free places take the sentinel slot
@@ -968,9 +984,9 @@ struct RadialWin2Body {
             if (!b.use_amask && live)
               amap[(int64_t)idx * N] = cs;
             if (S::TS == 2 && ((unsigned)c[u].rw >> kIdxBits) == 1u)
-              push_back(c[u]);
+              push_back(c[u], 4 * (w & 7) + 2 * hh + u);
             else
-              push_front(c[u]);
+              push_front(c[u], 4 * (w & 7) + 2 * hh + u);
           }
           if (S::TS > 0 && !ZIP) { // one type: the two candidates side by side
             f2 fn[S::KRM + 1];
@@ -995,6 +1011,11 @@ struct RadialWin2Body {
             accumulate1(c[0]);
             accumulate1(c[1]);
           }
+        }
+        if (b.use_rmask && ((w & 7) == 7 || w == wa - 1)) {
+          if ((w >> 3) < b.MAW)
+            b.rmaskA[(int64_t)(w >> 3) * N + k] = mcur;
+          mcur = 0u;
         }
       }
     }
@@ -1045,14 +1066,19 @@ struct RadialWin2Body {
           }
 #pragma unroll
           for (int u = 0; u < HN; ++u) {
-            push_front(x[u]);
-            push_back(y[u]);
+            push_front(x[u], 8 * (p & 3) + HN * hh + u);
+            push_back(y[u], 8 * (p & 3) + 4 + HN * hh + u);
             f2 fn[S::KRM + 1];
             basis2(x[u], y[u], fn);
 #pragma unroll
             for (int kk = 0; kk <= S::KRM; ++kk)
               SS[kk] = SS[kk] + fn[kk];
           }
+        }
+        if (b.use_rmask && ((p & 3) == 3 || p == wb - 1)) {
+          if ((p >> 2) < b.MBW)
+            b.rmaskB[(int64_t)(p >> 2) * N + k] = mcur;
+          mcur = 0u;
         }
       }
     } else {
@@ -1074,7 +1100,12 @@ struct RadialWin2Body {
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-          push_front(c[u]);
+          push_front(c[u], 4 * (w & 7) + u);
+        if (b.use_rmask && ((w & 7) == 7 || w == wb - 1)) {
+          if ((w >> 3) < b.MBW)
+            b.rmaskB[(int64_t)(w >> 3) * N + k] = mcur;
+          mcur = 0u;
+        }
         if (S::TS > 0) {
 #pragma unroll
           for (int u = 0; u < 4; u += 2) {

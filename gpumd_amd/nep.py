@@ -309,6 +309,11 @@ class NEP:
         (nepmi_engine_set_force_form)"""
         self._ck(self.lib.nepmi_engine_set_force_form(self.handle, int(mode)))
 
+    def set_radial_mask(self, on=True):
+        """scatter-form loop steps: inside bits over the packed Verlet words instead of a compacted radial list
+        (nepmi_engine_set_radial_mask)"""
+        self._ck(self.lib.nepmi_engine_set_radial_mask(self.handle, 1 if on else 0))
+
     def describe(self):
         """the kernel forms the last force evaluation ran (counted rules of the engine, as text)"""
         import ctypes as C

@@ -434,6 +434,12 @@ int nepmi_engine_set_win_lanes(nepmi_engine* e, int lanes);
  * applies (per-call evaluations then add the virial-only pass).  A pair half beyond 64 eV/A returns the engine to the gather
  * form for the rest of its life (the fixed-point sums wrap at +-512 eV/A net per window). */
 int nepmi_engine_set_force_form(nepmi_engine* e, int mode);
+/* The per-step radial list of the scatter-form steps of the run loops (find_neighbor_list_large_box, nep.cu:436-486, is what it
+ * replaces): on = 1 (default) one inside bit per candidate of the packed Verlet words, which the force assembly walks with the
+ * bits as weights -- no compacted list is written (a scattered 2-byte store per pair: a third of the radial pass's time); 0 =
+ * the compacted list on every step.  Same pairs, same per-pair arithmetic: identical trajectories bit for bit.  One or two
+ * atom types; the compacted list is rebuilt on demand when per-atom virials leave the engine. */
+int nepmi_engine_set_radial_mask(nepmi_engine* e, int on);
 /* Static window layout of the one-lane window kernels (default on): between two list rebuilds the LDS slot of every window
  * atom is fixed, so the rebuild tabulates the windows and stores the Verlet entries as LDS slots, four to an 8-byte word
  * (two-type models: list B as two type-pure streams); on = 0 keeps the per-launch scan of the window cells and the

@@ -151,7 +151,7 @@ struct HostLoopBackend {
   // the scatter form of the force assembly (gpumd_amd/csrc/nep_scatter.h) is device code only: never selected here
   static constexpr bool kHasScatter = false;
   template <class S>
-  void launch_force_scatter(int, int64_t, int, int64_t, const WinStage&, const ModelD&, int*, const unsigned*, int, bool, int, int, const int*)
+  void launch_force_scatter(int, int64_t, int, int64_t, const WinStage&, const ModelD&, int*, const unsigned*, int, bool, bool, int, int, const int*)
   {
     std::abort();
   }

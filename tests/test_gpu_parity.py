@@ -121,6 +121,47 @@ def test_scatter_form_properties(drv):
     assert np.abs(fsum).max() < 1e-9, fsum
 
 
+@pytest.mark.parametrize("model", ["PbTe", "C"])
+def test_run_loop_forms_are_bit_identical(drv, model):
+    """The run loop's scatter-form steps with the per-step radial list as inside bits over the packed Verlet words (the
+    default) and as a compacted list: the same pairs with the same per-pair arithmetic into integer sums -- identical
+    positions, velocities, forces and energies after 40 steps with list rebuilds, bit for bit; per-atom virials (the
+    virial-only gather pass at the exit, which needs the compacted list rebuilt on demand) identical as well; and both
+    against the gather form within f32 rounding."""
+    if model == "PbTe":
+        nep, (h, typ, x) = H.golden("PbTe", "nep.txt"), H.pbte_supercell((6, 6, 6), rattle=0.03, seed=17)
+        mass = np.where(typ == 0, H.MASS["Te"], H.MASS["Pb"]).astype(np.float64)
+    else:
+        nep, (h, typ, x) = H.golden("C", "nep.txt"), H.diamond((18, 18, 18), 3.57, rattle=0.03, seed=18)
+        mass = np.full(len(typ), H.MASS["C"])
+    n = len(typ)
+    vel = H.maxwell_velocities(mass, 2500.0, seed=4)
+    m = drv.model(nep)
+    out = []
+    for form, mask in ((-1, True), (-1, False), (0, True)):
+        eng = drv.engine(m, n)
+        eng.set_win_lanes(1)
+        eng.set_force_form(form)
+        eng.set_radial_mask(mask)
+        d_t, d_m, d_x, d_v = drv.dev(typ), drv.dev(mass), drv.dev(x), drv.dev(vel)
+        d_pe, d_f, d_w = drv.zeros(n), drv.zeros(3 * n), drv.zeros(9 * n)
+        eng.force_compute(h, d_t, d_x, d_pe, d_f, d_w)
+        th = eng.run_nve(h, d_t, d_m, 2.0 / H.TIME_UNIT, 40, d_x, d_v, d_pe, d_f, d_w, thermo_every=10)
+        out.append((drv.host(d_x), drv.host(d_v), drv.host(d_f), drv.host(d_pe), drv.host(d_w), np.asarray(th), eng.describe(),
+                    eng.stats().num_rebuild))
+    a, b, g = out
+    assert "inside_bits" in a[6] and "compacted" in b[6] and "lds_scatter" in b[6] and "lds_scatter" not in g[6], (a[6], b[6], g[6])
+    assert a[7] >= 2  # list rebuilds inside the run
+    for i in range(5):
+        assert np.array_equal(a[i], b[i]), (i, np.abs(a[i] - b[i]).max())
+    # thermo records: temperature and energy identical; the stresses come from the own-half virials, which are f32 sums over
+    # the pairs in the order they are walked (list order vs word order)
+    assert np.array_equal(a[5][:, :2], b[5][:, :2])
+    np.testing.assert_allclose(a[5], b[5], rtol=1e-6, atol=1e-9)
+    assert np.abs(a[0] - g[0]).max() < 1e-6 and np.abs(a[2] - g[2]).max() < 2e-4
+    np.testing.assert_allclose(a[5][:, :2], g[5][:, :2], rtol=1e-6)
+
+
 @pytest.mark.parametrize("name", ["PbTe-A", "C-2022"])
 def test_force_parity_with_pair_records(drv, name):
     """Tile mode 1: LDS-window radial pass that writes pair records + the record-reading force assembly."""
