@@ -504,6 +504,7 @@ public:
   // step.  The caller's arrays are read at entry and written at exit.
   // ---------------------------------------------------------------------------------------------
   enum Ensemble { kNve = 0, kBer = 1, kNhc = 2, kBdp = 3, kLan = 4, kBao = 5 };
+  static constexpr int64_t kScatterMinBricks = 768; // 3 workgroups x 256 CUs
   static constexpr int kPollEvery = 4; // steps between two snapshots of the device flags
   static constexpr int kPollDepth = 2; // snapshots in flight: the host runs 8-12 steps ahead of the device
 
@@ -978,6 +979,11 @@ private:
       b_.rmaskA = B::kHasScatter ? dalloc<unsigned>((size_t)b_.MAW * N) : nullptr;
       b_.rmaskB = B::kHasScatter ? dalloc<unsigned>((size_t)b_.MBW * N) : nullptr;
       b_.tmaskA = B::kHasScatter ? dalloc<unsigned>((size_t)b_.MAW * N) : nullptr;
+      b_.MA2 = 2 * ((b_.MN_ang + 3) / 4) + 2;
+      const bool two = B::kHasScatter && m.num_types == 2;
+      b_.acode2 = two ? dalloc<unsigned short>((size_t)b_.MA2 * N * 4) : nullptr;
+      b_.aorig2 = two ? dalloc<unsigned>((size_t)b_.MA2 * N) : nullptr;
+      b_.aseg2 = two ? dalloc<int>(N) : nullptr;
       b_.use_rmask = 0;
     } else { // Tersoff-1989: Tersoff1989::Tersoff1989 allocations (tersoff1989.cu:141-149)
       tb_.rec = dalloc<D4>((size_t)b_.MN_ang * N);
@@ -1562,7 +1568,10 @@ private:
       WinLayout layq = win_;
       layq.compact = 1;
       const WinStage wsq{box_, b_, layq};
-      b_.use_rmask = (NEPMI_RMASK && use_rmask_ && S::TS > 0 && win2 && b_.rmaskB && loop_ctx_ && scatter_wanted<S>(wsq)) ? 1 : 0;
+      b_.use_rmask = (NEPMI_RMASK && use_rmask_ && S::TS > 0 && win2 && b_.rmaskB && loop_ctx_ && max_ang_rebuild_ <= 96 &&
+                      (S::TS == 1 || b_.acode2) && scatter_wanted<S>(wsq))
+                       ? 1
+                       : 0;
       last_mask_form_ = b_.use_rmask != 0;
     } else {
       b_.use_rmask = 0; // (before the kernel bodies below copy Bufs)
@@ -1664,6 +1673,11 @@ private:
       return false;
     if (force_form_ < 0 && !loop_ctx_)
       return false;
+    // Fewer bricks than workgroup places on the chip (three per CU): both forms then take one brick's latency, and the scatter
+    // form has a second launch (the fold) on top -- 128,000 PbTe atoms (512 bricks): 4.7e8 atom-steps/s against 4.8e8 for the
+    // gather form, 250,000 atoms (1,000 bricks): 6.07e8 against 5.9e8 (profiles/r4p_size_sweep.txt).  A counted rule.
+    if (force_form_ < 0 && num_bricks_ < kScatterMinBricks)
+      return false;
     if (S::TS > 0)
       return 24 * (size_t)(win_.wmax + 4) <= B::kMaxLdsBytes;
     // many types / run-time shapes: the own half from the atom's radial Fp row and the coefficient table in LDS -- where the
@@ -1728,8 +1742,8 @@ public:
     }
     be_.frozen = nullptr;
   }
-  // 1 (default): scatter-form steps of the run loops keep the per-step radial list as inside bits over the packed Verlet words
-  // (Bufs::rmaskB) instead of compacting it; 0: the compact list on every step.  Identical results, bit for bit.
+  // 1: scatter-form steps of the run loops keep the per-step radial list as inside bits over the packed Verlet words
+  // (Bufs::rmaskB) instead of compacting it; 0 (default): the compact list on every step.  Identical results, bit for bit.
   void set_radial_mask(bool on) { use_rmask_ = on; }
   // the callers whose steps need forces, energies and the TOTAL virial only (run loops; the decomposed driver)
   void set_loop_context(bool on) { loop_ctx_ = on; }
@@ -1911,7 +1925,8 @@ private:
   int force_form_ = -1;          // set_force_form
   bool loop_ctx_ = false;        // set_loop_context
   bool virial_local_ = false;    // the virial planes of the last force evaluation hold the own-half form (exact_virials)
-  bool use_rmask_ = true;        // set_radial_mask
+  bool use_rmask_ = false;       // set_radial_mask (off: on PbTe 1 M atoms the radial pass gains what the force assembly's lockstep
+                                 // walk over all candidates loses -- profiles/r4q_ab_mask.txt)
   bool last_mask_form_ = false;
   bool ccode_valid_ = true;      // the compact radial list of the last force evaluation exists (else: the masks, Bufs::rmaskB)
   bool step_outputs_ = true;     // set_step_outputs

@@ -203,6 +203,13 @@ struct Bufs {
   unsigned* rmaskB;
   unsigned* tmaskA;
   int MAW, MBW;  // words per atom of rmaskA / tmaskA and of rmaskB
+  // Two-type shapes, written at the rebuild for the mask-form force assembly: list A once more as two type-pure runs of words
+  // (rows [0, wa0): entries of type 0, rows [wa0, wa0 + wa1): of type 1, padded with the sentinel slot), with the list-A index
+  // of every entry (one byte each, 255 = padding) to find its bit in rmaskA; aseg2[k] = wa0 | wa1 << 8
+  unsigned short* acode2; // [MA2][N][4]
+  unsigned* aorig2;       // [MA2][N]
+  int* aseg2;
+  int MA2;
   int use_rmask; // 1: this step's radial pass writes the masks instead of ccode
   int compact_all;       // 1: every atom with level >= 1 writes its compact radial list (the scatter form walks the lists of the
                          // atoms that have descriptors, the gather form those of the atoms that receive forces)
@@ -998,6 +1005,44 @@ struct PackCodesBody {
           bits |= (b.posq[b.nl_ang[(int64_t)s * N + k]].type != 0 ? 1u : 0u) << (s & 31);
         b.tmaskA[(int64_t)w * N + k] = bits;
       }
+    }
+    if (b.acode2 && parts == 2) { // list A as two type-pure runs of words for the mask-form force assembly
+      int row2 = 0, wa0 = 0;
+      for (int t = 0; t < 2; ++t) {
+        unsigned short sl[4];
+        unsigned ix = 0u;
+        int f2 = 0;
+        auto emit = [&]() {
+          if (row2 < b.MA2) {
+            for (int u = 0; u < 4; ++u)
+              b.acode2[((int64_t)row2 * N + k) * 4 + u] = sl[u];
+            b.aorig2[(int64_t)row2 * N + k] = ix;
+          }
+          ++row2;
+          f2 = 0;
+          ix = 0u;
+        };
+        for (int s2 = 0; s2 < na; ++s2) {
+          if ((b.posq[b.nl_ang[(int64_t)s2 * N + k]].type != 0) != (t != 0))
+            continue;
+          sl[f2] = slot_of(b.code_ang[(int64_t)s2 * N + k]);
+          ix |= (unsigned)(s2 < 255 ? s2 : 255) << (8 * f2);
+          if (++f2 == 4)
+            emit();
+        }
+        if (f2 != 0) {
+          for (; f2 < 4; ++f2) {
+            sl[f2] = (unsigned short)b.wsent;
+            ix |= 255u << (8 * f2);
+          }
+          emit();
+        }
+        if (t == 0)
+          wa0 = row2;
+      }
+      if (row2 > b.MA2 || na > 255)
+        NEPMI_ATOMIC_OR(&b.flags[kFlagOverflow], 1);
+      b.aseg2[k] = wa0 | ((row2 - wa0) << 8);
     }
     int wb = 0;
     if (parts == 2) {

@@ -174,28 +174,42 @@ __device__ __forceinline__ void force_scatter_atom(const ForceScatterBody<S>& B,
   // (find_fn_and_fnp, nep_utilities.cuh:590-623), contracted as  fc'/2 (SA + sum_k A_k T_k) + (dx/dr fc/2) sum_k (k A_k) U_{k-1}:
   // the Chebyshev recurrences feed two running sums instead of seven separate basis derivatives.  The own rows of BOTH
   // neighbour types stay in registers as f2 pairs (two pairs are evaluated side by side).
-  f2 A2[TSM][K + 1], B2[TSM][K + 1], SA2[TSM];
-  float rcp_t[TSM], rip_t[TSM];
-#pragma unroll
-  for (int t = 0; t < TSM; ++t) {
+  struct Rows { // the own row of one neighbour type: A_k, k A_k, sum_k A_k as f2 pairs, the pair cutoff of that type
+    f2 A[K + 1], B[K + 1], SA, rc, ri;
+  };
+  auto load_rows = [&](const int t, Rows& r) __attribute__((always_inline)) {
     float sa = 0.0f;
 #pragma unroll
     for (int kk = 0; kk <= K; ++kk) {
       const float a = atab[t * KRP + kk];
-      A2[t][kk] = bc2(a);
-      B2[t][kk] = bc2((float)kk * a);
+      r.A[kk] = bc2(a);
+      r.B[kk] = bc2((float)kk * a);
       sa += a;
     }
-    SA2[t] = bc2(sa);
-    rcp_t[t] = m.uniform_rc ? m.rc_r_max : (rc1 + m.rc_r[t]) * 0.5f;
-    rip_t[t] = m.uniform_rc ? m.rcinv_r : fast_rcp(rcp_t[t]);
-  }
+    r.SA = bc2(sa);
+    const float rcp = m.uniform_rc ? m.rc_r_max : (rc1 + m.rc_r[t]) * 0.5f;
+    r.rc = bc2(rcp);
+    r.ri = bc2(m.uniform_rc ? m.rcinv_r : fast_rcp(rcp));
+  };
   // two pairs side by side (packed FP32): LDS slots a0 / a1, weights w0 / w1 (0: the place adds nothing), own rows Ax / Bx / SAx
   // and pair cutoffs rc2 / ri2 per half
   auto two_pairs = [&](const unsigned a0, const unsigned a1, const float w0, const float w1, const f2* Ax, const f2* Bx, const f2 SAx,
                        const f2 rc2, const f2 ri2) __attribute__((always_inline)) {
     const unsigned o0 = row12(a0), o1 = row12(a1);
-    const I3 p0 = *(NEPMI_LDS(const I3)*)(wpos + o0), p1 = *(NEPMI_LDS(const I3)*)(wpos + o1);
+    I3 p0, p1;
+    if (MASK) {
+      // a place of weight zero (a candidate outside the cutoff) touches the LDS neither for its position nor for the
+      // reaction: it is evaluated at the sentinel's distance, where the envelope and its derivative vanish
+      p0 = I3{ox + 0x38000000, oy, oz};
+      p1 = p0;
+      if (w0 != 0.0f)
+        p0 = *(NEPMI_LDS(const I3)*)(wpos + o0);
+      if (w1 != 0.0f)
+        p1 = *(NEPMI_LDS(const I3)*)(wpos + o1);
+    } else {
+      p0 = *(NEPMI_LDS(const I3)*)(wpos + o0);
+      p1 = *(NEPMI_LDS(const I3)*)(wpos + o1);
+    }
     const f2 fx = mk2((float)(p0.x - ox), (float)(p1.x - ox));
     const f2 fy = mk2((float)(p0.y - oy), (float)(p1.y - oy));
     const f2 fz = mk2((float)(p0.z - oz), (float)(p1.z - oz));
@@ -248,12 +262,16 @@ __device__ __forceinline__ void force_scatter_atom(const ForceScatterBody<S>& B,
     NEPMI_LDS(int)* r1 = (NEPMI_LDS(int)*)(wacc + o1);
     if (NEPMI_FS_ABL == 1)
       return;
-    lds_sub(r0, ax);
-    lds_sub(r0 + 1, ay);
-    lds_sub(r0 + 2, az);
-    lds_sub(r1, bx); // (a place of weight zero subtracts zero)
-    lds_sub(r1 + 1, by);
-    lds_sub(r1 + 2, bz);
+    if (!MASK || w0 != 0.0f) {
+      lds_sub(r0, ax);
+      lds_sub(r0 + 1, ay);
+      lds_sub(r0 + 2, az);
+    }
+    if (!MASK || w1 != 0.0f) {
+      lds_sub(r1, bx); // (compact form: the repeated entry of an odd end subtracts zero)
+      lds_sub(r1 + 1, by);
+      lds_sub(r1 + 2, bz);
+    }
   };
 
   if constexpr (!MASK) {
@@ -262,7 +280,8 @@ __device__ __forceinline__ void force_scatter_atom(const ForceScatterBody<S>& B,
 #pragma unroll
     for (int t = 0; t < TSM; ++t) {
       const int count = t == 0 ? n0 : nrad - n0;
-      const f2 rc2 = bc2(rcp_t[t]), ri2 = bc2(rip_t[t]);
+      Rows R;
+      load_rows(t, R);
       // the segment's entries: row r of ccode at r N; the front segment walks rows 0, 1, ..., the back one MN_rad-1, MN_rad-2, ...
       const int64_t stride = t == 0 ? N : -N;
       const unsigned short* __restrict__ q = b.ccode + k + (t == 0 ? (int64_t)0 : (int64_t)(b.MN_rad - 1) * N);
@@ -287,105 +306,101 @@ __device__ __forceinline__ void force_scatter_atom(const ForceScatterBody<S>& B,
         const unsigned x0 = a0, x1 = a1;
         if (pr2 + 2 < npairs)
           load2(q, a0, a1);
-        two_pairs(x0, x1, 1.0f, 1.0f, A2[t], B2[t], SA2[t], rc2, ri2);
+        two_pairs(x0, x1, 1.0f, 1.0f, R.A, R.B, R.SA, R.rc, R.ri);
         if (pr2 + 1 < npairs) {
           const unsigned y0 = n0c, y1 = n1c;
           if (pr2 + 3 < npairs)
             load2(q + 2 * stride, n0c, n1c);
-          two_pairs(y0, y1, 1.0f, 1.0f, A2[t], B2[t], SA2[t], rc2, ri2);
+          two_pairs(y0, y1, 1.0f, 1.0f, R.A, R.B, R.SA, R.rc, R.ri);
         }
         q += 4 * stride;
       }
       if (count & 1)
-        two_pairs(tail, tail, 1.0f, 0.0f, A2[t], B2[t], SA2[t], rc2, ri2);
+        two_pairs(tail, tail, 1.0f, 0.0f, R.A, R.B, R.SA, R.rc, R.ri);
     }
   } else {
     // Mask form: the packed Verlet words (Bufs::wcode: four LDS slots per 8 bytes, segments padded with the sentinel slot) with
-    // this step's inside bits as weights -- no compact list was written (Bufs::rmaskA / rmaskB).
+    // this step's inside bits as weights -- no compact list was written (Bufs::rmaskA / rmaskB).  One type-pure stream of words
+    // per neighbour type: the entries of list A of that type (two-type shapes: Bufs::acode2, tabulated at the rebuild with
+    // their list-A indices), then the rows of list B of that type.
     const int seg = b.wseg[k];
     const int wa = seg & 255, wb = (seg >> 8) & 255;
     const U2w* __restrict__ words = reinterpret_cast<const U2w*>(b.wcode) + k;
+    const U2w* __restrict__ wbp = words + (int64_t)wa * N;
     auto wgt = [](unsigned bits, int i) __attribute__((always_inline)) -> float { return (float)((bits >> i) & 1u); };
-    // list A: mixed types (two-type shapes: the own row of every candidate's type is selected per half)
-    {
-      U2w cur = {0u, 0u}, nxt = {0u, 0u};
-      if (wa > 0)
-        cur = words[0];
-      unsigned mw = 0u, tw = 0u;
-      for (int w = 0; w < (NEPMI_FS_ABL == 2 ? 0 : wa); ++w) {
-        if (w + 1 < wa)
-          nxt = words[(int64_t)(w + 1) * N];
-        if ((w & 7) == 0) {
-          mw = b.rmaskA[(int64_t)(w >> 3) * N + k];
-          if (TSM == 2)
-            tw = b.tmaskA[(int64_t)(w >> 3) * N + k];
+    unsigned mA[3] = {0u, 0u, 0u}; // the inside bits of list A (lists longer than 96 entries: the rule keeps the compact form)
+#pragma unroll
+    for (int w = 0; w < 3; ++w)
+      if (w < b.MAW)
+        mA[w] = b.rmaskA[(int64_t)w * N + k];
+    auto bitA = [&](unsigned idx) __attribute__((always_inline)) -> float {
+      const unsigned w = idx >> 5;
+      const unsigned m3 = w == 0 ? mA[0] : (w == 1 ? mA[1] : (w == 2 ? mA[2] : 0u));
+      return (float)((m3 >> (idx & 31u)) & 1u);
+    };
+#pragma unroll
+    for (int t = 0; t < TSM; ++t) {
+      Rows R;
+      load_rows(t, R);
+      // list A entries of type t
+      if (TSM == 2) {
+        const int sg = b.aseg2[k];
+        const int wat = t == 0 ? (sg & 255) : ((sg >> 8) & 255), base = t == 0 ? 0 : (sg & 255);
+        const U2w* __restrict__ aw = reinterpret_cast<const U2w*>(b.acode2) + k + (int64_t)base * N;
+        const unsigned* __restrict__ ao = b.aorig2 + k + (int64_t)base * N;
+        U2w cur = {0u, 0u}, nxt = {0u, 0u};
+        unsigned ic = 0u, in = 0u;
+        if (wat > 0) {
+          cur = aw[0];
+          ic = ao[0];
         }
-        const unsigned bits = mw >> (4 * (w & 7)), tb = tw >> (4 * (w & 7));
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-          const unsigned pr = hh == 0 ? cur.lo : cur.hi;
-          const int i0 = 2 * hh, i1 = 2 * hh + 1;
-          if (TSM == 2) {
-            const bool t0 = ((tb >> i0) & 1u) != 0u, t1 = ((tb >> i1) & 1u) != 0u;
-            f2 Am[K + 1], Bm[K + 1];
-#pragma unroll
-            for (int kk = 0; kk <= K; ++kk) {
-              Am[kk] = mk2(t0 ? A2[TSM - 1][kk].x : A2[0][kk].x, t1 ? A2[TSM - 1][kk].x : A2[0][kk].x);
-              Bm[kk] = mk2(t0 ? B2[TSM - 1][kk].x : B2[0][kk].x, t1 ? B2[TSM - 1][kk].x : B2[0][kk].x);
-            }
-            const f2 SAm = mk2(t0 ? SA2[TSM - 1].x : SA2[0].x, t1 ? SA2[TSM - 1].x : SA2[0].x);
-            const f2 rc2 = mk2(t0 ? rcp_t[TSM - 1] : rcp_t[0], t1 ? rcp_t[TSM - 1] : rcp_t[0]);
-            const f2 ri2 = mk2(t0 ? rip_t[TSM - 1] : rip_t[0], t1 ? rip_t[TSM - 1] : rip_t[0]);
-            two_pairs(pr & 0xFFFFu, pr >> 16, wgt(bits, i0), wgt(bits, i1), Am, Bm, SAm, rc2, ri2);
-          } else {
-            two_pairs(pr & 0xFFFFu, pr >> 16, wgt(bits, i0), wgt(bits, i1), A2[0], B2[0], SA2[0], bc2(rcp_t[0]), bc2(rip_t[0]));
+        for (int w = 0; w < (NEPMI_FS_ABL == 2 ? 0 : wat); ++w) {
+          if (w + 1 < wat) {
+            nxt = aw[(int64_t)(w + 1) * N];
+            in = ao[(int64_t)(w + 1) * N];
           }
+          two_pairs(cur.lo & 0xFFFFu, cur.lo >> 16, bitA(ic & 255u), bitA((ic >> 8) & 255u), R.A, R.B, R.SA, R.rc, R.ri);
+          two_pairs(cur.hi & 0xFFFFu, cur.hi >> 16, bitA((ic >> 16) & 255u), bitA(ic >> 24), R.A, R.B, R.SA, R.rc, R.ri);
+          cur = nxt;
+          ic = in;
         }
-        cur = nxt;
-      }
-    }
-    // list B
-    if (TSM == 2) {
-      // word pair p: row wa + 2p holds four neighbours of type 0, row wa + 2p + 1 four of type 1
-      const U2w* __restrict__ wbp = words + (int64_t)wa * N;
-      U2w c0 = {0u, 0u}, c1 = {0u, 0u}, n0w = {0u, 0u}, n1w = {0u, 0u};
-      if (wb > 0) {
-        c0 = wbp[0];
-        c1 = wbp[N];
-      }
-      unsigned mw = 0u;
-      for (int p = 0; p < (NEPMI_FS_ABL == 2 ? 0 : wb); ++p) {
-        if (p + 1 < wb) {
-          n0w = wbp[(int64_t)(2 * p + 2) * N];
-          n1w = wbp[(int64_t)(2 * p + 3) * N];
+      } else {
+        U2w cur = {0u, 0u}, nxt = {0u, 0u};
+        if (wa > 0)
+          cur = words[0];
+        for (int w = 0; w < (NEPMI_FS_ABL == 2 ? 0 : wa); ++w) {
+          if (w + 1 < wa)
+            nxt = words[(int64_t)(w + 1) * N];
+          two_pairs(cur.lo & 0xFFFFu, cur.lo >> 16, bitA(4u * w), bitA(4u * w + 1u), R.A, R.B, R.SA, R.rc, R.ri);
+          two_pairs(cur.hi & 0xFFFFu, cur.hi >> 16, bitA(4u * w + 2u), bitA(4u * w + 3u), R.A, R.B, R.SA, R.rc, R.ri);
+          cur = nxt;
         }
-        if ((p & 3) == 0)
-          mw = b.rmaskB[(int64_t)(p >> 2) * N + k];
-        const unsigned bits = mw >> (8 * (p & 3));
-        two_pairs(c0.lo & 0xFFFFu, c0.lo >> 16, wgt(bits, 0), wgt(bits, 1), A2[0], B2[0], SA2[0], bc2(rcp_t[0]), bc2(rip_t[0]));
-        two_pairs(c0.hi & 0xFFFFu, c0.hi >> 16, wgt(bits, 2), wgt(bits, 3), A2[0], B2[0], SA2[0], bc2(rcp_t[0]), bc2(rip_t[0]));
-        two_pairs(c1.lo & 0xFFFFu, c1.lo >> 16, wgt(bits, 4), wgt(bits, 5), A2[TSM - 1], B2[TSM - 1], SA2[TSM - 1], bc2(rcp_t[TSM - 1]),
-                  bc2(rip_t[TSM - 1]));
-        two_pairs(c1.hi & 0xFFFFu, c1.hi >> 16, wgt(bits, 6), wgt(bits, 7), A2[TSM - 1], B2[TSM - 1], SA2[TSM - 1], bc2(rcp_t[TSM - 1]),
-                  bc2(rip_t[TSM - 1]));
-        c0 = n0w;
-        c1 = n1w;
       }
-    } else {
-      const U2w* __restrict__ wbp = words + (int64_t)wa * N;
-      U2w cur = {0u, 0u}, nxt = {0u, 0u};
-      if (wb > 0)
-        cur = wbp[0];
-      unsigned mw = 0u;
-      for (int w = 0; w < (NEPMI_FS_ABL == 2 ? 0 : wb); ++w) {
-        if (w + 1 < wb)
-          nxt = wbp[(int64_t)(w + 1) * N];
-        if ((w & 7) == 0)
-          mw = b.rmaskB[(int64_t)(w >> 3) * N + k];
-        const unsigned bits = mw >> (4 * (w & 7));
-        two_pairs(cur.lo & 0xFFFFu, cur.lo >> 16, wgt(bits, 0), wgt(bits, 1), A2[0], B2[0], SA2[0], bc2(rcp_t[0]), bc2(rip_t[0]));
-        two_pairs(cur.hi & 0xFFFFu, cur.hi >> 16, wgt(bits, 2), wgt(bits, 3), A2[0], B2[0], SA2[0], bc2(rcp_t[0]), bc2(rip_t[0]));
-        cur = nxt;
+      // list B rows of type t: two-type shapes keep them as word pairs (row 2p: type 0, row 2p + 1: type 1)
+      {
+        const int64_t rstep = (int64_t)TSM * N;
+        const U2w* __restrict__ bw = wbp + (int64_t)t * N;
+        U2w cur = {0u, 0u}, nxt = {0u, 0u};
+        if (wb > 0)
+          cur = bw[0];
+        unsigned mw = 0u;
+        for (int p = 0; p < (NEPMI_FS_ABL == 2 ? 0 : wb); ++p) {
+          if (p + 1 < wb)
+            nxt = bw[(int64_t)(p + 1) * rstep];
+          unsigned bits;
+          if (TSM == 2) {
+            if ((p & 3) == 0)
+              mw = b.rmaskB[(int64_t)(p >> 2) * N + k];
+            bits = mw >> (8 * (p & 3) + 4 * t);
+          } else {
+            if ((p & 7) == 0)
+              mw = b.rmaskB[(int64_t)(p >> 3) * N + k];
+            bits = mw >> (4 * (p & 7));
+          }
+          two_pairs(cur.lo & 0xFFFFu, cur.lo >> 16, wgt(bits, 0), wgt(bits, 1), R.A, R.B, R.SA, R.rc, R.ri);
+          two_pairs(cur.hi & 0xFFFFu, cur.hi >> 16, wgt(bits, 2), wgt(bits, 3), R.A, R.B, R.SA, R.rc, R.ri);
+          cur = nxt;
+        }
       }
     }
   }

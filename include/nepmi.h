@@ -435,10 +435,12 @@ int nepmi_engine_set_win_lanes(nepmi_engine* e, int lanes);
  * form for the rest of its life (the fixed-point sums wrap at +-512 eV/A net per window). */
 int nepmi_engine_set_force_form(nepmi_engine* e, int mode);
 /* The per-step radial list of the scatter-form steps of the run loops (find_neighbor_list_large_box, nep.cu:436-486, is what it
- * replaces): on = 1 (default) one inside bit per candidate of the packed Verlet words, which the force assembly walks with the
- * bits as weights -- no compacted list is written (a scattered 2-byte store per pair: a third of the radial pass's time); 0 =
- * the compacted list on every step.  Same pairs, same per-pair arithmetic: identical trajectories bit for bit.  One or two
- * atom types; the compacted list is rebuilt on demand when per-atom virials leave the engine. */
+ * replaces): on = 1: one inside bit per candidate of the packed Verlet words, which the force assembly walks with the bits as
+ * weights -- no compacted list is written (a conditional 2-byte store per pair and its bookkeeping: a third of the radial
+ * pass's time); 0 (default): the compacted list on every step.  Same pairs, same per-pair arithmetic: identical trajectories
+ * bit for bit (tests/test_gpu_parity.py).  Measured on PbTe 1 M atoms the radial pass gains 0.07 ms and the force assembly,
+ * which then evaluates the 24 % of the candidates outside the cutoff in lockstep, loses as much (profiles/r4q_ab_mask.txt);
+ * carbon gains 2 %.  One or two atom types; the compacted list is rebuilt on demand when per-atom virials leave the engine. */
 int nepmi_engine_set_radial_mask(nepmi_engine* e, int on);
 /* Static window layout of the one-lane window kernels (default on): between two list rebuilds the LDS slot of every window
  * atom is fixed, so the rebuild tabulates the windows and stores the Verlet entries as LDS slots, four to an 8-byte word

@@ -27,6 +27,14 @@ def read(path, counter):
             if row["counter"] == counter:
                 rows.append(row)
     out = {}
+    # the scatter form of the force assembly is two launches (window scatter + fold): their sum is the force assembly
+    def first(key):
+        # (of the scatter kernel's variants the one without energy / virial outputs comes first: the step between two records)
+        cand = sorted((row for row in rows if key in row["kernel"]), key=lambda r: -int(r["dispatches"]))
+        return float(cand[0]["sum_per_dispatch"]) if cand else None
+    sc, fo = first("nepmi_force_scatter"), first("ForceFoldBody")
+    if sc is not None and fo is not None:
+        out["force_assemble"] = sc + fo
     for key, name in NAMES:
         if name in out:
             continue

@@ -55,6 +55,9 @@ def run_rank(out_dir, spec, rank, world, make_transport, stream=None):
              drv.dev(np.ascontiguousarray(vel.reshape(3, n)[:, mine]).reshape(-1)), drv.dev(ids))
     if "overlap" in spec:
         md.set_overlap(spec["overlap"])
+    if spec.get("force_form") is not None:  # the local engine's force-assembly form (systems below the run loops' size rule)
+        e = md.lib.nepmi_dist_engine(md.handle)
+        md._ck(md.lib.nepmi_engine_set_force_form(e, int(spec["force_form"])))
     if spec.get("seed") is not None:
         md.bdp_seed(spec["seed"])
         md.lan_seed(spec["seed"])

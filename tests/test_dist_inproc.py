@@ -146,7 +146,7 @@ def test_reverse_exchange_overlapped_with_the_interior_bricks_on_gpu():
     if not os.path.exists(LIB["gpu"]):
         pytest.skip("tests/inproc transports not built")
     import test_dist as T
-    spec = T._spec("gpu", "PbTe-reps", (12, 8, 8), (2, 1, 1), "nve", 12, 1500.0, ghosts=1)
+    spec = dict(T._spec("gpu", "PbTe-reps", (12, 8, 8), (2, 1, 1), "nve", 12, 1500.0, ghosts=1), force_form=1)
     a = _run_threads(2, dict(spec, overlap=True))
     b = _run_threads(2, dict(spec, overlap=False))
     assert all(int(r["nrev"]) >= 6 for r in a) and all(int(r["nrev"]) == 0 for r in b)
