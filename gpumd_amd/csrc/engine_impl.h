@@ -1676,7 +1676,10 @@ private:
     // Fewer bricks than workgroup places on the chip (three per CU): both forms then take one brick's latency, and the scatter
     // form has a second launch (the fold) on top -- 128,000 PbTe atoms (512 bricks): 4.7e8 atom-steps/s against 4.8e8 for the
     // gather form, 250,000 atoms (1,000 bricks): 6.07e8 against 5.9e8 (profiles/r4p_size_sweep.txt).  A counted rule.
-    if (force_form_ < 0 && num_bricks_ < kScatterMinBricks)
+    // (With reverse-mode ghosts the scatter form is kept at every size: there the ghosts have no own pair halves and skip the
+    // assembly altogether, where the gather form runs it on them in full -- 8 ranks sharing a GPU, 1 M atoms: 3.30 against
+    // 3.53 ms per step, profiles/r4l_strong8_g1_ov0.json / r4z_inproc_strong8_g1.json.)
+    if (force_form_ < 0 && num_bricks_ < kScatterMinBricks && !reverse_ghosts_)
       return false;
     if (S::TS > 0)
       return 24 * (size_t)(win_.wmax + 4) <= B::kMaxLdsBytes;
@@ -1862,6 +1865,8 @@ public:
     s += last_scatter_form_ ? " force_assembly=lds_scatter_of_own_halves(fixed_point)+fold" :
          last_rows_form_ ? " force_assembly=table_rows_in_lds"
                          : (last_fpj_form_ ? " force_assembly=neighbour_half_from_fp_rows" : " force_assembly=table_rows_gathered");
+    if (tile_ok_)
+      s += " bricks=" + std::to_string(num_bricks_) + " window_slots=" + std::to_string(win_.wmax);
     return s;
   }
   // frozen != nullptr: a speculatively enqueued step of a fused run loop -- every kernel of the force path looks at

@@ -310,9 +310,13 @@ int nepmi_dist_run(
 int nepmi_dist_thermo(nepmi_dist* d, double thermo8_host[8]);
 int nepmi_dist_bdp_seed(nepmi_dist* d, uint64_t seed);
 /* Langevin thermostats of a decomposed run (ensembles 4 and 5 of nepmi_dist_run = `ensemble nvt_lan` / `nvt_bao`): the seed of the
- * per-atom generators, the same value on every rank (the reference seeds them with rand(), ensemble_lan.cu:39).  State s belongs
- * to the atom with global id s exactly as in the single-domain nepmi_run_nvt_lan, so the noise of an atom does not depend on the
- * decomposition: every rank carries all states, kicks the atoms it owns and advances the others. */
+ * per-atom generators, the same value on every rank (the reference seeds them with rand(), ensemble_lan.cu:39).  The state of the
+ * atom with global id s is hiprand_init(seed, s, 0) exactly as in the single-domain nepmi_run_nvt_lan, so the noise of an atom does
+ * not depend on the decomposition.  A rank holds the states of the atoms it OWNS only (48 bytes each); they travel with the atom's
+ * record when it migrates (memory and work per rank are O(N_local), no collective beyond the momentum sums).  The ids of
+ * nepmi_dist_setup only seed the generators and label the gathered output -- nothing on the device is indexed by them during a run
+ * (nepmi_dist_gather_global, which is, checks them and returns -4) -- but two atoms with the same id would draw the same noise:
+ * ids must be unique over the ranks. */
 int nepmi_dist_lan_seed(nepmi_dist* d, int seed);
 /* on: the radial pass of the interior bricks (no ghost in their 8x8x8-cell window) is enqueued on the compute stream while the
  * skin vote and the ghost positions travel on a communication stream; off (default since round 3): the plain
@@ -335,7 +339,11 @@ int nepmi_dist_set_overlap(nepmi_dist* d, int on);
  *     atoms per owned one for a 1 M-atom PbTe cell on 2 x 2 x 2 ranks -- the form for strong scaling.  NEP models only;
  *  -1 (default) the counted rule: reverse when the forward shell would leave less than 70 % of the local atoms owned at
  *     uniform density (volume of the sub-box / volume of its padded box), or when the sub-box is thinner than the forward
- *     shell.  Per-atom virials of nepmi_dist_gather_* are completed by one extra reverse exchange when asked for. */
+ *     shell.  Per-atom virials of nepmi_dist_gather_* are completed by one extra reverse exchange when asked for.
+ * Environment read by the library (experiments and A/B runs; an embedding application that must not be steered from outside calls
+ * nepmi_dist_set_ghost_mode / nepmi_dist_set_overlap explicitly, which take precedence): NEPMI_DIST_GHOSTS=forward|reverse replaces
+ * the counted rule of mode -1 when the context is created; NEPMI_RCCL_FUSE_VOTE=1 makes the RCCL transport carry the skin vote
+ * inside the ghost exchange's group (NEPMI_DT_DEFER); NEPMI_DIST_TRACE prints the stages of a re-decomposition to stderr. */
 int nepmi_dist_set_ghost_mode(nepmi_dist* d, int mode);
 typedef struct {
   int64_t n_owned, n_local, n_total; /* atoms owned by this rank, owned + ghosts, in the whole system */
@@ -352,9 +360,12 @@ int nepmi_dist_info_bytes(void);
  * nepmi_dist_set_overlap(1)): the boundary bricks and the ghosts' fold first, the reverse exchange on the communication stream */
 int64_t nepmi_dist_num_overlapped_reverse(nepmi_dist* d);
 /* The owned atoms of this rank (n_owned entries per plane, global coordinates) into the caller's DEVICE arrays;
- * any pointer may be NULL.  With reverse-mode ghosts (nepmi_dist_set_ghost_mode) a non-NULL `virial` makes the call
- * collective -- every rank has to ask for the virials in the same call, the halves computed on other ranks' ghosts come
- * home through one more reverse exchange. */
+ * any pointer may be NULL.  With reverse-mode ghosts (nepmi_dist_set_ghost_mode -- also when the counted rule picked them)
+ * the call is COLLECTIVE whatever the arguments: every rank has to make it, the virial halves computed on other ranks'
+ * ghosts come home through one more reverse exchange (once per force evaluation) whether or not this rank passes `virial`.
+ * Per-atom virials are the reference's attribution (a virial-only pass of the gather form after scatter-form steps).
+ * ids (nepmi_dist_setup) have to be unique; nepmi_dist_gather_global additionally needs them to be 0 .. n_total - 1.  The
+ * Langevin generator of an atom is created from (seed, id) and travels with the atom: no array is indexed by an id. */
 int nepmi_dist_gather_owned(
   nepmi_dist* d, int64_t* ids, double* pos, double* vel, double* force, double* pe, double* virial);
 /* Every atom of the system on rank `root`, ordered by global id (which must be 0 .. n_total-1, the default): DEVICE
