@@ -392,38 +392,6 @@ nepmi_win2_kernel(const Body body, const int64_t nbricks)
     body.compute(brick, k, lds);
 }
 
-// Static layout, NB bricks per workgroup of NB x 256 threads: every 256-thread group stages and runs its own brick's window, one
-// coefficient table (many-type shapes) behind the windows serves them all (RadialWin2Body::share).
-template <class Body, int NB>
-__global__ void __launch_bounds__(kWinThreads * NB) nepmi_win2_kernel_shared(const Body body, const int64_t nbricks)
-{
-  extern __shared__ __attribute__((aligned(16))) char nepmi_win_lds[];
-  NEPMI_LDS(char)* lds = (NEPMI_LDS(char)*)nepmi_win_lds;
-  if (body.skip())
-    return;
-  const int64_t groups = (nbricks + NB - 1) / NB;
-  const unsigned per_xcd = gridDim.x >> 3;
-  const int64_t wg = (int64_t)(blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
-  if (wg >= groups)
-    return;
-  const int sub = (int)threadIdx.x / kWinThreads, tid = (int)threadIdx.x % kWinThreads;
-  const int64_t bi = wg * NB + sub;
-  const bool have = bi < nbricks;
-  const int64_t brick = have ? body.map_brick(bi) : 0;
-  NEPMI_LDS(char)* win = lds + sub * body.win_bytes();
-  NEPMI_LDS(char)* tab = lds + NB * body.win_bytes();
-  if (have)
-    body.stage_window(brick, win, tid, kWinThreads);
-  body.stage_table(tab, (int)threadIdx.x, kWinThreads * NB);
-  __syncthreads();
-  if (!have)
-    return;
-  int64_t a0, a1;
-  body.brick_range(brick, a0, a1);
-  for (int64_t k = a0 + tid; k < a1; k += kWinThreads)
-    body.compute_with(brick, k, win, tab);
-}
-
 // Static layout with Body::kLanes lanes per atom and a second staging phase (ForceWinBody<..., ROWS>: the table rows of the
 // window atoms behind the records): 256 kLanes threads, one workgroup per CU when the rows fill the LDS.
 template <class Body>
@@ -1191,38 +1159,6 @@ struct HipBackend {
     NEPMI_HIP_CHECK(hipGetLastError());
     if (t)
       timer_stop(timing->slot[slot]);
-  }
-
-  template <class Body, int NB>
-  void launch_win2_shared_nb(int slot, int64_t nbricks, const Body& body)
-  {
-    const int64_t groups = (nbricks + NB - 1) / NB;
-    const int64_t grid = (groups + 7) / 8 * 8;
-    const size_t lds_bytes = ((size_t)body.shared_lds_bytes() + 15) / 16 * 16;
-    if (lds_bytes > 64 * 1024)
-      NEPMI_HIP_CHECK(hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&nepmi_win2_kernel_shared<Body, NB>), hipFuncAttributeMaxDynamicSharedMemorySize,
-        (int)lds_bytes));
-    const bool t = timed(slot);
-    if (t)
-      timer_start(timing->slot[slot]);
-    hipLaunchKernelGGL((nepmi_win2_kernel_shared<Body, NB>), dim3((unsigned)grid), dim3(kWinThreads * NB), lds_bytes, stream, body,
-                       nbricks);
-    NEPMI_HIP_CHECK(hipGetLastError());
-    if (t)
-      timer_stop(timing->slot[slot]);
-  }
-  // body.share (2..4) bricks per workgroup, one coefficient table for them
-  template <class Body>
-  void launch_win2_shared(int slot, int64_t nbricks, const Body& body)
-  {
-    if (nbricks <= 0)
-      return;
-    switch (body.share) {
-      case 2: launch_win2_shared_nb<Body, 2>(slot, nbricks, body); break;
-      case 3: launch_win2_shared_nb<Body, 3>(slot, nbricks, body); break;
-      default: launch_win2_shared_nb<Body, 4>(slot, nbricks, body); break;
-    }
   }
 
   template <class Body>

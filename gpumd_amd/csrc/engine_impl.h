@@ -938,9 +938,6 @@ private:
     b_.nn_ang = dalloc<int>(N);
     b_.nl_ang = dalloc<int>((size_t)b_.MN_ang * N);
     b_.code_ang = dalloc<unsigned short>((size_t)b_.MN_ang * N);
-    b_.toff = nullptr;
-    if (NEPMI_SORT_TYPES && m.kind == 0 && m.num_types > 2 && m.num_types <= kSortTypesMax && b_.MN_ang <= kSortRowMax)
-      b_.toff = dalloc<unsigned short>((size_t)(m.num_types + 1) * N); // many types: lists ordered by type (SortListsByTypeBody)
     b_.rev_ang = dalloc<unsigned short>((size_t)b_.MN_ang * N);
     b_.nn_rad = dalloc<int>(N);
     b_.nn_angstep = dalloc<int>(N);
@@ -960,7 +957,7 @@ private:
       be_.ann_prepare(md_, b_);
       b_.pe_i = dalloc<float>(N);
       b_.MN_rad = m.MN_radial;
-      b_.ccode = dalloc<unsigned short>((size_t)(b_.MN_rad + 1) * N); // (+ the trash plane of RadialWin2Body's branch-free pushes)
+      b_.ccode = dalloc<unsigned short>((size_t)b_.MN_rad * N);
       b_.nn_t0 = dalloc<int>(N);
       b_.prec = dalloc<WinRec>(N);
       b_.aidx = dalloc<unsigned short>((size_t)b_.MN_acomp * N);
@@ -1262,8 +1259,6 @@ private:
       be_.template launch<256>(kSlotMisc, N_, TypeFillBody{b_, model_.num_types});
     }
     be_.template launch<128>(kSlotMisc, N_, BuildListsBody{box_, b_});
-    if (b_.toff)
-      be_.template launch<64>(kSlotMisc, N_, SortListsByTypeBody{b_, model_.num_types});
     be_.template launch<128>(kSlotMisc, N_, ReverseSlotsBody{box_, b_});
     be_.memset(b_.flags + kFlagMaxWindow, 0, 3 * sizeof(int));
     num_bricks_ = (int64_t)b_.gbx * b_.gby * b_.gbz;
@@ -1586,14 +1581,7 @@ private:
     const WinStage ws2{box_, b_, lay2};
     B& rbe = radial_side_ ? *radial_side_ : be_; // (force_kernels_on: the boundary bricks on the communication stream)
     auto radial = [&](int64_t nb, int first) {
-      if (win2 && radial_share<S>(ws2) > 1) {
-        if constexpr (S::TS == 0 && S::fixed) {
-          RadialWin2Body<S, NEPMI_RW_SHARE_VEC != 0> body{ws2, md_, first, frozen};
-          body.share = radial_share<S>(ws2);
-          last_radial_share_ = body.share;
-          rbe.launch_win2_shared(kSlotRadial, nb, body);
-        }
-      } else if (win2)
+      if (win2)
         rbe.launch_win2(kSlotRadial, nb, RadialWin2Body<S>{ws2, md_, first, frozen});
       else if (lanes == 4)
         rbe.launch_win_split(kSlotRadial, nb, RadialWinSplitBody<S, 4>{ws, md_, first, frozen});
@@ -1678,24 +1666,6 @@ private:
   // Force assembly as an LDS-local scatter of the own pair halves (nep_scatter.h): the static window layout with one lane per
   // atom, shapes with register-resident per-type rows, a device backend; in the run loops (or wherever set_force_form(1)
   // asks for it) and until a pair half has left the fixed-point guard band (flags[kFlagRange]).  A counted rule.
-  // Many-type shapes on the static window layout: how many bricks share one workgroup and one coefficient table of 16-byte blocks in
-  // the radial pass (RadialWin2Body::share; 0: the one-brick form).  A counted rule: as many windows as fit next to the table, at
-  // most four (1024 threads), and only where that holds more wavefronts per CU than the one-brick form does.
-  template <class S>
-  int radial_share(const WinStage& ws2) const
-  {
-    if (S::TS > 0 || !S::fixed || !radial_share_on_ || !NEPMI_RW_SHARE)
-      return 0;
-    RadialWin2Body<S, NEPMI_RW_SHARE_VEC != 0> v{ws2, md_, -1, nullptr};
-    const int64_t tab = 4 * (int64_t)v.ctab_floats(), win = v.win_bytes();
-    int nb = (int)(((int64_t)B::kMaxLdsBytes - tab) / win);
-    nb = nb > 4 ? 4 : nb;
-    RadialWin2Body<S> one{ws2, md_, -1, nullptr};
-    const int per_cu_one = one.ctab_on() ? (int)((int64_t)B::kMaxLdsBytes / one.lds_bytes()) : 0;
-    if (nb < 2 || (per_cu_one > 0 && nb <= (per_cu_one > 4 ? 4 : per_cu_one)))
-      return 0;
-    return nb;
-  }
   template <class S>
   bool scatter_wanted(const WinStage& ws2) const
   {
@@ -1895,8 +1865,6 @@ public:
     s += last_scatter_form_ ? " force_assembly=lds_scatter_of_own_halves(fixed_point)+fold" :
          last_rows_form_ ? " force_assembly=table_rows_in_lds"
                          : (last_fpj_form_ ? " force_assembly=neighbour_half_from_fp_rows" : " force_assembly=table_rows_gathered");
-    if (last_radial_share_ > 1)
-      s += " radial_pass=" + std::to_string(last_radial_share_) + "_bricks_per_workgroup_around_one_table";
     if (tile_ok_)
       s += " bricks=" + std::to_string(num_bricks_) + " window_slots=" + std::to_string(win_.wmax);
     return s;
@@ -1965,8 +1933,6 @@ private:
   bool use_rmask_ = false;       // set_radial_mask (off: on PbTe 1 M atoms the radial pass gains what the force assembly's lockstep
                                  // walk over all candidates loses -- profiles/r4q_ab_mask.txt)
   bool last_mask_form_ = false;
-  int last_radial_share_ = 0;
-  bool radial_share_on_ = true;  // many types: several bricks per workgroup around one coefficient table (radial_share)
   bool ccode_valid_ = true;      // the compact radial list of the last force evaluation exists (else: the masks, Bufs::rmaskB)
   bool step_outputs_ = true;     // set_step_outputs
   int assembly_part_ = 0;        // set_assembly_part

@@ -112,11 +112,6 @@ struct Bufs {
   int* nn_skin;  int* nl_skin;                          // B: [MN_skin][N]
   unsigned short* code_ang;  // A: window code (window cell << 7 | rank in cell) of each entry
   unsigned short* code_skin; // B: the same; used by the LDS-window radial pass
-  // Many-type models: both lists of every atom are ordered by the neighbour's type (SortListsByTypeBody; inside a type the
-  // order of the build, i.e. ascending window codes), so that the kernels which contract a coefficient block c[t_i][t_j] per
-  // neighbour meet runs of one block.  toff[t N + k], t = 0 .. T: first entry of type t in list A of atom k (toff[T] = its
-  // length); nullptr: lists in build order.
-  unsigned short* toff;
   // per step
   int* nn_rad;   F4* rstash;   // pair records (r12, j | t2 << 25 or -1) at rows [A slots | MN_ang + B slots]
   int* nn_angstep; F4* acomp;  // compacted angular pair records [MN_acomp][N]
@@ -772,54 +767,6 @@ struct BuildListsBody {
   }
 };
 
-// Many types: lists A and B of atom k reordered by the type of the neighbour, stable (counting sort over the row, which is
-// copied to the stack first); list A's segment starts go to Bufs::toff for ReverseSlotsBody's search.  Rows longer than
-// kSortRowMax stay in build order: list B only (list A is at most 256 entries wherever toff is allocated).
-#ifndef NEPMI_SORT_TYPES
-#define NEPMI_SORT_TYPES 1
-#endif
-constexpr int kSortRowMax = 256;
-constexpr int kSortTypesMax = 64;
-struct SortListsByTypeBody {
-  Bufs b;
-  int T;
-  NEPMI_HD void sort_row(int* nl, unsigned short* code, int n, int64_t k, unsigned short* toff) const
-  {
-    const int64_t N = b.N;
-    int jj[kSortRowMax];
-    unsigned short cc[kSortRowMax];
-    unsigned char tt[kSortRowMax];
-    int start[kSortTypesMax + 1];
-    for (int t = 0; t <= T; ++t)
-      start[t] = 0;
-    for (int s = 0; s < n; ++s) {
-      jj[s] = nl[(int64_t)s * N + k];
-      cc[s] = code[(int64_t)s * N + k];
-      const int t = b.posq[jj[s]].type;
-      tt[s] = (unsigned char)t;
-      ++start[t + 1];
-    }
-    for (int t = 0; t < T; ++t)
-      start[t + 1] += start[t];
-    if (toff)
-      for (int t = 0; t <= T; ++t)
-        toff[(int64_t)t * N + k] = (unsigned short)start[t];
-    for (int s = 0; s < n; ++s) {
-      const int pos = start[tt[s]]++;
-      nl[(int64_t)pos * N + k] = jj[s];
-      code[(int64_t)pos * N + k] = cc[s];
-    }
-  }
-  NEPMI_HD void operator()(int64_t k) const
-  {
-    const int na = b.nn_ang[k] < b.MN_ang ? b.nn_ang[k] : b.MN_ang;
-    const int nb = b.nn_skin[k] < b.MN_skin ? b.nn_skin[k] : b.MN_skin;
-    sort_row(b.nl_ang, b.code_ang, na, k, b.toff);
-    if (nb <= kSortRowMax)
-      sort_row(b.nl_skin, b.code_skin, nb, k, nullptr);
-  }
-};
-
 // Work order of the ANN kernel: atoms grouped by type inside chunks of 1024 consecutive atoms, so
 // that a wavefront holds (almost always) one type and runs the network once, with that type's
 // weights as scalar operands -- instead of once per type present (16x for the 16-metal UNEP model).
@@ -917,11 +864,6 @@ struct ReverseSlotsBody {
         const int wc = (((jz & 3) + 2 + dz) << 6) | (((jy & 3) + 2 + dy) << 3) | ((jx & 3) + 2 + dx);
         const unsigned target = (unsigned)((wc << 7) | rank);
         int lo = 0, hi = (nj < b.MN_ang ? nj : b.MN_ang) - 1;
-        if (b.toff) { // lists ordered by type: the codes ascend inside the segment of k's type
-          const int tk = b.posq[k].type;
-          lo = b.toff[(int64_t)tk * N + j];
-          hi = (int)b.toff[(int64_t)(tk + 1) * N + j] - 1;
-        }
         while (lo < hi) {
           const int mid = (lo + hi) >> 1;
           if ((unsigned)b.code_ang[(int64_t)mid * N + j] < target)

@@ -665,25 +665,6 @@ struct RadialWinBody {
                    // no pipeline) vs 0.508 (words, pipelined, 3 waves) vs 1.02 (4 waves: the two stages spill); carbon 0.79 ->
                    // 0.98.  Off.
 #endif
-#ifndef NEPMI_RW_SHARE
-#define NEPMI_RW_SHARE 0 // 1: many-type shapes: several bricks per workgroup around one coefficient table (RadialWin2Body::share).
-                         // Measured on UNEP-v1 1 M atoms (profiles/r4aa_ab_unep_share.txt): radial pass 1.163 ms one brick per workgroup
-                         // (two 4-wave workgroups per CU), 1.158 three bricks + 16-byte blocks, 1.146 three bricks + 4-byte reads:
-                         // neither the occupancy nor the read width is what binds it (the table's bank conflicts are: 64 lanes
-                         // read the same element of up to 64 different blocks).  Off.
-#endif
-#ifndef NEPMI_RW_SHARE_VEC
-#define NEPMI_RW_SHARE_VEC 1 // ... whose blocks are read with 16-byte ds_reads
-#endif
-#ifndef NEPMI_RW2_RUNS
-#define NEPMI_RW2_RUNS 1 // many types: contract the radial coefficient block once per run of neighbours of one type (RadialWin2Body)
-#endif
-#ifndef NEPMI_RW2_PUSH
-#define NEPMI_RW2_PUSH 0 // 1: branch-free pushes of the compact radial list into cursor-or-trash places (RadialWin2Body), 0: the nested-if
-                         // form.  Measured (profiles/r4ad_ab_radial_push.txt): PbTe 1 M radial pass 0.362 ms nested ifs, 0.375 branch-free;
-                         // carbon 4 M 3.29 / 3.40 -- every candidate then issues a store, and the pass pays per store instruction
-                         // and cache line touched (lanes of a wavefront sit at different list rows), not per branch.  Off.
-#endif
 #ifndef NEPMI_RW2_ABL
 #define NEPMI_RW2_ABL 0 // ablation builds (timings only): 1 = no compact-list stores, 2 = no stores and no counters
 #endif
@@ -694,40 +675,18 @@ struct alignas(8) U2w { // four 16-bit LDS slots
   unsigned lo, hi;
 };
 
-// CV (many-type shapes): the coefficient blocks are read with 16-byte ds_reads (block stride ctab_block(.., true)); only in the
-// shared form below, where one copy of the table serves `share` bricks.
-template <class S, bool CV = false>
+template <class S>
 struct RadialWin2Body {
   WinStage st;
   ModelD m;
   int first;         // workgroup w runs brick_order[first + w] (first < 0: brick w)
   const int* frozen;
-  // Shared form (many types; nepmi_win2_kernel_shared): one workgroup of `share` x 256 threads runs `share` bricks, each with its own
-  // window, and ONE coefficient table behind the windows.  UNEP-v1: 34.8 KB window + 45 KB table = 80 KB per brick allow two
-  // 4-wave workgroups per CU (2 waves per SIMD; the vector units issue 30 % of the time: profiles/r4z_unep_pmc_sq1.csv); three
-  // windows + one table with 16-byte blocks (52 KB) = 157 KB: 3 waves per SIMD and a quarter of the table's read instructions.
-  int share = 0;
   static constexpr int kMinWavesPerEu = NEPMI_RW2_WAVES;
 
-  NEPMI_HD int ctab_floats() const { return S::TS > 0 ? 0 : m.T * m.T * ctab_block(m.NR, m.KR, CV); }
+  NEPMI_HD int ctab_floats() const { return S::TS > 0 ? 0 : m.T * m.T * ctab_block(m.NR, m.KR, false); }
   NEPMI_HD int ctab_offset() const { return (st.lay.bytes() + 15) / 16 * 16; }
-  NEPMI_HD int win_bytes() const { return ctab_offset(); }
-  NEPMI_HD int shared_lds_bytes() const { return share * win_bytes() + 4 * ctab_floats(); }
-  NEPMI_HD bool ctab_on() const
-  {
-    return share > 0 || (NEPMI_RW_CTAB && S::TS == 0 && ctab_offset() + 4 * ctab_floats() <= 80 * 1024);
-  }
+  NEPMI_HD bool ctab_on() const { return NEPMI_RW_CTAB && S::TS == 0 && ctab_offset() + 4 * ctab_floats() <= 80 * 1024; }
   NEPMI_HD int lds_bytes() const { return ctab_on() ? ctab_offset() + 4 * ctab_floats() : st.lay.bytes(); }
-  template <class LC>
-  NEPMI_HD void stage_window(int64_t brick, LC win, int tid, int nth) const
-  {
-    st.stage_direct(brick, win, tid, nth);
-  }
-  template <class LC>
-  NEPMI_HD void stage_table(LC tab, int tid, int nth) const
-  {
-    ctab_stage_padded(m, tab, tid, nth, CV);
-  }
   NEPMI_HD int64_t map_brick(int64_t w) const { return first < 0 ? w : (int64_t)st.b.brick_order[first + w]; }
   NEPMI_HD bool skip() const { return frozen && *frozen != 0; }
   template <class LC>
@@ -735,18 +694,12 @@ struct RadialWin2Body {
   {
     st.stage_direct(brick, lds, tid, nth);
     if (ctab_on())
-      ctab_stage_padded(m, lds + ctab_offset(), tid, nth, CV);
+      ctab_stage_padded(m, lds + ctab_offset(), tid, nth, false);
   }
   NEPMI_HD void brick_range(int64_t brick, int64_t& a0, int64_t& a1) const { st.brick_range(brick, a0, a1); }
 
   template <class LC>
   NEPMI_HD void compute(int64_t brick, int64_t k, LC lds) const
-  {
-    compute_with(brick, k, lds, lds + ctab_offset());
-  }
-  // lds: the brick's window; tab: the coefficient table (many-type shapes with ctab_on())
-  template <class LC>
-  NEPMI_HD void compute_with(int64_t brick, int64_t k, LC lds, LC tab) const
   {
     const Bufs& b = st.b;
     const int64_t N = b.N;
@@ -757,7 +710,7 @@ struct RadialWin2Body {
     }
     NEPMI_LDS(const WinRec)* wrec = (NEPMI_LDS(const WinRec)*)(lds + st.lay.off_rec());
     const bool ctab = ctab_on();
-    NEPMI_LDS(const float)* ctab_lds = (NEPMI_LDS(const float)*)tab;
+    NEPMI_LDS(const float)* ctab_lds = (NEPMI_LDS(const float)*)(lds + ctab_offset());
     const int NR = S::fixed ? S::NR : m.NR;
     const int KR = S::fixed ? S::KR : m.KR;
     const PosQ p1 = b.posq[k];
@@ -837,28 +790,10 @@ struct RadialWin2Body {
     U2w* __restrict__ cword = reinterpret_cast<U2w*>(b.cword) + k;
     unsigned long long accf = 0ull, accb = 0ull;
     unsigned mcur = 0u; // the mask word being filled (Bufs::rmaskA / rmaskB)
-    // Branch-free form (NEPMI_RW2_PUSH 1; measured slower, see the macro): EVERY candidate stores -- an inside one at the cursor of its stream, the
-    // others (and atoms that keep no list, and entries beyond MN_rad) into the trash plane ccode[MN_rad] -- and the cursor moves
-    // by N or 0.  The plain form `if (inside) { if (room) store; ++cnt; }` compiles to two nested exec-mask regions per
-    // candidate, placed out of line: two taken branches, two spilled-SGPR reloads and a 64-bit multiply per push (ISA of round 4;
-    // profiles/r4m_ab_radial_stores.txt: the radial pass without its stores 0.285 ms against 0.372).
-    unsigned short* pf = ccode;                                    // cursor of the front stream
-    unsigned short* pb = ccode + (int64_t)(b.MN_rad - 1) * N;      // ... of the back stream (moves down)
-    unsigned short* const trash = ccode + (int64_t)b.MN_rad * N;   // plane MN_rad: never read
     auto push_front = [&](const Cand& c, const int bit) __attribute__((always_inline)) {
       if (b.use_rmask) {
         mcur |= c.inside ? (1u << bit) : 0u;
         cnt += c.inside ? 1 : 0;
-        return;
-      }
-      if (NEPMI_RW2_PUSH && !NEPMI_CW) {
-        const bool st = c.inside && owned && cnt + cnt1 < b.MN_rad;
-        unsigned short* const q = st ? pf : trash;
-        if (NEPMI_RW2_ABL == 0)
-          *q = (unsigned short)c.slot;
-        pf += c.inside ? N : (int64_t)0;
-        if (NEPMI_RW2_ABL < 2)
-          cnt += c.inside ? 1 : 0;
         return;
       }
       if (c.inside) {
@@ -885,16 +820,6 @@ struct RadialWin2Body {
       if (b.use_rmask) {
         mcur |= c.inside ? (1u << bit) : 0u;
         cnt1 += c.inside ? 1 : 0;
-        return;
-      }
-      if (NEPMI_RW2_PUSH && !NEPMI_CW) {
-        const bool st = c.inside && owned && cnt + cnt1 < b.MN_rad;
-        unsigned short* const q = st ? pb : trash;
-        if (NEPMI_RW2_ABL == 0)
-          *q = (unsigned short)c.slot;
-        pb -= c.inside ? N : (int64_t)0;
-        if (NEPMI_RW2_ABL < 2)
-          cnt1 += c.inside ? 1 : 0;
         return;
       }
       if (c.inside) {
@@ -961,41 +886,7 @@ struct RadialWin2Body {
       fc = fc * mk2(c0.inside ? 1.0f : 0.0f, c1.inside ? 1.0f : 0.0f);
       basis_fn_v<S::KRM>(rcinv, dc, fc, fn);
     };
-    // One-wide accumulation with the coefficients contracted per RUN of neighbours of one type (many types / run-time shape):
-    // q[n] += sum_k c[t_i][t_j][n][k] (sum over the run of f_k(r)).  The lists are ordered by type (Bufs::toff,
-    // SortListsByTypeBody), so an atom contracts ~T blocks per list instead of one per neighbour -- the table reads are what
-    // binds this kernel for UNEP-v1 (64 lanes read the same element of different blocks: two thirds of the LDS cycles are bank
-    // conflicts, profiles/r4ac_unep_pmc_lds.csv); in build order every run has one member and nothing changes.
-    int tcur = -1;
-    float Sk[S::KRM + 1];
-#pragma unroll
-    for (int kk = 0; kk <= S::KRM; ++kk)
-      Sk[kk] = 0.0f;
-    auto run_flush = [&]() __attribute__((always_inline)) {
-      if (tcur < 0)
-        return;
-      if (ctab) {
-        float g[S::NRM + 1];
-        ctab_contract<S, CV>(ctab_lds + (t1 * m.T + tcur) * ctab_block(NR, KR, CV), NR, KR, Sk, g);
-#pragma unroll
-        for (int n = 0; n <= S::NRM; ++n) {
-          if (!S::fixed && n > NR)
-            break;
-          q[n] += g[n];
-        }
-      } else {
-        const float* cc = m.c_rad + (t1 * m.T + tcur) * (NR + 1) * (KR + 1);
-        for (int n = 0; n <= NR; ++n) {
-          float gsum = 0.0f;
-          for (int kk = 0; kk <= KR; ++kk)
-            gsum += Sk[kk] * cc[n * (KR + 1) + kk];
-          q[n] += gsum;
-        }
-      }
-#pragma unroll
-      for (int kk = 0; kk <= S::KRM; ++kk)
-        Sk[kk] = 0.0f;
-    };
+    // one-wide accumulation with the coefficients contracted per pair (many types / run-time shape)
     auto accumulate1 = [&](const Cand& c) __attribute__((always_inline)) {
       if (!c.inside)
         return;
@@ -1012,20 +903,9 @@ struct RadialWin2Body {
         basis_fn<S::KRM>(rcinv, dc, fc, fn);
       else
         basis_fn_rt(KR, rcinv, dc, fc, fn);
-      if (NEPMI_RW2_RUNS) {
-        if (t2 != tcur) {
-          run_flush();
-          tcur = t2;
-        }
-#pragma unroll
-        for (int kk = 0; kk <= S::KRM; ++kk)
-          if (S::fixed || kk <= KR)
-            Sk[kk] += fn[kk];
-        return;
-      }
       if (ctab) {
         float g[S::NRM + 1];
-        ctab_contract<S, CV>(ctab_lds + (t1 * m.T + t2) * ctab_block(NR, KR, CV), NR, KR, fn, g);
+        ctab_contract<S, false>(ctab_lds + (t1 * m.T + t2) * ctab_block(NR, KR, false), NR, KR, fn, g);
 #pragma unroll
         for (int n = 0; n <= S::NRM; ++n) {
           if (!S::fixed && n > NR)
@@ -1243,8 +1123,6 @@ struct RadialWin2Body {
       }
     }
 
-    if (S::TS == 0)
-      run_flush();
     flush_words();
     if (ca > b.MN_acomp || cnt + cnt1 > b.MN_rad) {
       NEPMI_ATOMIC_OR(&b.flags[kFlagOverflow], 4);

@@ -129,29 +129,6 @@ struct HostLoopBackend {
     }
   }
 
-  // body.share bricks per "workgroup" with one coefficient table behind their windows (nepmi_win2_kernel_shared)
-  template <class Body>
-  void launch_win2_shared(int, int64_t nbricks, const Body& body)
-  {
-    if (body.skip())
-      return;
-    std::vector<double> raw((size_t)body.shared_lds_bytes() / 8 + 8);
-    char* lds = reinterpret_cast<char*>(raw.data());
-    lds += (16 - reinterpret_cast<uintptr_t>(lds) % 16) % 16; // (16-byte blocks of the table)
-    const int NB = body.share;
-    char* tab = lds + (size_t)NB * body.win_bytes();
-    body.stage_table(tab, 0, 1);
-    for (int64_t bi = 0; bi < nbricks; ++bi) {
-      const int64_t brick = body.map_brick(bi);
-      char* win = lds + (size_t)(bi % NB) * body.win_bytes();
-      body.stage_window(brick, win, 0, 1);
-      int64_t a0, a1;
-      body.brick_range(brick, a0, a1);
-      for (int64_t k = a0; k < a1; ++k)
-        body.compute_with(brick, k, win, tab);
-    }
-  }
-
   // ... with the second staging phase of the bodies that keep the neighbours' table rows in "LDS"; the host loop runs one lane
   template <class Body>
   void launch_win2_split(int, int64_t nbricks, const Body& body)
