@@ -301,6 +301,18 @@ def kernel_report(st, info, n_atoms_per_launch, st_all=None, tersoff=False):
                 ran = int(src.launches[k]) - (int(src.discarded_steps) if 1 <= k <= 6 else 0)
                 ran = max(ran, 1)
                 kern[name] = {"launches": ran, "avg_ms": src.ms_kernel_sum[k] / ran}
+    # every kernel priced the same way as the roofline object below: algorithmic bytes / duration / HBM peak, and (where the
+    # builder's PMC pass matches this workload size) the counter traffic beside it
+    tj_all = {}
+    tfile_all = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    if os.path.exists(tfile_all):
+        tj_all = json.load(open(tfile_all))
+    for name, e in kern.items():
+        if name in per_kernel and e["avg_ms"] > 0.0:
+            e["algorithmic_bytes_per_atom"] = per_kernel[name]
+            e["frac"] = per_kernel[name] * n_atoms_per_launch / (e["avg_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+            if tj_all.get("atoms") == n_atoms_per_launch and name in tj_all.get("kernels", {}):
+                e["traffic"] = tj_all["kernels"][name]["hbm_bytes_per_launch"]
     force_kernels = [k for k in kern if k in per_kernel and k not in ("velocity_verlet", "gather_skin_check")]
     dom = max(force_kernels, key=lambda k: kern[k]["avg_ms"] * kern[k]["launches"]) if force_kernels else None
     roofline = None
