@@ -103,6 +103,15 @@ public:
   EngineT(const NepModel& model, int64_t n_atoms, B backend) : model_(model), be_(backend), cap_(n_atoms), N_(n_atoms)
   {
     std::memset(&b_, 0, sizeof(b_));
+    b_.scatter_limit = 64.0f;   // nep_scatter.h: kScatterFlagLimit
+    b_.fold_guard = 1 << 30;    // kFoldGuard
+    if (const char* g = std::getenv("NEPMI_SCATTER_GUARD")) { // tests: a guard band low enough for ordinary forces to leave it
+      const double v = std::atof(g);
+      if (v > 0.0 && v <= 64.0) {
+        b_.scatter_limit = (float)v;
+        b_.fold_guard = (int)(4.0 * v * 4194304.0);
+      }
+    }
     std::memset(&md_, 0, sizeof(md_));
     std::memset(&box_, 0, sizeof(box_));
     try {
@@ -158,8 +167,25 @@ public:
       return;
     }
     force_kernels(kPhaseAll);
+    redo_outside_scatter_range();
     scatter_add(pe, force, virial);
     ++num_compute;
+  }
+
+  // A force evaluation in the scatter form met a value beyond the guard band of its fixed-point sums (nep_scatter.h): the gather
+  // form, which has no such limit, evaluates the same positions again and takes over for the rest of the run.  One read of the
+  // flag word per evaluation in that form (systems of >= kScatterMinBricks bricks).
+  void redo_outside_scatter_range()
+  {
+    if (!last_scatter_form_ || scatter_disabled_)
+      return;
+    int flag = 0;
+    be_.d2h(&flag, b_.flags + kFlagRange, sizeof(int));
+    if (!flag)
+      return;
+    scatter_disabled_ = true;
+    be_.memset(b_.flags + kFlagRange, 0, sizeof(int));
+    force_kernels(kPhaseAll);
   }
 
   // Neighbor::find_neighbor_global (neighbor.cu:741-800): gather the caller's positions into internal order,
@@ -629,7 +655,9 @@ public:
       const bool record = thermo_every > 0 && (step + 1) % thermo_every == 0;
       const bool last = step + 1 == nsteps;
       step_outputs_ = record || last; // per-atom energies and virials: read at thermo records and at the exit only
+      b_.trip_tag = tag_of(step);     // (scatter form: a force beyond its fixed-point guard band freezes the loop at this step)
       force_kernels(kPhaseAll, frozen);
+      b_.trip_tag = 0;
       bool need_sync = record || last;
       if (ens == kNve && !record && !last) {
         kick2_pending = true; // fused into the next step's pass over the atoms

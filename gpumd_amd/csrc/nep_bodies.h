@@ -211,6 +211,11 @@ struct Bufs {
   int* aseg2;
   int MA2;
   int use_rmask; // 1: this step's radial pass writes the masks instead of ccode
+  float scatter_limit; // guard band of the scatter-form assembly per pair half, eV/A (nep_scatter.h: kScatterFlagLimit)
+  int fold_guard;      // ... and per component of an atom's net force, fixed point (kFoldGuard)
+  int trip_tag;  // != 0: a speculatively enqueued step of a single-domain run loop -- a force beyond the fixed-point guard band of the
+                 // scatter-form assembly freezes the loop at this step like a skin trip (flags[kFlagMoved] = tag), and the host
+                 // re-runs the step in the gather form
   int compact_all;       // 1: every atom with level >= 1 writes its compact radial list (the scatter form walks the lists of the
                          // atoms that have descriptors, the gather form those of the atoms that receive forces)
 };

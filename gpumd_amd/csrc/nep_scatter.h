@@ -30,6 +30,7 @@
 // (sum_i sum_j r_ij (x) f21 re-indexed) but whose per-atom attribution is not; the run loops need the total only
 // (find_thermo) and the engine re-runs the gather form for the virial planes when per-atom virials leave the engine.
 #pragma once
+#include <climits>
 #include "nep_window.h"
 
 #ifndef NEPMI_FS_MT_VEC
@@ -45,6 +46,7 @@ namespace nepmi {
 constexpr float kScatterScale = 4194304.0f;             // 2^22 fixed-point units per eV/A
 constexpr double kScatterInvScale = 1.0 / 4194304.0;
 constexpr float kScatterFlagLimit = 64.0f;              // eV/A per pair half: beyond it the engine leaves this form
+constexpr int kFoldGuard = 1 << 30;                     // ... and per component of an atom's net force: 256 eV/A in fixed point
 constexpr unsigned kFoldNone = 0xFFFFFFFFu;             // unused entry of the fold map
 constexpr int kFoldSlotBits = 13;                       // fold map entry = brick << 13 | slot (windows hold <= 5,000 atoms)
 
@@ -77,6 +79,14 @@ struct ForceScatterBody {
   int first; // workgroup w runs brick brick_order[first + w] (first < 0: brick w): the boundary bricks of a decomposed run first,
              // so that the ghosts' partial forces can travel while the interior bricks run (DistT, reverse-mode ghosts)
 };
+
+// a value beyond the guard band: the engine leaves this form (check_overflow); inside a run loop the step is frozen and re-run
+__device__ __forceinline__ void scatter_range_trip(const Bufs& b)
+{
+  atomicOr(&b.flags[kFlagRange], 1);
+  if (b.trip_tag)
+    atomicCAS(&b.flags[kFlagMoved], 0, b.trip_tag);
+}
 
 __device__ __forceinline__ void lds_add(NEPMI_LDS(int)* p, int v)
 {
@@ -461,8 +471,8 @@ __device__ __forceinline__ void force_scatter_atom(const ForceScatterBody<S>& B,
     lds_add(ro + 1, Fi[1]);
     lds_add(ro + 2, Fi[2]);
   }
-  if (NEPMI_FS_ABL == 0 && big >= kScatterFlagLimit)
-    atomicOr(&b.flags[kFlagRange], 1);
+  if (NEPMI_FS_ABL == 0 && big >= b.scatter_limit)
+    scatter_range_trip(b);
 
   // ---- outputs of this kernel, internal order: energy and the local-form virial (the force comes from ForceFoldBody) ----
   if (!OUT || lv < b.lvl_force)
@@ -746,8 +756,8 @@ __device__ __forceinline__ void force_scatter_atom_mt(const ForceScatterBody<S>&
     lds_add(ro + 1, Fi[1]);
     lds_add(ro + 2, Fi[2]);
   }
-  if (NEPMI_FS_ABL == 0 && big >= kScatterFlagLimit)
-    atomicOr(&b.flags[kFlagRange], 1);
+  if (NEPMI_FS_ABL == 0 && big >= b.scatter_limit)
+    scatter_range_trip(b);
   if (!OUT)
     return;
 #pragma unroll
@@ -964,6 +974,11 @@ struct ForceFoldBody {
         s2 += h[u].z;
       }
     }
+    // the sums are modular: the NET force of an atom has to fit.  Half the range (256 eV/A) is the guard band of the total; the
+    // pair halves have their own, a factor four below it (kScatterFlagLimit)
+    const int a0 = s0 < 0 ? -s0 : s0, a1 = s1 < 0 ? -s1 : s1, a2 = s2 < 0 ? -s2 : s2;
+    if (a0 >= b.fold_guard || a1 >= b.fold_guard || a2 >= b.fold_guard || s0 == INT_MIN || s1 == INT_MIN || s2 == INT_MIN)
+      scatter_range_trip(b);
     double F[3] = {(double)s0 * kScatterInvScale, (double)s1 * kScatterInvScale, (double)s2 * kScatterInvScale};
     if (m.zbl_enabled && lv >= 2) {
 #pragma unroll

@@ -343,7 +343,9 @@ int nepmi_dist_set_overlap(nepmi_dist* d, int on);
  * Environment read by the library (experiments and A/B runs; an embedding application that must not be steered from outside calls
  * nepmi_dist_set_ghost_mode / nepmi_dist_set_overlap explicitly, which take precedence): NEPMI_DIST_GHOSTS=forward|reverse replaces
  * the counted rule of mode -1 when the context is created; NEPMI_RCCL_FUSE_VOTE=1 makes the RCCL transport carry the skin vote
- * inside the ghost exchange's group (NEPMI_DT_DEFER); NEPMI_DIST_TRACE prints the stages of a re-decomposition to stderr. */
+ * inside the ghost exchange's group (NEPMI_DT_DEFER); NEPMI_DIST_TRACE prints the stages of a re-decomposition to stderr.
+ * Engines read NEPMI_SCATTER_GUARD (eV/A, <= 64) when they are created: a test hook that narrows the guard band of the scatter-form
+ * force assembly (see nepmi_engine_set_force_form) so that its hand-over to the gather form can be exercised with ordinary forces. */
 int nepmi_dist_set_ghost_mode(nepmi_dist* d, int mode);
 typedef struct {
   int64_t n_owned, n_local, n_total; /* atoms owned by this rank, owned + ghosts, in the whole system */
@@ -442,8 +444,11 @@ int nepmi_engine_set_win_lanes(nepmi_engine* e, int lanes);
  *             itself whenever per-atom virials leave it.  Static window layout, one lane per atom, one or two types.
  * mode -1 (default): the fused run loops (nepmi_run_*, nepmi_dist_*) take the scatter form where it applies, the per-call
  * entry points (nepmi_potential_compute, nepmi_force_compute) the gather form; 0: gather everywhere; 1: scatter wherever it
- * applies (per-call evaluations then add the virial-only pass).  A pair half beyond 64 eV/A returns the engine to the gather
- * form for the rest of its life (the fixed-point sums wrap at +-512 eV/A net per window). */
+ * applies (per-call evaluations then add the virial-only pass).  Range: the fixed-point sums hold +-512 eV/A net per atom (they
+ * are modular, so only the net has to fit).  A pair half beyond 64 eV/A or a net force component beyond 256 eV/A returns the engine
+ * to the gather form for the rest of its life, and the evaluation that met it does not stand: a per-call evaluation is repeated in
+ * the gather form before it returns, a step of a single-domain run loop freezes like a skin trip and is re-run.  In a decomposed
+ * run (nepmi_dist_*) the flagged step stands -- exact while the net stays inside +-512 eV/A -- and the next steps use the gather form. */
 int nepmi_engine_set_force_form(nepmi_engine* e, int mode);
 /* The per-step radial list of the scatter-form steps of the run loops (find_neighbor_list_large_box, nep.cu:436-486, is what it
  * replaces): on = 1: one inside bit per candidate of the packed Verlet words, which the force assembly walks with the bits as

@@ -121,6 +121,59 @@ def test_scatter_form_properties(drv):
     assert np.abs(fsum).max() < 1e-9, fsum
 
 
+def test_scatter_guard_band_hands_over_to_the_gather_form(drv, monkeypatch):
+    """The fixed-point sums of the scatter form hold +-512 eV/A; a pair half beyond 64 eV/A (or a net force beyond 256) makes the
+    engine leave the form.  No NEP model of the repository produces such forces on a sane structure, so the test lowers the band
+    through NEPMI_SCATTER_GUARD (read when an engine is created): (a) a force evaluation that leaves the band is REPEATED in the
+    gather form before anything is returned -- bit-identical to an engine that never used the scatter form; (b) inside a run loop
+    the step freezes like a skin trip and is re-run in the gather form -- same trajectory as the gather-form engine (to the
+    rounding of a different list generation: the replay rebuilds the lists)."""
+    nep = H.golden("PbTe", "nep.txt")
+    h, typ, x = H.pbte_supercell((6, 6, 6), rattle=0.05, seed=21)
+    mass = np.where(typ == 0, H.MASS["Te"], H.MASS["Pb"]).astype(np.float64)
+    n = len(typ)
+    model = drv.model(nep)
+
+    def make(form, guard):
+        if guard:
+            monkeypatch.setenv("NEPMI_SCATTER_GUARD", guard)
+        else:
+            monkeypatch.delenv("NEPMI_SCATTER_GUARD", raising=False)
+        eng = drv.engine(model, n)
+        monkeypatch.delenv("NEPMI_SCATTER_GUARD", raising=False)
+        eng.set_win_lanes(1)
+        eng.set_force_form(form)
+        return eng
+
+    # (a) one evaluation
+    ref = make(0, None)
+    _, pe0, f0, v0 = H.engine_force(drv, ref, h, typ, x)
+    assert np.abs(f0).max() > 0.5  # the lowered band is below the forces of this structure
+    sc = make(1, None)
+    H.engine_force(drv, sc, h, typ, x)
+    assert "lds_scatter" in sc.describe()  # with the real band the scatter form stays
+    low = make(1, "0.25")
+    _, pe1, f1, v1 = H.engine_force(drv, low, h, typ, x)
+    assert "lds_scatter" not in low.describe(), low.describe()
+    assert np.array_equal(f1, f0) and np.array_equal(pe1, pe0) and np.array_equal(v1, v0)
+    _, pe2, f2, v2 = H.engine_force(drv, low, h, typ, x)  # ... and for the rest of the engine's life
+    assert "lds_scatter" not in low.describe() and np.array_equal(f2, f0)
+
+    # (b) a run loop whose first force evaluation leaves the band (entered with zero forces: no evaluation before the loop)
+    vel = H.maxwell_velocities(mass, 600.0, seed=5)
+    out = []
+    for eng in (make(0, None), make(1, "0.25")):
+        d_t, d_m, d_x, d_v = drv.dev(typ), drv.dev(mass), drv.dev(x), drv.dev(vel)
+        d_pe, d_f, d_w = drv.zeros(n), drv.zeros(3 * n), drv.zeros(9 * n)
+        th = eng.run_nve(h, d_t, d_m, 1.0 / H.TIME_UNIT, 12, d_x, d_v, d_pe, d_f, d_w, thermo_every=4)
+        out.append((drv.host(d_x), drv.host(d_v), drv.host(d_f), np.asarray(th), eng.describe(), eng.stats().discarded_steps))
+    g, t = out
+    assert "lds_scatter" not in t[4], t[4]
+    assert t[5] > g[5]  # steps enqueued behind the frozen one ran as no-ops and were replayed
+    assert np.abs(t[0] - g[0]).max() < 2e-8 and np.abs(t[1] - g[1]).max() < 2e-8 and np.abs(t[2] - g[2]).max() < 2e-5
+    np.testing.assert_allclose(t[3], g[3], rtol=1e-6, atol=1e-9)
+
+
 @pytest.mark.parametrize("model", ["PbTe", "C"])
 def test_run_loop_forms_are_bit_identical(drv, model):
     """The run loop's scatter-form steps with the per-step radial list as inside bits over the packed Verlet words (the
