@@ -115,6 +115,19 @@ public:
         base += all[r];
       n_total_ += all[r];
     }
+    // caller-supplied ids label the gathered output and seed the Langevin generators: 0 .. n_total - 1 (checked here on every
+    // rank together; uniqueness is the caller's to keep -- nothing on the device is indexed by an id during a run)
+    int64_t bad_ids = 0;
+    if (ids && n > 0) {
+      std::vector<int64_t> hid((size_t)n);
+      be_.d2h(hid.data(), ids, sizeof(int64_t) * n);
+      for (int64_t i = 0; i < n; ++i)
+        if (hid[i] < 0 || hid[i] >= n_total_)
+          bad_ids = 1;
+    }
+    host_allreduce(&bad_ids, 1, kDtI64, kOpSum);
+    if (bad_ids)
+      throw EngineError{-4, "nepmi_dist_setup: atom ids must be 0 .. n_total - 1"};
     alloc_state(cur_, n > 0 ? n : 1);
     cur_.n = n;
     cur_.n_own = n;

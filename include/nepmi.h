@@ -314,9 +314,9 @@ int nepmi_dist_bdp_seed(nepmi_dist* d, uint64_t seed);
  * atom with global id s is hiprand_init(seed, s, 0) exactly as in the single-domain nepmi_run_nvt_lan, so the noise of an atom does
  * not depend on the decomposition.  A rank holds the states of the atoms it OWNS only (48 bytes each); they travel with the atom's
  * record when it migrates (memory and work per rank are O(N_local), no collective beyond the momentum sums).  The ids of
- * nepmi_dist_setup only seed the generators and label the gathered output -- nothing on the device is indexed by them during a run
- * (nepmi_dist_gather_global, which is, checks them and returns -4) -- but two atoms with the same id would draw the same noise:
- * ids must be unique over the ranks. */
+ * nepmi_dist_setup only seed the generators and label the gathered output -- nothing on the device is indexed by them during a run.
+ * nepmi_dist_setup checks their range (0 .. n_total - 1; the check is all-reduced, every rank returns -4 together); two atoms with
+ * the same id would draw the same noise and land on the same row of nepmi_dist_gather_global: ids must be unique over the ranks. */
 int nepmi_dist_lan_seed(nepmi_dist* d, int seed);
 /* on: the radial pass of the interior bricks (no ghost in their 8x8x8-cell window) is enqueued on the compute stream while the
  * skin vote and the ghost positions travel on a communication stream; off (default since round 3): the plain

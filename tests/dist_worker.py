@@ -49,6 +49,8 @@ def run_rank(out_dir, spec, rank, world, make_transport, stream=None):
     vel = H.maxwell_velocities(mass, spec["temp"], seed=5)
     mine = np.arange(n) % world == rank  # arbitrary initial distribution; setup() migrates
     ids = np.arange(n, dtype=np.int64)[mine]
+    if spec.get("bad_ids") and rank == world - 1:  # one id outside 0 .. n_total - 1, on one rank only
+        ids[0] = n
     tr = make_transport(drv)
     md = DistMD(model, tr, h, tuple(spec.get("pbc", (1, 1, 1))), spec["grid"], stream=stream, ghost_mode=spec.get("ghosts"))
     md.setup(drv.dev(typ[mine]), drv.dev(mass[mine]), drv.dev(np.ascontiguousarray(x.reshape(3, n)[:, mine]).reshape(-1)),

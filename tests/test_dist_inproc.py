@@ -168,3 +168,16 @@ def test_a_capacity_error_of_one_rank_ends_the_run_on_every_rank():
     errors = _run_threads(2, spec, expect_errors=True)
     assert sorted(r for r, _ in errors) == [0, 1], errors
     assert all("capacity" in msg for _, msg in errors), errors
+
+
+def test_an_atom_id_outside_the_system_is_refused_on_every_rank():
+    """nepmi_dist_setup: the caller's ids label the gathered output and seed the Langevin generators; one id outside
+    0 .. n_total - 1 on ONE rank is reported by both (the check is all-reduced), before anything is decomposed."""
+    import test_dist as T
+    if not os.path.exists(LIB["cpu"]):
+        pytest.skip("tests/inproc transports not built")
+    spec = T._spec("cpu", "PbTe-reps", (4, 2, 2), (2, 1, 1), "nve", 2, 300.0)
+    spec["bad_ids"] = True
+    errors = _run_threads(2, spec, expect_errors=True)
+    assert sorted(r for r, _ in errors) == [0, 1], errors
+    assert all("atom ids must be" in msg for _, msg in errors), errors
