@@ -719,6 +719,22 @@ def check_full_size_parity(drv, name):
     assert np.abs(f.reshape(3, n).sum(axis=1)).max() < 1e-4 * np.sqrt(n)
     st = eng.stats(True)
     assert st.max_nn_radial == L["radial"][0].max() and st.max_nn_angular == L["angular"][0].max()
-    print("\n[full-size parity] %s: %d atoms, oracle %.1f s, engine + comparison %.1f s, max|dF| vs FP64 %.2e, vs FP32 %.2e"
-          % (name, n, t_oracle, time.time() - t0, np.abs(f - f64).max(), np.abs(f - f32).max()))
+    df_gather = np.abs(f - f64).max()
+    # the same positions through the scatter form of the force assembly -- the form the run loops (and the bench line) take at
+    # this size; per-call evaluations use the gather form unless asked
+    eng.set_force_form(1)
+    _, pe_s, f_s, v_s = H.engine_force(drv, eng, h, typ, x)
+    scattered = "lds_scatter_of_own_halves" in eng.describe()
+    if isinstance(drv, H.GpuDriver) and "lanes_per_atom=1" in eng.describe():  # (few bricks: several lanes per atom, gather form)
+        assert scattered, eng.describe()
+    assert np.array_equal(pe_s, pe)  # energies: the same kernels
+    ds = np.abs(f_s - f64) - 1e-4 * np.abs(f64)
+    assert ds.max() <= 3e-5, "scatter form: forces vs FP64 oracle, worst excess %.3e" % ds.max()
+    dvs = np.abs(v_s - v64) - 1e-4 * np.abs(v64)
+    assert dvs.max() <= 1e-4, "scatter form: virials vs FP64 oracle, worst excess %.3e" % dvs.max()
+    if scattered and not name.startswith("UNEP"):
+        # +g and -g are the same integer: the total force vanishes to the FP64 rounding of the fold (UNEP adds ZBL in floating point)
+        assert np.abs(f_s.reshape(3, n).sum(axis=1)).max() < 1e-6
+    print("\n[full-size parity] %s: %d atoms, oracle %.1f s, engine + comparison %.1f s, max|dF| vs FP64 %.2e (gather) %.2e (scatter), "
+          "vs FP32 %.2e" % (name, n, t_oracle, time.time() - t0, df_gather, np.abs(f_s - f64).max(), np.abs(f - f32).max()))
     return eng
