@@ -1450,7 +1450,8 @@ public:
       return 1;
     if (win_lanes_ > 0)
       return win_lanes_;
-    return num_bricks_ <= 256 ? 4 : (num_bricks_ <= 400 ? 2 : 1);
+    // (profiles/r4al_lanes_sweep.txt: 512 bricks 0.259 ms with two lanes / 0.273 with one; 640 bricks 0.348 / 0.333)
+    return num_bricks_ <= 256 ? 4 : (num_bricks_ <= 512 ? 2 : 1);
   }
   void set_win_lanes(int lanes) { win_lanes_ = (lanes == 1 || lanes == 2 || lanes == 4) ? lanes : 0; }
   int tile_mode_in_use() const { return tile_ok_ ? ((win2_ok_ && win_lanes() == 1) ? 3 : 2) : 0; }
