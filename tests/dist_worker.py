@@ -60,6 +60,8 @@ def run_rank(out_dir, spec, rank, world, make_transport, stream=None):
     if spec.get("force_form") is not None:  # the local engine's force-assembly form (systems below the run loops' size rule)
         e = md.lib.nepmi_dist_engine(md.handle)
         md._ck(md.lib.nepmi_engine_set_force_form(e, int(spec["force_form"])))
+        if int(spec["force_form"]) == 1:  # the scatter form is the one-lane form: pin it (the rule takes two lanes up to 512 bricks)
+            md._ck(md.lib.nepmi_engine_set_win_lanes(e, 1))
     if spec.get("seed") is not None:
         md.bdp_seed(spec["seed"])
         md.lan_seed(spec["seed"])
