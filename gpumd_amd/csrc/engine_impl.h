@@ -1286,8 +1286,7 @@ private:
       be_.exclusive_scan(b_.tcount, nkeys + 1, scan_scratch_);
       be_.template launch<256>(kSlotMisc, N_, TypeFillBody{b_, model_.num_types});
     }
-    be_.template launch<128>(kSlotMisc, N_, BuildListsBody{box_, b_});
-    be_.template launch<128>(kSlotMisc, N_, ReverseSlotsBody{box_, b_});
+    // the bricks' statistics first (they need the cells only): they say whether the Verlet lists can be built from LDS windows
     be_.memset(b_.flags + kFlagMaxWindow, 0, 3 * sizeof(int));
     num_bricks_ = (int64_t)b_.gbx * b_.gby * b_.gbz;
     if (b_.level)
@@ -1296,8 +1295,25 @@ private:
     be_.memset(b_.brick_flag + num_bricks_, 0, sizeof(int));
     be_.exclusive_scan(b_.brick_flag, num_bricks_ + 1, scan_scratch_);
     be_.template launch<64>(kSlotMisc, num_bricks_, BrickOrderBody{b_, num_bricks_});
-    be_.end_region(kRegionRebuild);
     int flags[kNumFlags];
+    bool build_in_windows = false;
+    if (NEPMI_BUILD_WIN && use_tiles_ && model_.kind == 0 && b_.prec) {
+      be_.d2h(flags, b_.flags, sizeof(flags));
+      build_in_windows = flags[kFlagMaxCell] <= 127 && flags[kFlagMaxWindow] <= kWinMaxAtoms && !flags[kFlagOutlier];
+      for (int d = 0; d < 3; ++d)
+        if (box_.pbc[d] && nb[d] < 8)
+          build_in_windows = false;
+      if (build_in_windows) {
+        WinLayout lay = win_;
+        lay.wmax = (flags[kFlagMaxWindow] + 63) / 64 * 64;
+        lay.compact = 0;
+        be_.launch_win(kSlotMisc, num_bricks_, BuildListsWinBody{WinStage{box_, b_, lay}});
+      }
+    }
+    if (!build_in_windows)
+      be_.template launch<128>(kSlotMisc, N_, BuildListsBody{box_, b_});
+    be_.template launch<128>(kSlotMisc, N_, ReverseSlotsBody{box_, b_});
+    be_.end_region(kRegionRebuild);
     be_.d2h(flags, b_.flags, sizeof(flags));
     check_overflow(flags);
     num_boundary_bricks_ = flags[kFlagNumBoundary];

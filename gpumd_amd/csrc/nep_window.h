@@ -271,6 +271,128 @@ struct WinStage {
   }
 };
 
+// gpu_find_neighbor_ON1 (neighbor.cu:85-162) as a window kernel: the Verlet lists A (rc_a + skin) and B (up to rc_r + skin) of the
+// brick's atoms from the fixed-point records of its 8x8x8-cell window in LDS -- the same 5x5x5-cell sweep, order, codes and list
+// decisions as BuildListsBody (a decision closer to a cutoff than the band is retaken with the reference's arithmetic), but the
+// ~490 candidate positions per atom are LDS reads instead of 32-byte gathers (BuildListsBody is bound by the address unit: one
+// cache line per lane and candidate).  Scanned window layout (cell counts -> scan -> records): the window table of the static
+// layout is built FROM these lists' codes, later in the rebuild.
+struct BuildListsWinBody {
+  WinStage st;
+  static constexpr int kMinWavesPerEu = 1;
+  NEPMI_HD int lds_bytes() const { return st.lay.bytes(); }
+  NEPMI_HD int64_t map_brick(int64_t w) const { return w; }
+  NEPMI_HD bool skip() const { return false; }
+  template <class LC>
+  NEPMI_HD void stage_cells(int64_t brick, LC lds, int tid, int nth) const { st.stage_cells(brick, lds, tid, nth); }
+  template <class LC>
+  NEPMI_HD void stage_copy(int64_t brick, LC lds, int tid, int nth) const { st.stage_copy(brick, lds, tid, nth); }
+  NEPMI_HD void brick_range(int64_t brick, int64_t& a0, int64_t& a1) const { st.brick_range(brick, a0, a1); }
+
+  template <class LC>
+  NEPMI_HD void compute(int64_t, int64_t k, LC lds) const
+  {
+    const Bufs& b = st.b;
+    const BoxD& box = st.box;
+    const int64_t N = b.N;
+    NEPMI_LDS(const int)* woff = (NEPMI_LDS(const int)*)(lds + st.lay.off_woff());
+    NEPMI_LDS(const WinRec)* wrec = (NEPMI_LDS(const WinRec)*)(lds + st.lay.off_rec());
+    const PosQ p1 = b.posq[k];
+    int ox, oy, oz;
+    st.place_own(k, ox, oy, oz);
+    const int c = b.kcell[k];
+    int cx, cy, cz;
+    cell_coords(b, c, cx, cy, cz);
+    const int l = c & 63;
+    const int wx0 = (l & 3) + 2, wy0 = ((l >> 2) & 3) + 2, wz0 = (l >> 4) + 2; // own cell in the window
+    const float unit2 = b.wg.unit2, band = b.wg.band;
+    const int lx = b.nbx > 1 ? 2 : 0, ly = b.nby > 1 ? 2 : 0, lz = b.nbz > 1 ? 2 : 0;
+    int cnta = 0, cntb = 0;
+    bool near_owned = false;
+    // a row of the sweep (fixed kz, ky; kx = -lx .. lx) is ONE range of window slots: consecutive window cells hold consecutive
+    // slots.  One loop per row instead of one per cell: a wavefront runs the longest of its lanes' loops, and the longest of 64
+    // rows of ~20 atoms is relatively much shorter than the longest of 64 cells of ~4.
+    int xlo = -lx, xhi = lx;
+    if (!box.pbc[0]) { // cells beyond an open face hold nothing: the row stops at the box
+      xlo = cx + xlo < 0 ? -cx : xlo;
+      xhi = cx + xhi >= b.nbx ? b.nbx - 1 - cx : xhi;
+    }
+    for (int kz = -lz; kz <= lz; ++kz) {
+      if (!box.pbc[2] && (cz + kz < 0 || cz + kz >= b.nbz))
+        continue;
+      for (int ky = -ly; ky <= ly; ++ky) {
+        if (!box.pbc[1] && (cy + ky < 0 || cy + ky >= b.nby))
+          continue;
+        int wc = ((wz0 + kz) << 6) | ((wy0 + ky) << 3) | (wx0 + xlo);
+        const int wc_end = wc + (xhi - xlo) + 1;
+        const int s_end = woff[wc_end];
+        int cell_lo = woff[wc], cell_hi = woff[wc + 1];
+        // 32 slots at a time: first the decisions as two bit masks (no memory traffic but LDS reads), then one trip per ACCEPTED
+        // slot.  A store instruction costs the address unit the same whether one lane or all take part, and some lane of the
+        // wavefront accepts in nearly every trip of a loop over all slots (one candidate in five is a neighbour): storing inside
+        // that loop issued ~1,400 store instructions per wavefront, this form issues ~400.
+        for (int base = cell_lo; base < s_end; base += 32) {
+          const int nch = s_end - base < 32 ? s_end - base : 32;
+          unsigned ms = 0u, ma = 0u;
+          for (int i2 = 0; i2 < nch; ++i2) {
+            const WinRec r = wrec[base + i2];
+            const int j = (int)((unsigned)r.w & (unsigned)kIdxMask);
+            const float fx = (float)(r.x - ox), fy = (float)(r.y - oy), fz = (float)(r.z - oz);
+            const float d2 = dot3f(fx, fx, fy, fy, fz, fz) * unit2;
+            const float es = d2 - b.rc_skin_sq, ea = d2 - b.rc_askin_sq;
+            bool in_skin = es < 0.0f, in_a = ea < 0.0f;
+            if (fminf(fabsf(es), fabsf(ea)) < band && j != (int)k) { // the reference's arithmetic decides (rare)
+              float x, y, z;
+              const float d2e = pair_geometry(box, p1, b.posq[j], x, y, z);
+              in_skin = d2e < b.rc_skin_sq;
+              in_a = d2e < b.rc_askin_sq;
+            }
+            in_skin = in_skin && j != (int)k;
+            ms |= (in_skin ? 1u : 0u) << i2;
+            ma |= ((in_skin && in_a) ? 1u : 0u) << i2;
+          }
+          while (ms != 0u) {
+            const int i2 = __builtin_ctz(ms);
+            ms &= ms - 1u;
+            const int s = base + i2;
+            while (s >= cell_hi) { // the cell of this slot (slots ascend: the cursor only moves forward; empty cells are stepped over)
+              ++wc;
+              cell_lo = cell_hi;
+              cell_hi = woff[wc + 1];
+            }
+            const int j = (int)((unsigned)wrec[s].w & (unsigned)kIdxMask);
+            const unsigned short code = (unsigned short)((wc << 7) | ((s - cell_lo) & 127));
+            if ((ma >> i2) & 1u) {
+              if (cnta < b.MN_ang) {
+                b.nl_ang[(int64_t)cnta * N + k] = j;
+                b.code_ang[(int64_t)cnta * N + k] = code;
+              }
+              ++cnta;
+              near_owned = near_owned || b.lvl[j] >= 2;
+            } else {
+              if (cntb < b.MN_skin) {
+                b.nl_skin[(int64_t)cntb * N + k] = j;
+                b.code_skin[(int64_t)cntb * N + k] = code;
+              }
+              ++cntb;
+            }
+          }
+        }
+      }
+    }
+    NEPMI_ATOMIC_MAX(&b.flags[kFlagMaxSkin], cnta + cntb);
+    NEPMI_ATOMIC_MAX(&b.flags[kFlagMaxAng], cnta);
+    if (cnta > b.MN_ang || cnta + cntb > b.MN_skin) {
+      NEPMI_ATOMIC_OR(&b.flags[kFlagOverflow], 1);
+      cnta = cnta > b.MN_ang ? b.MN_ang : cnta;
+      cntb = cntb > b.MN_skin ? b.MN_skin : cntb;
+    }
+    b.nn_ang[k] = cnta;
+    b.nn_skin[k] = cntb;
+    b.angf[k] = (b.lvl[k] >= 2 || (b.lvl[k] >= b.lvl_desc && near_owned)) ? 1 : 0;
+  }
+};
+
 constexpr int kWinG = 4; // candidates whose LDS look-ups and arithmetic are interleaved
 
 // build-time switches for A/B measurements (profiles/ab_variants.sh); the defaults are the product
@@ -664,6 +786,9 @@ struct RadialWinBody {
                    // (profiles/r3cd_ab_window_variants.txt, r3e): radial pass 0.364 -> 0.359 ms; force assembly 0.517 (2-byte list,
                    // no pipeline) vs 0.508 (words, pipelined, 3 waves) vs 1.02 (4 waves: the two stages spill); carbon 0.79 ->
                    // 0.98.  Off.
+#endif
+#ifndef NEPMI_BUILD_WIN
+#define NEPMI_BUILD_WIN 1 // the Verlet lists of a rebuild from LDS windows (BuildListsWinBody) where the window kernels apply; 0: BuildListsBody
 #endif
 #ifndef NEPMI_RW2_ABL
 #define NEPMI_RW2_ABL 0 // ablation builds (timings only): 1 = no compact-list stores, 2 = no stores and no counters
