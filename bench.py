@@ -707,6 +707,8 @@ def bench(args):
         eng.set_mfma(os.environ["NEPMI_BENCH_MFMA"] != "0")
     if "NEPMI_BENCH_LANES" in os.environ:
         eng.set_win_lanes(int(os.environ["NEPMI_BENCH_LANES"]))
+    if "NEPMI_BENCH_ANGFUSED" in os.environ:  # angular descriptor + ANN + partial forces: 1 one kernel (default), 0 separate
+        eng.set_angular_fused(os.environ["NEPMI_BENCH_ANGFUSED"] != "0")
     if "NEPMI_BENCH_FORM" in os.environ:  # force assembly: 0 gather, 1 scatter (default: the run loops' rule)
         eng.set_force_form(int(os.environ["NEPMI_BENCH_FORM"]))
     # initial force (Run::perform_a_run computes it before the loop), then warm-up steps

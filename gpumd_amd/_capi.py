@@ -108,6 +108,7 @@ SYMBOLS = {
     "nepmi_engine_set_win_lanes": (C.c_int, [VP, C.c_int]),
     "nepmi_engine_set_force_form": (C.c_int, [VP, C.c_int]),
     "nepmi_engine_set_radial_mask": (C.c_int, [VP, C.c_int]),
+    "nepmi_engine_set_angular_fused": (C.c_int, [VP, C.c_int]),
     "nepmi_engine_set_win_static": (C.c_int, [VP, C.c_int]),
     "nepmi_engine_set_stepwise_loops": (C.c_int, [VP, C.c_int]),
     "nepmi_engine_describe": (C.c_int, [VP, C.c_char_p, C.c_int]),

@@ -493,6 +493,14 @@ int nepmi_engine_set_radial_mask(nepmi_engine* e, int on)
   return NEPMI_OK;
 }
 
+int nepmi_engine_set_angular_fused(nepmi_engine* e, int on)
+{
+  if (!e)
+    return fail(NEPMI_ERR_ARG, "null engine");
+  e->e->set_angular_fused(on != 0);
+  return NEPMI_OK;
+}
+
 int nepmi_engine_set_stepwise_loops(nepmi_engine* e, int on)
 {
   if (!e)

@@ -16,6 +16,7 @@
 
 #include "engine_impl.h"
 #include "nep_scatter.h" // device-only force assembly (LDS scatter of the own pair halves)
+#include "nep_fused.h"   // device-only: angular descriptor + ANN + partial angular forces in one kernel
 
 namespace nepmi {
 
@@ -1187,6 +1188,7 @@ struct HipBackend {
   // window accumulator and writes it to its row of hacc; ForceFoldBody then adds every atom's entries.  One timing bracket
   // around both launches: together they are the force assembly.
   static constexpr bool kHasScatter = true;
+  static constexpr bool kHasFusedAngular = true; // nep_fused.h
   // nb bricks from brick_order[first ...] (first < 0: all bricks in their own order); then the fold of the atoms with level in
   // [fold_lo, fold_hi] (fold_lo > fold_hi: no fold)
   template <class S>
@@ -1358,6 +1360,13 @@ struct HipBackend {
     NEPMI_HIP_CHECK(hipGetLastError());
     if (t)
       timer_stop(timing->slot[slot]);
+  }
+
+  // angular descriptor + ANN + partial angular forces, two lanes per atom (nep_fused.h)
+  template <class S>
+  void launch_angular_fused(int slot, int64_t n, const ModelD& md, const Bufs& b, int export_qfp)
+  {
+    launch_lds_pairs<256>(slot, n, AngularFusedBody<S>{md, b, export_qfp});
   }
 
   void exclusive_scan(int* data, int64_t n, int* scratch)

@@ -833,7 +833,17 @@ public:
       throw EngineError{-4, "no force evaluation has been performed yet"};
     if (model_.kind != 0)
       throw EngineError{-4, "descriptors exist for NEP models only"};
-    if (q && !last_small_ && fuse_ann_active()) {
+    if (!last_small_ && last_ang_fused_) {
+      // one kernel from the sums to the partial forces: run it once more with the descriptor and Fp written out
+      switch (shape_) {
+        case 1: launch_angular_fused<S_PbTeA>(1); break;
+        case 2: launch_angular_fused<S_PbTeB>(1); break;
+        case 3: launch_angular_fused<S_C2022>(1); break;
+        case 4: launch_angular_fused<S_UNEP>(1); break;
+        case 5: launch_angular_fused<S_BZO>(1); break;
+        default: break;
+      }
+    } else if (q && !last_small_ && fuse_ann_active()) {
       // the fused descriptor + ANN kernel keeps the angular descriptor in registers: write it out now (the compact
       // angular records of the last evaluation are still in place)
       switch (shape_) {
@@ -1398,6 +1408,17 @@ private:
     return floats * sizeof(float) <= 60 * 1024;
   }
 
+  // Angular descriptor + ANN + partial angular forces in one lane-pair kernel (nep_fused.h: the sums never leave the
+  // registers, no second descriptor evaluation in the force kernel): wherever the descriptor + ANN fusion applies, on a
+  // device backend.  A counted rule; set_angular_fused(0) keeps the two kernels.
+  bool ang_fused_active() const { return B::kHasFusedAngular && ang_fused_ && fuse_ann_active(); }
+  template <class S>
+  void launch_angular_fused(int export_qfp = 0)
+  {
+    if constexpr (B::kHasFusedAngular && S::fixed)
+      be_.template launch_angular_fused<S>(kSlotAngular, N_, md_, b_, export_qfp);
+  }
+
   template <class S>
   void launch_angular_force()
   {
@@ -1546,6 +1567,7 @@ public:
     external_skin_ = o.external_skin_;
     force_form_ = o.force_form_;
     use_rmask_ = o.use_rmask_;
+    ang_fused_ = o.ang_fused_;
     loop_ctx_ = o.loop_ctx_;
     scatter_disabled_ = o.scatter_disabled_;
     if (reverse_ghosts_ != o.reverse_ghosts_)
@@ -1662,13 +1684,18 @@ private:
       be_.template launch<64>(kSlotRadial, N_, RadialDescBody<S>{box_, md_, b_, 1});
     ccode_valid_ = b_.use_rmask == 0;
     b_.skip_atab = (win2 && fpj_wanted<S>(ws2)) ? 1 : 0; // the FPJ force assembly needs no radial table from the ANN kernel
-    if (fuse_ann_active()) {
+    last_ang_fused_ = false;
+    if (ang_fused_active()) {
+      launch_angular_fused<S>();
+      last_ang_fused_ = true;
+    } else if (fuse_ann_active()) {
       launch_angular_desc<S>(true);
     } else {
       launch_angular_desc<S>();
       be_.template launch_ann<S>(kSlotAnn, N_, md_, b_, true);
     }
-    launch_angular_force<S>();
+    if (!last_ang_fused_)
+      launch_angular_force<S>();
     last_scatter_form_ = false;
     outputs_stale_ = false;
     if (win2 && scatter_form<S>(ws2, frozen)) {
@@ -1793,6 +1820,8 @@ public:
   // 1: scatter-form steps of the run loops keep the per-step radial list as inside bits over the packed Verlet words
   // (Bufs::rmaskB) instead of compacting it; 0 (default): the compact list on every step.  Identical results, bit for bit.
   void set_radial_mask(bool on) { use_rmask_ = on; }
+  // 1 (default): angular descriptor, ANN and partial angular forces in one kernel where ang_fused_active() allows; 0: separately
+  void set_angular_fused(bool on) { ang_fused_ = on; }
   // the callers whose steps need forces, energies and the TOTAL virial only (run loops; the decomposed driver)
   void set_loop_context(bool on) { loop_ctx_ = on; }
   // Run loops: does the NEXT force evaluation have to leave per-atom energies and virials (a thermo record, a thermostat that
@@ -1898,14 +1927,18 @@ public:
     const bool win2 = win2_ok_ && lanes == 1;
     s += tile_ok_ ? (win2 ? " window=lds_static" : " window=lds_scanned") : " window=none(gather kernels)";
     s += " lanes_per_atom=" + std::to_string(tile_ok_ ? lanes : 1);
-    if (fuse_ann_active())
+    if (last_ang_fused_)
+      s += " angular=descriptor+ann+partial_forces_in_one_kernel(lane_pairs,sums_in_registers)";
+    else if (fuse_ann_active())
       s += " ann=fused_with_angular_descriptor(packed_fp32,no_mfma)";
     else if (ann_mode_ != 0 && b_.ann_img)
       s += " ann=mfma_f32_32x32x2";
     else
       s += " ann=per_atom";
-    s += (shape_ != 0 && model_.n_max_angular + 1 >= 7) ? " angular_force=lane_pairs" : " angular_force=one_lane";
-    s += recompute_s() ? " angular_sums=recomputed" : " angular_sums=stored";
+    if (!last_ang_fused_) {
+      s += (shape_ != 0 && model_.n_max_angular + 1 >= 7) ? " angular_force=lane_pairs" : " angular_force=one_lane";
+      s += recompute_s() ? " angular_sums=recomputed" : " angular_sums=stored";
+    }
     s += (last_scatter_form_ && last_mask_form_) ? " radial_list=inside_bits_over_the_verlet_words" : " radial_list=compacted";
     s += last_scatter_form_ ? " force_assembly=lds_scatter_of_own_halves(fixed_point)+fold" :
          last_rows_form_ ? " force_assembly=table_rows_in_lds"
@@ -1975,6 +2008,8 @@ private:
   int force_form_ = -1;          // set_force_form
   bool loop_ctx_ = false;        // set_loop_context
   bool virial_local_ = false;    // the virial planes of the last force evaluation hold the own-half form (exact_virials)
+  bool ang_fused_ = true;        // set_angular_fused
+  bool last_ang_fused_ = false;
   bool use_rmask_ = false;       // set_radial_mask (off: on PbTe 1 M atoms the radial pass gains what the force assembly's lockstep
                                  // walk over all candidates loses -- profiles/r4q_ab_mask.txt)
   bool last_mask_form_ = false;

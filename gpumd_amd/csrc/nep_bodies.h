@@ -2059,10 +2059,7 @@ struct AngularForceBody {
     const int64_t gk = b.tpos[k]; // q / fp column of this atom (work order)
     const int NR = S::fixed ? S::NR : m.NR;
     const int NA = S::fixed ? S::NA : m.NA;
-    const int KA = S::fixed ? S::KA : m.KA;
     const int t1 = b.posq[k].type;
-    const float rc1 = m.rc_a[t1];
-    const int cstride = cang_stride(m);
 
     float G[NLOC * kNumHarm];
     if (recompute_s)
@@ -2083,6 +2080,21 @@ struct AngularForceBody {
       }
       invariants_adjoint<!S::fixed>(m, fpn, 1, &G[i * kNumHarm]);
     }
+    pairs_from_G<PARTS>(k, part, cang, t1, G);
+  }
+
+  // The pair loop: partial forces f12 of this step's angular pairs from the atom's adjoint table G (this lane's channels,
+  // harmonic order), + ZBL.  Also the tail of the fused descriptor + ANN + force kernel (nep_fused.h), which arrives here
+  // with G built from sums that never left the registers.
+  template <int PARTS, class LP>
+  NEPMI_HD void pairs_from_G(int64_t k, int part, LP cang, int t1, const float* G) const
+  {
+    constexpr int NLOC = (S::NAM + PARTS) / PARTS;
+    const int64_t N = b.N;
+    const int NA = S::fixed ? S::NA : m.NA;
+    const int KA = S::fixed ? S::KA : m.KA;
+    const float rc1 = m.rc_a[t1];
+    const int cstride = cang_stride(m);
     // fixed shapes: the table as register pairs (harmonics_pairs order), P and Q as pairs as well
     constexpr int NG2 = S::fixed ? NLOC * kHarmPairs : 1;
     f2 G2[NG2];

@@ -22,13 +22,36 @@
 
 #if defined(__HIP_DEVICE_COMPILE__)
 #define NEPMI_WAVE_ANY(pred) (__any((int)(pred)))
-#define NEPMI_PAIR_XCHG(v) (__shfl_xor((v), 1)) // value held by the partner lane (lanes 2i, 2i+1)
+#define NEPMI_PAIR_XCHG(v) (nepmi::quad_xor<1>(v)) // value held by the partner lane (lanes 2i, 2i+1)
 #else
 #define NEPMI_WAVE_ANY(pred) (pred)
 #define NEPMI_PAIR_XCHG(v) (v) // host loops run one lane per atom: never reached with PARTS > 1
 #endif
 
 namespace nepmi {
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// Value held by lane (l ^ MSK), MSK = 1 or 2: the lanes that share an atom are adjacent, so the exchange stays inside a quad
+// and is a DPP operand modifier (quad_perm) of the consuming VALU instruction -- `v_add_f32_dpp` -- instead of the
+// ds_bpermute_b32 + s_waitcnt lgkmcnt(0) that __shfl_xor compiles to (an LDS-pipe round trip that also drains every LDS read
+// in flight).  Same values, same sums.
+template <int MSK>
+__device__ __forceinline__ int quad_xor(int v)
+{
+  static_assert(MSK == 1 || MSK == 2, "quad-local exchange");
+  return __builtin_amdgcn_update_dpp(0, v, MSK == 1 ? 0xB1 : 0x4E, 0xF, 0xF, true);
+}
+template <int MSK>
+__device__ __forceinline__ float quad_xor(float v)
+{
+  return __int_as_float(quad_xor<MSK>(__float_as_int(v)));
+}
+template <int MSK>
+__device__ __forceinline__ unsigned quad_xor(unsigned v)
+{
+  return (unsigned)quad_xor<MSK>((int)v);
+}
+#endif
 
 // Read-only model tables (weights, descriptor coefficients) are read through the CONSTANT address
 // space on the device: loads whose address is wave-uniform then become scalar (s_load) loads

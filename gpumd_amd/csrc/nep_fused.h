@@ -1,0 +1,237 @@
+// Angular descriptor + per-atom ANN + partial angular forces in ONE kernel (device only: gfx950; tests/emu keeps the separate
+// kernels, whose results these equal up to the summation order of the ANN's dot products).
+//
+// Replaces, in one launch: the angular half of find_descriptor (nep.cu:549-640), apply_ann_one_layer
+// (nep_utilities.cuh:169-194), find_partial_force_angular (nep.cu:774-861) and find_force_ZBL (nep.cu:863-975) -- the
+// reference's own descriptor + ANN fusion (nep.cu:488-659) taken one kernel further.  The separate kernels
+// (AngularDescBody::fuse_ann, AngularForceBody<.., recompute_s>) evaluate the sums s_{n,lm} TWICE, because the adjoint table
+// G = dU/ds needs Fp, which only exists after the ANN, i.e. in the next launch: a second walk over the pair records, 145 of the
+// 479 instructions per pair of the force kernel.  Here the sums stay in the registers across the ANN and become G in place.
+//
+// Two adjacent lanes per atom (the lane-pair form of the angular kernels): lane `part` owns the radial channels
+// n = part, part + 2, ... -- its 24 sums per channel, its rows of G -- and, for the ANN, the descriptor components that belong
+// to those channels (d-split): q_half = {q_rad[n], q_ang[L][n] : n = part mod 2}.  Per neuron each lane forms its half of the
+// dot product from its half of the weight row (LDS image below), the halves meet in one v_add_f32_dpp, both lanes apply tanh,
+// and each accumulates Fp for ITS components only: neither q nor Fp is ever exchanged, and what each lane ends up with is
+// exactly the Fp rows its own channels' adjoint needs.  The radial force table A[t2][k] = sum_n Fp[n] c[t1][t2][n][k]
+// (AnnBody) is two half sums joined the same way.
+//
+// LDS per workgroup (floats):  c_ang [T T][stride] | Wh [T][neuron][2][DPH] | b0 [T][neuron] | w1 [T][neuron] |
+//                              c_rad [T T][(n_r+1)(k_r+1)] | qscale_half [2][DPH]
+// DPH = components per lane, zero padded to a multiple of four (PbTe: 4 radial + 5 x 4 angular = 24): a weight half-row is
+// DPH / 4 ds_read_b128.
+#pragma once
+#include "nep_bodies.h"
+
+namespace nepmi {
+
+template <class S>
+struct FusedShape {
+  static_assert(S::fixed, "compiled shapes only");
+  static constexpr int NRH = (S::NR + 2) / 2;  // radial components per lane (lane 0 has the extra one of an odd count)
+  static constexpr int NLOC = (S::NA + 2) / 2; // angular channels per lane
+  static constexpr int DPH = (NRH + S::NL * NLOC + 3) / 4 * 4;
+  // descriptor component of local index i on lane `part`, or -1 (padding)
+  NEPMI_HD static int component(int part, int i)
+  {
+    if (i < NRH) {
+      const int n = 2 * i + part;
+      return n <= S::NR ? n : -1;
+    }
+    const int ii = i - NRH, L = ii / NLOC, c = ii - L * NLOC, n = 2 * c + part;
+    if (L >= S::NL || n > S::NA)
+      return -1;
+    return (S::NR + 1) + L * (S::NA + 1) + n;
+  }
+};
+
+struct FusedLdsLayout {
+  int wstride, off_w, off_b0, off_w1, off_c, off_qs, total;
+};
+template <class S>
+NEPMI_HD FusedLdsLayout fused_lds_layout(const ModelD& m)
+{
+  using F = FusedShape<S>;
+  FusedLdsLayout a;
+  a.wstride = m.nneu * 2 * F::DPH;
+  a.wstride += (8 - (a.wstride & 31) + 32) & 31; // type stride 8 mod 32 words: lanes of two types read different banks
+  a.off_w = (cang_floats(m) + 3) / 4 * 4;
+  a.off_b0 = a.off_w + m.T * a.wstride;
+  a.off_w1 = a.off_b0 + m.T * m.nneu;
+  a.off_c = a.off_w1 + m.T * m.nneu;
+  a.off_qs = a.off_c + m.T * m.T * (m.NR + 1) * (m.KR + 1);
+  a.total = a.off_qs + 2 * F::DPH;
+  return a;
+}
+
+template <class S>
+struct AngularFusedBody {
+  ModelD m;
+  Bufs b;
+  int export_qfp; // parity hooks (nepmi_descriptors_export): also write the angular descriptor and Fp, which otherwise never
+                  // leave the registers
+  static constexpr bool kUsesLds = true;
+#ifndef NEPMI_AFU_WAVES
+#define NEPMI_AFU_WAVES 2
+#endif
+  static constexpr int kMinWavesPerEu = 1, kMinWavesPerEuPairs = NEPMI_AFU_WAVES;
+  using F = FusedShape<S>;
+
+  NEPMI_HD int lds_floats() const { return fused_lds_layout<S>(m).total; }
+  NEPMI_HD void lds_stage(float* dst, int tid, int nth) const
+  {
+    cang_stage(m, dst, tid, nth);
+    const FusedLdsLayout a = fused_lds_layout<S>(m);
+    const int per_t = m.nneu * 2 * F::DPH;
+    for (int idx = tid; idx < m.T * per_t; idx += nth) {
+      const int t = idx / per_t, r = idx - t * per_t;
+      const int j = r / (2 * F::DPH), pi = r - j * (2 * F::DPH);
+      const int p = pi / F::DPH, i = pi - p * F::DPH;
+      const int d = F::component(p, i);
+      dst[a.off_w + t * a.wstride + r] = d >= 0 ? m.w0[((size_t)t * m.nneu + j) * m.dim + d] : 0.0f;
+    }
+    for (int idx = tid; idx < m.T * m.nneu; idx += nth) {
+      dst[a.off_b0 + idx] = m.b0[idx];
+      dst[a.off_w1 + idx] = m.w1[idx];
+    }
+    for (int idx = tid; idx < m.T * m.T * (m.NR + 1) * (m.KR + 1); idx += nth)
+      dst[a.off_c + idx] = m.c_rad[idx];
+    for (int idx = tid; idx < 2 * F::DPH; idx += nth) {
+      const int d = F::component(idx / F::DPH, idx % F::DPH);
+      dst[a.off_qs + idx] = d >= 0 ? m.qscale[d] : 0.0f;
+    }
+  }
+
+  template <int PARTS, class LP>
+  NEPMI_HD void run_parts(int64_t k, int part, LP lds) const
+  {
+    static_assert(PARTS == 2, "lane pairs");
+    constexpr int NRH = F::NRH, NLOC = F::NLOC, DPH = F::DPH;
+    const int64_t N = b.N;
+    if (b.lvl[k] < b.lvl_desc)
+      return;
+    const FusedLdsLayout a = fused_lds_layout<S>(m);
+    const int64_t gk = b.tpos[k];
+    const int t1 = b.posq[k].type;
+    LP QS = lds + a.off_qs + part * DPH;
+
+    // ---- sums of this lane's channels (angular_s_sums: what AngularDescBody runs) ----
+    float s[NLOC * kNumHarm];
+    angular_s_sums<S, 2>(m, b, k, t1, lds, part, s);
+
+    // ---- this lane's half of the scaled descriptor ----
+    float ql[DPH];
+#pragma unroll
+    for (int i = 0; i < DPH; ++i)
+      ql[i] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NRH; ++i) {
+      const int n = 2 * i + part;
+      if (n <= S::NR)
+        ql[i] = b.q[(int64_t)n * N + gk]; // radial part, written (scaled) by the radial pass
+    }
+#pragma unroll
+    for (int i = 0; i < NLOC; ++i) {
+      const int n = part + 2 * i;
+      if (n > S::NA)
+        break;
+      float qn[S::kRows];
+#pragma unroll
+      for (int L = 0; L < S::kRows; ++L)
+        qn[L] = 0.0f;
+      invariants<false>(m, &s[i * kNumHarm], qn, 1);
+#pragma unroll
+      for (int L = 0; L < S::NL; ++L) {
+        ql[NRH + L * NLOC + i] = qn[L] * QS[NRH + L * NLOC + i];
+        if (export_qfp)
+          b.q[(int64_t)((S::NR + 1) + L * (S::NA + 1) + n) * N + gk] = ql[NRH + L * NLOC + i];
+      }
+    }
+
+    // ---- ANN: per neuron, half a dot product per lane; Fp of this lane's components only ----
+    f2 g2[DPH / 2];
+#pragma unroll
+    for (int i = 0; i < DPH / 2; ++i)
+      g2[i] = bc2(0.0f);
+    float e = 0.0f;
+    {
+      LP W = lds + a.off_w + t1 * a.wstride + part * DPH;
+      LP B0 = lds + a.off_b0 + t1 * m.nneu;
+      LP W1 = lds + a.off_w1 + t1 * m.nneu;
+      for (int j = 0; j < m.nneu; ++j) {
+        LP w = W + j * (2 * DPH);
+        f2 w2[DPH / 2];
+#pragma unroll
+        for (int i = 0; i < DPH / 2; ++i)
+          w2[i] = mk2(w[2 * i], w[2 * i + 1]);
+        f2 acc = bc2(0.0f);
+#pragma unroll
+        for (int i = 0; i < DPH / 2; ++i)
+          acc = vfma(w2[i], mk2(ql[2 * i], ql[2 * i + 1]), acc);
+        float dot = acc.x + acc.y;
+        dot += NEPMI_PAIR_XCHG(dot); // (a + b and b + a: both lanes hold the same bits)
+        const float h = ann_tanh(dot - B0[j]);
+        const float wj = W1[j];
+        e = fmaf(wj, h, e);
+        const f2 coef = bc2(wj * (1.0f - h * h));
+#pragma unroll
+        for (int i = 0; i < DPH / 2; ++i)
+          g2[i] = vfma(coef, w2[i], g2[i]);
+      }
+    }
+    if (part == 0)
+      b.pe_i[k] = e - (m.b1 + m.b1t[t1]);
+    float Fp[DPH];
+#pragma unroll
+    for (int i = 0; i < DPH; ++i)
+      Fp[i] = ((i & 1) ? g2[i >> 1].y : g2[i >> 1].x) * QS[i];
+    if (export_qfp) {
+#pragma unroll
+      for (int i = 0; i < DPH; ++i) {
+        const int d = F::component(part, i);
+        if (d >= 0)
+          b.fp[(int64_t)d * N + gk] = Fp[i];
+      }
+    }
+
+    // ---- radial force table A[t2][k] = sum_n Fp[n] c[t1][t2][n][k]: two half sums; lane t2 mod 2 stores row t2 ----
+    if (!b.skip_atab) {
+      const int KRP = b.KRP;
+      for (int t2 = 0; t2 < m.T; ++t2) {
+        LP c = lds + a.off_c + (t1 * m.T + t2) * (S::NR + 1) * (S::KR + 1);
+#pragma unroll
+        for (int kk = 0; kk <= S::KR; ++kk) {
+          float v = 0.0f;
+#pragma unroll
+          for (int i = 0; i < NRH; ++i) {
+            const int n = 2 * i + part;
+            if (n <= S::NR)
+              v = fmaf(Fp[i], c[n * (S::KR + 1) + kk], v);
+          }
+          v += NEPMI_PAIR_XCHG(v);
+          if ((t2 & 1) == part)
+            b.atab[(size_t)k * (m.T * KRP) + t2 * KRP + kk] = v;
+        }
+      }
+    }
+
+    // ---- adjoint table in place of the sums, then the pair loop of AngularForceBody ----
+    if (b.level && !b.angf[k]) // an inner-ring ghost whose partial forces no owned atom will read
+      return;
+#pragma unroll
+    for (int i = 0; i < NLOC; ++i) {
+      const int n = part + 2 * i;
+      if (n > S::NA)
+        break;
+      float fpn[S::kRows];
+#pragma unroll
+      for (int L = 0; L < S::kRows; ++L)
+        fpn[L] = L < S::NL ? Fp[NRH + (L < S::NL ? L : 0) * NLOC + i] : 0.0f;
+      invariants_adjoint<false>(m, fpn, 1, &s[i * kNumHarm]);
+    }
+    const AngularForceBody<S> af{m, b, 1};
+    af.template pairs_from_G<2>(k, part, lds, t1, s);
+  }
+};
+
+} // namespace nepmi

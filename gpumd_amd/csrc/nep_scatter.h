@@ -764,10 +764,10 @@ __device__ __forceinline__ void force_scatter_atom_mt(const ForceScatterBody<S>&
   for (int msk = 1; msk < L; msk <<= 1) { // the L lanes of an atom are adjacent: a fixed tree
 #pragma unroll
     for (int d = 0; d < 6; ++d)
-      W[d] += __shfl_xor(W[d], msk);
+      W[d] += NEPMI_SHFL_XOR(W[d], msk);
 #pragma unroll
     for (int d = 0; d < 9; ++d)
-      Wa[d] += __shfl_xor(Wa[d], msk);
+      Wa[d] += NEPMI_SHFL_XOR(Wa[d], msk);
   }
   if (sub != 0 || lv < b.lvl_force)
     return;

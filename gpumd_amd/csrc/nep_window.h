@@ -1304,7 +1304,7 @@ struct RadialWin2Body {
 // plus the number of admitted candidates before it in the round, found from the lanes' flag bits (shuffles) -- so the
 // downstream kernels and the results are the same; the basis sums are added across the lanes at the end.
 #if defined(__HIP_DEVICE_COMPILE__)
-#define NEPMI_SHFL_XOR(v, mask) (__shfl_xor((v), (mask)))
+#define NEPMI_SHFL_XOR(v, mask) ((mask) == 1 ? nepmi::quad_xor<1>(v) : nepmi::quad_xor<2>(v)) // (mask: 1 or 2 -- L <= 4 adjacent lanes)
 #else
 #define NEPMI_SHFL_XOR(v, mask) (v) // host loops run one lane per atom: the split bodies are never selected there
 #endif

@@ -314,6 +314,11 @@ class NEP:
         (nepmi_engine_set_radial_mask)"""
         self._ck(self.lib.nepmi_engine_set_radial_mask(self.handle, 1 if on else 0))
 
+    def set_angular_fused(self, on=True):
+        """angular descriptor + ANN + partial angular forces in one kernel (default) or as separate kernels
+        (nepmi_engine_set_angular_fused)"""
+        self._ck(self.lib.nepmi_engine_set_angular_fused(self.handle, 1 if on else 0))
+
     def describe(self):
         """the kernel forms the last force evaluation ran (counted rules of the engine, as text)"""
         import ctypes as C

@@ -458,6 +458,13 @@ int nepmi_engine_set_force_form(nepmi_engine* e, int mode);
  * which then evaluates the 24 % of the candidates outside the cutoff in lockstep, loses as much (profiles/r4q_ab_mask.txt);
  * carbon gains 2 %.  One or two atom types; the compacted list is rebuilt on demand when per-atom virials leave the engine. */
 int nepmi_engine_set_radial_mask(nepmi_engine* e, int on);
+/* Angular descriptor, per-atom ANN and partial angular forces (the angular half of find_descriptor, nep.cu:549-640;
+ * apply_ann_one_layer, nep_utilities.cuh:169-194; find_partial_force_angular, nep.cu:774-861; find_force_ZBL, nep.cu:863-975) in
+ * ONE kernel with two lanes per atom: on = 1 (default) wherever the descriptor + ANN fusion applies (compiled shapes, at most 4
+ * types, fewer than 9 angular channels) -- the sums s_{n,lm} stay in the registers across the ANN and become the adjoint table in
+ * place, where the separate kernels evaluate them twice; 0: the separate kernels.  Same results up to the summation order of
+ * the ANN's dot products (tests/test_gpu_parity.py). */
+int nepmi_engine_set_angular_fused(nepmi_engine* e, int on);
 /* Static window layout of the one-lane window kernels (default on): between two list rebuilds the LDS slot of every window
  * atom is fixed, so the rebuild tabulates the windows and stores the Verlet entries as LDS slots, four to an 8-byte word
  * (two-type models: list B as two type-pure streams); on = 0 keeps the per-launch scan of the window cells and the

@@ -150,6 +150,12 @@ struct HostLoopBackend {
   static constexpr size_t kMaxLdsBytes = 160 * 1024;
   // the scatter form of the force assembly (gpumd_amd/csrc/nep_scatter.h) is device code only: never selected here
   static constexpr bool kHasScatter = false;
+  static constexpr bool kHasFusedAngular = false; // gpumd_amd/csrc/nep_fused.h: device code only
+  template <class S>
+  void launch_angular_fused(int, int64_t, const ModelD&, const Bufs&, int)
+  {
+    std::abort();
+  }
   template <class S>
   void launch_force_scatter(int, int64_t, int, int64_t, const WinStage&, const ModelD&, int*, const unsigned*, int, bool, bool, int, int, const int*)
   {

@@ -62,6 +62,35 @@ def test_mfma_ann_matches_per_atom_ann(drv, name):
         assert np.abs(v1 - v0).max() <= 2e-5 * max(1.0, np.abs(v0).max())
 
 
+@pytest.mark.parametrize("name", ["PbTe-A", "PbTe-B", "BaZrO3", "PbTe-ortho", "PbTe-3x3x3"])
+def test_fused_angular_kernel_matches_the_separate_kernels(drv, name):
+    """Angular descriptor + ANN + partial angular forces in one lane-pair kernel (nep_fused.h, the default where the
+    descriptor + ANN fusion applies) vs the separate kernels: descriptor and Fp through the parity hook, energies, forces and
+    virials; the same contractions, the ANN's dot products summed in another order."""
+    nep_rel, build, _ = P.MODELS[name]
+    nep = H.golden(*nep_rel.split("/"))
+    h, typ, x = build()
+    n = len(typ)
+    model = drv.model(nep)
+    out = []
+    for fused in (True, False):
+        eng = drv.engine(model, n)
+        eng.set_angular_fused(fused)
+        _, pe, f, v = H.engine_force(drv, eng, h, typ, x)
+        assert ("partial_forces_in_one_kernel" in eng.describe()) == fused
+        q = drv.zeros(model.info.dim * n, dtype=np.float32)
+        fp = drv.zeros(model.info.dim * n, dtype=np.float32)
+        eng.descriptors(q, fp)
+        out.append((pe, f, v, drv.host(q).reshape(-1, n), drv.host(fp).reshape(-1, n)))
+    pe1, f1, v1, q1, fp1 = out[0]
+    pe0, f0, v0, q0, fp0 = out[1]
+    np.testing.assert_allclose(q1, q0, rtol=1e-6, atol=1e-7 * np.abs(q0).max())
+    np.testing.assert_allclose(fp1, fp0, rtol=1e-4, atol=2e-6 * np.abs(fp0).max())
+    np.testing.assert_allclose(pe1, pe0, rtol=1e-5, atol=5e-6)
+    assert np.abs(f1 - f0).max() <= 1e-5 * max(1.0, np.abs(f0).max())
+    assert np.abs(v1 - v0).max() <= 2e-5 * max(1.0, np.abs(v0).max())
+
+
 @pytest.mark.parametrize("lanes", [1, 2, 4])
 @pytest.mark.parametrize("name", ["PbTe-A", "PbTe-B", "C-2022", "UNEP-v1", "BaZrO3"])
 def test_force_parity_lanes_per_atom(drv, name, lanes):
