@@ -1411,7 +1411,19 @@ private:
   // Angular descriptor + ANN + partial angular forces in one lane-pair kernel (nep_fused.h: the sums never leave the
   // registers, no second descriptor evaluation in the force kernel): wherever the descriptor + ANN fusion applies, on a
   // device backend.  A counted rule; set_angular_fused(0) keeps the two kernels.
-  bool ang_fused_active() const { return B::kHasFusedAngular && ang_fused_ && fuse_ann_active(); }
+  bool ang_fused_active() const
+  {
+    if (!B::kHasFusedAngular || !ang_fused_ || model_.kind != 0 || shape_ == 0 || ann_mode_ != 1 || model_.num_types > 4)
+      return false;
+    // the LDS image of nep_fused.h (fused_lds_layout): both weight half-rows of every neuron and type, the two coefficient tables
+    const int nrh = (model_.n_max_radial + 2) / 2, nloc = (model_.n_max_angular + 2) / 2;
+    const int dph = (nrh + model_.num_L * nloc + 3) / 4 * 4;
+    const size_t T = (size_t)model_.num_types;
+    const size_t floats = T * ((size_t)model_.num_neurons * 2 * dph + 32 + 2 * model_.num_neurons) + 2 * dph +
+                          T * T * ((model_.n_max_radial + 1) * (model_.basis_size_radial + 1) +
+                                   (model_.n_max_angular + 1) * (model_.basis_size_angular + 1) + 1) + 8;
+    return floats * sizeof(float) <= 64 * 1024;
+  }
   template <class S>
   void launch_angular_fused(int export_qfp = 0)
   {
@@ -1893,7 +1905,7 @@ private:
   template <class S>
   bool fpj_wanted(const WinStage& ws2) const
   {
-    if (S::TS > 0 || !NEPMI_FW_FPJ || NEPMI_CW || !b_.fpr || fuse_ann_active() || (ann_mode_ != 0 && b_.ann_img != nullptr))
+    if (S::TS > 0 || !NEPMI_FW_FPJ || NEPMI_CW || !b_.fpr || fuse_ann_active() || ang_fused_active() || (ann_mode_ != 0 && b_.ann_img != nullptr))
       return false; // (fpr is written by the per-atom ANN kernel only)
     const ForceWinBody<S, 1, false, false, true> body{ws2, md_, nullptr};
     return body.lds_bytes() <= 80 * 1024;

@@ -158,16 +158,20 @@ struct AngularFusedBody {
       LP W = lds + a.off_w + t1 * a.wstride + part * DPH;
       LP B0 = lds + a.off_b0 + t1 * m.nneu;
       LP W1 = lds + a.off_w1 + t1 * m.nneu;
+      // a half-row of up to 24 weights stays in the registers between the forward dot product and the backward axpy; longer
+      // ones (carbon: 36) are read from LDS twice instead -- the sums and the two descriptor halves already fill the file
+      constexpr bool kKeepRow = DPH <= 24;
       for (int j = 0; j < m.nneu; ++j) {
         LP w = W + j * (2 * DPH);
-        f2 w2[DPH / 2];
-#pragma unroll
-        for (int i = 0; i < DPH / 2; ++i)
-          w2[i] = mk2(w[2 * i], w[2 * i + 1]);
+        f2 w2[kKeepRow ? DPH / 2 : 1];
         f2 acc = bc2(0.0f);
 #pragma unroll
-        for (int i = 0; i < DPH / 2; ++i)
-          acc = vfma(w2[i], mk2(ql[2 * i], ql[2 * i + 1]), acc);
+        for (int i = 0; i < DPH / 2; ++i) {
+          const f2 wv = mk2(w[2 * i], w[2 * i + 1]);
+          if (kKeepRow)
+            w2[i] = wv;
+          acc = vfma(wv, mk2(ql[2 * i], ql[2 * i + 1]), acc);
+        }
         float dot = acc.x + acc.y;
         dot += NEPMI_PAIR_XCHG(dot); // (a + b and b + a: both lanes hold the same bits)
         const float h = ann_tanh(dot - B0[j]);
@@ -176,7 +180,7 @@ struct AngularFusedBody {
         const f2 coef = bc2(wj * (1.0f - h * h));
 #pragma unroll
         for (int i = 0; i < DPH / 2; ++i)
-          g2[i] = vfma(coef, w2[i], g2[i]);
+          g2[i] = vfma(coef, kKeepRow ? w2[i] : mk2(w[2 * i], w[2 * i + 1]), g2[i]);
       }
     }
     if (part == 0)

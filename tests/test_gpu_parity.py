@@ -62,7 +62,7 @@ def test_mfma_ann_matches_per_atom_ann(drv, name):
         assert np.abs(v1 - v0).max() <= 2e-5 * max(1.0, np.abs(v0).max())
 
 
-@pytest.mark.parametrize("name", ["PbTe-A", "PbTe-B", "BaZrO3", "PbTe-ortho", "PbTe-3x3x3"])
+@pytest.mark.parametrize("name", ["PbTe-A", "PbTe-B", "BaZrO3", "PbTe-ortho", "PbTe-3x3x3", "C-2022", "C-nep3", "water-model"])
 def test_fused_angular_kernel_matches_the_separate_kernels(drv, name):
     """Angular descriptor + ANN + partial angular forces in one lane-pair kernel (nep_fused.h, the default where the
     descriptor + ANN fusion applies) vs the separate kernels: descriptor and Fp through the parity hook, energies, forces and
