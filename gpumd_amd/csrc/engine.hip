@@ -311,6 +311,13 @@ nepmi_kernel_lds_pairs(const Body body, const int64_t n, const int* frozen)
     body.template run_parts<2>(i, (int)(threadIdx.x & 1u), (lds_cfloat_ptr)nepmi_lds_pairs);
 }
 
+// One-off: a body's LDS image written to global memory by the body's own staging code (nep_fused.h)
+template <class Body>
+__global__ void __launch_bounds__(256) nepmi_fused_image(const Body body, float* img)
+{
+  body.lds_stage(img, (int)threadIdx.x, 256);
+}
+
 // P adjacent lanes per atom (Body::run_parts<P>): TersoffPartialBody -- 54 atoms per CU need more than one wavefront per CU
 template <int BLOCK, int P, class Body>
 __global__ void __launch_bounds__(BLOCK) nepmi_kernel_lds_parts(const Body body, const int64_t n, const int* frozen)
@@ -1362,11 +1369,26 @@ struct HipBackend {
       timer_stop(timing->slot[slot]);
   }
 
-  // angular descriptor + ANN + partial angular forces, two lanes per atom (nep_fused.h)
+  // angular descriptor + ANN + partial angular forces, two lanes per atom (nep_fused.h).  The kernel's LDS image lives in
+  // global memory (`img`, owned by the engine; written here when `build` is set) and is copied by every workgroup.
   template <class S>
-  void launch_angular_fused(int slot, int64_t n, const ModelD& md, const Bufs& b, int export_qfp)
+  size_t fused_image_floats(const ModelD& md) const
   {
-    launch_lds_pairs<256>(slot, n, AngularFusedBody<S>{md, b, export_qfp});
+    return (size_t)fused_lds_layout<S>(md).total;
+  }
+  template <class S>
+  void launch_angular_fused(int slot, int64_t n, const ModelD& md, const Bufs& b, int export_qfp, float* img, bool build)
+  {
+    AngularFusedBody<S> body{md, b, export_qfp, nullptr};
+    if (build) {
+      hipLaunchKernelGGL((nepmi_fused_image<AngularFusedBody<S>>), dim3(1), dim3(256), 0, stream, body, img);
+      NEPMI_HIP_CHECK(hipGetLastError());
+    }
+    body.img = img;
+#ifndef NEPMI_AFU_BLOCK
+#define NEPMI_AFU_BLOCK 256 // A/B switch: threads per workgroup (half as many atoms)
+#endif
+    launch_lds_pairs<NEPMI_AFU_BLOCK>(slot, n, body);
   }
 
   void exclusive_scan(int* data, int64_t n, int* scratch)

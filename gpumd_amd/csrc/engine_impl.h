@@ -1427,8 +1427,16 @@ private:
   template <class S>
   void launch_angular_fused(int export_qfp = 0)
   {
-    if constexpr (B::kHasFusedAngular && S::fixed)
-      be_.template launch_angular_fused<S>(kSlotAngular, N_, md_, b_, export_qfp);
+    if constexpr (B::kHasFusedAngular && S::fixed) {
+      const size_t need = be_.template fused_image_floats<S>(md_);
+      if (!fused_img_ || fused_img_floats_ < need) { // (once per engine: the shape does not change)
+        fused_img_ = dalloc<float>(need);
+        fused_img_floats_ = need;
+        fused_img_stale_ = true;
+      }
+      be_.template launch_angular_fused<S>(kSlotAngular, N_, md_, b_, export_qfp, fused_img_, fused_img_stale_);
+      fused_img_stale_ = false;
+    }
   }
 
   template <class S>
@@ -1559,6 +1567,7 @@ public:
       b0_eff_[k] = m.b0[k] - m.w0_temp[k] * qT;
     be_.h2d(const_cast<float*>(md_.b0), b0_eff_.data(), sizeof(float) * b0_eff_.size());
     be_.ann_prepare(md_, b_); // the matrix-core weight image carries the bias as well
+    fused_img_stale_ = true;  // ... and so does the fused angular kernel's LDS image
   }
   double temperature() const { return temperature_; }
   bool temperature_model() const { return model_.temperature_model; }
@@ -2021,6 +2030,9 @@ private:
   bool loop_ctx_ = false;        // set_loop_context
   bool virial_local_ = false;    // the virial planes of the last force evaluation hold the own-half form (exact_virials)
   bool ang_fused_ = true;        // set_angular_fused
+  float* fused_img_ = nullptr;   // LDS image of the fused angular kernel (nep_fused.h), built at its first launch
+  size_t fused_img_floats_ = 0;
+  bool fused_img_stale_ = true;
   bool last_ang_fused_ = false;
   bool use_rmask_ = false;       // set_radial_mask (off: on PbTe 1 M atoms the radial pass gains what the force assembly's lockstep
                                  // walk over all candidates loses -- profiles/r4q_ab_mask.txt)

@@ -21,7 +21,7 @@
 // DPH = components per lane, zero padded to a multiple of four (PbTe: 4 radial + 5 x 4 angular = 24): a weight half-row is
 // DPH / 4 ds_read_b128.
 #pragma once
-#include "nep_bodies.h"
+#include "nep_window.h" // F4f
 
 namespace nepmi {
 
@@ -60,7 +60,7 @@ NEPMI_HD FusedLdsLayout fused_lds_layout(const ModelD& m)
   a.off_w1 = a.off_b0 + m.T * m.nneu;
   a.off_c = a.off_w1 + m.T * m.nneu;
   a.off_qs = a.off_c + m.T * m.T * (m.NR + 1) * (m.KR + 1);
-  a.total = a.off_qs + 2 * F::DPH;
+  a.total = (a.off_qs + 2 * F::DPH + 3) / 4 * 4;
   return a;
 }
 
@@ -70,9 +70,18 @@ struct AngularFusedBody {
   Bufs b;
   int export_qfp; // parity hooks (nepmi_descriptors_export): also write the angular descriptor and Fp, which otherwise never
                   // leave the registers
+  const float* img; // the LDS image below, built once in global memory (backend: nepmi_fused_image), or nullptr = build it here.
+                    // Building it costs a few integer divisions per element -- per workgroup of 128 atoms that was as many
+                    // instructions as the ANN itself; the copy is one 16-byte load and store per four elements.
   static constexpr bool kUsesLds = true;
 #ifndef NEPMI_AFU_WAVES
 #define NEPMI_AFU_WAVES 2
+#endif
+#ifndef NEPMI_AFU_ABL
+#define NEPMI_AFU_ABL 0 // ablation builds (timings only, results are wrong): 1 no ANN loop, 2 no pair loop, 3 no sums, 4 no atab
+#endif
+#ifndef NEPMI_AFU_NJ
+#define NEPMI_AFU_NJ 1 // neurons per trip of the ANN loop (A/B switch; r5: 1 -> 0.500 ms, 2 -> 0.531, 3 -> 0.538 on PbTe 1 M atoms)
 #endif
   static constexpr int kMinWavesPerEu = 1, kMinWavesPerEuPairs = NEPMI_AFU_WAVES;
   using F = FusedShape<S>;
@@ -80,6 +89,14 @@ struct AngularFusedBody {
   NEPMI_HD int lds_floats() const { return fused_lds_layout<S>(m).total; }
   NEPMI_HD void lds_stage(float* dst, int tid, int nth) const
   {
+    if (img) {
+      const int n4 = (fused_lds_layout<S>(m).total + 3) / 4;
+      const F4f* __restrict__ src = reinterpret_cast<const F4f*>(img);
+      F4f* d4 = reinterpret_cast<F4f*>(dst);
+      for (int i = tid; i < n4; i += nth)
+        d4[i] = src[i];
+      return;
+    }
     cang_stage(m, dst, tid, nth);
     const FusedLdsLayout a = fused_lds_layout<S>(m);
     const int per_t = m.nneu * 2 * F::DPH;
@@ -117,7 +134,13 @@ struct AngularFusedBody {
 
     // ---- sums of this lane's channels (angular_s_sums: what AngularDescBody runs) ----
     float s[NLOC * kNumHarm];
-    angular_s_sums<S, 2>(m, b, k, t1, lds, part, s);
+    if (NEPMI_AFU_ABL != 3) {
+      angular_s_sums<S, 2>(m, b, k, t1, lds, part, s);
+    } else {
+#pragma unroll
+      for (int i = 0; i < NLOC * kNumHarm; ++i)
+        s[i] = (float)(k & 15) * 0.01f + 0.001f * i;
+    }
 
     // ---- this lane's half of the scaled descriptor ----
     float ql[DPH];
@@ -159,29 +182,54 @@ struct AngularFusedBody {
       LP B0 = lds + a.off_b0 + t1 * m.nneu;
       LP W1 = lds + a.off_w1 + t1 * m.nneu;
       // a half-row of up to 24 weights stays in the registers between the forward dot product and the backward axpy; longer
-      // ones (carbon: 36) are read from LDS twice instead -- the sums and the two descriptor halves already fill the file
+      // ones (carbon: 36) are read from LDS twice instead -- the sums and the two descriptor halves already fill the file.
+      // NJ neurons per trip: their LDS reads go out together and their dot-product / tanh chains (one dependent chain each:
+      // 12 packed fmas, a DPP add, v_exp, v_rcp) interleave -- at two wavefronts per SIMD nothing else hides those latencies.
       constexpr bool kKeepRow = DPH <= 24;
-      for (int j = 0; j < m.nneu; ++j) {
-        LP w = W + j * (2 * DPH);
-        f2 w2[kKeepRow ? DPH / 2 : 1];
-        f2 acc = bc2(0.0f);
+      constexpr int NJ = kKeepRow ? NEPMI_AFU_NJ : 1;
+      auto neurons = [&](const int j0, const int nj) __attribute__((always_inline)) {
+        f2 w2[NJ][kKeepRow ? DPH / 2 : 1];
+        f2 acc0[NJ], acc1[NJ];
 #pragma unroll
-        for (int i = 0; i < DPH / 2; ++i) {
-          const f2 wv = mk2(w[2 * i], w[2 * i + 1]);
-          if (kKeepRow)
-            w2[i] = wv;
-          acc = vfma(wv, mk2(ql[2 * i], ql[2 * i + 1]), acc);
+        for (int u = 0; u < NJ; ++u) {
+          if (u >= nj)
+            break;
+          LP w = W + (j0 + u) * (2 * DPH);
+          acc0[u] = bc2(0.0f);
+          acc1[u] = bc2(0.0f);
+#pragma unroll
+          for (int i = 0; i < DPH / 2; ++i) {
+            const f2 wv = mk2(w[2 * i], w[2 * i + 1]);
+            if (kKeepRow)
+              w2[u][i] = wv;
+            if (i & 1)
+              acc1[u] = vfma(wv, mk2(ql[2 * i], ql[2 * i + 1]), acc1[u]);
+            else
+              acc0[u] = vfma(wv, mk2(ql[2 * i], ql[2 * i + 1]), acc0[u]);
+          }
         }
-        float dot = acc.x + acc.y;
-        dot += NEPMI_PAIR_XCHG(dot); // (a + b and b + a: both lanes hold the same bits)
-        const float h = ann_tanh(dot - B0[j]);
-        const float wj = W1[j];
-        e = fmaf(wj, h, e);
-        const f2 coef = bc2(wj * (1.0f - h * h));
 #pragma unroll
-        for (int i = 0; i < DPH / 2; ++i)
-          g2[i] = vfma(coef, kKeepRow ? w2[i] : mk2(w[2 * i], w[2 * i + 1]), g2[i]);
-      }
+        for (int u = 0; u < NJ; ++u) {
+          if (u >= nj)
+            break;
+          LP w = W + (j0 + u) * (2 * DPH);
+          const f2 acc = acc0[u] + acc1[u];
+          float dot = acc.x + acc.y;
+          dot += NEPMI_PAIR_XCHG(dot); // (a + b and b + a: both lanes hold the same bits)
+          const float h = ann_tanh(dot - B0[j0 + u]);
+          const float wj = W1[j0 + u];
+          e = fmaf(wj, h, e);
+          const f2 coef = bc2(wj * (1.0f - h * h));
+#pragma unroll
+          for (int i = 0; i < DPH / 2; ++i)
+            g2[i] = vfma(coef, kKeepRow ? w2[u][i] : mk2(w[2 * i], w[2 * i + 1]), g2[i]);
+        }
+      };
+      int j = 0;
+      for (; j + NJ <= (NEPMI_AFU_ABL == 1 ? 0 : m.nneu); j += NJ)
+        neurons(j, NJ);
+      if (NJ > 1 && j < m.nneu)
+        neurons(j, m.nneu - j);
     }
     if (part == 0)
       b.pe_i[k] = e - (m.b1 + m.b1t[t1]);
@@ -199,22 +247,31 @@ struct AngularFusedBody {
     }
 
     // ---- radial force table A[t2][k] = sum_n Fp[n] c[t1][t2][n][k]: two half sums; lane t2 mod 2 stores row t2 ----
-    if (!b.skip_atab) {
+    if (!b.skip_atab && NEPMI_AFU_ABL != 4) {
       const int KRP = b.KRP;
+      constexpr int KRPC = (S::KR + 1 + 3) / 4 * 4; // = Bufs::KRP: rows of whole 16-byte groups
       for (int t2 = 0; t2 < m.T; ++t2) {
         LP c = lds + a.off_c + (t1 * m.T + t2) * (S::NR + 1) * (S::KR + 1);
+        float row[KRPC];
 #pragma unroll
-        for (int kk = 0; kk <= S::KR; ++kk) {
+        for (int kk = 0; kk < KRPC; ++kk) {
           float v = 0.0f;
+          if (kk <= S::KR) {
 #pragma unroll
-          for (int i = 0; i < NRH; ++i) {
-            const int n = 2 * i + part;
-            if (n <= S::NR)
-              v = fmaf(Fp[i], c[n * (S::KR + 1) + kk], v);
+            for (int i = 0; i < NRH; ++i) {
+              const int n = 2 * i + part;
+              if (n <= S::NR)
+                v = fmaf(Fp[i], c[n * (S::KR + 1) + kk], v);
+            }
+            v += NEPMI_PAIR_XCHG(v);
           }
-          v += NEPMI_PAIR_XCHG(v);
-          if ((t2 & 1) == part)
-            b.atab[(size_t)k * (m.T * KRP) + t2 * KRP + kk] = v;
+          row[kk] = v;
+        }
+        if ((t2 & 1) == part) {
+          F4f* __restrict__ out = reinterpret_cast<F4f*>(b.atab + (size_t)k * (m.T * KRP) + t2 * KRP);
+#pragma unroll
+          for (int g = 0; g < KRPC / 4; ++g)
+            out[g] = F4f{row[4 * g], row[4 * g + 1], row[4 * g + 2], row[4 * g + 3]};
         }
       }
     }
@@ -234,7 +291,11 @@ struct AngularFusedBody {
       invariants_adjoint<false>(m, fpn, 1, &s[i * kNumHarm]);
     }
     const AngularForceBody<S> af{m, b, 1};
-    af.template pairs_from_G<2>(k, part, lds, t1, s);
+    if (NEPMI_AFU_ABL != 2) {
+      af.template pairs_from_G<2>(k, part, lds, t1, s);
+    } else if (s[3] + s[30] == 12345.0f) {
+      b.pe_i[k] = s[5] + s[77];
+    }
   }
 };
 

@@ -152,7 +152,9 @@ struct HostLoopBackend {
   static constexpr bool kHasScatter = false;
   static constexpr bool kHasFusedAngular = false; // gpumd_amd/csrc/nep_fused.h: device code only
   template <class S>
-  void launch_angular_fused(int, int64_t, const ModelD&, const Bufs&, int)
+  size_t fused_image_floats(const ModelD&) const { return 0; }
+  template <class S>
+  void launch_angular_fused(int, int64_t, const ModelD&, const Bufs&, int, float*, bool)
   {
     std::abort();
   }
