@@ -18,6 +18,7 @@ One JSON line is printed by rank 0 (see the contract in the task description); i
                   bounded 16,000-atom sample of the same crystal (rank 0, N = 1 only)
 """
 import argparse
+import subprocess
 import datetime
 import json
 import os
@@ -282,7 +283,7 @@ def cpu_baseline_tersoff(pot, h, typ, x, mass, vel, seconds=12.0):
                       "neighbour search every call, %.1f s" % (n, calls, el)}
 
 
-def kernel_report(st, info, n_atoms_per_launch, st_all=None, tersoff=False):
+def kernel_report(st, info, n_atoms_per_launch, st_all=None, tersoff=False, fused_angular=False):
     """per-kernel mean durations (HIP events) + the roofline object of the dominant force kernel.
     st: stats of the timed region (timing mode 2: only the force-assembly slot is filled); st_all: stats of the
     instrumented pass after it (every slot) -- the timed region's own figure wins where both exist."""
@@ -291,6 +292,11 @@ def kernel_report(st, info, n_atoms_per_launch, st_all=None, tersoff=False):
     else:
         per_kernel, b_step = algorithmic_bytes(info, st.mean_nn_radial, st.mean_nn_angular)
     kern = {}
+    if fused_angular and not tersoff:
+        # nep_fused.h: descriptor + ANN + partial angular forces are ONE launch (timed in the angular-descriptor slot); its
+        # algorithmic bytes are the three stages' shares of the SURVEY 8(d) split (the step total is unchanged)
+        per_kernel = dict(per_kernel)
+        per_kernel["angular_fused"] = per_kernel.pop("angular_descriptor") + per_kernel.pop("ann") + per_kernel.pop("angular_partial_force")
     for src in (st_all, st):
         if src is None:
             continue
@@ -300,7 +306,10 @@ def kernel_report(st, info, n_atoms_per_launch, st_all=None, tersoff=False):
                 # they are not work, the mean is over the launches that ran
                 ran = int(src.launches[k]) - (int(src.discarded_steps) if 1 <= k <= 6 else 0)
                 ran = max(ran, 1)
-                kern[name] = {"launches": ran, "avg_ms": src.ms_kernel_sum[k] / ran}
+                if fused_angular and name == "angular_descriptor":
+                    name = "angular_fused"
+                kern[name] = {"launches": ran, "avg_ms": src.ms_kernel_sum[k] / ran, "slot": k,
+                              "timed_in": "timed region" if src is st else "instrumented pass after the clock"}
     # every kernel priced the same way as the roofline object below: algorithmic bytes / duration / HBM peak, and (where the
     # builder's PMC pass matches this workload size) the counter traffic beside it
     tj_all = {}
@@ -314,7 +323,8 @@ def kernel_report(st, info, n_atoms_per_launch, st_all=None, tersoff=False):
             if tj_all.get("atoms") == n_atoms_per_launch and name in tj_all.get("kernels", {}):
                 e["traffic"] = tj_all["kernels"][name]["hbm_bytes_per_launch"]
     force_kernels = [k for k in kern if k in per_kernel and k not in ("velocity_verlet", "gather_skin_check")]
-    dom = max(force_kernels, key=lambda k: kern[k]["avg_ms"] * kern[k]["launches"]) if force_kernels else None
+    ranked = sorted(force_kernels, key=lambda k: -kern[k]["avg_ms"])
+    dom = ranked[0] if ranked else None
     roofline = None
     if dom:
         traffic, tj = None, {}
@@ -333,10 +343,47 @@ def kernel_report(st, info, n_atoms_per_launch, st_all=None, tersoff=False):
                     "algorithmic_bytes_per_launch": per_kernel[dom] * n_atoms_per_launch,
                     "algorithmic_bytes_per_atom": per_kernel[dom], "avg_launch_ms": kern[dom]["avg_ms"],
                     "note": "FP32-VALU/gather bound stage (SURVEY.md 8d); see step_hbm_frac for the whole step"}
+        if len(ranked) > 1:  # the runner-up, priced the same way (two kernels can be tied to a per cent)
+            k2 = ranked[1]
+            roofline["second"] = {"kernel": k2, "avg_launch_ms": kern[k2]["avg_ms"], "frac": kern[k2].get("frac"),
+                                  "algorithmic_bytes_per_atom": per_kernel[k2], "traffic": kern[k2].get("traffic")}
     return kern, roofline, b_step
 
 
-def measure_extra(workload, reps, steps, warmup, dev):
+def dominant_slot(eng, run_steps, probe_steps=4):
+    """A short instrumented pass BEFORE the clock: which per-step force kernel (timing slots 1..5) takes longest?  Its slot
+    is the one that carries HIP events inside the timed region (nepmi_engine_set_timing(16 + slot))."""
+    eng.set_timing(1)
+    run_steps(probe_steps)
+    st = eng.stats(with_lists=False)
+    eng.set_timing(0)
+    best, slot = -1.0, 5
+    for k in range(1, 6):
+        if st.launches[k] > 0:
+            ran = max(int(st.launches[k]) - int(st.discarded_steps), 1)
+            if st.ms_kernel_sum[k] / ran > best:
+                best, slot = st.ms_kernel_sum[k] / ran, k
+    return slot
+
+
+def gpu_state():
+    """clocks and power state of the device the line was measured on (rocm-smi), to tell boxes apart: the same library runs
+    the radial pass at 0.365 ms on one box and 0.405 ms on another (README round 4)"""
+    out = {}
+    try:
+        r = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--showmaxpower", "--showperflevel", "--json"],
+                           capture_output=True, text=True, timeout=20)
+        j = json.loads(r.stdout)
+        card = j.get("card0", next(iter(j.values())) if j else {})
+        for k, v in card.items():
+            if any(t in k.lower() for t in ("sclk", "mclk", "fclk", "socclk", "power", "performance")):
+                out[k] = v
+    except Exception as e:  # never lose the bench line to this
+        out["error"] = "%s: %s" % (type(e).__name__, e)
+    return out
+
+
+def measure_extra(workload, reps, steps, warmup, dev, generic=False):
     """One more measurement AFTER the clock of the bench line has stopped (config.extra_measurements): its own engine, the
     same protocol (inputs resident, warm-up, K steps between synchronisations, HIP events on the dominant kernel inside
     the timed region, an instrumented pass after it).  -> dict with value / ms_per_step / roofline."""
@@ -347,6 +394,8 @@ def measure_extra(workload, reps, steps, warmup, dev):
     n = len(typ)
     model = gpumd_amd.Model(nep_txt)
     eng = gpumd_amd.NEP(model, n)
+    if generic:
+        eng.set_generic(True)
     dt = 1.0 / H.TIME_UNIT
     t_type, t_mass = torch.from_numpy(typ).to(dev), torch.from_numpy(mass).to(dev)
     t_x, t_v = torch.from_numpy(x).to(dev), torch.from_numpy(vel).to(dev)
@@ -354,7 +403,7 @@ def measure_extra(workload, reps, steps, warmup, dev):
     eng.force_compute(h, t_type, t_x, t_pe, t_f, t_w)
     if warmup > 0:
         eng.run_nve(h, t_type, t_mass, dt, warmup, t_x, t_v, t_pe, t_f, t_w)
-    eng.set_timing(2)
+    eng.set_timing(16 + dominant_slot(eng, lambda k: eng.run_nve(h, t_type, t_mass, dt, k, t_x, t_v, t_pe, t_f, t_w, thermo_every=k)))
     reb0 = eng.stats().num_rebuild
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -368,7 +417,8 @@ def measure_extra(workload, reps, steps, warmup, dev):
     st_all = eng.stats(with_lists=False)
     eng.set_timing(0)
     tersoff = workload == "si_tersoff"
-    kern, roofline, b_step = kernel_report(st, model.info, n, st_all, tersoff=tersoff)
+    kern, roofline, b_step = kernel_report(st, model.info, n, st_all, tersoff=tersoff,
+                                           fused_angular="partial_forces_in_one_kernel" in eng.describe())
     if tersoff and roofline:
         roofline["kernel"] = {"radial_descriptor": "tersoff_bond_order", "force_assemble": "tersoff_force"}[roofline["kernel"]]
     return {"workload": label, "metric": METRIC[workload], "value": n * steps / elapsed, "unit": "atom-steps/s",
@@ -718,7 +768,8 @@ def bench(args):
     # Inside the timed region only the dominant kernel (force assembly) carries HIP events -- two records per step; a
     # record around EVERY kernel stops them from running back to back and costs about 5 % of the step.  The full
     # per-kernel table comes from an instrumented pass of further steps after the clock has stopped.
-    eng.set_timing(2)
+    dom_slot = dominant_slot(eng, lambda k: eng.run_nve(h, t_type, t_mass, dt, k, t_x, t_v, t_pe, t_f, t_w, thermo_every=k))
+    eng.set_timing(16 + dom_slot)
     reb0 = eng.stats().num_rebuild
     barrier()
     t0 = time.perf_counter()
@@ -741,7 +792,8 @@ def bench(args):
 
     if rank == 0:
         tersoff = args.workload == "si_tersoff"
-        kern, roofline, b_step = kernel_report(st, model.info, n, st_all, tersoff=tersoff)
+        kern, roofline, b_step = kernel_report(st, model.info, n, st_all, tersoff=tersoff,
+                                               fused_angular="partial_forces_in_one_kernel" in eng.describe())
         if tersoff:
             # the two Tersoff kernels sit in the radial and force-assembly slots of the engine's timing table
             kern = {{"radial_descriptor": "tersoff_bond_order", "force_assemble": "tersoff_force"}.get(k, k): v
@@ -773,7 +825,9 @@ def bench(args):
             "step_algorithmic_bytes_per_atom": b_step,
             "step_hbm_frac": b_step * (n * args.steps / elapsed) / (HBM_PEAK_GBS * 1e9),
             "kernels": kern,
-            "kernels_note": "force_assemble: HIP events inside the timed region; the others: an instrumented pass of %d further steps" % extra,
+            "kernels_note": "the step's longest force kernel (found by a 4-step instrumented probe before the clock): HIP events inside "
+                            "the timed region; the others: an instrumented pass of %d further steps" % extra,
+            "gpu_state": gpu_state(),
             "thermo_last": [float(v) for v in th[-1]] if len(th) else None,
         }
         if args.workload == "pbte":
@@ -796,7 +850,7 @@ def bench(args):
                 seg = None
                 for _ in range(4):
                     r0 = eng.stats().num_rebuild
-                    eng.set_timing(2)
+                    eng.set_timing(16 + dom_slot)
                     torch.cuda.synchronize()
                     t1 = time.perf_counter()
                     eng.run_nve(h, t_type, t_mass, dt, 100, t_x, t_v, t_pe, t_f, t_w, thermo_every=100)
@@ -804,7 +858,8 @@ def bench(args):
                     el = time.perf_counter() - t1
                     st2 = eng.stats(with_lists=True)
                     eng.set_timing(0)
-                    kern2, roof2, _ = kernel_report(st2, model.info, n, None)
+                    kern2, roof2, _ = kernel_report(st2, model.info, n, None,
+                                                    fused_angular="partial_forces_in_one_kernel" in eng.describe())
                     seg = {"workload": label, "steps": 100, "ms_per_step": el / 100 * 1e3, "value": n * 100 / el,
                            "unit": "atom-steps/s", "rebuilds_in_timed_region": int(st2.num_rebuild - r0), "roofline": roof2}
                     if seg["rebuilds_in_timed_region"] >= 1:
@@ -812,6 +867,48 @@ def bench(args):
                 extras["pbte_100_steps_with_rebuild"] = seg
             except Exception as e:  # never lose the bench line to an extra
                 extras["pbte_100_steps_with_rebuild"] = {"error": str(e)}
+            # (a2) like for like with Ensemble_NVE::compute2 (ensemble_nve.cu:59-95 reduces thermo every step): thermo_every = 1,
+            #      i.e. energies and virials written and reduced on every step
+            try:
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                eng.run_nve(h, t_type, t_mass, dt, 40, t_x, t_v, t_pe, t_f, t_w, thermo_every=1)
+                torch.cuda.synchronize()
+                el = time.perf_counter() - t1
+                extras["pbte_thermo_every_step"] = {"workload": label, "steps": 40, "thermo_every": 1, "ms_per_step": el / 40 * 1e3,
+                                                    "value": n * 40 / el, "unit": "atom-steps/s"}
+            except Exception as e:
+                extras["pbte_thermo_every_step"] = {"error": str(e)}
+            # (a3) the drop-in entry as a GPUMD maintainer would call it (force.cu:819-822 inside
+            #      run.cu:250-326): per step nepmi_vv_step1 -> nepmi_force_compute -> nepmi_vv_step2 -> nepmi_find_thermo on the
+            #      caller's arrays -- gather-form assembly, all thirteen outputs, scatter-add into caller order, every step
+            try:
+                vol = float(abs(np.linalg.det(np.asarray(h, dtype=np.float64).reshape(3, 3))))
+                t_th = torch.zeros(8, dtype=torch.float64, device=dev)
+                ksteps = 30
+                for timed_pass in (False, True):
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    for _ in range(ksteps if timed_pass else 3):
+                        eng.vv_step1(dt, t_mass, t_f, t_x, t_v)
+                        eng.force_compute(h, t_type, t_x, t_pe, t_f, t_w)
+                        eng.vv_step2(dt, t_mass, t_f, t_v)
+                        eng.find_thermo(vol, t_mass, t_pe, t_v, t_w, t_th)
+                    torch.cuda.synchronize()
+                    el = time.perf_counter() - t1
+                extras["pbte_per_call_dropin"] = {"workload": label, "steps": ksteps, "ms_per_step": el / ksteps * 1e3,
+                                                  "value": n * ksteps / el, "unit": "atom-steps/s",
+                                                  "kernel_forms": eng.describe(),
+                                                  "note": "one host call per stage and step through the C ABI (what gpumd_ref_mi executes); "
+                                                          "thermo every step"}
+            except Exception as e:
+                extras["pbte_per_call_dropin"] = {"error": str(e)}
+            # (a4) the run-time-shape kernels (any n_max / basis_size / l_max / neuron count: what a user-trained potential
+            #      outside the compiled shapes gets), forced on this model so that the same workload is compared
+            try:
+                extras["pbte_generic_shape"] = measure_extra("pbte", reps, 10, 3, dev, generic=True)
+            except Exception as e:
+                extras["pbte_generic_shape"] = {"error": str(e)}
             try:
                 extras["config2_si_tersoff"] = measure_extra("si_tersoff", (16, 16, 16), 2000, 200, dev)
             except Exception as e:

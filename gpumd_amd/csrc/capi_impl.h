@@ -462,7 +462,7 @@ int nepmi_engine_set_timing(nepmi_engine* e, int on)
 {
   if (!e)
     return fail(NEPMI_ERR_ARG, "null engine");
-  e->e->backend().set_timing(on < 0 ? 0 : (on > 2 ? 1 : on));
+  e->e->backend().set_timing(on < 0 ? 0 : ((on >= 16 && on < 32) ? on : (on > 2 ? 1 : on)));
   e->e->num_discarded = 0; // counted over the same window as the kernel sums
   return NEPMI_OK;
 }

@@ -859,7 +859,8 @@ struct HipBackend {
   int* pinned = nullptr;       // 64-byte pinned staging for flag read-back
   bool timing_on = false; // any timing
   int timing_mode = 0;    // 1: every kernel and region; 2: the force-assembly kernel only (two events per step)
-  bool timed(int slot) const { return timing_mode == 1 ? slot != kSlotMisc : (timing_mode == 2 && slot == kSlotForce); }
+  int timing_slot = kSlotForce; // mode 2: the one slot that carries events (set_timing(16 + slot) chooses it)
+  bool timed(int slot) const { return timing_mode == 1 ? slot != kSlotMisc : (timing_mode == 2 && slot == timing_slot); }
   hipEvent_t probe_ev[2] = {nullptr, nullptr};
   bool mfma_on = true; // per-atom ANN on the matrix cores when the model shape allows it
   // device word the launches of the force path look at first (null: always run); set by the engine around the force
@@ -998,7 +999,8 @@ struct HipBackend {
       timing->reg[k].sum_ms = 0.0;
       timing->reg[k].count = 0;
     }
-    timing_mode = mode;
+    timing_slot = mode >= 16 ? mode - 16 : kSlotForce;
+    timing_mode = mode >= 16 ? 2 : mode;
     timing_on = mode != 0;
   }
   // stand-alone stopwatch on the engine's stream (independent of set_timing): used once per engine

@@ -939,6 +939,31 @@ private:
     md_.zbl_para = upload(m.zbl_para_f);
     md_.zbl_rco = m.zbl_typewise ? upload(m.zbl_rc_outer_pair) : nullptr;
     md_.atomic_number = upload(m.atomic_numbers);
+    md_.ctab_img[0] = md_.ctab_img[1] = md_.cang_img = nullptr;
+    if (m.kind != 0) // (Tersoff: no descriptor tables)
+      return;
+    // the radial coefficient table in the padded LDS layouts of the many-type window kernels (ctab_stage_padded)
+    for (int v = 0; v < 2; ++v) {
+      const int raw = (m.n_max_radial + 1) * (m.basis_size_radial + 1), blk = ctab_block(m.n_max_radial, m.basis_size_radial, v != 0);
+      const int npair = m.num_types * m.num_types;
+      std::vector<float> img(((size_t)npair * blk + 3) / 4 * 4, 0.0f);
+      if (m.c_rad.size() < (size_t)npair * raw)
+        continue;
+      for (int pr = 0; pr < npair; ++pr)
+        for (int e = 0; e < raw; ++e)
+          img[(size_t)pr * blk + e] = m.c_rad[(size_t)pr * raw + e];
+      md_.ctab_img[v] = upload(img);
+    }
+    {
+      md_.cang_img = nullptr; // (cang_stride / cang_floats read the shape fields set above)
+      const int per = (md_.NA + 1) * (md_.KA + 1), stride = cang_stride(md_);
+      std::vector<float> img((size_t)cang_floats(md_), 0.0f);
+      for (int pr = 0; pr < md_.T * md_.T && m.c_ang.size() >= (size_t)md_.T * md_.T * per; ++pr)
+        for (int r = 0; r < per; ++r)
+          img[(size_t)pr * stride + r] = m.c_ang[(size_t)pr * per + r];
+      if (m.c_ang.size() >= (size_t)md_.T * md_.T * per)
+        md_.cang_img = upload(img);
+    }
   }
 
   void allocate()
@@ -2019,7 +2044,7 @@ private:
   B be_;
   int64_t cap_; // allocation size (atoms)
   int64_t N_;   // atoms of the current (local) system, <= cap_; stride of every [slot][atom] array
-  ModelD md_;
+  ModelD md_{};
   Bufs b_;
   BoxD box_;
   WinLayout win_{0, 0};

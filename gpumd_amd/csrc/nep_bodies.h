@@ -1288,6 +1288,12 @@ NEPMI_HD int cang_floats(const ModelD& m) { return m.T * m.T * cang_stride(m); }
 NEPMI_HD void cang_stage(const ModelD& m, float* dst, int tid, int nth)
 {
   const int per = (m.NA + 1) * (m.KA + 1), stride = cang_stride(m);
+  if (m.cang_img) { // the engine's image of this layout (upload_model): a plain copy, no division per element
+    const int n = cang_floats(m);
+    for (int i = tid; i < n; i += nth)
+      dst[i] = m.cang_img[i];
+    return;
+  }
   for (int idx = tid; idx < m.T * m.T * per; idx += nth) {
     const int pair = idx / per, r = idx - pair * per;
     dst[pair * stride + r] = m.c_ang[idx];

@@ -136,6 +136,11 @@ struct ModelD {
   const float* zbl_para;   // [T(T+1)/2][10]
   const float* zbl_rco;    // [T*T] type-wise outer cutoff of the universal ZBL (inner cutoff 0 then), or nullptr
   const int* atomic_number; // [T]
+  // c_rad once more in the two padded LDS layouts of the window kernels of many-type shapes (nep_window.h: ctab_block; [0]
+  // element-wise reads, odd block stride; [1] 16-byte reads), so that a workgroup stages its copy with 16-byte loads instead
+  // of an integer division per element; nullptr: built by the workgroup
+  const float* ctab_img[2];
+  const float* cang_img; // c_ang in the LDS layout of the angular kernels (nep_bodies.h: cang_stage), or nullptr
 };
 
 // ---- geometry -------------------------------------------------------------------------------

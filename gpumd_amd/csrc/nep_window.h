@@ -74,6 +74,16 @@ NEPMI_HD void ctab_stage_padded(const ModelD& m, LC dst_bytes, int tid, int nth,
 {
   NEPMI_LDS(float)* ct = (NEPMI_LDS(float)*)dst_bytes;
   const int raw = (m.NR + 1) * (m.KR + 1), blk = ctab_block(m.NR, m.KR, vec), npair = m.T * m.T;
+  if (const float* img = m.ctab_img[vec ? 1 : 0]) { // the image of the engine (upload_model): a plain copy
+    const int n = npair * blk, n4 = n >> 2;
+    const F4f* __restrict__ src4 = reinterpret_cast<const F4f*>(img);
+    NEPMI_LDS(F4f)* d4 = (NEPMI_LDS(F4f)*)dst_bytes;
+    for (int i = tid; i < n4; i += nth)
+      d4[i] = src4[i];
+    for (int i = 4 * n4 + tid; i < n; i += nth)
+      ct[i] = img[i];
+    return;
+  }
   for (int i = tid; i < npair * blk; i += nth) {
     const int pr = i / blk, e = i - pr * blk;
     ct[i] = e < raw ? m.c_rad[pr * raw + e] : 0.0f;

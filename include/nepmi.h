@@ -418,8 +418,9 @@ int nepmi_engine_stats(nepmi_engine* e, int with_lists, nepmi_stats* out);
  * as config.kernel_forms).  Returns the length written (without the terminator) or a negative status. */
 int nepmi_engine_describe(nepmi_engine* e, char* buf, int len);
 /* HIP-event timing on the engine's stream.  on = 1: every kernel and region (two event records per launch: the
- * kernels no longer run back to back, about 5 % slower steps); on = 2: the force-assembly kernel only (what bench.py
- * keeps inside its timed region for the roofline figure); 0: off. */
+ * kernels no longer run back to back, about 5 % slower steps); on = 2: the force-assembly kernel only; on = 16 + k: only the
+ * kernel of slot k of nepmi_stats::ms_kernel_sum (what bench.py keeps inside its timed region for the roofline figure: the
+ * slot of the step's longest kernel); 0: off. */
 int nepmi_engine_set_timing(nepmi_engine* e, int on);
 /* Force the run-time-shaped (generic) kernel instantiation instead of a model-shape-specialised
  * one; used by the parity tests to cover both code paths with one model. */
