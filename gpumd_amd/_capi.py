@@ -52,7 +52,7 @@ class NepmiTransport(C.Structure):
 class NepmiDistInfo(C.Structure):
     _fields_ = [("n_owned", c_i64), ("n_local", c_i64), ("n_total", c_i64), ("num_decompositions", c_i64),
                 ("num_steps", c_i64), ("num_overlapped", c_i64), ("decompose_ms", C.c_double),
-                ("reverse_ghosts", c_i64)]
+                ("reverse_ghosts", c_i64), ("num_range_handovers", c_i64)]
 
 
 # every symbol include/nepmi.h declares: name -> (restype, argtypes)
@@ -109,6 +109,7 @@ SYMBOLS = {
     "nepmi_engine_set_force_form": (C.c_int, [VP, C.c_int]),
     "nepmi_engine_set_radial_mask": (C.c_int, [VP, C.c_int]),
     "nepmi_engine_set_angular_fused": (C.c_int, [VP, C.c_int]),
+    "nepmi_engine_set_scatter_guard": (C.c_int, [VP, C.c_double, C.c_double]),
     "nepmi_engine_set_win_static": (C.c_int, [VP, C.c_int]),
     "nepmi_engine_set_stepwise_loops": (C.c_int, [VP, C.c_int]),
     "nepmi_engine_describe": (C.c_int, [VP, C.c_char_p, C.c_int]),

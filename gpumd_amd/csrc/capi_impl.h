@@ -493,6 +493,14 @@ int nepmi_engine_set_radial_mask(nepmi_engine* e, int on)
   return NEPMI_OK;
 }
 
+int nepmi_engine_set_scatter_guard(nepmi_engine* e, double ev_per_angstrom, double hard_factor)
+{
+  if (!e)
+    return fail(NEPMI_ERR_ARG, "null engine");
+  e->e->set_scatter_guard(ev_per_angstrom, hard_factor);
+  return NEPMI_OK;
+}
+
 int nepmi_engine_set_angular_fused(nepmi_engine* e, int on)
 {
   if (!e)

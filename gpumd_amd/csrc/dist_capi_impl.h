@@ -129,6 +129,7 @@ int nepmi_dist_get_info(nepmi_dist* d, nepmi_dist_info* out)
   out->num_overlapped = d->d->num_overlapped;
   out->decompose_ms = d->d->decompose_ms;
   out->reverse_ghosts = d->d->reverse_ghosts() ? 1 : 0;
+  out->num_range_handovers = d->d->num_range_handovers();
   return NEPMI_OK;
 }
 

@@ -189,9 +189,25 @@ public:
     halo_exchange();
     eng_->force_kernels(Engine::kPhaseAll);
     force_reverse();
+    // The scatter form's guard band (nep_scatter.h): one word, reduced over the ranks -- whichever forms they ran -- so that
+    // all of them repeat the evaluation in the gather form, or none (a per-call evaluation never stands flagged).
+    {
+      int* word = eng_->bufs().flags + kFlagRange;
+      device_allreduce(word, 1, kDtI32, kOpMax);
+      int w = 0;
+      be_.d2h(&w, word, sizeof(int));
+      if (w) {
+        eng_->disable_scatter();
+        eng_->clear_range_hard();
+        halo_exchange(); // (the ghosts' positions are in place; the exchange keeps the step's collectives paired on every rank)
+        eng_->force_kernels(Engine::kPhaseAll);
+        force_reverse();
+      }
+    }
     ++eng_->num_compute;
     have_force_ = true;
   }
+  int64_t num_range_handovers() const { return eng_ ? eng_->num_range_handovers : 0; } // (nepmi_dist_info)
 
   // ---- the run loop (Run::perform_a_run, run.cu:250-318) for the ensembles of EngineT::run_md ----
   void run(int ens, double dt, int64_t nsteps, double t1, double t2, double tcoup, int64_t thermo_every, double* thermo_host)
@@ -355,6 +371,12 @@ public:
             pending.erase(pending.begin());
             if (snap[kFlagMoved])
               trip = sync_flags();
+            else if (snap[kFlagRange] && e->scatter_enabled()) {
+              // the scatter form's guard band, voted: every rank reads the same snapshot of the same step and leaves the form
+              // here; the flagged steps stand (a value beyond the hard limit met meanwhile raised kOverflowRangeHard, which the
+              // vote carries to every rank as well)
+              trip = sync_flags();
+            }
           }
         }
       }
@@ -375,7 +397,7 @@ public:
     num_steps += nsteps;
     // the last step's kernels may have raised a capacity bit after its vote: reduce the words once more, so that the
     // final check throws on every rank or on none
-    device_allreduce(e->bufs().flags + kFlagMoved, 2, kDtI32, kOpMax);
+    device_allreduce(e->bufs().flags + kFlagMoved, 3, kDtI32, kOpMax);
     be_.sync();
     e->check_flags_now();
   }
@@ -675,12 +697,12 @@ private:
     // [moved, overflow] are adjacent: the capacity bits travel with the vote, so that every rank sees a capacity error at
     // the same synchronisation point and they all report it (a rank that threw alone would leave the others waiting in
     // their next collective)
-    static_assert(kFlagOverflow == kFlagMoved + 1, "the vote reduces two adjacent flag words");
+    static_assert(kFlagOverflow == kFlagMoved + 1 && kFlagRange == kFlagMoved + 2, "the vote reduces three adjacent flag words");
     int* word = eng_->bufs().flags + kFlagMoved;
     // a transport that can (nepmi.h: NEPMI_DT_DEFER) posts the reduction inside the group of the ghost exchange that follows on
     // the same stream: the word is first read by the kernels behind that exchange
     const bool defer = spec && (tr_.device_buffers & 2) != 0;
-    device_allreduce_on(on, word, 2, kDtI32 | (defer ? NEPMI_DT_DEFER : 0), kOpMax);
+    device_allreduce_on(on, word, 3, kDtI32 | (defer ? NEPMI_DT_DEFER : 0), kOpMax);
     if (spec)
       return 0;
     int w = 0;
@@ -1170,6 +1192,7 @@ private:
       grown->set_external_skin(true); // the global vote is the skin policy
       grown->set_loop_context(true);  // every force evaluation here feeds the integrator and the global sums: the force
                                       // assembly may take its scatter form (per-atom virials: exact_virials at the gathers)
+      grown->set_flagged_steps_stand(true); // (the scatter form's guard band: hand-over by vote, hard limit as an error)
       grown->set_reverse_ghosts(reverse_);
       grown->bdp_seed(seed_);
       if (eng_) // a grown local system: the switches, the temperature, the noise sequence and the counters move over

@@ -104,14 +104,9 @@ public:
   {
     std::memset(&b_, 0, sizeof(b_));
     b_.scatter_limit = 64.0f;   // nep_scatter.h: kScatterFlagLimit
-    b_.fold_guard = 1 << 30;    // kFoldGuard
-    if (const char* g = std::getenv("NEPMI_SCATTER_GUARD")) { // tests: a guard band low enough for ordinary forces to leave it
-      const double v = std::atof(g);
-      if (v > 0.0 && v <= 64.0) {
-        b_.scatter_limit = (float)v;
-        b_.fold_guard = (int)(4.0 * v * 4194304.0);
-      }
-    }
+    b_.fold_guard = 1 << 29;    // kFoldGuard
+    b_.scatter_hard = 0.0f;     // set_flagged_steps_stand
+    b_.fold_hard = 0;
     std::memset(&md_, 0, sizeof(md_));
     std::memset(&box_, 0, sizeof(box_));
     try {
@@ -138,6 +133,7 @@ public:
   const Bufs& bufs() const { return b_; }
   int64_t num_atoms() const { return N_; }
   int64_t num_compute = 0, num_rebuild = 0, num_discarded = 0;
+  int64_t num_range_handovers = 0; // times the scatter form was left for the gather form (guard band of its fixed-point sums)
   // kPhaseBoundaryRadial / kPhaseAfterRadial: kPhaseBoundary in two parts, so that the boundary bricks' radial pass can be
   // enqueued on the communication stream right behind the ghost unpack (force_kernels_on) and run beside the tail of the
   // interior launch instead of after it
@@ -184,6 +180,7 @@ public:
     if (!flag)
       return;
     scatter_disabled_ = true;
+    ++num_range_handovers;
     be_.memset(b_.flags + kFlagRange, 0, sizeof(int));
     force_kernels(kPhaseAll);
   }
@@ -296,6 +293,7 @@ public:
     } else {
       force_kernels(kPhaseBoundary);
     }
+    redo_outside_scatter_range(); // (the split form can take the scatter form too: set_force_form(1))
     scatter_add(pe, force, virial);
     ++num_compute;
   }
@@ -1082,8 +1080,12 @@ private:
       // nep_scatter.h: a pair half beyond the guard band of the fixed-point accumulators (the sums are still exact: the band
       // sits a factor eight below their range).  The gather form has no such limit: it takes over for the rest of the run.
       scatter_disabled_ = true;
+      ++num_range_handovers;
       be_.memset(b_.flags + kFlagRange, 0, sizeof(int));
     }
+    if (flags[kFlagOverflow] & kOverflowRangeHard)
+      throw EngineError{-4, "a force beyond 256 eV/A reached the fixed-point sums of the scatter-form force assembly before the gather "
+                            "form had taken over (decomposed run: a flagged step stands): run with nepmi_engine_set_force_form(e, 0)"};
     if (flags[kFlagOverflow] & 8)
       throw EngineError{-4, "non-finite atom coordinates (the simulation has blown up, or the position array is not initialised)"};
     if (flags[kFlagOverflow]) {
@@ -1374,6 +1376,8 @@ private:
       // per window slot) and, per atom, the table of the windows that hold it (nep_scatter.h: FoldMapBody)
       const size_t need = (size_t)num_bricks_ * (size_t)win_.wmax * 4;
       if (need > halo_cap_) {
+        dfree(halo_);
+        halo_ = nullptr;
         halo_ = dalloc<int>(need + need / 8);
         halo_cap_ = need + need / 8;
       }
@@ -1384,6 +1388,8 @@ private:
         int most = be_.build_fold_map(N_, box_, b_, win_.wmax, fold_rows_, fmap_);
         if (most > fold_rows_) { // (partly filled bricks next to a periodic face: a cell can lie in up to 27 windows)
           fold_rows_ = most;
+          dfree(fmap_);
+          fmap_ = nullptr;
           fmap_ = dalloc<unsigned>((size_t)fold_rows_ * cap_);
           most = be_.build_fold_map(N_, box_, b_, win_.wmax, fold_rows_, fmap_);
         }
@@ -1616,6 +1622,11 @@ public:
     ang_fused_ = o.ang_fused_;
     loop_ctx_ = o.loop_ctx_;
     scatter_disabled_ = o.scatter_disabled_;
+    b_.scatter_limit = o.b_.scatter_limit;
+    b_.fold_guard = o.b_.fold_guard;
+    b_.scatter_hard = o.b_.scatter_hard;
+    b_.fold_hard = o.b_.fold_hard;
+    hard_factor_ = o.hard_factor_;
     if (reverse_ghosts_ != o.reverse_ghosts_)
       set_reverse_ghosts(o.reverse_ghosts_);
     unwrapped_ = o.unwrapped_;
@@ -1627,6 +1638,7 @@ public:
     num_compute = o.num_compute;
     num_rebuild = o.num_rebuild;
     num_discarded = o.num_discarded;
+    num_range_handovers = o.num_range_handovers;
     be_.adopt_options(o.be_);
     if (ann_mode_ != o.ann_mode_)
       set_use_mfma(o.ann_mode_);
@@ -1866,6 +1878,47 @@ public:
   // 1: scatter-form steps of the run loops keep the per-step radial list as inside bits over the packed Verlet words
   // (Bufs::rmaskB) instead of compacting it; 0 (default): the compact list on every step.  Identical results, bit for bit.
   void set_radial_mask(bool on) { use_rmask_ = on; }
+  // Guard band of the scatter form (nepmi_engine_set_scatter_guard): a pair half beyond `limit` eV/A (default 64; a net force
+  // component beyond twice that) hands the force assembly over to the gather form.  Tests lower it so that ordinary forces trip it.
+  void set_scatter_guard(double limit, double hard_factor = 4.0)
+  {
+    if (!(limit > 0.0) || limit > 64.0)
+      limit = 64.0;
+    if (!(hard_factor >= 1.0) || hard_factor * limit > 256.0)
+      hard_factor = 256.0 / limit < 4.0 ? 256.0 / limit : 4.0;
+    b_.scatter_limit = (float)limit;
+    b_.fold_guard = (int)(2.0 * limit * 4194304.0);
+    hard_factor_ = hard_factor;
+    if (b_.scatter_hard > 0.0f)
+      set_flagged_steps_stand(true);
+  }
+  double scatter_guard() const { return b_.scatter_limit; }
+  // Decomposed runs: a flagged step stands (every rank leaves the scatter form together, a few steps later, when the flag has
+  // travelled with the skin vote), so a value beyond four times the guard band met meanwhile is an error instead of a wrap
+  void set_flagged_steps_stand(bool on)
+  {
+    b_.scatter_hard = on ? (float)(hard_factor_ * b_.scatter_limit) : 0.0f;
+    b_.fold_hard = on ? (int)(hard_factor_ * b_.scatter_limit * 4194304.0) : 0;
+  }
+  bool scatter_enabled() const { return !scatter_disabled_; }
+  // a flagged evaluation that is being repeated in the gather form does not stand: its hard-limit bit goes with it
+  void clear_range_hard()
+  {
+    int ov = 0;
+    be_.d2h(&ov, b_.flags + kFlagOverflow, sizeof(int));
+    if (ov & kOverflowRangeHard) {
+      ov &= ~kOverflowRangeHard;
+      be_.h2d(b_.flags + kFlagOverflow, &ov, sizeof(int));
+    }
+  }
+  void disable_scatter()
+  {
+    if (!scatter_disabled_)
+      ++num_range_handovers;
+    scatter_disabled_ = true;
+    be_.memset(b_.flags + kFlagRange, 0, sizeof(int));
+  }
+  bool last_scatter_form() const { return last_scatter_form_; }
   // 1 (default): angular descriptor, ANN and partial angular forces in one kernel where ang_fused_active() allows; 0: separately
   void set_angular_fused(bool on) { ang_fused_ = on; }
   // the callers whose steps need forces, energies and the TOTAL virial only (run loops; the decomposed driver)
@@ -2054,6 +2107,7 @@ private:
   int force_form_ = -1;          // set_force_form
   bool loop_ctx_ = false;        // set_loop_context
   bool virial_local_ = false;    // the virial planes of the last force evaluation hold the own-half form (exact_virials)
+  double hard_factor_ = 4.0;     // set_scatter_guard: hard limit of runs whose flagged steps stand = factor x guard band
   bool ang_fused_ = true;        // set_angular_fused
   float* fused_img_ = nullptr;   // LDS image of the fused angular kernel (nep_fused.h), built at its first launch
   size_t fused_img_floats_ = 0;
@@ -2120,6 +2174,18 @@ private:
   int bdp_iset_ = 0;
   double bdp_gset_ = 0.0;
   std::vector<void*> allocs_;
+  void dfree(void* p) // a buffer that is being replaced (halo_, fmap_): back to the device now, not at the engine's end
+  {
+    if (!p)
+      return;
+    for (size_t i = 0; i < allocs_.size(); ++i)
+      if (allocs_[i] == p) {
+        allocs_.erase(allocs_.begin() + i);
+        break;
+      }
+    be_.sync(); // (a launch still reading it may be in flight)
+    be_.free(p);
+  }
 };
 
 } // namespace nepmi

@@ -79,13 +79,18 @@ struct Shape {
 using ShapeGeneric = Shape<-1, -1, -1, -1, -1, 0>;
 
 enum FlagSlot {
-  kFlagMoved = 0, kFlagOverflow = 1, kFlagMaxSkin = 2, kFlagMaxAng = 3,
-  kFlagMaxWindow = 4, kFlagMaxBrick = 5, kFlagMaxCell = 6, kFlagNumBoundary = 7,
-  kFlagOutlier = 8, // an atom sits more than half a cell outside the box along an open direction
-  kFlagRange = 9,   // the scatter-form force assembly met a pair half beyond its fixed-point guard band (nep_scatter.h)
+  kFlagMoved = 0, kFlagOverflow = 1,
+  kFlagRange = 2,   // the scatter-form force assembly met a pair half beyond its fixed-point guard band (nep_scatter.h); right
+                    // behind the two words of the skin vote: a decomposed run reduces the three together (dist_impl.h: vote)
+  kFlagMaxSkin = 3, kFlagMaxAng = 4,
+  kFlagMaxWindow = 5, kFlagMaxBrick = 6, kFlagMaxCell = 7, kFlagNumBoundary = 8,
+  kFlagOutlier = 9, // an atom sits more than half a cell outside the box along an open direction
   kFlagFoldRows = 10, // scratch word of FoldMapBody: the most windows an atom lies in
   kNumFlags = 12
 };
+// bits of flags[kFlagOverflow]: 1, 2, 4 list capacities; 8 non-finite coordinates; 16 a force beyond the HARD limit of the
+// scatter form's fixed-point sums in a run whose flagged steps stand (decomposed runs)
+constexpr int kOverflowRangeHard = 16;
 
 struct Bufs {
   int64_t N;
@@ -213,6 +218,11 @@ struct Bufs {
   int use_rmask; // 1: this step's radial pass writes the masks instead of ccode
   float scatter_limit; // guard band of the scatter-form assembly per pair half, eV/A (nep_scatter.h: kScatterFlagLimit)
   int fold_guard;      // ... and per component of an atom's net force, fixed point (kFoldGuard)
+  // Decomposed runs (a flagged step stands until every rank has seen the vote): a pair half / net component beyond these is
+  // an ERROR (flags[kFlagOverflow] |= kOverflowRangeHard) instead of a silent wrap of the 32-bit sums; 0: no hard limit (the
+  // single-domain callers re-run a flagged evaluation in the gather form at once)
+  float scatter_hard;
+  int fold_hard;
   int trip_tag;  // != 0: a speculatively enqueued step of a single-domain run loop -- a force beyond the fixed-point guard band of the
                  // scatter-form assembly freezes the loop at this step like a skin trip (flags[kFlagMoved] = tag), and the host
                  // re-runs the step in the gather form

@@ -21,10 +21,11 @@
 // kernels is not needed here (type-pure list segments; nothing is gathered by index) -- + accumulators as 12-byte rows:
 // 24 B per window atom, 49 KB for the 2,048-slot windows of PbTe 1 M atoms: three workgroups per CU.
 //
-// Range: a pair half beyond +-64 eV/A (|s12| or a partial angular force component) sets flags[kFlagRange]; the engine then
-// returns to the gather form for good at its next look at the flags.  The accumulators wrap modulo 2^32 (two's complement),
-// so only the NET sum of a window has to stay inside +-512 eV/A -- eight aligned pair halves of a size that has already
-// tripped the flag.
+// Range: a pair half beyond +-64 eV/A (|s12| or a partial angular force component) or a net force component beyond 128 eV/A
+// sets flags[kFlagRange]; the engine then returns to the gather form for good -- a single-domain evaluation or loop step is
+// re-run at once, a decomposed run hands over within a dozen steps (the flag travels with the skin vote) and treats a value
+// beyond 256 eV/A met before that as an error (kOverflowRangeHard).  The accumulators wrap modulo 2^32 (two's complement), so
+// only the NET sum of a window has to stay inside +-512 eV/A.
 //
 // Per-atom virials: the own half gives W'_i = -sum_j r_ij (x) g_ij, whose SUM over the atoms is the reference's total
 // (sum_i sum_j r_ij (x) f21 re-indexed) but whose per-atom attribution is not; the run loops need the total only
@@ -46,7 +47,9 @@ namespace nepmi {
 constexpr float kScatterScale = 4194304.0f;             // 2^22 fixed-point units per eV/A
 constexpr double kScatterInvScale = 1.0 / 4194304.0;
 constexpr float kScatterFlagLimit = 64.0f;              // eV/A per pair half: beyond it the engine leaves this form
-constexpr int kFoldGuard = 1 << 30;                     // ... and per component of an atom's net force: 256 eV/A in fixed point
+constexpr int kFoldGuard = 1 << 29;                     // ... and per component of an atom's net force: 128 eV/A in fixed point
+constexpr float kScatterHardLimit = 256.0f;             // decomposed runs: a pair half beyond this is an error, not a hand-over
+constexpr int kFoldHard = 1 << 30;                      // ... and a net force component beyond 256 eV/A (the sums wrap at 512)
 constexpr unsigned kFoldNone = 0xFFFFFFFFu;             // unused entry of the fold map
 constexpr int kFoldSlotBits = 13;                       // fold map entry = brick << 13 | slot (windows hold <= 5,000 atoms)
 
@@ -86,6 +89,12 @@ __device__ __forceinline__ void scatter_range_trip(const Bufs& b)
   atomicOr(&b.flags[kFlagRange], 1);
   if (b.trip_tag)
     atomicCAS(&b.flags[kFlagMoved], 0, b.trip_tag);
+}
+
+// the value may have been beyond what the sums hold: where a flagged step stands (Bufs::scatter_hard != 0) that is an error
+__device__ __forceinline__ void scatter_range_hard(const Bufs& b)
+{
+  atomicOr(&b.flags[kFlagOverflow], kOverflowRangeHard);
 }
 
 __device__ __forceinline__ void lds_add(NEPMI_LDS(int)* p, int v)
@@ -471,8 +480,11 @@ __device__ __forceinline__ void force_scatter_atom(const ForceScatterBody<S>& B,
     lds_add(ro + 1, Fi[1]);
     lds_add(ro + 2, Fi[2]);
   }
-  if (NEPMI_FS_ABL == 0 && big >= b.scatter_limit)
+  if (NEPMI_FS_ABL == 0 && big >= b.scatter_limit) {
     scatter_range_trip(b);
+    if (b.scatter_hard > 0.0f && big >= b.scatter_hard)
+      scatter_range_hard(b);
+  }
 
   // ---- outputs of this kernel, internal order: energy and the local-form virial (the force comes from ForceFoldBody) ----
   if (!OUT || lv < b.lvl_force)
@@ -756,8 +768,11 @@ __device__ __forceinline__ void force_scatter_atom_mt(const ForceScatterBody<S>&
     lds_add(ro + 1, Fi[1]);
     lds_add(ro + 2, Fi[2]);
   }
-  if (NEPMI_FS_ABL == 0 && big >= b.scatter_limit)
+  if (NEPMI_FS_ABL == 0 && big >= b.scatter_limit) {
     scatter_range_trip(b);
+    if (b.scatter_hard > 0.0f && big >= b.scatter_hard)
+      scatter_range_hard(b);
+  }
   if (!OUT)
     return;
 #pragma unroll
@@ -974,11 +989,16 @@ struct ForceFoldBody {
         s2 += h[u].z;
       }
     }
-    // the sums are modular: the NET force of an atom has to fit.  Half the range (256 eV/A) is the guard band of the total; the
-    // pair halves have their own, a factor four below it (kScatterFlagLimit)
+    // the sums are modular: the NET force of an atom has to fit.  A quarter of the range (128 eV/A) is the guard band of the
+    // total, half of it (256 eV/A) the hard limit of runs whose flagged steps stand; the pair halves have their own (64 / 256).
+    // What neither sees: a net beyond 768 eV/A made of a dozen aligned pair halves that each stay under 64 eV/A aliases into the
+    // band -- no physical configuration of a NEP model gets there (the ZBL term of a collision is not part of these sums).
     const int a0 = s0 < 0 ? -s0 : s0, a1 = s1 < 0 ? -s1 : s1, a2 = s2 < 0 ? -s2 : s2;
-    if (a0 >= b.fold_guard || a1 >= b.fold_guard || a2 >= b.fold_guard || s0 == INT_MIN || s1 == INT_MIN || s2 == INT_MIN)
+    if (a0 >= b.fold_guard || a1 >= b.fold_guard || a2 >= b.fold_guard || s0 == INT_MIN || s1 == INT_MIN || s2 == INT_MIN) {
       scatter_range_trip(b);
+      if (b.fold_hard > 0 && (a0 >= b.fold_hard || a1 >= b.fold_hard || a2 >= b.fold_hard || s0 == INT_MIN || s1 == INT_MIN || s2 == INT_MIN))
+        scatter_range_hard(b);
+    }
     double F[3] = {(double)s0 * kScatterInvScale, (double)s1 * kScatterInvScale, (double)s2 * kScatterInvScale};
     if (m.zbl_enabled && lv >= 2) {
 #pragma unroll

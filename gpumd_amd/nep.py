@@ -314,6 +314,10 @@ class NEP:
         (nepmi_engine_set_radial_mask)"""
         self._ck(self.lib.nepmi_engine_set_radial_mask(self.handle, 1 if on else 0))
 
+    def set_scatter_guard(self, ev_per_angstrom=64.0, hard_factor=0.0):
+        """guard band of the scatter-form force assembly per pair half (test hook: nepmi_engine_set_scatter_guard)"""
+        self._ck(self.lib.nepmi_engine_set_scatter_guard(self.handle, float(ev_per_angstrom), float(hard_factor)))
+
     def set_angular_fused(self, on=True):
         """angular descriptor + ANN + partial angular forces in one kernel (default) or as separate kernels
         (nepmi_engine_set_angular_fused)"""

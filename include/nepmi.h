@@ -344,8 +344,8 @@ int nepmi_dist_set_overlap(nepmi_dist* d, int on);
  * nepmi_dist_set_ghost_mode / nepmi_dist_set_overlap explicitly, which take precedence): NEPMI_DIST_GHOSTS=forward|reverse replaces
  * the counted rule of mode -1 when the context is created; NEPMI_RCCL_FUSE_VOTE=1 makes the RCCL transport carry the skin vote
  * inside the ghost exchange's group (NEPMI_DT_DEFER); NEPMI_DIST_TRACE prints the stages of a re-decomposition to stderr.
- * Engines read NEPMI_SCATTER_GUARD (eV/A, <= 64) when they are created: a test hook that narrows the guard band of the scatter-form
- * force assembly (see nepmi_engine_set_force_form) so that its hand-over to the gather form can be exercised with ordinary forces. */
+ * (The guard band of the scatter-form force assembly is narrowed for tests through nepmi_engine_set_scatter_guard, not through the
+ * environment.) */
 int nepmi_dist_set_ghost_mode(nepmi_dist* d, int mode);
 typedef struct {
   int64_t n_owned, n_local, n_total; /* atoms owned by this rank, owned + ghosts, in the whole system */
@@ -353,6 +353,8 @@ typedef struct {
   int64_t num_overlapped; /* steps whose interior radial pass was enqueued before the ghost exchange completed */
   double decompose_ms;    /* wall time spent in the (re-)decompositions so far: migration, ghost stages, list rebuild */
   int64_t reverse_ghosts; /* 1: reverse-mode ghosts (nepmi_dist_set_ghost_mode), 0: forward */
+  int64_t num_range_handovers; /* times the scatter-form force assembly was left for the gather form because a force reached its
+                                  guard band (nepmi_engine_set_force_form): 0 or 1 per engine generation */
 } nepmi_dist_info;
 int nepmi_dist_get_info(nepmi_dist* d, nepmi_dist_info* out);
 /* sizeof(nepmi_dist_info) of the library: a caller compiled against an older header (a shorter struct) can tell before
@@ -432,7 +434,7 @@ int nepmi_engine_set_generic(nepmi_engine* e, int on);
  * fit LDS or an atom sits far outside the box along an open direction.  Both give identical lists and forces to
  * f32 rounding. */
 int nepmi_engine_set_tiles(nepmi_engine* e, int on);
-/* Lanes per atom of the LDS-window kernels: 0 (default) = by the number of bricks (4 up to 256 bricks, 2 up to 400,
+/* Lanes per atom of the LDS-window kernels: 0 (default) = by the number of bricks (4 up to 256 bricks, 2 up to 512,
  * else 1: small systems are bound by the latency of one workgroup); 1, 2, 4 pin it. */
 int nepmi_engine_set_win_lanes(nepmi_engine* e, int lanes);
 /* Form of the force assembly (find_force_radial + gpu_find_force_many_body: nep.cu:661-772, potential.cu:170-297).
@@ -446,11 +448,21 @@ int nepmi_engine_set_win_lanes(nepmi_engine* e, int lanes);
  * mode -1 (default): the fused run loops (nepmi_run_*, nepmi_dist_*) take the scatter form where it applies, the per-call
  * entry points (nepmi_potential_compute, nepmi_force_compute) the gather form; 0: gather everywhere; 1: scatter wherever it
  * applies (per-call evaluations then add the virial-only pass).  Range: the fixed-point sums hold +-512 eV/A net per atom (they
- * are modular, so only the net has to fit).  A pair half beyond 64 eV/A or a net force component beyond 256 eV/A returns the engine
- * to the gather form for the rest of its life, and the evaluation that met it does not stand: a per-call evaluation is repeated in
- * the gather form before it returns, a step of a single-domain run loop freezes like a skin trip and is re-run.  In a decomposed
- * run (nepmi_dist_*) the flagged step stands -- exact while the net stays inside +-512 eV/A -- and the next steps use the gather form. */
+ * are modular, so only the net has to fit).  A pair half beyond 64 eV/A or a net force component beyond 128 eV/A returns the engine
+ * to the gather form for the rest of its life, and the evaluation that met it does not stand: a per-call evaluation (one-call or
+ * begin/end form) is repeated in the gather form before it returns, a step of a single-domain run loop freezes like a skin trip and
+ * is re-run.  In a decomposed run (nepmi_dist_*) the flag travels with the skin vote (one reduction of three words per step), every
+ * rank leaves the scatter form at the same step -- at most twelve steps later (the host looks at the voted words every fourth
+ * step, two looks in flight) -- and the steps in between stand: they are exact while every value stays inside the sums, and a pair
+ * half or a net component beyond 256 eV/A met in that window is an ERROR on every rank (NEPMI_ERR_STATE at the next look), never a
+ * silent wrap.  nepmi_dist_compute checks the flag before it returns (one 4-byte reduction) and repeats the evaluation in the
+ * gather form on every rank.  Not seen by either guard: a net beyond 768 eV/A made of a dozen or more aligned pair halves that
+ * each stay under 64 eV/A. */
 int nepmi_engine_set_force_form(nepmi_engine* e, int mode);
+/* Test hook: the guard band of the scatter form per pair half in eV/A (default and maximum 64; the net-force guard is twice the
+ * value), so that the hand-over can be exercised with ordinary forces; hard_factor: the hard limit of decomposed runs as a
+ * multiple of the band (<= 0: the default 4; the limit never exceeds 256 eV/A). */
+int nepmi_engine_set_scatter_guard(nepmi_engine* e, double ev_per_angstrom, double hard_factor);
 /* The per-step radial list of the scatter-form steps of the run loops (find_neighbor_list_large_box, nep.cu:436-486, is what it
  * replaces): on = 1: one inside bit per candidate of the packed Verlet words, which the force assembly walks with the bits as
  * weights -- no compacted list is written (a conditional 2-byte store per pair and its bookkeeping: a third of the radial

@@ -62,10 +62,18 @@ def run_rank(out_dir, spec, rank, world, make_transport, stream=None):
         md._ck(md.lib.nepmi_engine_set_force_form(e, int(spec["force_form"])))
         if int(spec["force_form"]) == 1:  # the scatter form is the one-lane form: pin it (the rule takes two lanes up to 512 bricks)
             md._ck(md.lib.nepmi_engine_set_win_lanes(e, 1))
+    def set_guard():  # narrow the guard band of the scatter form (on the ranks listed, default: all)
+        if spec.get("scatter_guard") is not None and (spec.get("guard_ranks") is None or rank in spec["guard_ranks"]):
+            e = md.lib.nepmi_dist_engine(md.handle)
+            md._ck(md.lib.nepmi_engine_set_scatter_guard(e, float(spec["scatter_guard"]), float(spec.get("guard_hard_factor", 0.0))))
+    if not spec.get("guard_after_compute"):
+        set_guard()
     if spec.get("seed") is not None:
         md.bdp_seed(spec["seed"])
         md.lan_seed(spec["seed"])
     md.compute()
+    if spec.get("guard_after_compute"):
+        set_guard()
 
     def snapshot():
         no = md.info().n_owned
@@ -90,7 +98,7 @@ def run_rank(out_dir, spec, rank, world, make_transport, stream=None):
     info = md.info()
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), i0=i0, f0=f0, th0=th0, i1=i1, x1=x1, v1=v1, f1=f1, th1=th1, th=th, w1=w1, th2=th2,
              n_loc=info.n_local, n_own=info.n_owned, reverse=info.reverse_ghosts, ndec=info.num_decompositions, nover=info.num_overlapped,
-             nrev=md.num_overlapped_reverse())
+             nrev=md.num_overlapped_reverse(), nhand=info.num_range_handovers)
     md.close()
     tr.close()
 

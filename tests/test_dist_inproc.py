@@ -157,6 +157,43 @@ def test_reverse_exchange_overlapped_with_the_interior_bricks_on_gpu():
         np.testing.assert_allclose(ra["th1"], rb["th1"], rtol=0, atol=0)
 
 
+@pytest.mark.gpu
+def test_scatter_guard_band_in_a_decomposed_run_is_voted():
+    """The fixed-point sums of the scatter-form force assembly in a decomposed run (192,000 atoms, two ranks, device transport,
+    speculative enqueue).  The guard band is lowered on ONE rank only, so that ordinary forces trip it there: (a) the per-call
+    evaluation (nepmi_dist_compute) is repeated in the gather form on BOTH ranks -- initial forces equal the gather-form run's bit
+    for bit; (b) with the band lowered after that evaluation the loop's first steps trip it: the flag travels with the skin vote,
+    both ranks leave the form together, the flagged steps stand, and the trajectory agrees with the gather-form run to the
+    rounding of the two forms; (c) a band so low that the hard limit (four times the band) is reached ends the run with an error
+    on both ranks instead of letting a wrapped sum through."""
+    if not os.path.exists(LIB["gpu"]):
+        pytest.skip("tests/inproc transports not built")
+    import test_dist as T
+    base = T._spec("gpu", "PbTe-reps", (12, 8, 8), (2, 1, 1), "nve", 24, 600.0, ghosts=1)
+    gather = _run_threads(2, dict(base, force_form=0))
+    plain = _run_threads(2, dict(base, force_form=1))
+    assert all(int(r["nhand"]) == 0 for r in gather + plain)
+    for a, b in zip(plain, gather):  # the two forms: the same trajectory to their rounding
+        assert np.array_equal(a["i1"], b["i1"]) and np.abs(a["x1"] - b["x1"]).max() < 2e-6
+    # (a) band 0.25 eV/A on rank 1 from the start (forces of this structure: a few eV/A): nepmi_dist_compute trips it there
+    low = _run_threads(2, dict(base, force_form=1, scatter_guard=0.25, guard_ranks=[1], guard_hard_factor=1000.0))
+    assert all(int(r["nhand"]) == 1 for r in low), [int(r["nhand"]) for r in low]
+    for a, b in zip(low, gather):
+        assert np.array_equal(a["i0"], b["i0"]) and np.array_equal(a["f0"], b["f0"])
+        assert np.abs(a["x1"] - b["x1"]).max() < 2e-6 and np.abs(a["f1"] - b["f1"]).max() < 1e-3  # ... and so is the run
+    # (b) the same band set AFTER the per-call evaluation: the loop's first steps trip it on rank 1, the vote carries it
+    voted = _run_threads(2, dict(base, force_form=1, scatter_guard=0.25, guard_ranks=[1], guard_hard_factor=1000.0,
+                                 guard_after_compute=True))
+    assert all(int(r["nhand"]) == 1 for r in voted), [int(r["nhand"]) for r in voted]
+    for a, b in zip(voted, gather):
+        assert np.array_equal(a["i1"], b["i1"])
+        assert np.abs(a["x1"] - b["x1"]).max() < 2e-6 and np.abs(a["f1"] - b["f1"]).max() < 1e-3
+    # (c) the hard limit (default: four times the band): band 0.01 eV/A after compute() -> an error on every rank
+    errors = _run_threads(2, dict(base, force_form=1, scatter_guard=0.01, guard_after_compute=True), expect_errors=True)
+    assert sorted(r for r, _ in errors) == [0, 1], errors
+    assert all("fixed-point" in msg for _, msg in errors), errors
+
+
 def test_a_capacity_error_of_one_rank_ends_the_run_on_every_rank():
     """40 steps at 3000 K melt the PbTe block until one rank exceeds the angular list capacity of the model file (MN): the
     capacity bits travel with the skin vote, so both ranks report the error at the same point instead of one of them

@@ -153,7 +153,7 @@ def test_scatter_form_properties(drv):
 def test_scatter_guard_band_hands_over_to_the_gather_form(drv, monkeypatch):
     """The fixed-point sums of the scatter form hold +-512 eV/A; a pair half beyond 64 eV/A (or a net force beyond 256) makes the
     engine leave the form.  No NEP model of the repository produces such forces on a sane structure, so the test lowers the band
-    through NEPMI_SCATTER_GUARD (read when an engine is created): (a) a force evaluation that leaves the band is REPEATED in the
+    through nepmi_engine_set_scatter_guard: (a) a force evaluation that leaves the band is REPEATED in the
     gather form before anything is returned -- bit-identical to an engine that never used the scatter form; (b) inside a run loop
     the step freezes like a skin trip and is re-run in the gather form -- same trajectory as the gather-form engine (to the
     rounding of a different list generation: the replay rebuilds the lists)."""
@@ -164,12 +164,9 @@ def test_scatter_guard_band_hands_over_to_the_gather_form(drv, monkeypatch):
     model = drv.model(nep)
 
     def make(form, guard):
-        if guard:
-            monkeypatch.setenv("NEPMI_SCATTER_GUARD", guard)
-        else:
-            monkeypatch.delenv("NEPMI_SCATTER_GUARD", raising=False)
         eng = drv.engine(model, n)
-        monkeypatch.delenv("NEPMI_SCATTER_GUARD", raising=False)
+        if guard:
+            eng.set_scatter_guard(float(guard))
         eng.set_win_lanes(1)
         eng.set_force_form(form)
         return eng
