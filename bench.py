@@ -244,17 +244,49 @@ def reference_gpu_baseline(steps=200, timeout=180.0):
         return None
     sys.path.insert(0, os.path.join(ROOT, "profiles"))
     import ref_compare as R
+    from gpumd_amd import structures as S
+    traj = None
     with tempfile.TemporaryDirectory() as d:
         n = R.case_inputs("pbte_1m", d)
         with open(os.path.join(d, "run.in")) as f:
             run = f.read()
+        # velocities in model.xyz (vel:R:3 of the 250-atom cell; `replicate` repeats them with the cell, replicate.cu:51-72), no
+        # `velocity` keyword: the reference's HIP build draws from the process-wide rand() stream the runtime also uses, so only
+        # this makes the two programs start from the same state -- and lets their trajectories be compared below
+        fr = S.read_xyz_frames(os.path.join(d, "model.xyz"))[0]
+        spec, pos = list(fr["species"]), np.asarray(fr["pos"], dtype=np.float64)
+        mass = np.array([S.MASS.get(e, 100.0) for e in spec])
+        vel = S.maxwell_velocities(mass, 300.0, seed=3).reshape(3, -1).T / S.TIME_UNIT
+        lat = np.asarray(fr["lattice"], dtype=np.float64).reshape(9)
+        with open(os.path.join(d, "model.xyz"), "w") as f:
+            f.write("%d\n" % len(spec))
+            f.write('pbc="T T T" Lattice="%s" Properties=species:S:1:pos:R:3:vel:R:3\n' % " ".join("%.12g" % v for v in lat))
+            for e, p, v in zip(spec, pos, vel):
+                f.write("%s %.12f %.12f %.12f %.15e %.15e %.15e\n" % (e, p[0], p[1], p[2], v[0], v[1], v[2]))
+        run = re.sub(r"velocity [^\n]*\n", "", run)
         with open(os.path.join(d, "run.in"), "w") as f:
             f.write(re.sub(r"\nrun \d+", "\nrun %d" % steps, re.sub(r"dump_thermo \d+", "dump_thermo %d" % steps, run)))
-        res, _ = R.run_binary(exe, d, timeout)
+        res, th_ref = R.run_binary(exe, d, timeout)
+        # the same inputs through this repository's own host (gpumd-mi): the last thermo row of both, i.e. the bench path -- the
+        # fused run loop in its scatter form at 1,024,000 atoms, list rebuilds included -- against the reference's trajectory
+        if os.path.exists(R.MI) and th_ref is not None:
+            for fn in ("thermo.out", "neighbor.out"):
+                if os.path.exists(os.path.join(d, fn)):
+                    os.remove(os.path.join(d, fn))
+            res_mi, th_mi = R.run_binary(R.MI, d, timeout)
+            if th_mi is not None and th_mi.shape == th_ref.shape:
+                a, b = th_ref[-1], th_mi[-1]
+                traj = {"steps": steps, "atoms": n,
+                        "rel_dT": float(abs(b[0] / a[0] - 1.0)), "rel_dU": float(abs(b[2] / a[2] - 1.0)),
+                        "max_abs_dP_GPa": float(np.abs(b[3:9] - a[3:9]).max()),
+                        "gpumd_mi_speed": res_mi.get("speed"),
+                        "note": "last thermo.out row of gpumd-mi (this engine: fused run loop, scatter-form assembly, list rebuilds "
+                                "inside) vs the reference's gpumd on identical run.in / model.xyz (velocities from the file)"}
     if not res.get("speed"):
         return None
     return {"value": res["speed"], "unit": "atom-steps/s", "kind": "reference gpumd (src/makefile.hip flags, gfx950), same GPU",
-            "sample": "PbTe %d atoms (replicate 16 16 16), %d NVE steps, %.2f s in its run block" % (n, steps, res["run_seconds"])}
+            "sample": "PbTe %d atoms (replicate 16 16 16), %d NVE steps, %.2f s in its run block" % (n, steps, res["run_seconds"]),
+            "trajectory_vs_this_engine": traj}
 
 
 def cpu_baseline_tersoff(pot, h, typ, x, mass, vel, seconds=12.0):
@@ -430,7 +462,7 @@ def measure_extra(workload, reps, steps, warmup, dev, generic=False):
 
 
 def run_decomposed(args, world, rank, dev, model, label, h_block, typ, x, mass, vel, scaling=None, leg=0, steps=None,
-                   warmup=None):
+                   warmup=None, overlap=None, ghosts=None, checksum=False, brief=False):
     """N > 1 (or --decomposed on one GPU): the C++ domain-decomposed driver of libnepmi (nepmi_dist_*), one rank per
     GPU, ghost positions over RCCL/xGMI.  Python only builds the synthetic block and passes pointers.
     -> the bench line as a dict on rank 0 (None elsewhere).  `leg` numbers the runs of one process (own TCP port each)."""
@@ -483,9 +515,11 @@ def run_decomposed(args, world, rank, dev, model, label, h_block, typ, x, mass, 
     STAGE = "decomposed[%s]: setup (first decomposition, ghost exchange, list build)" % scaling
     if os.environ.get("NEPMI_BENCH_FAIL_STAGE") == "setup" and rank == world - 1:
         raise RuntimeError("injected failure (NEPMI_BENCH_FAIL_STAGE: tests/test_bench_launch.py)")
-    md = DistMD(model, tr, Hg.reshape(9), (1, 1, 1), grid, ghost_mode=args.ghosts)
-    if args.overlap >= 0:
-        md.set_overlap(bool(args.overlap))
+    ghosts = args.ghosts if ghosts is None else ghosts
+    overlap = args.overlap if overlap is None else overlap
+    md = DistMD(model, tr, Hg.reshape(9), (1, 1, 1), grid, ghost_mode=ghosts)
+    if overlap >= 0:
+        md.set_overlap(bool(overlap))
     md.setup(torch.from_numpy(np.ascontiguousarray(T)).to(dev), torch.from_numpy(np.ascontiguousarray(M)).to(dev),
              torch.from_numpy(np.ascontiguousarray(X).reshape(-1)).to(dev),
              torch.from_numpy(np.ascontiguousarray(V).reshape(-1)).to(dev))
@@ -498,6 +532,7 @@ def run_decomposed(args, world, rank, dev, model, label, h_block, typ, x, mass, 
     if warmup > 0:
         md.run(ens, dt, warmup, *t_args)
     md.engine_set_timing(2)  # the dominant kernel only inside the timed region (see the single-GPU path)
+    tr.rccl_stats(time_every=4, reset=True)  # (RCCL transports: count what the timed region moves, time every 4th exchange)
     dec0 = md.info().num_decompositions
     STAGE = "decomposed[%s]: timed region" % scaling
     if world > 1:
@@ -511,6 +546,7 @@ def run_decomposed(args, world, rank, dev, model, label, h_block, typ, x, mass, 
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    rccl = tr.rccl_stats(time_every=0)
     STAGE = "decomposed[%s]: instrumented pass" % scaling
     st = md.engine_stats(with_lists=True)
     th = md.thermo()
@@ -519,6 +555,32 @@ def run_decomposed(args, world, rank, dev, model, label, h_block, typ, x, mass, 
     st_all = md.engine_stats(with_lists=False)
     md.engine_set_timing(0)
     info = md.info()
+    # A checksum of the decomposed forces: every atom's force gathered on rank 0 and compared with ONE-domain evaluation of the
+    # same positions there -- a transport that silently delivered wrong ghosts would produce a fast wrong number otherwise
+    check = None
+    if checksum:
+        STAGE = "decomposed[%s]: checksum (gather_global + one-domain evaluation on rank 0)" % scaling
+        nt = int(info.n_total)
+        g_x = torch.zeros(3 * nt if rank == 0 else 1, dtype=torch.float64, device=dev)
+        g_f = torch.zeros(3 * nt if rank == 0 else 1, dtype=torch.float64, device=dev)
+        md.compute()  # forces of the current positions (the run loops leave the last step's kick pending)
+        md.gather_global(0, pos=g_x, force=g_f)
+        if rank == 0:
+            try:
+                # ids of the strong leg: rank r contributed atoms r, r + world, ... in that order: global id = position in the
+                # concatenation of the ranks' slices
+                ids_of = np.concatenate([np.arange(n)[np.arange(n) % world == r] for r in range(world)]) if scaling == "strong" else np.arange(nt)
+                t_typ = torch.from_numpy(np.ascontiguousarray(typ[ids_of] if scaling == "strong" else np.tile(typ, world))).to(dev)
+                one = gpumd_amd.NEP(model, nt)
+                o_pe, o_f, o_w = (torch.zeros(k * nt, dtype=torch.float64, device=dev) for k in (1, 3, 9))
+                one.force_compute(Hg.reshape(9), t_typ, g_x, o_pe, o_f, o_w)
+                torch.cuda.synchronize()
+                check = {"atoms": nt, "max_abs_dF_eV_per_A": float((o_f - g_f).abs().max().item()),
+                         "max_abs_F": float(o_f.abs().max().item()),
+                         "note": "decomposed forces (gather_global) vs one-domain nepmi_force_compute of the same positions on rank 0"}
+                del one
+            except Exception as e:  # never lose the line to the check
+                check = {"error": "%s: %s" % (type(e).__name__, e)}
     t_el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     n_loc = torch.tensor([float(info.n_local)], dtype=torch.float64, device=dev)
     t_own = torch.zeros(world, dtype=torch.float64, device=dev)
@@ -561,6 +623,22 @@ def run_decomposed(args, world, rank, dev, model, label, h_block, typ, x, mass, 
         out["device_memory"] = {"used_gb_rank0": (total_b - free_b) / 1e9, "total_gb": total_b / 1e9,
                                 "note": "hipMemGetInfo after the run on rank 0: engine + decomposition buffers + the PyTorch context"}
         out["config"]["kernel_forms"] = md.engine_describe()
+        out["config"]["overlap"] = int(overlap)
+        if rccl is not None:
+            ex = max(int(rccl["exchanges"]), 1)
+            out["rccl"] = {"comm_nranks": int(rccl["comm_nranks"]), "comm_rank": int(rccl["comm_rank"]),
+                           "exchanges_in_timed_region": int(rccl["exchanges"]), "exchanges_per_step": rccl["exchanges"] / steps,
+                           "messages_per_exchange": rccl["messages"] / ex, "bytes_sent_per_exchange": rccl["bytes_sent"] / ex,
+                           "allreduces_per_step": rccl["allreduces"] / steps,
+                           "us_per_exchange": rccl["us_per_timed_exchange"], "timed_exchanges": int(rccl["timed_exchanges"]),
+                           "note": "rank 0's RCCL transport over the timed region; us_per_exchange: HIP events on the stream of every "
+                                   "4th grouped ncclSend/ncclRecv exchange (it includes waiting for the slowest peer)"}
+        if check is not None:
+            out["checksum"] = check
+        if brief:
+            out = {k: out[k] for k in ("value", "unit", "ms_per_step", "steps", "scaling", "rccl", "checksum") if k in out}
+            out.update(overlap=int(overlap), ghost_mode="reverse" if info.reverse_ghosts else "forward",
+                       local_atoms_max=int(n_loc.item()))
     STAGE = "decomposed[%s]: teardown" % scaling
     md.close()
     tr.close()
@@ -716,18 +794,41 @@ def bench(args):
             out["functional_only"] = ("ranks share %d GPU(s) over the TCP transport (host staging): the protocol of the N-GPU run, "
                                       "not its performance" % torch.cuda.device_count())
         if world > 1 and args.scaling == "weak" and not args.no_extras:
-            # after the clock: the SAME 1,024,000-atom system as the N = 1 line cut over the N GPUs (strong scaling)
+            # after the clock: the SAME 1,024,000-atom system as the N = 1 line cut over the N GPUs (strong scaling), with the
+            # force checksum against a one-domain evaluation on rank 0
             try:
                 label_s, _, h_s, typ_s, x_s, mass_s, vel_s = build_workload(args.workload, reps, 42)
                 strong = run_decomposed(args, world, rank, dev, model, label_s, h_s, typ_s, x_s, mass_s, vel_s,
-                                        scaling="strong", leg=1, steps=min(args.steps, 100), warmup=min(args.warmup, 10))
+                                        scaling="strong", leg=1, steps=min(args.steps, 100), warmup=min(args.warmup, 10), checksum=True)
                 if out is not None and strong is not None:
                     out.setdefault("extra_measurements", {})["strong"] = {
                         k: strong[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "scaling", "config", "roofline",
-                                               "step_hbm_frac")}
+                                               "step_hbm_frac", "rccl", "checksum") if k in strong}
             except Exception as e:  # never lose the bench line to an extra
                 if out is not None:
                     out.setdefault("extra_measurements", {})["strong"] = {"error": "%s: %s" % (type(e).__name__, e), "stage": STAGE}
+            # ... and the 2 x 2 matrix exchange/compute overlap {off, on} x ghosts {forward, reverse} on both legs (40 steps
+            # each), so that ONE driver command settles the defaults on real hardware
+            matrix = {}
+            leg = 2
+            for sc in ("weak", "strong"):
+                for ov in (0, 1):
+                    for gh in (0, 1):
+                        key = "%s_overlap%d_%s" % (sc, ov, "reverse" if gh else "forward")
+                        try:
+                            if sc == "weak":
+                                wl = (label, h, typ, x, mass, vel)
+                            else:
+                                wl = (label_s, h_s, typ_s, x_s, mass_s, vel_s)
+                            r = run_decomposed(args, world, rank, dev, model, wl[0], wl[1], wl[2], wl[3].copy(), wl[4], wl[5].copy(),
+                                               scaling=sc, leg=leg, steps=40, warmup=5, overlap=ov, ghosts=gh, brief=True)
+                            if r is not None:
+                                matrix[key] = r
+                        except Exception as e:
+                            matrix[key] = {"error": "%s: %s" % (type(e).__name__, e), "stage": STAGE}
+                        leg += 1
+            if out is not None:
+                out.setdefault("extra_measurements", {})["overlap_x_ghosts"] = matrix
         if out is not None:
             print(json.dumps(out))
             sys.stdout.flush()

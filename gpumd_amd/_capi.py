@@ -55,6 +55,12 @@ class NepmiDistInfo(C.Structure):
                 ("reverse_ghosts", c_i64), ("num_range_handovers", c_i64)]
 
 
+class NepmiRcclStats(C.Structure):
+    _fields_ = [("comm_nranks", c_i64), ("comm_rank", c_i64), ("exchanges", c_i64), ("messages", c_i64),
+                ("bytes_sent", c_i64), ("bytes_received", c_i64), ("allreduces", c_i64), ("timed_exchanges", c_i64),
+                ("us_per_timed_exchange", C.c_double)]
+
+
 # every symbol include/nepmi.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "nepmi_last_error": (C.c_char_p, []),
@@ -119,6 +125,7 @@ SYMBOLS = {
     "nepmi_transport_rccl_id": (C.c_int, [C.c_char_p]),
     "nepmi_transport_rccl": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(NepmiTransport)]),
     "nepmi_transport_tcp": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(NepmiTransport)]),
+    "nepmi_transport_rccl_stats": (C.c_int, [C.POINTER(NepmiTransport), C.c_int, C.c_int, C.POINTER(NepmiRcclStats)]),
     "nepmi_transport_destroy": (None, [C.POINTER(NepmiTransport)]),
     "nepmi_dist_create": (VP, [VP, C.POINTER(NepmiTransport), c_dp, c_ip, c_ip, VP]),
     "nepmi_dist_destroy": (None, [VP]),

@@ -1505,6 +1505,8 @@ struct RcclApi {
   decltype(&ncclSend) Send = nullptr;
   decltype(&ncclRecv) Recv = nullptr;
   decltype(&ncclAllReduce) AllReduce = nullptr;
+  decltype(&ncclCommCount) CommCount = nullptr;       // (optional: statistics only)
+  decltype(&ncclCommUserRank) CommUserRank = nullptr;
   bool ok = false;
 };
 
@@ -1528,6 +1530,8 @@ const RcclApi& rccl_api()
     NEPMI_RCCL_SYM(Send);
     NEPMI_RCCL_SYM(Recv);
     NEPMI_RCCL_SYM(AllReduce);
+    NEPMI_RCCL_SYM(CommCount);
+    NEPMI_RCCL_SYM(CommUserRank);
 #undef NEPMI_RCCL_SYM
     a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.GroupStart && a.GroupEnd && a.Send && a.Recv && a.AllReduce;
     return a;
@@ -1537,6 +1541,13 @@ const RcclApi& rccl_api()
 
 struct RcclCtx {
   ncclComm_t comm;
+  // what travelled (nepmi_transport_rccl_stats): grouped exchanges, their messages and bytes, reductions; and, for every
+  // `time_every`-th exchange, a pair of HIP events on the exchange's own stream around the ncclGroup
+  int64_t n_exchange = 0, n_msgs = 0, bytes_sent = 0, bytes_recv = 0, n_allreduce = 0;
+  int time_every = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> timed; // recorded pairs, drained by the stats call
+  double timed_us_sum = 0.0;
+  int64_t timed_count = 0;
   // NEPMI_RCCL_FUSE_VOTE=1: a reduction passed with NEPMI_DT_DEFER waits for the next exchange on its stream and is posted inside
   // that call's ncclGroup (off by default: a collective and point-to-point operations in one group has only ever run here on a
   // single rank)
@@ -1562,6 +1573,16 @@ int rccl_exchange(void* vctx, int ns, const nepmi_msg* sends, int nr, const nepm
     ok = rccl_reduce_now(c, c->p_buf, c->p_count, c->p_dtype, c->p_op, c->p_stream) == ncclSuccess;
     c->pending = false;
   }
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  if (c->time_every > 0 && c->n_exchange % c->time_every == 0 && c->timed.size() < 4096 &&
+      hipEventCreate(&ev0) == hipSuccess && hipEventCreate(&ev1) == hipSuccess)
+    (void)hipEventRecord(ev0, (hipStream_t)stream);
+  ++c->n_exchange;
+  c->n_msgs += ns + nr;
+  for (int k = 0; k < ns; ++k)
+    c->bytes_sent += sends[k].bytes;
+  for (int k = 0; k < nr; ++k)
+    c->bytes_recv += recvs[k].bytes;
   ok = (R.GroupStart() == ncclSuccess) && ok;
   if (c->pending && ok) { // the skin vote rides in this group: one collective for the vote and the ghost positions
     ok = rccl_reduce_now(c, c->p_buf, c->p_count, c->p_dtype, c->p_op, stream) == ncclSuccess;
@@ -1572,6 +1593,10 @@ int rccl_exchange(void* vctx, int ns, const nepmi_msg* sends, int nr, const nepm
   for (int k = 0; k < nr && ok; ++k)
     ok = R.Recv(recvs[k].buf, (size_t)recvs[k].bytes, ncclChar, recvs[k].peer, c->comm, (hipStream_t)stream) == ncclSuccess;
   ok = (R.GroupEnd() == ncclSuccess) && ok;
+  if (ev0 && ev1) {
+    (void)hipEventRecord(ev1, (hipStream_t)stream);
+    c->timed.emplace_back(ev0, ev1);
+  }
   return ok ? 0 : -1;
 }
 
@@ -1579,6 +1604,7 @@ int rccl_allreduce(void* vctx, void* buf, int64_t count, int dtype, int op, void
 {
   RcclCtx* c = (RcclCtx*)vctx;
   bool ok = true;
+  ++c->n_allreduce;
   if (c->pending) { // reductions stay in order
     ok = rccl_reduce_now(c, c->p_buf, c->p_count, c->p_dtype, c->p_op, c->p_stream) == ncclSuccess;
     c->pending = false;
@@ -1595,10 +1621,25 @@ int rccl_allreduce(void* vctx, void* buf, int64_t count, int dtype, int op, void
   return (rccl_reduce_now(c, buf, count, dtype & 0xFF, op, stream) == ncclSuccess && ok) ? 0 : -1;
 }
 
+void rccl_drain_timed(RcclCtx* c)
+{
+  for (auto& pr : c->timed) {
+    float ms = 0.0f;
+    if (hipEventSynchronize(pr.second) == hipSuccess && hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+      c->timed_us_sum += 1.0e3 * (double)ms;
+      ++c->timed_count;
+    }
+    (void)hipEventDestroy(pr.first);
+    (void)hipEventDestroy(pr.second);
+  }
+  c->timed.clear();
+}
+
 void rccl_destroy(void* vctx)
 {
   RcclCtx* c = (RcclCtx*)vctx;
   if (c) {
+    rccl_drain_timed(c);
     rccl_api().CommDestroy(c->comm);
     delete c;
   }
@@ -1643,5 +1684,36 @@ extern "C" int nepmi_transport_rccl(const char id[NEPMI_RCCL_ID_BYTES], int rank
   out->exchange = rccl_exchange;
   out->allreduce = rccl_allreduce;
   out->destroy = rccl_destroy;
+  return NEPMI_OK;
+}
+
+extern "C" int nepmi_transport_rccl_stats(const nepmi_transport* t, int time_every, int reset, nepmi_rccl_stats* out)
+{
+  if (!t || !t->ctx || t->exchange != rccl_exchange)
+    return fail(NEPMI_ERR_ARG, "not an RCCL transport");
+  RcclCtx* c = (RcclCtx*)t->ctx;
+  rccl_drain_timed(c);
+  if (out) {
+    int cnt = -1, ur = -1;
+    if (rccl_api().CommCount)
+      (void)rccl_api().CommCount(c->comm, &cnt);
+    if (rccl_api().CommUserRank)
+      (void)rccl_api().CommUserRank(c->comm, &ur);
+    out->comm_nranks = cnt;
+    out->comm_rank = ur;
+    out->exchanges = c->n_exchange;
+    out->messages = c->n_msgs;
+    out->bytes_sent = c->bytes_sent;
+    out->bytes_received = c->bytes_recv;
+    out->allreduces = c->n_allreduce;
+    out->timed_exchanges = c->timed_count;
+    out->us_per_timed_exchange = c->timed_count > 0 ? c->timed_us_sum / (double)c->timed_count : 0.0;
+  }
+  if (reset) {
+    c->n_exchange = c->n_msgs = c->bytes_sent = c->bytes_recv = c->n_allreduce = 0;
+    c->timed_us_sum = 0.0;
+    c->timed_count = 0;
+  }
+  c->time_every = time_every > 0 ? time_every : 0;
   return NEPMI_OK;
 }

@@ -56,6 +56,14 @@ class Transport:
         _capi.check(lib, lib.nepmi_transport_rccl(ident, int(rank), int(nranks), C.byref(t)))
         return cls(lib, t)
 
+    def rccl_stats(self, time_every=0, reset=False):
+        """counters of an RCCL transport (nepmi_transport_rccl_stats) as a dict, or None for any other transport; time_every > 0:
+        from now on every time_every-th grouped exchange is bracketed by HIP events on its stream"""
+        out = _capi.NepmiRcclStats()
+        if self.lib.nepmi_transport_rccl_stats(C.byref(self.struct), int(time_every), 1 if reset else 0, C.byref(out)) != 0:
+            return None
+        return {k: getattr(out, k) for k, _ in out._fields_}
+
     def close(self):
         if self.struct is not None:
             self.lib.nepmi_transport_destroy(C.byref(self.struct))
@@ -142,6 +150,12 @@ class DistMD:
     def gather_owned(self, ids, pos, vel, force, pe=None, virial=None):
         self._ck(self.lib.nepmi_dist_gather_owned(self.handle, self._ptr(ids), self._ptr(pos), self._ptr(vel),
                                                   self._ptr(force), self._ptr(pe), self._ptr(virial)))
+
+    def gather_global(self, root, pos=None, vel=None, force=None, pe=None, virial=None):
+        """every atom of the system on rank `root`, ordered by global id (device arrays with n_total entries per plane on the
+        root, ignored elsewhere); collective (nepmi_dist_gather_global)"""
+        self._ck(self.lib.nepmi_dist_gather_global(self.handle, int(root), self._ptr(pos), self._ptr(vel), self._ptr(force),
+                                                   self._ptr(pe), self._ptr(virial)))
 
     def engine_stats(self, with_lists=False):
         e = self.lib.nepmi_dist_engine(self.handle)

@@ -941,8 +941,14 @@ void Run::perform_a_run()
   const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   std::printf("Time used for this run = %g second.\n", sec);
   std::printf("Speed of this run = %g atom*step/second.\n", (double)N * number_of_steps / sec); // run.cu:325-326
-  if (auto* p = dynamic_cast<NEP_MI*>(force.potentials[0].get()))
+  if (auto* p = dynamic_cast<NEP_MI*>(force.potentials[0].get())) {
     p->write_neighbor_out();
+    // which kernel forms the engine's counted rules chose, and how often the lists were rebuilt (not in the reference's log)
+    char forms[512];
+    nepmi_stats st;
+    if (nepmi_engine_describe(p->engine(), forms, (int)sizeof(forms)) >= 0 && nepmi_engine_stats(p->engine(), 0, &st) >= 0)
+      std::printf("    (libnepmi: %s; list rebuilds so far: %lld)\n", forms, (long long)st.num_rebuild);
+  }
   for (auto& d : dump_xyzs)
     if (d.fid) {
       std::fclose(d.fid);

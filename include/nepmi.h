@@ -287,6 +287,18 @@ int nepmi_transport_rccl(const char id[NEPMI_RCCL_ID_BYTES], int rank, int nrank
 /* TCP sockets on one node (rank 0 listens on master_addr:port, the MASTER_ADDR / MASTER_PORT of a torchrun-style
  * launch); host buffers. */
 int nepmi_transport_tcp(const char* master_addr, int port, int rank, int nranks, nepmi_transport* out);
+/* What an RCCL transport has moved so far (bench.py prints it next to an N-GPU line, so that a run explains itself): the size and
+ * rank the COMMUNICATOR reports (ncclCommCount / ncclCommUserRank), grouped exchanges, their point-to-point messages and bytes,
+ * reductions, and the mean duration of the exchanges that were timed.  time_every > 0: from now on every time_every-th exchange
+ * is bracketed by two HIP events on the stream it is enqueued on (0: no events -- the default); reset != 0 clears the counters
+ * after reading them.  out may be NULL (only set time_every / reset).  Not an RCCL transport: NEPMI_ERR_ARG. */
+typedef struct {
+  int64_t comm_nranks, comm_rank;
+  int64_t exchanges, messages, bytes_sent, bytes_received, allreduces;
+  int64_t timed_exchanges;
+  double us_per_timed_exchange;
+} nepmi_rccl_stats;
+int nepmi_transport_rccl_stats(const nepmi_transport* t, int time_every, int reset, nepmi_rccl_stats* out);
 void nepmi_transport_destroy(nepmi_transport* t);
 
 typedef struct nepmi_dist nepmi_dist;

@@ -68,8 +68,8 @@ FINE = 0
 def case_inputs(name, d):
     """Writes run.in, model.xyz and the potential file into d; returns the number of atoms after replication."""
     os.makedirs(d, exist_ok=True)
-    if name in ("pbte_1m", "pbte_128k", "pbte_16k", "pbte_250"):
-        reps = {"pbte_1m": 16, "pbte_128k": 8, "pbte_16k": 4, "pbte_250": 1}[name]
+    if name in ("pbte_1m", "pbte_250k", "pbte_128k", "pbte_16k", "pbte_250"):
+        reps = {"pbte_1m": 16, "pbte_250k": 10, "pbte_128k": 8, "pbte_16k": 4, "pbte_250": 1}[name]
         shutil.copy(os.path.join(GOLD, "PbTe", "model.xyz"), os.path.join(d, "model.xyz"))
         shutil.copy(os.path.join(GOLD, "PbTe", "nep.txt"), os.path.join(d, "nep.txt"))
         steps = 500 if reps >= 8 else 2000
@@ -136,7 +136,7 @@ def case_inputs(name, d):
         run = re.sub(r"velocity [^\n]*\n", "", run)
         m = re.search(r"replicate (\d+) (\d+) (\d+)\n", run)
         reps = tuple(int(v) for v in m.groups()) if m else (1, 1, 1)
-        cap = 4 if name.startswith("pbte") else (20 if name.startswith("carbon") else (1 if name == "unep" else 99))
+        cap = 10 if name == "pbte_250k" else 4 if name.startswith("pbte") else (20 if name.startswith("carbon") else (1 if name == "unep" else 99))
         reps = tuple(min(r, cap) for r in reps)  # explicit files: 13,824 to 64,000 atoms
         run = re.sub(r"replicate [^\n]*\n", "", run)
         from gpumd_amd import structures as S

@@ -340,3 +340,7 @@ extern "C" int nepmi_transport_rccl(const char*, int, int, nepmi_transport*)
 {
   return fail(NEPMI_ERR_HIP, "no RCCL in the kernel-logic emulator");
 }
+extern "C" int nepmi_transport_rccl_stats(const nepmi_transport*, int, int, nepmi_rccl_stats*)
+{
+  return fail(NEPMI_ERR_ARG, "not an RCCL transport");
+}
