@@ -36,6 +36,7 @@ METRIC = {"pbte": "atom-steps/sec, NEP PbTe NVE (nep4 2 Te Pb, examples/nep_trai
           "pbte_ortho": "atom-steps/sec, NEP PbTe NVE, orthogonal rock-salt cell (examples/nep_train/nep.txt)",
           "carbon": "atom-steps/sec, NEP carbon (potentials/nep/C_2022_NEP4.txt)",
           "unep": "atom-steps/sec, NEP UNEP-v1 16-metal alloy (potentials/nep/Song-2024-UNEP-v1)",
+          "carbon2024": "atom-steps/sec, NEP C_2024 (potentials/nep/C_2024_NEP4.txt), a model shape outside the compiled set",
           "si_tersoff": "atom-steps/sec, Tersoff-1989 Si NVE (BASELINE config 2: examples/gpumd_benchmark/Si_Tersoff)"}
 KERNEL_NAMES = ["gather_skin_check", "radial_descriptor", "angular_descriptor", "ann", "angular_partial_force",
                 "force_assemble", "velocity_verlet", "list_rebuild"]
@@ -71,6 +72,13 @@ def build_workload(name, reps, seed):
         h, typ, x, mass, vel = S.diamond_block(cells, seed=seed)
         return ("diamond C %d atoms (%dx%dx%d cells), C_2022_NEP4, 300 K" % ((len(typ),) + cells),
                 S.golden("C", "nep.txt"), h, typ, x, mass, vel)
+    if name == "carbon2024":
+        # a shipped potential OUTSIDE the library's compiled shapes (n_max 12 8, basis_size 16 12, rc 7 / 4 A, 100 neurons):
+        # served by a JIT core (capi_jit.h) or, with NEPMI_JIT=0, by the run-time-shape kernels
+        cells = tuple(4 * r for r in reps)  # 10 10 10 -> 40^3 diamond cells = 512,000 atoms
+        h, typ, x, mass, vel = S.diamond_block(cells, seed=seed)
+        return ("diamond C %d atoms (%dx%dx%d cells), C_2024_NEP4 (potentials/nep), 300 K" % ((len(typ),) + cells),
+                S.golden("C", "nep_2024.txt"), h, typ, x, mass, vel)
     if name == "unep":
         cells = tuple(4 * r for r in reps)
         h, typ, x, mass, vel = S.fcc_alloy_block(cells, seed=seed)
@@ -711,7 +719,7 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--reps", type=int, nargs=3, default=[16, 16, 16], help="replicate na nb nc of the 250-atom cell")
-    ap.add_argument("--workload", default="pbte", choices=["pbte", "pbte_ortho", "carbon", "unep", "si_tersoff"],
+    ap.add_argument("--workload", default="pbte", choices=["pbte", "pbte_ortho", "carbon", "carbon2024", "unep", "si_tersoff"],
                     help="pbte = BASELINE config 3 (the bench line); the others are extra single-GPU measurements")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
@@ -1010,6 +1018,20 @@ def bench(args):
                 extras["pbte_generic_shape"] = measure_extra("pbte", reps, 10, 3, dev, generic=True)
             except Exception as e:
                 extras["pbte_generic_shape"] = {"error": str(e)}
+            # (a5) a shipped potential of ANOTHER shape (C_2024: n_max 12 8, basis 16 12): kernels compiled for its shape (a JIT
+            #      core, prebuilt by build(): NEPMI_JIT=2 = never the compiler here) against the run-time-shape kernels
+            for key, mode in (("c2024_512k_jit_core", "2"), ("c2024_512k_run_time_shape", "0")):
+                old_mode = os.environ.get("NEPMI_JIT")
+                os.environ["NEPMI_JIT"] = mode
+                try:
+                    extras[key] = measure_extra("carbon2024", (10, 10, 10), 10 if mode == "2" else 3, 2, dev)
+                except Exception as e:
+                    extras[key] = {"error": str(e)}
+                finally:
+                    if old_mode is None:
+                        os.environ.pop("NEPMI_JIT", None)
+                    else:
+                        os.environ["NEPMI_JIT"] = old_mode
             try:
                 extras["config2_si_tersoff"] = measure_extra("si_tersoff", (16, 16, 16), 2000, 200, dev)
             except Exception as e:

@@ -9,11 +9,24 @@
 #include <exception>
 #include <string>
 
+// Every handle starts with the function table of the library that created it (capi_dispatch.inc: a model whose shape is not
+// among this library's compiled ones is served by a JIT core, capi_jit.h, and calls on its handles are forwarded there);
+// nullptr in builds without the dispatch layer (tests/emu).
+struct nepmi_api;
+#if defined(NEPMI_CAPI_DISPATCH)
+extern "C" const nepmi_api nepmi_self_api;
+#define NEPMI_SELF_API (&nepmi_self_api)
+#else
+#define NEPMI_SELF_API nullptr
+#endif
+
 struct nepmi_model {
+  const nepmi_api* api;
   nepmi::NepModel m;
 };
 
 struct nepmi_engine {
+  const nepmi_api* api;
   nepmi::EngineT<NepmiBackend>* e;
 };
 
@@ -54,6 +67,7 @@ nepmi_model* nepmi_model_load(const char* path)
     return nullptr;
   }
   nepmi_model* m = new nepmi_model();
+  m->api = NEPMI_SELF_API;
   bool unsupported = false;
   const std::string err = nepmi::load_nep_model(path, m->m, &unsupported);
   if (!err.empty()) {
@@ -114,6 +128,7 @@ nepmi_engine* nepmi_engine_create(const nepmi_model* m, int64_t n_atoms, void* s
     return nullptr;
   }
   nepmi_engine* e = new nepmi_engine();
+  e->api = NEPMI_SELF_API;
   e->e = nullptr;
   const int st = guarded([&] { e->e = new nepmi::EngineT<NepmiBackend>(m->m, n_atoms, nepmi_make_backend(stream)); });
   if (st != NEPMI_OK) {

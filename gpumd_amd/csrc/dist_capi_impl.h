@@ -5,6 +5,7 @@
 #include "dist_impl.h"
 
 struct nepmi_dist {
+  const nepmi_api* api; // (capi_impl.h: the library that created the handle)
   nepmi::DistT<NepmiBackend>* d;
   nepmi_engine view; // non-owning handle of the local system's engine (nepmi_dist_engine)
 };
@@ -27,7 +28,9 @@ nepmi_dist* nepmi_dist_create(
     return nullptr;
   }
   nepmi_dist* d = new nepmi_dist();
+  d->api = NEPMI_SELF_API;
   d->d = nullptr;
+  d->view.api = NEPMI_SELF_API;
   d->view.e = nullptr;
   const int st = guarded([&] { d->d = new nepmi::DistT<NepmiBackend>(m->m, *t, h, pbc, grid, nepmi_make_backend(stream)); });
   if (st != NEPMI_OK) {

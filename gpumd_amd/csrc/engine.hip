@@ -1487,6 +1487,12 @@ static NepmiBackend nepmi_make_backend(void* stream)
   return b;
 }
 
+// ---- C ABI.  The implementations below (capi_impl.h, dist_capi_impl.h, the RCCL transport) are compiled as nepmi_*__impl;
+//      the public names are the per-handle trampolines at the end of this file (capi_dispatch.inc, generated from nepmi.h). ----
+#define NEPMI_CAPI_DISPATCH
+#define NEPMI_CAPI_RENAME
+#include "capi_dispatch.inc"
+#undef NEPMI_CAPI_RENAME
 #include "dist_capi_impl.h"
 
 // ---- RCCL transport (device buffers over xGMI): nepmi_transport_rccl ---------------------------------------
@@ -1717,3 +1723,43 @@ extern "C" int nepmi_transport_rccl_stats(const nepmi_transport* t, int time_eve
   c->time_every = time_every > 0 ? time_every : 0;
   return NEPMI_OK;
 }
+
+// ---- which library serves a model (capi_jit.h); host code only ----
+#if !defined(__HIP_DEVICE_COMPILE__)
+#include "capi_jit.h"
+
+// nullptr: this library (a compiled shape, a shape only the run-time-shape kernels handle, a Tersoff file, a file that does not
+// parse -- the caller's own nepmi_model_load reports that -- or NEPMI_JIT=0); else the JIT core compiled for the model's shape
+static const nepmi_api* nepmi_jit_core_for_model_file(const char* path)
+{
+#if defined(NEPMI_JIT_CORE)
+  (void)path;
+  return nullptr; // a core serves the shape it was compiled for (and nothing is compiled from inside a core)
+#else
+  const char* mode = std::getenv("NEPMI_JIT");
+  if (!path || (mode && mode[0] == '0'))
+    return nullptr;
+  nepmi::NepModel m;
+  bool unsupported = false;
+  if (!nepmi::load_nep_model(path, m, &unsupported).empty())
+    return nullptr;
+  if (m.kind != 0 || nepmi::builtin_shape_of(m) != 0 || !nepmi::shape_is_compilable(m))
+    return nullptr;
+  const nepmi::jit::ShapeKey key{m.n_max_radial, m.basis_size_radial, m.n_max_angular, m.basis_size_angular, m.num_L,
+                                 m.num_types <= 2 ? m.num_types : 0};
+  return nepmi::jit::core_for(key);
+#endif
+}
+
+static void nepmi_adopt_error(const nepmi_api* core); // (defined behind the table: it reads the core's own last error)
+
+#define NEPMI_CAPI_TRAMPOLINES
+#include "capi_dispatch.inc"
+#undef NEPMI_CAPI_TRAMPOLINES
+
+static void nepmi_adopt_error(const nepmi_api* core)
+{
+  if (core && core->nepmi_last_error)
+    g_last_error = core->nepmi_last_error();
+}
+#endif // !__HIP_DEVICE_COMPILE__

@@ -23,7 +23,56 @@
 #define NEPMI_WIN2_DEFAULT 1 // A/B switch (profiles/ab_variants.sh): 0 = the scanned window layout unless asked for
 #endif
 
+// NEPMI_SHAPE_DISPATCH(fn, generic, (args)): fn<S>(args) for the compiled shape this engine selected (shape_), or for the
+// run-time shape (generic = 1) / nothing (0).  A JIT core (capi_jit.h: the same sources compiled once more for ONE further
+// shape, -DNEPMI_JIT_SHAPE=n_r,k_r,n_a,k_a,n_L,types -DNEPMI_JIT_CORE) knows that shape and the run-time shape only.
+#define NEPMI_UNPAREN(...) __VA_ARGS__
+#if defined(NEPMI_JIT_CORE)
+#define NEPMI_SHAPE_DISPATCH(FN, GENERIC, ARGS)                                   \
+  switch (shape_) {                                                               \
+    case 6: FN<S_JIT>(NEPMI_UNPAREN ARGS); break;                                 \
+    default: if (GENERIC) FN<ShapeGeneric>(NEPMI_UNPAREN ARGS); break;            \
+  }
+#else
+#define NEPMI_SHAPE_DISPATCH(FN, GENERIC, ARGS)                                   \
+  switch (shape_) {                                                               \
+    case 1: FN<S_PbTeA>(NEPMI_UNPAREN ARGS); break;                               \
+    case 2: FN<S_PbTeB>(NEPMI_UNPAREN ARGS); break;                               \
+    case 3: FN<S_C2022>(NEPMI_UNPAREN ARGS); break;                               \
+    case 4: FN<S_UNEP>(NEPMI_UNPAREN ARGS); break;                                \
+    case 5: FN<S_BZO>(NEPMI_UNPAREN ARGS); break;                                 \
+    default: if (GENERIC) FN<ShapeGeneric>(NEPMI_UNPAREN ARGS); break;            \
+  }
+#endif
+
 namespace nepmi {
+
+// Does a compiled kernel shape serve this model?  l_max_3body < 4 and the optional 4-body rows live in the run-time shape only.
+inline bool shape_is_compilable(const NepModel& m)
+{
+  return m.kind == 0 && m.L_max == 4 && !m.has_q_112 && !m.has_q_123 && !m.has_q_233 && !m.has_q_134;
+}
+template <class S>
+inline bool model_matches_shape(const NepModel& m)
+{
+  if (!S::fixed)
+    return true;
+  if (!shape_is_compilable(m))
+    return false;
+  return S::NR == m.n_max_radial && S::KR == m.basis_size_radial && S::NA == m.n_max_angular &&
+         S::KA == m.basis_size_angular && S::NL == m.num_L && (S::TS == 0 || S::TS == m.num_types);
+}
+// the shapes every build of the library carries (EngineT::select_shape numbers them 1..5; 0: none of them)
+inline int builtin_shape_of(const NepModel& m)
+{
+  if (model_matches_shape<Shape<6, 6, 6, 6, 5, 2>>(m)) return 1;
+  if (model_matches_shape<Shape<4, 8, 4, 8, 5, 2>>(m)) return 2;
+  if (model_matches_shape<Shape<10, 10, 8, 8, 6, 1>>(m)) return 3;
+  if (model_matches_shape<Shape<4, 8, 4, 8, 6, 0>>(m)) return 4;
+  if (model_matches_shape<Shape<8, 8, 6, 8, 5, 0>>(m)) return 5;
+  return 0;
+}
+
 
 enum KernelSlot {
   kSlotGather = 0,
@@ -833,25 +882,11 @@ public:
       throw EngineError{-4, "descriptors exist for NEP models only"};
     if (!last_small_ && last_ang_fused_) {
       // one kernel from the sums to the partial forces: run it once more with the descriptor and Fp written out
-      switch (shape_) {
-        case 1: launch_angular_fused<S_PbTeA>(1); break;
-        case 2: launch_angular_fused<S_PbTeB>(1); break;
-        case 3: launch_angular_fused<S_C2022>(1); break;
-        case 4: launch_angular_fused<S_UNEP>(1); break;
-        case 5: launch_angular_fused<S_BZO>(1); break;
-        default: break;
-      }
+      NEPMI_SHAPE_DISPATCH(launch_angular_fused, 0, (1))
     } else if (q && !last_small_ && fuse_ann_active()) {
       // the fused descriptor + ANN kernel keeps the angular descriptor in registers: write it out now (the compact
       // angular records of the last evaluation are still in place)
-      switch (shape_) {
-        case 1: launch_angular_desc<S_PbTeA>(); break;
-        case 2: launch_angular_desc<S_PbTeB>(); break;
-        case 3: launch_angular_desc<S_C2022>(); break;
-        case 4: launch_angular_desc<S_UNEP>(); break;
-        case 5: launch_angular_desc<S_BZO>(); break;
-        default: break;
-      }
+      NEPMI_SHAPE_DISPATCH(launch_angular_desc, 0, ())
     }
     ExportDescBody body{b_, model_.dim, q, fp};
     be_.template launch<64>(kSlotMisc, N_, body);
@@ -1169,14 +1204,7 @@ private:
 
   void small_force_kernels()
   {
-    switch (shape_) {
-      case 1: small_force_kernels_shape<S_PbTeA>(); break;
-      case 2: small_force_kernels_shape<S_PbTeB>(); break;
-      case 3: small_force_kernels_shape<S_C2022>(); break;
-      case 4: small_force_kernels_shape<S_UNEP>(); break;
-      case 5: small_force_kernels_shape<S_BZO>(); break;
-      default: small_force_kernels_shape<ShapeGeneric>(); break;
-    }
+    NEPMI_SHAPE_DISPATCH(small_force_kernels_shape, 1, ())
   }
 
   // Neighbor::find_neighbor (neighbor.cu:303-365) + find_cell_list (:164-215)
@@ -1446,6 +1474,8 @@ private:
   {
     if (!B::kHasFusedAngular || !ang_fused_ || model_.kind != 0 || shape_ == 0 || ann_mode_ != 1 || model_.num_types > 4)
       return false;
+    if ((model_.n_max_angular + 2) / 2 > 5) // more than five channels (120 sums) per lane: the register file does not hold them
+      return false;
     // the LDS image of nep_fused.h (fused_lds_layout): both weight half-rows of every neuron and type, the two coefficient tables
     const int nrh = (model_.n_max_radial + 2) / 2, nloc = (model_.n_max_angular + 2) / 2;
     const int dph = (nrh + model_.num_L * nloc + 3) / 4 * 4;
@@ -1488,6 +1518,9 @@ private:
   }
 
   // ---- shape dispatch ----
+#if defined(NEPMI_JIT_SHAPE)
+  using S_JIT = Shape<NEPMI_JIT_SHAPE>;     // the shape this core was compiled for
+#endif
   using S_PbTeA = Shape<6, 6, 6, 6, 5, 2>;   // examples/nep_train/nep.txt
   using S_PbTeB = Shape<4, 8, 4, 8, 5, 2>;   // tests/gpumd/dump_observer/PbTe_species/PbTe.txt
   using S_C2022 = Shape<10, 10, 8, 8, 6, 1>; // potentials/nep/C_2022_NEP4.txt
@@ -1497,23 +1530,21 @@ private:
   template <class S>
   bool shape_matches() const
   {
-    const NepModel& m = model_;
-    if (!S::fixed)
-      return true;
-    if (m.L_max != 4 || m.has_q_112 || m.has_q_123 || m.has_q_233 || m.has_q_134)
-      return false; // l_max_3body < 4 and the extra 4-body rows live in the generic shape only
-    return S::NR == m.n_max_radial && S::KR == m.basis_size_radial && S::NA == m.n_max_angular &&
-           S::KA == m.basis_size_angular && S::NL == m.num_L && (S::TS == 0 || S::TS == m.num_types);
+    return model_matches_shape<S>(model_);
   }
 
   void select_shape()
   {
+#if defined(NEPMI_JIT_CORE)
+    shape_ = shape_matches<S_JIT>() ? 6 : 0;
+#else
     if (shape_matches<S_PbTeA>()) shape_ = 1;
     else if (shape_matches<S_PbTeB>()) shape_ = 2;
     else if (shape_matches<S_C2022>()) shape_ = 3;
     else if (shape_matches<S_UNEP>()) shape_ = 4;
     else if (shape_matches<S_BZO>()) shape_ = 5;
     else shape_ = 0;
+#endif
     if (force_generic_)
       shape_ = 0;
   }
@@ -1655,7 +1686,14 @@ public:
     have_list_ = false; // the packed list words follow the shape (two type-pure streams for two-type shapes)
   }
   // types with register-resident sums of the selected shape (Shape::TS)
-  int shape_ts() const { return (shape_ == 1 || shape_ == 2) ? 2 : (shape_ == 3 ? 1 : 0); }
+  int shape_ts() const
+  {
+#if defined(NEPMI_JIT_SHAPE)
+    if (shape_ == 6)
+      return S_JIT::TS;
+#endif
+    return (shape_ == 1 || shape_ == 2) ? 2 : (shape_ == 3 ? 1 : 0);
+  }
   // 1 (default): the one-lane window kernels run on the static window layout (RadialWin2Body); 0: the scanned layout
   void set_win2(bool on)
   {
@@ -1865,14 +1903,7 @@ public:
       return;
     assembly_pending_ = false;
     be_.frozen = frozen;
-    switch (shape_) {
-      case 1: assembly_rest_shape<S_PbTeA>(frozen); break;
-      case 2: assembly_rest_shape<S_PbTeB>(frozen); break;
-      case 3: assembly_rest_shape<S_C2022>(frozen); break;
-      case 4: assembly_rest_shape<S_UNEP>(frozen); break;
-      case 5: assembly_rest_shape<S_BZO>(frozen); break;
-      default: assembly_rest_shape<ShapeGeneric>(frozen); break;
-    }
+    NEPMI_SHAPE_DISPATCH(assembly_rest_shape, 1, (frozen))
     be_.frozen = nullptr;
   }
   // 1: scatter-form steps of the run loops keep the per-step radial list as inside bits over the packed Verlet words
@@ -1935,14 +1966,7 @@ public:
     if (!virial_local_ || model_.kind != 0 || last_small_)
       return;
     be_.frozen = nullptr;
-    switch (shape_) {
-      case 1: exact_virials_shape<S_PbTeA>(); break;
-      case 2: exact_virials_shape<S_PbTeB>(); break;
-      case 3: exact_virials_shape<S_C2022>(); break;
-      case 4: exact_virials_shape<S_UNEP>(); break;
-      case 5: exact_virials_shape<S_BZO>(); break;
-      default: exact_virials_shape<ShapeGeneric>(); break;
-    }
+    NEPMI_SHAPE_DISPATCH(exact_virials_shape, 1, ())
   }
   bool virial_local() const { return virial_local_; }
 
@@ -2019,7 +2043,14 @@ public:
     std::string s;
     if (model_.kind == 1)
       return "potential=tersoff1989 kernels=bond_order+force(fp64)";
-    s += std::string("shape=") + shapes[shape_ >= 0 && shape_ <= 5 ? shape_ : 0];
+    if (shape_ == 6) {
+      char jb[96];
+      std::snprintf(jb, sizeof jb, "shape=jit(%d,%d,%d,%d,%d;%s)", model_.n_max_radial, model_.basis_size_radial, model_.n_max_angular,
+                    model_.basis_size_angular, model_.num_L, model_.num_types <= 2 ? std::to_string(model_.num_types).c_str() : "T");
+      s += jb;
+    } else {
+      s += std::string("shape=") + shapes[shape_ >= 0 && shape_ <= 5 ? shape_ : 0];
+    }
     if (last_small_)
       return s + " path=small_box(all image pairs)";
     const int lanes = win_lanes();
@@ -2083,14 +2114,7 @@ private:
       be_.end_region(kRegionForce);
       return;
     }
-    switch (shape_) {
-      case 1: force_kernels_shape<S_PbTeA>(phase, frozen); break;
-      case 2: force_kernels_shape<S_PbTeB>(phase, frozen); break;
-      case 3: force_kernels_shape<S_C2022>(phase, frozen); break;
-      case 4: force_kernels_shape<S_UNEP>(phase, frozen); break;
-      case 5: force_kernels_shape<S_BZO>(phase, frozen); break;
-      default: force_kernels_shape<ShapeGeneric>(phase, frozen); break;
-    }
+    NEPMI_SHAPE_DISPATCH(force_kernels_shape, 1, (phase, frozen))
   }
 
   NepModel model_;

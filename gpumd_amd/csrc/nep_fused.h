@@ -293,8 +293,8 @@ struct AngularFusedBody {
     const AngularForceBody<S> af{m, b, 1};
     if (NEPMI_AFU_ABL != 2) {
       af.template pairs_from_G<2>(k, part, lds, t1, s);
-    } else if (s[3] + s[30] == 12345.0f) {
-      b.pe_i[k] = s[5] + s[77];
+    } else if (s[3] + s[NLOC * kNumHarm - 1] == 12345.0f) {
+      b.pe_i[k] = s[5] + s[NLOC * kNumHarm - 2];
     }
   }
 };

@@ -21,6 +21,11 @@
 #include <string>
 #include <vector>
 
+#if defined(__HIPCC__) // the product build: the C-ABI functions are compiled as nepmi_*__impl (capi_dispatch.inc: the public
+#define NEPMI_CAPI_RENAME // names are per-handle trampolines); tests/emu compiles this file with g++ and keeps the plain names
+#include "capi_dispatch.inc"
+#undef NEPMI_CAPI_RENAME
+#endif
 #include "../../include/nepmi.h"
 
 namespace {

@@ -4,7 +4,7 @@ cd /root/repo/gpumd_amd/csrc
 mkdir -p ../lib/variants
 for spec in "$@"; do
   name=${spec%%:*}; flags=${spec#*:}
-  ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-pass-failed -Wl,-rpath,/opt/rocm/lib $flags \
+  ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-pass-failed -Wl,-Bsymbolic -Wl,-rpath,/opt/rocm/lib $flags \
       -o ../lib/variants/libnepmi_$name.so engine.hip nep_model.cpp transport_tcp.cpp -ldl 2>&1 | grep -E "error" ) &
 done
 wait

@@ -1,0 +1,114 @@
+"""Kernels compiled for a model's own shape (gpumd_amd/csrc/capi_jit.h): a model outside the library's five compiled shapes is
+served by a JIT core -- the same sources compiled once more for that shape -- behind the same C ABI (capi_dispatch.inc: every
+handle carries the function table of the library that made it).  The cores of two shipped potentials are built ahead of time
+(__graft_entry__.build() -> gpumd_amd/lib/jit/, they travel to the GPU box); NEPMI_JIT=2 = cores that exist, never the compiler.
+The reference runs any n_max / basis_size / neuron count through one code path (src/force/nep.cu:488-659, 774-861)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import helpers as H
+import parity_cases as P
+
+JIT_DIR = os.path.join(H.ROOT, "gpumd_amd", "lib", "jit")
+CASES = {"C-2024": "12_16_8_12_6_1", "Si-5body": "10_10_10_10_6_1"}
+
+
+def _core(shape):
+    return glob.glob(os.path.join(JIT_DIR, "libnepmi_jit_%s_*.so" % shape))
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_prebuilt_core_is_found_and_serves_the_model(name, monkeypatch, capfd):
+    """no GPU needed: nepmi_model_load decides which library serves the model, loads the core (the name carries the hash of the
+    sources: a stale core is not found) and every call on the handle is forwarded to it"""
+    if not _core(CASES[name]):
+        pytest.skip("no prebuilt JIT core for %s (python -c 'import __graft_entry__ as g; g.build()')" % name)
+    import gpumd_amd
+    nep = H.golden(*P.MODELS[name][0].split("/"))
+    monkeypatch.setenv("NEPMI_JIT", "2")
+    m = gpumd_amd.Model(nep)
+    err = capfd.readouterr().err
+    assert "no kernels compiled" not in err, err
+    monkeypatch.setenv("NEPMI_JIT", "0")
+    m0 = gpumd_amd.Model(nep)
+    import ctypes as C
+    # the first word of a handle: the function table of the library that made it (capi_impl.h) -- two different libraries
+    assert C.c_void_p.from_address(m.handle).value != C.c_void_p.from_address(m0.handle).value
+    for f, _ in m.info._fields_:
+        assert getattr(m.info, f) == getattr(m0.info, f), f
+    m.close()
+    m0.close()
+
+
+def test_a_model_of_a_compiled_shape_stays_with_the_library(monkeypatch, capfd):
+    import gpumd_amd
+    monkeypatch.setenv("NEPMI_JIT", "2")
+    m = gpumd_amd.Model(H.golden("PbTe", "nep.txt"))
+    assert "nepmi:" not in capfd.readouterr().err
+    m.close()
+
+
+def test_without_a_core_the_run_time_shape_kernels_serve_the_model(monkeypatch, capfd):
+    """NEPMI_JIT=2 and no core for the shape (Si with the 4-body row only: 10,10,10,10,5;1): one line on stderr, the model loads"""
+    import gpumd_amd
+    assert not _core("10_10_10_10_5_1")
+    monkeypatch.setenv("NEPMI_JIT", "2")
+    m = gpumd_amd.Model(H.golden("Si", "nep_4body.txt"))
+    assert "run-time-shape kernels serve it" in capfd.readouterr().err
+    assert m.info.num_types == 1 and m.info.num_L == 5
+    m.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_force_parity_on_a_jit_core(name, monkeypatch):
+    """the oracle comparison of tests/test_gpu_parity.py::test_force_parity, the engine served by the model's JIT core"""
+    if not _core(CASES[name]):
+        pytest.skip("no prebuilt JIT core for %s" % name)
+    monkeypatch.setenv("NEPMI_JIT", "2")
+    drv = H.GpuDriver()
+    # (against the FP64 oracle: the suite's tolerance; against the FP32 oracle, two FP32 evaluations in different orders of sums
+    # over up to 358 neighbours: twice the band)
+    eng = P.check_force_parity(drv, name, f32_atol=4e-5)
+    assert "shape=jit(" in eng.describe(), eng.describe()
+
+
+@pytest.mark.gpu
+def test_run_loop_on_a_jit_core_matches_the_run_time_shape_kernels(monkeypatch):
+    """20 NVE steps of diamond with the C-2024 model: JIT core vs the run-time-shape kernels of the library (same trajectory to
+    FP32 rounding), and how much faster the step is"""
+    name = "C-2024"
+    if not _core(CASES[name]):
+        pytest.skip("no prebuilt JIT core")
+    import time
+    nep = H.golden(*P.MODELS[name][0].split("/"))
+    h, typ, x = H.diamond((16, 16, 16), 3.57, rattle=0.02, seed=3)
+    n = len(typ)
+    mass = np.full(n, H.MASS["C"])
+    vel = H.maxwell_velocities(mass, 300.0, seed=5)
+    out = {}
+    for mode in ("2", "0"):
+        monkeypatch.setenv("NEPMI_JIT", mode)
+        drv = H.GpuDriver()
+        model = drv.model(nep)
+        eng = drv.engine(model, n)
+        d_t, d_m, d_x, d_v = drv.dev(typ), drv.dev(mass), drv.dev(x), drv.dev(vel)
+        d_pe, d_f, d_w = drv.zeros(n), drv.zeros(3 * n), drv.zeros(9 * n)
+        eng.force_compute(h, d_t, d_x, d_pe, d_f, d_w)
+        eng.run_nve(h, d_t, d_m, 1.0 / H.TIME_UNIT, 5, d_x, d_v, d_pe, d_f, d_w)
+        drv.sync()
+        t0 = time.perf_counter()
+        th = eng.run_nve(h, d_t, d_m, 1.0 / H.TIME_UNIT, 20, d_x, d_v, d_pe, d_f, d_w, thermo_every=20)
+        drv.sync()
+        out[mode] = (drv.host(d_x), np.asarray(th), (time.perf_counter() - t0) / 20 * 1e3, eng.describe())
+    assert "shape=jit(" in out["2"][3] and "shape=generic" in out["0"][3]
+    dx = np.abs(out["2"][0] - out["0"][0]).max()
+    print("\n[JIT core] max |dx| after 25 steps vs the run-time-shape kernels: %.2e A" % dx)
+    assert dx < 2e-5
+    np.testing.assert_allclose(out["2"][1][:, :3], out["0"][1][:, :3], rtol=1e-5)
+    print("\n[JIT core] C-2024, %d atoms: %.3f ms/step on the JIT core, %.3f ms/step on the run-time-shape kernels (%.1fx)"
+          % (n, out["2"][2], out["0"][2], out["0"][2] / out["2"][2]))
+    assert out["2"][2] < out["0"][2]
