@@ -259,8 +259,8 @@ def reference_gpu_baseline(steps=200, timeout=180.0):
         with open(os.path.join(d, "run.in")) as f:
             run = f.read()
         # velocities in model.xyz (vel:R:3 of the 250-atom cell; `replicate` repeats them with the cell, replicate.cu:51-72), no
-        # `velocity` keyword: the reference's HIP build draws from the process-wide rand() stream the runtime also uses, so only
-        # this makes the two programs start from the same state -- and lets their trajectories be compared below
+        # draw: the reference's HIP build draws from the process-wide rand() stream the runtime also uses, so only this makes the
+        # two programs start from the same state -- and lets their trajectories be compared below
         fr = S.read_xyz_frames(os.path.join(d, "model.xyz"))[0]
         spec, pos = list(fr["species"]), np.asarray(fr["pos"], dtype=np.float64)
         mass = np.array([S.MASS.get(e, 100.0) for e in spec])
@@ -271,7 +271,8 @@ def reference_gpu_baseline(steps=200, timeout=180.0):
             f.write('pbc="T T T" Lattice="%s" Properties=species:S:1:pos:R:3:vel:R:3\n' % " ".join("%.12g" % v for v in lat))
             for e, p, v in zip(spec, pos, vel):
                 f.write("%s %.12f %.12f %.12f %.15e %.15e %.15e\n" % (e, p[0], p[1], p[2], v[0], v[1], v[2]))
-        run = re.sub(r"velocity [^\n]*\n", "", run)
+        # (the `velocity 300` line stays: with velocities in the file the keyword draws nothing, velocity.cu:322, but it is what
+        # uploads the REPLICATED host velocities -- `replicate` re-allocates the device array and does not fill it, run.cu:356-358)
         with open(os.path.join(d, "run.in"), "w") as f:
             f.write(re.sub(r"\nrun \d+", "\nrun %d" % steps, re.sub(r"dump_thermo \d+", "dump_thermo %d" % steps, run)))
         res, th_ref = R.run_binary(exe, d, timeout)
