@@ -324,7 +324,7 @@ def cpu_baseline_tersoff(pot, h, typ, x, mass, vel, seconds=12.0):
                       "neighbour search every call, %.1f s" % (n, calls, el)}
 
 
-def kernel_report(st, info, n_atoms_per_launch, st_all=None, tersoff=False, fused_angular=False):
+def kernel_report(st, info, n_atoms_per_launch, st_all=None, tersoff=False, fused_angular=False, brick_force=False):
     """per-kernel mean durations (HIP events) + the roofline object of the dominant force kernel.
     st: stats of the timed region (timing mode 2: only the force-assembly slot is filled); st_all: stats of the
     instrumented pass after it (every slot) -- the timed region's own figure wins where both exist."""
@@ -338,6 +338,11 @@ def kernel_report(st, info, n_atoms_per_launch, st_all=None, tersoff=False, fuse
         # algorithmic bytes are the three stages' shares of the SURVEY 8(d) split (the step total is unchanged)
         per_kernel = dict(per_kernel)
         per_kernel["angular_fused"] = per_kernel.pop("angular_descriptor") + per_kernel.pop("ann") + per_kernel.pop("angular_partial_force")
+    if brick_force and not tersoff:
+        # nep_brick.h: ... and the scatter-form force assembly in the same launch (angular slot); the fold in the force slot
+        per_kernel["brick_force"] = per_kernel.pop("angular_fused") + per_kernel["force_assemble"] - 24.0
+        per_kernel["force_fold"] = 24.0  # the forces written
+        per_kernel.pop("force_assemble")
     for src in (st_all, st):
         if src is None:
             continue
@@ -348,7 +353,9 @@ def kernel_report(st, info, n_atoms_per_launch, st_all=None, tersoff=False, fuse
                 ran = int(src.launches[k]) - (int(src.discarded_steps) if 1 <= k <= 6 else 0)
                 ran = max(ran, 1)
                 if fused_angular and name == "angular_descriptor":
-                    name = "angular_fused"
+                    name = "brick_force" if brick_force else "angular_fused"
+                if brick_force and name == "force_assemble":
+                    name = "force_fold"
                 kern[name] = {"launches": ran, "avg_ms": src.ms_kernel_sum[k] / ran, "slot": k,
                               "timed_in": "timed region" if src is st else "instrumented pass after the clock"}
     # every kernel priced the same way as the roofline object below: algorithmic bytes / duration / HBM peak, and (where the
@@ -459,7 +466,8 @@ def measure_extra(workload, reps, steps, warmup, dev, generic=False):
     eng.set_timing(0)
     tersoff = workload == "si_tersoff"
     kern, roofline, b_step = kernel_report(st, model.info, n, st_all, tersoff=tersoff,
-                                           fused_angular="partial_forces_in_one_kernel" in eng.describe())
+                                           fused_angular=("partial_forces_in_one_kernel" in eng.describe() or "one_kernel_per_brick" in eng.describe()),
+                                               brick_force="one_kernel_per_brick" in eng.describe())
     if tersoff and roofline:
         roofline["kernel"] = {"radial_descriptor": "tersoff_bond_order", "force_assemble": "tersoff_force"}[roofline["kernel"]]
     return {"workload": label, "metric": METRIC[workload], "value": n * steps / elapsed, "unit": "atom-steps/s",
@@ -869,6 +877,8 @@ def bench(args):
         eng.set_win_lanes(int(os.environ["NEPMI_BENCH_LANES"]))
     if "NEPMI_BENCH_ANGFUSED" in os.environ:  # angular descriptor + ANN + partial forces: 1 one kernel (default), 0 separate
         eng.set_angular_fused(os.environ["NEPMI_BENCH_ANGFUSED"] != "0")
+    if "NEPMI_BENCH_BRICK" in os.environ:  # one force kernel per brick (default) / fused angular kernel + scatter kernel
+        eng.set_brick_force(os.environ["NEPMI_BENCH_BRICK"] != "0")
     if "NEPMI_BENCH_FORM" in os.environ:  # force assembly: 0 gather, 1 scatter (default: the run loops' rule)
         eng.set_force_form(int(os.environ["NEPMI_BENCH_FORM"]))
     # initial force (Run::perform_a_run computes it before the loop), then warm-up steps
@@ -903,7 +913,8 @@ def bench(args):
     if rank == 0:
         tersoff = args.workload == "si_tersoff"
         kern, roofline, b_step = kernel_report(st, model.info, n, st_all, tersoff=tersoff,
-                                               fused_angular="partial_forces_in_one_kernel" in eng.describe())
+                                               fused_angular=("partial_forces_in_one_kernel" in eng.describe() or "one_kernel_per_brick" in eng.describe()),
+                                               brick_force="one_kernel_per_brick" in eng.describe())
         if tersoff:
             # the two Tersoff kernels sit in the radial and force-assembly slots of the engine's timing table
             kern = {{"radial_descriptor": "tersoff_bond_order", "force_assemble": "tersoff_force"}.get(k, k): v
@@ -969,7 +980,8 @@ def bench(args):
                     st2 = eng.stats(with_lists=True)
                     eng.set_timing(0)
                     kern2, roof2, _ = kernel_report(st2, model.info, n, None,
-                                                    fused_angular="partial_forces_in_one_kernel" in eng.describe())
+                                                    fused_angular=("partial_forces_in_one_kernel" in eng.describe() or "one_kernel_per_brick" in eng.describe()),
+                                               brick_force="one_kernel_per_brick" in eng.describe())
                     seg = {"workload": label, "steps": 100, "ms_per_step": el / 100 * 1e3, "value": n * 100 / el,
                            "unit": "atom-steps/s", "rebuilds_in_timed_region": int(st2.num_rebuild - r0), "roofline": roof2}
                     if seg["rebuilds_in_timed_region"] >= 1:

@@ -516,6 +516,14 @@ int nepmi_engine_set_scatter_guard(nepmi_engine* e, double ev_per_angstrom, doub
   return NEPMI_OK;
 }
 
+int nepmi_engine_set_brick_force(nepmi_engine* e, int on)
+{
+  if (!e)
+    return fail(NEPMI_ERR_ARG, "null engine");
+  e->e->set_brick_force(on != 0);
+  return NEPMI_OK;
+}
+
 int nepmi_engine_set_angular_fused(nepmi_engine* e, int on)
 {
   if (!e)

@@ -17,6 +17,7 @@
 #include "engine_impl.h"
 #include "nep_scatter.h" // device-only force assembly (LDS scatter of the own pair halves)
 #include "nep_fused.h"   // device-only: angular descriptor + ANN + partial angular forces in one kernel
+#include "nep_brick.h"   // device-only: ... and the scatter-form force assembly behind them, one kernel per brick
 
 namespace nepmi {
 
@@ -1391,6 +1392,56 @@ struct HipBackend {
 #define NEPMI_AFU_BLOCK 256 // A/B switch: threads per workgroup (half as many atoms)
 #endif
     launch_lds_pairs<NEPMI_AFU_BLOCK>(slot, n, body);
+  }
+
+  // One force kernel per brick behind the radial pass (nep_brick.h) + the fold.  Two timing brackets: the brick kernel in the
+  // angular slot (it replaces the angular kernel and the scatter kernel), the fold in the force-assembly slot.
+  static constexpr bool kHasBrickForce = true;
+  template <class S>
+  size_t brick_lds_bytes(const ModelD& md, int wmax) const
+  {
+    return (size_t)BrickLayout{wmax, fused_lds_layout<S>(md).total}.bytes();
+  }
+  template <class S>
+  void launch_brick_force(int slot_brick, int slot_fold, int64_t nb, int64_t natoms, const WinStage& ws2, const ModelD& md, int* halo,
+                          const unsigned* fmap, int fold_rows, bool outputs, const float* img, const int* frz)
+  {
+    if constexpr (S::fixed && S::TS == 2) {
+      const BrickForceBody<S> body{ForceScatterBody<S>{ws2, md, frz, reinterpret_cast<I4*>(halo), -1},
+                                   AngularFusedBody<S>{md, ws2.b, 0, img}};
+      const int64_t grid = (nb + 7) / 8 * 8;
+      const size_t lds_bytes = (brick_lds_bytes<S>(md, ws2.lay.wmax) + 15) / 16 * 16;
+      bool t = timed(slot_brick);
+      if (t)
+        timer_start(timing->slot[slot_brick]);
+      if (nb > 0) {
+        if (outputs) {
+          if (lds_bytes > 64 * 1024)
+            NEPMI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&nepmi_brick_force_kernel<S, true>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+          hipLaunchKernelGGL((nepmi_brick_force_kernel<S, true>), dim3((unsigned)grid), dim3(kBrickThreads), lds_bytes, stream, body, nb);
+        } else {
+          if (lds_bytes > 64 * 1024)
+            NEPMI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&nepmi_brick_force_kernel<S, false>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+          hipLaunchKernelGGL((nepmi_brick_force_kernel<S, false>), dim3((unsigned)grid), dim3(kBrickThreads), lds_bytes, stream, body, nb);
+        }
+        NEPMI_HIP_CHECK(hipGetLastError());
+      }
+      if (t)
+        timer_stop(timing->slot[slot_brick]);
+      t = timed(slot_fold);
+      if (t)
+        timer_start(timing->slot[slot_fold]);
+      if (natoms > 0) {
+        const ForceFoldBody fold{ws2.b, md, ws2.lay.wmax, fold_rows, fmap, reinterpret_cast<const I4*>(halo), 0, 2};
+        const int64_t fgrid = ((natoms + 255) / 256 + 7) / 8 * 8;
+        hipLaunchKernelGGL((nepmi_kernel<256, ForceFoldBody>), dim3((unsigned)fgrid), dim3(256), 0, stream, fold, natoms, frz);
+        NEPMI_HIP_CHECK(hipGetLastError());
+      }
+      if (t)
+        timer_stop(timing->slot[slot_fold]);
+    }
   }
 
   void exclusive_scan(int* data, int64_t n, int* scratch)

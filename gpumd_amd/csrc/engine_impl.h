@@ -1500,6 +1500,32 @@ private:
     }
   }
 
+  // One force kernel per brick behind the radial pass (nep_brick.h): the fused angular kernel and the scatter-form force
+  // assembly in one launch -- where both apply, on shapes with two register-resident types, in single-domain engines (no ghost
+  // levels), with the compact radial list.  Opt-in (set_brick_force(1)): measured SLOWER than the two kernels, see nep_brick.h.
+  template <class S>
+  bool brick_force_wanted(const WinStage& ws2) const
+  {
+    if constexpr (!(B::kHasBrickForce && S::fixed && S::TS == 2)) {
+      return false;
+    } else {
+      if (!brick_force_ || !ang_fused_active() || b_.level || b_.use_rmask || !scatter_wanted<S>(ws2))
+        return false;
+      return be_.template brick_lds_bytes<S>(md_, win_.wmax) <= B::kMaxLdsBytes;
+    }
+  }
+  template <class S>
+  void launch_brick_force(const WinStage& ws2, const int* frozen)
+  {
+    if constexpr (B::kHasBrickForce && S::fixed && S::TS == 2) {
+      if (fused_img_stale_ || !fused_img_) { // the image is written by the fused angular kernel's launcher: once, before anything
+        launch_angular_fused<S>(0);        // (a whole launch of that kernel, once per engine / temperature change)
+      }
+      be_.template launch_brick_force<S>(kSlotAngular, kSlotForce, num_bricks_, N_, ws2, md_, halo_, fmap_, fold_rows_, step_outputs_,
+                                         fused_img_, frozen);
+    }
+  }
+
   template <class S>
   void launch_angular_force()
   {
@@ -1651,6 +1677,7 @@ public:
     force_form_ = o.force_form_;
     use_rmask_ = o.use_rmask_;
     ang_fused_ = o.ang_fused_;
+    brick_force_ = o.brick_force_;
     loop_ctx_ = o.loop_ctx_;
     scatter_disabled_ = o.scatter_disabled_;
     b_.scatter_limit = o.b_.scatter_limit;
@@ -1781,6 +1808,20 @@ private:
     ccode_valid_ = b_.use_rmask == 0;
     b_.skip_atab = (win2 && fpj_wanted<S>(ws2)) ? 1 : 0; // the FPJ force assembly needs no radial table from the ANN kernel
     last_ang_fused_ = false;
+    last_brick_ = false;
+    if (win2 && brick_force_wanted<S>(ws2)) {
+      launch_brick_force<S>(ws2, frozen);
+      last_ang_fused_ = last_brick_ = true;
+      last_scatter_form_ = true;
+      outputs_stale_ = !step_outputs_;
+      virial_local_ = true; // the virial planes hold the own-half form: exact_virials() before they leave the engine
+      if (force_form_ == 1 && !loop_ctx_) { // a per-call evaluation in the forced scatter form returns per-atom virials
+        materialise_for_gather<S>();
+        gather_assembly<S>(ws, ws2, lanes, win2, frozen, 1);
+      }
+      be_.end_region(kRegionForce);
+      return;
+    }
     if (ang_fused_active()) {
       launch_angular_fused<S>();
       last_ang_fused_ = true;
@@ -1803,6 +1844,17 @@ private:
       gather_assembly<S>(ws, ws2, lanes, win2, frozen, 0);
     }
     be_.end_region(kRegionForce);
+  }
+
+  // After a per-brick force kernel the partial forces and the radial table exist in registers only: the gather form's
+  // virial-only pass (exact_virials) reads them from the arrays the separate angular kernel writes
+  template <class S>
+  void materialise_for_gather()
+  {
+    if (!last_brick_)
+      return;
+    launch_angular_fused<S>(0);
+    last_brick_ = false;
   }
 
   // The gather form of the force assembly (ForceWinBody / ForceAssembleBody); wonly: only the nine virial planes are written
@@ -1952,6 +2004,8 @@ public:
   bool last_scatter_form() const { return last_scatter_form_; }
   // 1 (default): angular descriptor, ANN and partial angular forces in one kernel where ang_fused_active() allows; 0: separately
   void set_angular_fused(bool on) { ang_fused_ = on; }
+  // 1: ... and the scatter-form force assembly in the same kernel, one workgroup per brick (nep_brick.h); 0 (default)
+  void set_brick_force(bool on) { brick_force_ = on; }
   // the callers whose steps need forces, energies and the TOTAL virial only (run loops; the decomposed driver)
   void set_loop_context(bool on) { loop_ctx_ = on; }
   // Run loops: does the NEXT force evaluation have to leave per-atom energies and virials (a thermo record, a thermostat that
@@ -1981,6 +2035,7 @@ private:
     const int lanes = win_lanes();
     if (!ccode_valid_) // the last radial pass wrote the masks: the compact list the gather form walks, on the same positions
       force_kernels_shape<S>(kPhaseRadialOnly, nullptr);
+    materialise_for_gather<S>(); // (after a per-brick force kernel: the partial forces and the radial table, once more, to HBM)
     gather_assembly<S>(ws, ws2, lanes, win2_ok_ && lanes == 1, nullptr, 1);
   }
 
@@ -2057,7 +2112,9 @@ public:
     const bool win2 = win2_ok_ && lanes == 1;
     s += tile_ok_ ? (win2 ? " window=lds_static" : " window=lds_scanned") : " window=none(gather kernels)";
     s += " lanes_per_atom=" + std::to_string(tile_ok_ ? lanes : 1);
-    if (last_ang_fused_)
+    if (last_brick_)
+      s += " force=one_kernel_per_brick(descriptor+ann+partial_forces+lds_scatter_of_own_halves,lane_pairs)";
+    else if (last_ang_fused_)
       s += " angular=descriptor+ann+partial_forces_in_one_kernel(lane_pairs,sums_in_registers)";
     else if (fuse_ann_active())
       s += " ann=fused_with_angular_descriptor(packed_fp32,no_mfma)";
@@ -2133,6 +2190,8 @@ private:
   bool virial_local_ = false;    // the virial planes of the last force evaluation hold the own-half form (exact_virials)
   double hard_factor_ = 4.0;     // set_scatter_guard: hard limit of runs whose flagged steps stand = factor x guard band
   bool ang_fused_ = true;        // set_angular_fused
+  bool brick_force_ = false;     // set_brick_force (off: measured slower, see nep_brick.h)
+  bool last_brick_ = false;      // the last force evaluation ran the per-brick force kernel (f12 / atab were not written)
   float* fused_img_ = nullptr;   // LDS image of the fused angular kernel (nep_fused.h), built at its first launch
   size_t fused_img_floats_ = 0;
   bool fused_img_stale_ = true;

@@ -2096,14 +2096,26 @@ struct AngularForceBody {
       }
       invariants_adjoint<!S::fixed>(m, fpn, 1, &G[i * kNumHarm]);
     }
-    pairs_from_G<PARTS>(k, part, cang, t1, G);
+    pairs_from_G<PARTS>(k, part, cang, t1, G, F12Store{b.f12 + k, b.N});
   }
+
+  // where the partial force of pair `a` goes: the compact f12 rows (the separate force-assembly kernels read them) -- or, in the
+  // per-brick kernel of nep_fused.h, straight into the LDS accumulators of the scatter form
+  struct F12Store {
+    F4* f12;
+    int64_t N;
+    NEPMI_HD void operator()(int a, int part, const F4& out, const F4& /*record*/) const
+    {
+      if (part == 0)
+        f12[(int64_t)a * N] = out;
+    }
+  };
 
   // The pair loop: partial forces f12 of this step's angular pairs from the atom's adjoint table G (this lane's channels,
   // harmonic order), + ZBL.  Also the tail of the fused descriptor + ANN + force kernel (nep_fused.h), which arrives here
   // with G built from sums that never left the registers.
-  template <int PARTS, class LP>
-  NEPMI_HD void pairs_from_G(int64_t k, int part, LP cang, int t1, const float* G) const
+  template <int PARTS, class LP, class Sink>
+  NEPMI_HD void pairs_from_G(int64_t k, int part, LP cang, int t1, const float* G, Sink&& sink) const
   {
     constexpr int NLOC = (S::NAM + PARTS) / PARTS;
     const int64_t N = b.N;
@@ -2133,7 +2145,6 @@ struct AngularForceBody {
 
     const int na = b.nn_angstep[k];
     const F4* __restrict__ acomp = b.acomp + k;
-    F4* __restrict__ f12 = b.f12 + k;
     F4 e_next;
     if (na > 0)
       e_next = acomp[0];
@@ -2224,8 +2235,7 @@ struct AngularForceBody {
       out.y = uy * w + (vy - uy * udv) * dinv;
       out.z = uz * w + (vz - uz * udv) * dinv;
       out.w = 0;
-      if (part == 0)
-        f12[(int64_t)a * N] = out;
+      sink(a, part, out, e);
 
       // ZBL is per pair and independent of the channel split: the lanes take alternate neighbours.  A pair beyond
       // the outer cutoff contributes exact zeros (fc = 0): it is skipped, and with it four exponentials, a sine, a

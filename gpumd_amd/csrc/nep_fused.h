@@ -123,17 +123,94 @@ struct AngularFusedBody {
   NEPMI_HD void run_parts(int64_t k, int part, LP lds) const
   {
     static_assert(PARTS == 2, "lane pairs");
-    constexpr int NRH = F::NRH, NLOC = F::NLOC, DPH = F::DPH;
-    const int64_t N = b.N;
+    constexpr int NLOC = F::NLOC, DPH = F::DPH;
     if (b.lvl[k] < b.lvl_desc)
       return;
+    const int t1 = b.posq[k].type;
+    float s[NLOC * kNumHarm], Fp[DPH], e;
+    descriptor_and_ann(k, part, lds, t1, s, Fp, e);
+    if (part == 0)
+      b.pe_i[k] = e;
+    // ---- radial force table A[t2][k] = sum_n Fp[n] c[t1][t2][n][k]: two half sums; lane t2 mod 2 stores row t2 ----
+    if (!b.skip_atab && NEPMI_AFU_ABL != 4) {
+      constexpr int KRPC = (S::KR + 1 + 3) / 4 * 4; // = Bufs::KRP: rows of whole 16-byte groups
+      const int KRP = b.KRP;
+      for (int t2 = 0; t2 < m.T; ++t2) {
+        float row[KRPC];
+        radial_row(part, lds, t1, t2, Fp, row);
+        if ((t2 & 1) == part) {
+          F4f* __restrict__ out = reinterpret_cast<F4f*>(b.atab + (size_t)k * (m.T * KRP) + t2 * KRP);
+#pragma unroll
+          for (int g = 0; g < KRPC / 4; ++g)
+            out[g] = F4f{row[4 * g], row[4 * g + 1], row[4 * g + 2], row[4 * g + 3]};
+        }
+      }
+    }
+    // ---- adjoint table in place of the sums, then the pair loop of AngularForceBody ----
+    if (b.level && !b.angf[k]) // an inner-ring ghost whose partial forces no owned atom will read
+      return;
+    adjoint_in_place(part, Fp, s);
+    const AngularForceBody<S> af{m, b, 1};
+    if (NEPMI_AFU_ABL != 2) {
+      af.template pairs_from_G<2>(k, part, lds, t1, s, typename AngularForceBody<S>::F12Store{b.f12 + k, b.N});
+    } else if (s[3] + s[NLOC * kNumHarm - 1] == 12345.0f) {
+      b.pe_i[k] = s[5] + s[NLOC * kNumHarm - 2];
+    }
+  }
+
+  // row t2 of the radial force table, whole on both lanes (kk beyond k_r: zero)
+  template <class LP>
+  NEPMI_HD void radial_row(int part, LP lds, int t1, int t2, const float* Fp, float* row) const
+  {
+    constexpr int NRH = F::NRH;
+    constexpr int KRPC = (S::KR + 1 + 3) / 4 * 4;
+    const FusedLdsLayout a = fused_lds_layout<S>(m);
+    LP c = lds + a.off_c + (t1 * m.T + t2) * (S::NR + 1) * (S::KR + 1);
+#pragma unroll
+    for (int kk = 0; kk < KRPC; ++kk) {
+      float v = 0.0f;
+      if (kk <= S::KR) {
+#pragma unroll
+        for (int i = 0; i < NRH; ++i) {
+          const int n = 2 * i + part;
+          if (n <= S::NR)
+            v = fmaf(Fp[i], c[n * (S::KR + 1) + kk], v);
+        }
+        v += NEPMI_PAIR_XCHG(v);
+      }
+      row[kk] = v;
+    }
+  }
+
+  // G = dU/ds of this lane's channels in place of their sums (invariants_adjoint with this lane's Fp rows)
+  NEPMI_HD void adjoint_in_place(int part, const float* Fp, float* s) const
+  {
+    constexpr int NRH = F::NRH, NLOC = F::NLOC;
+#pragma unroll
+    for (int i = 0; i < NLOC; ++i) {
+      const int n = part + 2 * i;
+      if (n > S::NA)
+        break;
+      float fpn[S::kRows];
+#pragma unroll
+      for (int L = 0; L < S::kRows; ++L)
+        fpn[L] = L < S::NL ? Fp[NRH + (L < S::NL ? L : 0) * NLOC + i] : 0.0f;
+      invariants_adjoint<false>(m, fpn, 1, &s[i * kNumHarm]);
+    }
+  }
+
+  // sums of this lane's channels -> its half of the descriptor -> ANN: s (kept for the adjoint), Fp of this lane's components,
+  // e = the atom's energy (both lanes)
+  template <class LP>
+  NEPMI_HD void descriptor_and_ann(int64_t k, int part, LP lds, int t1, float* s, float* Fp, float& e_out) const
+  {
+    constexpr int NRH = F::NRH, NLOC = F::NLOC, DPH = F::DPH;
+    const int64_t N = b.N;
     const FusedLdsLayout a = fused_lds_layout<S>(m);
     const int64_t gk = b.tpos[k];
-    const int t1 = b.posq[k].type;
     LP QS = lds + a.off_qs + part * DPH;
 
     // ---- sums of this lane's channels (angular_s_sums: what AngularDescBody runs) ----
-    float s[NLOC * kNumHarm];
     if (NEPMI_AFU_ABL != 3) {
       angular_s_sums<S, 2>(m, b, k, t1, lds, part, s);
     } else {
@@ -231,9 +308,7 @@ struct AngularFusedBody {
       if (NJ > 1 && j < m.nneu)
         neurons(j, m.nneu - j);
     }
-    if (part == 0)
-      b.pe_i[k] = e - (m.b1 + m.b1t[t1]);
-    float Fp[DPH];
+    e_out = e - (m.b1 + m.b1t[t1]);
 #pragma unroll
     for (int i = 0; i < DPH; ++i)
       Fp[i] = ((i & 1) ? g2[i >> 1].y : g2[i >> 1].x) * QS[i];
@@ -244,57 +319,6 @@ struct AngularFusedBody {
         if (d >= 0)
           b.fp[(int64_t)d * N + gk] = Fp[i];
       }
-    }
-
-    // ---- radial force table A[t2][k] = sum_n Fp[n] c[t1][t2][n][k]: two half sums; lane t2 mod 2 stores row t2 ----
-    if (!b.skip_atab && NEPMI_AFU_ABL != 4) {
-      const int KRP = b.KRP;
-      constexpr int KRPC = (S::KR + 1 + 3) / 4 * 4; // = Bufs::KRP: rows of whole 16-byte groups
-      for (int t2 = 0; t2 < m.T; ++t2) {
-        LP c = lds + a.off_c + (t1 * m.T + t2) * (S::NR + 1) * (S::KR + 1);
-        float row[KRPC];
-#pragma unroll
-        for (int kk = 0; kk < KRPC; ++kk) {
-          float v = 0.0f;
-          if (kk <= S::KR) {
-#pragma unroll
-            for (int i = 0; i < NRH; ++i) {
-              const int n = 2 * i + part;
-              if (n <= S::NR)
-                v = fmaf(Fp[i], c[n * (S::KR + 1) + kk], v);
-            }
-            v += NEPMI_PAIR_XCHG(v);
-          }
-          row[kk] = v;
-        }
-        if ((t2 & 1) == part) {
-          F4f* __restrict__ out = reinterpret_cast<F4f*>(b.atab + (size_t)k * (m.T * KRP) + t2 * KRP);
-#pragma unroll
-          for (int g = 0; g < KRPC / 4; ++g)
-            out[g] = F4f{row[4 * g], row[4 * g + 1], row[4 * g + 2], row[4 * g + 3]};
-        }
-      }
-    }
-
-    // ---- adjoint table in place of the sums, then the pair loop of AngularForceBody ----
-    if (b.level && !b.angf[k]) // an inner-ring ghost whose partial forces no owned atom will read
-      return;
-#pragma unroll
-    for (int i = 0; i < NLOC; ++i) {
-      const int n = part + 2 * i;
-      if (n > S::NA)
-        break;
-      float fpn[S::kRows];
-#pragma unroll
-      for (int L = 0; L < S::kRows; ++L)
-        fpn[L] = L < S::NL ? Fp[NRH + (L < S::NL ? L : 0) * NLOC + i] : 0.0f;
-      invariants_adjoint<false>(m, fpn, 1, &s[i * kNumHarm]);
-    }
-    const AngularForceBody<S> af{m, b, 1};
-    if (NEPMI_AFU_ABL != 2) {
-      af.template pairs_from_G<2>(k, part, lds, t1, s);
-    } else if (s[3] + s[NLOC * kNumHarm - 1] == 12345.0f) {
-      b.pe_i[k] = s[5] + s[NLOC * kNumHarm - 2];
     }
   }
 };

@@ -318,6 +318,11 @@ class NEP:
         """guard band of the scatter-form force assembly per pair half (test hook: nepmi_engine_set_scatter_guard)"""
         self._ck(self.lib.nepmi_engine_set_scatter_guard(self.handle, float(ev_per_angstrom), float(hard_factor)))
 
+    def set_brick_force(self, on=True):
+        """fused angular kernel + scatter-form force assembly as ONE kernel per brick (default where it applies) or separately
+        (nepmi_engine_set_brick_force)"""
+        self._ck(self.lib.nepmi_engine_set_brick_force(self.handle, 1 if on else 0))
+
     def set_angular_fused(self, on=True):
         """angular descriptor + ANN + partial angular forces in one kernel (default) or as separate kernels
         (nepmi_engine_set_angular_fused)"""

@@ -490,6 +490,13 @@ int nepmi_engine_set_radial_mask(nepmi_engine* e, int on);
  * place, where the separate kernels evaluate them twice; 0: the separate kernels.  Same results up to the summation order of
  * the ANN's dot products (tests/test_gpu_parity.py). */
 int nepmi_engine_set_angular_fused(nepmi_engine* e, int on);
+/* ... and the scatter-form force assembly (find_force_radial, nep.cu:661-772; gpu_find_force_many_body, potential.cu:170-297) in
+ * the SAME kernel, one 512-thread workgroup per brick behind the radial pass: on = 1 where the fused angular kernel and the
+ * scatter form both apply, on shapes with two register-resident atom types, in single-domain engines; the partial forces and
+ * the per-atom radial table then never reach HBM (the virial-only pass of the gather form runs the separate angular kernel
+ * first when per-atom virials leave the engine).  0 (default): the separate kernels -- measured faster on MI355X (PbTe 1 M atoms:
+ * 0.44 + 0.25 ms against 0.95 ms; gpumd_amd/csrc/nep_brick.h says why).  Same results to FP32 rounding. */
+int nepmi_engine_set_brick_force(nepmi_engine* e, int on);
 /* Static window layout of the one-lane window kernels (default on): between two list rebuilds the LDS slot of every window
  * atom is fixed, so the rebuild tabulates the windows and stores the Verlet entries as LDS slots, four to an 8-byte word
  * (two-type models: list B as two type-pure streams); on = 0 keeps the per-launch scan of the window cells and the

@@ -1,25 +1,25 @@
-import faulthandler, sys, os
-faulthandler.enable()
-sys.path.insert(0, "/root/repo")
-import numpy as np, torch
-import gpumd_amd, bench
-from gpumd_amd import structures as H
-label, nep_txt, h, typ, x, mass, vel = bench.build_workload("pbte", (6, 6, 6), 42)
-n = len(typ); dev = torch.device("cuda", 0)
-print("n", n, flush=True)
-model = gpumd_amd.Model(nep_txt); print("model", flush=True)
-eng = gpumd_amd.NEP(model, n); print("engine", flush=True)
-t_type, t_mass = torch.from_numpy(typ).to(dev), torch.from_numpy(mass).to(dev)
-t_x, t_v = torch.from_numpy(x).to(dev), torch.from_numpy(vel).to(dev)
-t_pe, t_f, t_w = (torch.zeros(k * n, dtype=torch.float64, device=dev) for k in (1, 3, 9))
-eng.force_compute(h, t_type, t_x, t_pe, t_f, t_w); torch.cuda.synchronize(); print("force", flush=True)
-dt = 1.0 / H.TIME_UNIT
-eng.run_nve(h, t_type, t_mass, dt, 5, t_x, t_v, t_pe, t_f, t_w); torch.cuda.synchronize(); print("warm", flush=True)
-eng.set_timing(1); print("t1", flush=True)
-eng.run_nve(h, t_type, t_mass, dt, 4, t_x, t_v, t_pe, t_f, t_w, thermo_every=4); print("probe", flush=True)
-st = eng.stats(with_lists=False); print("stats", list(st.launches)[:8], flush=True)
-eng.set_timing(0)
-eng.set_timing(18); print("t18", flush=True)
-eng.run_nve(h, t_type, t_mass, dt, 4, t_x, t_v, t_pe, t_f, t_w, thermo_every=4); torch.cuda.synchronize(); print("timed", flush=True)
-st = eng.stats(with_lists=True); print("stats2", list(st.ms_kernel_sum)[:8], flush=True)
-print(bench.gpu_state())
+import sys, os
+sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+import numpy as np
+import helpers as H
+drv = H.GpuDriver()
+nep, (h, typ, x) = H.golden("PbTe", "nep.txt"), H.pbte_supercell((6, 6, 6), rattle=0.03, seed=17)
+mass = np.where(typ == 0, H.MASS["Te"], H.MASS["Pb"]).astype(np.float64)
+n = len(typ)
+vel = H.maxwell_velocities(mass, 2500.0, seed=4)
+m = drv.model(nep)
+def run(brick, mask, steps):
+    eng = drv.engine(m, n)
+    eng.set_win_lanes(1); eng.set_force_form(1); eng.set_brick_force(brick); eng.set_radial_mask(mask)
+    d_t, d_m, d_x, d_v = drv.dev(typ), drv.dev(mass), drv.dev(x), drv.dev(vel)
+    d_pe, d_f, d_w = drv.zeros(n), drv.zeros(3 * n), drv.zeros(9 * n)
+    eng.force_compute(h, d_t, d_x, d_pe, d_f, d_w)
+    f0 = drv.host(d_f).copy()
+    th = eng.run_nve(h, d_t, d_m, 2.0 / H.TIME_UNIT, steps, d_x, d_v, d_pe, d_f, d_w, thermo_every=steps)
+    return f0, drv.host(d_x), drv.host(d_f), eng.describe(), eng.stats().num_rebuild
+for steps in (1, 2, 5, 12, 40):
+    r = {}
+    for key, (brick, mask) in {"brick": (True, False), "brick2": (True, False), "sep": (False, False), "mask": (False, True), "brickmask": (True, True)}.items():
+        r[key] = run(brick, mask, steps)
+    print(steps, "rebuilds", r["sep"][4], {k: (float(np.abs(v[0]-r["sep"][0]).max()), float(np.abs(v[1]-r["sep"][1]).max()), float(np.abs(v[2]-r["sep"][2]).max())) for k, v in r.items()})
+print(r["brickmask"][3])

@@ -39,7 +39,7 @@ MODELS = {
 
 
 def check_force_parity(drv, name, generic=False, check_lists=True, tiles=True, mfma=True, lanes=None, win_static=None,
-                       force_form=None, f32_atol=2e-5):
+                       force_form=None, f32_atol=2e-5, brick=None):
     nep_rel, build, _ = MODELS[name]
     nep = H.golden(*nep_rel.split("/"))
     h, typ, x = build()
@@ -62,6 +62,8 @@ def check_force_parity(drv, name, generic=False, check_lists=True, tiles=True, m
         eng.set_win_static(win_static)
     if force_form is not None:
         eng.set_force_form(force_form)
+    if brick is not None:
+        eng.set_brick_force(brick)
     xw, pe, f, v = H.engine_force(drv, eng, h, typ, x)
     if not tiles:
         assert eng.stats().radial_tiles == 0

@@ -242,6 +242,42 @@ def test_run_loop_forms_are_bit_identical(drv, model):
     np.testing.assert_allclose(a[5][:, :2], g[5][:, :2], rtol=1e-6)
 
 
+def test_one_force_kernel_per_brick_matches_the_separate_kernels(drv):
+    """nep_brick.h (opt-in: measured slower than the two kernels it replaces): fused angular kernel + scatter-form force assembly
+    in ONE kernel per brick vs the two kernels.  The same arithmetic compiled into another kernel (other fma contractions): forces
+    equal to a few units of the 2^-22 eV/A fixed point, energies and per-atom virials (the virial-only gather pass, which first
+    has to bring the partial forces and the radial table back to HBM) to FP32 rounding; a 40-step run loop with list rebuilds
+    stays on the same trajectory -- and the kernel itself against the oracle (check_force_parity's comparisons)."""
+    eng = P.check_force_parity(drv, "PbTe-ortho-big", lanes=1, win_static=True, force_form=1, brick=True)
+    assert "one_kernel_per_brick" in eng.describe(), eng.describe()
+    nep, (h, typ, x) = H.golden("PbTe", "nep.txt"), H.pbte_supercell((6, 6, 6), rattle=0.03, seed=17)
+    mass = np.where(typ == 0, H.MASS["Te"], H.MASS["Pb"]).astype(np.float64)
+    n = len(typ)
+    vel = H.maxwell_velocities(mass, 2500.0, seed=4)
+    m = drv.model(nep)
+    out = []
+    for brick in (True, False):
+        eng = drv.engine(m, n)
+        eng.set_win_lanes(1)
+        eng.set_force_form(1)
+        eng.set_brick_force(brick)
+        _, pe0, f0, v0 = H.engine_force(drv, eng, h, typ, x)
+        d_t, d_m, d_x, d_v = drv.dev(typ), drv.dev(mass), drv.dev(x), drv.dev(vel)
+        d_pe, d_f, d_w = drv.zeros(n), drv.zeros(3 * n), drv.zeros(9 * n)
+        eng.force_compute(h, d_t, d_x, d_pe, d_f, d_w)
+        th = eng.run_nve(h, d_t, d_m, 2.0 / H.TIME_UNIT, 40, d_x, d_v, d_pe, d_f, d_w, thermo_every=10)
+        out.append((pe0, f0, v0, drv.host(d_x), drv.host(d_v), drv.host(d_f), drv.host(d_pe), drv.host(d_w), np.asarray(th),
+                    eng.describe(), eng.stats().num_rebuild))
+    a, b = out
+    assert "one_kernel_per_brick" in a[9] and "one_kernel_per_brick" not in b[9] and "lds_scatter" in b[9], (a[9], b[9])
+    assert a[10] >= 2
+    np.testing.assert_allclose(a[0], b[0], rtol=1e-6, atol=1e-6)      # energies
+    assert np.abs(a[1] - b[1]).max() < 2e-6                           # forces: a few fixed-point units
+    np.testing.assert_allclose(a[2], b[2], rtol=1e-5, atol=2e-5)      # per-atom virials
+    assert np.abs(a[3] - b[3]).max() < 1e-6 and np.abs(a[4] - b[4]).max() < 1e-6 and np.abs(a[5] - b[5]).max() < 2e-4
+    np.testing.assert_allclose(a[8], b[8], rtol=1e-6, atol=1e-7)
+
+
 @pytest.mark.parametrize("name", ["PbTe-A", "C-2022"])
 def test_force_parity_with_pair_records(drv, name):
     """Tile mode 1: LDS-window radial pass that writes pair records + the record-reading force assembly."""
