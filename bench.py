@@ -515,7 +515,10 @@ def run_decomposed(args, world, rank, dev, model, label, h_block, typ, x, mass, 
         coords = (rank % grid[0], (rank // grid[0]) % grid[1], rank // (grid[0] * grid[1]))
         X = x.reshape(3, n) + (Hb @ np.asarray(coords, dtype=np.float64))[:, None]
         V, T, M = vel.reshape(3, n), typ, mass
-    if world > 1 and os.environ.get("NEPMI_DIST_BACKEND", "nccl") == "nccl":
+    global _TRANSPORT
+    if _TRANSPORT is not None:  # one communicator for all the legs of a process (the first leg opened it)
+        tr, transport = _TRANSPORT
+    elif world > 1 and os.environ.get("NEPMI_DIST_BACKEND", "nccl") == "nccl":
         def bcast(ident):
             t = torch.zeros(128, dtype=torch.uint8, device=dev)
             if ident is not None:
@@ -529,6 +532,7 @@ def run_decomposed(args, world, rank, dev, model, label, h_block, typ, x, mass, 
         tr = Transport.tcp(lib, os.environ.get("MASTER_ADDR", "127.0.0.1"),
                            int(os.environ.get("MASTER_PORT", "29400")) + 1 + leg, rank, world)
         transport = "TCP sockets (host staging)" if world > 1 else "single rank"
+    _TRANSPORT = (tr, transport)
     STAGE = "decomposed[%s]: setup (first decomposition, ghost exchange, list build)" % scaling
     if os.environ.get("NEPMI_BENCH_FAIL_STAGE") == "setup" and rank == world - 1:
         raise RuntimeError("injected failure (NEPMI_BENCH_FAIL_STAGE: tests/test_bench_launch.py)")
@@ -658,13 +662,13 @@ def run_decomposed(args, world, rank, dev, model, label, h_block, typ, x, mass, 
                        local_atoms_max=int(n_loc.item()))
     STAGE = "decomposed[%s]: teardown" % scaling
     md.close()
-    tr.close()
     if world > 1:
         dist.barrier()
     return out
 
 
 STAGE = "start"  # what the process was doing when it failed (the "error" line names it)
+_TRANSPORT = None  # (gpumd_amd.dist.Transport, description): opened by the first decomposed leg, closed when the process ends
 
 
 def self_launch(args):
@@ -838,7 +842,7 @@ def bench(args):
                             else:
                                 wl = (label_s, h_s, typ_s, x_s, mass_s, vel_s)
                             r = run_decomposed(args, world, rank, dev, model, wl[0], wl[1], wl[2], wl[3].copy(), wl[4], wl[5].copy(),
-                                               scaling=sc, leg=leg, steps=40, warmup=5, overlap=ov, ghosts=gh, brief=True)
+                                               scaling=sc, leg=leg, steps=30, warmup=5, overlap=ov, ghosts=gh, brief=True)
                             if r is not None:
                                 matrix[key] = r
                         except Exception as e:
@@ -849,6 +853,8 @@ def bench(args):
         if out is not None:
             print(json.dumps(out))
             sys.stdout.flush()
+        if _TRANSPORT is not None:
+            _TRANSPORT[0].close()
         if world > 1:
             dist.destroy_process_group()
         return

@@ -1809,9 +1809,11 @@ private:
     b_.skip_atab = (win2 && fpj_wanted<S>(ws2)) ? 1 : 0; // the FPJ force assembly needs no radial table from the ANN kernel
     last_ang_fused_ = false;
     last_brick_ = false;
+    brick_pending_ = false;
     if (win2 && brick_force_wanted<S>(ws2)) {
       launch_brick_force<S>(ws2, frozen);
       last_ang_fused_ = last_brick_ = true;
+      brick_pending_ = true;
       last_scatter_form_ = true;
       outputs_stale_ = !step_outputs_;
       virial_local_ = true; // the virial planes hold the own-half form: exact_virials() before they leave the engine
@@ -1851,10 +1853,10 @@ private:
   template <class S>
   void materialise_for_gather()
   {
-    if (!last_brick_)
+    if (!brick_pending_)
       return;
     launch_angular_fused<S>(0);
-    last_brick_ = false;
+    brick_pending_ = false;
   }
 
   // The gather form of the force assembly (ForceWinBody / ForceAssembleBody); wonly: only the nine virial planes are written
@@ -2191,7 +2193,8 @@ private:
   double hard_factor_ = 4.0;     // set_scatter_guard: hard limit of runs whose flagged steps stand = factor x guard band
   bool ang_fused_ = true;        // set_angular_fused
   bool brick_force_ = false;     // set_brick_force (off: measured slower, see nep_brick.h)
-  bool last_brick_ = false;      // the last force evaluation ran the per-brick force kernel (f12 / atab were not written)
+  bool last_brick_ = false;      // the last force evaluation ran the per-brick force kernel
+  bool brick_pending_ = false;   // ... and its partial forces / radial table have not been written to HBM since (materialise_for_gather)
   float* fused_img_ = nullptr;   // LDS image of the fused angular kernel (nep_fused.h), built at its first launch
   size_t fused_img_floats_ = 0;
   bool fused_img_stale_ = true;

@@ -12,7 +12,7 @@ import sys
 NAMES = [("CheckGatherBody", "gather_skin_check"), ("RadialWin2Body", "radial_descriptor"), ("RadialWinBody", "radial_descriptor"),
          ("ForceWinBody", "force_assemble"),
          ("ResidentStepBody", "velocity_verlet"), ("RadialTileBody", "radial_descriptor"),
-         ("RadialDescBody", "radial_descriptor"), ("AngularDescBody", "angular_descriptor"),
+         ("RadialDescBody", "radial_descriptor"), ("AngularFusedBody", "angular_fused"), ("AngularDescBody", "angular_descriptor"),
          ("nepmi_ann_mfma", "ann"), ("AnnBody", "ann"), ("AngularForceBody", "angular_partial_force"),
          ("ForceTileBody", "force_assemble"), ("ForceAssembleBody", "force_assemble"), ("VerletSeamBody", "velocity_verlet"),
          ("VelocityVerletBody", "velocity_verlet_unfused")]
@@ -39,7 +39,7 @@ def read(path, counter):
         if name in out:
             continue
         for row in rows:
-            if key in row["kernel"]:
+            if key in row["kernel"] and "nepmi_fused_image" not in row["kernel"]:  # (the one-off image builder is not the kernel)
                 out[name] = float(row["sum_per_dispatch"])
                 break
     return out

@@ -54,6 +54,12 @@ def test_plain_gpus_2_launches_its_own_ranks_and_prints_one_line():
     strong = line["extra_measurements"]["strong"]
     assert "error" not in strong, strong
     assert strong["scaling"] == "strong" and strong["config"]["atoms_total"] == 6 * 4 * 4 * 250 and strong["value"] > 0
+    # the decomposed forces against a one-domain evaluation of the same positions on rank 0 (a wrong ghost would show here)
+    assert strong["checksum"]["atoms"] == 6 * 4 * 4 * 250 and strong["checksum"]["max_abs_dF_eV_per_A"] < 3e-5, strong["checksum"]
+    # exchange/compute overlap {0, 1} x ghosts {forward, reverse} on both legs, after the clock
+    matrix = line["extra_measurements"]["overlap_x_ghosts"]
+    assert len(matrix) == 8 and all("error" not in v and v["value"] > 0 for v in matrix.values()), matrix
+    assert {v["ghost_mode"] for v in matrix.values()} == {"forward", "reverse"} and {v["overlap"] for v in matrix.values()} == {0, 1}
     import torch
     if torch.cuda.device_count() < 2:
         assert "functional_only" in line
