@@ -613,7 +613,10 @@ def run_decomposed(args, world, rank, dev, model, label, h_block, typ, x, mass, 
     elapsed = float(t_el.item())
     out = None
     if rank == 0:
-        kern, roofline, b_step = kernel_report(st, model.info, info.n_local, st_all)
+        forms = md.engine_describe()
+        kern, roofline, b_step = kernel_report(st, model.info, info.n_local, st_all,
+                                               fused_angular=("partial_forces_in_one_kernel" in forms or "one_kernel_per_brick" in forms),
+                                               brick_force="one_kernel_per_brick" in forms)
         total = info.n_total
         per_rank_ms = [float(v) / steps * 1e3 for v in t_own.cpu().numpy()]
         out = {
