@@ -1032,6 +1032,23 @@ def bench(args):
                                                   "kernel_forms": eng.describe(),
                                                   "note": "one host call per stage and step through the C ABI (what gpumd_ref_mi executes); "
                                                           "thermo every step"}
+                # ... and with nepmi_engine_set_virial_mode(e, 1): a host that needs the TOTAL virial only (no heat current, no
+                # per-atom virial dump) lets the per-call evaluations take the scatter form as well
+                eng.set_virial_mode(1)
+                for timed_pass in (False, True):
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    for _ in range(ksteps if timed_pass else 3):
+                        eng.vv_step1(dt, t_mass, t_f, t_x, t_v)
+                        eng.force_compute(h, t_type, t_x, t_pe, t_f, t_w)
+                        eng.vv_step2(dt, t_mass, t_f, t_v)
+                        eng.find_thermo(vol, t_mass, t_pe, t_v, t_w, t_th)
+                    torch.cuda.synchronize()
+                    el = time.perf_counter() - t1
+                extras["pbte_per_call_dropin_totals"] = {"workload": label, "steps": ksteps, "ms_per_step": el / ksteps * 1e3,
+                                                         "value": n * ksteps / el, "unit": "atom-steps/s", "kernel_forms": eng.describe(),
+                                                         "note": "the same sequence with nepmi_engine_set_virial_mode(e, 1)"}
+                eng.set_virial_mode(0)
             except Exception as e:
                 extras["pbte_per_call_dropin"] = {"error": str(e)}
             # (a4) the run-time-shape kernels (any n_max / basis_size / l_max / neuron count: what a user-trained potential
@@ -1047,6 +1064,9 @@ def bench(args):
                 os.environ["NEPMI_JIT"] = mode
                 try:
                     extras[key] = measure_extra("carbon2024", (10, 10, 10), 10 if mode == "2" else 3, 2, dev)
+                    # (a prebuilt core carries the hash of the sources it was compiled from: a stale one is not loaded -- say so)
+                    extras[key]["served_by"] = ("JIT core of the model's shape" if "shape=jit(" in extras[key].get("kernel_forms", "")
+                                                else "run-time-shape kernels")
                 except Exception as e:
                     extras[key] = {"error": str(e)}
                 finally:

@@ -116,6 +116,7 @@ SYMBOLS = {
     "nepmi_engine_set_radial_mask": (C.c_int, [VP, C.c_int]),
     "nepmi_engine_set_angular_fused": (C.c_int, [VP, C.c_int]),
     "nepmi_engine_set_brick_force": (C.c_int, [VP, C.c_int]),
+    "nepmi_engine_set_virial_mode": (C.c_int, [VP, C.c_int]),
     "nepmi_engine_set_scatter_guard": (C.c_int, [VP, C.c_double, C.c_double]),
     "nepmi_engine_set_win_static": (C.c_int, [VP, C.c_int]),
     "nepmi_engine_set_stepwise_loops": (C.c_int, [VP, C.c_int]),

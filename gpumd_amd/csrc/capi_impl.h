@@ -516,6 +516,16 @@ int nepmi_engine_set_scatter_guard(nepmi_engine* e, double ev_per_angstrom, doub
   return NEPMI_OK;
 }
 
+int nepmi_engine_set_virial_mode(nepmi_engine* e, int mode)
+{
+  if (!e)
+    return fail(NEPMI_ERR_ARG, "null engine");
+  if (mode != 0 && mode != 1)
+    return fail(NEPMI_ERR_ARG, "virial mode: 0 (per-atom, the reference's attribution), 1 (totals)");
+  e->e->set_loop_context(mode == 1);
+  return NEPMI_OK;
+}
+
 int nepmi_engine_set_brick_force(nepmi_engine* e, int on)
 {
   if (!e)

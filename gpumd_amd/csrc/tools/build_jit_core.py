@@ -33,7 +33,31 @@ def shape_of_model(path):
     return (nr, kr, na, ka, nl, ntypes if ntypes <= 2 else 0)
 
 
+def refresh():
+    """rebuild, side by side, every core in gpumd_amd/lib/jit/ whose name carries another source hash (`make` calls this after
+    libnepmi.so: a core is only ever loaded by a library built from the same sources)"""
+    out_dir = os.path.join(SRC, "..", "lib", "jit")
+    if not os.path.isdir(out_dir):
+        return
+    h = source_hash()
+    shapes = set()
+    for f in os.listdir(out_dir):
+        if f.startswith("libnepmi_jit_") and f.endswith(".so"):
+            parts = f[len("libnepmi_jit_"):-3].split("_")
+            if len(parts) == 7 and parts[6] != h:
+                shapes.add(",".join(parts[:6]))
+    jobs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), sh], stdout=subprocess.DEVNULL) for sh in sorted(shapes)]
+    for j in jobs:
+        if j.wait() != 0:
+            raise SystemExit("a JIT core did not build")
+    if shapes:
+        print("JIT cores rebuilt for the new sources:", ", ".join(sorted(shapes)))
+
+
 def main():
+    if sys.argv[1] == "--refresh":
+        refresh()
+        return
     if sys.argv[1] == "--model":
         shape = shape_of_model(sys.argv[2])
     else:

@@ -318,6 +318,11 @@ class NEP:
         """guard band of the scatter-form force assembly per pair half (test hook: nepmi_engine_set_scatter_guard)"""
         self._ck(self.lib.nepmi_engine_set_scatter_guard(self.handle, float(ev_per_angstrom), float(hard_factor)))
 
+    def set_virial_mode(self, mode=0):
+        """per-call evaluations: 0 per-atom virials in the reference's attribution (default), 1 only the total has to be right
+        (the scatter form of the force assembly where it applies): nepmi_engine_set_virial_mode"""
+        self._ck(self.lib.nepmi_engine_set_virial_mode(self.handle, int(mode)))
+
     def set_brick_force(self, on=True):
         """fused angular kernel + scatter-form force assembly as ONE kernel per brick (default where it applies) or separately
         (nepmi_engine_set_brick_force)"""

@@ -471,6 +471,14 @@ int nepmi_engine_set_win_lanes(nepmi_engine* e, int lanes);
  * gather form on every rank.  Not seen by either guard: a net beyond 768 eV/A made of a dozen or more aligned pair halves that
  * each stay under 64 eV/A. */
 int nepmi_engine_set_force_form(nepmi_engine* e, int mode);
+/* What the per-call entry points (nepmi_potential_compute, nepmi_force_compute, the _levels forms) owe the caller in the virial
+ * planes.  mode 0 (default): per-atom virials in the reference's attribution, W_i = sum_j r_ij (x) f_21 (potential.cu:203-296) --
+ * what compute_hac / compute_hnemd / dump_xyz ... virial read; the gather form of the force assembly provides it.  mode 1: only
+ * the TOTAL has to be right (Ensemble::find_thermo, dump_thermo: ensemble.cu:434-633 sums the planes): the per-call evaluations
+ * then follow the run loops' rule and take the scatter form where it applies (from 768 bricks on), whose planes hold the own-half
+ * attribution -- the same sum, the same forces and energies to f32 rounding, a third less time per call at a million atoms
+ * (bench.py: pbte_per_call_dropin / _totals).  A host sets 1 while no consumer of per-atom virials is active. */
+int nepmi_engine_set_virial_mode(nepmi_engine* e, int mode);
 /* Test hook: the guard band of the scatter form per pair half in eV/A (default and maximum 64; the net-force guard is twice the
  * value), so that the hand-over can be exercised with ordinary forces; hard_factor: the hard limit of decomposed runs as a
  * multiple of the band (<= 0: the default 4; the limit never exceeds 256 eV/A). */

@@ -242,6 +242,28 @@ def test_run_loop_forms_are_bit_identical(drv, model):
     np.testing.assert_allclose(a[5][:, :2], g[5][:, :2], rtol=1e-6)
 
 
+def test_virial_mode_totals_lets_per_call_evaluations_take_the_scatter_form(drv):
+    """nepmi_engine_set_virial_mode(e, 1): a host that only needs the TOTAL virial (find_thermo) gets the run loops' rule on
+    the per-call entry points -- forces and energies equal to f32 rounding, the SUM of the virial planes equal, per-atom planes in
+    the own-half attribution (not compared); mode 0 afterwards: the reference's attribution again, bit for bit."""
+    nep = H.golden("PbTe", "nep.txt")
+    h, typ, x = H.rocksalt_orthogonal((30, 30, 30), rattle=0.02, seed=9)  # 216,000 atoms, about a thousand bricks (>= 768: asserted below)
+    n = len(typ)
+    model = drv.model(nep)
+    eng = drv.engine(model, n)
+    _, pe0, f0, v0 = H.engine_force(drv, eng, h, typ, x)
+    assert "lds_scatter" not in eng.describe()
+    eng.set_virial_mode(1)
+    _, pe1, f1, v1 = H.engine_force(drv, eng, h, typ, x)
+    assert int(eng.describe().split("bricks=")[1].split()[0]) >= 768 and "lds_scatter" in eng.describe(), eng.describe()
+    np.testing.assert_allclose(pe1, pe0, rtol=1e-6, atol=1e-6)
+    assert np.abs(f1 - f0).max() < 1e-5
+    np.testing.assert_allclose(v1.reshape(9, n).sum(axis=1), v0.reshape(9, n).sum(axis=1), rtol=1e-5, atol=1e-3)
+    eng.set_virial_mode(0)
+    _, pe2, f2, v2 = H.engine_force(drv, eng, h, typ, x)
+    assert np.array_equal(pe2, pe0) and np.array_equal(f2, f0) and np.array_equal(v2, v0)
+
+
 def test_one_force_kernel_per_brick_matches_the_separate_kernels(drv):
     """nep_brick.h (opt-in: measured slower than the two kernels it replaces): fused angular kernel + scatter-form force assembly
     in ONE kernel per brick vs the two kernels.  The same arithmetic compiled into another kernel (other fma contractions): forces
