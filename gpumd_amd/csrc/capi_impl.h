@@ -609,8 +609,7 @@ int nepmi_engine_set_generic(nepmi_engine* e, int on)
 {
   if (!e)
     return fail(NEPMI_ERR_ARG, "null engine");
-  e->e->set_force_generic(on != 0);
-  return NEPMI_OK;
+  return guarded([&] { e->e->set_force_generic(on != 0); });
 }
 
 } // extern "C"

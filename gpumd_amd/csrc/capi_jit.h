@@ -6,7 +6,7 @@
 // five instantiations (engine_impl.h: S_PbTeA ... S_BZO) next to the run-time-shape kernels, whose register arrays live in
 // scratch memory (PbTe 1 M atoms: 13.1 ms per step against 1.2: profiles/r5c_bench.json, pbte_generic_shape).  For a model of
 // another shape the library therefore compiles ITSELF once more -- the same sources, `-DNEPMI_JIT_CORE
-// -DNEPMI_JIT_SHAPE=n_r,k_r,n_a,k_a,n_L,types`: that shape and the run-time shape only, ~50 s of hipcc -- into a JIT core
+// -DNEPMI_JIT_SHAPE=n_r,k_r,n_a,k_a,n_L,types`: that shape only, ~40 s of hipcc -- into a JIT core
 //     libnepmi_jit_<shape>_<hash of the sources>.so
 // kept in <directory of libnepmi.so>/jit/ (cores built ahead of time, e.g. by __graft_entry__.build()) or in the user's cache
 // ($NEPMI_JIT_CACHE, else ~/.cache/nepmi), loads it (dlopen, RTLD_LOCAL) and lets it serve the model: every handle carries the

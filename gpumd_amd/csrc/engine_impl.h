@@ -28,10 +28,12 @@
 // shape, -DNEPMI_JIT_SHAPE=n_r,k_r,n_a,k_a,n_L,types -DNEPMI_JIT_CORE) knows that shape and the run-time shape only.
 #define NEPMI_UNPAREN(...) __VA_ARGS__
 #if defined(NEPMI_JIT_CORE)
+// (a core serves models of its own shape only -- nepmi_model_load hands it nothing else -- so it does not carry the run-time-shape
+// kernels, the slowest part of the library to compile; nepmi_engine_set_generic is refused there)
 #define NEPMI_SHAPE_DISPATCH(FN, GENERIC, ARGS)                                   \
   switch (shape_) {                                                               \
     case 6: FN<S_JIT>(NEPMI_UNPAREN ARGS); break;                                 \
-    default: if (GENERIC) FN<ShapeGeneric>(NEPMI_UNPAREN ARGS); break;            \
+    default: if (GENERIC) throw EngineError{-4, "a JIT core carries the kernels of its own shape only"}; break; \
   }
 #else
 #define NEPMI_SHAPE_DISPATCH(FN, GENERIC, ARGS)                                   \
@@ -1708,6 +1710,11 @@ public:
   }
   void set_force_generic(bool on)
   {
+#if defined(NEPMI_JIT_CORE)
+    if (on)
+      throw EngineError{-4, "nepmi_engine_set_generic: a JIT core carries the kernels of its own shape only (NEPMI_JIT=0 loads the "
+                            "model into the library itself)"};
+#endif
     force_generic_ = on;
     select_shape();
     have_list_ = false; // the packed list words follow the shape (two type-pure streams for two-type shapes)
