@@ -237,14 +237,16 @@ inline const nepmi_api* core_for(const ShapeKey& key)
         path = d + "/" + name;
   }
   const char* mode = std::getenv("NEPMI_JIT");
-  if (path.empty() && !(mode && mode[0] == '2')) // NEPMI_JIT=2: cores that exist already, never the compiler
+  const bool may_build = !(mode && mode[0] == '2'); // NEPMI_JIT=2: cores that exist already, never the compiler
+  if (path.empty() && may_build)
     path = build_core(key, cache_dir(), why);
   if (!path.empty())
     api = load_core(path, why);
   if (!api)
     std::fprintf(stderr, "nepmi: no kernels compiled for this model's shape (%s): the run-time-shape kernels serve it, several "
                          "times slower\n", why.empty() ? "no core found, NEPMI_JIT=2" : why.c_str());
-  cores[key.name()] = api;
+  if (api || may_build) // (a failed compilation is not tried again by this process; a look-up without the compiler may be)
+    cores[key.name()] = api;
   return api;
 }
 

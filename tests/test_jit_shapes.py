@@ -62,6 +62,33 @@ def test_without_a_core_the_run_time_shape_kernels_serve_the_model(monkeypatch, 
     m.close()
 
 
+def test_first_load_of_a_new_shape_compiles_its_core(monkeypatch, capfd, tmp_path):
+    """the compiler path itself (no GPU needed, ~40 s of hipcc): NEPMI_JIT=1, an empty cache, a shape nobody built a core for
+    (Si with the 4-body row: 10,10,10,10,5;1) -> nepmi_model_load compiles the core into the cache, says so on stderr, loads it;
+    a second load finds the file"""
+    import ctypes as C
+    import shutil
+    import gpumd_amd
+    if shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc on this host")
+    assert not _core("10_10_10_10_5_1")
+    monkeypatch.setenv("NEPMI_JIT", "1")
+    monkeypatch.setenv("NEPMI_JIT_CACHE", str(tmp_path / "cache"))
+    nep = H.golden("Si", "nep_4body.txt")
+    m = gpumd_amd.Model(nep)
+    err = capfd.readouterr().err
+    assert "compiling the NEP kernels for this model's shape" in err and "no kernels compiled" not in err, err
+    built = glob.glob(str(tmp_path / "cache" / "libnepmi_jit_10_10_10_10_5_1_*.so"))
+    assert len(built) == 1, os.listdir(str(tmp_path / "cache"))
+    assert not glob.glob(str(tmp_path / "cache" / "*.lock")) and not glob.glob(str(tmp_path / "cache" / "*.tmp*"))
+    monkeypatch.setenv("NEPMI_JIT", "0")
+    m0 = gpumd_amd.Model(nep)
+    assert C.c_void_p.from_address(m.handle).value != C.c_void_p.from_address(m0.handle).value  # two libraries
+    assert m.info.dim == m0.info.dim and m.info.num_L == 5
+    m.close()
+    m0.close()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_force_parity_on_a_jit_core(name, monkeypatch):
