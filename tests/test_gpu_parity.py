@@ -202,8 +202,8 @@ def test_scatter_guard_band_hands_over_to_the_gather_form(drv, monkeypatch):
 
 @pytest.mark.parametrize("model", ["PbTe", "C"])
 def test_run_loop_forms_are_bit_identical(drv, model):
-    """The run loop's scatter-form steps with the per-step radial list as inside bits over the packed Verlet words (the
-    default) and as a compacted list: the same pairs with the same per-pair arithmetic into integer sums -- identical
+    """The run loop's scatter-form steps with the per-step radial list as inside bits over the packed Verlet words (opt-in:
+    nepmi_engine_set_radial_mask) and as a compacted list (the default): the same pairs with the same per-pair arithmetic into integer sums -- identical
     positions, velocities, forces and energies after 40 steps with list rebuilds, bit for bit; per-atom virials (the
     virial-only gather pass at the exit, which needs the compacted list rebuilt on demand) identical as well; and both
     against the gather form within f32 rounding."""
