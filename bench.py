@@ -391,6 +391,10 @@ def kernel_report(st, info, n_atoms_per_launch, st_all=None, tersoff=False, fuse
                     "algorithmic_bytes_per_launch": per_kernel[dom] * n_atoms_per_launch,
                     "algorithmic_bytes_per_atom": per_kernel[dom], "avg_launch_ms": kern[dom]["avg_ms"],
                     "note": "FP32-VALU/gather bound stage (SURVEY.md 8d); see step_hbm_frac for the whole step"}
+        if dom in ("angular_fused", "brick_force"):
+            roofline["note"] += ("; this launch is the angular descriptor, the ANN and the partial angular forces in one kernel: its algorithmic bytes "
+                                 "are the three stages' shares of the SURVEY 8(d) split, which counts the q / Fp round trips between them -- the "
+                                 "kernel keeps those on-chip, so its counter traffic lies BELOW its algorithmic bytes")
         if len(ranked) > 1:  # the runner-up, priced the same way (two kernels can be tied to a per cent)
             k2 = ranked[1]
             roofline["second"] = {"kernel": k2, "avg_launch_ms": kern[k2]["avg_ms"], "frac": kern[k2].get("frac"),
