@@ -25,6 +25,7 @@
 #include <unistd.h>
 
 #include <chrono>
+#include <ctime>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -165,7 +166,14 @@ inline std::string build_core(const ShapeKey& key, const std::string& dir, std::
   const std::string out = dir + "/" + name, lock = out + ".lock", log = out + ".log";
   if (file_exists(out))
     return out;
-  const int fd = ::open(lock.c_str(), O_CREAT | O_EXCL | O_WRONLY, 0644);
+  int fd = ::open(lock.c_str(), O_CREAT | O_EXCL | O_WRONLY, 0644);
+  if (fd < 0) { // a lock left behind by a process that died while compiling (older than a quarter of an hour): take it over
+    struct stat st;
+    if (::stat(lock.c_str(), &st) == 0 && std::time(nullptr) - st.st_mtime > 900) {
+      ::unlink(lock.c_str());
+      fd = ::open(lock.c_str(), O_CREAT | O_EXCL | O_WRONLY, 0644);
+    }
+  }
   if (fd < 0) {
     // another process compiles this core: wait for it (a stale lock of a killed process: give up after ten minutes)
     for (int i = 0; i < 1200; ++i) {
