@@ -892,6 +892,8 @@ def bench(args):
         eng.set_angular_fused(os.environ["NEPMI_BENCH_ANGFUSED"] != "0")
     if "NEPMI_BENCH_BRICK" in os.environ:  # one force kernel per brick (default) / fused angular kernel + scatter kernel
         eng.set_brick_force(os.environ["NEPMI_BENCH_BRICK"] != "0")
+    if "NEPMI_BENCH_SYNC" in os.environ:  # per-step radial list of the scatter-form steps: 1 wave-synchronous words (default), 0 slot-major compact list
+        eng.set_radial_sync(os.environ["NEPMI_BENCH_SYNC"] != "0")
     if "NEPMI_BENCH_FORM" in os.environ:  # force assembly: 0 gather, 1 scatter (default: the run loops' rule)
         eng.set_force_form(int(os.environ["NEPMI_BENCH_FORM"]))
     # initial force (Run::perform_a_run computes it before the loop), then warm-up steps

@@ -109,20 +109,10 @@ SYMBOLS = {
     "nepmi_descriptors_export": (C.c_int, [VP, VP, VP]),
     "nepmi_engine_stats": (C.c_int, [VP, C.c_int, C.POINTER(NepmiStats)]),
     "nepmi_engine_set_timing": (C.c_int, [VP, C.c_int]),
-    "nepmi_engine_set_generic": (C.c_int, [VP, C.c_int]),
-    "nepmi_engine_set_tiles": (C.c_int, [VP, C.c_int]),
-    "nepmi_engine_set_win_lanes": (C.c_int, [VP, C.c_int]),
     "nepmi_engine_set_force_form": (C.c_int, [VP, C.c_int]),
-    "nepmi_engine_set_radial_mask": (C.c_int, [VP, C.c_int]),
-    "nepmi_engine_set_angular_fused": (C.c_int, [VP, C.c_int]),
-    "nepmi_engine_set_brick_force": (C.c_int, [VP, C.c_int]),
+    "nepmi_engine_set_option": (C.c_int, [VP, C.c_char_p, C.c_double]),
     "nepmi_engine_set_virial_mode": (C.c_int, [VP, C.c_int]),
-    "nepmi_engine_set_scatter_guard": (C.c_int, [VP, C.c_double, C.c_double]),
-    "nepmi_engine_set_win_static": (C.c_int, [VP, C.c_int]),
-    "nepmi_engine_set_stepwise_loops": (C.c_int, [VP, C.c_int]),
     "nepmi_engine_describe": (C.c_int, [VP, C.c_char_p, C.c_int]),
-    "nepmi_engine_set_mfma": (C.c_int, [VP, C.c_int]),
-    "nepmi_engine_set_angular_recompute": (C.c_int, [VP, C.c_int]),
     "nepmi_engine_set_temperature": (C.c_int, [VP, C.c_double]),
     "nepmi_transport_rccl_id": (C.c_int, [C.c_char_p]),
     "nepmi_transport_rccl": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(NepmiTransport)]),

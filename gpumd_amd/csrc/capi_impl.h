@@ -482,14 +482,6 @@ int nepmi_engine_set_timing(nepmi_engine* e, int on)
   return NEPMI_OK;
 }
 
-int nepmi_engine_set_win_lanes(nepmi_engine* e, int lanes)
-{
-  if (!e)
-    return fail(NEPMI_ERR_ARG, "null engine");
-  e->e->set_win_lanes(lanes);
-  return NEPMI_OK;
-}
-
 int nepmi_engine_set_force_form(nepmi_engine* e, int mode)
 {
   if (!e)
@@ -500,22 +492,6 @@ int nepmi_engine_set_force_form(nepmi_engine* e, int mode)
   return NEPMI_OK;
 }
 
-int nepmi_engine_set_radial_mask(nepmi_engine* e, int on)
-{
-  if (!e)
-    return fail(NEPMI_ERR_ARG, "null engine");
-  e->e->set_radial_mask(on != 0);
-  return NEPMI_OK;
-}
-
-int nepmi_engine_set_scatter_guard(nepmi_engine* e, double ev_per_angstrom, double hard_factor)
-{
-  if (!e)
-    return fail(NEPMI_ERR_ARG, "null engine");
-  e->e->set_scatter_guard(ev_per_angstrom, hard_factor);
-  return NEPMI_OK;
-}
-
 int nepmi_engine_set_virial_mode(nepmi_engine* e, int mode)
 {
   if (!e)
@@ -523,62 +499,6 @@ int nepmi_engine_set_virial_mode(nepmi_engine* e, int mode)
   if (mode != 0 && mode != 1)
     return fail(NEPMI_ERR_ARG, "virial mode: 0 (per-atom, the reference's attribution), 1 (totals)");
   e->e->set_loop_context(mode == 1);
-  return NEPMI_OK;
-}
-
-int nepmi_engine_set_brick_force(nepmi_engine* e, int on)
-{
-  if (!e)
-    return fail(NEPMI_ERR_ARG, "null engine");
-  e->e->set_brick_force(on != 0);
-  return NEPMI_OK;
-}
-
-int nepmi_engine_set_angular_fused(nepmi_engine* e, int on)
-{
-  if (!e)
-    return fail(NEPMI_ERR_ARG, "null engine");
-  e->e->set_angular_fused(on != 0);
-  return NEPMI_OK;
-}
-
-int nepmi_engine_set_stepwise_loops(nepmi_engine* e, int on)
-{
-  if (!e)
-    return fail(NEPMI_ERR_ARG, "null engine");
-  e->e->set_stepwise_loops(on != 0);
-  return NEPMI_OK;
-}
-
-int nepmi_engine_set_win_static(nepmi_engine* e, int on)
-{
-  if (!e)
-    return fail(NEPMI_ERR_ARG, "null engine");
-  e->e->set_win2(on != 0);
-  return NEPMI_OK;
-}
-
-int nepmi_engine_set_tiles(nepmi_engine* e, int on)
-{
-  if (!e)
-    return fail(NEPMI_ERR_ARG, "null engine");
-  e->e->set_tile_mode(on < 0 ? -1 : on > 2 ? 2 : on);
-  return NEPMI_OK;
-}
-
-int nepmi_engine_set_mfma(nepmi_engine* e, int on)
-{
-  if (!e)
-    return fail(NEPMI_ERR_ARG, "null engine");
-  e->e->set_use_mfma(on);
-  return NEPMI_OK;
-}
-
-int nepmi_engine_set_angular_recompute(nepmi_engine* e, int mode)
-{
-  if (!e)
-    return fail(NEPMI_ERR_ARG, "null engine");
-  e->e->set_angular_recompute(mode);
   return NEPMI_OK;
 }
 
@@ -605,11 +525,47 @@ int nepmi_engine_set_unwrapped(nepmi_engine* e, double* d_unwrapped)
   return NEPMI_OK;
 }
 
-int nepmi_engine_set_generic(nepmi_engine* e, int on)
+int nepmi_engine_set_option(nepmi_engine* e, const char* name, double value)
 {
-  if (!e)
-    return fail(NEPMI_ERR_ARG, "null engine");
-  return guarded([&] { e->e->set_force_generic(on != 0); });
+  if (!e || !name)
+    return fail(NEPMI_ERR_ARG, "null engine or option name");
+  const std::string n(name);
+  const int iv = (int)value;
+  auto& eng = *e->e;
+  if (n == "generic")
+    return guarded([&] { eng.set_force_generic(iv != 0); });
+  if (n == "tiles")
+    eng.set_tile_mode(iv < 0 ? -1 : iv > 2 ? 2 : iv);
+  else if (n == "win_lanes")
+    eng.set_win_lanes(iv);
+  else if (n == "scatter_guard")
+    eng.set_scatter_guard_delayed(value, eng.take_guard_delay());
+  else if (n == "scatter_guard_hard")
+    eng.set_scatter_guard(-1.0, value);
+  else if (n == "scatter_guard_delay") // the NEXT "scatter_guard" applies from the value-th force assembly after it on
+    eng.set_guard_delay(iv);
+  else if (n == "radial_mask")
+    eng.set_radial_mask(iv != 0);
+  else if (n == "radial_sync")
+    eng.set_radial_sync(iv != 0);
+  else if (n == "angular_fused")
+    eng.set_angular_fused(iv != 0);
+  else if (n == "brick_force") {
+    if (iv != 0 && !eng.has_brick_force())
+      return fail(NEPMI_ERR_ARG, "option 'brick_force': the per-brick force kernel is not part of this build (make BRICK=1)");
+    eng.set_brick_force(iv != 0);
+  }
+  else if (n == "win_static")
+    eng.set_win2(iv != 0);
+  else if (n == "stepwise_loops")
+    eng.set_stepwise_loops(iv != 0);
+  else if (n == "mfma")
+    eng.set_use_mfma(iv);
+  else if (n == "angular_recompute")
+    eng.set_angular_recompute(iv);
+  else
+    return fail(NEPMI_ERR_ARG, "unknown engine option '" + n + "'");
+  return NEPMI_OK;
 }
 
 } // extern "C"

@@ -34,6 +34,10 @@
 #include <sstream>
 #include <string>
 #include <thread>
+#include <vector>
+#include <cerrno>
+#include <sys/file.h>
+#include <sys/wait.h>
 
 struct nepmi_api;
 extern "C" const nepmi_api nepmi_self_api;
@@ -70,12 +74,16 @@ inline const char* const* source_files()
   static const char* const files[] = {
     "engine.hip", "nep_model.cpp", "transport_tcp.cpp", "engine_impl.h", "capi_impl.h", "capi_jit.h", "capi_dispatch.inc",
     "dist_bodies.h", "dist_impl.h", "dist_capi_impl.h", "nep_dev.h", "nep_bodies.h", "nep_window.h", "nep_scatter.h",
-    "nep_fused.h", "nep_brick.h", "nep_highl.h", "nep_highl_tables.h", "nep_invariants_extra.h", "nep_md.h", "nep_model.h", "tersoff_bodies.h",
+    "nep_fused.h", "nep_highl.h", "nep_highl_tables.h", "nep_invariants_extra.h", "nep_md.h", "nep_model.h", "tersoff_bodies.h",
     "../../include/nepmi.h", nullptr};
   return files;
 }
 
-// FNV-1a over the sources: a core is only ever loaded by a library built from the same text
+// FNV-1a over the sources.  The hash of the text THIS library was built from is baked in at build time (Makefile:
+// -DNEPMI_SRC_HASH, tools/build_jit_core.py --hash): it names the cores this library may load, and a core reports the hash it
+// was built with (nepmi_core_abi) -- a core and a library of different text can differ in the order of the function table or
+// in the layout of the handles.  The files on disk are read only when a core has to be COMPILED, and only used when they
+// still hash to the baked value.
 inline bool source_hash(const std::string& dir, uint64_t& h)
 {
   h = 1469598103934665603ull;
@@ -96,6 +104,11 @@ inline bool source_hash(const std::string& dir, uint64_t& h)
   return true;
 }
 
+#ifndef NEPMI_SRC_HASH
+#define NEPMI_SRC_HASH 0ull // a build without the Makefile: no JIT cores (nothing to match them with)
+#endif
+inline uint64_t baked_hash() { return (uint64_t)NEPMI_SRC_HASH; }
+
 inline std::string hipcc_path()
 {
   if (const char* e = std::getenv("NEPMI_HIPCC"))
@@ -105,12 +118,16 @@ inline std::string hipcc_path()
   return "hipcc";
 }
 
+// $NEPMI_JIT_CACHE, else ~/.cache/nepmi; "" when neither is known (no HOME): a predictable path under a world-writable
+// directory is not a place to dlopen shared objects from
 inline std::string cache_dir()
 {
   if (const char* e = std::getenv("NEPMI_JIT_CACHE"))
     return e;
   const char* home = std::getenv("HOME");
-  return std::string(home ? home : "/tmp") + "/.cache/nepmi";
+  if (!home || !home[0])
+    return "";
+  return std::string(home) + "/.cache/nepmi";
 }
 
 inline void mkdirs(const std::string& p)
@@ -119,11 +136,18 @@ inline void mkdirs(const std::string& p)
   for (size_t i = 0; i <= p.size(); ++i) {
     if (i == p.size() || p[i] == '/') {
       if (!cur.empty())
-        ::mkdir(cur.c_str(), 0755);
+        ::mkdir(cur.c_str(), 0700);
     }
     if (i < p.size())
       cur.push_back(p[i]);
   }
+}
+
+// the cache directory must be ours alone before anything in it is loaded into the process
+inline bool private_dir(const std::string& p)
+{
+  struct stat st;
+  return ::stat(p.c_str(), &st) == 0 && S_ISDIR(st.st_mode) && st.st_uid == ::geteuid() && (st.st_mode & (S_IWGRP | S_IWOTH)) == 0;
 }
 
 struct ShapeKey {
@@ -142,75 +166,119 @@ struct ShapeKey {
   }
 };
 
-// the file name of the core for `key` built from the sources in `src`, or "" when the sources cannot be read
-inline std::string core_name(const ShapeKey& key, const std::string& src)
+// the file name of the core for `key` that matches this library
+inline std::string core_name(const ShapeKey& key)
 {
-  uint64_t h = 0;
-  if (!source_hash(src, h))
-    return "";
   char hb[32];
-  std::snprintf(hb, sizeof hb, "%016llx", (unsigned long long)h);
+  std::snprintf(hb, sizeof hb, "%016llx", (unsigned long long)baked_hash());
   return "libnepmi_jit_" + key.name() + "_" + hb + ".so";
 }
 
-// Compile the core into `dir` (created if need be).  Returns the path, or "" (with `why` set).
+// hipcc with an argument vector (no shell: paths may hold any character), output into `log`
+inline int run_compiler(const std::vector<std::string>& argv, const std::string& log)
+{
+  const pid_t pid = ::fork();
+  if (pid < 0)
+    return -1;
+  if (pid == 0) {
+    const int fd = ::open(log.c_str(), O_CREAT | O_TRUNC | O_WRONLY, 0600);
+    if (fd >= 0) {
+      ::dup2(fd, 1);
+      ::dup2(fd, 2);
+      ::close(fd);
+    }
+    std::vector<char*> av;
+    for (const std::string& a : argv)
+      av.push_back(const_cast<char*>(a.c_str()));
+    av.push_back(nullptr);
+    ::execvp(av[0], av.data());
+    ::_exit(127);
+  }
+  int status = 0;
+  while (::waitpid(pid, &status, 0) < 0 && errno == EINTR) {
+  }
+  return WIFEXITED(status) ? WEXITSTATUS(status) : -1;
+}
+
+// Compile the core into `dir` (created if need be).  Returns the path, or "" (with `why` set).  One process compiles, the
+// others wait on the lock file (flock: released by the kernel when its holder dies, however it dies).
 inline std::string build_core(const ShapeKey& key, const std::string& dir, std::string& why)
 {
+  if (dir.empty()) {
+    why = "no cache directory (set NEPMI_JIT_CACHE or HOME)";
+    return "";
+  }
   const std::string src = src_dir();
-  const std::string name = core_name(key, src);
-  if (name.empty()) {
+  uint64_t on_disk = 0;
+  if (!source_hash(src, on_disk)) {
     why = "the kernel sources were not found in " + src + " (NEPMI_SRC_DIR)";
     return "";
   }
-  mkdirs(dir);
-  const std::string out = dir + "/" + name, lock = out + ".lock", log = out + ".log";
-  if (file_exists(out))
-    return out;
-  int fd = ::open(lock.c_str(), O_CREAT | O_EXCL | O_WRONLY, 0644);
-  if (fd < 0) { // a lock left behind by a process that died while compiling (older than a quarter of an hour): take it over
-    struct stat st;
-    if (::stat(lock.c_str(), &st) == 0 && std::time(nullptr) - st.st_mtime > 900) {
-      ::unlink(lock.c_str());
-      fd = ::open(lock.c_str(), O_CREAT | O_EXCL | O_WRONLY, 0644);
-    }
-  }
-  if (fd < 0) {
-    // another process compiles this core: wait for it (a stale lock of a killed process: give up after ten minutes)
-    for (int i = 0; i < 1200; ++i) {
-      if (file_exists(out))
-        return out;
-      if (!file_exists(lock))
-        break;
-      std::this_thread::sleep_for(std::chrono::milliseconds(500));
-    }
-    if (file_exists(out))
-      return out;
-    why = "timed out waiting for another process to compile " + out + " (remove " + lock + " if it is stale)";
+  if (on_disk != baked_hash()) {
+    why = "the sources in " + src + " are not the ones this library was built from (rebuild the library, or point NEPMI_SRC_DIR at its sources)";
     return "";
   }
-  ::close(fd);
-  char tmp[64];
-  std::snprintf(tmp, sizeof tmp, ".tmp%d", (int)::getpid());
-  const std::string cmd = hipcc_path() + " --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-pass-failed -Wl,-Bsymbolic -Wl,-rpath,/opt/rocm/lib" +
-                          " -DNEPMI_JIT_CORE -DNEPMI_JIT_SHAPE=" + key.macro() + " -o '" + out + tmp + "' '" + src + "/engine.hip' '" + src +
-                          "/nep_model.cpp' '" + src + "/transport_tcp.cpp' -ldl > '" + log + "' 2>&1";
-  std::fprintf(stderr, "nepmi: compiling the NEP kernels for this model's shape (n_max %d %d, basis_size %d %d, %d invariant rows, %s): "
-                       "one-off, about a minute, kept as %s\n",
-               key.nr, key.na, key.kr, key.ka, key.nl, key.ts ? "type-pure lists" : "any number of types", out.c_str());
-  const int rc = std::system(cmd.c_str());
-  std::string result;
-  if (rc == 0 && file_exists(out + tmp) && ::rename((out + tmp).c_str(), out.c_str()) == 0) {
-    result = out;
-    ::unlink(log.c_str());
-  } else {
-    why = "hipcc failed (log: " + log + ")";
-    ::unlink((out + tmp).c_str());
+  mkdirs(dir);
+  if (!private_dir(dir)) {
+    why = dir + " is not a directory owned by this user and writable by nobody else";
+    return "";
   }
+  const std::string name = core_name(key);
+  const std::string out = dir + "/" + name, lock = out + ".lock";
+  if (file_exists(out))
+    return out;
+  const int lfd = ::open(lock.c_str(), O_CREAT | O_RDWR, 0600);
+  if (lfd < 0) {
+    why = "cannot create " + lock;
+    return "";
+  }
+  if (::flock(lfd, LOCK_EX) != 0) {
+    ::close(lfd);
+    why = "cannot lock " + lock;
+    return "";
+  }
+  std::string result;
+  if (file_exists(out)) { // another process compiled it while this one waited
+    result = out;
+  } else {
+    char tag[64];
+    std::snprintf(tag, sizeof tag, ".%d.%llx", (int)::getpid(),
+                  (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count());
+    const std::string tmp = out + tag + ".tmp", log = out + tag + ".log";
+    char hash_def[64];
+    std::snprintf(hash_def, sizeof hash_def, "-DNEPMI_SRC_HASH=0x%016llxull", (unsigned long long)baked_hash());
+    const std::vector<std::string> argv = {hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-pass-failed",
+                                           "-Wl,-Bsymbolic", "-Wl,-rpath,/opt/rocm/lib", "-DNEPMI_JIT_CORE", "-DNEPMI_JIT_SHAPE=" + key.macro(),
+                                           hash_def, "-o", tmp, src + "/engine.hip", src + "/nep_model.cpp", src + "/transport_tcp.cpp", "-ldl"};
+    std::fprintf(stderr, "nepmi: compiling the NEP kernels for this model's shape (n_max %d %d, basis_size %d %d, %d invariant rows, %s): "
+                         "one-off, about a minute, kept as %s\n",
+                 key.nr, key.na, key.kr, key.ka, key.nl, key.ts ? "type-pure lists" : "any number of types", out.c_str());
+    const int rc = run_compiler(argv, log);
+    if (rc == 0 && file_exists(tmp) && ::rename(tmp.c_str(), out.c_str()) == 0) {
+      result = out;
+      ::unlink(log.c_str());
+    } else {
+      why = rc == 127 ? "no compiler (" + hipcc_path() + ": NEPMI_HIPCC)" : "hipcc failed (log: " + log + ")";
+      ::unlink(tmp.c_str());
+    }
+  }
+  // (a waiter that opened the file before this unlink gets the lock of the orphaned inode next, finds the core in place and
+  // returns; one that comes later creates a fresh lock file)
   ::unlink(lock.c_str());
+  ::flock(lfd, LOCK_UN);
+  ::close(lfd);
+  if (result.empty() && why.empty())
+    why = "the process that held " + lock + " did not produce the core (its compiler failed)";
   return result;
 }
 
-inline const nepmi_api* load_core(const std::string& path, std::string& why)
+// what a core reports about itself: the hash of the sources it was compiled from, the size of its function table
+struct CoreAbi {
+  uint64_t src_hash;
+  uint64_t api_bytes;
+};
+
+inline const nepmi_api* load_core(const std::string& path, uint64_t api_bytes, std::string& why)
 {
   void* h = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
   if (!h) {
@@ -218,16 +286,25 @@ inline const nepmi_api* load_core(const std::string& path, std::string& why)
     return nullptr;
   }
   typedef const nepmi_api* (*get_api)(void);
+  typedef CoreAbi (*get_abi)(void);
   get_api f = reinterpret_cast<get_api>(dlsym(h, "nepmi_core_api"));
-  if (!f) {
-    why = "no nepmi_core_api in " + path;
+  get_abi g = reinterpret_cast<get_abi>(dlsym(h, "nepmi_core_abi"));
+  if (!f || !g) {
+    why = "no nepmi_core_api / nepmi_core_abi in " + path;
+    dlclose(h);
+    return nullptr;
+  }
+  const CoreAbi abi = g();
+  if (abi.src_hash != baked_hash() || abi.api_bytes != api_bytes) {
+    why = path + " was built from other sources than this library (its name says otherwise: remove it)";
+    dlclose(h);
     return nullptr;
   }
   return f();
 }
 
 // the core that serves models of this shape: loaded once per process; nullptr = the run-time-shape kernels of this library
-inline const nepmi_api* core_for(const ShapeKey& key)
+inline const nepmi_api* core_for(const ShapeKey& key, uint64_t api_bytes)
 {
   static std::mutex mu;
   static std::map<std::string, const nepmi_api*> cores;
@@ -237,19 +314,23 @@ inline const nepmi_api* core_for(const ShapeKey& key)
     return it->second;
   const nepmi_api* api = nullptr;
   std::string why;
-  const std::string name = core_name(key, src_dir());
-  std::string path;
-  if (!name.empty()) {
-    for (const std::string& d : {lib_dir() + "/jit", cache_dir()})
-      if (path.empty() && file_exists(d + "/" + name))
-        path = d + "/" + name;
-  }
   const char* mode = std::getenv("NEPMI_JIT");
   const bool may_build = !(mode && mode[0] == '2'); // NEPMI_JIT=2: cores that exist already, never the compiler
-  if (path.empty() && may_build)
-    path = build_core(key, cache_dir(), why);
-  if (!path.empty())
-    api = load_core(path, why);
+  if (baked_hash() == 0) {
+    why = "this library was built without a source hash (NEPMI_SRC_HASH: use the Makefile)";
+  } else {
+    const std::string name = core_name(key);
+    std::string path;
+    const std::string user = cache_dir();
+    if (file_exists(lib_dir() + "/jit/" + name)) // cores built ahead of time, next to the library
+      path = lib_dir() + "/jit/" + name;
+    else if (!user.empty() && private_dir(user) && file_exists(user + "/" + name))
+      path = user + "/" + name;
+    if (path.empty() && may_build)
+      path = build_core(key, user, why);
+    if (!path.empty())
+      api = load_core(path, api_bytes, why);
+  }
   if (!api)
     std::fprintf(stderr, "nepmi: no kernels compiled for this model's shape (%s): the run-time-shape kernels serve it, several "
                          "times slower\n", why.empty() ? "no core found, NEPMI_JIT=2" : why.c_str());

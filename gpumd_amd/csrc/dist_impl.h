@@ -300,6 +300,16 @@ public:
         e->force_kernels_on(comm, Engine::kPhaseBoundaryRadial, frozen());
       if (&comm != &be_)
         be_.join_from(comm);
+      // The host's look at the voted words (every kPollEvery-th step, kPollDepth looks in flight) is taken HERE, behind the vote
+      // and in front of the force phase: all three words of the snapshot are then the reduced ones -- the same on every rank.
+      // (Taken behind the force phase, the range word could also hold what THIS rank's scatter kernel raised during the step,
+      // one look before the others see it: one rank alone would have left the loop's collective sequence.)
+      const bool look = !trip && spec && !(record || last || ens == Engine::kBdp) && (step + 1) % Engine::kPollEvery == 0;
+      if (look) {
+        be_.poll_record(ring_next, e->bufs().flags);
+        pending.push_back(ring_next);
+        ring_next = (ring_next + 1) % 8;
+      }
       if (!trip) {
         // Reverse-mode ghosts with the overlap on: the boundary bricks' force assembly and the ghosts' fold first, then the
         // ghosts' partial forces travel on the communication stream while the interior bricks (and the owned atoms' fold) run
@@ -361,10 +371,7 @@ public:
             if (record && thermo_host)
               be_.d2h(thermo_host + 8 * ((step + 1) / thermo_every - 1), thermo_dev_, 8 * sizeof(double));
           }
-        } else if (spec && (step + 1) % Engine::kPollEvery == 0) {
-          be_.poll_record(ring_next, e->bufs().flags);
-          pending.push_back(ring_next);
-          ring_next = (ring_next + 1) % 8;
+        } else if (look) {
           if ((int)pending.size() > Engine::kPollDepth) {
             int snap[8];
             be_.poll_wait(pending.front(), snap);
@@ -709,8 +716,13 @@ private:
     be_.d2h(&w, word, sizeof(int));
     return w;
   }
+  // A full look at the flags, taken by every rank at the same step (thermo records, the last step, a voted skin or range
+  // trip).  The three voted words are reduced once more first: the step's force kernels may have raised a capacity bit, the
+  // hard-limit bit or the range word on ONE rank after its vote, and a rank that threw or left the scatter form alone would
+  // leave the others waiting in their next collective.
   int sync_flags()
   {
+    device_allreduce(eng_->bufs().flags + kFlagMoved, 3, kDtI32, kOpMax);
     be_.sync();
     int flags[kNumFlags];
     be_.d2h(flags, eng_->bufs().flags, sizeof(flags));

@@ -17,7 +17,13 @@
 #include "engine_impl.h"
 #include "nep_scatter.h" // device-only force assembly (LDS scatter of the own pair halves)
 #include "nep_fused.h"   // device-only: angular descriptor + ANN + partial angular forces in one kernel
-#include "nep_brick.h"   // device-only: ... and the scatter-form force assembly behind them, one kernel per brick
+#ifndef NEPMI_WITH_BRICK
+#define NEPMI_WITH_BRICK 0 // 1 (make BRICK=1): also the one-force-kernel-per-brick experiment (experimental/nep_brick.h: built, parity-tested,
+                           // measured slower than the two kernels it replaces -- not part of the default library or of the JIT cores)
+#endif
+#if NEPMI_WITH_BRICK
+#include "experimental/nep_brick.h" // device-only: ... and the scatter-form force assembly behind them, one kernel per brick
+#endif
 
 namespace nepmi {
 
@@ -1203,7 +1209,7 @@ struct HipBackend {
   // [fold_lo, fold_hi] (fold_lo > fold_hi: no fold)
   template <class S>
   void launch_force_scatter(int slot, int64_t nb, int first, int64_t natoms, const WinStage& ws2, const ModelD& md, int* halo,
-                            const unsigned* fmap, int fold_rows, bool outputs, bool mask, int fold_lo, int fold_hi, const int* frz)
+                            const unsigned* fmap, int fold_rows, bool outputs, int mode, int fold_lo, int fold_hi, const int* frz)
   {
     const ForceScatterBody<S> body{ws2, md, frz, reinterpret_cast<I4*>(halo), first};
     const int64_t grid = (nb + 7) / 8 * 8;
@@ -1214,22 +1220,26 @@ struct HipBackend {
       if constexpr (S::TS > 0) {
         const ScatterLayout lay{ws2.lay.wmax};
         const size_t lds_bytes = ((size_t)lay.bytes() + 15) / 16 * 16;
-#define NEPMI_FS_LAUNCH(OUTV, MASKV)                                                                                             \
+#define NEPMI_FS_LAUNCH(OUTV, MODEV)                                                                                             \
   do {                                                                                                                           \
     if (lds_bytes > 64 * 1024)                                                                                                   \
-      NEPMI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&nepmi_force_scatter_kernel<S, OUTV, MASKV>),           \
+      NEPMI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&nepmi_force_scatter_kernel<S, OUTV, MODEV>),           \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));                         \
-    hipLaunchKernelGGL((nepmi_force_scatter_kernel<S, OUTV, MASKV>), dim3((unsigned)grid), dim3(kWinThreads), lds_bytes, stream, \
+    hipLaunchKernelGGL((nepmi_force_scatter_kernel<S, OUTV, MODEV>), dim3((unsigned)grid), dim3(kWinThreads), lds_bytes, stream, \
                        body, nb);                                                                                               \
   } while (0)
-        if (outputs && mask)
-          NEPMI_FS_LAUNCH(true, true);
+        if (outputs && mode == 2)
+          NEPMI_FS_LAUNCH(true, 2);
+        else if (outputs && mode == 1)
+          NEPMI_FS_LAUNCH(true, 1);
         else if (outputs)
-          NEPMI_FS_LAUNCH(true, false);
-        else if (mask)
-          NEPMI_FS_LAUNCH(false, true);
+          NEPMI_FS_LAUNCH(true, 0);
+        else if (mode == 2)
+          NEPMI_FS_LAUNCH(false, 2);
+        else if (mode == 1)
+          NEPMI_FS_LAUNCH(false, 1);
         else
-          NEPMI_FS_LAUNCH(false, false);
+          NEPMI_FS_LAUNCH(false, 0);
 #undef NEPMI_FS_LAUNCH
       } else {
         // many types / run-time shapes: nepmi_force_scatter_mt_kernel, four lanes per atom, one workgroup per CU
@@ -1396,6 +1406,7 @@ struct HipBackend {
 
   // One force kernel per brick behind the radial pass (nep_brick.h) + the fold.  Two timing brackets: the brick kernel in the
   // angular slot (it replaces the angular kernel and the scatter kernel), the fold in the force-assembly slot.
+#if NEPMI_WITH_BRICK
   static constexpr bool kHasBrickForce = true;
   template <class S>
   size_t brick_lds_bytes(const ModelD& md, int wmax) const
@@ -1443,6 +1454,16 @@ struct HipBackend {
         timer_stop(timing->slot[slot_fold]);
     }
   }
+#else
+  static constexpr bool kHasBrickForce = false;
+  template <class S>
+  size_t brick_lds_bytes(const ModelD&, int) const { return 0; }
+  template <class S>
+  void launch_brick_force(int, int, int64_t, int64_t, const WinStage&, const ModelD&, int*, const unsigned*, int, bool, const float*, const int*)
+  {
+  }
+#endif
+
 
   void exclusive_scan(int* data, int64_t n, int* scratch)
   {
@@ -1779,6 +1800,20 @@ extern "C" int nepmi_transport_rccl_stats(const nepmi_transport* t, int time_eve
 #if !defined(__HIP_DEVICE_COMPILE__)
 #include "capi_jit.h"
 
+static const nepmi_api* nepmi_jit_core_for_model_file(const char* path); // (defined behind the table: it checks the core's table size)
+
+static void nepmi_adopt_error(const nepmi_api* core); // (defined behind the table: it reads the core's own last error)
+
+#define NEPMI_CAPI_TRAMPOLINES
+#include "capi_dispatch.inc"
+#undef NEPMI_CAPI_TRAMPOLINES
+
+static void nepmi_adopt_error(const nepmi_api* core)
+{
+  if (core && core->nepmi_last_error)
+    g_last_error = core->nepmi_last_error();
+}
+
 // nullptr: this library (a compiled shape, a shape only the run-time-shape kernels handle, a Tersoff file, a file that does not
 // parse -- the caller's own nepmi_model_load reports that -- or NEPMI_JIT=0); else the JIT core compiled for the model's shape
 static const nepmi_api* nepmi_jit_core_for_model_file(const char* path)
@@ -1798,19 +1833,10 @@ static const nepmi_api* nepmi_jit_core_for_model_file(const char* path)
     return nullptr;
   const nepmi::jit::ShapeKey key{m.n_max_radial, m.basis_size_radial, m.n_max_angular, m.basis_size_angular, m.num_L,
                                  m.num_types <= 2 ? m.num_types : 0};
-  return nepmi::jit::core_for(key);
+  return nepmi::jit::core_for(key, (uint64_t)sizeof(nepmi_api));
 #endif
 }
 
-static void nepmi_adopt_error(const nepmi_api* core); // (defined behind the table: it reads the core's own last error)
-
-#define NEPMI_CAPI_TRAMPOLINES
-#include "capi_dispatch.inc"
-#undef NEPMI_CAPI_TRAMPOLINES
-
-static void nepmi_adopt_error(const nepmi_api* core)
-{
-  if (core && core->nepmi_last_error)
-    g_last_error = core->nepmi_last_error();
-}
+// what this library was built from (capi_jit.h: load_core checks a core against the library that loads it)
+extern "C" nepmi::jit::CoreAbi nepmi_core_abi(void) { return nepmi::jit::CoreAbi{nepmi::jit::baked_hash(), (uint64_t)sizeof(nepmi_api)}; }
 #endif // !__HIP_DEVICE_COMPILE__

@@ -1083,6 +1083,7 @@ private:
       b_.aorig2 = two ? dalloc<unsigned>((size_t)b_.MA2 * N) : nullptr;
       b_.aseg2 = two ? dalloc<int>(N) : nullptr;
       b_.use_rmask = 0;
+      b_.use_csync = 0;
     } else { // Tersoff-1989: Tersoff1989::Tersoff1989 allocations (tersoff1989.cu:141-149)
       tb_.rec = dalloc<D4>((size_t)b_.MN_ang * N);
       tb_.bb = dalloc<double>((size_t)b_.MN_ang * N);
@@ -1511,7 +1512,7 @@ private:
     if constexpr (!(B::kHasBrickForce && S::fixed && S::TS == 2)) {
       return false;
     } else {
-      if (!brick_force_ || !ang_fused_active() || b_.level || b_.use_rmask || !scatter_wanted<S>(ws2))
+      if (!brick_force_ || !ang_fused_active() || b_.level || b_.use_rmask || b_.use_csync || !scatter_wanted<S>(ws2))
         return false;
       return be_.template brick_lds_bytes<S>(md_, win_.wmax) <= B::kMaxLdsBytes;
     }
@@ -1678,6 +1679,7 @@ public:
     external_skin_ = o.external_skin_;
     force_form_ = o.force_form_;
     use_rmask_ = o.use_rmask_;
+    use_csync_ = o.use_csync_;
     ang_fused_ = o.ang_fused_;
     brick_force_ = o.brick_force_;
     loop_ctx_ = o.loop_ctx_;
@@ -1740,6 +1742,9 @@ private:
 #ifndef NEPMI_RMASK
 #define NEPMI_RMASK 1 // A/B switch (profiles/ab_variants.sh): 0 = the compact list on every step
 #endif
+#ifndef NEPMI_CSYNC
+#define NEPMI_CSYNC 1 // A/B switch: 0 = never the wave-synchronous words
+#endif
   template <class S>
   void force_kernels_shape(int phase, const int* frozen)
   {
@@ -1748,6 +1753,9 @@ private:
 #endif
     // membership mask instead of amap: the one-lane window kernels, list A within the mask's 128 bits (counted at the rebuild)
     b_.use_amask = (NEPMI_AMASK && tile_ok_ && win_lanes() == 1 && max_ang_rebuild_ <= 128) ? 1 : 0;
+    // test hook (option "scatter_guard_delay"): a narrowed guard band that starts to apply at the n-th force assembly from now
+    if (guard_delay_ > 0 && (phase == kPhaseAll || phase == kPhaseBoundary || phase == kPhaseAfterRadial) && --guard_delay_ == 0)
+      set_scatter_guard(guard_delayed_, -1.0);
     const WinStage ws{box_, b_, win_};
     if (phase == kPhaseRecords) { // diagnostics: materialise the pair records of the current positions
       be_.template launch<64>(kSlotMisc, N_, RadialDescBody<S>{box_, md_, b_, 1});
@@ -1770,15 +1778,24 @@ private:
                        ? 1
                        : 0;
       last_mask_form_ = b_.use_rmask != 0;
+      // Wave-synchronous words (nep_window.h: SyncFifo): under the same conditions, whenever the mask form was not asked for
+      b_.use_csync = (NEPMI_CSYNC && use_csync_ && !b_.use_rmask && S::TS > 0 && win2 && b_.cword && loop_ctx_ && b_.MN_cw < 256 &&
+                      scatter_wanted<S>(wsq))
+                       ? 1
+                       : 0;
+      last_sync_form_ = b_.use_csync != 0;
     } else {
       b_.use_rmask = 0; // (before the kernel bodies below copy Bufs)
+      b_.use_csync = 0;
     }
     WinLayout lay2 = win_;
     lay2.compact = 1;
     const WinStage ws2{box_, b_, lay2};
     B& rbe = radial_side_ ? *radial_side_ : be_; // (force_kernels_on: the boundary bricks on the communication stream)
     auto radial = [&](int64_t nb, int first) {
-      if (win2)
+      if (win2 && b_.use_csync)
+        rbe.launch_win2(kSlotRadial, nb, RadialWin2Body<S, (S::TS > 0 ? 1 : 0)>{ws2, md_, first, frozen});
+      else if (win2)
         rbe.launch_win2(kSlotRadial, nb, RadialWin2Body<S>{ws2, md_, first, frozen});
       else if (lanes == 4)
         rbe.launch_win_split(kSlotRadial, nb, RadialWinSplitBody<S, 4>{ws, md_, first, frozen});
@@ -1789,6 +1806,7 @@ private:
     };
     if (phase == kPhaseRadialOnly) { // exact_virials: the compact list of the current positions (the masks were written instead)
       b_.use_rmask = 0;
+      b_.use_csync = 0;
       if (tile_ok_)
         radial(num_bricks_, -1);
       ccode_valid_ = true;
@@ -1812,7 +1830,7 @@ private:
       radial(num_bricks_, -1);
     else
       be_.template launch<64>(kSlotRadial, N_, RadialDescBody<S>{box_, md_, b_, 1});
-    ccode_valid_ = b_.use_rmask == 0;
+    ccode_valid_ = b_.use_rmask == 0 && b_.use_csync == 0;
     b_.skip_atab = (win2 && fpj_wanted<S>(ws2)) ? 1 : 0; // the FPJ force assembly needs no radial table from the ANN kernel
     last_ang_fused_ = false;
     last_brick_ = false;
@@ -1917,6 +1935,8 @@ private:
     return fpj_wanted<S>(ws2) &&
            25 * (size_t)win_.wmax + 4 * (size_t)model_.num_types * model_.num_types * ctab_block(md_.NR, md_.KR, true) <= B::kMaxLdsBytes;
   }
+  // how this step's radial pass left the pairs inside the cutoff (nep_scatter.h: MODE)
+  int list_mode() const { return b_.use_csync ? 2 : (b_.use_rmask ? 1 : 0); }
   template <class S>
   bool scatter_form(const WinStage& ws2, const int* frozen)
   {
@@ -1926,12 +1946,12 @@ private:
       // a decomposed run with reverse-mode ghosts: the bricks whose window holds a ghost first, then the ghosts' fold -- their
       // partial forces can travel while force_assembly_rest() runs the interior bricks and the owned atoms' fold
       be_.template launch_force_scatter<S>(kSlotForce, num_boundary_bricks_, (int)(num_bricks_ - num_boundary_bricks_), N_, ws2, md_,
-                                           halo_, fmap_, fold_rows_, step_outputs_, b_.use_rmask != 0, 0, 1, frozen);
+                                           halo_, fmap_, fold_rows_, step_outputs_, list_mode(), 0, 1, frozen);
       assembly_pending_ = true;
       pending_outputs_ = step_outputs_;
     } else {
       be_.template launch_force_scatter<S>(kSlotForce, num_bricks_, -1, N_, ws2, md_, halo_, fmap_, fold_rows_, step_outputs_,
-                                           b_.use_rmask != 0, 0, 2, frozen);
+                                           list_mode(), 0, 2, frozen);
     }
     if (!step_outputs_)
       outputs_stale_ = true;
@@ -1945,7 +1965,7 @@ private:
     lay2.compact = 1;
     const WinStage ws2{box_, b_, lay2};
     be_.template launch_force_scatter<S>(kSlotForce, num_bricks_ - num_boundary_bricks_, 0, N_, ws2, md_, halo_, fmap_, fold_rows_,
-                                         pending_outputs_, b_.use_rmask != 0, 2, 2, frozen);
+                                         pending_outputs_, list_mode(), 2, 2, frozen);
   }
 
 public:
@@ -1970,10 +1990,17 @@ public:
   // 1: scatter-form steps of the run loops keep the per-step radial list as inside bits over the packed Verlet words
   // (Bufs::rmaskB) instead of compacting it; 0 (default): the compact list on every step.  Identical results, bit for bit.
   void set_radial_mask(bool on) { use_rmask_ = on; }
+  // 1 (default): scatter-form steps of the run loops keep the per-step radial list as wave-synchronous words (SyncFifo); 0: slot-major compact list
+  void set_radial_sync(bool on) { use_csync_ = on; }
   // Guard band of the scatter form (nepmi_engine_set_scatter_guard): a pair half beyond `limit` eV/A (default 64; a net force
   // component beyond twice that) hands the force assembly over to the gather form.  Tests lower it so that ordinary forces trip it.
+  // limit < 0 / hard_factor < 0: that one stays as it is
   void set_scatter_guard(double limit, double hard_factor = 4.0)
   {
+    if (limit < 0.0)
+      limit = b_.scatter_limit;
+    if (hard_factor < 0.0)
+      hard_factor = hard_factor_;
     if (!(limit > 0.0) || limit > 64.0)
       limit = 64.0;
     if (!(hard_factor >= 1.0) || hard_factor * limit > 256.0)
@@ -1985,12 +2012,31 @@ public:
       set_flagged_steps_stand(true);
   }
   double scatter_guard() const { return b_.scatter_limit; }
+  // test hook: `limit` becomes the guard band at the n-th force assembly from now (n <= 0: at once) -- to trip the band at a
+  // chosen step of a run loop (tests/test_dist_inproc.py: on a step the host looks at)
+  void set_scatter_guard_delayed(double limit, int n)
+  {
+    if (n <= 0) {
+      set_scatter_guard(limit, -1.0);
+      return;
+    }
+    guard_delayed_ = limit;
+    guard_delay_ = n;
+  }
+  void set_guard_delay(int n) { guard_delay_next_ = n > 0 ? n : 0; }
+  int take_guard_delay()
+  {
+    const int n = guard_delay_next_;
+    guard_delay_next_ = 0;
+    return n;
+  }
   // Decomposed runs: a flagged step stands (every rank leaves the scatter form together, a few steps later, when the flag has
   // travelled with the skin vote), so a value beyond four times the guard band met meanwhile is an error instead of a wrap
   void set_flagged_steps_stand(bool on)
   {
     b_.scatter_hard = on ? (float)(hard_factor_ * b_.scatter_limit) : 0.0f;
-    b_.fold_hard = on ? (int)(hard_factor_ * b_.scatter_limit * 4194304.0) : 0;
+    // (the net-force guard is twice the band: the hard limit on the net never sits below the hand-over it backs up)
+    b_.fold_hard = on ? (int)((hard_factor_ > 2.0 ? hard_factor_ : 2.0) * b_.scatter_limit * 4194304.0) : 0;
   }
   bool scatter_enabled() const { return !scatter_disabled_; }
   // a flagged evaluation that is being repeated in the gather form does not stand: its hard-limit bit goes with it
@@ -2015,6 +2061,7 @@ public:
   void set_angular_fused(bool on) { ang_fused_ = on; }
   // 1: ... and the scatter-form force assembly in the same kernel, one workgroup per brick (nep_brick.h); 0 (default)
   void set_brick_force(bool on) { brick_force_ = on; }
+  static constexpr bool has_brick_force() { return B::kHasBrickForce; }
   // the callers whose steps need forces, energies and the TOTAL virial only (run loops; the decomposed driver)
   void set_loop_context(bool on) { loop_ctx_ = on; }
   // Run loops: does the NEXT force evaluation have to leave per-atom energies and virials (a thermo record, a thermostat that
@@ -2135,7 +2182,9 @@ public:
       s += (shape_ != 0 && model_.n_max_angular + 1 >= 7) ? " angular_force=lane_pairs" : " angular_force=one_lane";
       s += recompute_s() ? " angular_sums=recomputed" : " angular_sums=stored";
     }
-    s += (last_scatter_form_ && last_mask_form_) ? " radial_list=inside_bits_over_the_verlet_words" : " radial_list=compacted";
+    s += (last_scatter_form_ && last_mask_form_)   ? " radial_list=inside_bits_over_the_verlet_words"
+         : (last_scatter_form_ && last_sync_form_) ? " radial_list=wave_synchronous_words"
+                                                   : " radial_list=compacted";
     s += last_scatter_form_ ? " force_assembly=lds_scatter_of_own_halves(fixed_point)+fold" :
          last_rows_form_ ? " force_assembly=table_rows_in_lds"
                          : (last_fpj_form_ ? " force_assembly=neighbour_half_from_fp_rows" : " force_assembly=table_rows_gathered");
@@ -2209,6 +2258,11 @@ private:
   bool use_rmask_ = false;       // set_radial_mask (off: on PbTe 1 M atoms the radial pass gains what the force assembly's lockstep
                                  // walk over all candidates loses -- profiles/r4q_ab_mask.txt)
   bool last_mask_form_ = false;
+  bool last_sync_form_ = false;
+  int guard_delay_ = 0;          // set_scatter_guard_delayed
+  int guard_delay_next_ = 0;
+  double guard_delayed_ = 64.0;
+  bool use_csync_ = true;
   bool ccode_valid_ = true;      // the compact radial list of the last force evaluation exists (else: the masks, Bufs::rmaskB)
   bool step_outputs_ = true;     // set_step_outputs
   int assembly_part_ = 0;        // set_assembly_part

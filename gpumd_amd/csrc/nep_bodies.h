@@ -216,6 +216,8 @@ struct Bufs {
   int* aseg2;
   int MA2;
   int use_rmask; // 1: this step's radial pass writes the masks instead of ccode
+  int use_csync; // 1: this step's radial pass writes the list as wave-synchronous words into cword (nep_window.h: SyncFifo);
+                 //    nn_t0[k] = words of stream 0 | words of stream 1 << 8
   float scatter_limit; // guard band of the scatter-form assembly per pair half, eV/A (nep_scatter.h: kScatterFlagLimit)
   int fold_guard;      // ... and per component of an atom's net force, fixed point (kFoldGuard)
   // Decomposed runs (a flagged step stands until every rank has seen the vote): a pair half / net component beyond these is

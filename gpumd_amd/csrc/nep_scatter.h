@@ -124,11 +124,14 @@ __device__ __forceinline__ int to_fixed(float v)
 // step of a run loop, a per-call evaluation; the other steps of a run loop need forces only (the reference computes and
 // stores all thirteen per-atom outputs every step, potential.cu:170-297; find_thermo reads them at the dump_thermo interval
 // only): no virial arithmetic, no pair-vector loads in the angular part, no 80 bytes of stores per atom.
-template <class S, bool OUT, bool MASK>
+// MODE: how this step's radial pass left the list of pairs inside the cutoff -- 0 the slot-major compact list (Bufs::ccode),
+// 1 inside bits over the packed Verlet words (Bufs::rmaskA / rmaskB), 2 wave-synchronous words (SyncFifo, Bufs::cword)
+template <class S, bool OUT, int MODE>
 __device__ __forceinline__ void force_scatter_atom(const ForceScatterBody<S>& B, const int64_t brick, const int64_t k,
                                                    NEPMI_LDS(char)* lds, const ScatterLayout lay)
 {
   static_assert(S::TS > 0, "type-pure list segments (one or two types with register-resident rows)");
+  constexpr bool MASK = MODE != 0; // places of weight zero exist (and touch the LDS neither for a position nor for the reaction)
   const Bufs& b = B.st.b;
   const ModelD& m = B.m;
   const int64_t N = b.N;
@@ -293,7 +296,33 @@ __device__ __forceinline__ void force_scatter_atom(const ForceScatterBody<S>& B,
     }
   };
 
-  if constexpr (!MASK) {
+  if constexpr (MODE == 2) {
+    // Wave-synchronous words: stream t = rows [t MN_cw, t MN_cw + rows_t) of Bufs::cword, rows_t the same on every lane of the
+    // wavefront that wrote them (RadialWin2Body<S, 1>, the same atoms on the same lanes as here); a place holding the
+    // sentinel slot is padding
+    const int rw = b.nn_t0[k];
+    const unsigned sent = (unsigned)b.wsent;
+    auto wgt = [&](unsigned slot) __attribute__((always_inline)) -> float { return slot != sent ? 1.0f : 0.0f; };
+#pragma unroll
+    for (int t = 0; t < TSM; ++t) {
+      const int rows = (rw >> (8 * t)) & 255;
+      Rows R;
+      load_rows(t, R);
+      const U2w* __restrict__ wq = reinterpret_cast<const U2w*>(b.cword) + k + (int64_t)t * b.MN_cw * N;
+      // requested two rows ahead of the arithmetic, unconditionally (the last rows are requested again: a conditional
+      // load would put a full wait in front of every pair, see v3 / v4 in DESIGN section 5)
+      const int last = rows > 0 ? rows - 1 : 0;
+      U2w cur = wq[0], nxt = wq[(int64_t)(1 < last ? 1 : last) * N];
+      for (int r = 0; r < (NEPMI_FS_ABL == 2 ? 0 : rows); ++r) {
+        const U2w c = cur;
+        cur = nxt;
+        nxt = wq[(int64_t)(r + 2 < last ? r + 2 : last) * N];
+        const unsigned s0 = c.lo & 0xFFFFu, s1 = c.lo >> 16, s2 = c.hi & 0xFFFFu, s3 = c.hi >> 16;
+        two_pairs(s0, s1, wgt(s0), wgt(s1), R.A, R.B, R.SA, R.rc, R.ri);
+        two_pairs(s2, s3, wgt(s2), wgt(s3), R.A, R.B, R.SA, R.rc, R.ri);
+      }
+    }
+  } else if constexpr (!MASK) {
     // type-pure segments of the compact list (Bufs::ccode; front: neighbours of type 0, back: of type 1)
     const int n0 = b.nn_t0[k] < nrad ? b.nn_t0[k] : nrad;
 #pragma unroll
@@ -522,7 +551,7 @@ __device__ __forceinline__ void force_scatter_atom(const ForceScatterBody<S>& B,
 #ifndef NEPMI_FS_WAVES
 #define NEPMI_FS_WAVES 3
 #endif
-template <class S, bool OUT, bool MASK>
+template <class S, bool OUT, int MODE>
 __global__ void __launch_bounds__(kWinThreads) __attribute__((amdgpu_waves_per_eu(NEPMI_FS_WAVES)))
 nepmi_force_scatter_kernel(const ForceScatterBody<S> body, const int64_t nbricks)
 {
@@ -578,7 +607,7 @@ nepmi_force_scatter_kernel(const ForceScatterBody<S> body, const int64_t nbricks
   int64_t a0, a1;
   body.st.brick_range(brick, a0, a1);
   for (int64_t k = a0 + tid; k < a1; k += kWinThreads)
-    force_scatter_atom<S, OUT, MASK>(body, brick, k, lds, lay);
+    force_scatter_atom<S, OUT, MODE>(body, brick, k, lds, lay);
   __syncthreads();
   {
     // the window sums, one 16-byte row per slot: what ForceFoldBody gathers

@@ -810,7 +810,66 @@ struct alignas(8) U2w { // four 16-bit LDS slots
   unsigned lo, hi;
 };
 
-template <class S>
+// The compact radial list as WAVE-SYNCHRONOUS words (RadialWin2Body<S, 1> writes them, the scatter-form force assembly walks
+// them).  The slot-major compact list (Bufs::ccode) costs the radial pass a third of its time although it is 130 bytes per
+// atom: the lanes of a wavefront accept different candidates, so their list cursors drift apart (like the square root of the
+// number of candidates), every 2-byte store instruction touches half a dozen partially written lines, and a store
+// instruction occupies the address unit the same with one lane as with 64 (profiles/r4m_ab_radial_stores.txt,
+// r4ad_ab_radial_push.txt: 0.63 GB of HBM-side write traffic for 0.27 GB of list).  Here an accepted slot waits in a queue of
+// eight 16-bit entries in the lane's registers; when any lane of the wavefront holds more than four after a word of
+// candidates, EVERY lane stores its four oldest entries as one 8-byte word -- row r of the stream, r the same on all lanes,
+// 512 contiguous bytes per wavefront -- a lane with fewer than four fills the word with the sentinel slot and starts again from
+// an empty queue.  The consumer is one lane per atom in lockstep too: it walks max-over-the-wavefront entries whatever the
+// layout, and the padded stream has exactly that many rows (simulated and measured: rows = ceil(longest list / 4) for the
+// two-type streams of ~11 Verlet words, + 4 % for 22), so the padding costs it nothing.  A fifth of the store instructions
+// of the 2-byte list, every one of them whole lines.  The ORDER of the entries inside an atom's list is not the Verlet order
+// any more where a lane padded; nothing downstream depends on it (integer accumulators; nepmi_neighbors_export reads the
+// pair records).
+struct SyncFifo {
+  unsigned f0, f1, f2, f3; // entries 0 (oldest) .. 7 (newest): two per register; the p newest are waiting
+  int p, rows;
+  NEPMI_HD void init()
+  {
+    f0 = f1 = f2 = f3 = 0u;
+    p = 0;
+    rows = 0;
+  }
+  static NEPMI_HD unsigned funnel16(unsigned hi, unsigned lo) // (hi:lo) >> 16
+  {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbit(hi, lo, 16u);
+#else
+    return (lo >> 16) | (hi << 16);
+#endif
+  }
+  NEPMI_HD void push(unsigned slot) // the queue moves down by one entry, the new one enters at the top: four v_alignbit_b32
+  {
+    f0 = funnel16(f1, f0);
+    f1 = funnel16(f2, f1);
+    f2 = funnel16(f3, f2);
+    f3 = funnel16(slot, f3);
+    ++p;
+  }
+  // the four oldest waiting entries as one word (fewer than four: padded with the sentinel, and the queue is empty afterwards)
+  NEPMI_HD unsigned long long pop_word(unsigned long long sent64)
+  {
+    const int s = 8 - p; // place of the oldest waiting entry
+    const unsigned long long lo01 = ((unsigned long long)f1 << 32) | f0, hi23 = ((unsigned long long)f3 << 32) | f2;
+    const unsigned long long lo = (s & 4) ? hi23 : lo01, hi = (s & 4) ? 0ull : hi23;
+    const int sh = 16 * (s & 3);
+    unsigned long long w = sh ? ((lo >> sh) | (hi << (64 - sh))) : lo;
+    if (p < 4) {
+      const unsigned long long keep = (1ull << (16 * p)) - 1ull; // (p = 0: nothing is kept -- s = 8 read entries that have left)
+      w = (w & keep) | (sent64 & ~keep);
+      p = 0;
+    } else {
+      p -= 4;
+    }
+    return w;
+  }
+};
+
+template <class S, int SYNC = 0>
 struct RadialWin2Body {
   WinStage st;
   ModelD m;
@@ -925,7 +984,42 @@ struct RadialWin2Body {
     U2w* __restrict__ cword = reinterpret_cast<U2w*>(b.cword) + k;
     unsigned long long accf = 0ull, accb = 0ull;
     unsigned mcur = 0u; // the mask word being filled (Bufs::rmaskA / rmaskB)
+    // SYNC: the compact list as WAVE-SYNCHRONOUS words (see SyncFifo above): the accepted slots wait in the lane's queue and
+    // every lane of the wavefront stores one 8-byte word of four at the same time
+    SyncFifo q0, q1;
+    q0.init();
+    q1.init();
+    U2w* __restrict__ sync0 = cword;
+    U2w* __restrict__ sync1 = cword + (int64_t)b.MN_cw * N;
+    const unsigned long long sent64 = 0x0001000100010001ull * (unsigned long long)(unsigned)b.wsent;
+    auto sync_emit = [&](SyncFifo& f, U2w* __restrict__& at) __attribute__((always_inline)) {
+      const unsigned long long w = f.pop_word(sent64);
+      if (f.rows < b.MN_cw) {
+        U2w v;
+        v.lo = (unsigned)w;
+        v.hi = (unsigned)(w >> 32);
+        *at = v;
+        at += N;
+      }
+      ++f.rows;
+    };
+    // after a word of candidates: no lane may enter the next one with more than four entries waiting
+    auto sync_check = [&]() __attribute__((always_inline)) {
+      if (SYNC) {
+        if (NEPMI_WAVE_ANY(q0.p > 4))
+          sync_emit(q0, sync0);
+        if (S::TS == 2 && NEPMI_WAVE_ANY(q1.p > 4))
+          sync_emit(q1, sync1);
+      }
+    };
     auto push_front = [&](const Cand& c, const int bit) __attribute__((always_inline)) {
+      if (SYNC) {
+        if (c.inside) {
+          q0.push((unsigned)c.slot);
+          ++cnt;
+        }
+        return;
+      }
       if (b.use_rmask) {
         mcur |= c.inside ? (1u << bit) : 0u;
         cnt += c.inside ? 1 : 0;
@@ -952,6 +1046,13 @@ struct RadialWin2Body {
       }
     };
     auto push_back = [&](const Cand& c, const int bit) __attribute__((always_inline)) {
+      if (SYNC) {
+        if (c.inside) {
+          q1.push((unsigned)c.slot);
+          ++cnt1;
+        }
+        return;
+      }
       if (b.use_rmask) {
         mcur |= c.inside ? (1u << bit) : 0u;
         cnt1 += c.inside ? 1 : 0;
@@ -1147,11 +1248,12 @@ struct RadialWin2Body {
             accumulate1(c[1]);
           }
         }
-        if (b.use_rmask && ((w & 7) == 7 || w == wa - 1)) {
+        if (!SYNC && b.use_rmask && ((w & 7) == 7 || w == wa - 1)) {
           if ((w >> 3) < b.MAW)
             b.rmaskA[(int64_t)(w >> 3) * N + k] = mcur;
           mcur = 0u;
         }
+        sync_check();
       }
     }
     if (b.use_amask) {
@@ -1210,11 +1312,12 @@ struct RadialWin2Body {
               SS[kk] = SS[kk] + fn[kk];
           }
         }
-        if (b.use_rmask && ((p & 3) == 3 || p == wb - 1)) {
+        if (!SYNC && b.use_rmask && ((p & 3) == 3 || p == wb - 1)) {
           if ((p >> 2) < b.MBW)
             b.rmaskB[(int64_t)(p >> 2) * N + k] = mcur;
           mcur = 0u;
         }
+        sync_check();
       }
     } else {
       U2w w1 = load_word(wa, wa + wb), w2 = load_word(wa + 1, wa + wb);
@@ -1236,11 +1339,12 @@ struct RadialWin2Body {
 #pragma unroll
         for (int u = 0; u < 4; ++u)
           push_front(c[u], 4 * (w & 7) + u);
-        if (b.use_rmask && ((w & 7) == 7 || w == wb - 1)) {
+        if (!SYNC && b.use_rmask && ((w & 7) == 7 || w == wb - 1)) {
           if ((w >> 3) < b.MBW)
             b.rmaskB[(int64_t)(w >> 3) * N + k] = mcur;
           mcur = 0u;
         }
+        sync_check();
         if (S::TS > 0) {
 #pragma unroll
           for (int u = 0; u < 4; u += 2) {
@@ -1259,12 +1363,23 @@ struct RadialWin2Body {
     }
 
     flush_words();
-    if (ca > b.MN_acomp || cnt + cnt1 > b.MN_rad) {
+    if (SYNC) { // what still waits leaves as padded words: again every lane of the wavefront at once
+      while (NEPMI_WAVE_ANY(q0.p > 0))
+        sync_emit(q0, sync0);
+      while (S::TS == 2 && NEPMI_WAVE_ANY(q1.p > 0))
+        sync_emit(q1, sync1);
+    }
+    if (ca > b.MN_acomp || (SYNC ? (q0.rows > b.MN_cw || q1.rows > b.MN_cw) : cnt + cnt1 > b.MN_rad)) {
       NEPMI_ATOMIC_OR(&b.flags[kFlagOverflow], 4);
       ca = ca > b.MN_acomp ? b.MN_acomp : ca;
     }
     b.nn_rad[k] = cnt + cnt1;
-    b.nn_t0[k] = cnt;
+    if (SYNC) {
+      const int r0 = q0.rows < b.MN_cw ? q0.rows : b.MN_cw, r1 = q1.rows < b.MN_cw ? q1.rows : b.MN_cw;
+      b.nn_t0[k] = r0 | (r1 << 8); // words per stream (the same on every lane of the wavefront)
+    } else {
+      b.nn_t0[k] = cnt;
+    }
     b.nn_angstep[k] = ca;
     if (S::TS > 0) {
       float Ssum[TSM][S::KRM + 1];

@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.dirname(HERE)
 FILES = ["engine.hip", "nep_model.cpp", "transport_tcp.cpp", "engine_impl.h", "capi_impl.h", "capi_jit.h", "capi_dispatch.inc",
          "dist_bodies.h", "dist_impl.h", "dist_capi_impl.h", "nep_dev.h", "nep_bodies.h", "nep_window.h", "nep_scatter.h",
-         "nep_fused.h", "nep_brick.h", "nep_highl.h", "nep_highl_tables.h", "nep_invariants_extra.h", "nep_md.h", "nep_model.h", "tersoff_bodies.h",
+         "nep_fused.h", "nep_highl.h", "nep_highl_tables.h", "nep_invariants_extra.h", "nep_md.h", "nep_model.h", "tersoff_bodies.h",
          "../../include/nepmi.h"]  # = capi_jit.h: source_files()
 
 
@@ -58,6 +58,9 @@ def main():
     if sys.argv[1] == "--refresh":
         refresh()
         return
+    if sys.argv[1] == "--hash":  # what the Makefile bakes into libnepmi.so (-DNEPMI_SRC_HASH): capi_jit.h
+        print(source_hash())
+        return
     if sys.argv[1] == "--model":
         shape = shape_of_model(sys.argv[2])
     else:
@@ -74,7 +77,7 @@ def main():
             os.remove(os.path.join(out_dir, f))
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-pass-failed", "-Wl,-Bsymbolic", "-Wl,-rpath,/opt/rocm/lib",
-           "-DNEPMI_JIT_CORE", "-DNEPMI_JIT_SHAPE=" + ",".join(str(v) for v in shape), "-o", out,
+           "-DNEPMI_JIT_CORE", "-DNEPMI_JIT_SHAPE=" + ",".join(str(v) for v in shape), "-DNEPMI_SRC_HASH=0x%sull" % source_hash(), "-o", out,
            os.path.join(SRC, "engine.hip"), os.path.join(SRC, "nep_model.cpp"), os.path.join(SRC, "transport_tcp.cpp"), "-ldl"]
     subprocess.run(cmd, check=True)
     print(out)

@@ -294,15 +294,19 @@ class NEP:
         """False/0 off, True/1 every kernel, 2 the force-assembly kernel only (see include/nepmi.h)."""
         self._ck(self.lib.nepmi_engine_set_timing(self.handle, int(on)))
 
+    def set_option(self, name, value):
+        """experiment / test switches by name (nepmi_engine_set_option; include/nepmi.h lists them)"""
+        self._ck(self.lib.nepmi_engine_set_option(self.handle, name.encode(), float(value)))
+
     def set_tiles(self, mode=-1):
         """0/False: no LDS-window kernels; 1: radial pass only; 2/True: radial pass + force assembly;
         -1: chosen by the engine (times modes 2 and 1 once)."""
         mode = 2 if mode is True else 0 if mode is False else int(mode)
-        self._ck(self.lib.nepmi_engine_set_tiles(self.handle, mode))
+        self.set_option("tiles", mode)
 
     def set_win_lanes(self, lanes=0):
         """lanes per atom of the LDS-window kernels: 0 = by the number of bricks, or 1 / 2 / 4"""
-        self._ck(self.lib.nepmi_engine_set_win_lanes(self.handle, int(lanes)))
+        self.set_option("win_lanes", int(lanes))
 
     def set_force_form(self, mode=-1):
         """force assembly: -1 run loops scatter / per-call gather (default), 0 gather everywhere, 1 scatter wherever it applies
@@ -311,12 +315,18 @@ class NEP:
 
     def set_radial_mask(self, on=True):
         """scatter-form loop steps: inside bits over the packed Verlet words instead of a compacted radial list
-        (nepmi_engine_set_radial_mask)"""
-        self._ck(self.lib.nepmi_engine_set_radial_mask(self.handle, 1 if on else 0))
+        (option "radial_mask")"""
+        self.set_option("radial_mask", 1 if on else 0)
+
+    def set_radial_sync(self, on=True):
+        """scatter-form loop steps: the radial list as wave-synchronous words (default) or the slot-major compact list
+        (option "radial_sync")"""
+        self.set_option("radial_sync", 1 if on else 0)
 
     def set_scatter_guard(self, ev_per_angstrom=64.0, hard_factor=0.0):
-        """guard band of the scatter-form force assembly per pair half (test hook: nepmi_engine_set_scatter_guard)"""
-        self._ck(self.lib.nepmi_engine_set_scatter_guard(self.handle, float(ev_per_angstrom), float(hard_factor)))
+        """guard band of the scatter-form force assembly per pair half (test hook: options "scatter_guard", "scatter_guard_hard")"""
+        self.set_option("scatter_guard", float(ev_per_angstrom))
+        self.set_option("scatter_guard_hard", float(hard_factor))
 
     def set_virial_mode(self, mode=0):
         """per-call evaluations: 0 per-atom virials in the reference's attribution (default), 1 only the total has to be right
@@ -325,13 +335,13 @@ class NEP:
 
     def set_brick_force(self, on=True):
         """fused angular kernel + scatter-form force assembly as ONE kernel per brick (default where it applies) or separately
-        (nepmi_engine_set_brick_force)"""
-        self._ck(self.lib.nepmi_engine_set_brick_force(self.handle, 1 if on else 0))
+        (option "brick_force")"""
+        self.set_option("brick_force", 1 if on else 0)
 
     def set_angular_fused(self, on=True):
         """angular descriptor + ANN + partial angular forces in one kernel (default) or as separate kernels
-        (nepmi_engine_set_angular_fused)"""
-        self._ck(self.lib.nepmi_engine_set_angular_fused(self.handle, 1 if on else 0))
+        (option "angular_fused")"""
+        self.set_option("angular_fused", 1 if on else 0)
 
     def describe(self):
         """the kernel forms the last force evaluation ran (counted rules of the engine, as text)"""
@@ -344,16 +354,16 @@ class NEP:
 
     def set_stepwise_loops(self, on=True):
         """test hook: run_nvt_lan / run_nvt_bao as the stepwise sequence on the caller's arrays"""
-        self._ck(self.lib.nepmi_engine_set_stepwise_loops(self.handle, int(bool(on))))
+        self.set_option("stepwise_loops", int(bool(on)))
 
     def set_win_static(self, on=True):
         """static window layout of the one-lane window kernels (default on); False = the scanned layout"""
-        self._ck(self.lib.nepmi_engine_set_win_static(self.handle, int(bool(on))))
+        self.set_option("win_static", int(bool(on)))
 
     def set_mfma(self, on=True):
         """False / 0: per-atom ANN kernel; True / 1 (default): descriptor + ANN fused where the shape allows it, else the
         matrix-core ANN kernel; 2: the matrix-core kernel wherever it applies (no fusion)"""
-        self._ck(self.lib.nepmi_engine_set_mfma(self.handle, int(on)))
+        self.set_option("mfma", int(on))
 
     def set_temperature(self, temperature):
         """The `temperature` argument of NEP::compute(temperature, ...) for nep4[_zbl]_temperature models (no effect on
@@ -361,7 +371,7 @@ class NEP:
         self._ck(self.lib.nepmi_engine_set_temperature(self.handle, float(temperature)))
 
     def set_angular_recompute(self, mode=-1):
-        self._ck(self.lib.nepmi_engine_set_angular_recompute(self.handle, int(mode)))
+        self.set_option("angular_recompute", int(mode))
 
     def set_generic(self, on=True):
-        self._ck(self.lib.nepmi_engine_set_generic(self.handle, 1 if on else 0))
+        self.set_option("generic", 1 if on else 0)

@@ -436,19 +436,6 @@ int nepmi_engine_describe(nepmi_engine* e, char* buf, int len);
  * kernel of slot k of nepmi_stats::ms_kernel_sum (what bench.py keeps inside its timed region for the roofline figure: the
  * slot of the step's longest kernel); 0: off. */
 int nepmi_engine_set_timing(nepmi_engine* e, int on);
-/* Force the run-time-shaped (generic) kernel instantiation instead of a model-shape-specialised
- * one; used by the parity tests to cover both code paths with one model. */
-int nepmi_engine_set_generic(nepmi_engine* e, int on);
-/* LDS-window kernels: 0 = none (plain gather kernel for the radial pass, pair records for the force
- * assembly); anything else (the default) = the radial pass and the force assembly both work from the LDS position
- * window.  The choice is a rule, never a timing: the same input always runs the same kernels.  The window
- * kernels are dropped automatically when a periodic direction has fewer than 8 cells, a brick's window does not
- * fit LDS or an atom sits far outside the box along an open direction.  Both give identical lists and forces to
- * f32 rounding. */
-int nepmi_engine_set_tiles(nepmi_engine* e, int on);
-/* Lanes per atom of the LDS-window kernels: 0 (default) = by the number of bricks (4 up to 256 bricks, 2 up to 512,
- * else 1: small systems are bound by the latency of one workgroup); 1, 2, 4 pin it. */
-int nepmi_engine_set_win_lanes(nepmi_engine* e, int lanes);
 /* Form of the force assembly (find_force_radial + gpu_find_force_many_body: nep.cu:661-772, potential.cu:170-297).
  *   gather  : every lane evaluates both halves of its pairs, f12 - f21, the partner's half from rows gathered from the
  *             partner -- per-atom virials in the reference's attribution (W_i = sum_j r_ij (x) f21);
@@ -479,52 +466,66 @@ int nepmi_engine_set_force_form(nepmi_engine* e, int mode);
  * attribution -- the same sum, the same forces and energies to f32 rounding, a third less time per call at a million atoms
  * (bench.py: pbte_per_call_dropin / _totals).  A host sets 1 while no consumer of per-atom virials is active. */
 int nepmi_engine_set_virial_mode(nepmi_engine* e, int mode);
-/* Test hook: the guard band of the scatter form per pair half in eV/A (default and maximum 64; the net-force guard is twice the
- * value), so that the hand-over can be exercised with ordinary forces; hard_factor: the hard limit of decomposed runs as a
- * multiple of the band (<= 0: the default 4; the limit never exceeds 256 eV/A). */
-int nepmi_engine_set_scatter_guard(nepmi_engine* e, double ev_per_angstrom, double hard_factor);
-/* The per-step radial list of the scatter-form steps of the run loops (find_neighbor_list_large_box, nep.cu:436-486, is what it
- * replaces): on = 1: one inside bit per candidate of the packed Verlet words, which the force assembly walks with the bits as
- * weights -- no compacted list is written (a conditional 2-byte store per pair and its bookkeeping: a third of the radial
- * pass's time); 0 (default): the compacted list on every step.  Same pairs, same per-pair arithmetic: identical trajectories
- * bit for bit (tests/test_gpu_parity.py).  Measured on PbTe 1 M atoms the radial pass gains 0.07 ms and the force assembly,
- * which then evaluates the 24 % of the candidates outside the cutoff in lockstep, loses as much (profiles/r4q_ab_mask.txt);
- * carbon gains 2 %.  One or two atom types; the compacted list is rebuilt on demand when per-atom virials leave the engine. */
-int nepmi_engine_set_radial_mask(nepmi_engine* e, int on);
-/* Angular descriptor, per-atom ANN and partial angular forces (the angular half of find_descriptor, nep.cu:549-640;
- * apply_ann_one_layer, nep_utilities.cuh:169-194; find_partial_force_angular, nep.cu:774-861; find_force_ZBL, nep.cu:863-975) in
- * ONE kernel with two lanes per atom: on = 1 (default) wherever the descriptor + ANN fusion applies (compiled shapes, at most 4
- * types, fewer than 9 angular channels) -- the sums s_{n,lm} stay in the registers across the ANN and become the adjoint table in
- * place, where the separate kernels evaluate them twice; 0: the separate kernels.  Same results up to the summation order of
- * the ANN's dot products (tests/test_gpu_parity.py). */
-int nepmi_engine_set_angular_fused(nepmi_engine* e, int on);
-/* ... and the scatter-form force assembly (find_force_radial, nep.cu:661-772; gpu_find_force_many_body, potential.cu:170-297) in
- * the SAME kernel, one 512-thread workgroup per brick behind the radial pass: on = 1 where the fused angular kernel and the
- * scatter form both apply, on shapes with two register-resident atom types, in single-domain engines; the partial forces and
- * the per-atom radial table then never reach HBM (the virial-only pass of the gather form runs the separate angular kernel
- * first when per-atom virials leave the engine).  0 (default): the separate kernels -- measured faster on MI355X (PbTe 1 M atoms:
- * 0.44 + 0.25 ms against 0.95 ms; gpumd_amd/csrc/nep_brick.h says why).  Same results to FP32 rounding. */
-int nepmi_engine_set_brick_force(nepmi_engine* e, int on);
-/* Static window layout of the one-lane window kernels (default on): between two list rebuilds the LDS slot of every window
- * atom is fixed, so the rebuild tabulates the windows and stores the Verlet entries as LDS slots, four to an 8-byte word
- * (two-type models: list B as two type-pure streams); on = 0 keeps the per-launch scan of the window cells and the
- * (window cell, rank) codes.  Same lists bit for bit, sums differ by their order only.  Forces a list rebuild. */
-int nepmi_engine_set_win_static(nepmi_engine* e, int on);
-/* Test hook: on = 1 makes nepmi_run_nvt_lan / nepmi_run_nvt_bao run as the plain sequence of the per-call steps on the caller's
- * arrays (what they were before they became device-resident loops); the resident forms reproduce it bit for bit. */
-int nepmi_engine_set_stepwise_loops(nepmi_engine* e, int on);
-/* How the per-atom ANN runs.  on = 1 (default): inside the angular-descriptor kernel where the shape allows it (one
- * lane per atom, at most 4 types: the descriptor never leaves the registers), else the matrix-core
- * (v_mfma_f32_32x32x2_f32) ANN kernel; on = 2: the matrix-core kernel wherever it applies; on = 0: the per-atom ANN
- * kernel, which is also taken automatically for models with more than 4 types, more than 128 neurons or more than
- * 128 descriptor + radial-table rows.  The three differ by f32 summation order only.  Forces a list rebuild (the
- * work order of the descriptor columns follows the mode). */
-int nepmi_engine_set_mfma(nepmi_engine* e, int on);
-/* Angular s_{n,lm} sums between the angular descriptor and angular force kernels: mode 0 = stored
- * ((n_a+1)*24 floats per atom through HBM), 1 = rebuilt in the force kernel from the compact pair
- * records, -1 (default) = rebuilt when the model has few angular neighbours (MN_angular <= 16).
- * Both give bit-identical results. */
-int nepmi_engine_set_angular_recompute(nepmi_engine* e, int mode);
+/* Experiment and test switches of an engine, by name (one entry point instead of a setter per switch: these select between
+ * kernel forms that give the same results, or narrow a guard for a test; production uses the defaults).  Returns NEPMI_ERR_ARG
+ * for an unknown name or a value outside the switch's range.
+ *
+ *   "generic": Force the run-time-shaped (generic) kernel instantiation instead of a model-shape-specialised
+ *       one; used by the parity tests to cover both code paths with one model.
+ *   "tiles": LDS-window kernels: 0 = none (plain gather kernel for the radial pass, pair records for the force
+ *       assembly); anything else (the default) = the radial pass and the force assembly both work from the LDS position
+ *       window.  The choice is a rule, never a timing: the same input always runs the same kernels.  The window
+ *       kernels are dropped automatically when a periodic direction has fewer than 8 cells, a brick's window does not
+ *       fit LDS or an atom sits far outside the box along an open direction.  Both give identical lists and forces to
+ *       f32 rounding.
+ *   "win_lanes": Lanes per atom of the LDS-window kernels: 0 (default) = by the number of bricks (4 up to 256 bricks, 2 up to 512,
+ *       else 1: small systems are bound by the latency of one workgroup); 1, 2, 4 pin it.
+ *   "scatter_guard / scatter_guard_hard": Test hook: the guard band of the scatter form per pair half in eV/A (default and maximum 64; the net-force guard is twice the
+ *       value), so that the hand-over can be exercised with ordinary forces; hard_factor: the hard limit of decomposed runs as a
+ *       multiple of the band (<= 0: the default 4; the limit never exceeds 256 eV/A).
+ *   "scatter_guard_delay": test hook: the NEXT "scatter_guard" takes effect at the value-th force assembly after it (to trip the band
+ *       at a chosen step of a run loop).
+ *   "radial_mask": The per-step radial list of the scatter-form steps of the run loops (find_neighbor_list_large_box, nep.cu:436-486, is what it
+ *       replaces): value = 1: one inside bit per candidate of the packed Verlet words, which the force assembly walks with the bits as
+ *       weights -- no compacted list is written (a conditional 2-byte store per pair and its bookkeeping: a third of the radial
+ *       pass's time); 0 (default): the compacted list on every step.  Same pairs, same per-pair arithmetic: identical trajectories
+ *       bit for bit (tests/test_gpu_parity.py).  Measured on PbTe 1 M atoms the radial pass gains 0.07 ms and the force assembly,
+ *       which then evaluates the 24 % of the candidates outside the cutoff in lockstep, loses as much (profiles/r4q_ab_mask.txt);
+ *       carbon gains 2 %.  One or two atom types; the compacted list is rebuilt on demand when per-atom virials leave the engine.
+ *   "angular_fused": Angular descriptor, per-atom ANN and partial angular forces (the angular half of find_descriptor, nep.cu:549-640;
+ *       apply_ann_one_layer, nep_utilities.cuh:169-194; find_partial_force_angular, nep.cu:774-861; find_force_ZBL, nep.cu:863-975) in
+ *       ONE kernel with two lanes per atom: value = 1 (default) wherever the descriptor + ANN fusion applies (compiled shapes, at most 4
+ *       types, fewer than 9 angular channels) -- the sums s_{n,lm} stay in the registers across the ANN and become the adjoint table in
+ *       place, where the separate kernels evaluate them twice; 0: the separate kernels.  Same results up to the summation order of
+ *       the ANN's dot products (tests/test_gpu_parity.py).
+ *   "brick_force": ... and the scatter-form force assembly (find_force_radial, nep.cu:661-772; gpu_find_force_many_body, potential.cu:170-297) in
+ *       the SAME kernel, one 512-thread workgroup per brick behind the radial pass: value = 1 where the fused angular kernel and the
+ *       scatter form both apply, on shapes with two register-resident atom types, in single-domain engines; the partial forces and
+ *       the per-atom radial table then never reach HBM (the virial-only pass of the gather form runs the separate angular kernel
+ *       first when per-atom virials leave the engine).  0 (default): the separate kernels -- measured faster on MI355X (PbTe 1 M atoms:
+ *       0.44 + 0.25 ms against 0.95 ms; gpumd_amd/csrc/nep_brick.h says why).  Same results to FP32 rounding.
+ *   "win_static": Static window layout of the one-lane window kernels (default on): between two list rebuilds the LDS slot of every window
+ *       atom is fixed, so the rebuild tabulates the windows and stores the Verlet entries as LDS slots, four to an 8-byte word
+ *       (two-type models: list B as two type-pure streams); value = 0 keeps the per-launch scan of the window cells and the
+ *       (window cell, rank) codes.  Same lists bit for bit, sums differ by their order only.  Forces a list rebuild.
+ *   "stepwise_loops": Test hook: value = 1 makes nepmi_run_nvt_lan / nepmi_run_nvt_bao run as the plain sequence of the per-call steps on the caller's
+ *       arrays (what they were before they became device-resident loops); the resident forms reproduce it bit for bit.
+ *   "mfma": How the per-atom ANN runs.  value = 1 (default): inside the angular-descriptor kernel where the shape allows it (one
+ *       lane per atom, at most 4 types: the descriptor never leaves the registers), else the matrix-core
+ *       (v_mfma_f32_32x32x2_f32) ANN kernel; value = 2: the matrix-core kernel wherever it applies; value = 0: the per-atom ANN
+ *       kernel, which is also taken automatically for models with more than 4 types, more than 128 neurons or more than
+ *       128 descriptor + radial-table rows.  The three differ by f32 summation order only.  Forces a list rebuild (the
+ *       work order of the descriptor columns follows the mode).
+ *   "angular_recompute": Angular s_{n,lm} sums between the angular descriptor and angular force kernels: value 0 = stored
+ *       ((n_a+1)*24 floats per atom through HBM), 1 = rebuilt in the force kernel from the compact pair
+ *       records, -1 (default) = rebuilt when the model has few angular neighbours (MN_angular <= 16).
+ *       Both give bit-identical results.
+ *   "radial_sync": the per-step radial list of the scatter-form steps as WAVE-SYNCHRONOUS words (default 1): the accepted LDS
+ *       slots wait in a short queue in the lane's registers and every lane of a wavefront stores one 8-byte word of four at the
+ *       same time (a lane with fewer than four pads with the sentinel slot) -- whole 512-byte rows instead of 2-byte stores at
+ *       per-lane rows (gpumd_amd/csrc/nep_window.h: SyncFifo); 0: the slot-major compact list.  Same pairs, integer sums:
+ *       identical forces bit for bit (tests/test_gpu_parity.py).  One or two atom types. */
+int nepmi_engine_set_option(nepmi_engine* e, const char* name, double value);
 /* Temperature-dependent NEP (nep4[_zbl]_temperature): the `temperature` argument of
  * NEP::compute(const float temperature, Box&, ...) (src/force/nep.cuh:126, nep.cu:1813-1856; Force::compute passes
  * its own `temperature`, advanced by delta_T before every compute of a run, force.cu:803).  It stays in force for

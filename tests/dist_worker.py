@@ -61,11 +61,14 @@ def run_rank(out_dir, spec, rank, world, make_transport, stream=None):
         e = md.lib.nepmi_dist_engine(md.handle)
         md._ck(md.lib.nepmi_engine_set_force_form(e, int(spec["force_form"])))
         if int(spec["force_form"]) == 1:  # the scatter form is the one-lane form: pin it (the rule takes two lanes up to 512 bricks)
-            md._ck(md.lib.nepmi_engine_set_win_lanes(e, 1))
+            md._ck(md.lib.nepmi_engine_set_option(e, b"win_lanes", 1.0))
     def set_guard():  # narrow the guard band of the scatter form (on the ranks listed, default: all)
         if spec.get("scatter_guard") is not None and (spec.get("guard_ranks") is None or rank in spec["guard_ranks"]):
             e = md.lib.nepmi_dist_engine(md.handle)
-            md._ck(md.lib.nepmi_engine_set_scatter_guard(e, float(spec["scatter_guard"]), float(spec.get("guard_hard_factor", 0.0))))
+            if spec.get("guard_delay"):  # ... from the n-th force assembly of the run on
+                md._ck(md.lib.nepmi_engine_set_option(e, b"scatter_guard_delay", float(spec["guard_delay"])))
+            md._ck(md.lib.nepmi_engine_set_option(e, b"scatter_guard", float(spec["scatter_guard"])))
+            md._ck(md.lib.nepmi_engine_set_option(e, b"scatter_guard_hard", float(spec.get("guard_hard_factor", 0.0))))
     if not spec.get("guard_after_compute"):
         set_guard()
     if spec.get("seed") is not None:

@@ -188,6 +188,19 @@ def test_scatter_guard_band_in_a_decomposed_run_is_voted():
     for a, b in zip(voted, gather):
         assert np.array_equal(a["i1"], b["i1"])
         assert np.abs(a["x1"] - b["x1"]).max() < 2e-6 and np.abs(a["f1"] - b["f1"]).max() < 1e-3
+    # (d) the band tripped on rank 1 DURING A STEP THE HOST LOOKS AT (the run's fourth force assembly: step 3, (3 + 1) % 4 == 0), hot
+    # enough for list rebuilds inside the speculation window: the look is taken behind the vote and in front of the force phase,
+    # so both ranks see the flag at the same look (a rank acting on its own, un-voted flag one look early would re-decompose or
+    # throw alone and the other would wait for ever in its next collective: this case then ends in the harness's hang detector)
+    hot = dict(T._spec("gpu", "PbTe-reps", (12, 8, 8), (2, 1, 1), "nve", 28, 3000.0, ghosts=1), thermo_every=7)  # (looks at steps 3, 7, 11, ...)
+    hot_gather = _run_threads(2, dict(hot, force_form=0))
+    hot_voted = _run_threads(2, dict(hot, force_form=1, scatter_guard=0.25, guard_ranks=[1], guard_hard_factor=1000.0,
+                                     guard_after_compute=True, guard_delay=4))
+    assert all(int(r["nhand"]) == 1 for r in hot_voted), [int(r["nhand"]) for r in hot_voted]
+    assert max(int(r["ndec"]) for r in hot_voted) >= 2  # list rebuilds (re-decompositions) happened inside the run
+    for a, b in zip(hot_voted, hot_gather):
+        assert np.array_equal(a["i1"], b["i1"])
+        assert np.abs(a["x1"] - b["x1"]).max() < 2e-5 and np.abs(a["f1"] - b["f1"]).max() < 1e-2
     # (c) the hard limit (default: four times the band): band 0.01 eV/A after compute() -> an error on every rank
     errors = _run_threads(2, dict(base, force_form=1, scatter_guard=0.01, guard_after_compute=True), expect_errors=True)
     assert sorted(r for r, _ in errors) == [0, 1], errors

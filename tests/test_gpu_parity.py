@@ -203,7 +203,7 @@ def test_scatter_guard_band_hands_over_to_the_gather_form(drv, monkeypatch):
 @pytest.mark.parametrize("model", ["PbTe", "C"])
 def test_run_loop_forms_are_bit_identical(drv, model):
     """The run loop's scatter-form steps with the per-step radial list as inside bits over the packed Verlet words (opt-in:
-    nepmi_engine_set_radial_mask) and as a compacted list (the default): the same pairs with the same per-pair arithmetic into integer sums -- identical
+    option "radial_mask"), as a compacted list and as wave-synchronous words (the default): the same pairs with the same per-pair arithmetic into integer sums -- identical
     positions, velocities, forces and energies after 40 steps with list rebuilds, bit for bit; per-atom virials (the
     virial-only gather pass at the exit, which needs the compacted list rebuilt on demand) identical as well; and both
     against the gather form within f32 rounding."""
@@ -217,19 +217,28 @@ def test_run_loop_forms_are_bit_identical(drv, model):
     vel = H.maxwell_velocities(mass, 2500.0, seed=4)
     m = drv.model(nep)
     out = []
-    for form, mask in ((1, True), (1, False), (0, True)):  # (form 1: these systems are below the size the run loops' rule asks for)
+    # (form 1: these systems are below the size the run loops' rule asks for)
+    for form, mask, sync in ((1, True, False), (1, False, False), (0, True, False), (1, False, True)):
         eng = drv.engine(m, n)
         eng.set_win_lanes(1)
         eng.set_force_form(form)
         eng.set_radial_mask(mask)
+        eng.set_radial_sync(sync)
         d_t, d_m, d_x, d_v = drv.dev(typ), drv.dev(mass), drv.dev(x), drv.dev(vel)
         d_pe, d_f, d_w = drv.zeros(n), drv.zeros(3 * n), drv.zeros(9 * n)
         eng.force_compute(h, d_t, d_x, d_pe, d_f, d_w)
         th = eng.run_nve(h, d_t, d_m, 2.0 / H.TIME_UNIT, 40, d_x, d_v, d_pe, d_f, d_w, thermo_every=10)
         out.append((drv.host(d_x), drv.host(d_v), drv.host(d_f), drv.host(d_pe), drv.host(d_w), np.asarray(th), eng.describe(),
                     eng.stats().num_rebuild))
-    a, b, g = out
+    a, b, g, w = out
     assert "inside_bits" in a[6] and "compacted" in b[6] and "lds_scatter" in b[6] and "lds_scatter" not in g[6], (a[6], b[6], g[6])
+    # ... and as wave-synchronous words (the default of the run loops; nep_window.h: SyncFifo): the same pairs once more, in words
+    # every lane of a wavefront stores at the same time (padded with the sentinel slot) -- bit for bit as well
+    assert "wave_synchronous_words" in w[6] and "lds_scatter" in w[6], w[6]
+    for i in range(5):
+        assert np.array_equal(w[i], b[i]), (i, np.abs(w[i] - b[i]).max())
+    assert np.array_equal(w[5][:, :2], b[5][:, :2]) and w[7] == b[7]
+    np.testing.assert_allclose(w[5], b[5], rtol=1e-6, atol=1e-9)
     if model == "PbTe":
         assert a[7] >= 2  # list rebuilds inside the run (the stiff diamond lattice keeps its lists over these 40 steps)
     for i in range(5):
@@ -269,7 +278,13 @@ def test_one_force_kernel_per_brick_matches_the_separate_kernels(drv):
     in ONE kernel per brick vs the two kernels.  The same arithmetic compiled into another kernel (other fma contractions): forces
     equal to a few units of the 2^-22 eV/A fixed point, energies and per-atom virials (the virial-only gather pass, which first
     has to bring the partial forces and the radial table back to HBM) to FP32 rounding; a 40-step run loop with list rebuilds
-    stays on the same trajectory -- and the kernel itself against the oracle (check_force_parity's comparisons)."""
+    stays on the same trajectory -- and the kernel itself against the oracle (check_force_parity's comparisons).
+    The kernel is an experiment outside the default build (make -C gpumd_amd/csrc BRICK=1): skipped where the library lacks it."""
+    probe = drv.engine(drv.model(H.golden("PbTe", "nep.txt")), 64)
+    try:
+        probe.set_brick_force(True)
+    except Exception as exc:
+        pytest.skip("libnepmi.so was built without the per-brick force kernel: %s" % exc)
     eng = P.check_force_parity(drv, "PbTe-ortho-big", lanes=1, win_static=True, force_form=1, brick=True)
     assert "one_kernel_per_brick" in eng.describe(), eng.describe()
     nep, (h, typ, x) = H.golden("PbTe", "nep.txt"), H.pbte_supercell((6, 6, 6), rattle=0.03, seed=17)

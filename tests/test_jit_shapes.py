@@ -89,6 +89,47 @@ def test_first_load_of_a_new_shape_compiles_its_core(monkeypatch, capfd, tmp_pat
     m0.close()
 
 
+def test_a_core_built_from_other_sources_is_refused(tmp_path):
+    """A core is matched to the library by the hash of the sources BAKED INTO both at build time (capi_jit.h: nepmi_core_abi), not by
+    what lies on disk at run time: the library's own hash is in the names of its prebuilt cores, and a file that carries the right
+    name but was compiled from other text (here: a copy of a prebuilt core with the baked constant patched, under the name of a
+    shape nobody built a core for) is not used -- its function table and handle layouts need not match."""
+    import ctypes as C
+    import struct
+    import gpumd_amd
+    cores = _core(CASES["Si-5body"])
+    if not cores:
+        pytest.skip("no prebuilt JIT core")
+
+    class Abi(C.Structure):
+        _fields_ = [("src_hash", C.c_uint64), ("api_bytes", C.c_uint64)]
+    lib = C.CDLL(os.path.join(H.ROOT, "gpumd_amd", "lib", "libnepmi.so"))
+    lib.nepmi_core_abi.restype = Abi
+    mine = lib.nepmi_core_abi()
+    assert mine.src_hash != 0 and ("%016x" % mine.src_hash) in os.path.basename(cores[0])
+    blob = open(cores[0], "rb").read()
+    key = struct.pack("<Q", mine.src_hash)
+    assert blob.count(key) >= 1
+    cache = tmp_path / "cache"
+    cache.mkdir(mode=0o700)
+    fake = cache / ("libnepmi_jit_10_10_10_10_5_1_%016x.so" % mine.src_hash)
+    fake.write_bytes(blob.replace(key, struct.pack("<Q", mine.src_hash ^ 1)))
+    assert not _core("10_10_10_10_5_1")
+    # in a process of its own: a process keeps the cores it has loaded (test_first_load_of_a_new_shape_compiles_its_core builds the
+    # genuine core of this shape)
+    import subprocess
+    import sys
+    code = ("import ctypes as C, gpumd_amd\n"
+            "m = gpumd_amd.Model(%r); p = gpumd_amd.Model(%r)\n"
+            "print('same_library', C.c_void_p.from_address(m.handle).value == C.c_void_p.from_address(p.handle).value)\n"
+            % (H.golden("Si", "nep_4body.txt"), H.golden("PbTe", "nep.txt")))
+    env = dict(os.environ, NEPMI_JIT="2", NEPMI_JIT_CACHE=str(cache), PYTHONPATH=H.ROOT)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "built from other sources" in r.stderr and "run-time-shape kernels serve it" in r.stderr, r.stderr
+    assert "same_library True" in r.stdout, r.stdout
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_force_parity_on_a_jit_core(name, monkeypatch):
