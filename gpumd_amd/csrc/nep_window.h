@@ -801,7 +801,7 @@ struct RadialWinBody {
 #define NEPMI_BUILD_WIN 1 // the Verlet lists of a rebuild from LDS windows (BuildListsWinBody) where the window kernels apply; 0: BuildListsBody
 #endif
 #ifndef NEPMI_RW2_ABL
-#define NEPMI_RW2_ABL 0 // ablation builds (timings only): 1 = no compact-list stores, 2 = no stores and no counters
+#define NEPMI_RW2_ABL 0 // ablation builds (timings only): 1 = no compact-list stores, 2 = no stores and no counters, 3 = no angular record stores
 #endif
 #ifndef NEPMI_RW2_HALF
 #define NEPMI_RW2_HALF 1 // 1: a word pair is processed as two halves of 2 + 2 candidates (fewer live registers), 0: 4 + 4 at once
@@ -1203,10 +1203,12 @@ struct RadialWin2Body {
                 e.y = c[u].fy * unit;
                 e.z = c[u].fz * unit;
                 e.w = c[u].rw;
-                acomp[(int64_t)ca * N] = e;
-                aidx[(int64_t)ca * N] = b.rev_ang[(int64_t)idx * N + k]; // reverse slot of this pair in j's list A
-                if (b.aslot)
-                  b.aslot[(int64_t)ca * N + k] = (unsigned short)c[u].slot; // the partner's place in this brick's window
+                if (NEPMI_RW2_ABL != 3) {
+                  acomp[(int64_t)ca * N] = e;
+                  aidx[(int64_t)ca * N] = b.rev_ang[(int64_t)idx * N + k]; // reverse slot of this pair in j's list A
+                  if (b.aslot)
+                    b.aslot[(int64_t)ca * N + k] = (unsigned short)c[u].slot; // the partner's place in this brick's window
+                }
                 cs = (unsigned short)ca;
                 const unsigned bit = 1u << (idx & 31);
                 const int aw = idx >> 5;

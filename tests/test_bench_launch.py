@@ -51,6 +51,11 @@ def test_plain_gpus_2_launches_its_own_ranks_and_prints_one_line():
     assert cfg["atoms_total"] == 2 * 6 * 4 * 4 * 250
     assert cfg["ghost_mode"] in ("forward", "reverse") and cfg["local_atoms_max"] > 6 * 4 * 4 * 250
     assert len(cfg["per_rank_ms_per_step"]["all"]) == 2 and "2x1x1" in cfg["parallelism"]
+    # the form probe before the clock: four combinations timed, the headline ran the one that won
+    probe = cfg["form_probe_before_the_clock"]
+    assert len(probe["results"]) == 4 and all("ms_per_step" in v for v in probe["results"].values()), probe
+    best = min(probe["results"].values(), key=lambda v: v["ms_per_step"])
+    assert cfg["overlap"] == best["overlap"] and cfg["ghost_mode"] == ("reverse" if best["ghosts"] else "forward")
     strong = line["extra_measurements"]["strong"]
     assert "error" not in strong, strong
     assert strong["scaling"] == "strong" and strong["config"]["atoms_total"] == 6 * 4 * 4 * 250 and strong["value"] > 0
