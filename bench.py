@@ -332,6 +332,20 @@ def cpu_baseline_tersoff(pot, h, typ, x, mass, vel, seconds=12.0):
                       "neighbour search every call, %.1f s" % (n, calls, el)}
 
 
+def load_traffic(n_atoms):
+    """profiles/traffic_latest.json: the builder's counter passes, one entry per workload size (`by_atoms`), or the single
+    entry of the earlier rounds' format"""
+    tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    if not os.path.exists(tfile):
+        return {}
+    tj = json.load(open(tfile))
+    by = tj.get("by_atoms")
+    if by:
+        e = by.get(str(int(n_atoms)))
+        return dict(e, source=e.get("source", tj.get("source"))) if e else {}
+    return tj
+
+
 def kernel_report(st, info, n_atoms_per_launch, st_all=None, tersoff=False, fused_angular=False, brick_force=False):
     """per-kernel mean durations (HIP events) + the roofline object of the dominant force kernel.
     st: stats of the timed region (timing mode 2: only the force-assembly slot is filled); st_all: stats of the
@@ -369,10 +383,7 @@ def kernel_report(st, info, n_atoms_per_launch, st_all=None, tersoff=False, fuse
                               "timed_in": "timed region" if src is st else "instrumented pass after the clock"}
     # every kernel priced the same way as the roofline object below: algorithmic bytes / duration / HBM peak, and (where the
     # builder's PMC pass matches this workload size) the counter traffic beside it
-    tj_all = {}
-    tfile_all = os.path.join(ROOT, "profiles", "traffic_latest.json")
-    if os.path.exists(tfile_all):
-        tj_all = json.load(open(tfile_all))
+    tj_all = load_traffic(n_atoms_per_launch)
     for name, e in kern.items():
         if name in per_kernel and e["avg_ms"] > 0.0:
             e["algorithmic_bytes_per_atom"] = per_kernel[name]
@@ -389,14 +400,11 @@ def kernel_report(st, info, n_atoms_per_launch, st_all=None, tersoff=False, fuse
     dom = ranked[0] if ranked else None
     roofline = None
     if dom:
-        traffic, tj = None, {}
-        tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tfile):
-            # HBM-side bytes per launch from a separate rocprofv3 PMC pass of this same command
-            # (profiles/*_pmc_*.csv); only meaningful for the workload size it was taken on
-            tj = json.load(open(tfile))
-            if tj.get("atoms") == n_atoms_per_launch and dom in tj.get("kernels", {}):
-                traffic = tj["kernels"][dom]["hbm_bytes_per_launch"]
+        # HBM-side bytes per launch from a separate rocprofv3 PMC pass of this same command (profiles/*_pmc_*.csv); only
+        # meaningful for the workload (number of atoms) it was taken on
+        traffic, tj = None, load_traffic(n_atoms_per_launch)
+        if tj.get("atoms") == n_atoms_per_launch and dom in tj.get("kernels", {}):
+            traffic = tj["kernels"][dom]["hbm_bytes_per_launch"]
         dom_bytes = kern[dom].get("own_bytes_per_atom", per_kernel[dom])
         achieved = dom_bytes * n_atoms_per_launch / (kern[dom]["avg_ms"] * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -1112,6 +1120,17 @@ def bench(args):
                 extras["pbte_generic_shape"] = measure_extra("pbte", reps, 10, 3, dev, generic=True)
             except Exception as e:
                 extras["pbte_generic_shape"] = {"error": str(e)}
+            # (a4') ... and what such a model gets WITHOUT a compiler: zero-padded into a compiled cover shape (nep_model.h:
+            #      embed_model; forced here on the same PbTe model and on C_2024, whose own shapes have kernels / a JIT core)
+            os.environ["NEPMI_FORCE_COVER"] = "1"
+            try:
+                for key, wl, rp, k in (("pbte_zero_padded_into_cover_shape", "pbte", reps, 20), ("c2024_512k_zero_padded_into_cover_shape", "carbon2024", (10, 10, 10), 5)):
+                    try:
+                        extras[key] = measure_extra(wl, rp, k, 3, dev)
+                    except Exception as e:
+                        extras[key] = {"error": str(e)}
+            finally:
+                os.environ.pop("NEPMI_FORCE_COVER", None)
             # (a5) a shipped potential of ANOTHER shape (C_2024: n_max 12 8, basis 16 12): kernels compiled for its shape (a JIT
             #      core, prebuilt by build(): NEPMI_JIT=2 = never the compiler here) against the run-time-shape kernels
             for key, mode in (("c2024_512k_jit_core", "2"), ("c2024_512k_run_time_shape", "0")):

@@ -75,6 +75,32 @@ nepmi_model* nepmi_model_load(const char* path)
     delete m;
     return nullptr;
   }
+#if !defined(NEPMI_JIT_CORE)
+  // A model whose shape has no compiled kernels here (and no JIT core took it: the public nepmi_model_load asks for one
+  // first) is zero-padded into the smallest COVER shape that holds it (nep_model.h: embed_model) -- compiled kernels at the
+  // price of the padded work -- instead of the run-time-shape kernels.  NEPMI_JIT=0 or NEPMI_COVER=0: the run-time-shape
+  // kernels; NEPMI_FORCE_COVER=1 (measurements): pad even a model of a compiled shape.
+  {
+    const char* jit = std::getenv("NEPMI_JIT");
+    const char* cov = std::getenv("NEPMI_COVER");
+    const char* force = std::getenv("NEPMI_FORCE_COVER");
+    const bool forced = force && force[0] == '1';
+    const bool allowed = !(jit && jit[0] == '0') && !(cov && cov[0] == '0');
+    int c[4];
+    const int builtin = nepmi::builtin_shape_of(m->m);
+    if (m->m.kind == 0 && (forced || (allowed && builtin == 0)) && builtin != 7 && builtin != 8 && nepmi::cover_shape_for(m->m, c)) {
+      const int f[5] = {m->m.n_max_radial, m->m.basis_size_radial, m->m.n_max_angular, m->m.basis_size_angular, m->m.num_L};
+      if (!nepmi::embed_model(m->m, c[0], c[1], c[2], c[3]))
+        std::fprintf(stderr, "nepmi: the run-time-shape kernels serve this model, several times slower than compiled ones\n");
+      else if (!forced)
+        std::fprintf(stderr, "nepmi: no kernels compiled for this model's shape (n_max %d %d, basis_size %d %d, %d invariant rows): it is served, "
+                             "zero-padded, by the kernels of the compiled shape (n_max %d %d, basis_size %d %d, 6 rows)\n",
+                     f[0], f[2], f[1], f[3], f[4], c[0], c[2], c[1], c[3]);
+    } else if (m->m.kind == 0 && builtin == 0 && !(jit && jit[0] == '0')) {
+      std::fprintf(stderr, "nepmi: the run-time-shape kernels serve this model (no compiled shape holds it), several times slower than compiled ones\n");
+    }
+  }
+#endif
   return m;
 }
 
@@ -95,15 +121,15 @@ int nepmi_model_info(const nepmi_model* mm, nepmi_info* o)
   o->rc_angular = m.rc_angular_max;
   o->MN_radial = m.MN_radial;
   o->MN_angular = m.MN_angular;
-  o->n_max_radial = m.n_max_radial;
-  o->n_max_angular = m.n_max_angular;
-  o->basis_size_radial = m.basis_size_radial;
-  o->basis_size_angular = m.basis_size_angular;
-  o->L_max = m.L_max;
-  o->has_q_222 = m.has_q_222;
-  o->has_q_1111 = m.has_q_1111;
-  o->num_L = m.num_L;
-  o->dim = m.dim;
+  o->n_max_radial = m.embedded() ? m.file_n_max_radial : m.n_max_radial;
+  o->n_max_angular = m.embedded() ? m.file_n_max_angular : m.n_max_angular;
+  o->basis_size_radial = m.embedded() ? m.file_basis_size_radial : m.basis_size_radial;
+  o->basis_size_angular = m.embedded() ? m.file_basis_size_angular : m.basis_size_angular;
+  o->L_max = m.embedded() ? m.file_L_max : m.L_max;
+  o->has_q_222 = m.embedded() ? m.file_has_q_222 : m.has_q_222;
+  o->has_q_1111 = m.embedded() ? m.file_has_q_1111 : m.has_q_1111;
+  o->num_L = m.embedded() ? m.file_num_L : m.num_L;
+  o->dim = m.embedded() ? m.file_dim : m.dim;
   o->num_neurons = m.num_neurons;
   o->num_para = m.num_para;
   o->has_q_112 = m.has_q_112;

@@ -332,8 +332,7 @@ inline const nepmi_api* core_for(const ShapeKey& key, uint64_t api_bytes)
       api = load_core(path, api_bytes, why);
   }
   if (!api)
-    std::fprintf(stderr, "nepmi: no kernels compiled for this model's shape (%s): the run-time-shape kernels serve it, several "
-                         "times slower\n", why.empty() ? "no core found, NEPMI_JIT=2" : why.c_str());
+    std::fprintf(stderr, "nepmi: no JIT core for this model's shape (%s)\n", why.empty() ? "no core found, NEPMI_JIT=2" : why.c_str());
   if (api || may_build) // (a failed compilation is not tried again by this process; a look-up without the compiler may be)
     cores[key.name()] = api;
   return api;

@@ -147,7 +147,12 @@ __global__ void __launch_bounds__(256) nepmi_ann_pack(const ModelD m, const Bufs
   }
 }
 
-template <int MT, int DT, int QB>
+// BYTYPE (models with more than four types, e.g. UNEP-v1's 16): a 1024-atom chunk then holds ~64 atoms of a type -- one wave
+// tile -- and a workgroup that staged one type's image (39 KB) for a single tile would spend its time staging.  Instead one
+// workgroup serves ONE type over kAnnGroup consecutive chunks: the image is staged once, the four waves take that type's tiles
+// chunk after chunk.  Grid: ceil(nchunks / kAnnGroup) x T workgroups.
+constexpr int kAnnGroup = 16;
+template <int MT, int DT, int QB, bool BYTYPE>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ann_mfma_waves(MT, DT, QB))))
 nepmi_ann_mfma(const ModelD m, const Bufs b, const int64_t nchunks, const int* frozen)
 {
@@ -164,15 +169,32 @@ nepmi_ann_mfma(const ModelD m, const Bufs b, const int64_t nchunks, const int* f
   // kAnnSplit workgroups share one chunk (more, shorter workgroups: less tail at 3 waves/SIMD)
   const unsigned per_xcd = gridDim.x >> 3;
   const int64_t wg = (int64_t)(blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
-  const int64_t chunk = wg / kAnnSplit;
-  if (chunk >= nchunks)
+  const int64_t c_first = BYTYPE ? (wg / T) * kAnnGroup : wg / kAnnSplit;
+  if (c_first >= nchunks)
     return;
+  const int64_t c_last = BYTYPE ? (c_first + kAnnGroup < nchunks ? c_first + kAnnGroup : nchunks) : c_first + 1;
   const int64_t N = b.N;
   const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, col = lane & 31;
-  const int wave = (tid >> 6) + 4 * (int)(wg % kAnnSplit); // tile slot of this wave within the chunk
-  for (int tu = 0; tu < T; ++tu) {
-    const int lo = b.tcount[chunk * T + tu], end = b.tcount[chunk * T + tu + 1];
-    if (lo == end)
+  // tile slot of this wave within the chunk.  BYTYPE: a (chunk, type) segment is about ONE tile (1024 atoms / 16 types) and a
+  // second, nearly empty tile half of the time, so the type's segments of the group's chunks are walked as ONE flat range:
+  // flat index f -> work index seg_lo[s] + f - seg_pre[s] (two small tables in LDS behind the image); the four waves take
+  // every fourth tile of that range
+  const int wave = BYTYPE ? (tid >> 6) : (tid >> 6) + 4 * (int)(wg % kAnnSplit);
+  constexpr int kStride = BYTYPE ? 4 : kAnnStride;
+  int* seg_lo = reinterpret_cast<int*>(nepmi_ann_lds + img_floats); // [kAnnGroup]
+  int* seg_pre = seg_lo + kAnnGroup;                                // [kAnnGroup + 1] exclusive prefix of the segment lengths
+  auto WI = [&](const int f) __attribute__((always_inline)) -> int { // flat index -> work index (column of q / fp, entry of tperm)
+    if (!BYTYPE)
+      return f;
+    int sidx = 0;
+#pragma unroll
+    for (int i = 1; i < kAnnGroup; ++i)
+      sidx += (f >= seg_pre[i]) ? 1 : 0;
+    return seg_lo[sidx] + (f - seg_pre[sidx]);
+  };
+  const int t_first = BYTYPE ? (int)(wg % T) : 0, t_last = BYTYPE ? t_first + 1 : T;
+  for (int tu = t_first; tu < t_last; ++tu) {
+    if (!BYTYPE && b.tcount[c_first * T + tu] == b.tcount[c_first * T + tu + 1])
       continue;
     __syncthreads();
     {
@@ -181,10 +203,25 @@ nepmi_ann_mfma(const ModelD m, const Bufs b, const int64_t nchunks, const int* f
       for (int idx = tid; idx < img_floats / 4; idx += 256)
         dst[idx] = src[idx];
     }
+    if (BYTYPE && tid == 0) {
+      int run = 0;
+      for (int i = 0; i < kAnnGroup; ++i) {
+        const int64_t c = c_first + i;
+        const int l0 = c < c_last ? b.tcount[c * T + tu] : 0, l1 = c < c_last ? b.tcount[c * T + tu + 1] : 0;
+        seg_lo[i] = l0;
+        seg_pre[i] = run;
+        run += l1 - l0;
+      }
+      seg_pre[kAnnGroup] = run;
+    }
     __syncthreads();
+   for (int64_t chunk = c_first; chunk < (BYTYPE ? c_first + 1 : c_last); ++chunk) {
+    const int lo = BYTYPE ? 0 : b.tcount[chunk * T + tu], end = BYTYPE ? seg_pre[kAnnGroup] : b.tcount[chunk * T + tu + 1];
+    if (lo == end)
+      continue;
     const float ebias = m.b1 + m.b1t[tu];
     const nepmi_f32x16 zero16 = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-    const int nrows = dim + T * KRP;
+    const int nrows = T > 4 ? dim : dim + T * KRP; // (more than four types: no radial-table rows, the force assembly contracts from Bufs::fpr)
     // This wave's tiles: lo + 64 (wave + 4 i).  The loop runs over units = (tile, 32-column half);
     // the q rows of unit u+1 are requested right after unit u's forward MFMAs have consumed the
     // operand registers -- i.e. before unit u's stores, so that (vmcnt being in-order) waiting for
@@ -192,12 +229,12 @@ nepmi_ann_mfma(const ModelD m, const Bufs b, const int64_t nchunks, const int* f
     const int ntiles = (end - lo + 63) >> 6;
     if (wave >= ntiles)
       continue;
-    const int nunits = 2 * ((ntiles - wave + kAnnStride - 1) / kAnnStride);
+    const int nunits = 2 * ((ntiles - wave + kStride - 1) / kStride);
     int tile = lo + wave * 64;
     int k_cur, act_cur, k_nxt = 0, act_nxt = 0;
     {
       const int gl = tile + lane;
-      k_cur = b.tperm[gl < end ? gl : lo];
+      k_cur = b.tperm[WI(gl < end ? gl : lo)];
       act_cur = (gl < end && b.lvl[k_cur] >= b.lvl_desc) ? 1 : 0;
     }
     // q and fp are stored in work order: column g of the [dim][N] arrays is work item g
@@ -205,7 +242,7 @@ nepmi_ann_mfma(const ModelD m, const Bufs b, const int64_t nchunks, const int* f
     float bq[QB];
 #pragma unroll
     for (int s = 0; s < QB; ++s)
-      bq[s] = b.q[(int64_t)min(2 * s + hi, dim - 1) * N + gc];
+      bq[s] = b.q[(int64_t)min(2 * s + hi, dim - 1) * N + WI(gc)];
     float e_own = 0.0f;
 #pragma unroll 1
     for (int u = 0; u < nunits; ++u) {
@@ -214,9 +251,9 @@ nepmi_ann_mfma(const ModelD m, const Bufs b, const int64_t nchunks, const int* f
       int hi_o = hi;
       asm volatile("" : "+v"(hi_o) : : "memory");
       if (nt == 0) {
-        const int gl = tile + 64 * kAnnStride + lane;
-        const bool more = tile + 64 * kAnnStride < end;
-        k_nxt = b.tperm[(more && gl < end) ? gl : lo];
+        const int gl = tile + 64 * kStride + lane;
+        const bool more = tile + 64 * kStride < end;
+        k_nxt = b.tperm[WI((more && gl < end) ? gl : lo)];
         act_nxt = (more && gl < end && b.lvl[k_nxt] >= b.lvl_desc) ? 1 : 0;
       }
       const int actc = __shfl(act_cur, nt * 32 + col);
@@ -233,11 +270,12 @@ nepmi_ann_mfma(const ModelD m, const Bufs b, const int64_t nchunks, const int* f
         }
       }
       const int kc = __shfl(k_cur, nt * 32 + col);
-      const int gc_n = min(nt == 0 ? tile + 32 + col : tile + 64 * kAnnStride + col, end - 1);
+      const int gc_n = min(nt == 0 ? tile + 32 + col : tile + 64 * kStride + col, end - 1);
+      const int gcw_n = WI(gc_n);
       if (u + 1 < nunits) {
 #pragma unroll
         for (int s = 0; s < QB; ++s)
-          bq[s] = b.q[(int64_t)min(2 * s + hi_o, dim - 1) * N + gc_n];
+          bq[s] = b.q[(int64_t)min(2 * s + hi_o, dim - 1) * N + gcw_n];
       }
       float e_part = 0.0f;
       float cf[MT][16]; // C = w1 (1 - tanh^2): the backward B operand, same lane layout as acc
@@ -272,16 +310,18 @@ nepmi_ann_mfma(const ModelD m, const Bufs b, const int64_t nchunks, const int* f
         // rows in register order: d = 32 dt + {0,1,2,3, 8,.., 27} + 4 hi, i.e. steps of +1,+1,+1,+5;
         // rows [dim, dim + T KRP) are the radial-table rows, laid out exactly like atab's row
         int d = 4 * hi_o;
-        float* pf = b.fp + gc + (int64_t)d * N;
+        float* pf = b.fp + WI(gc) + (int64_t)d * N;
         float* pa = b.atab + (size_t)kc * (T * KRP) - dim;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const float v = out[dt][r];
-            if (d < dim)
+            if (d < dim) {
               *pf = v;
-            else if (d < nrows)
+              if (b.fpr && d <= m.NR) // the radial rows again, atom-major (what AnnBody writes for the many-type force assembly)
+                b.fpr[(size_t)kc * b.FPR + d] = v;
+            } else if (d < nrows)
               pa[d] = v;
             const int step = (r & 3) == 3 ? 5 : 1;
             d += step;
@@ -293,10 +333,11 @@ nepmi_ann_mfma(const ModelD m, const Bufs b, const int64_t nchunks, const int* f
           b.pe_i[k_cur] = e_own - ebias;
         k_cur = k_nxt;
         act_cur = act_nxt;
-        tile += 64 * kAnnStride;
+        tile += 64 * kStride;
       }
       gc = gc_n;
     }
+   }
   }
 }
 
@@ -1062,16 +1103,16 @@ struct HipBackend {
 
   // ANN launch: the MFMA kernel when the shape fits (few types, <= 128 neurons, <= 128 output rows
   // incl. the radial-table rows), else the per-atom AnnBody.
-  template <int MT, int QB>
+  template <int MT, int QB, bool BYTYPE = false>
   void launch_ann_mfma(int DT, size_t lds_bytes, int64_t grid, const ModelD& m, const Bufs& b, int64_t nchunks)
   {
 #define NEPMI_ANN_CASE(D)                                                                           \
   case D:                                                                                           \
     if (lds_bytes > 64 * 1024)                                                                      \
       NEPMI_HIP_CHECK(hipFuncSetAttribute(                                                          \
-        reinterpret_cast<const void*>(&nepmi_ann_mfma<MT, D, QB>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+        reinterpret_cast<const void*>(&nepmi_ann_mfma<MT, D, QB, BYTYPE>), hipFuncAttributeMaxDynamicSharedMemorySize, \
         (int)lds_bytes));                                                                           \
-    hipLaunchKernelGGL((nepmi_ann_mfma<MT, D, QB>), dim3((unsigned)grid), dim3(256), lds_bytes, stream, m, b, nchunks, frozen); \
+    hipLaunchKernelGGL((nepmi_ann_mfma<MT, D, QB, BYTYPE>), dim3((unsigned)grid), dim3(256), lds_bytes, stream, m, b, nchunks, frozen); \
     break;
     switch (DT) {
       NEPMI_ANN_CASE(1)
@@ -1094,20 +1135,30 @@ struct HipBackend {
   template <class S>
   void launch_ann(int slot, int64_t n, const ModelD& m, const Bufs& b, bool grouped)
   {
-    if (!mfma_on || !b.ann_img || !grouped) {
+    // (more than four types: the image carries no radial-table rows -- the matrix-core kernel serves the steps whose force
+    // assembly contracts from Bufs::fpr, the per-atom kernel the others)
+    if (!mfma_on || !b.ann_img || !grouped || (m.T > 4 && !b.skip_atab)) {
       launch<64>(slot, n, AnnBody<S>{m, b});
       return;
     }
     if (n <= 0)
       return;
     const AnnMfmaShape a = ann_mfma_shape(m.T, m.dim, m.nneu, b.KRP);
-    const size_t lds_bytes = a.img_floats * sizeof(float);
+    const bool bytype = m.T > 4;
+    const size_t lds_bytes = a.img_floats * sizeof(float) + (bytype ? (2 * kAnnGroup + 2) * sizeof(int) : 0);
     const int64_t nchunks = (n >> kTypeChunkShift) + 1;
-    const int64_t grid = (nchunks * kAnnSplit + 7) / 8 * 8;
+    const int64_t grid = bytype ? ((nchunks + kAnnGroup - 1) / kAnnGroup * m.T + 7) / 8 * 8 : (nchunks * kAnnSplit + 7) / 8 * 8;
     const bool t = timed(slot);
     if (t)
       timer_start(timing->slot[slot]);
-    if (a.KS <= 24) {
+    if (bytype) {
+      switch (a.MT) {
+        case 1: launch_ann_mfma<1, 24, true>(a.DT, lds_bytes, grid, m, b, nchunks); break;
+        case 2: launch_ann_mfma<2, 24, true>(a.DT, lds_bytes, grid, m, b, nchunks); break;
+        case 3: launch_ann_mfma<3, 24, true>(a.DT, lds_bytes, grid, m, b, nchunks); break;
+        default: launch_ann_mfma<4, 24, true>(a.DT, lds_bytes, grid, m, b, nchunks); break;
+      }
+    } else if (a.KS <= 24) {
       switch (a.MT) {
         case 1: launch_ann_mfma<1, 24>(a.DT, lds_bytes, grid, m, b, nchunks); break;
         case 2: launch_ann_mfma<2, 24>(a.DT, lds_bytes, grid, m, b, nchunks); break;
@@ -1249,19 +1300,23 @@ struct HipBackend {
         constexpr int L = NEPMI_FS_MT_LANES;
         const ScatterLayoutMT lay{ws2.lay.wmax, md.T * md.T * ctab_block(md.NR, md.KR, NEPMI_FS_MT_VEC != 0)};
         const size_t lds_bytes = ((size_t)lay.bytes() + 15) / 16 * 16;
-        if (outputs) {
-          if (lds_bytes > 64 * 1024)
-            NEPMI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&nepmi_force_scatter_mt_kernel<S, true, L>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-          hipLaunchKernelGGL((nepmi_force_scatter_mt_kernel<S, true, L>), dim3((unsigned)grid), dim3(kWinThreads * L), lds_bytes, stream,
-                             body, nb);
-        } else {
-          if (lds_bytes > 64 * 1024)
-            NEPMI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&nepmi_force_scatter_mt_kernel<S, false, L>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-          hipLaunchKernelGGL((nepmi_force_scatter_mt_kernel<S, false, L>), dim3((unsigned)grid), dim3(kWinThreads * L), lds_bytes, stream,
-                             body, nb);
-        }
+#define NEPMI_FSMT_LAUNCH(OUTV, MODEV)                                                                                                  \
+  do {                                                                                                                                 \
+    if (lds_bytes > 64 * 1024)                                                                                                         \
+      NEPMI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&nepmi_force_scatter_mt_kernel<S, OUTV, L, MODEV>),           \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));                               \
+    hipLaunchKernelGGL((nepmi_force_scatter_mt_kernel<S, OUTV, L, MODEV>), dim3((unsigned)grid), dim3(kWinThreads * L), lds_bytes,      \
+                       stream, body, nb);                                                                                             \
+  } while (0)
+        if (outputs && mode == 2)
+          NEPMI_FSMT_LAUNCH(true, 2);
+        else if (outputs)
+          NEPMI_FSMT_LAUNCH(true, 0);
+        else if (mode == 2)
+          NEPMI_FSMT_LAUNCH(false, 2);
+        else
+          NEPMI_FSMT_LAUNCH(false, 0);
+#undef NEPMI_FSMT_LAUNCH
       }
       NEPMI_HIP_CHECK(hipGetLastError());
     }
@@ -1823,7 +1878,8 @@ static const nepmi_api* nepmi_jit_core_for_model_file(const char* path)
   return nullptr; // a core serves the shape it was compiled for (and nothing is compiled from inside a core)
 #else
   const char* mode = std::getenv("NEPMI_JIT");
-  if (!path || (mode && mode[0] == '0'))
+  const char* force_cover = std::getenv("NEPMI_FORCE_COVER");
+  if (!path || (mode && mode[0] == '0') || (force_cover && force_cover[0] == '1'))
     return nullptr;
   nepmi::NepModel m;
   bool unsupported = false;

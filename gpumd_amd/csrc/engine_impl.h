@@ -43,6 +43,8 @@
     case 3: FN<S_C2022>(NEPMI_UNPAREN ARGS); break;                               \
     case 4: FN<S_UNEP>(NEPMI_UNPAREN ARGS); break;                                \
     case 5: FN<S_BZO>(NEPMI_UNPAREN ARGS); break;                                 \
+    case 7: FN<S_COV1>(NEPMI_UNPAREN ARGS); break;                                \
+    case 8: FN<S_COV2>(NEPMI_UNPAREN ARGS); break;                                \
     default: if (GENERIC) FN<ShapeGeneric>(NEPMI_UNPAREN ARGS); break;            \
   }
 #endif
@@ -72,7 +74,36 @@ inline int builtin_shape_of(const NepModel& m)
   if (model_matches_shape<Shape<10, 10, 8, 8, 6, 1>>(m)) return 3;
   if (model_matches_shape<Shape<4, 8, 4, 8, 6, 0>>(m)) return 4;
   if (model_matches_shape<Shape<8, 8, 6, 8, 5, 0>>(m)) return 5;
+  if (model_matches_shape<Shape<8, 12, 8, 12, 6, 0>>(m)) return 7;
+  if (model_matches_shape<Shape<12, 16, 10, 12, 6, 0>>(m)) return 8;
   return 0;
+}
+// a model whose compiled shape keeps type-pure list segments (Shape::TS > 0)
+inline bool served_by_type_pure_shape(const NepModel& m)
+{
+#if defined(NEPMI_JIT_CORE)
+  using SJ = Shape<NEPMI_JIT_SHAPE>;
+  return SJ::TS > 0 && model_matches_shape<SJ>(m);
+#else
+  const int bs = builtin_shape_of(m);
+  return bs >= 1 && bs <= 3;
+#endif
+}
+// The COVER shapes (7, 8: any number of types, all six invariant rows): a model of a shape nobody compiled kernels for is
+// zero-padded into the smallest one that holds it (nep_model.h: embed_model) instead of falling to the run-time-shape kernels.
+// n_r, k_r, n_a, k_a of the cover, or false.
+inline bool cover_shape_for(const NepModel& m, int out[4])
+{
+  static const int covers[2][4] = {{8, 12, 8, 12}, {12, 16, 10, 12}};
+  if (m.kind != 0 || m.L_max < 1 || m.L_max > 4 || m.has_q_112 || m.has_q_123 || m.has_q_233 || m.has_q_134)
+    return false;
+  for (const auto& c : covers)
+    if (m.n_max_radial <= c[0] && m.basis_size_radial <= c[1] && m.n_max_angular <= c[2] && m.basis_size_angular <= c[3]) {
+      for (int i = 0; i < 4; ++i)
+        out[i] = c[i];
+      return true;
+    }
+  return false;
 }
 
 
@@ -890,7 +921,10 @@ public:
       // angular records of the last evaluation are still in place)
       NEPMI_SHAPE_DISPATCH(launch_angular_desc, 0, ())
     }
-    ExportDescBody body{b_, model_.dim, q, fp};
+    // (a zero-padded model: the caller's arrays hold the FILE's components, dmap says where each lives in the padded descriptor)
+    if (model_.embedded() && !dmap_dev_)
+      dmap_dev_ = upload(model_.dmap);
+    ExportDescBody body{b_, model_.embedded() ? model_.file_dim : model_.dim, q, fp, model_.embedded() ? dmap_dev_ : nullptr};
     be_.template launch<64>(kSlotMisc, N_, body);
   }
 
@@ -1065,7 +1099,9 @@ private:
       b_.wcode = dalloc<unsigned short>((size_t)b_.MN_wchunks * 4 * N);
       b_.wseg = dalloc<int>(N);
       b_.FPR = (m.n_max_radial + 1 + 3) / 4 * 4;
-      b_.fpr = m.num_types > 4 ? dalloc<float>((size_t)N * b_.FPR) : nullptr; // many-type models: see ForceWinBody<..., FPJ>
+      // models served by a shape WITHOUT type-pure lists (more than two types, the cover shapes, the run-time shape): the radial
+      // Fp row per atom, what their force assembly contracts from (ForceWinBody<..., FPJ>, the many-type LDS scatter)
+      b_.fpr = (m.num_types > 4 || !served_by_type_pure_shape(m)) ? dalloc<float>((size_t)N * b_.FPR) : nullptr;
       b_.MN_cw = (b_.MN_rad + 3) / 4 + 1;
       b_.cword = dalloc<unsigned short>((size_t)2 * b_.MN_cw * 4 * N);
       // scatter-form force assembly (nep_scatter.h; device backends only)
@@ -1555,6 +1591,8 @@ private:
   using S_C2022 = Shape<10, 10, 8, 8, 6, 1>; // potentials/nep/C_2022_NEP4.txt
   using S_UNEP = Shape<4, 8, 4, 8, 6, 0>;    // potentials/nep/Song-2024-UNEP-v1-...txt (16 types)
   using S_BZO = Shape<8, 8, 6, 8, 5, 0>;     // tests_pytest/fixtures/models/nep_BaZrO3.txt (3 types)
+  using S_COV1 = Shape<8, 12, 8, 12, 6, 0>;   // cover shapes: models of other shapes are zero-padded into them (cover_shape_for)
+  using S_COV2 = Shape<12, 16, 10, 12, 6, 0>;
 
   template <class S>
   bool shape_matches() const
@@ -1572,6 +1610,8 @@ private:
     else if (shape_matches<S_C2022>()) shape_ = 3;
     else if (shape_matches<S_UNEP>()) shape_ = 4;
     else if (shape_matches<S_BZO>()) shape_ = 5;
+    else if (shape_matches<S_COV1>()) shape_ = 7;
+    else if (shape_matches<S_COV2>()) shape_ = 8;
     else shape_ = 0;
 #endif
     if (force_generic_)
@@ -1689,6 +1729,9 @@ public:
     b_.scatter_hard = o.b_.scatter_hard;
     b_.fold_hard = o.b_.fold_hard;
     hard_factor_ = o.hard_factor_;
+    hard_asked_ = o.hard_asked_;
+    guard_delay_ = o.guard_delay_;
+    guard_delayed_ = o.guard_delayed_;
     if (reverse_ghosts_ != o.reverse_ghosts_)
       set_reverse_ghosts(o.reverse_ghosts_);
     unwrapped_ = o.unwrapped_;
@@ -1779,7 +1822,7 @@ private:
                        : 0;
       last_mask_form_ = b_.use_rmask != 0;
       // Wave-synchronous words (nep_window.h: SyncFifo): under the same conditions, whenever the mask form was not asked for
-      b_.use_csync = (NEPMI_CSYNC && use_csync_ && !b_.use_rmask && S::TS > 0 && win2 && b_.cword && loop_ctx_ && b_.MN_cw < 256 &&
+      b_.use_csync = (NEPMI_CSYNC && use_csync_ && !b_.use_rmask && win2 && b_.cword && loop_ctx_ && b_.MN_cw < 256 &&
                       scatter_wanted<S>(wsq))
                        ? 1
                        : 0;
@@ -1794,7 +1837,7 @@ private:
     B& rbe = radial_side_ ? *radial_side_ : be_; // (force_kernels_on: the boundary bricks on the communication stream)
     auto radial = [&](int64_t nb, int first) {
       if (win2 && b_.use_csync)
-        rbe.launch_win2(kSlotRadial, nb, RadialWin2Body<S, (S::TS > 0 ? 1 : 0)>{ws2, md_, first, frozen});
+        rbe.launch_win2(kSlotRadial, nb, RadialWin2Body<S, 1>{ws2, md_, first, frozen});
       else if (win2)
         rbe.launch_win2(kSlotRadial, nb, RadialWin2Body<S>{ws2, md_, first, frozen});
       else if (lanes == 4)
@@ -1994,15 +2037,17 @@ public:
   void set_radial_sync(bool on) { use_csync_ = on; }
   // Guard band of the scatter form (nepmi_engine_set_scatter_guard): a pair half beyond `limit` eV/A (default 64; a net force
   // component beyond twice that) hands the force assembly over to the gather form.  Tests lower it so that ordinary forces trip it.
-  // limit < 0 / hard_factor < 0: that one stays as it is
+  // limit < 0 / hard_factor < 0: that one stays as it is.  The hard factor is kept as ASKED and clamped against the band in
+  // force (never beyond 256 eV/A), so the two can be set in either order.
   void set_scatter_guard(double limit, double hard_factor = 4.0)
   {
     if (limit < 0.0)
       limit = b_.scatter_limit;
-    if (hard_factor < 0.0)
-      hard_factor = hard_factor_;
+    if (hard_factor >= 0.0)
+      hard_asked_ = hard_factor;
     if (!(limit > 0.0) || limit > 64.0)
       limit = 64.0;
+    hard_factor = hard_asked_;
     if (!(hard_factor >= 1.0) || hard_factor * limit > 256.0)
       hard_factor = 256.0 / limit < 4.0 ? 256.0 / limit : 4.0;
     b_.scatter_limit = (float)limit;
@@ -2127,8 +2172,8 @@ private:
   template <class S>
   bool fpj_wanted(const WinStage& ws2) const
   {
-    if (S::TS > 0 || !NEPMI_FW_FPJ || NEPMI_CW || !b_.fpr || fuse_ann_active() || ang_fused_active() || (ann_mode_ != 0 && b_.ann_img != nullptr))
-      return false; // (fpr is written by the per-atom ANN kernel only)
+    if (S::TS > 0 || !NEPMI_FW_FPJ || NEPMI_CW || !b_.fpr || (fuse_ann_active() && !ang_fused_active()))
+      return false; // (fpr is written by the per-atom ANN kernel, the matrix-core kernel and the fused angular kernel)
     const ForceWinBody<S, 1, false, false, true> body{ws2, md_, nullptr};
     return body.lds_bytes() <= 80 * 1024;
   }
@@ -2160,7 +2205,17 @@ public:
                     model_.basis_size_angular, model_.num_L, model_.num_types <= 2 ? std::to_string(model_.num_types).c_str() : "T");
       s += jb;
     } else {
-      s += std::string("shape=") + shapes[shape_ >= 0 && shape_ <= 5 ? shape_ : 0];
+      if (shape_ == 7 || shape_ == 8) {
+        s += shape_ == 7 ? "shape=cover(8,12,8,12,6;T)" : "shape=cover(12,16,10,12,6;T)";
+        if (model_.embedded()) {
+          char eb[128];
+          std::snprintf(eb, sizeof eb, "<-zero_padded_model(%d,%d,%d,%d,%d)", model_.file_n_max_radial, model_.file_basis_size_radial,
+                        model_.file_n_max_angular, model_.file_basis_size_angular, model_.file_num_L);
+          s += eb;
+        }
+      } else {
+        s += std::string("shape=") + shapes[shape_ >= 0 && shape_ <= 5 ? shape_ : 0];
+      }
     }
     if (last_small_)
       return s + " path=small_box(all image pairs)";
@@ -2174,8 +2229,8 @@ public:
       s += " angular=descriptor+ann+partial_forces_in_one_kernel(lane_pairs,sums_in_registers)";
     else if (fuse_ann_active())
       s += " ann=fused_with_angular_descriptor(packed_fp32,no_mfma)";
-    else if (ann_mode_ != 0 && b_.ann_img)
-      s += " ann=mfma_f32_32x32x2";
+    else if (ann_mode_ != 0 && b_.ann_img && (model_.num_types <= 4 || b_.skip_atab))
+      s += model_.num_types > 4 ? " ann=mfma_f32_32x32x2(one_type_per_workgroup)" : " ann=mfma_f32_32x32x2";
     else
       s += " ann=per_atom";
     if (!last_ang_fused_) {
@@ -2261,6 +2316,8 @@ private:
   bool last_sync_form_ = false;
   int guard_delay_ = 0;          // set_scatter_guard_delayed
   int guard_delay_next_ = 0;
+  const int* dmap_dev_ = nullptr; // NepModel::dmap on the device (export_descriptors of a zero-padded model)
+  double hard_asked_ = 4.0;      // set_scatter_guard: the hard factor as asked for
   double guard_delayed_ = 64.0;
   bool use_csync_ = true;
   bool ccode_valid_ = true;      // the compact radial list of the last force evaluation exists (else: the masks, Bufs::rmaskB)

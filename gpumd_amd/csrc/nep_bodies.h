@@ -801,10 +801,14 @@ inline AnnMfmaShape ann_mfma_shape(int T, int dim, int nneu, int KRP)
 {
   AnnMfmaShape a;
   a.MT = (nneu + 31) / 32;
-  a.DT = (dim + T * KRP + 31) / 32;
+  // more than four types (UNEP-v1: 16): output rows = Fp only -- the radial-table rows (T KRP per atom) are what the force
+  // assembly of such models does not read (it contracts from the atom's radial Fp row, Bufs::fpr); one workgroup then serves ONE
+  // type over several chunks (engine.hip: nepmi_ann_mfma<.., BYTYPE>), operand buffer of 24 k-pairs
+  const bool many = T > 4;
+  a.DT = ((many ? dim : dim + T * KRP) + 31) / 32;
   a.KS = (dim + 1) / 2;
   a.img_floats = (size_t)(a.KS * a.MT + a.MT * 16 * a.DT) * 64 + 2 * a.MT * 32;
-  a.ok = T <= 4 && a.MT <= 4 && a.DT <= 4 && a.KS <= 40 && a.img_floats * sizeof(float) <= 144 * 1024;
+  a.ok = a.MT <= 4 && a.DT <= 4 && a.KS <= (many ? 24 : 40) && a.img_floats * sizeof(float) <= 144 * 1024;
   return a;
 }
 struct IdentityOrderBody { // q / fp columns in internal atom order (fused descriptor + ANN kernel)
@@ -2597,15 +2601,17 @@ struct ExportDescBody {
   int dim;
   float* q_out;
   float* fp_out;
+  const int* dmap; // component d of the caller's arrays = component dmap[d] of the engine's (nullptr: the same)
   NEPMI_HD void operator()(int64_t k) const
   {
     const int64_t N = b.N;
     const int64_t i = b.perm[k];
     for (int d = 0; d < dim; ++d) {
+      const int de = dmap ? dmap[d] : d;
       if (q_out)
-        q_out[(int64_t)d * N + i] = b.q[(int64_t)d * N + b.tpos[k]];
+        q_out[(int64_t)d * N + i] = b.q[(int64_t)de * N + b.tpos[k]];
       if (fp_out)
-        fp_out[(int64_t)d * N + i] = b.fp[(int64_t)d * N + b.tpos[k]];
+        fp_out[(int64_t)d * N + i] = b.fp[(int64_t)de * N + b.tpos[k]];
     }
   }
 };

@@ -131,6 +131,16 @@ struct AngularFusedBody {
     descriptor_and_ann(k, part, lds, t1, s, Fp, e);
     if (part == 0)
       b.pe_i[k] = e;
+    // many-type form of the force assembly (shapes without type-pure lists): the atom's radial Fp row, atom-major -- each lane
+    // its own components (what AnnBody writes for it)
+    if (b.fpr) {
+#pragma unroll
+      for (int i = 0; i < F::NRH; ++i) {
+        const int n = 2 * i + part;
+        if (n <= S::NR)
+          b.fpr[(size_t)k * b.FPR + n] = Fp[i];
+      }
+    }
     // ---- radial force table A[t2][k] = sum_n Fp[n] c[t1][t2][n][k]: two half sums; lane t2 mod 2 stores row t2 ----
     if (!b.skip_atab && NEPMI_AFU_ABL != 4) {
       constexpr int KRPC = (S::KR + 1 + 3) / 4 * 4; // = Bufs::KRP: rows of whole 16-byte groups

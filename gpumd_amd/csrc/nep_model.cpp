@@ -321,4 +321,75 @@ std::string load_nep_model(const std::string& path, NepModel& m, bool* unsupport
   return "";
 }
 
+bool embed_model(NepModel& m, int NR, int KR, int NA, int KA)
+{
+  if (m.kind != 0 || m.embedded() || m.L_max < 1 || m.L_max > 4 || m.has_q_112 || m.has_q_123 || m.has_q_233 || m.has_q_134)
+    return false;
+  if (m.n_max_radial > NR || m.basis_size_radial > KR || m.n_max_angular > NA || m.basis_size_angular > KA)
+    return false;
+  const int T = m.num_types, nn = m.num_neurons;
+  const int nR0 = m.n_max_radial + 1, nA0 = m.n_max_angular + 1, kR0 = m.basis_size_radial + 1, kA0 = m.basis_size_angular + 1;
+  const int nR1 = NR + 1, nA1 = NA + 1, kR1 = KR + 1, kA1 = KA + 1;
+  const int rows1 = 6; // L = 1, 2, 3, 4, then 222, then 1111
+  const int dim0 = m.dim, dim1 = nR1 + nA1 * rows1;
+  // the file's row r (0 .. num_L - 1: L = 1 .. l_max, then 222, then 1111, as far as the model has them) -> padded row
+  std::vector<int> row_of(m.num_L);
+  {
+    int r = 0;
+    for (int L = 1; L <= m.L_max; ++L)
+      row_of[r++] = L - 1;
+    if (m.has_q_222)
+      row_of[r++] = 4;
+    if (m.has_q_1111)
+      row_of[r++] = 5;
+  }
+  std::vector<int> dmap(dim0);
+  for (int n = 0; n < nR0; ++n)
+    dmap[n] = n;
+  for (int r = 0; r < m.num_L; ++r)
+    for (int n = 0; n < nA0; ++n)
+      dmap[nR0 + r * nA0 + n] = nR1 + row_of[r] * nA1 + n;
+  // ANN input weights and the descriptor scaler on the padded components: zero
+  std::vector<float> w0((size_t)T * nn * dim1, 0.0f), qs(dim1, 0.0f);
+  for (int t = 0; t < T; ++t)
+    for (int j = 0; j < nn; ++j)
+      for (int d = 0; d < dim0; ++d)
+        w0[((size_t)t * nn + j) * dim1 + dmap[d]] = m.w0[((size_t)t * nn + j) * dim0 + d];
+  for (int d = 0; d < dim0; ++d)
+    qs[dmap[d]] = m.q_scaler[d];
+  std::vector<float> cr((size_t)T * T * nR1 * kR1, 0.0f), ca((size_t)T * T * nA1 * kA1, 0.0f);
+  for (int pair = 0; pair < T * T; ++pair) {
+    for (int n = 0; n < nR0; ++n)
+      for (int k = 0; k < kR0; ++k)
+        cr[((size_t)pair * nR1 + n) * kR1 + k] = m.c_rad[((size_t)pair * nR0 + n) * kR0 + k];
+    for (int n = 0; n < nA0; ++n)
+      for (int k = 0; k < kA0; ++k)
+        ca[((size_t)pair * nA1 + n) * kA1 + k] = m.c_ang[((size_t)pair * nA0 + n) * kA0 + k];
+  }
+  m.file_n_max_radial = m.n_max_radial;
+  m.file_n_max_angular = m.n_max_angular;
+  m.file_basis_size_radial = m.basis_size_radial;
+  m.file_basis_size_angular = m.basis_size_angular;
+  m.file_L_max = m.L_max;
+  m.file_has_q_222 = m.has_q_222;
+  m.file_has_q_1111 = m.has_q_1111;
+  m.file_num_L = m.num_L;
+  m.file_dim = m.dim;
+  m.dmap.swap(dmap);
+  m.w0.swap(w0);
+  m.q_scaler.swap(qs);
+  m.c_rad.swap(cr);
+  m.c_ang.swap(ca);
+  m.n_max_radial = NR;
+  m.n_max_angular = NA;
+  m.basis_size_radial = KR;
+  m.basis_size_angular = KA;
+  m.L_max = 4;
+  m.has_q_222 = 1;
+  m.has_q_1111 = 1;
+  m.num_L = rows1;
+  m.dim = dim1;
+  return true;
+}
+
 } // namespace nepmi

@@ -55,10 +55,27 @@ struct NepModel {
   std::vector<float> q_scaler;
   std::vector<float> rc_radial_f, rc_angular_f;
   std::vector<float> zbl_para_f;
+
+  // --- a model served by the kernels of a LARGER compiled shape (embed_model below) ---
+  // dmap[d of the file's descriptor] = component of the padded descriptor (identity, empty, for a model that is not embedded);
+  // file_* keep the header as the file states it (nepmi_model_info reports the model, not the kernels that serve it)
+  std::vector<int> dmap;
+  int file_n_max_radial = 0, file_n_max_angular = 0, file_basis_size_radial = 0, file_basis_size_angular = 0;
+  int file_L_max = 0, file_has_q_222 = 0, file_has_q_1111 = 0, file_num_L = 0, file_dim = 0;
+  bool embedded() const { return !dmap.empty(); }
 };
 
 // returns empty string on success, else the error text; *unsupported is set when the file is a
 // valid NEP model that this engine does not cover (charge/dipole variants, extra invariants...).
 std::string load_nep_model(const std::string& path, NepModel& m, bool* unsupported);
+
+// Zero padding into a larger shape: n_max -> NR / NA, basis_size -> KR / KA, invariant rows -> L = 1..4, 222, 1111.  The
+// padded radial functions have zero coefficients (their descriptor components are identically zero), the padded basis
+// functions multiply zero coefficients, and the ANN's weights on every padded component are zero -- so energies, forces
+// and virials are those of the model itself (sums of exact zeros added), evaluated by kernels compiled for the larger
+// shape: what a model of a shape nobody compiled kernels for gets instead of the run-time-shape kernels (capi_impl.h).
+// Needs: a NEP model with l_max_3body <= 4 and none of the optional rows 112 / 123 / 233 / 134, n_max <= NR / NA,
+// basis_size <= KR / KA.  Returns false (m untouched) otherwise.
+bool embed_model(NepModel& m, int NR, int KR, int NA, int KA);
 
 } // namespace nepmi

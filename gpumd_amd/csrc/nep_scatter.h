@@ -639,7 +639,7 @@ struct ScatterLayoutMT {
   __device__ __host__ int bytes() const { return 25 * wmax + 4 * ctab_floats; }
 };
 
-template <class S, bool OUT, int L>
+template <class S, bool OUT, int L, int MODE = 0>
 __device__ __forceinline__ void force_scatter_atom_mt(const ForceScatterBody<S>& B, const int64_t brick, const int64_t k, const int sub,
                                                       NEPMI_LDS(char)* lds, const ScatterLayoutMT lay)
 {
@@ -750,8 +750,26 @@ __device__ __forceinline__ void force_scatter_atom_mt(const ForceScatterBody<S>&
     lds_sub(r0 + 1, ay);
     lds_sub(r0 + 2, az);
   };
-  // this lane's entries: sub, sub + L, ...; the next one requested while the current one is evaluated
-  {
+  if constexpr (MODE == 2) {
+    // Wave-synchronous words (nep_window.h: SyncFifo; one stream): row r of Bufs::cword holds four entries of this atom's list --
+    // one for each of its L = 4 lanes (the lanes of an atom read the same 8 bytes: one request); the sentinel slot is padding
+    static_assert(L == 4, "one entry of every word per lane");
+    const int rows = b.nn_t0[k] & 255;
+    const unsigned sent = (unsigned)b.wsent;
+    const U2w* __restrict__ wq = reinterpret_cast<const U2w*>(b.cword) + k;
+    const int last = rows > 0 ? rows - 1 : 0;
+    U2w cur = wq[0], nxt = wq[(int64_t)(1 < last ? 1 : last) * N];
+    for (int r = 0; r < (NEPMI_FS_ABL == 2 ? 0 : rows); ++r) {
+      const U2w c = cur;
+      cur = nxt;
+      nxt = wq[(int64_t)(r + 2 < last ? r + 2 : last) * N];
+      const unsigned half = (sub & 2) ? c.hi : c.lo;
+      const unsigned slot = (sub & 1) ? (half >> 16) : (half & 0xFFFFu);
+      if (slot != sent)
+        one_pair(slot);
+    }
+  } else {
+    // this lane's entries: sub, sub + L, ...; the next one requested while the current one is evaluated
     const unsigned short* __restrict__ q = b.ccode + k + (int64_t)sub * N;
     const int64_t stride = (int64_t)L * N;
     unsigned cur = 0, nxt = 0;
@@ -845,7 +863,7 @@ __device__ __forceinline__ void force_scatter_atom_mt(const ForceScatterBody<S>&
     fo[(int64_t)(kOutW + d) * N] = Wd[d];
 }
 
-template <class S, bool OUT, int L>
+template <class S, bool OUT, int L, int MODE>
 __global__ void __launch_bounds__(kWinThreads * L) nepmi_force_scatter_mt_kernel(const ForceScatterBody<S> body, const int64_t nbricks)
 {
   constexpr int NT = kWinThreads * L;
@@ -903,7 +921,7 @@ __global__ void __launch_bounds__(kWinThreads * L) nepmi_force_scatter_mt_kernel
   body.st.brick_range(brick, a0, a1);
   const int sub = tid % L;
   for (int64_t k = a0 + tid / L; k < a1; k += kWinThreads)
-    force_scatter_atom_mt<S, OUT, L>(body, brick, k, sub, lds, lay);
+    force_scatter_atom_mt<S, OUT, L, MODE>(body, brick, k, sub, lds, lay);
   __syncthreads();
   {
     NEPMI_LDS(const I3)* acc = (NEPMI_LDS(const I3)*)(lds + lay.off_acc());

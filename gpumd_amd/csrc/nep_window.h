@@ -984,6 +984,42 @@ struct RadialWin2Body {
     U2w* __restrict__ cword = reinterpret_cast<U2w*>(b.cword) + k;
     unsigned long long accf = 0ull, accb = 0ull;
     unsigned mcur = 0u; // the mask word being filled (Bufs::rmaskA / rmaskB)
+    // one-wide accumulation with the coefficients contracted per pair (many types / run-time shape)
+    auto accumulate1 = [&](const Cand& c) __attribute__((always_inline)) {
+      if (!c.inside)
+        return;
+      const int t2 = (int)((unsigned)c.rw >> kIdxBits);
+      const float rc = m.uniform_rc ? m.rc_r_max : (rc1 + m.rc_r[t2]) * 0.5f;
+      float d, dinv;
+      dist_and_inv(c.d2, d, dinv);
+      const float rcinv = fast_rcp(rc);
+      const float dc = d < rc ? d : rc;
+      float fc;
+      cutoff_fc(rcinv, dc, fc);
+      float fn[S::KRM + 1];
+      if (S::fixed)
+        basis_fn<S::KRM>(rcinv, dc, fc, fn);
+      else
+        basis_fn_rt(KR, rcinv, dc, fc, fn);
+      if (ctab) {
+        float g[S::NRM + 1];
+        ctab_contract<S, false>(ctab_lds + (t1 * m.T + t2) * ctab_block(NR, KR, false), NR, KR, fn, g);
+#pragma unroll
+        for (int n = 0; n <= S::NRM; ++n) {
+          if (!S::fixed && n > NR)
+            break;
+          q[n] += g[n];
+        }
+      } else {
+        const float* cc = m.c_rad + (t1 * m.T + t2) * (NR + 1) * (KR + 1);
+        for (int n = 0; n <= NR; ++n) {
+          float gsum = 0.0f;
+          for (int kk = 0; kk <= KR; ++kk)
+            gsum += fn[kk] * cc[n * (KR + 1) + kk];
+          q[n] += gsum;
+        }
+      }
+    };
     // SYNC: the compact list as WAVE-SYNCHRONOUS words (see SyncFifo above): the accepted slots wait in the lane's queue and
     // every lane of the wavefront stores one 8-byte word of four at the same time
     SyncFifo q0, q1;
@@ -992,6 +1028,10 @@ struct RadialWin2Body {
     U2w* __restrict__ sync0 = cword;
     U2w* __restrict__ sync1 = cword + (int64_t)b.MN_cw * N;
     const unsigned long long sent64 = 0x0001000100010001ull * (unsigned long long)(unsigned)b.wsent;
+    // (Measured and dropped, r6c: many-type shapes evaluating a neighbour when its word LEAVES the queue -- basis functions and the
+    // c[t1][t2] contraction once per row of the padded list, 74 instead of 96 times per atom for UNEP-v1: 1.02 ms against 0.99.
+    // Neither the compact-list stores nor the number of contractions bind that kernel; two workgroups per CU -- the 46 KB
+    // coefficient table next to the window -- leave the walk's dependent chain of LDS reads uncovered.)
     auto sync_emit = [&](SyncFifo& f, U2w* __restrict__& at) __attribute__((always_inline)) {
       const unsigned long long w = f.pop_word(sent64);
       if (f.rows < b.MN_cw) {
@@ -1121,42 +1161,6 @@ struct RadialWin2Body {
       cutoff_fc_v(rcinv, dc, fc);
       fc = fc * mk2(c0.inside ? 1.0f : 0.0f, c1.inside ? 1.0f : 0.0f);
       basis_fn_v<S::KRM>(rcinv, dc, fc, fn);
-    };
-    // one-wide accumulation with the coefficients contracted per pair (many types / run-time shape)
-    auto accumulate1 = [&](const Cand& c) __attribute__((always_inline)) {
-      if (!c.inside)
-        return;
-      const int t2 = (int)((unsigned)c.rw >> kIdxBits);
-      const float rc = m.uniform_rc ? m.rc_r_max : (rc1 + m.rc_r[t2]) * 0.5f;
-      float d, dinv;
-      dist_and_inv(c.d2, d, dinv);
-      const float rcinv = fast_rcp(rc);
-      const float dc = d < rc ? d : rc;
-      float fc;
-      cutoff_fc(rcinv, dc, fc);
-      float fn[S::KRM + 1];
-      if (S::fixed)
-        basis_fn<S::KRM>(rcinv, dc, fc, fn);
-      else
-        basis_fn_rt(KR, rcinv, dc, fc, fn);
-      if (ctab) {
-        float g[S::NRM + 1];
-        ctab_contract<S, false>(ctab_lds + (t1 * m.T + t2) * ctab_block(NR, KR, false), NR, KR, fn, g);
-#pragma unroll
-        for (int n = 0; n <= S::NRM; ++n) {
-          if (!S::fixed && n > NR)
-            break;
-          q[n] += g[n];
-        }
-      } else {
-        const float* cc = m.c_rad + (t1 * m.T + t2) * (NR + 1) * (KR + 1);
-        for (int n = 0; n <= NR; ++n) {
-          float gsum = 0.0f;
-          for (int kk = 0; kk <= KR; ++kk)
-            gsum += fn[kk] * cc[n * (KR + 1) + kk];
-          q[n] += gsum;
-        }
-      }
     };
 
     // The packed sums: ZIP: SS[k] = {sum over type-0 neighbours, sum over type-1 neighbours}; one type: the two halves

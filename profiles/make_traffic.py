@@ -1,6 +1,6 @@
 """fetch/write PMC summaries (summarize_rocpd.py pmc) -> traffic json read by bench.py.
 
-  python profiles/make_traffic.py profiles/r1e_pmc_fetch.csv profiles/r1e_pmc_write.csv 1024000 profiles/r1e_traffic.json
+  python profiles/make_traffic.py profiles/r1e_pmc_fetch.csv profiles/r1e_pmc_write.csv 1024000 profiles/r1e_traffic.json [merged_by_atoms.json]
 
 bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE/WRITE_SIZE are in KiB, and on gfx950
 FETCH_SIZE tallies the 128-byte fabric read requests at 64 bytes (MI355X_MICROARCH.md, HBM section).
@@ -51,10 +51,18 @@ def main():
     for name in fetch:
         w = write.get(name, 0.0)
         kern[name] = {"fetch_kb": fetch[name], "write_kb": w, "hbm_bytes_per_launch": (2.0 * fetch[name] + w) * 1024.0}
-    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `bench.py --steps 6 --warmup 2`; "
-                         "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch (gfx950 FETCH_SIZE correction, "
-                         "MI355X_MICROARCH.md)", "atoms": int(sys.argv[3]), "kernels": kern},
-              open(sys.argv[4], "w"), indent=1)
+    entry = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of `bench.py --steps 6 --warmup 2`; "
+                       "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch (gfx950 FETCH_SIZE correction, "
+                       "MI355X_MICROARCH.md)", "atoms": int(sys.argv[3]), "kernels": kern}
+    # --merge FILE (6th argument): add this entry to a by_atoms file (one entry per workload size: bench.py: load_traffic)
+    if len(sys.argv) > 5:
+        import os
+        merged = json.load(open(sys.argv[5])) if os.path.exists(sys.argv[5]) else {}
+        if "by_atoms" not in merged:
+            merged = {"source": entry["source"], "by_atoms": {}}
+        merged["by_atoms"][str(entry["atoms"])] = entry
+        json.dump(merged, open(sys.argv[5], "w"), indent=1)
+    json.dump(entry, open(sys.argv[4], "w"), indent=1)
 
 
 if __name__ == "__main__":

@@ -125,6 +125,21 @@ def case_inputs(name, d):
         shutil.copy(os.path.join(GOLD, "UNEP", "nep.txt"), os.path.join(d, "nep.txt"))
         run = "replicate 4 4 4\npotential nep.txt\nvelocity 300\nensemble nve\ntime_step 1\ndump_thermo 20\nrun 200\n"
         n = 4 * 16 ** 3 * 64
+    elif name == "unep_256k":
+        # config 4's model where the run loop takes the many-type LDS scatter: 4 x 40^3 = 256,000 atoms = 1,000 bricks
+        symbols = open(os.path.join(GOLD, "UNEP", "nep.txt")).readline().split()[2:]
+        lat, spec, pos = fcc_alloy_cell(3.9, symbols, 40)
+        write_xyz(os.path.join(d, "model.xyz"), lat, spec, pos)
+        shutil.copy(os.path.join(GOLD, "UNEP", "nep.txt"), os.path.join(d, "nep.txt"))
+        run = "potential nep.txt\nvelocity 2000\nensemble nve\ntime_step 1\ndump_thermo 10\nrun 100\n"
+        n = 4 * 40 ** 3
+    elif name == "carbon_262k":
+        # config 5's model at >= 768 bricks: 8 x 32^3 = 262,144 atoms
+        lat, spec, pos = diamond_cell(3.57, "C")
+        write_xyz(os.path.join(d, "model.xyz"), lat, spec, pos)
+        shutil.copy(os.path.join(GOLD, "C", "nep.txt"), os.path.join(d, "nep.txt"))
+        run = "replicate 32 32 32\npotential nep.txt\nvelocity 2000\nensemble nve\ntime_step 1\ndump_thermo 10\nrun 100\n"
+        n = 8 * 32 ** 3
     else:
         raise SystemExit("unknown case " + name)
     if FINE:
@@ -136,7 +151,7 @@ def case_inputs(name, d):
         run = re.sub(r"velocity [^\n]*\n", "", run)
         m = re.search(r"replicate (\d+) (\d+) (\d+)\n", run)
         reps = tuple(int(v) for v in m.groups()) if m else (1, 1, 1)
-        cap = 10 if name == "pbte_250k" else 4 if name.startswith("pbte") else (20 if name.startswith("carbon") else (1 if name == "unep" else 99))
+        cap = 99 if name in ("unep_256k", "carbon_262k") else 10 if name == "pbte_250k" else 4 if name.startswith("pbte") else (20 if name.startswith("carbon") else (1 if name == "unep" else 99))
         reps = tuple(min(r, cap) for r in reps)  # explicit files: 13,824 to 64,000 atoms
         run = re.sub(r"replicate [^\n]*\n", "", run)
         from gpumd_amd import structures as S
@@ -152,7 +167,10 @@ def case_inputs(name, d):
         pos = np.concatenate(pos)
         lat = (h * np.asarray(reps, dtype=np.float64)[None, :]).T.reshape(9)
         mass = np.array([S.MASS.get(e, 100.0) for e in spec])  # only shapes the velocity distribution
-        vel = S.maxwell_velocities(mass, 300.0, seed=3).reshape(3, -1).T / S.TIME_UNIT  # model.xyz carries A/fs
+        # (the two large cases start hot: perfect lattices at 300 K would not rebuild their lists within a hundred steps)
+        # (diamond is stiff: only a very hot start moves an atom past skin / 2 within a hundred steps)
+        t_start = {"unep_256k": 2000.0, "carbon_262k": 8000.0}.get(name, 300.0)
+        vel = S.maxwell_velocities(mass, t_start, seed=3).reshape(3, -1).T / S.TIME_UNIT  # model.xyz carries A/fs
         with open(os.path.join(d, "model.xyz"), "w") as f:
             f.write("%d\n" % len(spec))
             f.write('pbc="T T T" Lattice="%s" Properties=species:S:1:pos:R:3:vel:R:3\n' % " ".join("%.12g" % v for v in lat))

@@ -22,6 +22,19 @@ def test_force_parity_generic_shape(drv, name):
     P.check_force_parity(drv, name, generic=True, check_lists=False)
 
 
+@pytest.mark.parametrize("name,forced", [("Si-3body", False), ("Si-4body", False), ("water-model", True), ("PbTe-A", True), ("C-2022", True)])
+def test_force_parity_zero_padded_into_a_cover_shape(drv, name, forced, monkeypatch):
+    """A model of a shape nobody compiled kernels for is zero-padded into a compiled COVER shape (nep_model.h: embed_model; here
+    with NEPMI_JIT=2: existing cores only): zero coefficients on the padded radial functions and basis functions, zero ANN
+    weights on the padded descriptor components -- the model's own energies, forces, virials, lists and (through the component
+    map) descriptors, against the oracle with the suite's tolerances.  forced: a model of a compiled shape padded all the same."""
+    monkeypatch.setenv("NEPMI_JIT", "2")
+    if forced:
+        monkeypatch.setenv("NEPMI_FORCE_COVER", "1")
+    eng = P.check_force_parity(drv, name)
+    assert "shape=cover(" in eng.describe() and "zero_padded_model" in eng.describe(), eng.describe()
+
+
 @pytest.mark.parametrize("name", ["PbTe-A", "PbTe-ortho", "UNEP-v1"])
 def test_force_parity_without_lds_window(drv, name):
     """the plain gather radial kernel (fallback of the LDS-window pass) gives the same answers"""

@@ -30,16 +30,30 @@ def test_force_parity_without_lds_window(drv, name):
     P.check_force_parity(drv, name, tiles=False)
 
 
+@pytest.mark.parametrize("name,forced", [("Si-3body", False), ("Si-4body", False), ("water-model", True), ("PbTe-A", True),
+                                         ("PbTe-ortho-big", True), ("C-2022", True)])
+def test_force_parity_zero_padded_into_a_cover_shape(drv, name, forced, monkeypatch):
+    """tests/test_emu_parity.py::test_force_parity_zero_padded_into_a_cover_shape on the real kernels: a model without compiled
+    kernels of its own shape served, zero-padded, by a compiled cover shape -- against the oracle."""
+    monkeypatch.setenv("NEPMI_JIT", "2")
+    if forced:
+        monkeypatch.setenv("NEPMI_FORCE_COVER", "1")
+    eng = P.check_force_parity(drv, name, f32_atol=4e-5)
+    assert "shape=cover(" in eng.describe() and "zero_padded_model" in eng.describe(), eng.describe()
+
+
 @pytest.mark.parametrize("name", ["PbTe-A", "C-2022", "BaZrO3"])
 def test_force_parity_without_mfma(drv, name):
     """The per-atom ANN kernel (taken automatically for many-type models such as UNEP-v1)."""
     P.check_force_parity(drv, name, check_lists=False, mfma=False)
 
 
-@pytest.mark.parametrize("name", ["PbTe-A", "PbTe-B", "C-2022", "BaZrO3"])
+@pytest.mark.parametrize("name", ["PbTe-A", "PbTe-B", "C-2022", "BaZrO3", "UNEP-v1-big"])
 def test_mfma_ann_matches_per_atom_ann(drv, name):
     """Matrix-core ANN (mode 2) and the fused descriptor + ANN kernel (mode 1, where the shape allows it) vs the per-atom
-    ANN kernel (mode 0): same contractions, different f32 summation order."""
+    ANN kernel (mode 0): same contractions, different f32 summation order.  UNEP-v1 (16 types): the by-type form of the
+    matrix-core kernel (one workgroup serves one type over sixteen chunks; no radial-table rows -- it runs where the force
+    assembly contracts from the atoms' radial Fp rows, i.e. on the one-lane window kernels)."""
     nep_rel, build, _ = P.MODELS[name]
     nep = H.golden(*nep_rel.split("/"))
     h, typ, x = build()
@@ -49,7 +63,11 @@ def test_mfma_ann_matches_per_atom_ann(drv, name):
     for on in (2, 0, 1):
         eng = drv.engine(model, n)
         eng.set_mfma(on)
+        if name.startswith("UNEP"):
+            eng.set_win_lanes(1)
         _, pe, f, v = H.engine_force(drv, eng, h, typ, x)
+        if name.startswith("UNEP"):
+            assert ("ann=mfma_f32_32x32x2(one_type_per_workgroup)" in eng.describe()) == (on != 0), eng.describe()
         q = drv.zeros(model.info.dim * n, dtype=np.float32)
         fp = drv.zeros(model.info.dim * n, dtype=np.float32)
         eng.descriptors(q, fp)

@@ -31,7 +31,7 @@ def test_prebuilt_core_is_found_and_serves_the_model(name, monkeypatch, capfd):
     monkeypatch.setenv("NEPMI_JIT", "2")
     m = gpumd_amd.Model(nep)
     err = capfd.readouterr().err
-    assert "no kernels compiled" not in err, err
+    assert "no JIT core" not in err and "zero-padded" not in err, err
     monkeypatch.setenv("NEPMI_JIT", "0")
     m0 = gpumd_amd.Model(nep)
     import ctypes as C
@@ -51,14 +51,22 @@ def test_a_model_of_a_compiled_shape_stays_with_the_library(monkeypatch, capfd):
     m.close()
 
 
-def test_without_a_core_the_run_time_shape_kernels_serve_the_model(monkeypatch, capfd):
-    """NEPMI_JIT=2 and no core for the shape (Si with the 4-body row only: 10,10,10,10,5;1): one line on stderr, the model loads"""
+def test_without_a_core_a_cover_shape_serves_the_model(monkeypatch, capfd):
+    """NEPMI_JIT=2 and no core for the shape (Si with the 4-body row only: 10,10,10,10,5;1): the model is zero-padded into the smallest
+    compiled COVER shape that holds it (12,16,10,12, six rows; nep_model.h: embed_model) -- one line on stderr says so --, and
+    nepmi_model_info keeps reporting the MODEL, not the kernels that serve it.  NEPMI_COVER=0: the run-time-shape kernels."""
     import gpumd_amd
     assert not _core("10_10_10_10_5_1")
     monkeypatch.setenv("NEPMI_JIT", "2")
     m = gpumd_amd.Model(H.golden("Si", "nep_4body.txt"))
-    assert "run-time-shape kernels serve it" in capfd.readouterr().err
-    assert m.info.num_types == 1 and m.info.num_L == 5
+    err = capfd.readouterr().err
+    assert "zero-padded" in err and "n_max 12 10, basis_size 16 12" in err, err
+    assert m.info.num_types == 1 and m.info.num_L == 5 and m.info.n_max_radial == 10 and m.info.basis_size_angular == 10
+    assert m.info.dim == 11 + 11 * 5
+    m.close()
+    monkeypatch.setenv("NEPMI_COVER", "0")
+    m = gpumd_amd.Model(H.golden("Si", "nep_4body.txt"))
+    assert "run-time-shape kernels serve this model" in capfd.readouterr().err
     m.close()
 
 
@@ -77,7 +85,7 @@ def test_first_load_of_a_new_shape_compiles_its_core(monkeypatch, capfd, tmp_pat
     nep = H.golden("Si", "nep_4body.txt")
     m = gpumd_amd.Model(nep)
     err = capfd.readouterr().err
-    assert "compiling the NEP kernels for this model's shape" in err and "no kernels compiled" not in err, err
+    assert "compiling the NEP kernels for this model's shape" in err and "no JIT core" not in err, err
     built = glob.glob(str(tmp_path / "cache" / "libnepmi_jit_10_10_10_10_5_1_*.so"))
     assert len(built) == 1, os.listdir(str(tmp_path / "cache"))
     assert not glob.glob(str(tmp_path / "cache" / "*.lock")) and not glob.glob(str(tmp_path / "cache" / "*.tmp*"))
@@ -126,7 +134,7 @@ def test_a_core_built_from_other_sources_is_refused(tmp_path):
     env = dict(os.environ, NEPMI_JIT="2", NEPMI_JIT_CACHE=str(cache), PYTHONPATH=H.ROOT)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
-    assert "built from other sources" in r.stderr and "run-time-shape kernels serve it" in r.stderr, r.stderr
+    assert "built from other sources" in r.stderr and "zero-padded" in r.stderr, r.stderr
     assert "same_library True" in r.stdout, r.stdout
 
 

@@ -133,39 +133,53 @@ def test_200_steps_with_list_rebuilds_match_reference_gpumd(case, tmp_path):
     assert np.abs(a[:, 0] - a[0, 0]).max() > 20.0
 
 
-def test_scatter_form_run_loop_matches_reference_gpumd(tmp_path):
-    """The path the bench line times, under the reference's trajectory (missing 3): 250,000 PbTe atoms = 1,000 bricks,
-    where the run loop's counted rule takes the fused angular kernel and the scatter form of the force assembly (forces-only
-    steps, fixed-point window sums, fold) -- asserted through the forms gpumd-mi reports; 120 steps with a thermo.out row every
-    6th step from the hot model.xyz snapshot, so that both programs rebuild their lists inside the run."""
+# (case, atoms, steps, forms the run loop must report, rtol of T / K / U, atol of the stresses in GPa)
+SCATTER_CASES = {
+    "pbte_250k": (250000, 120, ("lds_scatter_of_own_halves", "partial_forces_in_one_kernel"), 1e-5, 2e-3),
+    # configs 4 and 5's models where their run loops take the LDS scatter (>= 768 bricks), started at 2000 K so that both
+    # programs rebuild their lists inside the 100 steps (missing 5)
+    "unep_256k": (256000, 100, ("lds_scatter_of_own_halves",), 1e-5, 2e-3),
+    "carbon_262k": (262144, 100, ("lds_scatter_of_own_halves", "partial_forces_in_one_kernel"), 1e-5, 2e-3),
+}
+
+
+@pytest.mark.parametrize("case", sorted(SCATTER_CASES))
+def test_scatter_form_run_loop_matches_reference_gpumd(case, tmp_path):
+    """The path the bench lines time, under the reference's trajectory (missing 3; r5, missing 5): systems of about a
+    thousand bricks, where the run loop's counted rule takes the scatter form of the force assembly (forces-only steps,
+    fixed-point window sums, fold; PbTe and carbon: behind the fused angular kernel; UNEP-v1: the many-type scatter) -- asserted
+    through the forms gpumd-mi reports; a thermo.out row every 6th step, and both programs rebuild their lists inside the run."""
     import ref_compare as R
     if not os.path.exists(R.REF):
         pytest.skip("oracle/_ref/gpumd_ref not built (needs /root/reference at build time)")
-    R.FINE = 120
+    natoms, steps, want, rt, ap = SCATTER_CASES[case]
+    R.FINE = steps
     try:
         th, out = {}, {}
         for tag, exe in (("ref", R.REF), ("mi", R.MI)):
             d = str(tmp_path / tag)
-            n = R.case_inputs("pbte_250k", d)
-            run_in = os.path.join(d, "run.in")  # a row every 6th step: the five steps in between are forces-only steps of the loop
-            text = open(run_in).read().replace("dump_thermo 1\n", "dump_thermo 6\n")
+            n = R.case_inputs(case, d)
+            run_in = os.path.join(d, "run.in")  # a row every 6th (5th) step: the steps in between are forces-only steps of the loop
+            every = 6 if steps % 6 == 0 else 5
+            text = open(run_in).read().replace("dump_thermo 1\n", "dump_thermo %d\n" % every)
             open(run_in, "w").write(text)
             res, th[tag] = R.run_binary(exe, d, 600.0)
             out[tag] = open(os.path.join(d, "stdout.txt")).read()
             assert res["rc"] == 0, out[tag][-2000:]
     finally:
         R.FINE = 0
-    assert n == 250000
+    assert n == natoms
     forms = [ln for ln in out["mi"].splitlines() if "libnepmi:" in ln]
-    assert forms and "lds_scatter_of_own_halves" in forms[-1] and "partial_forces_in_one_kernel" in forms[-1], forms
+    assert forms and all(w in forms[-1] for w in want), forms
     rebuilds = int(forms[-1].rsplit("list rebuilds so far:", 1)[1].strip(" )"))
     assert rebuilds >= 2, forms[-1]  # the initial build and at least one inside the run
     a, b = th["ref"], th["mi"]
-    assert a is not None and b is not None and a.shape == b.shape and a.shape[0] == 20
+    assert a is not None and b is not None and a.shape == b.shape and a.shape[0] == steps // every
     dev = [np.abs(b[:, c] / a[:, c] - 1.0).max() for c in (0, 1, 2)] + [np.abs(b[:, 3:9] - a[:, 3:9]).max()]
-    print("\n[120-step MD parity, scatter-form run loop, 250,000 atoms] max rel dT %.2e dK %.2e dU %.2e, max |dP| %.2e GPa" % tuple(dev))
-    np.testing.assert_allclose(b[:, 0], a[:, 0], rtol=1e-5)
-    np.testing.assert_allclose(b[:, 1], a[:, 1], rtol=1e-5)
-    np.testing.assert_allclose(b[:, 2], a[:, 2], rtol=1e-5)
-    np.testing.assert_allclose(b[:, 3:9], a[:, 3:9], rtol=0, atol=2e-3)
+    print("\n[%d-step MD parity, scatter-form run loop, %s, %d atoms] max rel dT %.2e dK %.2e dU %.2e, max |dP| %.2e GPa"
+          % ((steps, case, natoms) + tuple(dev)))
+    np.testing.assert_allclose(b[:, 0], a[:, 0], rtol=rt)
+    np.testing.assert_allclose(b[:, 1], a[:, 1], rtol=rt)
+    np.testing.assert_allclose(b[:, 2], a[:, 2], rtol=rt)
+    np.testing.assert_allclose(b[:, 3:9], a[:, 3:9], rtol=0, atol=ap)
     np.testing.assert_allclose(b[:, 9:], a[:, 9:], rtol=1e-12)
