@@ -1729,6 +1729,8 @@ int rccl_exchange(void* vctx, int ns, const nepmi_msg* sends, int nr, const nepm
   if (ev0 && ev1) {
     (void)hipEventRecord(ev1, (hipStream_t)stream);
     c->timed.emplace_back(ev0, ev1);
+  } else if (ev0) { // the second event could not be created: this exchange is not timed
+    (void)hipEventDestroy(ev0);
   }
   return ok ? 0 : -1;
 }

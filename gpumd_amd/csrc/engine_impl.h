@@ -1530,6 +1530,7 @@ private:
     if constexpr (B::kHasFusedAngular && S::fixed) {
       const size_t need = be_.template fused_image_floats<S>(md_);
       if (!fused_img_ || fused_img_floats_ < need) { // (once per engine: the shape does not change)
+        dfree(fused_img_);
         fused_img_ = dalloc<float>(need);
         fused_img_floats_ = need;
         fused_img_stale_ = true;

@@ -1020,6 +1020,60 @@ struct RadialWin2Body {
         }
       }
     };
+    // The same for the NC candidates of a word AT ONCE, without a branch (compiled many-type shapes with the table in LDS): a
+    // candidate outside the cutoff is evaluated at d = rc with weight zero and adds exact zeros, in the same order as the
+    // one-by-one form -- the sums are the same bit for bit.  Why: accumulate1 sits behind `if (inside)`, so the chains of the four
+    // candidates of a word (record -> distance -> 9 basis functions -> 45 table reads and multiply-adds) run one after the
+    // other.  Side by side the four chains are independent and interleave -- measured SLOWER (profiles/r6g_ab_wide.txt: UNEP-v1
+    // 1 M atoms, radial pass 1.196 ms against 0.983): the quarter of the candidates that lies in the skin is then contracted too,
+    // and the kernel's time follows the number of table reads (the LDS pipe is active 47 % of the kernel, two thirds of that
+    // bank conflicts: 64 lanes gather from 256 random blocks), not their latency.  Off (NEPMI_RW2_WIDE).
+    auto accumulate_wide = [&](const Cand* c, const int NC) __attribute__((always_inline)) {
+      constexpr int W = 4;
+      float fn[W][S::KRM + 1];
+      NEPMI_LDS(const float)* blk[W];
+#pragma unroll
+      for (int u = 0; u < W; ++u) {
+        if (u >= NC)
+          break;
+        const int t2 = (int)((unsigned)c[u].rw >> kIdxBits);
+        const float rc = m.uniform_rc ? m.rc_r_max : (rc1 + m.rc_r[t2]) * 0.5f;
+        float d, dinv;
+        dist_and_inv(c[u].d2, d, dinv);
+        const float rcinv = fast_rcp(rc);
+        const float dc = d < rc ? d : rc;
+        float fc;
+        cutoff_fc(rcinv, dc, fc);
+        fc *= c[u].inside ? 1.0f : 0.0f;
+        basis_fn<S::KRM>(rcinv, dc, fc, fn[u]);
+        blk[u] = ctab_lds + (t1 * m.T + t2) * ctab_block(NR, KR, false);
+      }
+      float g[W][S::NRM + 1];
+#pragma unroll
+      for (int n = 0; n <= S::NRM; ++n) {
+#pragma unroll
+        for (int u = 0; u < W; ++u)
+          g[u][n] = 0.0f;
+#pragma unroll
+        for (int kk = 0; kk <= S::KRM; ++kk)
+#pragma unroll
+          for (int u = 0; u < W; ++u)
+            if (u < NC)
+              g[u][n] = fmaf(blk[u][n * (S::KRM + 1) + kk], fn[u][kk], g[u][n]);
+      }
+#pragma unroll
+      for (int u = 0; u < W; ++u) {
+        if (u >= NC)
+          break;
+#pragma unroll
+        for (int n = 0; n <= S::NRM; ++n)
+          q[n] += g[u][n];
+      }
+    };
+#ifndef NEPMI_RW2_WIDE
+#define NEPMI_RW2_WIDE 0
+#endif
+    const bool wide = NEPMI_RW2_WIDE && S::fixed && S::TS == 0 && ctab;
     // SYNC: the compact list as WAVE-SYNCHRONOUS words (see SyncFifo above): the accepted slots wait in the lane's queue and
     // every lane of the wavefront stores one 8-byte word of four at the same time
     SyncFifo q0, q1;
@@ -1249,6 +1303,8 @@ struct RadialWin2Body {
               for (int kk = 0; kk <= S::KRM; ++kk)
                 SS[kk] = vfma(wt, fn[kk], SS[kk]);
             }
+          } else if (wide) {
+            accumulate_wide(c, 2);
           } else {
             accumulate1(c[0]);
             accumulate1(c[1]);
@@ -1360,6 +1416,8 @@ struct RadialWin2Body {
             for (int kk = 0; kk <= S::KRM; ++kk)
               SS[kk] = SS[kk] + fn[kk];
           }
+        } else if (wide) {
+          accumulate_wide(c, 4);
         } else {
 #pragma unroll
           for (int u = 0; u < 4; ++u)
