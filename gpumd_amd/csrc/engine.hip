@@ -359,6 +359,51 @@ nepmi_kernel_lds_pairs(const Body body, const int64_t n, const int* frozen)
     body.template run_parts<2>(i, (int)(threadIdx.x & 1u), (lds_cfloat_ptr)nepmi_lds_pairs);
 }
 
+// The fused angular kernel of MANY-TYPE models (nep_fused.h: AngularFusedBody with a type window): 256 threads = 128 atoms, two lanes
+// each, taken in the type-sorted work order of the matrix-core ANN (Bufs::tperm: sorted by type inside every 1024-atom chunk, and a
+// workgroup lies inside one chunk), so a workgroup's atoms span a few consecutive types.  It stages those types' slices of the image
+// -- kFusedWindowTypes at a time; a range that is longer (rare types) takes another pass -- and every lane pair whose type is
+// resident runs the whole chain descriptor -> ANN -> adjoint -> partial forces.
+// MEASURED SLOWER than the three kernels it replaces (profiles/r6i_ab_fused_window.txt: UNEP-v1 1 M atoms 2.19 ms against 0.51 + 0.32 +
+// 0.97): in the type-sorted order the 16-byte pair records of a wavefront's atoms lie in 32 different 64-byte sectors (35 pairs,
+// read twice: 4.5 GB through the L2 per step against 1.1 GB in brick order), and brick order would need every type's weights at
+// once.  Compiled only with -DNEPMI_WITH_FUSED_WINDOW=1 (make FUSED_WINDOW=1); the default step keeps descriptor / matrix-core ANN /
+// partial forces as three launches.
+#ifndef NEPMI_WITH_FUSED_WINDOW
+#define NEPMI_WITH_FUSED_WINDOW 0
+#endif
+constexpr int kFusedWindowTypes = 4;
+#if NEPMI_WITH_FUSED_WINDOW
+template <class Body>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(Body::kMinWavesPerEuPairs)))
+nepmi_fused_window_kernel(const Body body, const int64_t n, const int* frozen)
+{
+  extern __shared__ __attribute__((aligned(16))) float nepmi_lds_window[];
+  if (frozen && *frozen != 0)
+    return;
+  const unsigned per_xcd = gridDim.x >> 3;
+  const int64_t wg = (int64_t)(blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+  const int64_t i0 = wg * 128;
+  if (i0 >= n)
+    return;
+  const int tid = (int)threadIdx.x;
+  const int64_t i = i0 + (tid >> 1);
+  const bool live = i < n;
+  const int64_t k = body.b.tperm[live ? i : i0];
+  const int t1 = body.b.posq[k].type;
+  const int64_t ilast = i0 + 127 < n ? i0 + 127 : n - 1;
+  const int t_lo = body.b.posq[body.b.tperm[i0]].type, t_hi = body.b.posq[body.b.tperm[ilast]].type;
+  for (int tb = t_lo; tb <= t_hi; tb += kFusedWindowTypes) {
+    const int nt = body.m.T - tb < kFusedWindowTypes ? body.m.T - tb : kFusedWindowTypes;
+    __syncthreads(); // (the lanes of the pass before are done with the window)
+    body.stage_window(nepmi_lds_window, tb, nt, tid, 256);
+    __syncthreads();
+    if (live && t1 >= tb && t1 < tb + nt)
+      body.run_window(k, tid & 1, (lds_cfloat_ptr)nepmi_lds_window, tb);
+  }
+}
+#endif
+
 // One-off: a body's LDS image written to global memory by the body's own staging code (nep_fused.h)
 template <class Body>
 __global__ void __launch_bounds__(256) nepmi_fused_image(const Body body, float* img)
@@ -1457,6 +1502,43 @@ struct HipBackend {
 #define NEPMI_AFU_BLOCK 256 // A/B switch: threads per workgroup (half as many atoms)
 #endif
     launch_lds_pairs<NEPMI_AFU_BLOCK>(slot, n, body);
+  }
+
+  // ... for many-type models: type-sorted work order, a window of kFusedWindowTypes types in LDS (nepmi_fused_window_kernel)
+  template <class S>
+  size_t fused_window_lds_bytes(const ModelD& md) const
+  {
+    return (size_t)fused_lds_layout<S>(md, kFusedWindowTypes).total * sizeof(float);
+  }
+  static constexpr bool kHasFusedWindow = NEPMI_WITH_FUSED_WINDOW != 0;
+  template <class S>
+  void launch_angular_fused_window(int slot, int64_t n, const ModelD& md, const Bufs& b, int export_qfp, float* img, bool build)
+  {
+#if NEPMI_WITH_FUSED_WINDOW
+    if (n <= 0)
+      return;
+    AngularFusedBody<S> body{md, b, export_qfp, nullptr};
+    if (build) { // the image of ALL types (tw = 0), once
+      hipLaunchKernelGGL((nepmi_fused_image<AngularFusedBody<S>>), dim3(1), dim3(256), 0, stream, body, img);
+      NEPMI_HIP_CHECK(hipGetLastError());
+    }
+    body.img = img;
+    body.tw = kFusedWindowTypes;
+    const int64_t grid = ((n + 127) / 128 + 7) / 8 * 8;
+    const size_t lds_bytes = (fused_window_lds_bytes<S>(md) + 15) / 16 * 16;
+    if (lds_bytes > 64 * 1024)
+      NEPMI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&nepmi_fused_window_kernel<AngularFusedBody<S>>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    const bool t = timed(slot);
+    if (t)
+      timer_start(timing->slot[slot]);
+    hipLaunchKernelGGL((nepmi_fused_window_kernel<AngularFusedBody<S>>), dim3((unsigned)grid), dim3(256), lds_bytes, stream, body, n, frozen);
+    NEPMI_HIP_CHECK(hipGetLastError());
+    if (t)
+      timer_stop(timing->slot[slot]);
+#else
+    (void)slot; (void)n; (void)md; (void)b; (void)export_qfp; (void)img; (void)build;
+#endif
   }
 
   // One force kernel per brick behind the radial pass (nep_brick.h) + the fold.  Two timing brackets: the brick kernel in the

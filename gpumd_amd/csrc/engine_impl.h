@@ -19,6 +19,9 @@
 #include <random>
 #include <vector>
 
+#ifndef NEPMI_TERSOFF_SEAM
+#define NEPMI_TERSOFF_SEAM 1 // A/B switch: 0 = the Tersoff force assembly always as its own launch
+#endif
 #ifndef NEPMI_WIN2_DEFAULT
 #define NEPMI_WIN2_DEFAULT 1 // A/B switch (profiles/ab_variants.sh): 0 = the scanned window layout unless asked for
 #endif
@@ -724,6 +727,9 @@ public:
           be_.template launch<256>(kSlotVV, N_, ResidentBaoBody{box_, b_, dt, 1, 0, tag_of(step)});
           lan_half(t1, true);
           be_.template launch<256>(kSlotVV, N_, ResidentBaoBody{box_, b_, dt, 2, 0, tag_of(step)});
+        } else if (tersoff_deferred_) {
+          be_.template launch<64>(kSlotVV, N_, TersoffSeamBody{TersoffAssembleBody{b_, tb_}, ResidentStepBody{box_, b_, dt, 1, 1, tag_of(step)}});
+          tersoff_deferred_ = false;
         } else {
           be_.template launch<256>(kSlotVV, N_, ResidentStepBody{box_, b_, dt, kick2_pending ? 1 : 0, 1, tag_of(step)});
         }
@@ -736,7 +742,9 @@ public:
       const bool last = step + 1 == nsteps;
       step_outputs_ = record || last; // per-atom energies and virials: read at thermo records and at the exit only
       b_.trip_tag = tag_of(step);     // (scatter form: a force beyond its fixed-point guard band freezes the loop at this step)
+      tersoff_defer_ = NEPMI_TERSOFF_SEAM && model_.kind == 1 && ens == kNve && !record && !last;
       force_kernels(kPhaseAll, frozen);
+      tersoff_defer_ = false;
       b_.trip_tag = 0;
       bool need_sync = record || last;
       if (ens == kNve && !record && !last) {
@@ -789,6 +797,7 @@ public:
       if (trip) {
         step = handle_trip(trip, step);
         resume_after_vv1 = true;
+        tersoff_deferred_ = false; // (the frozen step's pass had taken the assembly of the step before it; what was enqueued since ran as no-ops)
         continue;
       }
       ++step;
@@ -913,7 +922,9 @@ public:
       throw EngineError{-4, "no force evaluation has been performed yet"};
     if (model_.kind != 0)
       throw EngineError{-4, "descriptors exist for NEP models only"};
-    if (!last_small_ && last_ang_fused_) {
+    if (!last_small_ && last_ang_fused_ && last_ang_window_) {
+      NEPMI_SHAPE_DISPATCH(launch_angular_fused_window, 0, (1))
+    } else if (!last_small_ && last_ang_fused_) {
       // one kernel from the sums to the partial forces: run it once more with the descriptor and Fp written out
       NEPMI_SHAPE_DISPATCH(launch_angular_fused, 0, (1))
     } else if (q && !last_small_ && fuse_ann_active()) {
@@ -1524,6 +1535,37 @@ private:
                                    (model_.n_max_angular + 1) * (model_.basis_size_angular + 1) + 1) + 8;
     return floats * sizeof(float) <= 64 * 1024;
   }
+  // The same kernel for MANY-TYPE models (more than four types: the weight image of all types does not fit the LDS): atoms in the
+  // type-sorted work order, a window of four types resident (engine.hip: nepmi_fused_window_kernel).  Where the force assembly
+  // contracts from the atoms' radial Fp rows (skip_atab: the fused kernel writes them, not the radial table).
+  bool ang_fused_window_active() const
+  {
+    if (!B::kHasFusedWindow || !B::kHasFusedAngular || !ang_fused_ || model_.kind != 0 || shape_ == 0 || ann_mode_ != 1 || model_.num_types <= 4 || !b_.fpr)
+      return false;
+    if ((model_.n_max_angular + 2) / 2 > 5)
+      return false;
+    const int nrh = (model_.n_max_radial + 2) / 2, nloc = (model_.n_max_angular + 2) / 2;
+    const int dph = (nrh + model_.num_L * nloc + 3) / 4 * 4;
+    const size_t T = (size_t)model_.num_types, tw = 4;
+    const size_t floats = tw * ((size_t)model_.num_neurons * 2 * dph + 32 + 2 * model_.num_neurons) + 2 * dph +
+                          tw * T * ((model_.n_max_angular + 1) * (model_.basis_size_angular + 1) + 1) + 16;
+    return floats * sizeof(float) <= 80 * 1024; // two workgroups per CU
+  }
+  template <class S>
+  void launch_angular_fused_window(int export_qfp = 0)
+  {
+    if constexpr (B::kHasFusedWindow && B::kHasFusedAngular && S::fixed && S::TS == 0) {
+      const size_t need = be_.template fused_image_floats<S>(md_);
+      if (!fused_img_ || fused_img_floats_ < need) {
+        dfree(fused_img_);
+        fused_img_ = dalloc<float>(need);
+        fused_img_floats_ = need;
+        fused_img_stale_ = true;
+      }
+      be_.template launch_angular_fused_window<S>(kSlotAngular, N_, md_, b_, export_qfp, fused_img_, fused_img_stale_);
+      fused_img_stale_ = false;
+    }
+  }
   template <class S>
   void launch_angular_fused(int export_qfp = 0)
   {
@@ -1893,9 +1935,13 @@ private:
       be_.end_region(kRegionForce);
       return;
     }
+    last_ang_window_ = false;
     if (ang_fused_active()) {
       launch_angular_fused<S>();
       last_ang_fused_ = true;
+    } else if (ang_fused_window_active() && b_.skip_atab) {
+      launch_angular_fused_window<S>();
+      last_ang_fused_ = last_ang_window_ = true;
     } else if (fuse_ann_active()) {
       launch_angular_desc<S>(true);
     } else {
@@ -2227,7 +2273,8 @@ public:
     if (last_brick_)
       s += " force=one_kernel_per_brick(descriptor+ann+partial_forces+lds_scatter_of_own_halves,lane_pairs)";
     else if (last_ang_fused_)
-      s += " angular=descriptor+ann+partial_forces_in_one_kernel(lane_pairs,sums_in_registers)";
+      s += last_ang_window_ ? " angular=descriptor+ann+partial_forces_in_one_kernel(lane_pairs,sums_in_registers,type_sorted,window_of_4_types)"
+                            : " angular=descriptor+ann+partial_forces_in_one_kernel(lane_pairs,sums_in_registers)";
     else if (fuse_ann_active())
       s += " ann=fused_with_angular_descriptor(packed_fp32,no_mfma)";
     else if (ann_mode_ != 0 && b_.ann_img && (model_.num_types <= 4 || b_.skip_atab))
@@ -2281,7 +2328,11 @@ private:
         be_.template launch_lds_parts<kTersoffBlock, kTersoffLanes>(kSlotRadial, N_, TersoffPartialBody{box_, tp_, b_, tb_});
       else
         be_.template launch_lds<kTersoffBlock>(kSlotRadial, N_, TersoffPartialBody{box_, tp_, b_, tb_});
-      be_.template launch<64>(kSlotForce, N_, TersoffAssembleBody{b_, tb_});
+      // (a run loop's forces-only NVE step: the assembly rides in the next pass over the atoms, TersoffSeamBody)
+      if (tersoff_defer_)
+        tersoff_deferred_ = true;
+      else
+        be_.template launch<64>(kSlotForce, N_, TersoffAssembleBody{b_, tb_});
       be_.end_region(kRegionForce);
       return;
     }
@@ -2314,9 +2365,12 @@ private:
   bool use_rmask_ = false;       // set_radial_mask (off: on PbTe 1 M atoms the radial pass gains what the force assembly's lockstep
                                  // walk over all candidates loses -- profiles/r4q_ab_mask.txt)
   bool last_mask_form_ = false;
+  bool last_ang_window_ = false; // the last fused angular launch was the many-type (type window) form
   bool last_sync_form_ = false;
   int guard_delay_ = 0;          // set_scatter_guard_delayed
   int guard_delay_next_ = 0;
+  bool tersoff_defer_ = false;    // this force evaluation leaves the Tersoff assembly to the next pass over the atoms (run loop, NVE)
+  bool tersoff_deferred_ = false; // ... and that assembly is still due
   const int* dmap_dev_ = nullptr; // NepModel::dmap on the device (export_descriptors of a zero-padded model)
   double hard_asked_ = 4.0;      // set_scatter_guard: the hard factor as asked for
   double guard_delayed_ = 64.0;

@@ -48,18 +48,25 @@ struct FusedShape {
 struct FusedLdsLayout {
   int wstride, off_w, off_b0, off_w1, off_c, off_qs, total;
 };
+// TW = 0: every type of the model (models with at most four types).  TW > 0: a WINDOW of TW consecutive types -- the form for
+// many-type models (UNEP-v1: 16 types, 246 KB of weight half-rows): the atoms are taken in the type-sorted work order of the
+// matrix-core ANN (Bufs::tperm), a workgroup's 128 atoms span two or three types, and only those types' slices of the image
+// are staged: c_ang rows [tb, tb + TW) x T, the weight half-rows, biases and output weights of those types, the scalers.  No
+// radial table (such models' force assembly contracts from Bufs::fpr).
 template <class S>
-NEPMI_HD FusedLdsLayout fused_lds_layout(const ModelD& m)
+NEPMI_HD FusedLdsLayout fused_lds_layout(const ModelD& m, int TW = 0)
 {
   using F = FusedShape<S>;
+  const int tw = TW > 0 ? TW : m.T;
   FusedLdsLayout a;
   a.wstride = m.nneu * 2 * F::DPH;
   a.wstride += (8 - (a.wstride & 31) + 32) & 31; // type stride 8 mod 32 words: lanes of two types read different banks
-  a.off_w = (cang_floats(m) + 3) / 4 * 4;
-  a.off_b0 = a.off_w + m.T * a.wstride;
-  a.off_w1 = a.off_b0 + m.T * m.nneu;
-  a.off_c = a.off_w1 + m.T * m.nneu;
-  a.off_qs = a.off_c + m.T * m.T * (m.NR + 1) * (m.KR + 1);
+  a.off_w = (tw * m.T * cang_stride(m) + 3) / 4 * 4;
+  a.off_b0 = a.off_w + tw * a.wstride;
+  a.off_w1 = a.off_b0 + tw * m.nneu;
+  a.off_c = a.off_w1 + tw * m.nneu;
+  a.off_qs = a.off_c + (TW > 0 ? 0 : m.T * m.T * (m.NR + 1) * (m.KR + 1));
+  a.off_qs = (a.off_qs + 3) / 4 * 4;
   a.total = (a.off_qs + 2 * F::DPH + 3) / 4 * 4;
   return a;
 }
@@ -73,6 +80,7 @@ struct AngularFusedBody {
   const float* img; // the LDS image below, built once in global memory (backend: nepmi_fused_image), or nullptr = build it here.
                     // Building it costs a few integer divisions per element -- per workgroup of 128 atoms that was as many
                     // instructions as the ANN itself; the copy is one 16-byte load and store per four elements.
+  int tw = 0;       // type slots of the LDS window (0: all types; see fused_lds_layout).  The global image always has every type.
   static constexpr bool kUsesLds = true;
 #ifndef NEPMI_AFU_WAVES
 #define NEPMI_AFU_WAVES 2
@@ -86,7 +94,30 @@ struct AngularFusedBody {
   static constexpr int kMinWavesPerEu = 1, kMinWavesPerEuPairs = NEPMI_AFU_WAVES;
   using F = FusedShape<S>;
 
-  NEPMI_HD int lds_floats() const { return fused_lds_layout<S>(m).total; }
+  NEPMI_HD int lds_floats() const { return fused_lds_layout<S>(m, tw).total; }
+  // the slices of types [tb, tb + nt) of the global image -> the LDS window (layout with `tw` slots)
+  NEPMI_HD void stage_window(float* dst, int tb, int nt, int tid, int nth) const
+  {
+    const FusedLdsLayout G = fused_lds_layout<S>(m, 0), A = fused_lds_layout<S>(m, tw);
+    const int cs = cang_stride(m);
+    {
+      const float* src = img + (size_t)tb * m.T * cs;
+      for (int i = tid; i < nt * m.T * cs; i += nth)
+        dst[i] = src[i];
+    }
+    {
+      const F4f* __restrict__ src = reinterpret_cast<const F4f*>(img + G.off_w + (size_t)tb * G.wstride); // (16-byte aligned: off_w and
+      F4f* d4 = reinterpret_cast<F4f*>(dst + A.off_w);                                                     //  wstride are multiples of 4)
+      for (int i = tid; i < nt * A.wstride / 4; i += nth)
+        d4[i] = src[i];
+    }
+    for (int i = tid; i < nt * m.nneu; i += nth) {
+      dst[A.off_b0 + i] = img[G.off_b0 + tb * m.nneu + i];
+      dst[A.off_w1 + i] = img[G.off_w1 + tb * m.nneu + i];
+    }
+    for (int i = tid; i < 2 * F::DPH; i += nth)
+      dst[A.off_qs + i] = img[G.off_qs + i];
+  }
   NEPMI_HD void lds_stage(float* dst, int tid, int nth) const
   {
     if (img) {
@@ -123,12 +154,19 @@ struct AngularFusedBody {
   NEPMI_HD void run_parts(int64_t k, int part, LP lds) const
   {
     static_assert(PARTS == 2, "lane pairs");
+    run_window(k, part, lds, 0);
+  }
+  // tb: the first type of the LDS window (0 when every type is resident)
+  template <class LP>
+  NEPMI_HD void run_window(int64_t k, int part, LP lds, int tb) const
+  {
     constexpr int NLOC = F::NLOC, DPH = F::DPH;
     if (b.lvl[k] < b.lvl_desc)
       return;
     const int t1 = b.posq[k].type;
+    LP cang = lds - tb * m.T * cang_stride(m); // (block (t1, t2) of the window sits where block (t1 - tb, t2) of a full table would)
     float s[NLOC * kNumHarm], Fp[DPH], e;
-    descriptor_and_ann(k, part, lds, t1, s, Fp, e);
+    descriptor_and_ann(k, part, lds, cang, t1, t1 - tb, s, Fp, e);
     if (part == 0)
       b.pe_i[k] = e;
     // many-type form of the force assembly (shapes without type-pure lists): the atom's radial Fp row, atom-major -- each lane
@@ -142,7 +180,7 @@ struct AngularFusedBody {
       }
     }
     // ---- radial force table A[t2][k] = sum_n Fp[n] c[t1][t2][n][k]: two half sums; lane t2 mod 2 stores row t2 ----
-    if (!b.skip_atab && NEPMI_AFU_ABL != 4) {
+    if (!b.skip_atab && tw == 0 && NEPMI_AFU_ABL != 4) {
       constexpr int KRPC = (S::KR + 1 + 3) / 4 * 4; // = Bufs::KRP: rows of whole 16-byte groups
       const int KRP = b.KRP;
       for (int t2 = 0; t2 < m.T; ++t2) {
@@ -162,7 +200,7 @@ struct AngularFusedBody {
     adjoint_in_place(part, Fp, s);
     const AngularForceBody<S> af{m, b, 1};
     if (NEPMI_AFU_ABL != 2) {
-      af.template pairs_from_G<2>(k, part, lds, t1, s, typename AngularForceBody<S>::F12Store{b.f12 + k, b.N});
+      af.template pairs_from_G<2>(k, part, cang, t1, s, typename AngularForceBody<S>::F12Store{b.f12 + k, b.N});
     } else if (s[3] + s[NLOC * kNumHarm - 1] == 12345.0f) {
       b.pe_i[k] = s[5] + s[NLOC * kNumHarm - 2];
     }
@@ -212,17 +250,17 @@ struct AngularFusedBody {
   // sums of this lane's channels -> its half of the descriptor -> ANN: s (kept for the adjoint), Fp of this lane's components,
   // e = the atom's energy (both lanes)
   template <class LP>
-  NEPMI_HD void descriptor_and_ann(int64_t k, int part, LP lds, int t1, float* s, float* Fp, float& e_out) const
+  NEPMI_HD void descriptor_and_ann(int64_t k, int part, LP lds, LP cang, int t1, int tl, float* s, float* Fp, float& e_out) const
   {
     constexpr int NRH = F::NRH, NLOC = F::NLOC, DPH = F::DPH;
     const int64_t N = b.N;
-    const FusedLdsLayout a = fused_lds_layout<S>(m);
+    const FusedLdsLayout a = fused_lds_layout<S>(m, tw);
     const int64_t gk = b.tpos[k];
     LP QS = lds + a.off_qs + part * DPH;
 
     // ---- sums of this lane's channels (angular_s_sums: what AngularDescBody runs) ----
     if (NEPMI_AFU_ABL != 3) {
-      angular_s_sums<S, 2>(m, b, k, t1, lds, part, s);
+      angular_s_sums<S, 2>(m, b, k, t1, cang, part, s);
     } else {
 #pragma unroll
       for (int i = 0; i < NLOC * kNumHarm; ++i)
@@ -265,9 +303,9 @@ struct AngularFusedBody {
       g2[i] = bc2(0.0f);
     float e = 0.0f;
     {
-      LP W = lds + a.off_w + t1 * a.wstride + part * DPH;
-      LP B0 = lds + a.off_b0 + t1 * m.nneu;
-      LP W1 = lds + a.off_w1 + t1 * m.nneu;
+      LP W = lds + a.off_w + tl * a.wstride + part * DPH; // (tl: the type's slot in the LDS window)
+      LP B0 = lds + a.off_b0 + tl * m.nneu;
+      LP W1 = lds + a.off_w1 + tl * m.nneu;
       // a half-row of up to 24 weights stays in the registers between the forward dot product and the backward axpy; longer
       // ones (carbon: 36) are read from LDS twice instead -- the sums and the two descriptor halves already fill the file.
       // NJ neurons per trip: their LDS reads go out together and their dot-product / tanh chains (one dependent chain each:

@@ -133,21 +133,32 @@ struct ResidentStepBody {
   double dt;
   int do_kick2, do_vv1;
   int step_tag; // > 0; written to flags[kFlagMoved] when the skin check fires
+  NEPMI_HD bool frozen_now() const
+  {
+    const int mv = b.flags[kFlagMoved];
+    return mv != 0 && mv != step_tag; // a rebuild is pending since an earlier step
+  }
   NEPMI_HD void operator()(int64_t k) const
   {
-#pragma clang fp contract(off)
-    const int mv = b.flags[kFlagMoved];
-    if (mv != 0 && mv != step_tag)
-      return; // a rebuild is pending since an earlier step: frozen
+    if (frozen_now())
+      return;
     if (b.lvl[k] < 2)
       return;
+    const int64_t N = b.N;
+    const double f[3] = {b.fo[(kOutF + 0) * N + k], b.fo[(kOutF + 1) * N + k], b.fo[(kOutF + 2) * N + k]};
+    step(k, f);
+  }
+  // the pass itself, with the atom's force handed in (TersoffSeamBody assembles it in the same kernel)
+  NEPMI_HD void step(int64_t k, const double* f) const
+  {
+#pragma clang fp contract(off)
     const int64_t N = b.N;
     const double half = dt * 0.5;
     const double minv = 1.0 / b.mi[k];
     double v[3];
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
-      const double a = b.fo[(kOutF + d) * N + k] * minv;
+      const double a = f[d] * minv;
       const double kick = a * half;
       v[d] = b.vi[d * N + k];
       if (do_kick2)

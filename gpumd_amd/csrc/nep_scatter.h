@@ -1016,6 +1016,7 @@ struct ForceFoldBody {
       return;
     const int64_t N = b.N;
     int s0 = 0, s1 = 0, s2 = 0; // (modular: the net of a window is what has to fit)
+    unsigned g0 = 0u, g1 = 0u, g2 = 0u; // sum of |row| / 16 per component (up to 27 rows of < 2^31: no overflow): the shadow below
     constexpr int G = 4;
     for (int r0 = 0; r0 < rows; r0 += G) {
       unsigned e[G];
@@ -1034,16 +1035,22 @@ struct ForceFoldBody {
         s0 += h[u].x;
         s1 += h[u].y;
         s2 += h[u].z;
+        g0 += (unsigned)(h[u].x < 0 ? -h[u].x : h[u].x) >> 4;
+        g1 += (unsigned)(h[u].y < 0 ? -h[u].y : h[u].y) >> 4;
+        g2 += (unsigned)(h[u].z < 0 ? -h[u].z : h[u].z) >> 4;
       }
     }
     // the sums are modular: the NET force of an atom has to fit.  A quarter of the range (128 eV/A) is the guard band of the
     // total, half of it (256 eV/A) the hard limit of runs whose flagged steps stand; the pair halves have their own (64 / 256).
-    // What neither sees: a net beyond 768 eV/A made of a dozen aligned pair halves that each stay under 64 eV/A aliases into the
-    // band -- no physical configuration of a NEP model gets there (the ZBL term of a collision is not part of these sums).
+    // A net beyond 768 eV/A made of rows that each fit would alias into the band: the shadow sums g = sum |row| / 16 bound every
+    // partial sum of the fold, so while g stays below 2^31 / 16 the modular sum above IS the sum; beyond that the step is
+    // flagged like a value outside the band (the rows of ordinary forces add up to a few dozen eV/A).  What is still not seen: a
+    // wrap INSIDE one brick's accumulator -- eight or more aligned pair halves of nearly 64 eV/A each into one slot.
     const int a0 = s0 < 0 ? -s0 : s0, a1 = s1 < 0 ? -s1 : s1, a2 = s2 < 0 ? -s2 : s2;
-    if (a0 >= b.fold_guard || a1 >= b.fold_guard || a2 >= b.fold_guard || s0 == INT_MIN || s1 == INT_MIN || s2 == INT_MIN) {
+    const bool shadow = g0 >= (1u << 27) || g1 >= (1u << 27) || g2 >= (1u << 27);
+    if (shadow || a0 >= b.fold_guard || a1 >= b.fold_guard || a2 >= b.fold_guard || s0 == INT_MIN || s1 == INT_MIN || s2 == INT_MIN) {
       scatter_range_trip(b);
-      if (b.fold_hard > 0 && (a0 >= b.fold_hard || a1 >= b.fold_hard || a2 >= b.fold_hard || s0 == INT_MIN || s1 == INT_MIN || s2 == INT_MIN))
+      if (b.fold_hard > 0 && (shadow || a0 >= b.fold_hard || a1 >= b.fold_hard || a2 >= b.fold_hard || s0 == INT_MIN || s1 == INT_MIN || s2 == INT_MIN))
         scatter_range_hard(b);
     }
     double F[3] = {(double)s0 * kScatterInvScale, (double)s1 * kScatterInvScale, (double)s2 * kScatterInvScale};

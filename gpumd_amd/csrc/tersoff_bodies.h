@@ -11,6 +11,7 @@
 //                        searches j's list linearly, potential.cu:86-92); output planes in internal order.
 #pragma once
 #include "nep_bodies.h"
+#include "nep_md.h"
 
 namespace nepmi {
 
@@ -440,10 +441,18 @@ struct TersoffAssembleBody {
   TersoffBufs tb;
   NEPMI_HD void operator()(int64_t k) const
   {
-    const int64_t N = b.N;
     if (b.lvl[k] < 2)
       return;
-    double F[3] = {0, 0, 0}, W[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    double F[3];
+    assemble<true>(k, F);
+  }
+  // OUT: energy and virial planes written too (else the force planes only; the force is also handed back)
+  template <bool OUT>
+  NEPMI_HD void assemble(int64_t k, double* F) const
+  {
+    const int64_t N = b.N;
+    F[0] = F[1] = F[2] = 0.0;
+    double W[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     const int nn = b.nn_ang[k];
     if (nn <= 64) {
       // the members straight from the membership bits, four at a time with their loads in flight together, in slot order
@@ -512,13 +521,36 @@ struct TersoffAssembleBody {
       W[8] += r.z * f21.y;
     }
     double* __restrict__ fo = b.fo + k;
-    fo[0] = tb.pe_d[k];
 #pragma unroll
     for (int d = 0; d < 3; ++d)
       fo[(int64_t)(kOutF + d) * N] = F[d];
+    if (OUT) {
+      fo[0] = tb.pe_d[k];
 #pragma unroll
-    for (int d = 0; d < 9; ++d)
-      fo[(int64_t)(kOutW + d) * N] = W[d];
+      for (int d = 0; d < 9; ++d)
+        fo[(int64_t)(kOutW + d) * N] = W[d];
+    }
+  }
+};
+
+// The seam between two NVE steps of a Tersoff run loop as ONE pass over the atoms: the force assembly of the step just
+// evaluated (many-body accumulate, potential.cu:35-134: partial forces and reverse slots only -- it reads no positions, so the
+// drift below cannot disturb another lane's assembly), the second half-kick of that step and the first half of the next.
+// Config 2 (13,824 atoms) is bound by the number of launches (three kernels of 4-13 us per step): one launch and its
+// ramp less.  Steps that record thermo data or end the run keep the separate kernels (energies and virials are written).
+// Bit-identical to the separate kernels (the same additions in the same order).
+struct TersoffSeamBody {
+  TersoffAssembleBody as;
+  ResidentStepBody rs;
+  NEPMI_HD void operator()(int64_t k) const
+  {
+    if (rs.frozen_now())
+      return;
+    if (as.b.lvl[k] < 2)
+      return;
+    double F[3];
+    as.template assemble<false>(k, F);
+    rs.step(k, F);
   }
 };
 

@@ -151,6 +151,7 @@ struct HostLoopBackend {
   // the scatter form of the force assembly (gpumd_amd/csrc/nep_scatter.h) is device code only: never selected here
   static constexpr bool kHasScatter = false;
   static constexpr bool kHasFusedAngular = false; // gpumd_amd/csrc/nep_fused.h: device code only
+  static constexpr bool kHasFusedWindow = false;
   static constexpr bool kHasBrickForce = false; // gpumd_amd/csrc/nep_brick.h: device code only
   template <class S>
   size_t brick_lds_bytes(const ModelD&, int) const { return 0; }
@@ -161,6 +162,10 @@ struct HostLoopBackend {
   }
   template <class S>
   size_t fused_image_floats(const ModelD&) const { return 0; }
+  template <class S>
+  void launch_angular_fused_window(int, int64_t, const ModelD&, const Bufs&, int, float*, bool)
+  {
+  }
   template <class S>
   void launch_angular_fused(int, int64_t, const ModelD&, const Bufs&, int, float*, bool)
   {
