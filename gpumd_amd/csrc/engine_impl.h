@@ -942,6 +942,10 @@ public:
   // per-step list statistics of the last compute (host reduction over nn arrays)
   void list_stats(int& max_skin, int& max_rad, int& max_ang, double& mean_rad, double& mean_ang)
   {
+    if (model_.kind == 0 && have_list_ && !last_small_ && !ccode_valid_) { // (padded rows count more than the atom's neighbours)
+      be_.frozen = nullptr;
+      NEPMI_SHAPE_DISPATCH(compact_lists_shape, 1, ())
+    }
     std::vector<int> nr(N_), na(N_);
     be_.d2h(nr.data(), b_.nn_rad, sizeof(int) * N_);
     be_.d2h(na.data(), b_.nn_angstep, sizeof(int) * N_);
@@ -1058,6 +1062,7 @@ private:
     // Neighbor::initialize, neighbor.cu:824-833
     const double rcs = m.rc_radial_max + kSkin;
     b_.MN_acomp = m.MN_angular;
+    b_.MN_arows = b_.MN_acomp + kAngRowPad;
     b_.MN_skin = (int)(m.MN_radial * rcs * rcs * rcs / (m.rc_radial_max * m.rc_radial_max * m.rc_radial_max));
     const double ras = m.rc_angular_max + kSkin;
     // List A (the part of the Verlet list inside rc_a + skin) is this engine's own structure: its capacity
@@ -1086,9 +1091,9 @@ private:
     b_.nn_angstep = dalloc<int>(N);
     if (m.kind == 0) {
       b_.rstash = dalloc<F4>((size_t)(b_.MN_ang + b_.MN_skin) * N);
-      b_.acomp = dalloc<F4>((size_t)b_.MN_acomp * N);
+      b_.acomp = dalloc<F4>((size_t)b_.MN_arows * N);
       b_.amap = dalloc<unsigned short>((size_t)b_.MN_ang * N);
-      b_.f12 = dalloc<F4>((size_t)b_.MN_acomp * N);
+      b_.f12 = dalloc<F4>((size_t)b_.MN_arows * N);
       b_.q = dalloc<float>((size_t)m.dim * N);
       b_.fp = dalloc<float>((size_t)m.dim * N);
       b_.sbuf = dalloc<float>((size_t)(m.n_max_angular + 1) * kNumHarm * N);
@@ -1116,7 +1121,7 @@ private:
       b_.MN_cw = (b_.MN_rad + 3) / 4 + 1;
       b_.cword = dalloc<unsigned short>((size_t)2 * b_.MN_cw * 4 * N);
       // scatter-form force assembly (nep_scatter.h; device backends only)
-      b_.aslot = B::kHasScatter ? dalloc<unsigned short>((size_t)b_.MN_acomp * N) : nullptr;
+      b_.aslot = B::kHasScatter ? dalloc<unsigned short>((size_t)b_.MN_arows * N) : nullptr;
       b_.compact_all = b_.aslot ? 1 : 0;
       // mask form of the per-step radial list (Bufs::rmaskA / rmaskB / tmaskA)
       b_.MAW = (4 * ((b_.MN_ang + 3) / 4) + 31) / 32 + 1;
@@ -1477,7 +1482,7 @@ private:
       // the rows a ghost would have written in forward mode are read by its neighbours' (and its own) force assembly: zero
       // = no contribution; owned atoms rewrite theirs every step
       be_.memset(b_.atab, 0, sizeof(float) * (size_t)cap_ * model_.num_types * b_.KRP);
-      be_.memset(b_.f12, 0, sizeof(F4) * (size_t)b_.MN_acomp * cap_);
+      be_.memset(b_.f12, 0, sizeof(F4) * (size_t)b_.MN_arows * cap_);
       if (b_.fpr)
         be_.memset(b_.fpr, 0, sizeof(float) * (size_t)cap_ * b_.FPR);
     }
@@ -1935,7 +1940,26 @@ private:
       be_.end_region(kRegionForce);
       return;
     }
+    angular_kernels<S>();
+    last_scatter_form_ = false;
+    outputs_stale_ = false;
+    if (win2 && scatter_form<S>(ws2, frozen)) {
+      virial_local_ = true; // the virial planes hold the own-half form: exact_virials() before they leave the engine
+      if (force_form_ == 1 && !loop_ctx_) // a per-call evaluation in the forced scatter form returns per-atom virials
+        gather_assembly<S>(ws, ws2, lanes, win2, frozen, 1);
+    } else {
+      virial_local_ = false;
+      gather_assembly<S>(ws, ws2, lanes, win2, frozen, 0);
+    }
+    be_.end_region(kRegionForce);
+  }
+
+  // angular descriptor, ANN and partial angular forces of the current angular records: one kernel or three
+  template <class S>
+  void angular_kernels()
+  {
     last_ang_window_ = false;
+    last_ang_fused_ = false;
     if (ang_fused_active()) {
       launch_angular_fused<S>();
       last_ang_fused_ = true;
@@ -1950,17 +1974,6 @@ private:
     }
     if (!last_ang_fused_)
       launch_angular_force<S>();
-    last_scatter_form_ = false;
-    outputs_stale_ = false;
-    if (win2 && scatter_form<S>(ws2, frozen)) {
-      virial_local_ = true; // the virial planes hold the own-half form: exact_virials() before they leave the engine
-      if (force_form_ == 1 && !loop_ctx_) // a per-call evaluation in the forced scatter form returns per-atom virials
-        gather_assembly<S>(ws, ws2, lanes, win2, frozen, 1);
-    } else {
-      virial_local_ = false;
-      gather_assembly<S>(ws, ws2, lanes, win2, frozen, 0);
-    }
-    be_.end_region(kRegionForce);
   }
 
   // After a per-brick force kernel the partial forces and the radial table exist in registers only: the gather form's
@@ -2173,6 +2186,16 @@ public:
   bool virial_local() const { return virial_local_; }
 
 private:
+  // The last radial pass wrote the masks / the wave-synchronous words: the compact list the gather form (and the list statistics)
+  // read, on the same positions -- and, where the angular records were padded rows, the partial forces once more at the compact slots
+  template <class S>
+  void compact_lists_shape()
+  {
+    const bool padded_rows = b_.use_csync != 0;
+    force_kernels_shape<S>(kPhaseRadialOnly, nullptr);
+    if (padded_rows)
+      angular_kernels<S>();
+  }
   template <class S>
   void exact_virials_shape()
   {
@@ -2181,8 +2204,8 @@ private:
     lay2.compact = 1;
     const WinStage ws2{box_, b_, lay2};
     const int lanes = win_lanes();
-    if (!ccode_valid_) // the last radial pass wrote the masks: the compact list the gather form walks, on the same positions
-      force_kernels_shape<S>(kPhaseRadialOnly, nullptr);
+    if (!ccode_valid_)
+      compact_lists_shape<S>();
     materialise_for_gather<S>(); // (after a per-brick force kernel: the partial forces and the radial table, once more, to HBM)
     gather_assembly<S>(ws, ws2, lanes, win2_ok_ && lanes == 1, nullptr, 1);
   }

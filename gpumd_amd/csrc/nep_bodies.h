@@ -92,6 +92,8 @@ enum FlagSlot {
 // scatter form's fixed-point sums in a run whose flagged steps stand (decomposed runs)
 constexpr int kOverflowRangeHard = 16;
 
+constexpr int kAngRowPad = 8;   // rows beyond MN_acomp (see Bufs::MN_arows)
+constexpr int kNullRecord = -1; // F4::w of a padding row of the angular records (nep_window.h: wave-synchronous rows): every walk skips it
 struct Bufs {
   int64_t N;
   // cell list
@@ -113,6 +115,7 @@ struct Bufs {
   //   list A: candidates with d < rc_a + skin (angular AND radial), with reverse slots
   //   list B: the remaining radial candidates, rc_a + skin <= d < rc_r + skin
   int MN_skin, MN_ang, MN_acomp;
+  int MN_arows; // rows of acomp / f12 / aslot that exist: MN_acomp + kAngRowPad (the wave-synchronous form of the angular records pads)
   int* nn_ang;   int* nl_ang;  unsigned short* rev_ang; // A: [MN_ang][N]
   int* nn_skin;  int* nl_skin;                          // B: [MN_skin][N]
   unsigned short* code_ang;  // A: window code (window cell << 7 | rank in cell) of each entry
@@ -1648,6 +1651,8 @@ NEPMI_HD void angular_s_sums_scalar(const ModelD& m, const Bufs& b, int64_t k, i
     const F4 e = e_next;
     if (a + 1 < na)
       e_next = acomp[(int64_t)(a + 1) * N]; // in flight while this record is processed
+    if (e.w == kNullRecord)
+      continue; // a padding row (wave-synchronous records)
     const int t2 = (int)((unsigned)e.w >> kIdxBits);
     const float x = e.x, y = e.y, z = e.z;
     float d, dinv;
@@ -1709,6 +1714,8 @@ NEPMI_HD void angular_s_sums(const ModelD& m, const Bufs& b, int64_t k, int t1, 
       const F4 e = e_next;
       if (a + 1 < na)
         e_next = acomp[(int64_t)(a + 1) * N]; // in flight while this record is processed
+      if (e.w == kNullRecord)
+        continue; // a padding row (wave-synchronous records)
       const int t2 = (int)((unsigned)e.w >> kIdxBits);
       const float x = e.x, y = e.y, z = e.z;
       float d, dinv;
@@ -2158,6 +2165,8 @@ struct AngularForceBody {
       const F4 e = e_next;
       if (a + 1 < na)
         e_next = acomp[(int64_t)(a + 1) * N];
+      if (e.w == kNullRecord)
+        continue; // a padding row (wave-synchronous records): no partial force is written for it, its aslot is the sentinel
       const int t2 = (int)((unsigned)e.w >> kIdxBits);
       const float x = e.x, y = e.y, z = e.z;
       float d, dinv;

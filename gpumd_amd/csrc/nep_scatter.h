@@ -477,7 +477,7 @@ __device__ __forceinline__ void force_scatter_atom(const ForceScatterBody<S>& B,
       }
 #pragma unroll
       for (int u = 0; u < kAngChunk; ++u) {
-        if (c0 + u < nang) {
+        if (c0 + u < nang && sl[u] != b.wsent) { // (the sentinel slot: a padding row of the wave-synchronous records, no partial force)
           big = fmaxf(big, fmaxf(fabsf(fa[u].x), fmaxf(fabsf(fa[u].y), fabsf(fa[u].z))));
           const int ax = to_fixed(fa[u].x * kScatterScale), ay = to_fixed(fa[u].y * kScatterScale),
                     az = to_fixed(fa[u].z * kScatterScale);
@@ -787,6 +787,8 @@ __device__ __forceinline__ void force_scatter_atom_mt(const ForceScatterBody<S>&
   for (int a = sub; a < nang; a += L) {
     const F4 fa = f12o[(int64_t)a * N];
     const int sl = aslot[(int64_t)a * N];
+    if (sl == b.wsent)
+      continue; // a padding row of the wave-synchronous records
     big = fmaxf(big, fmaxf(fabsf(fa.x), fmaxf(fabsf(fa.y), fabsf(fa.z))));
     const int ax = to_fixed(fa.x * kScatterScale), ay = to_fixed(fa.y * kScatterScale), az = to_fixed(fa.z * kScatterScale);
     Fi[0] += ax;

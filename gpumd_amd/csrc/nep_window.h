@@ -850,6 +850,17 @@ struct SyncFifo {
     f3 = funnel16(slot, f3);
     ++p;
   }
+  // the oldest waiting entry alone (none waiting: the sentinel)
+  NEPMI_HD unsigned pop_one(unsigned sent)
+  {
+    if (p <= 0)
+      return sent;
+    const int s = 8 - p; // place of the oldest waiting entry
+    const unsigned r01 = (s & 2) ? f1 : f0, r23 = (s & 2) ? f3 : f2;
+    const unsigned r = (s & 4) ? r23 : r01;
+    --p;
+    return (s & 1) ? (r >> 16) : (r & 0xFFFFu);
+  }
   // the four oldest waiting entries as one word (fewer than four: padded with the sentinel, and the queue is empty afterwards)
   NEPMI_HD unsigned long long pop_word(unsigned long long sent64)
   {
@@ -1106,6 +1117,35 @@ struct RadialWin2Body {
           sync_emit(q1, sync1);
       }
     };
+    // The angular records of list A the same way (compiled shapes): the accepted slots wait in a third queue, and ROW r of
+    // acomp / aslot is stored by every lane of the wavefront at once -- the record rebuilt from the LDS window at that moment
+    // (16 contiguous bytes per lane: 1 KB per wavefront and row), a lane with nothing waiting stores a null record
+    // (kNullRecord / the sentinel slot: every walk skips it).  No aidx, amap or amask: the gather form, which finds the
+    // partner's partial force through them, re-runs this pass in the compact layout when it is needed (ccode_valid_).
+    // Rows: max-over-the-wavefront(angular neighbours), occasionally one or two more (a lane that filled its queue early
+    // forces a row the others pad): the row arrays have kAngRowPad rows beyond MN_acomp.
+    constexpr bool ASYNC = SYNC != 0 && S::fixed;
+    SyncFifo qa;
+    qa.init();
+    int arows = 0;
+    auto ang_emit = [&]() __attribute__((always_inline)) {
+      const unsigned slot = qa.pop_one((unsigned)b.wsent);
+      if (arows < b.MN_arows) {
+        F4 e;
+        e.x = e.y = e.z = 0.0f;
+        e.w = kNullRecord;
+        if (slot != (unsigned)b.wsent) {
+          const WinRec r = wrec[slot];
+          e.x = (float)(r.x - ox) * unit;
+          e.y = (float)(r.y - oy) * unit;
+          e.z = (float)(r.z - oz) * unit;
+          e.w = r.w;
+        }
+        acomp[(int64_t)arows * N] = e;
+        b.aslot[(int64_t)arows * N + k] = (unsigned short)slot;
+      }
+      ++arows;
+    };
     auto push_front = [&](const Cand& c, const int bit) __attribute__((always_inline)) {
       if (SYNC) {
         if (c.inside) {
@@ -1249,12 +1289,21 @@ struct RadialWin2Body {
             retake(c[0], true);
             retake(c[1], true);
           }
+          if (ASYNC) { // (a half brings at most two: no lane enters it with more than six waiting)
+            while (NEPMI_WAVE_ANY(qa.p > 6))
+              ang_emit();
+          }
 #pragma unroll
           for (int u = 0; u < 2; ++u) {
             const int idx = 4 * w + 2 * hh + u;
             const bool live = idx < na; // (a sentinel is never inside a cutoff; `live` guards the amap rows)
             unsigned short cs = kNoSlot;
-            if (c[u].ang) {
+            if (ASYNC) {
+              if (c[u].ang) {
+                qa.push((unsigned)c[u].slot);
+                ++ca;
+              }
+            } else if (c[u].ang) {
               if (ca < b.MN_acomp) {
                 F4 e;
                 e.x = c[u].fx * unit;
@@ -1277,7 +1326,7 @@ struct RadialWin2Body {
               }
               ++ca;
             }
-            if (!b.use_amask && live)
+            if (!ASYNC && !b.use_amask && live)
               amap[(int64_t)idx * N] = cs;
             if (S::TS == 2 && ((unsigned)c[u].rw >> kIdxBits) == 1u)
               push_back(c[u], 4 * (w & 7) + 2 * hh + u);
@@ -1318,7 +1367,10 @@ struct RadialWin2Body {
         sync_check();
       }
     }
-    if (b.use_amask) {
+    if (ASYNC) { // what still waits: again every lane of the wavefront at once
+      while (NEPMI_WAVE_ANY(qa.p > 0))
+        ang_emit();
+    } else if (b.use_amask) {
       U4 mv;
       mv.x = am[0];
       mv.y = am[1];
@@ -1433,10 +1485,12 @@ struct RadialWin2Body {
       while (S::TS == 2 && NEPMI_WAVE_ANY(q1.p > 0))
         sync_emit(q1, sync1);
     }
-    if (ca > b.MN_acomp || (SYNC ? (q0.rows > b.MN_cw || q1.rows > b.MN_cw) : cnt + cnt1 > b.MN_rad)) {
+    if (ca > b.MN_acomp || (ASYNC && arows > b.MN_arows) || (SYNC ? (q0.rows > b.MN_cw || q1.rows > b.MN_cw) : cnt + cnt1 > b.MN_rad)) {
       NEPMI_ATOMIC_OR(&b.flags[kFlagOverflow], 4);
       ca = ca > b.MN_acomp ? b.MN_acomp : ca;
     }
+    if (ASYNC)
+      ca = arows < b.MN_arows ? arows : b.MN_arows; // rows of this atom's records, padding included (the same on the whole wavefront)
     b.nn_rad[k] = cnt + cnt1;
     if (SYNC) {
       const int r0 = q0.rows < b.MN_cw ? q0.rows : b.MN_cw, r1 = q1.rows < b.MN_cw ? q1.rows : b.MN_cw;
