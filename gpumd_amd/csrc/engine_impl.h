@@ -1062,7 +1062,9 @@ private:
     // Neighbor::initialize, neighbor.cu:824-833
     const double rcs = m.rc_radial_max + kSkin;
     b_.MN_acomp = m.MN_angular;
-    b_.MN_arows = b_.MN_acomp + kAngRowPad;
+    // (the padded rows of a wavefront exceed its longest true list by a few when one lane fills its queue early: simulated worst
+    // cases 4-5 rows at 55-70 % acceptance, more for long sparse lists -- a quarter of the capacity on top of the fixed pad)
+    b_.MN_arows = b_.MN_acomp + kAngRowPad + b_.MN_acomp / 4;
     b_.MN_skin = (int)(m.MN_radial * rcs * rcs * rcs / (m.rc_radial_max * m.rc_radial_max * m.rc_radial_max));
     const double ras = m.rc_angular_max + kSkin;
     // List A (the part of the Verlet list inside rc_a + skin) is this engine's own structure: its capacity

@@ -737,6 +737,19 @@ def check_full_size_parity(drv, name):
     if scattered and not name.startswith("UNEP"):
         # +g and -g are the same integer: the total force vanishes to the FP64 rounding of the fold (UNEP adds ZBL in floating point)
         assert np.abs(f_s.reshape(3, n).sum(axis=1)).max() < 1e-6
+    if scattered:
+        # ... and with the per-step lists in the form the run loops write them since round 6 -- the radial list as wave-synchronous
+        # words, the angular records as padded rows rebuilt from the LDS window (nep_window.h: SyncFifo) -- which a per-call
+        # evaluation takes when only the total virial is owed (virial mode 1 = the run loops' rule): the same pairs, the same
+        # per-pair arithmetic in the same order into integer sums, so forces and energies are the scatter form's bit for bit
+        eng.set_virial_mode(1)
+        _, pe_y, f_y, v_y = H.engine_force(drv, eng, h, typ, x)
+        assert "wave_synchronous_words" in eng.describe() and "lds_scatter_of_own_halves" in eng.describe(), eng.describe()
+        assert np.array_equal(f_y, f_s) and np.array_equal(pe_y, pe_s)
+        np.testing.assert_allclose(v_y.reshape(9, n).sum(axis=1), vt64, rtol=1e-4, atol=1e-5 * np.sqrt(n))
+        eng.set_virial_mode(0)
+        _, pe_z, f_z, v_z = H.engine_force(drv, eng, h, typ, x)  # back to the compact lists and the reference's virial attribution
+        assert np.array_equal(f_z, f_s) and np.array_equal(v_z, v_s)
     print("\n[full-size parity] %s: %d atoms, oracle %.1f s, engine + comparison %.1f s, max|dF| vs FP64 %.2e (gather) %.2e (scatter), "
           "vs FP32 %.2e" % (name, n, t_oracle, time.time() - t0, df_gather, np.abs(f_s - f64).max(), np.abs(f - f32).max()))
     return eng
