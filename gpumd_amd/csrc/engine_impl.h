@@ -613,7 +613,10 @@ public:
   // step.  The caller's arrays are read at entry and written at exit.
   // ---------------------------------------------------------------------------------------------
   enum Ensemble { kNve = 0, kBer = 1, kNhc = 2, kBdp = 3, kLan = 4, kBao = 5 };
-  static constexpr int64_t kScatterMinBricks = 768; // 3 workgroups x 256 CUs
+  // (r4: 768 = 3 workgroups x 256 CUs.  r6, with the radial pass's lists as wave-synchronous words / rows, which only the scatter form reads:
+  // 729 bricks 0.282 ms per step against 0.312 in the gather form, 512 bricks 0.230 against 0.239 with two lanes per atom
+  // (profiles/r6l_size_rule.txt) -- every system the rule gives one lane per atom, i.e. more than 512 bricks)
+  static constexpr int64_t kScatterMinBricks = 513;
   static constexpr int kPollEvery = 4; // steps between two snapshots of the device flags
   static constexpr int kPollDepth = 2; // snapshots in flight: the host runs 8-12 steps ahead of the device
 

@@ -462,7 +462,7 @@ int nepmi_engine_set_force_form(nepmi_engine* e, int mode);
  * planes.  mode 0 (default): per-atom virials in the reference's attribution, W_i = sum_j r_ij (x) f_21 (potential.cu:203-296) --
  * what compute_hac / compute_hnemd / dump_xyz ... virial read; the gather form of the force assembly provides it.  mode 1: only
  * the TOTAL has to be right (Ensemble::find_thermo, dump_thermo: ensemble.cu:434-633 sums the planes): the per-call evaluations
- * then follow the run loops' rule and take the scatter form where it applies (from 768 bricks on), whose planes hold the own-half
+ * then follow the run loops' rule and take the scatter form where it applies (systems of more than 512 bricks), whose planes hold the own-half
  * attribution -- the same sum, the same forces and energies to f32 rounding, a third less time per call at a million atoms
  * (bench.py: pbte_per_call_dropin / _totals).  A host sets 1 while no consumer of per-atom virials is active. */
 int nepmi_engine_set_virial_mode(nepmi_engine* e, int mode);
