@@ -88,7 +88,7 @@ nepmi_model* nepmi_model_load(const char* path)
     const bool allowed = !(jit && jit[0] == '0') && !(cov && cov[0] == '0');
     int c[4];
     const int builtin = nepmi::builtin_shape_of(m->m);
-    if (m->m.kind == 0 && (forced || (allowed && builtin == 0)) && builtin != 7 && builtin != 8 && nepmi::cover_shape_for(m->m, c)) {
+    if (m->m.kind == 0 && (forced || (allowed && builtin == 0)) && builtin != 7 && builtin != 8 && builtin != 9 && nepmi::cover_shape_for(m->m, c)) {
       const int f[5] = {m->m.n_max_radial, m->m.basis_size_radial, m->m.n_max_angular, m->m.basis_size_angular, m->m.num_L};
       if (!nepmi::embed_model(m->m, c[0], c[1], c[2], c[3]))
         std::fprintf(stderr, "nepmi: the run-time-shape kernels serve this model, several times slower than compiled ones\n");

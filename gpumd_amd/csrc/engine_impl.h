@@ -48,6 +48,7 @@
     case 5: FN<S_BZO>(NEPMI_UNPAREN ARGS); break;                                 \
     case 7: FN<S_COV1>(NEPMI_UNPAREN ARGS); break;                                \
     case 8: FN<S_COV2>(NEPMI_UNPAREN ARGS); break;                                \
+    case 9: FN<S_COV3>(NEPMI_UNPAREN ARGS); break;                                \
     default: if (GENERIC) FN<ShapeGeneric>(NEPMI_UNPAREN ARGS); break;            \
   }
 #endif
@@ -77,6 +78,7 @@ inline int builtin_shape_of(const NepModel& m)
   if (model_matches_shape<Shape<10, 10, 8, 8, 6, 1>>(m)) return 3;
   if (model_matches_shape<Shape<4, 8, 4, 8, 6, 0>>(m)) return 4;
   if (model_matches_shape<Shape<8, 8, 6, 8, 5, 0>>(m)) return 5;
+  if (model_matches_shape<Shape<8, 12, 8, 12, 6, 2>>(m)) return 9; // (two types: the cover with type-pure lists, before the any-types one)
   if (model_matches_shape<Shape<8, 12, 8, 12, 6, 0>>(m)) return 7;
   if (model_matches_shape<Shape<12, 16, 10, 12, 6, 0>>(m)) return 8;
   return 0;
@@ -89,7 +91,7 @@ inline bool served_by_type_pure_shape(const NepModel& m)
   return SJ::TS > 0 && model_matches_shape<SJ>(m);
 #else
   const int bs = builtin_shape_of(m);
-  return bs >= 1 && bs <= 3;
+  return (bs >= 1 && bs <= 3) || bs == 9;
 #endif
 }
 // The COVER shapes (7, 8: any number of types, all six invariant rows): a model of a shape nobody compiled kernels for is
@@ -1646,6 +1648,7 @@ private:
   using S_BZO = Shape<8, 8, 6, 8, 5, 0>;     // tests_pytest/fixtures/models/nep_BaZrO3.txt (3 types)
   using S_COV1 = Shape<8, 12, 8, 12, 6, 0>;   // cover shapes: models of other shapes are zero-padded into them (cover_shape_for)
   using S_COV2 = Shape<12, 16, 10, 12, 6, 0>;
+  using S_COV3 = Shape<8, 12, 8, 12, 6, 2>;   // ... two-type models: the first cover with type-pure list segments (two-type window kernels, 2-type scatter)
 
   template <class S>
   bool shape_matches() const
@@ -1663,6 +1666,7 @@ private:
     else if (shape_matches<S_C2022>()) shape_ = 3;
     else if (shape_matches<S_UNEP>()) shape_ = 4;
     else if (shape_matches<S_BZO>()) shape_ = 5;
+    else if (shape_matches<S_COV3>()) shape_ = 9;
     else if (shape_matches<S_COV1>()) shape_ = 7;
     else if (shape_matches<S_COV2>()) shape_ = 8;
     else shape_ = 0;
@@ -1824,7 +1828,7 @@ public:
     if (shape_ == 6)
       return S_JIT::TS;
 #endif
-    return (shape_ == 1 || shape_ == 2) ? 2 : (shape_ == 3 ? 1 : 0);
+    return (shape_ == 1 || shape_ == 2 || shape_ == 9) ? 2 : (shape_ == 3 ? 1 : 0);
   }
   // 1 (default): the one-lane window kernels run on the static window layout (RadialWin2Body); 0: the scanned layout
   void set_win2(bool on)
@@ -2280,8 +2284,8 @@ public:
                     model_.basis_size_angular, model_.num_L, model_.num_types <= 2 ? std::to_string(model_.num_types).c_str() : "T");
       s += jb;
     } else {
-      if (shape_ == 7 || shape_ == 8) {
-        s += shape_ == 7 ? "shape=cover(8,12,8,12,6;T)" : "shape=cover(12,16,10,12,6;T)";
+      if (shape_ == 7 || shape_ == 8 || shape_ == 9) {
+        s += shape_ == 7 ? "shape=cover(8,12,8,12,6;T)" : (shape_ == 8 ? "shape=cover(12,16,10,12,6;T)" : "shape=cover(8,12,8,12,6;2)");
         if (model_.embedded()) {
           char eb[128];
           std::snprintf(eb, sizeof eb, "<-zero_padded_model(%d,%d,%d,%d,%d)", model_.file_n_max_radial, model_.file_basis_size_radial,
