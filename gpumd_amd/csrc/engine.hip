@@ -404,6 +404,60 @@ nepmi_fused_window_kernel(const Body body, const int64_t n, const int* frozen)
 }
 #endif
 
+// The same with the workgroup's atoms handed to the lane pairs IN THE ORDER OF THEIR NUMBER OF ANGULAR NEIGHBOURS (Body::sort_key).
+// The angular loops run in lockstep: a wavefront walks the longest list among its 32 atoms (PbTe: 6.1 neighbours on average, ~10
+// for the longest of 32), and the lanes of the shorter lists wait -- 40 % of the lane time of those loops.  A counting sort of the
+// 128 keys in LDS (a histogram, one short serial prefix, one atomic per atom: about a microsecond of a ~30 us workgroup) gives the
+// first wavefront the longest lists, the last one the shortest: the four wavefronts walk ~10 + 7 + 6 + 5 rows instead of 4 x ~10.
+// Even workgroups sort descending, odd ones ascending, so that the wavefronts that share a SIMD (wave i of either workgroup on a
+// CU) are one heavy and one light.  Which lane pair serves which atom has no influence on the atom's results (every output is
+// indexed by the atom), so the results are the unsorted kernel's bit for bit whatever order equal keys end up in; the records
+// of the 128 atoms lie in one 2 KB span per row either way.
+template <int BLOCK, class Body>
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(Body::kMinWavesPerEuPairs)))
+nepmi_kernel_lds_pairs_sorted(const Body body, const int64_t n, const int* frozen)
+{
+  extern __shared__ __attribute__((aligned(16))) float nepmi_lds_pairs_s[];
+  __shared__ int hist[64];
+  __shared__ unsigned short perm[BLOCK / 2];
+  if (frozen && *frozen != 0)
+    return;
+  const int tid = (int)threadIdx.x;
+  body.lds_stage(nepmi_lds_pairs_s, tid, BLOCK);
+  if (tid < 64)
+    hist[tid] = 0;
+  const unsigned per_xcd = gridDim.x >> 3;
+  const unsigned tile = (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3);
+  const int64_t base = (int64_t)tile * (BLOCK / 2);
+  const int j = tid >> 1;
+  const bool live = base + j < n;
+  int key = 0;
+  if (live) {
+    key = body.sort_key(base + j);
+    key = key > 63 ? 63 : key;
+    if (tile & 1u)
+      key = 63 - key; // (odd workgroups: ascending)
+  }
+  __syncthreads();
+  if (live && (tid & 1) == 0)
+    atomicAdd(&hist[key], 1);
+  __syncthreads();
+  if (tid == 0) { // first position of every key, longest lists first
+    int run = 0;
+    for (int c = 63; c >= 0; --c) {
+      const int h = hist[c];
+      hist[c] = run;
+      run += h;
+    }
+  }
+  __syncthreads();
+  if (live && (tid & 1) == 0)
+    perm[atomicAdd(&hist[key], 1)] = (unsigned short)j;
+  __syncthreads();
+  if (live) // (the live atoms fill perm[0 .. number of live atoms): the same count as the live lane pairs)
+    body.template run_parts<2>(base + perm[j], tid & 1, (lds_cfloat_ptr)nepmi_lds_pairs_s);
+}
+
 // One-off: a body's LDS image written to global memory by the body's own staging code (nep_fused.h)
 template <class Body>
 __global__ void __launch_bounds__(256) nepmi_fused_image(const Body body, float* img)
@@ -1461,22 +1515,24 @@ struct HipBackend {
       timer_stop(timing->slot[slot]);
   }
 
-  template <int BLOCK, class Body>
+  template <int BLOCK, class Body, bool SORTED = false>
   void launch_lds_pairs(int slot, int64_t n, const Body& body)
   {
     if (n <= 0)
       return;
     const int64_t grid = ((2 * n + BLOCK - 1) / BLOCK + 7) / 8 * 8;
     const size_t lds_bytes = ((size_t)body.lds_floats() * sizeof(float) + 15) / 16 * 16;
-    if (lds_bytes > 64 * 1024)
-      NEPMI_HIP_CHECK(hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&nepmi_kernel_lds_pairs<BLOCK, Body>),
-        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    void (*kern)(const Body, const int64_t, const int*) = nullptr;
+    if constexpr (SORTED)
+      kern = &nepmi_kernel_lds_pairs_sorted<BLOCK, Body>;
+    else
+      kern = &nepmi_kernel_lds_pairs<BLOCK, Body>;
+    if (lds_bytes > 60 * 1024)
+      NEPMI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
     const bool t = timed(slot);
     if (t)
       timer_start(timing->slot[slot]);
-    hipLaunchKernelGGL((nepmi_kernel_lds_pairs<BLOCK, Body>), dim3((unsigned)grid), dim3(BLOCK), lds_bytes, stream,
-                       body, n, frozen);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(BLOCK), lds_bytes, stream, body, n, frozen);
     NEPMI_HIP_CHECK(hipGetLastError());
     if (t)
       timer_stop(timing->slot[slot]);
@@ -1501,7 +1557,12 @@ struct HipBackend {
 #ifndef NEPMI_AFU_BLOCK
 #define NEPMI_AFU_BLOCK 256 // A/B switch: threads per workgroup (half as many atoms)
 #endif
-    launch_lds_pairs<NEPMI_AFU_BLOCK>(slot, n, body);
+#ifndef NEPMI_AFU_SORT
+#define NEPMI_AFU_SORT 0 // 1: nepmi_kernel_lds_pairs_sorted.  Measured (profiles/r6q_ab_sort.txt, same box): PbTe 0.458 against 0.450 ms, carbon 2.326
+                         // against 2.290 -- the lockstep waiting it removes is not what the kernel's time is made of (vector issue of the heaviest
+                         // wavefront of a workgroup, which the sort makes no lighter).  Off.
+#endif
+    launch_lds_pairs<NEPMI_AFU_BLOCK, AngularFusedBody<S>, NEPMI_AFU_SORT != 0>(slot, n, body);
   }
 
   // ... for many-type models: type-sorted work order, a window of kFusedWindowTypes types in LDS (nepmi_fused_window_kernel)

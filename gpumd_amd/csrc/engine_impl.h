@@ -1096,6 +1096,7 @@ private:
     b_.rev_ang = dalloc<unsigned short>((size_t)b_.MN_ang * N);
     b_.nn_rad = dalloc<int>(N);
     b_.nn_angstep = dalloc<int>(N);
+    b_.nn_angtrue = dalloc<int>(N);
     if (m.kind == 0) {
       b_.rstash = dalloc<F4>((size_t)(b_.MN_ang + b_.MN_skin) * N);
       b_.acomp = dalloc<F4>((size_t)b_.MN_arows * N);

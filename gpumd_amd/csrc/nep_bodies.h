@@ -123,6 +123,7 @@ struct Bufs {
   // per step
   int* nn_rad;   F4* rstash;   // pair records (r12, j | t2 << 25 or -1) at rows [A slots | MN_ang + B slots]
   int* nn_angstep; F4* acomp;  // compacted angular pair records [MN_acomp][N]
+  int* nn_angtrue;             // [N] angular neighbours behind the padded rows (wave-synchronous records: nn_angstep counts the rows)
   unsigned short* amap;        // [MN_ang][N]: A slot -> compact angular slot of this step, 0xFFFF = none
   F4* f12;                     // [MN_acomp][N] partial forces dU_i/dr_ij at compact slots
   float* q;    // [dim][N]

@@ -150,6 +150,13 @@ struct AngularFusedBody {
     }
   }
 
+  // what the sorted launch orders a workgroup's atoms by: the atom's angular neighbours this step (0: no work at all)
+  NEPMI_HD int sort_key(int64_t k) const
+  {
+    if (b.lvl[k] < b.lvl_desc)
+      return 0;
+    return (b.use_csync && b.nn_angtrue) ? b.nn_angtrue[k] : b.nn_angstep[k]; // (padded rows: the neighbours behind them)
+  }
   template <int PARTS, class LP>
   NEPMI_HD void run_parts(int64_t k, int part, LP lds) const
   {

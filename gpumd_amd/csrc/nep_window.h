@@ -1489,8 +1489,10 @@ struct RadialWin2Body {
       NEPMI_ATOMIC_OR(&b.flags[kFlagOverflow], 4);
       ca = ca > b.MN_acomp ? b.MN_acomp : ca;
     }
-    if (ASYNC)
+    if (ASYNC) {
+      b.nn_angtrue[k] = ca;
       ca = arows < b.MN_arows ? arows : b.MN_arows; // rows of this atom's records, padding included (the same on the whole wavefront)
+    }
     b.nn_rad[k] = cnt + cnt1;
     if (SYNC) {
       const int r0 = q0.rows < b.MN_cw ? q0.rows : b.MN_cw, r1 = q1.rows < b.MN_cw ? q1.rows : b.MN_cw;
