@@ -1628,8 +1628,13 @@ private:
     // UNEP-v1.  With 64-thread workgroups that is three WAVEFRONTS per CU (r3a: 2.06 ms at 1 M atoms); large tables take
     // 512-thread workgroups so that the table is shared by eight wavefronts.
     const bool big_table = (size_t)cang_floats(md_) * sizeof(float) > 16 * 1024;
+#ifndef NEPMI_AF_PAIRS_BIG
+#define NEPMI_AF_PAIRS_BIG 0 // A/B switch: 1 = many-type models with a large table (UNEP-v1: 5 channels) run the partial forces with lane pairs in 512-thread workgroups
+#endif
     if (S::fixed && S::NA + 1 >= 7)
       be_.template launch_lds_pairs<64>(kSlotAngForce, N_, AngularForceBody<S>{md_, b_, recompute_s()});
+    else if (NEPMI_AF_PAIRS_BIG && S::fixed && big_table)
+      be_.template launch_lds_pairs<512>(kSlotAngForce, N_, AngularForceBody<S>{md_, b_, recompute_s()});
     else if (big_table)
       be_.template launch_lds<512>(kSlotAngForce, N_, AngularForceBody<S>{md_, b_, recompute_s()});
     else
