@@ -1320,6 +1320,7 @@ private:
       b_.cell_count = dalloc<int>(ncell + 1);
       b_.cell_fill = dalloc<int>(ncell);
       b_.cell_ghost = dalloc<int>(ncell);
+      brick_live_buf_ = dalloc<int>(ncell / 64 + 2);
       b_.brick_flag = dalloc<int>(ncell / 64 + 2);
       b_.brick_order = dalloc<int>(ncell / 64 + 1);
       b_.wtab = model_.kind == 0 ? dalloc<int>((size_t)(ncell / 64 + 1) * 1024) : nullptr;
@@ -1417,8 +1418,11 @@ private:
     // the bricks' statistics first (they need the cells only): they say whether the Verlet lists can be built from LDS windows
     be_.memset(b_.flags + kFlagMaxWindow, 0, 3 * sizeof(int));
     num_bricks_ = (int64_t)b_.gbx * b_.gby * b_.gbz;
-    if (b_.level)
+    b_.brick_live = (b_.level && brick_live_buf_) ? brick_live_buf_ : nullptr;
+    if (b_.level) {
+      be_.memset(brick_live_buf_, 0, sizeof(int) * (size_t)(num_bricks_ + 1));
       be_.template launch<256>(kSlotMisc, N_, MarkGhostCellsBody{b_});
+    }
     be_.template launch<64>(kSlotMisc, num_bricks_, TileStatsBody{box_, b_});
     be_.memset(b_.brick_flag + num_bricks_, 0, sizeof(int));
     be_.exclusive_scan(b_.brick_flag, num_bricks_ + 1, scan_scratch_);
@@ -2409,6 +2413,7 @@ private:
   int guard_delay_next_ = 0;
   bool tersoff_defer_ = false;    // this force evaluation leaves the Tersoff assembly to the next pass over the atoms (run loop, NVE)
   bool tersoff_deferred_ = false; // ... and that assembly is still due
+  int* brick_live_buf_ = nullptr; // Bufs::brick_live of decomposed runs
   const int* dmap_dev_ = nullptr; // NepModel::dmap on the device (export_descriptors of a zero-padded model)
   double hard_asked_ = 4.0;      // set_scatter_guard: the hard factor as asked for
   double guard_delayed_ = 64.0;

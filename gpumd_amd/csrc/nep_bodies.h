@@ -105,6 +105,8 @@ struct Bufs {
   int* cell_count;      // [ncell+1] -> exclusive scan in place = cell_start
   int* cell_fill;       // [ncell]
   int* cell_ghost;      // [ncell] 1: the cell holds an atom that is not owned (level < 2)
+  int* brick_live;      // [nbricks] decomposed runs (else nullptr): 1 = the brick holds an atom of level >= 1 -- the window kernels have
+                        // nothing to do in the bricks of the outer ghost ring (their atoms only lend positions) and skip them unstaged
   int* brick_flag;      // [nbricks+1] 1: a ghost sits in the brick's 8x8x8-cell window; scanned in place
   int* brick_order;     // [nbricks] interior bricks first (ascending), then boundary bricks
   int* cid;             // [N] caller order
@@ -970,6 +972,8 @@ struct MarkGhostCellsBody {
   {
     if (b.lvl[k] < 2)
       b.cell_ghost[b.kcell[k]] = 1; // benign race: all writers store 1
+    if (b.lvl[k] >= 1 && b.brick_live)
+      b.brick_live[b.kcell[k] >> 6] = 1;
   }
 };
 struct BrickOrderBody {

@@ -567,6 +567,8 @@ nepmi_force_scatter_kernel(const ForceScatterBody<S> body, const int64_t nbricks
   const int tid = (int)threadIdx.x;
   const ScatterLayout lay{body.st.lay.wmax};
   const Bufs& b = body.st.b;
+  if (b.brick_live && !b.brick_live[brick])
+    return; // (outer ghost ring of a decomposed run: no atom of the brick has descriptors; FoldMapBody leaves the brick out)
   {
     // staging: the window cells' fixed-point records from Bufs::prec with the cell's offset from the window centre added
     // (WinStage::stage_direct without the index | type word), accumulators cleared
@@ -881,6 +883,8 @@ __global__ void __launch_bounds__(kWinThreads * L) nepmi_force_scatter_mt_kernel
   const int tid = (int)threadIdx.x;
   const Bufs& b = body.st.b;
   const ModelD& m = body.m;
+  if (b.brick_live && !b.brick_live[brick])
+    return; // (outer ghost ring: no atom of the brick has descriptors; FoldMapBody leaves the brick out)
   const ScatterLayoutMT lay{body.st.lay.wmax, m.T * m.T * ctab_block(m.NR, m.KR, NEPMI_FS_MT_VEC != 0)};
   {
     NEPMI_LDS(I3)* wp = (NEPMI_LDS(I3)*)(lds + lay.off_pos());
@@ -986,6 +990,8 @@ struct FoldMapBody {
         for (int ix = 0; ix < nc[0]; ++ix) {
           const int64_t q = cand[0][ix] + (int64_t)b.gbx * (cand[1][iy] + (int64_t)b.gby * cand[2][iz]);
           const int wc = wpos[0][ix] + 8 * wpos[1][iy] + 64 * wpos[2][iz];
+          if (b.brick_live && !b.brick_live[q])
+            continue; // (a brick of the outer ghost ring: the scatter kernels skip it, its rows do not exist)
           const int* tab = b.wtab + (q * 512 + wc) * 2;
           const int r = (int)(k - tab[0]);
           if (r < 0 || r >= (tab[1] >> 16))

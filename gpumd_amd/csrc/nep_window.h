@@ -897,6 +897,8 @@ struct RadialWin2Body {
   template <class LC>
   NEPMI_HD void stage(int64_t brick, LC lds, int tid, int nth) const
   {
+    if (st.b.brick_live && !st.b.brick_live[brick])
+      return; // a brick of the outer ghost ring: compute() returns for every one of its atoms before it looks at the window
     st.stage_direct(brick, lds, tid, nth);
     if (ctab_on())
       ctab_stage_padded(m, lds + ctab_offset(), tid, nth, false);
