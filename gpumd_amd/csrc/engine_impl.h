@@ -1444,7 +1444,13 @@ private:
     }
     if (!build_in_windows)
       be_.template launch<128>(kSlotMisc, N_, BuildListsBody{box_, b_});
-    be_.template launch<128>(kSlotMisc, N_, ReverseSlotsBody{box_, b_});
+    // The reverse slots of list A (where does i sit in j's list: what the GATHER form needs to find the partner's partial force)
+    // are built when a kernel that reads them is about to run (ensure_reverse_slots): the run loops' radial pass in its
+    // wave-synchronous form does not, so a rebuild inside a scatter-form loop never pays for them (PbTe 0.32 ms, UNEP-v1 1.5 ms,
+    // carbon 3.6 ms per million atoms and rebuild).  Tersoff reads them on every step; single-domain engines only.
+    rev_valid_ = false;
+    if (model_.kind == 1 || b_.level) // (decomposed runs: eagerly -- their boundary bricks' radial pass may run on another stream)
+      ensure_reverse_slots();
     be_.end_region(kRegionRebuild);
     be_.d2h(flags, b_.flags, sizeof(flags));
     check_overflow(flags);
@@ -1868,6 +1874,7 @@ private:
       set_scatter_guard(guard_delayed_, -1.0);
     const WinStage ws{box_, b_, win_};
     if (phase == kPhaseRecords) { // diagnostics: materialise the pair records of the current positions
+      ensure_reverse_slots();
       be_.template launch<64>(kSlotMisc, N_, RadialDescBody<S>{box_, md_, b_, 1});
       records_valid_ = true;
       return;
@@ -1901,6 +1908,8 @@ private:
     WinLayout lay2 = win_;
     lay2.compact = 1;
     const WinStage ws2{box_, b_, lay2};
+    if (!(win2 && b_.use_csync && S::fixed)) // (every other form of the radial pass stores the reverse slot of each angular pair)
+      ensure_reverse_slots();
     B& rbe = radial_side_ ? *radial_side_ : be_; // (force_kernels_on: the boundary bricks on the communication stream)
     auto radial = [&](int64_t nb, int first) {
       if (win2 && b_.use_csync)
@@ -1973,6 +1982,16 @@ private:
     be_.end_region(kRegionForce);
   }
 
+  void ensure_reverse_slots()
+  {
+    if (rev_valid_)
+      return;
+    const int* saved = be_.frozen; // (never skipped: a later gather-form step would read what was not written)
+    be_.frozen = nullptr;
+    be_.template launch<128>(kSlotMisc, N_, ReverseSlotsBody{box_, b_});
+    be_.frozen = saved;
+    rev_valid_ = true;
+  }
   // angular descriptor, ANN and partial angular forces of the current angular records: one kernel or three
   template <class S>
   void angular_kernels()
@@ -2414,6 +2433,7 @@ private:
   bool tersoff_defer_ = false;    // this force evaluation leaves the Tersoff assembly to the next pass over the atoms (run loop, NVE)
   bool tersoff_deferred_ = false; // ... and that assembly is still due
   int* brick_live_buf_ = nullptr; // Bufs::brick_live of decomposed runs
+  bool rev_valid_ = false;        // Bufs::rev_ang holds the reverse slots of the current Verlet lists (ensure_reverse_slots)
   const int* dmap_dev_ = nullptr; // NepModel::dmap on the device (export_descriptors of a zero-padded model)
   double hard_asked_ = 4.0;      // set_scatter_guard: the hard factor as asked for
   double guard_delayed_ = 64.0;
