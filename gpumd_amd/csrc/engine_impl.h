@@ -709,6 +709,17 @@ public:
       return flags[kFlagMoved];
     };
 
+    // rows of the thermo records of this call, on the device until the loop ends
+    double* thermo_rows = nullptr;
+    const int64_t nrec = (thermo_every > 0 && thermo_host) ? nsteps / thermo_every : 0;
+    if (nrec > 0) {
+      if (thermo_rows_cap_ < nrec) {
+        dfree(thermo_rows_);
+        thermo_rows_ = dalloc<double>(8 * (size_t)nrec);
+        thermo_rows_cap_ = nrec;
+      }
+      thermo_rows = thermo_rows_;
+    }
     int64_t step = 0;
     // Temperature-dependent NEP under a thermostat: Force::temperature starts at t1 (run.cu:679-681) and EVERY
     // Force::compute of the run adds delta_T = (t2 - t1) / nsteps first (force.cu:803) -- the initial one included
@@ -751,7 +762,12 @@ public:
       force_kernels(kPhaseAll, frozen);
       tersoff_defer_ = false;
       b_.trip_tag = 0;
-      bool need_sync = record || last;
+      // A thermo record does not stop the pipeline: find_thermo's eight numbers go to row `rec` of a device buffer (a 64-byte copy on the
+      // stream) and all rows come to the host when the loop ends -- the reference reduces thermo on EVERY step (ensemble_nve.cu:59-95),
+      // so a record must not cost a host round trip.  (Measured, r6v: thermo every step 1.287 ms with or without the per-record
+      // synchronisation -- the speculative enqueue already hid it; what a record step costs is its work: energies and virials written,
+      // the second half-kick as a pass of its own, the reduction.)
+      bool need_sync = last;
       if (ens == kNve && !record && !last) {
         kick2_pending = true; // fused into the next step's pass over the atoms
       } else {
@@ -775,6 +791,8 @@ public:
           thermo_now();
         }
       }
+      if (record && thermo_rows)
+        be_.d2d(thermo_rows + 8 * ((step + 1) / thermo_every - 1), thermo_dev_, 8 * sizeof(double)); // (a frozen step's row is written again by its replay)
       int trip = 0;
       if (need_sync) {
         trip = sync_and_check();
@@ -784,8 +802,6 @@ public:
             be_.d2h(&T, thermo_dev_, sizeof(double));
             be_.template launch<256>(kSlotVV, N_, ResidentScaleBody{b_, nullptr, bdp_factor(N_, T, target, tcoup)});
           }
-          if (record)
-            be_.d2h(thermo_host + 8 * ((step + 1) / thermo_every - 1), thermo_dev_, 8 * sizeof(double));
         }
       } else if ((step + 1) % kPollEvery == 0) {
         be_.poll_record(ring_next, b_.flags);
@@ -795,7 +811,7 @@ public:
           int snap[8];
           be_.poll_wait(pending.front().ring, snap);
           pending.erase(pending.begin());
-          if (snap[kFlagMoved])
+          if (snap[kFlagMoved] || snap[kFlagOverflow]) // (a capacity bit: the full look throws)
             trip = sync_and_check();
         }
       }
@@ -812,6 +828,8 @@ public:
       exact_virials(); // per-atom virials leave the engine
     resident_export(pos, vel, pe, force, virial);
     be_.sync();
+    if (nrec > 0)
+      be_.d2h(thermo_host, thermo_rows, sizeof(double) * 8 * (size_t)nrec);
     be_.d2h(flags, b_.flags, sizeof(flags));
     check_overflow(flags);
   }
@@ -2433,6 +2451,8 @@ private:
   bool tersoff_defer_ = false;    // this force evaluation leaves the Tersoff assembly to the next pass over the atoms (run loop, NVE)
   bool tersoff_deferred_ = false; // ... and that assembly is still due
   int* brick_live_buf_ = nullptr; // Bufs::brick_live of decomposed runs
+  double* thermo_rows_ = nullptr; // thermo records of a run call (device), copied to the host when the loop ends
+  int64_t thermo_rows_cap_ = 0;
   bool rev_valid_ = false;        // Bufs::rev_ang holds the reverse slots of the current Verlet lists (ensure_reverse_slots)
   const int* dmap_dev_ = nullptr; // NepModel::dmap on the device (export_descriptors of a zero-padded model)
   double hard_asked_ = 4.0;      // set_scatter_guard: the hard factor as asked for
