@@ -621,6 +621,7 @@ public:
   static constexpr int64_t kScatterMinBricks = 513;
   static constexpr int kPollEvery = 4; // steps between two snapshots of the device flags
   static constexpr int kPollDepth = 2; // snapshots in flight: the host runs 8-12 steps ahead of the device
+  static constexpr int kPollEveryCalm = 16, kPollCalmSteps = 256; // ... and every 16 steps once the lists have stood for 256 (run_md)
 
   void run_md(
     int ens, const double h9[9], const int pbc[3], int64_t n, const int* type, const double* mass, double dt,
@@ -720,6 +721,12 @@ public:
       }
       thermo_rows = thermo_rows_;
     }
+    // A look costs a 32-byte copy and an event on the stream (7.6 us: 1.9 us per step of config 2's 28); a late look costs the steps
+    // enqueued behind a trip, which run as no-ops.  While the lists have been standing for kPollCalmSteps the looks are taken every
+    // kPollEveryCalm steps (r6x: Si 13,824 atoms 4.86e8 -> 5.22e8 atom-steps/s; PbTe 16,000 atoms, a rebuild every ~40 steps, loses
+    // 5 % when it always looks that rarely -- it never gets there).  NEPMI_POLL_EVERY fixes the interval (A/B switch).
+    static const int poll_fixed = std::getenv("NEPMI_POLL_EVERY") ? std::max(1, std::atoi(std::getenv("NEPMI_POLL_EVERY"))) : 0;
+    int64_t calm_since = -calm_steps_; // the step the lists were last rebuilt at (negative: in an earlier call; prepare_lists above resets the count when it rebuilds)
     int64_t step = 0;
     // Temperature-dependent NEP under a thermostat: Force::temperature starts at t1 (run.cu:679-681) and EVERY
     // Force::compute of the run adds delta_T = (t2 - t1) / nsteps first (force.cu:803) -- the initial one included
@@ -803,7 +810,7 @@ public:
             be_.template launch<256>(kSlotVV, N_, ResidentScaleBody{b_, nullptr, bdp_factor(N_, T, target, tcoup)});
           }
         }
-      } else if ((step + 1) % kPollEvery == 0) {
+      } else if ((step + 1) % (poll_fixed ? poll_fixed : (step - calm_since >= kPollCalmSteps ? kPollEveryCalm : kPollEvery)) == 0) {
         be_.poll_record(ring_next, b_.flags);
         pending.push_back(Snapshot{ring_next});
         ring_next = (ring_next + 1) % 8;
@@ -817,6 +824,7 @@ public:
       }
       if (trip) {
         step = handle_trip(trip, step);
+        calm_since = step;
         resume_after_vv1 = true;
         tersoff_deferred_ = false; // (the frozen step's pass had taken the assembly of the step before it; what was enqueued since ran as no-ops)
         continue;
@@ -824,6 +832,7 @@ public:
       ++step;
     }
     num_compute = compute0 + nsteps;
+    calm_steps_ = nsteps - calm_since;
     if (virial)
       exact_virials(); // per-atom virials leave the engine
     resident_export(pos, vel, pe, force, virial);
@@ -1292,6 +1301,7 @@ private:
   void rebuild(const int* type, const double* pos)
   {
     const NepModel& m = model_;
+    calm_steps_ = 0;
     const double rc_list = m.rc_radial_max + kSkin;
     double rc_cell = 0.5 * rc_list;
     int nb[3];
@@ -2450,6 +2460,7 @@ private:
   int guard_delay_next_ = 0;
   bool tersoff_defer_ = false;    // this force evaluation leaves the Tersoff assembly to the next pass over the atoms (run loop, NVE)
   bool tersoff_deferred_ = false; // ... and that assembly is still due
+  int64_t calm_steps_ = 0;        // run-loop steps since the last list rebuild, across calls (run_md: how often the host looks at the flags)
   int* brick_live_buf_ = nullptr; // Bufs::brick_live of decomposed runs
   double* thermo_rows_ = nullptr; // thermo records of a run call (device), copied to the host when the loop ends
   int64_t thermo_rows_cap_ = 0;
