@@ -2414,7 +2414,7 @@ private:
       // members of the local list in LDS; kTersoffLanes lanes per atom while the system leaves CUs short of wavefronts (a
       // counted rule: 13,824 atoms 36 -> 16 us, 884,736 atoms 0.55 -> 0.63 ms with four lanes)
       if (N_ < 200000)
-        be_.template launch_lds_parts<kTersoffBlock, kTersoffLanes>(kSlotRadial, N_, TersoffPartialBody{box_, tp_, b_, tb_});
+        be_.template launch_lds_parts<kTersoffBlock, kTersoffLanes>(kSlotRadial, N_, TersoffPartialBody{box_, tp_, b_, tb_, kTersoffLanes});
       else
         be_.template launch_lds<kTersoffBlock>(kSlotRadial, N_, TersoffPartialBody{box_, tp_, b_, tb_});
       // (a run loop's forces-only NVE step: the assembly rides in the next pass over the atoms, TersoffSeamBody)

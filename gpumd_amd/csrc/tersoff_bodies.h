@@ -85,6 +85,15 @@ constexpr int kTersoffLocalMax = 8;
 constexpr int kTersoffBlock = 64;
 constexpr int kTersoffLanes = 4; // lanes per atom on the device (the emulator's host loop runs one)
 constexpr int kTersoffLdsDoubles = kTersoffLocalMax * 7 * kTersoffBlock;
+// The several-lanes form (run_shared) keeps eleven numbers per member -- x, y, z, type, b, b', u and the member's own d, fc, fc', fA,
+// which every bond of the atom needs and one lane evaluates -- plus a staging area where the lane that tested a Verlet entry leaves
+// the record of a member it found (its position was in that lane's registers: no second gather):
+//   member table  [(m * 11 + e) * A + a],   stage  [((lane * kTersoffLocalMax + q) * 4 + e) * A + a],   A = atoms per workgroup
+constexpr int kTersoffMemberWords = 11;
+constexpr int tersoff_shared_doubles(int lanes)
+{
+  return (kTersoffLocalMax * kTersoffMemberWords + lanes * kTersoffLocalMax * 4) * (kTersoffBlock / lanes);
+}
 
 #if defined(__HIP_DEVICE_COMPILE__)
 // lanes of one wavefront hand data to each other through LDS: order the writes before the reads
@@ -105,8 +114,13 @@ struct TersoffPartialBody {
   TersoffParamsD tp;
   Bufs b;
   TersoffBufs tb;
+  int lanes = 1; // lanes per atom of the launch (sizes the LDS: run_shared's layout for more than one)
   static constexpr int kMinWavesPerEu = 1;
-  NEPMI_HD int lds_floats() const { return 2 * kTersoffLdsDoubles; }
+  NEPMI_HD int lds_floats() const // (the emulator's host loop runs the one-lane form whatever `lanes` says: never less than that needs)
+  {
+    const int shared = lanes > 1 ? tersoff_shared_doubles(lanes) : 0;
+    return 2 * (shared > kTersoffLdsDoubles ? shared : kTersoffLdsDoubles);
+  }
   template <class LP>
   NEPMI_HD void lds_stage(LP, int, int) const {}
   template <class LP>
@@ -121,6 +135,10 @@ struct TersoffPartialBody {
   template <int P, class LP>
   NEPMI_HD void run_parts(int64_t k, int part, LP lds_f) const
   {
+    if constexpr (P > 1) {
+      run_shared<P>(k, part, lds_f);
+      return;
+    }
     const int64_t N = b.N;
     if (b.lvl[k] < 1)
       return;
@@ -279,6 +297,191 @@ struct TersoffPartialBody {
         double fc13, fcp13;
         ters_fc(p13, d13, fc13, fcp13);
         const double fa13 = p13.b * exp(-p13.mu * d13);
+        const double bp13 = at(i2, 5);
+        const double od = 1.0 / (d12 * d13);
+        const double c123 = (x12 * x13 + y12 * y13 + z12 * z13) * od;
+        const double c_over = c123 * d12inv * d12inv;
+        const double tmp = s1.d2 + (c123 - s1.h) * (c123 - s1.h);
+        const double g123 = s1.one_plus_c2overd2 - s1.c2 / tmp;
+        const double gp123 = 2.0 * s1.c2 * (c123 - s1.h) / (tmp * tmp);
+        const double ta = (-bp12 * fc12 * fa12 * fc13 - bp13 * fc13 * fa13 * fc12) * gp123;
+        const double tbb = -bp13 * fc13 * fa13 * fcp12 * g123 * d12inv;
+        fx += (x12 * tbb + ta * (x13 * od - x12 * c_over)) * 0.5;
+        fy += (y12 * tbb + ta * (y13 * od - y12 * c_over)) * 0.5;
+        fz += (z12 * tbb + ta * (z13 * od - z12 * c_over)) * 0.5;
+      }
+      D4 out;
+      out.x = fx;
+      out.y = fy;
+      out.z = fz;
+      out.w = 0;
+      tb.f12[(int64_t)slot * N + k] = out;
+    }
+    NEPMI_WAVE_LDS_SYNC();
+    if (part == 0) { // the bonds' energies in bond order: the sum of the one-lane form, bit for bit
+      double u = 0.0;
+      for (int m = 0; m < cnt; ++m)
+        u += at(m, 6);
+      tb.pe_d[k] = u;
+    }
+  }
+
+  // Several lanes per atom (P > 1), two changes against the form above, same arithmetic per bond:
+  //  * the lane that TESTS a Verlet entry has the neighbour's position in its registers; when the entry is a member it forms the FP64
+  //    record at once and leaves it in its staging rows, and once all lanes know all membership bits it moves the record to row
+  //    m = (number of members in front of it) of the member table -- the form above gathered the members' positions a second time
+  //    (index -> position: two dependent round trips of a kernel that is one wavefront's latency long);
+  //  * a member's distance, cutoff function and attractive term are needed by every bond of the atom (as the "13" terms of steps 1
+  //    and 2): its owner lane evaluates them once (the same expressions on the same operands: the same bits) and the others read
+  //    them -- three exponentials and three square roots per lane less (silicon: four bonds on four lanes).
+  template <int P, class LP>
+  NEPMI_HD void run_shared(int64_t k, int part, LP lds_f) const
+  {
+    const int64_t N = b.N;
+    if (b.lvl[k] < 1)
+      return;
+    constexpr int APB = kTersoffBlock / P, E = kTersoffMemberWords;
+    double* L = const_cast<double*>(reinterpret_cast<const double*>(&lds_f[0])) + (int)(k % APB);
+    double* ST = L + kTersoffLocalMax * E * APB;
+    auto at = [&](int m, int e) -> double& { return L[(m * E + e) * APB]; };
+    auto st = [&](int q, int e) -> double& { return ST[((part * kTersoffLocalMax + q) * 4 + e) * APB]; };
+    const PosQ p1 = b.posq[k];
+    const int t1 = p1.type;
+    const TersoffSetD& s1 = tp.p[t1];
+    const int nn = b.nn_ang[k];
+    // pass A: membership of every Verlet entry (float geometry); a member's record goes to the global rows and to the stage
+    unsigned long long inr = 0ull;
+    int nk = 0; // members this lane has found
+    constexpr int RB = 8 / P > 0 ? 8 / P : 1;
+    for (int s0 = 0; s0 < nn && s0 < 64; s0 += RB * P) {
+      int jj[RB];
+#pragma unroll
+      for (int u = 0; u < RB; ++u) {
+        const int s = s0 + u * P + part;
+        jj[u] = b.nl_ang[(int64_t)(s < nn ? s : nn - 1) * N + k];
+      }
+      PosQ pp[RB];
+#pragma unroll
+      for (int u = 0; u < RB; ++u)
+        pp[u] = b.posq[jj[u]];
+#pragma unroll
+      for (int u = 0; u < RB; ++u) {
+        const int s = s0 + u * P + part;
+        float xf, yf, zf;
+        const float d2f = pair_geometry(box, p1, pp[u], xf, yf, zf);
+        if (s < nn && s < 64 && d2f < tp.rc_sq) {
+          inr |= 1ull << s;
+          if (nk < kTersoffLocalMax) {
+            D4 r;
+            r.x = pp[u].x - p1.x;
+            r.y = pp[u].y - p1.y;
+            r.z = pp[u].z - p1.z;
+            mic_d(box, r.x, r.y, r.z);
+            r.w = 1 | ((long long)pp[u].type << 8);
+            tb.rec[(int64_t)s * N + k] = r;
+            st(nk, 0) = r.x;
+            st(nk, 1) = r.y;
+            st(nk, 2) = r.z;
+            st(nk, 3) = (double)(pp[u].type + 256 * s);
+          }
+          ++nk;
+        }
+      }
+    }
+    {
+      unsigned lo = (unsigned)inr, hi = (unsigned)(inr >> 32);
+#pragma unroll
+      for (int msk = 1; msk < P; msk <<= 1) {
+        lo |= (unsigned)NEPMI_SHFL_XOR((int)lo, msk);
+        hi |= (unsigned)NEPMI_SHFL_XOR((int)hi, msk);
+      }
+      inr = (unsigned long long)lo | ((unsigned long long)hi << 32);
+    }
+    const int cnt = __builtin_popcountll(inr);
+    if (nn > 64 || cnt > kTersoffLocalMax) { // long lists: the plain form, one lane (it writes every record again)
+      if (part == 0)
+        (*this)(k);
+      return;
+    }
+    if (part == 0) {
+      tb.mask[k] = inr;
+      b.nn_rad[k] = cnt;
+      b.nn_angstep[k] = cnt;
+    }
+    // the staged records to their rows of the member table (cnt <= kTersoffLocalMax: every lane's members were staged)
+    for (int q = 0; q < nk; ++q) {
+      const int code = (int)st(q, 3);
+      const int s = code >> 8;
+      const int m = __builtin_popcountll(inr & ((1ull << s) - 1ull));
+      at(m, 0) = st(q, 0);
+      at(m, 1) = st(q, 1);
+      at(m, 2) = st(q, 2);
+      at(m, 3) = (double)(code & 255);
+    }
+    NEPMI_WAVE_LDS_SYNC();
+    // the members' own terms, by their owner lanes
+    for (int i1 = part; i1 < cnt; i1 += P) {
+      const double x12 = at(i1, 0), y12 = at(i1, 1), z12 = at(i1, 2);
+      const TersoffSetD& p12 = ters_pair(tp, t1, (int)at(i1, 3));
+      const double d12 = sqrt(x12 * x12 + y12 * y12 + z12 * z12);
+      double fc12, fcp12;
+      ters_fc(p12, d12, fc12, fcp12);
+      at(i1, 7) = d12;
+      at(i1, 8) = fc12;
+      at(i1, 9) = fcp12;
+      at(i1, 10) = p12.b * exp(-p12.mu * d12);
+    }
+    NEPMI_WAVE_LDS_SYNC();
+    // step 1: bond order of the bonds this lane owns
+    for (int i1 = part; i1 < cnt; i1 += P) {
+      const double x12 = at(i1, 0), y12 = at(i1, 1), z12 = at(i1, 2);
+      const double d12 = at(i1, 7);
+      double zeta = 0.0;
+      for (int i2 = 0; i2 < cnt; ++i2) {
+        if (i2 == i1)
+          continue;
+        const double x13 = at(i2, 0), y13 = at(i2, 1), z13 = at(i2, 2);
+        const double d13 = at(i2, 7), fc13 = at(i2, 8);
+        const double c123 = (x12 * x13 + y12 * y13 + z12 * z13) / (d12 * d13);
+        const double tmp = s1.d2 + (c123 - s1.h) * (c123 - s1.h);
+        zeta += fc13 * (s1.one_plus_c2overd2 - s1.c2 / tmp);
+      }
+      const double bzn = pow(s1.beta * zeta, s1.n);
+      const double b12 = pow(1.0 + bzn, s1.minus_half_over_n);
+      if (zeta < 1.0e-16) { // avoid division by 0
+        at(i1, 4) = 1.0;
+        at(i1, 5) = 0.0;
+      } else {
+        at(i1, 4) = b12;
+        at(i1, 5) = -b12 * bzn * 0.5 / ((1.0 + bzn) * zeta);
+      }
+    }
+    NEPMI_WAVE_LDS_SYNC();
+    // step 2: partial forces and energy of the bonds this lane owns
+    for (int i1 = part; i1 < cnt; i1 += P) {
+      int slot = 0;
+      {
+        unsigned long long rest = inr;
+        for (int q = 0; q < i1; ++q)
+          rest &= rest - 1ull;
+        slot = (int)__builtin_ctzll(rest);
+      }
+      const double x12 = at(i1, 0), y12 = at(i1, 1), z12 = at(i1, 2);
+      const int t2 = (int)at(i1, 3);
+      const TersoffSetD& p12 = ters_pair(tp, t1, t2);
+      const double d12 = at(i1, 7), fc12 = at(i1, 8), fcp12 = at(i1, 9), fa12 = at(i1, 10);
+      const double d12inv = 1.0 / d12;
+      const double fap12 = -p12.mu * fa12;
+      const double fr12 = p12.a * exp(-p12.lambda * d12), frp12 = -p12.lambda * fr12;
+      const double b12 = at(i1, 4), bp12 = at(i1, 5);
+      const double factor3 = (fcp12 * (fr12 - b12 * fa12) + fc12 * (frp12 - b12 * fap12)) * d12inv;
+      double fx = x12 * factor3 * 0.5, fy = y12 * factor3 * 0.5, fz = z12 * factor3 * 0.5;
+      at(i1, 6) = fc12 * (fr12 - b12 * fa12) * 0.5;
+      for (int i2 = 0; i2 < cnt; ++i2) {
+        if (i2 == i1)
+          continue;
+        const double x13 = at(i2, 0), y13 = at(i2, 1), z13 = at(i2, 2);
+        const double d13 = at(i2, 7), fc13 = at(i2, 8), fa13 = at(i2, 10);
         const double bp13 = at(i2, 5);
         const double od = 1.0 / (d12 * d13);
         const double c123 = (x12 * x13 + y12 * y13 + z12 * z13) * od;
