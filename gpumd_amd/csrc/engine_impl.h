@@ -1367,7 +1367,13 @@ private:
       if (!same) {
         const double edge0 = rc_cell;
         const int nb0 = nb[0];
-        double best = edge0;
+        // (when no coarser grid fits -- dense long-cutoff models, whose bricks take several passes anyway -- at least the even grid
+        // with the same number of cells: cells of exactly (rc + skin) / 2 leave the box's remainder to the last cell of every
+        // direction, up to twice as wide, and the window that holds eight of those per direction sets the LDS budget of every brick:
+        // C_2024_NEP4 in diamond, 35 cells per direction: 8,000 window slots against 6,100)
+        double best = box_.thickness[0] / nb0 * (1.0 - 1.0e-12);
+        if (best < edge0)
+          best = edge0;
         for (int k = 1; k <= 6 && nb0 - k >= 8; ++k) {
           rc_cell = box_.thickness[0] / (nb0 - k) * (1.0 - 1.0e-12);
           if (rc_cell < edge0)
@@ -1459,7 +1465,7 @@ private:
     bool build_in_windows = false;
     if (NEPMI_BUILD_WIN && use_tiles_ && model_.kind == 0 && b_.prec) {
       be_.d2h(flags, b_.flags, sizeof(flags));
-      build_in_windows = flags[kFlagMaxCell] <= 127 && flags[kFlagMaxWindow] <= kWinMaxAtoms && !flags[kFlagOutlier];
+      build_in_windows = flags[kFlagMaxCell] <= 127 && flags[kFlagMaxWindow] <= win_max_atoms() && !flags[kFlagOutlier];
       for (int d = 0; d < 3; ++d)
         if (box_.pbc[d] && nb[d] < 8)
           build_in_windows = false;
@@ -1486,11 +1492,14 @@ private:
     max_ang_rebuild_ = flags[kFlagMaxAng];
     // LDS-window radial pass: unique window cells (>= 8 cells per periodic direction), 7-bit rank
     // in cell, window fits the LDS budget
-    tile_ok_ = use_tiles_ && model_.kind == 0 && flags[kFlagMaxCell] <= 127 && flags[kFlagMaxWindow] <= kWinMaxAtoms &&
+    tile_ok_ = use_tiles_ && model_.kind == 0 && flags[kFlagMaxCell] <= 127 && flags[kFlagMaxWindow] <= win_max_atoms() &&
                !flags[kFlagOutlier];
     for (int d = 0; d < 3; ++d)
       if (box_.pbc[d] && nb[d] < 8)
         tile_ok_ = false;
+    if (std::getenv("NEPMI_DEBUG_REBUILD"))
+      std::fprintf(stderr, "nepmi rebuild: cells %d %d %d max_cell %d max_window %d (cap %d) max_brick %d outlier %d tiles %d -> tile_ok %d\n", nb[0], nb[1], nb[2],
+                   flags[kFlagMaxCell], flags[kFlagMaxWindow], win_max_atoms(), flags[kFlagMaxBrick], flags[kFlagOutlier], (int)use_tiles_, (int)tile_ok_);
     win_.wmax = (flags[kFlagMaxWindow] + 63) / 64 * 64;
     // static window layout of the one-lane window kernels: Verlet entries as LDS slots, four to a word
     win2_ok_ = tile_ok_ && use_win2_ && b_.wtab != nullptr && win_.wmax < 65535;
@@ -2103,6 +2112,12 @@ private:
     // FPJ gather form applies (it supplies the virial-only pass; neither needs the per-atom radial table from the ANN kernel)
     return fpj_wanted<S>(ws2) &&
            25 * (size_t)win_.wmax + 4 * (size_t)model_.num_types * model_.num_types * ctab_block(md_.NR, md_.KR, true) <= B::kMaxLdsBytes;
+  }
+  // window capacity in atoms (nep_window.h: kWinMaxAtoms); NEPMI_WIN_MAX_ATOMS overrides it (A/B switch)
+  static int win_max_atoms()
+  {
+    static const int v = std::getenv("NEPMI_WIN_MAX_ATOMS") ? std::atoi(std::getenv("NEPMI_WIN_MAX_ATOMS")) : kWinMaxAtoms;
+    return v;
   }
   // how this step's radial pass left the pairs inside the cutoff (nep_scatter.h: MODE)
   int list_mode() const { return b_.use_csync ? 2 : (b_.use_rmask ? 1 : 0); }

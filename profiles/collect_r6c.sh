@@ -1,19 +1,12 @@
-# round 6c: matrix-core ANN for many-type models, late evaluation in the many-type radial pass
-set -x
 cd /root/repo
-T=r6c
-(timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_model_variants.py -m gpu -q -x) > gpurun_out/pytest_${T}_par.log 2>&1; grep -E "passed|failed|^E |^FAILED" gpurun_out/pytest_${T}_par.log | head -20
-(timeout 900 python -m pytest tests/test_ref_md_parity.py -m gpu -q -x -s -k "scatter_form") > gpurun_out/pytest_${T}_traj.log 2>&1; grep -E "passed|failed|^E |^FAILED|MD parity" gpurun_out/pytest_${T}_traj.log | head -20
-(timeout 600 python -m pytest tests/test_dist_inproc.py -m gpu -q -x -k "guard or reverse_exchange") > gpurun_out/pytest_${T}_dist.log 2>&1; grep -E "passed|failed|^E |^FAILED" gpurun_out/pytest_${T}_dist.log | head -20
-for s in 1 0; do
-NEPMI_BENCH_SYNC=$s NEPMI_BENCH_MFMA=$s timeout 300 python bench.py --no-cpu-baseline --no-extras --workload unep --reps 16 16 16 --steps 20 --warmup 5 > gpurun_out/bench_${T}_u_s$s.json 2> gpurun_out/bench_${T}_u_s$s.err
-python - gpurun_out/bench_${T}_u_s$s.json <<'PY'
+export NEPMI_JIT=2 NEPMI_DEBUG_REBUILD=1
+NEPMI_WIN_MAX_ATOMS=5000 timeout 200 python tools/c2024_probe.py 24 gpurun_out/c24_gather.npz 2>&1 | grep -v amdgpu.ids | cut -c1-300
+NEPMI_WIN_MAX_ATOMS=6656 timeout 200 python tools/c2024_probe.py 24 gpurun_out/c24_window.npz 2>&1 | grep -v amdgpu.ids | cut -c1-300
+python tools/c2024_probe.py --compare gpurun_out/c24_gather.npz gpurun_out/c24_window.npz
+unset NEPMI_DEBUG_REBUILD
+for wm in 5000 6656; do
+  NEPMI_WIN_MAX_ATOMS=$wm timeout 200 python bench.py --no-cpu-baseline --no-extras --workload carbon2024 --reps 10 10 10 --steps 10 --warmup 3 2>gpurun_out/r6c_err_$wm.txt | python -c "
 import json,sys
-try:
-    d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
-    print("unep ms/step %.4f value %.4g"%(d["ms_per_step"], d["value"]), {k[:10]:round(v["avg_ms"],4) for k,v in d["kernels"].items()})
-    print(d["config"]["kernel_forms"])
-except Exception as e:
-    print(sys.argv[1], "ERR", e)
-PY
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('win_max $wm', d['config']['workload'][:40], 'ms/step %.4f value %.4g' % (d['ms_per_step'], d['value']), {k:round(v['avg_ms'],3) for k,v in d['kernels'].items()}); print(d['config']['kernel_forms']); print(d.get('thermo_last'))"
+  tail -2 gpurun_out/r6c_err_$wm.txt | cut -c1-300
 done

@@ -13,7 +13,7 @@ import helpers as H
 import parity_cases as P
 
 JIT_DIR = os.path.join(H.ROOT, "gpumd_amd", "lib", "jit")
-CASES = {"C-2024": "12_16_8_12_6_1", "Si-5body": "10_10_10_10_6_1"}
+CASES = {"C-2024": "12_16_8_12_6_1", "C-2024-window": "12_16_8_12_6_1", "Si-5body": "10_10_10_10_6_1"}
 
 
 def _core(shape):
@@ -150,6 +150,20 @@ def test_force_parity_on_a_jit_core(name, monkeypatch):
     # over up to 358 neighbours: twice the band)
     eng = P.check_force_parity(drv, name, f32_atol=4e-5)
     assert "shape=jit(" in eng.describe(), eng.describe()
+
+
+@pytest.mark.gpu
+def test_long_cutoff_model_in_the_scatter_form_on_its_jit_core(monkeypatch):
+    """C_2024_NEP4 (rc 7 A: ~380 Verlet entries per atom, windows of 5,900 slots, bricks of three passes) on the one-lane window
+    kernels with the force assembly as LDS scatter (147 KB of positions + accumulators per workgroup): the form bench.py's
+    c2024 extras run, against the oracle"""
+    if not _core(CASES["C-2024-window"]):
+        pytest.skip("no prebuilt JIT core")
+    monkeypatch.setenv("NEPMI_JIT", "2")
+    drv = H.GpuDriver()
+    eng = P.check_force_parity(drv, "C-2024-window", lanes=1, win_static=True, force_form=1)
+    d = eng.describe()
+    assert "shape=jit(" in d and "window=lds_static" in d and "lds_scatter_of_own_halves" in d, d
 
 
 @pytest.mark.gpu
