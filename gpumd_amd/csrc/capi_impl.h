@@ -564,6 +564,8 @@ int nepmi_engine_set_option(nepmi_engine* e, const char* name, double value)
     eng.set_tile_mode(iv < 0 ? -1 : iv > 2 ? 2 : iv);
   else if (n == "win_lanes")
     eng.set_win_lanes(iv);
+  else if (n == "win_max_atoms")
+    eng.set_win_max_atoms(iv);
   else if (n == "scatter_guard")
     eng.set_scatter_guard_delayed(value, eng.take_guard_delay());
   else if (n == "scatter_guard_hard")

@@ -1752,6 +1752,12 @@ public:
     return num_bricks_ <= 256 ? 4 : (num_bricks_ <= 512 ? 2 : 1);
   }
   void set_win_lanes(int lanes) { win_lanes_ = (lanes == 1 || lanes == 2 || lanes == 4) ? lanes : 0; }
+  // capacity of a brick's LDS window in atoms (win_max_atoms() below); 0 = the rule
+  void set_win_max_atoms(int v)
+  {
+    win_max_atoms_ = v > 0 ? (v < kWinMaxAtoms ? v : kWinMaxAtoms) : 0;
+    have_list_ = false;
+  }
   int tile_mode_in_use() const { return tile_ok_ ? ((win2_ok_ && win_lanes() == 1) ? 3 : 2) : 0; }
   bool tiles_active() const { return tile_ok_; }
   // 0: per-atom ANN kernel; 1 (default): descriptor + ANN fused where the shape allows it, else the matrix-core
@@ -1825,6 +1831,7 @@ public:
     tile_mode_ = o.tile_mode_;
     recompute_mode_ = o.recompute_mode_;
     win_lanes_ = o.win_lanes_;
+    win_max_atoms_ = o.win_max_atoms_;
     use_win2_ = o.use_win2_;
     external_skin_ = o.external_skin_;
     force_form_ = o.force_form_;
@@ -2113,11 +2120,21 @@ private:
     return fpj_wanted<S>(ws2) &&
            25 * (size_t)win_.wmax + 4 * (size_t)model_.num_types * model_.num_types * ctab_block(md_.NR, md_.KR, true) <= B::kMaxLdsBytes;
   }
-  // window capacity in atoms (nep_window.h: kWinMaxAtoms); NEPMI_WIN_MAX_ATOMS overrides it (A/B switch)
-  static int win_max_atoms()
+  // Window capacity in atoms.  Shapes with type-pure list streams (one or two types: their window kernels keep nothing but the
+  // window in LDS) take windows up to kWinMaxAtoms = 6,656 slots -- C_2024_NEP4 in diamond, 6,100-6,400 slots, 512,000 atoms on
+  // its JIT core: 6.57 -> 5.00 ms/step (r6c / r6za); the many-type and run-time-shape kernels (coefficient tables in LDS next to the
+  // window, one workgroup per CU at that size) lose against their gather kernels there (same model zero-padded into the
+  // any-types cover: 13.8 -> 18.7 ms/step, run-time shape 60 -> 102) and keep the former 5,000.  A counted rule; option
+  // "win_max_atoms" / NEPMI_WIN_MAX_ATOMS pin it (A/B switch, tests).
+  static constexpr int kWinMaxAtomsManyType = 5000;
+  int win_max_atoms() const
   {
-    static const int v = std::getenv("NEPMI_WIN_MAX_ATOMS") ? std::atoi(std::getenv("NEPMI_WIN_MAX_ATOMS")) : kWinMaxAtoms;
-    return v;
+    static const int env = std::getenv("NEPMI_WIN_MAX_ATOMS") ? std::atoi(std::getenv("NEPMI_WIN_MAX_ATOMS")) : 0;
+    if (win_max_atoms_ > 0)
+      return win_max_atoms_;
+    if (env > 0)
+      return env;
+    return shape_ts() > 0 ? kWinMaxAtoms : kWinMaxAtomsManyType;
   }
   // how this step's radial pass left the pairs inside the cutoff (nep_scatter.h: MODE)
   int list_mode() const { return b_.use_csync ? 2 : (b_.use_rmask ? 1 : 0); }
@@ -2511,6 +2528,7 @@ private:
   std::vector<float> b0_eff_; // hidden-layer bias with the temperature input folded in
   int ann_mode_ = 1;
   int win_lanes_ = 0;
+  int win_max_atoms_ = 0; // set_win_max_atoms (0: the rule)
   bool external_skin_ = false;
 #ifndef NEPMI_BRICK_FILL
 #define NEPMI_BRICK_FILL 256 // A/B switch (profiles/ab_variants.sh); r3l: 253 -> 256 lets PbTe 1 M atoms take the 64^3 grid (4,096 full bricks

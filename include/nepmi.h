@@ -480,6 +480,8 @@ int nepmi_engine_set_virial_mode(nepmi_engine* e, int mode);
  *       f32 rounding.
  *   "win_lanes": Lanes per atom of the LDS-window kernels: 0 (default) = by the number of bricks (4 up to 256 bricks, 2 up to 512,
  *       else 1: small systems are bound by the latency of one workgroup); 1, 2, 4 pin it.
+ *   "win_max_atoms": Capacity of a brick's LDS window in atoms: 0 (default) = the rule (6,656 for shapes with type-pure list streams,
+ *       5,000 for many-type and run-time shapes: beyond it the gather kernels serve the model); a value pins it (at most 6,656).
  *   "scatter_guard / scatter_guard_hard": Test hook: the guard band of the scatter form per pair half in eV/A (default and maximum 64; the net-force guard is twice the
  *       value), so that the hand-over can be exercised with ordinary forces; hard_factor: the hard limit of decomposed runs as a
  *       multiple of the band (<= 0: the default 4; the limit never exceeds 256 eV/A).

@@ -198,7 +198,10 @@ def test_run_loop_on_a_jit_core_matches_the_run_time_shape_kernels(monkeypatch):
     dx = np.abs(out["2"][0] - out["0"][0]).max()
     print("\n[JIT core] max |dx| after 25 steps vs the run-time-shape kernels: %.2e A" % dx)
     assert dx < 2e-5
-    np.testing.assert_allclose(out["2"][1][:, :3], out["0"][1][:, :3], rtol=1e-5)
+    # (temperature, potential energy, P_xx: the core runs the window kernels, the run-time shape the gather kernels -- FP32 sums over
+    # ~380 pairs per atom in different orders; the pressure is a difference of kinetic and virial parts)
+    np.testing.assert_allclose(out["2"][1][:, :2], out["0"][1][:, :2], rtol=1e-5)
+    np.testing.assert_allclose(out["2"][1][:, 2], out["0"][1][:, 2], rtol=5e-5)
     print("\n[JIT core] C-2024, %d atoms: %.3f ms/step on the JIT core, %.3f ms/step on the run-time-shape kernels (%.1fx)"
           % (n, out["2"][2], out["0"][2], out["0"][2] / out["2"][2]))
     assert out["2"][2] < out["0"][2]
