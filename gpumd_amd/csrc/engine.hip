@@ -525,8 +525,11 @@ nepmi_win_kernel(const Body body, const int64_t nbricks)
 
 // The window kernels on the static window layout (Bufs::wtab, RadialWin2Body / ForceWinBody::stage): the records are copied
 // straight to their slots -- no cell-count scan, one barrier.
-template <class Body>
-__global__ void __launch_bounds__(kWinThreads) __attribute__((amdgpu_waves_per_eu(Body::kMinWavesPerEu)))
+// NT = 512 (kWinThreadsBig): windows beyond half a CU's LDS (dense long-cutoff models, one workgroup per CU whatever its size, bricks
+// of several passes): eight wavefronts per CU instead of four walk the brick's atoms.  The atoms keep their places in the wavefronts
+// (64 consecutive atoms from the brick's first), so the wave-synchronous rows of one kernel are read in step by the other.
+template <class Body, int NT = kWinThreads>
+__global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(Body::kMinWavesPerEu)))
 nepmi_win2_kernel(const Body body, const int64_t nbricks)
 {
   extern __shared__ __attribute__((aligned(16))) char nepmi_win_lds[];
@@ -539,11 +542,11 @@ nepmi_win2_kernel(const Body body, const int64_t nbricks)
     return;
   const int64_t brick = body.map_brick(wg);
   const int tid = (int)threadIdx.x;
-  body.stage(brick, lds, tid, kWinThreads);
+  body.stage(brick, lds, tid, NT);
   __syncthreads();
   int64_t a0, a1;
   body.brick_range(brick, a0, a1);
-  for (int64_t k = a0 + tid; k < a1; k += kWinThreads)
+  for (int64_t k = a0 + tid; k < a1; k += NT)
     body.compute(brick, k, lds);
 }
 
@@ -1322,6 +1325,17 @@ struct HipBackend {
     const bool t = timed(slot);
     if (t)
       timer_start(timing->slot[slot]);
+    if constexpr (Body::kBigWindows) {
+      if (lds_bytes > kBigWindowLds) {
+        NEPMI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&nepmi_win2_kernel<Body, kWinThreadsBig>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        hipLaunchKernelGGL((nepmi_win2_kernel<Body, kWinThreadsBig>), dim3((unsigned)grid), dim3(kWinThreadsBig), lds_bytes, stream, body, nbricks);
+        NEPMI_HIP_CHECK(hipGetLastError());
+        if (t)
+          timer_stop(timing->slot[slot]);
+        return;
+      }
+    }
     hipLaunchKernelGGL((nepmi_win2_kernel<Body>), dim3((unsigned)grid), dim3(kWinThreads), lds_bytes, stream, body, nbricks);
     NEPMI_HIP_CHECK(hipGetLastError());
     if (t)
@@ -1372,6 +1386,13 @@ struct HipBackend {
         const size_t lds_bytes = ((size_t)lay.bytes() + 15) / 16 * 16;
 #define NEPMI_FS_LAUNCH(OUTV, MODEV)                                                                                             \
   do {                                                                                                                           \
+    if (lds_bytes > kBigWindowLds) { /* one workgroup per CU whatever its size: eight wavefronts (nepmi_win2_kernel) */           \
+      NEPMI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&nepmi_force_scatter_kernel<S, OUTV, MODEV, kWinThreadsBigScatter>), \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));                         \
+      hipLaunchKernelGGL((nepmi_force_scatter_kernel<S, OUTV, MODEV, kWinThreadsBigScatter>), dim3((unsigned)grid), dim3(kWinThreadsBigScatter), lds_bytes, \
+                         stream, body, nb);                                                                                     \
+      break;                                                                                                                     \
+    }                                                                                                                            \
     if (lds_bytes > 64 * 1024)                                                                                                   \
       NEPMI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&nepmi_force_scatter_kernel<S, OUTV, MODEV>),           \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));                         \

@@ -551,8 +551,8 @@ __device__ __forceinline__ void force_scatter_atom(const ForceScatterBody<S>& B,
 #ifndef NEPMI_FS_WAVES
 #define NEPMI_FS_WAVES 3
 #endif
-template <class S, bool OUT, int MODE>
-__global__ void __launch_bounds__(kWinThreads) __attribute__((amdgpu_waves_per_eu(NEPMI_FS_WAVES)))
+template <class S, bool OUT, int MODE, int NT = kWinThreads>
+__global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT > kWinThreads ? (NT + 255) / 256 : NEPMI_FS_WAVES)))
 nepmi_force_scatter_kernel(const ForceScatterBody<S> body, const int64_t nbricks)
 {
   extern __shared__ __attribute__((aligned(16))) char nepmi_win_lds[];
@@ -576,7 +576,7 @@ nepmi_force_scatter_kernel(const ForceScatterBody<S> body, const int64_t nbricks
     const int* tab = b.wtab + brick * 1024;
     int bx, by, bz;
     body.st.brick_coords(brick, bx, by, bz);
-    for (int wc = tid; wc < (NEPMI_FS_ABL == 3 ? 0 : kWinCells); wc += kWinThreads) {
+    for (int wc = tid; wc < (NEPMI_FS_ABL == 3 ? 0 : kWinCells); wc += NT) {
       const int j0 = tab[2 * wc], pk = tab[2 * wc + 1];
       const int w0 = pk & 0xFFFF;
       int cnt = pk >> 16;
@@ -602,20 +602,20 @@ nepmi_force_scatter_kernel(const ForceScatterBody<S> body, const int64_t nbricks
     if (tid == 0)
       wp[lay.wmax] = I3{0x38000000, 0x38000000, 0x38000000}; // the sentinel slot: 0.875 R away along every axis
     const U4 zero{0u, 0u, 0u, 0u};
-    for (int i = tid; i < n4; i += kWinThreads)
+    for (int i = tid; i < n4; i += NT)
       a4[i] = zero;
   }
   __syncthreads();
   int64_t a0, a1;
   body.st.brick_range(brick, a0, a1);
-  for (int64_t k = a0 + tid; k < a1; k += kWinThreads)
+  for (int64_t k = a0 + tid; k < a1; k += NT)
     force_scatter_atom<S, OUT, MODE>(body, brick, k, lds, lay);
   __syncthreads();
   {
     // the window sums, one 16-byte row per slot: what ForceFoldBody gathers
     NEPMI_LDS(const I3)* acc = (NEPMI_LDS(const I3)*)(lds + lay.off_acc());
     I4* __restrict__ out = body.halo + (size_t)brick * lay.wmax;
-    for (int i = tid; i < (NEPMI_FS_ABL == 5 ? 0 : lay.wmax); i += kWinThreads) {
+    for (int i = tid; i < (NEPMI_FS_ABL == 5 ? 0 : lay.wmax); i += NT) {
       const I3 v = acc[i];
       out[i] = I4{v.x, v.y, v.z, 0};
     }

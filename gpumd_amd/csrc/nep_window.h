@@ -27,6 +27,15 @@
 namespace nepmi {
 
 constexpr int kWinThreads = 256;
+#ifndef NEPMI_BIGWIN_RADIAL
+#define NEPMI_BIGWIN_RADIAL 1024
+#endif
+#ifndef NEPMI_BIGWIN_SCATTER
+#define NEPMI_BIGWIN_SCATTER 768
+#endif
+constexpr int kWinThreadsBig = NEPMI_BIGWIN_RADIAL;         // ... of the one-lane window kernels on windows beyond kBigWindowLds (engine.hip: nepmi_win2_kernel)
+constexpr int kWinThreadsBigScatter = NEPMI_BIGWIN_SCATTER; // ... of the scatter kernel there (its 137 registers allow three wavefronts per SIMD)
+constexpr size_t kBigWindowLds = 80 * 1024; // bytes of LDS per workgroup from which only one workgroup fits a CU
 constexpr int kWinCells = 512;
 constexpr int kWinMaxAtoms = 6656; // window capacity (LDS budget: 104 KB of records, 156 KB of positions + accumulators in the scatter form); larger windows take the gather path
                                    // (r6: 5000 -> 6656 puts C_2024_NEP4 in diamond, 6,100-6,400 slots, on the window kernels: 6.57 -> 5.01 ms/step at 512,000 atoms)
@@ -888,6 +897,7 @@ struct RadialWin2Body {
   int first;         // workgroup w runs brick_order[first + w] (first < 0: brick w)
   const int* frozen;
   static constexpr int kMinWavesPerEu = NEPMI_RW2_WAVES;
+  static constexpr bool kBigWindows = S::TS > 0; // 512-thread workgroups on windows beyond kBigWindowLds (engine.hip: launch_win2)
 
   NEPMI_HD int ctab_floats() const { return S::TS > 0 ? 0 : m.T * m.T * ctab_block(m.NR, m.KR, false); }
   NEPMI_HD int ctab_offset() const { return (st.lay.bytes() + 15) / 16 * 16; }
@@ -2130,6 +2140,7 @@ struct ForceWinBody {
   // (carbon 1 M atoms: 1.09 -> 0.97 ms)
   // (FPJ: window + coefficient table leave room for two workgroups per CU = two wavefronts per SIMD anyway)
   static constexpr int kMinWavesPerEu = L != 1 ? 1 : (FPJ ? 2 : ((S::TS > 0 && S::KR >= 8) ? 3 : NEPMI_FW_WAVES));
+  static constexpr bool kBigWindows = false;
   static constexpr int kLanes = L;
 
   NEPMI_HD int ctab_floats() const { return FPJ ? m.T * m.T * ctab_block(m.NR, m.KR, NEPMI_CT_VEC_FORCE != 0) : 0; }
