@@ -1336,6 +1336,18 @@ struct HipBackend {
         return;
       }
     }
+    if constexpr (Body::kMidWindows) {
+      // two workgroups per CU (many-type models: the window and the coefficient table, 79 KB for UNEP-v1): 512 threads each
+      if (lds_bytes > kMidWindowLds) {
+        NEPMI_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&nepmi_win2_kernel<Body, kWinThreadsMid>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        hipLaunchKernelGGL((nepmi_win2_kernel<Body, kWinThreadsMid>), dim3((unsigned)grid), dim3(kWinThreadsMid), lds_bytes, stream, body, nbricks);
+        NEPMI_HIP_CHECK(hipGetLastError());
+        if (t)
+          timer_stop(timing->slot[slot]);
+        return;
+      }
+    }
     hipLaunchKernelGGL((nepmi_win2_kernel<Body>), dim3((unsigned)grid), dim3(kWinThreads), lds_bytes, stream, body, nbricks);
     NEPMI_HIP_CHECK(hipGetLastError());
     if (t)

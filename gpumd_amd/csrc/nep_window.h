@@ -36,6 +36,11 @@ constexpr int kWinThreads = 256;
 constexpr int kWinThreadsBig = NEPMI_BIGWIN_RADIAL;         // ... of the one-lane window kernels on windows beyond kBigWindowLds (engine.hip: nepmi_win2_kernel)
 constexpr int kWinThreadsBigScatter = NEPMI_BIGWIN_SCATTER; // ... of the scatter kernel there (its 137 registers allow three wavefronts per SIMD)
 constexpr size_t kBigWindowLds = 80 * 1024; // bytes of LDS per workgroup from which only one workgroup fits a CU
+#ifndef NEPMI_MIDWIN
+#define NEPMI_MIDWIN 1 // A/B switch: 512-thread workgroups for the radial pass of many-type models whose LDS use leaves room for two per CU
+#endif
+constexpr int kWinThreadsMid = 512;
+constexpr size_t kMidWindowLds = 54 * 1024; // ... from which at most two fit
 constexpr int kWinCells = 512;
 constexpr int kWinMaxAtoms = 6656; // window capacity (LDS budget: 104 KB of records, 156 KB of positions + accumulators in the scatter form); larger windows take the gather path
                                    // (r6: 5000 -> 6656 puts C_2024_NEP4 in diamond, 6,100-6,400 slots, on the window kernels: 6.57 -> 5.01 ms/step at 512,000 atoms)
@@ -897,7 +902,8 @@ struct RadialWin2Body {
   int first;         // workgroup w runs brick_order[first + w] (first < 0: brick w)
   const int* frozen;
   static constexpr int kMinWavesPerEu = NEPMI_RW2_WAVES;
-  static constexpr bool kBigWindows = S::TS > 0; // 512-thread workgroups on windows beyond kBigWindowLds (engine.hip: launch_win2)
+  static constexpr bool kBigWindows = S::TS > 0; // 1,024-thread workgroups on windows beyond kBigWindowLds (engine.hip: launch_win2)
+  static constexpr bool kMidWindows = NEPMI_MIDWIN != 0 && S::TS == 0 && S::fixed && SYNC != 0;
 
   NEPMI_HD int ctab_floats() const { return S::TS > 0 ? 0 : m.T * m.T * ctab_block(m.NR, m.KR, false); }
   NEPMI_HD int ctab_offset() const { return (st.lay.bytes() + 15) / 16 * 16; }
@@ -2140,7 +2146,7 @@ struct ForceWinBody {
   // (carbon 1 M atoms: 1.09 -> 0.97 ms)
   // (FPJ: window + coefficient table leave room for two workgroups per CU = two wavefronts per SIMD anyway)
   static constexpr int kMinWavesPerEu = L != 1 ? 1 : (FPJ ? 2 : ((S::TS > 0 && S::KR >= 8) ? 3 : NEPMI_FW_WAVES));
-  static constexpr bool kBigWindows = false;
+  static constexpr bool kBigWindows = false, kMidWindows = false;
   static constexpr int kLanes = L;
 
   NEPMI_HD int ctab_floats() const { return FPJ ? m.T * m.T * ctab_block(m.NR, m.KR, NEPMI_CT_VEC_FORCE != 0) : 0; }
