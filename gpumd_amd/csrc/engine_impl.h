@@ -2124,7 +2124,8 @@ private:
   // window in LDS) take windows up to kWinMaxAtoms = 6,656 slots -- C_2024_NEP4 in diamond, 6,100-6,400 slots, 512,000 atoms on
   // its JIT core: 6.57 -> 5.00 ms/step (r6c / r6za); the many-type and run-time-shape kernels (coefficient tables in LDS next to the
   // window, one workgroup per CU at that size) lose against their gather kernels there (same model zero-padded into the
-  // any-types cover: 13.8 -> 18.7 ms/step, run-time shape 60 -> 102) and keep the former 5,000.  A counted rule; option
+  // any-types cover: 13.8 -> 18.7 ms/step, run-time shape 60 -> 102; with 1,024-thread workgroups as well, r6f: 15.5 and 68 -- the radial
+  // pass then wins, 6.9 against 7.5 ms, the window form of their force assembly loses more) and keep the former 5,000.  A counted rule; option
   // "win_max_atoms" / NEPMI_WIN_MAX_ATOMS pin it (A/B switch, tests).
   static constexpr int kWinMaxAtomsManyType = 5000;
   int win_max_atoms() const
