@@ -716,6 +716,8 @@ public:
     if (nrec > 0) {
       if (thermo_rows_cap_ < nrec) {
         dfree(thermo_rows_);
+        thermo_rows_ = nullptr; // (an allocation that throws must not leave the freed pointer behind)
+        thermo_rows_cap_ = 0;
         thermo_rows_ = dalloc<double>(8 * (size_t)nrec);
         thermo_rows_cap_ = nrec;
       }
