@@ -2146,7 +2146,8 @@ struct ForceWinBody {
   // (carbon 1 M atoms: 1.09 -> 0.97 ms)
   // (FPJ: window + coefficient table leave room for two workgroups per CU = two wavefronts per SIMD anyway)
   static constexpr int kMinWavesPerEu = L != 1 ? 1 : (FPJ ? 2 : ((S::TS > 0 && S::KR >= 8) ? 3 : NEPMI_FW_WAVES));
-  static constexpr bool kBigWindows = false, kMidWindows = false;
+  static constexpr bool kBigWindows = false;
+  static constexpr bool kMidWindows = NEPMI_MIDWIN != 0 && L == 1 && S::TS > 0; // (the gather form on windows of dense long-cutoff models: 512 threads)
   static constexpr int kLanes = L;
 
   NEPMI_HD int ctab_floats() const { return FPJ ? m.T * m.T * ctab_block(m.NR, m.KR, NEPMI_CT_VEC_FORCE != 0) : 0; }

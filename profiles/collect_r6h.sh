@@ -1,11 +1,12 @@
 cd /root/repo
-(timeout 600 python -m pytest tests/test_tersoff.py tests/test_ref_md_parity.py -m gpu -q -x -k "tersoff or Tersoff or si_") > gpurun_out/pytest_r6h.log 2>&1; grep -E "passed|failed|^E |^FAILED" gpurun_out/pytest_r6h.log | head
-timeout 200 python bench.py --no-cpu-baseline --no-extras --workload si_tersoff --steps 2000 --warmup 200 > gpurun_out/bench_r6h_si.json 2> gpurun_out/bench_r6h_si.err
-python - gpurun_out/bench_r6h_si.json <<'PY'
+export NEPMI_JIT=2
+(timeout 600 python -m pytest tests/test_jit_shapes.py -m gpu -q -x) 2>&1 | tail -2
+cd /tmp && export TMPDIR=/tmp
+timeout 240 rocprofv3 --kernel-trace --stats -d /root/repo/gpurun_out/prof_r6h -o bench -- python /root/repo/bench.py --no-cpu-baseline --no-extras --workload carbon2024 --reps 10 10 10 --steps 10 --warmup 3 > /root/repo/gpurun_out/prof_r6h.log 2>&1
+cd /root/repo
+python profiles/summarize_rocpd.py stats $(ls gpurun_out/prof_r6h/*.db | head -1) gpurun_out/r6h_kernel_stats.csv
+rm -rf gpurun_out/prof_r6h
+head -8 gpurun_out/r6h_kernel_stats.csv | cut -c1-200
+tail -1 gpurun_out/prof_r6h.log | python -c "
 import json,sys
-try:
-    d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
-    print("si ms/step %.5f value %.4g"%(d["ms_per_step"], d["value"]), {k[:10]:round(v["avg_ms"],4) for k,v in d["kernels"].items()})
-except Exception as e:
-    print(sys.argv[1], "ERR", e)
-PY
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('ms/step %.4f' % d['ms_per_step'], d.get('thermo_last')[:3])"
